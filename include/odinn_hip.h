@@ -1,0 +1,186 @@
+/*
+ * odinn_hip.h -- C ABI of libodinn_hip.so: the MI355X (gfx950) implementation of
+ * ODINN.jl's SIA2D(+NN_theta) time-stepping hot path and its discrete adjoint.
+ *
+ * This is the drop-in boundary.  The reference has no FFI today; its plug-in
+ * seams for this path are Julia dispatch points, each replaced here by one
+ * entry point (paths relative to the ODINN.jl tree):
+ *
+ *   odinn_sia2d_dhdt        <- SIA2D_UDE!(dH,H,container,t) -> Huginn.SIA2D!
+ *                              src/simulations/inversions/inversion_utils.jl:691-699
+ *   odinn_sia2d_vjp_H       <- VJP_lambda_dSIAdH(::DiscreteVJP, lam, H, theta, sim, t)
+ *                              src/inverse/SIA2D/VJPs.jl:2-5 -> adjoint.jl:31-151
+ *   odinn_sia2d_vjp_theta   <- VJP_lambda_dSIAdtheta(::DiscreteVJP, ...)
+ *                              src/inverse/SIA2D/VJPs.jl:30-33 -> adjoint.jl:178-255
+ *   odinn_mb_vjp_H          <- VJP_lambda_dMBdH(::DiscreteVJP, ...)  VJPs.jl:107-151
+ *   odinn_solve             <- _batch_iceflow_UDE / simulate_iceflow_UDE!
+ *                              src/simulations/inversions/inversion_utils.jl:472-572
+ *   odinn_loss              <- batch_loss_iceflow_transient  inversion_utils.jl:383-461
+ *   odinn_loss_grad         <- SIA2D_grad_batch! (DiscreteAdjoint + DiscreteVJP)
+ *                              src/inverse/SIA2D/gradient.jl:45-275, summed over the
+ *                              glaciers of the batch as SIA2D_grad! does (:6-31)
+ *
+ * Conventions
+ *   - every array is contiguous float64, Julia column-major: element [i,j] of an
+ *     nx-by-ny field is at i + nx*j (i = x = Julia dim 1).  Dual-grid fields are
+ *     (nx-1)-by-(ny-1).
+ *   - pointers are HOST pointers unless the name ends in _dev.
+ *   - every function returns 0 on success, non-zero on error;
+ *     odinn_last_error() returns a thread-local message.  No exceptions cross.
+ *   - an odinn_batch owns the device state of G glaciers on ONE device and one
+ *     HIP stream.  A batch is not thread-safe; different batches are independent.
+ *   - there is NO CPU fallback: if no gfx950 device is present every compute entry
+ *     point fails with ODINN_ERR_NO_DEVICE.
+ */
+#ifndef ODINN_HIP_H
+#define ODINN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODINN_OK 0
+#define ODINN_ERR_ARG 1
+#define ODINN_ERR_NO_DEVICE 2
+#define ODINN_ERR_HIP 3
+#define ODINN_ERR_STATE 4
+#define ODINN_ERR_MAXITERS 5
+#define ODINN_ERR_NONFINITE 6
+
+#define ODINN_MAX_LAYERS 8
+#define ODINN_MAX_WIDTH 32
+
+/* which quantity theta drives (src/laws/Laws.jl; targets src/models/target/) */
+enum odinn_law_kind {
+  ODINN_LAW_CONST_A = 0,      /* A given per glacier (scalar) or as a dual-grid field       */
+  ODINN_LAW_NN_A_SCALAR = 1,  /* A = minA+(maxA-minA)*MLP(T), scalar T   Laws.jl:348-358    */
+  ODINN_LAW_NN_A_GRIDDED = 2, /* same on a gridded T (dual grid), evaluated once per theta  */
+  ODINN_LAW_NN_Y = 3,         /* Y = max*exp((y-1)/y), y=MLP(T,Hbar)     Laws.jl:258-265    */
+  ODINN_LAW_NN_U = 4          /* U = post(MLP(Hbar,|gradS|)), D=Hbar*U   Laws.jl:114-123    */
+};
+
+enum odinn_act { ODINN_ACT_IDENTITY = 0, ODINN_ACT_SOFTPLUS = 1, ODINN_ACT_SIGMOID = 2,
+                 ODINN_ACT_GELU = 3, ODINN_ACT_TANH = 4, ODINN_ACT_RELU = 5 };
+
+enum odinn_post { ODINN_POST_NONE = 0,   /* identity                                          */
+                  ODINN_POST_AFFINE = 1, /* lo+(hi-lo)*y     target_utils.jl:109-113          */
+                  ODINN_POST_EXPMAX = 2, /* hi*exp((y-1)/y)  target_utils.jl:86-93            */
+                  ODINN_POST_SCALE = 3   /* hi*y                                              */ };
+
+/* Sleipnir.PhysicalParameters fields used on the path (test/params_construction.jl:24-34) */
+typedef struct odinn_phys {
+  double rho, g, eta0, n, p, q, C, minA, maxA;
+} odinn_phys;
+
+typedef struct odinn_glacier_desc {
+  int32_t nx, ny;
+  double dx, dy;
+  odinn_phys phys;
+  double A; /* creep coefficient for ODINN_LAW_CONST_A [Pa^-n yr^-1]                        */
+  double T; /* scalar long-term air temperature input of LawA / LawY [deg C]                */
+} odinn_glacier_desc;
+
+/* Lux.Chain(Dense...) descriptor; theta is flattened layer by layer as
+ * [vec(W_l) column-major (out x in), b_l]  (ML_utils.jl:31-36,54). */
+typedef struct odinn_mlp_desc {
+  int32_t n_layers;
+  int32_t widths[ODINN_MAX_LAYERS + 1]; /* widths[0] = n_in (1 or 2), widths[n_layers] = 1 */
+  int32_t acts[ODINN_MAX_LAYERS];
+  int32_t has_prescale;                 /* x~ = (x-lo)/(hi-lo)-0.5  target_utils.jl:131-141 */
+  double pre_lo[2], pre_hi[2];
+  int32_t post_kind;
+  double post_lo, post_hi;
+} odinn_mlp_desc;
+
+typedef struct odinn_solver_opts {
+  double reltol;    /* params.solver.reltol (inversion_utils.jl:565)                        */
+  double abstol;    /* OrdinaryDiffEq default 1e-6                                          */
+  double dtmax;     /* <=0: unbounded                                                       */
+  double dt0;       /* <=0: Hairer-Wanner automatic initial step                            */
+  double fixed_dt;  /* >0: non-adaptive RDPK3Sp35 with this step (clipped at tstops)        */
+  int64_t maxiters; /* params.solver.maxiters (:567); <=0 -> 1e6                            */
+} odinn_solver_opts;
+
+typedef struct odinn_solve_stats {
+  int64_t naccept, nreject, nrhs;
+  double t_final, dt_last;
+} odinn_solve_stats;
+
+typedef struct odinn_batch odinn_batch;
+
+const char* odinn_last_error(void);
+int odinn_device_count(int* n);
+/* name of device `dev` (e.g. "gfx950...") into buf */
+int odinn_device_name(int dev, char* buf, int buflen);
+
+/* ---- lifetime / inputs (H2D once; state stays resident in HBM) ---------------------- */
+int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* descs, odinn_batch** out);
+int odinn_batch_destroy(odinn_batch* b);
+int odinn_batch_sync(odinn_batch* b);
+int odinn_set_fields(odinn_batch* b, int g, const double* H0, const double* B);
+int odinn_set_A(odinn_batch* b, int g, double A);
+int odinn_set_A_field(odinn_batch* b, int g, const double* A_dual);   /* CONST_A, gridded  */
+int odinn_set_T_field(odinn_batch* b, int g, const double* T_dual);   /* NN_A_GRIDDED input */
+/* n_H / n_gradS: D_hybrid exponents (target_D_hybrid.jl:180-185); pass <0 to use phys.n */
+int odinn_set_law(odinn_batch* b, int kind, const odinn_mlp_desc* mlp, const double* theta, int P,
+                  double n_H, double n_gradS);
+int odinn_set_theta(odinn_batch* b, const double* theta, int P);
+/* thickness data glacier.thicknessData: n_ref fields at times t_ref; the loss mask is
+ * is_in_glacier(H_ref, distance) (Losses.jl:266) */
+int odinn_set_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, const double* H_ref,
+                        int distance);
+/* mass-balance increment per step_MB: mb = min(mb0 + dmb_dS*(S - S_ref), mb_max), masked and
+ * clipped as VJPs.jl:129-139.  S_ref may be NULL when dmb_dS == 0. Pass mb0 == NULL to disable. */
+int odinn_set_mass_balance(odinn_batch* b, int g, const double* mb0, double dmb_dS,
+                           const double* S_ref, double mb_max);
+
+/* ---- fine-grained seams (host in / host out; parity + drop-in, not the fast path) ---- */
+int odinn_sia2d_dhdt(odinn_batch* b, int g, const double* H, double t, double* dH);
+int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H, double t, double* dlam);
+/* dtheta has P entries (P = 1 for CONST_A: d/dA) */
+int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double* H, double t,
+                          double* dtheta, int P);
+int odinn_mb_apply(odinn_batch* b, int g, const double* H, double* H_new, double* MB_applied);
+int odinn_mb_vjp_H(odinn_batch* b, int g, const double* lam, const double* H_pre, double* out);
+/* value of the law on the dual grid (scalar laws: out[0]) */
+int odinn_eval_law(odinn_batch* b, int g, const double* H, double* out, int n_out);
+
+/* ---- device-resident time loop -------------------------------------------------------- */
+/* Integrates every glacier of the batch from tstops[0] to tstops[n_stops-1] with
+ * RDPK3Sp35 + PID (adaptive, all control on the device), storing a snapshot at every
+ * tstop and applying the mass balance at mb_times (subset of tstops[1:]).
+ * stats: array of n_glaciers entries (may be NULL). */
+int odinn_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times,
+                const odinn_solver_opts* opts, odinn_solve_stats* stats);
+int odinn_get_snapshot(odinn_batch* b, int g, int istop, double* H_out);
+int odinn_get_H(odinn_batch* b, int g, double* H_out); /* current state */
+/* loss_per_glacier[g] = sum_tau w_tau * L2Sum(H_tau, Href_tau, mask)/N over stored snapshots */
+int odinn_loss(odinn_batch* b, double* loss_per_glacier);
+/* forward solve + discrete adjoint; loss and dtheta are SUMS over the batch's glaciers
+ * (aggregate of Model.jl:208-224 for a FunctionalModel).  theta may be NULL (keep current).
+ * lam0_out (optional) receives lambda at t0 of glacier 0 .. G-1 concatenated. */
+int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops,
+                    int n_mb, const double* mb_times, const odinn_solver_opts* opts,
+                    double* loss, double* dtheta, odinn_solve_stats* stats);
+int odinn_get_lambda0(odinn_batch* b, int g, double* lam0);
+
+/* ---- measurement (HIP events on the batch's own stream, state already in HBM) -------- */
+enum odinn_timed {
+  ODINN_TIMED_DHDT = 0,     /* RHS only: read H,B write dH                    24 B/cell     */
+  ODINN_TIMED_RK_STEP = 1,  /* one full RDPK3Sp35 step = 5 fused stage kernels              */
+  ODINN_TIMED_VJP_H = 2,    /* read lam,H,B write dlam                        32 B/cell     */
+  ODINN_TIMED_VJP_THETA = 3,/* read lam,H,B -> reduction                      24 B/cell     */
+  ODINN_TIMED_RK_STAGE2 = 4 /* one interior stage kernel (stage 2)            56 B/cell     */
+};
+/* runs `iters` back-to-back launches over ALL glaciers of the batch after `warmup`
+ * untimed ones; *ms_total is the elapsed time of the timed launches. */
+int odinn_time_kernel(odinn_batch* b, int which, int warmup, int iters, double* ms_total);
+/* total primal cells in the batch */
+int64_t odinn_batch_cells(odinn_batch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODINN_HIP_H */

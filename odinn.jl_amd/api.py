@@ -1,0 +1,557 @@
+"""Host-side mirror of the reference's operator interface for the SIA2D(+NN) path.
+
+The reference is Julia and its toolchain is absent from the build image, so the host
+side above the C ABI is Python.  Names, argument meaning and error behaviour follow the
+reference (Julia's ``f!`` is spelled ``f_b``; non-ASCII ``∂`` is spelled ``d``):
+
+    Parameters / PhysicalParameters / SimulationParameters / SolverParameters /
+    Hyperparameters / UDEparameters           src/parameters/*.jl, Sleipnir (OOT)
+    NeuralNetwork                             src/models/trainable_components/NeuralNetwork.jl:18-74
+    LawA / LawY / LawU / ConstantA            src/laws/Laws.jl:97-386, Huginn (OOT)
+    SIA2Dmodel, Model                         Huginn (OOT), src/models/trainable_components/Model.jl:61-127
+    Prediction, Inversion (= FunctionalInversion, the legacy name)
+                                              Huginn (OOT), src/simulations/inversions/Inversion.jl:16-62
+    run_b  (run!)                             src/simulations/inversions/inversion_utils.jl:21-88
+    SIA2D_grad_b (SIA2D_grad!)                src/inverse/SIA2D/gradient.jl:6-31
+    VJP_lambda_dSIAdH / VJP_lambda_dSIAdtheta src/inverse/SIA2D/VJPs.jl:2-5,30-33
+    SIA2D_b (Huginn.SIA2D!)                   called at inversion_utils.jl:691-699
+
+Everything numerical runs in libodinn_hip.so on the GPU; this module only orchestrates
+(glacier sharding, the optimiser loop, the RCCL all-reduce of [loss, dtheta]).
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from .batch import GlacierBatch, MLPSpec, PhysicalParameters
+
+__all__ = [
+    "Parameters", "SimulationParameters", "SolverParameters", "Hyperparameters", "UDEparameters",
+    "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
+    "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "DiscreteVJP",
+    "LossH", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
+    "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
+    "shard_glaciers", "init_distributed", "allreduce_loss_grad",
+]
+
+
+# ----------------------------------------------------------------------------------------
+# parameters (field names as in the reference; only what the path reads)
+# ----------------------------------------------------------------------------------------
+@dataclass
+class SimulationParameters:
+    tspan: Tuple[float, float] = (2010.0, 2015.0)
+    use_MB: bool = False
+    step_MB: float = 1.0 / 12.0
+    multiprocessing: bool = False  # reference: Distributed workers; here: one rank per GPU
+    workers: int = 1
+    test_mode: bool = False  # light NN (NeuralNetwork.jl:43)
+
+
+@dataclass
+class SolverParameters:
+    """Huginn.SolverParameters (OOT).  solver is fixed to RDPK3Sp35 (test_grad_loss.jl:143)."""
+
+    solver: str = "RDPK3Sp35"
+    reltol: float = 1e-8
+    abstol: float = 1e-6
+    step: float = 1.0 / 12.0
+    tstops: Sequence[float] = ()
+    dtmax: float = 0.0
+    maxiters: int = 10 ** 6
+
+
+@dataclass
+class DiscreteVJP:
+    """src/inverse/VJPTypes.jl:29-37"""
+
+
+@dataclass
+class DiscreteAdjoint:
+    """src/inverse/AdjointTypes.jl:85-91"""
+
+    VJP_method: DiscreteVJP = field(default_factory=DiscreteVJP)
+    MB_VJP: DiscreteVJP = field(default_factory=DiscreteVJP)
+
+
+@dataclass
+class L2Sum:
+    """src/losses/Losses.jl: L2Sum(distance)"""
+
+    distance: int = 3
+
+
+@dataclass
+class LossH:
+    """src/losses/Losses.jl:250-291"""
+
+    loss: L2Sum = field(default_factory=L2Sum)
+
+
+@dataclass
+class Adam:
+    """Optimisers.Adam(eta, (beta1, beta2), eps)"""
+
+    eta: float = 1e-3
+    beta: Tuple[float, float] = (0.9, 0.999)
+    eps: float = 1e-8
+
+
+@dataclass
+class LBFGS:
+    """Optim.LBFGS stand-in (scipy L-BFGS-B drives the same loss/grad callbacks)."""
+
+    m: int = 10
+
+
+@dataclass
+class Hyperparameters:
+    optimizer: object = field(default_factory=Adam)
+    epochs: int = 50
+    batch_size: int = 0  # reference: whole simulation in one batch (ML_utils.jl:190-200)
+
+
+@dataclass
+class UDEparameters:
+    """src/parameters/UDEparameters.jl:60-80 (only the manual discrete adjoint is provided)."""
+
+    grad: DiscreteAdjoint = field(default_factory=DiscreteAdjoint)
+    empirical_loss_function: LossH = field(default_factory=LossH)
+    target: str = "A"  # :A | :D_hybrid | :D
+    optimization_method: str = "AD+AD"
+
+
+@dataclass
+class Parameters:
+    """src/parameters/UDEparameters.jl:109-128"""
+
+    physical: PhysicalParameters = field(default_factory=PhysicalParameters)
+    simulation: SimulationParameters = field(default_factory=SimulationParameters)
+    solver: SolverParameters = field(default_factory=SolverParameters)
+    hyper: Hyperparameters = field(default_factory=Hyperparameters)
+    UDE: UDEparameters = field(default_factory=UDEparameters)
+
+
+# ----------------------------------------------------------------------------------------
+# glaciers, data
+# ----------------------------------------------------------------------------------------
+@dataclass
+class ThicknessData:
+    t: Sequence[float]
+    H: Sequence[np.ndarray]
+
+
+@dataclass
+class Glacier2D:
+    """POD stand-in for Sleipnir.Glacier2D (kwargs as test/test_grad_loss.jl:595-597)."""
+
+    rgi_id: str
+    H0: np.ndarray  # H₀
+    B: np.ndarray
+    dx: float  # Δx
+    dy: float  # Δy
+    A: float = 2.21e-18
+    C: float = 0.0
+    n: float = 3.0
+    T: float = -5.0  # long-term air temperature (iAvgScalarTemp)
+    thicknessData: Optional[ThicknessData] = None
+
+    @property
+    def nx(self):
+        return self.H0.shape[0]
+
+    @property
+    def ny(self):
+        return self.H0.shape[1]
+
+
+def define_callback_steps(tspan, step):
+    """Huginn.define_callback_steps: tspan[0]:step:tspan[1] (end included)."""
+    n = int(round((tspan[1] - tspan[0]) / step))
+    ts = [tspan[0] + k * step for k in range(n + 1)]
+    ts[-1] = tspan[1]
+    return ts
+
+
+# ----------------------------------------------------------------------------------------
+# regressors and laws
+# ----------------------------------------------------------------------------------------
+def build_default_NN(n_input=1, lightNN=False):
+    """ML_utils.jl:23-39"""
+    if lightNN:
+        return [n_input, 3, 1], [L.ACT_SOFTPLUS, L.ACT_SIGMOID]
+    return [n_input, 3, 10, 3, 1], [L.ACT_SOFTPLUS, L.ACT_SOFTPLUS, L.ACT_SOFTPLUS, L.ACT_SIGMOID]
+
+
+class NeuralNetwork:
+    """Feed-forward regressor (NeuralNetwork.jl:18-74).  ``architecture`` = (widths, acts);
+    theta flattened [vec(W) column-major, b] per layer.  Glorot-uniform init, numpy
+    ``default_rng(seed)`` (the reference seeds MersenneTwister(666), ML_utils.jl:79)."""
+
+    def __init__(self, params: Parameters, architecture=None, theta=None, seed=666):
+        if architecture is None:
+            n_in = 1 if params.UDE.target == "A" else 2
+            architecture = build_default_NN(n_in, lightNN=params.simulation.test_mode)
+        self.widths, self.acts = list(architecture[0]), list(architecture[1])
+        if theta is None:
+            rng = np.random.default_rng(seed)
+            parts = []
+            for l in range(len(self.acts)):
+                nin, nout = self.widths[l], self.widths[l + 1]
+                lim = math.sqrt(6.0 / (nin + nout))
+                parts += [rng.uniform(-lim, lim, nin * nout), np.zeros(nout)]
+            theta = np.concatenate(parts)
+        self.theta = np.asarray(theta, dtype=np.float64).copy()
+
+    @property
+    def n_params(self):
+        return self.theta.size
+
+
+@dataclass
+class _Law:
+    kind: int
+    nn: Optional[NeuralNetwork] = None
+    mlp: Optional[MLPSpec] = None
+    n_H: float = -1.0
+    n_gradS: float = -1.0
+    value: Optional[float] = None
+
+
+def ConstantA(A=2.21e-18):
+    """Huginn.ConstantA"""
+    return _Law(L.LAW_CONST_A, value=A)
+
+
+def LawA(nn_model: NeuralNetwork, params: Parameters, scalar: bool = True):
+    """A = minA + (maxA-minA) * NN(T)  (Laws.jl:323-386); evaluated once per simulation
+    (callback_freq = 0 with the manual adjoints, Laws.jl:339-347)."""
+    ph = params.physical
+    mlp = MLPSpec(nn_model.widths, nn_model.acts, None, L.POST_AFFINE, ph.minA, ph.maxA)
+    return _Law(L.LAW_NN_A_SCALAR if scalar else L.LAW_NN_A_GRIDDED, nn_model, mlp)
+
+
+def LawY(nn_model: NeuralNetwork, params: Parameters, max_NN=None, prescale_bounds=((-25.0, 0.0), (0.0, 500.0)),
+         n_H=-1.0, n_gradS=-1.0):
+    """Y = max_NN*exp((y-1)/y), y = NN(norm(T), norm(Hbar))  (Laws.jl:240-273)."""
+    mx = params.physical.maxA if max_NN is None else max_NN
+    mlp = MLPSpec(nn_model.widths, nn_model.acts, prescale_bounds, L.POST_EXPMAX, 0.0, mx)
+    return _Law(L.LAW_NN_Y, nn_model, mlp, n_H, n_gradS)
+
+
+def LawU(nn_model: NeuralNetwork, params: Parameters, max_NN=None, prescale_bounds=None):
+    """U = post(NN(pre(Hbar, gradS)))  (Laws.jl:97-183); D = Hbar*U."""
+    kind = L.POST_EXPMAX if max_NN is not None else L.POST_NONE
+    mlp = MLPSpec(nn_model.widths, nn_model.acts, prescale_bounds, kind, 0.0, max_NN if max_NN is not None else 1.0)
+    return _Law(L.LAW_NN_U, nn_model, mlp)
+
+
+class SIA2Dmodel:
+    """Huginn.SIA2Dmodel(params; A|Y|U = law)  (call sites test/SIA2D_adjoint.jl:72-88)."""
+
+    def __init__(self, params: Parameters, A=None, Y=None, U=None):
+        given = [l for l in (A, Y, U) if l is not None]
+        if len(given) > 1:
+            raise ValueError("provide at most one of A, Y, U")
+        self.law = given[0] if given else ConstantA()
+        self.U_is_provided = U is not None
+        self.Y_is_provided = Y is not None
+
+
+@dataclass
+class LinearMB:
+    """Synthetic stand-in for Muninn.TImodel1 (climate pipeline is out of tree): mass-balance
+    rate min(grad*(S-ELA), max_acc) [m/yr], applied every step_MB with the reference's
+    mask/clip logic (src/inverse/SIA2D/VJPs.jl:129-139)."""
+
+    grad: float = 6e-3
+    ELA: float = 2000.0
+    max_acc: float = 1.2
+
+
+@dataclass
+class FieldMB:
+    """Prescribed MB increment per step_MB, one field per glacier."""
+
+    fields: Sequence[np.ndarray]
+
+
+class Model:
+    """Model(iceflow=..., mass_balance=..., regressors=(; A=nn))  (Model.jl:61-127)."""
+
+    def __init__(self, iceflow: SIA2Dmodel, mass_balance=None, regressors: Optional[Dict[str, NeuralNetwork]] = None):
+        self.iceflow = iceflow
+        self.mass_balance = mass_balance
+        self.regressors = regressors or {}
+        law = iceflow.law
+        self.theta = None if law.nn is None else law.nn.theta.copy()  # trainable_components.θ
+
+
+# ----------------------------------------------------------------------------------------
+# multi-GPU: glaciers shard across ranks (pmap of gradient.jl:9-10 -> one rank per GPU)
+# ----------------------------------------------------------------------------------------
+def shard_glaciers(cells: Sequence[int], world: int) -> List[List[int]]:
+    """Greedy longest-processing-time assignment by cell count; ties by index."""
+    order = sorted(range(len(cells)), key=lambda i: (-cells[i], i))
+    load = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += cells[i]
+    return [sorted(s) for s in out]
+
+
+_DIST = {"init": False, "rank": 0, "world": 1, "device": None}
+
+
+def init_distributed(backend: Optional[str] = None):
+    """One process per GPU (torchrun env: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  backend
+    'nccl' is RCCL on ROCm; 'gloo' for the CPU multi-process tests."""
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not _DIST["init"]:
+        import torch
+        import torch.distributed as dist
+
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        _DIST.update(init=True, device=(f"cuda:{local}" if backend == "nccl" else "cpu"))
+    _DIST.update(rank=rank, world=world, local=local)
+    return rank, world, local
+
+
+def allreduce_loss_grad(loss: float, dtheta: np.ndarray):
+    """sum over ranks of [loss, dtheta...]: the single collective of the path
+    (SIA2D_grad!: sum(losses), aggregate∇θ -- gradient.jl:14,25; Model.jl:208-224)."""
+    if _DIST["world"] <= 1 or not _DIST["init"]:
+        return loss, dtheta
+    import torch
+    import torch.distributed as dist
+
+    buf = torch.tensor(np.concatenate([[loss], dtheta]), dtype=torch.float64, device=_DIST["device"])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    out = buf.cpu().numpy()
+    return float(out[0]), out[1:].copy()
+
+
+# ----------------------------------------------------------------------------------------
+# simulations
+# ----------------------------------------------------------------------------------------
+@dataclass
+class TrainingStats:
+    losses: List[float] = field(default_factory=list)
+    niter: int = 0
+    θ_hist: List[np.ndarray] = field(default_factory=list)
+    grad_norms: List[float] = field(default_factory=list)
+    time_per_iter: List[float] = field(default_factory=list)
+    θ: Optional[np.ndarray] = None
+
+
+@dataclass
+class Results:
+    """Per-glacier result (Sleipnir.Results fields used downstream: H, t, rgi_id)."""
+
+    rgi_id: str
+    t: List[float]
+    H: List[np.ndarray]
+    stats: object = None
+
+
+class _Simulation:
+    def __init__(self, model: Model, glaciers: Sequence[Glacier2D], parameters: Parameters):
+        self.model = model
+        self.glaciers = list(glaciers)
+        self.parameters = parameters
+        self.results: List[Results] = []
+        self.stats = TrainingStats()
+        self._batch: Optional[GlacierBatch] = None
+        self._mine: List[int] = list(range(len(self.glaciers)))
+
+    # tstops exactly as _batch_iceflow_UDE builds them (inversion_utils.jl:487-495)
+    def tstops(self):
+        p = self.parameters
+        ts = set(define_callback_steps(p.simulation.tspan, p.solver.step)) | set(p.solver.tstops)
+        for g in self.glaciers:
+            if g.thicknessData is not None:
+                ts |= set(float(t) for t in g.thicknessData.t)
+        return sorted(t for t in ts if p.simulation.tspan[0] <= t <= p.simulation.tspan[1])
+
+    def mb_times(self):
+        p = self.parameters
+        if not (p.simulation.use_MB and self.model.mass_balance is not None):
+            return []
+        return define_callback_steps(p.simulation.tspan, p.simulation.step_MB)[1:]
+
+    def batch(self) -> GlacierBatch:
+        """Device context of this rank's shard (built once; state stays in HBM)."""
+        if self._batch is not None:
+            return self._batch
+        rank, world, local = init_distributed() if self.parameters.simulation.multiprocessing else (0, 1, 0)
+        cells = [g.nx * g.ny for g in self.glaciers]
+        self._mine = shard_glaciers(cells, world)[rank]
+        if not self._mine:
+            raise RuntimeError(f"rank {rank} received no glacier (G={len(cells)} < world={world})")
+        gl = [self.glaciers[i] for i in self._mine]
+        p = self.parameters
+        phys = []
+        for g in gl:
+            ph = PhysicalParameters(**{**p.physical.__dict__})
+            ph.C, ph.n = g.C, g.n
+            phys.append(ph)
+        b = GlacierBatch([(g.nx, g.ny) for g in gl], [g.dx for g in gl], [g.dy for g in gl], phys,
+                         A=[g.A for g in gl], T=[g.T for g in gl], device=local)
+        law = self.model.iceflow.law
+        for k, g in enumerate(gl):
+            b.set_fields(k, g.H0, g.B)
+            if g.thicknessData is not None:
+                b.set_reference(k, g.thicknessData.t, g.thicknessData.H,
+                                p.UDE.empirical_loss_function.loss.distance)
+        if law.kind == L.LAW_CONST_A:
+            if law.value is not None:
+                for k in range(len(gl)):
+                    b.set_A(k, gl[k].A if gl[k].A is not None else law.value)
+        else:
+            b.set_law(law.kind, law.mlp, self.model.theta, law.n_H, law.n_gradS)
+        mb = self.model.mass_balance
+        if p.simulation.use_MB and mb is not None:
+            for k, g in enumerate(gl):
+                if isinstance(mb, LinearMB):
+                    S0 = g.B + np.maximum(g.H0, 0.0)
+                    step = p.simulation.step_MB
+                    b.set_mass_balance(k, mb.grad * (S0 - mb.ELA) * step, mb.grad * step, S0, mb.max_acc * step)
+                else:
+                    b.set_mass_balance(k, mb.fields[self._mine[k]])
+        self._batch = b
+        return b
+
+    def _solver_opts(self):
+        s = self.parameters.solver
+        return dict(reltol=s.reltol, abstol=s.abstol, dtmax=s.dtmax, maxiters=s.maxiters)
+
+
+class Prediction(_Simulation):
+    """Forward simulation (Huginn.Prediction; run!(prediction) == docs/src/quick_start.jl:11-30)."""
+
+
+class Inversion(_Simulation):
+    """Functional inversion (src/simulations/inversions/Inversion.jl:16-62)."""
+
+
+FunctionalInversion = Inversion  # legacy name (scripts/benchmarks/sensealg_benchmark.jl:93)
+
+
+def SIA2D_b(dH: np.ndarray, H: np.ndarray, simulation: _Simulation, t: float, theta=None, glacier_idx: int = 0):
+    """Huginn.SIA2D!(dH, H, simulation, t, θ): in-place RHS of glacier ``glacier_idx`` of this rank's shard."""
+    b = simulation.batch()
+    if theta is not None and b.P:
+        b.set_theta(theta)
+    dH[...] = b.dhdt(glacier_idx, H, t)
+    return None
+
+
+def VJP_lambda_dSIAdH(VJPMode: DiscreteVJP, lam, H, theta, simulation: _Simulation, t, glacier_idx: int = 0):
+    """VJP_λ_∂SIA∂H(::DiscreteVJP, λ, H, θ, simulation, t) -> (λ_∂f∂H, nothing)  (VJPs.jl:2-5)."""
+    b = simulation.batch()
+    if theta is not None and b.P:
+        b.set_theta(theta)
+    return b.vjp_H(glacier_idx, lam, H, t), None
+
+
+def VJP_lambda_dSIAdtheta(VJPMode: DiscreteVJP, lam, H, theta, dH_H, simulation: _Simulation, t, glacier_idx: int = 0):
+    """VJP_λ_∂SIA∂θ(::DiscreteVJP, λ, H, θ, dH_H, simulation, t)  (VJPs.jl:30-33)."""
+    b = simulation.batch()
+    if theta is not None and b.P:
+        b.set_theta(theta)
+    return b.vjp_theta(glacier_idx, lam, H, t)
+
+
+def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
+    """SIA2D_grad!(dθ, θ, simulation): loss and gradient over ALL glaciers of ALL ranks
+    (gradient.jl:6-31).  Returns the loss; dθ is written in place."""
+    b = simulation.batch()
+    loss, dth = b.loss_grad(simulation.tstops(), theta=theta, mb_times=simulation.mb_times(),
+                            **simulation._solver_opts())
+    loss, dth = allreduce_loss_grad(loss, dth)
+    if np.linalg.norm(dth) > 1e7:  # gradient.jl:19-24
+        import warnings
+
+        warnings.warn(f"Potential unstable gradient: ‖dθ‖={np.linalg.norm(dth):.3e}. "
+                      "Try reducing the temporal stepsize Δt used for reverse simulation.")
+    dtheta[...] = dth
+    return loss
+
+
+def _run_prediction(sim: Prediction):
+    b = sim.batch()
+    ts = sim.tstops()
+    stats = b.solve(ts, mb_times=sim.mb_times(), **sim._solver_opts())
+    sim.results = [Results(sim.glaciers[gi].rgi_id, list(ts), [b.snapshot(k, j) for j in range(len(ts))], stats[k])
+                   for k, gi in enumerate(sim._mine)]
+    return sim.results
+
+
+def _run_inversion(sim: Inversion, callback: Optional[Callable] = None):
+    """train_UDE! (inversion_utils.jl:112-238): Adam or LBFGS over loss/grad callbacks."""
+    hyper = sim.parameters.hyper
+    theta = sim.model.theta.copy()
+    dth = np.zeros_like(theta)
+    st = sim.stats
+    opt = hyper.optimizer
+    if isinstance(opt, Adam):
+        m = np.zeros_like(theta)
+        v = np.zeros_like(theta)
+        b1, b2 = opt.beta
+        for it in range(1, hyper.epochs + 1):
+            t0 = time.perf_counter()
+            loss = SIA2D_grad_b(dth, theta, sim)
+            m = b1 * m + (1 - b1) * dth
+            v = b2 * v + (1 - b2) * dth * dth
+            theta = theta - opt.eta * (m / (1 - b1 ** it)) / (np.sqrt(v / (1 - b2 ** it)) + opt.eps)
+            st.losses.append(loss)
+            st.grad_norms.append(float(np.linalg.norm(dth)))
+            st.time_per_iter.append(time.perf_counter() - t0)
+            st.θ_hist.append(theta.copy())
+            st.niter = it
+            if callback is not None:
+                callback(it, loss, theta)
+    else:
+        from scipy.optimize import minimize
+
+        def fg(x):
+            loss = SIA2D_grad_b(dth, x, sim)
+            st.losses.append(loss)
+            st.grad_norms.append(float(np.linalg.norm(dth)))
+            return loss, dth.copy()
+
+        res = minimize(fg, theta, jac=True, method="L-BFGS-B",
+                       options=dict(maxiter=hyper.epochs, maxcor=opt.m, ftol=0.0, gtol=0.0))
+        theta = res.x
+        st.niter = len(st.losses)
+    sim.model.theta = theta
+    sim.model.iceflow.law.nn.theta = theta.copy()
+    st.θ = theta.copy()
+    sim.batch().set_theta(theta)
+    return st
+
+
+def run_b(simulation: _Simulation, callback: Optional[Callable] = None):
+    """run!(simulation) for Prediction and Inversion (inversion_utils.jl:21-88)."""
+    if isinstance(simulation, Inversion):
+        if simulation.model.theta is None:
+            raise ValueError("Inversion needs a trainable law (LawA/LawY/LawU)")
+        return _run_inversion(simulation, callback)
+    return _run_prediction(simulation)

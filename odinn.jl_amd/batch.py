@@ -1,0 +1,286 @@
+"""GlacierBatch: numpy-facing wrapper of one ``odinn_batch`` (G glaciers resident on one
+MI355X).  Arrays are logical ``[i, j]`` = (x, y) like the reference's Julia matrices; they
+are handed to the C ABI in column-major order (i contiguous)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+@dataclass
+class PhysicalParameters:
+    """Sleipnir.PhysicalParameters fields the SIA2D path reads
+    (reference test/params_construction.jl:24-34; p, q are the sliding-law exponents)."""
+
+    rho: float = 900.0
+    g: float = 9.81
+    eta0: float = 1.0
+    n: float = 3.0
+    p: float = 3.0
+    q: float = 0.0
+    C: float = 0.0
+    minA: float = 8e-21
+    maxA: float = 8e-17
+
+    def c_struct(self):
+        return L.Phys(self.rho, self.g, self.eta0, self.n, self.p, self.q, self.C, self.minA, self.maxA)
+
+
+@dataclass
+class MLPSpec:
+    """Architecture + scaling of a Lux.Chain(Dense...) regressor
+    (reference src/models/trainable_components/ML_utils.jl:23-39, target_utils.jl:58-141)."""
+
+    widths: Sequence[int]
+    acts: Sequence[int]
+    prescale: Optional[Sequence[Tuple[float, float]]] = None
+    post_kind: int = L.POST_NONE
+    post_lo: float = 0.0
+    post_hi: float = 1.0
+
+    @property
+    def n_params(self):
+        return sum(self.widths[l + 1] * (self.widths[l] + 1) for l in range(len(self.acts)))
+
+    def c_struct(self):
+        d = L.MlpDesc()
+        d.n_layers = len(self.acts)
+        for i, w in enumerate(self.widths):
+            d.widths[i] = int(w)
+        for i, a in enumerate(self.acts):
+            d.acts[i] = int(a)
+        d.has_prescale = 1 if self.prescale is not None else 0
+        if self.prescale is not None:
+            for i, (lo, hi) in enumerate(self.prescale):
+                d.pre_lo[i] = lo
+                d.pre_hi[i] = hi
+        d.post_kind = int(self.post_kind)
+        d.post_lo = float(self.post_lo)
+        d.post_hi = float(self.post_hi)
+        return d
+
+
+def _f(a, shape=None):
+    a = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+@dataclass
+class SolveStats:
+    naccept: int
+    nreject: int
+    nrhs: int
+    t_final: float
+    dt_last: float
+
+
+class GlacierBatch:
+    """G glaciers on one device.  ``shapes[g] = (nx, ny)``."""
+
+    def __init__(self, shapes, dxs, dys=None, phys=None, A=None, T=None, device=0):
+        G = len(shapes)
+        self.G = G
+        self.shapes = [tuple(int(v) for v in s) for s in shapes]
+        dys = dxs if dys is None else dys
+        phys = phys if phys is not None else [PhysicalParameters() for _ in range(G)]
+        if isinstance(phys, PhysicalParameters):
+            phys = [phys] * G
+        A = [2.21e-18] * G if A is None else list(np.broadcast_to(A, (G,)))
+        T = [-5.0] * G if T is None else list(np.broadcast_to(T, (G,)))
+        descs = (L.GlacierDesc * G)()
+        for g in range(G):
+            descs[g].nx, descs[g].ny = self.shapes[g]
+            descs[g].dx = float(np.broadcast_to(dxs, (G,))[g])
+            descs[g].dy = float(np.broadcast_to(dys, (G,))[g])
+            descs[g].phys = phys[g].c_struct()
+            descs[g].A = float(A[g])
+            descs[g].T = float(T[g])
+        self.phys = phys
+        self._h = C.c_void_p()
+        L.check(L.lib().odinn_batch_create(device, G, descs, C.byref(self._h)))
+        self.P = 0
+        self.law_kind = L.LAW_CONST_A
+        self.tstops = None
+
+    # -- lifetime -------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            L.lib().odinn_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def cells(self):
+        return int(L.lib().odinn_batch_cells(self._h))
+
+    # -- inputs ---------------------------------------------------------------------
+    def set_fields(self, g, H0, B):
+        H0, B = _f(H0, self.shapes[g]), _f(B, self.shapes[g])
+        L.check(L.lib().odinn_set_fields(self._h, g, _p(H0), _p(B)))
+
+    def set_A(self, g, A):
+        L.check(L.lib().odinn_set_A(self._h, g, float(A)))
+
+    def _dual(self, g):
+        return (self.shapes[g][0] - 1, self.shapes[g][1] - 1)
+
+    def set_A_field(self, g, A):
+        A = _f(A, self._dual(g))
+        L.check(L.lib().odinn_set_A_field(self._h, g, _p(A)))
+
+    def set_T_field(self, g, T):
+        T = _f(T, self._dual(g))
+        L.check(L.lib().odinn_set_T_field(self._h, g, _p(T)))
+
+    def set_law(self, kind, mlp: Optional[MLPSpec] = None, theta=None, n_H=-1.0, n_gradS=-1.0):
+        if kind == L.LAW_CONST_A:
+            L.check(L.lib().odinn_set_law(self._h, kind, None, None, 0, -1.0, -1.0))
+            self.P = 0
+        else:
+            th = np.ascontiguousarray(theta, dtype=np.float64)
+            d = mlp.c_struct()
+            L.check(L.lib().odinn_set_law(self._h, kind, C.byref(d), _p(th), th.size, float(n_H), float(n_gradS)))
+            self.P = th.size
+        self.law_kind = kind
+
+    def set_theta(self, theta):
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        L.check(L.lib().odinn_set_theta(self._h, _p(th), th.size))
+
+    def set_reference(self, g, t_ref, H_ref, distance=3):
+        t = np.ascontiguousarray(t_ref, dtype=np.float64)
+        nx, ny = self.shapes[g]
+        H = np.ascontiguousarray(np.stack([_f(h, (nx, ny)).ravel(order="F") for h in H_ref]))
+        L.check(L.lib().odinn_set_reference(self._h, g, len(t), _p(t), _p(H), int(distance)))
+
+    def set_mass_balance(self, g, mb0, dmb_dS=0.0, S_ref=None, mb_max=np.inf):
+        if mb0 is None:
+            L.check(L.lib().odinn_set_mass_balance(self._h, g, None, 0.0, None, np.inf))
+            return
+        mb0 = _f(mb0, self.shapes[g])
+        sp = None
+        if S_ref is not None:
+            S_ref = _f(S_ref, self.shapes[g])
+            sp = _p(S_ref)
+        L.check(L.lib().odinn_set_mass_balance(self._h, g, _p(mb0), float(dmb_dS), sp, float(mb_max)))
+
+    # -- seams (== Huginn.SIA2D!, VJP_lambda_dSIA/dH, VJP_lambda_dSIA/dtheta) -----------
+    def dhdt(self, g, H, t=0.0):
+        H = _f(H, self.shapes[g])
+        out = np.empty_like(H)
+        L.check(L.lib().odinn_sia2d_dhdt(self._h, g, _p(H), float(t), _p(out)))
+        return out
+
+    def vjp_H(self, g, lam, H, t=0.0):
+        H, lam = _f(H, self.shapes[g]), _f(lam, self.shapes[g])
+        out = np.empty_like(H)
+        L.check(L.lib().odinn_sia2d_vjp_H(self._h, g, _p(lam), _p(H), float(t), _p(out)))
+        return out
+
+    def vjp_theta(self, g, lam, H, t=0.0):
+        H, lam = _f(H, self.shapes[g]), _f(lam, self.shapes[g])
+        P = 1 if self.law_kind == L.LAW_CONST_A else self.P
+        out = np.empty(P)
+        L.check(L.lib().odinn_sia2d_vjp_theta(self._h, g, _p(lam), _p(H), float(t), _p(out), P))
+        return out
+
+    def mb_apply(self, g, H):
+        H = _f(H, self.shapes[g])
+        Hn, MB = np.empty_like(H), np.empty_like(H)
+        L.check(L.lib().odinn_mb_apply(self._h, g, _p(H), _p(Hn), _p(MB)))
+        return Hn, MB
+
+    def mb_vjp_H(self, g, lam, H_pre):
+        H, lam = _f(H_pre, self.shapes[g]), _f(lam, self.shapes[g])
+        out = np.empty_like(H)
+        L.check(L.lib().odinn_mb_vjp_H(self._h, g, _p(lam), _p(H), _p(out)))
+        return out
+
+    def eval_law(self, g, H=None):
+        scalar = self.law_kind in (L.LAW_NN_A_SCALAR,)
+        if scalar:
+            out = np.empty(1)
+            L.check(L.lib().odinn_eval_law(self._h, g, None, _p(out), 1))
+            return float(out[0])
+        nd = self._dual(g)
+        out = np.empty(nd, order="F")
+        Hf = _f(H if H is not None else np.zeros(self.shapes[g]), self.shapes[g])
+        L.check(L.lib().odinn_eval_law(self._h, g, _p(Hf), _p(out), out.size))
+        return out
+
+    # -- device-resident time loop -----------------------------------------------------
+    @staticmethod
+    def _opts(reltol=1e-8, abstol=1e-6, dtmax=0.0, dt0=0.0, fixed_dt=0.0, maxiters=10 ** 6):
+        return L.SolverOpts(reltol, abstol, dtmax if np.isfinite(dtmax) else 0.0, dt0, fixed_dt or 0.0, maxiters)
+
+    def solve(self, tstops, mb_times=(), **opts) -> List[SolveStats]:
+        ts = np.ascontiguousarray(tstops, dtype=np.float64)
+        mb = np.ascontiguousarray(mb_times, dtype=np.float64)
+        o = self._opts(**opts)
+        st = (L.SolveStats * self.G)()
+        L.check(L.lib().odinn_solve(self._h, ts.size, _p(ts), mb.size, _p(mb) if mb.size else None, C.byref(o), st))
+        self.tstops = ts
+        return [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
+
+    def snapshot(self, g, istop):
+        out = np.empty(self.shapes[g], order="F")
+        L.check(L.lib().odinn_get_snapshot(self._h, g, int(istop), _p(out)))
+        return out
+
+    def H(self, g):
+        out = np.empty(self.shapes[g], order="F")
+        L.check(L.lib().odinn_get_H(self._h, g, _p(out)))
+        return out
+
+    def loss(self):
+        out = np.empty(self.G)
+        L.check(L.lib().odinn_loss(self._h, _p(out)))
+        return out
+
+    def loss_grad(self, tstops, theta=None, mb_times=(), **opts):
+        """(loss, dtheta), both summed over the batch's glaciers
+        (== SIA2D_grad! without the cross-device reduction)."""
+        ts = np.ascontiguousarray(tstops, dtype=np.float64)
+        mb = np.ascontiguousarray(mb_times, dtype=np.float64)
+        o = self._opts(**opts)
+        P = 1 if self.law_kind == L.LAW_CONST_A else self.P
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        loss = C.c_double(0.0)
+        dth = np.zeros(P)
+        st = (L.SolveStats * self.G)()
+        L.check(L.lib().odinn_loss_grad(self._h, _p(th) if th is not None else None, P, ts.size, _p(ts), mb.size,
+                                        _p(mb) if mb.size else None, C.byref(o), C.byref(loss), _p(dth), st))
+        self.tstops = ts
+        self.last_stats = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
+        return float(loss.value), dth
+
+    def lambda0(self, g):
+        out = np.empty(self.shapes[g], order="F")
+        L.check(L.lib().odinn_get_lambda0(self._h, g, _p(out)))
+        return out
+
+    # -- measurement -------------------------------------------------------------------
+    def time_kernel(self, which, iters=20, warmup=3):
+        """Average milliseconds per launch (HIP events on the batch's stream)."""
+        ms = C.c_double(0.0)
+        L.check(L.lib().odinn_time_kernel(self._h, int(which), int(warmup), int(iters), C.byref(ms)))
+        return ms.value / iters
+
+    def sync(self):
+        L.check(L.lib().odinn_batch_sync(self._h))

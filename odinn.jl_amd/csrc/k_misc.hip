@@ -1,0 +1,54 @@
+// k_misc.hip -- controller, post-step, reductions, mass balance, hoisted-law kernels
+#define ODINN_MISC_KERNELS 1
+#include "launch.hpp"
+namespace odinn {
+void launch_controller(int G, hipStream_t st, Pools P, CtrlArgs C) { hipLaunchKernelGGL(k_controller, dim3(G), dim3(64), 0, st, P, C); }
+void launch_poststep(int nblk, hipStream_t st, Pools P, PostArgs A, double* Ua, double* Ub) {
+  hipLaunchKernelGGL(k_poststep, dim3(nblk), dim3(NT), 0, st, P, A, Ua, Ub);
+}
+void launch_sum_part(int ng, hipStream_t st, Pools P, int slot, double* out, int accumulate, int g0) {
+  hipLaunchKernelGGL(k_sum_part, dim3(ng), dim3(64), 0, st, P, slot, out, accumulate, g0);
+}
+void launch_sum_part_theta(int Pn, int ng, hipStream_t st, Pools P, const double* part_theta, double* out,
+                           int accumulate, int g0) {
+  hipLaunchKernelGGL(k_sum_part_theta, dim3(Pn, ng), dim3(64), 0, st, P, part_theta, Pn, out, accumulate, g0);
+}
+void launch_loss(int nblk, hipStream_t st, Pools P, const double* H, const double* Href, const unsigned char* mask,
+                 const double* ws, const int* refslot, long long ntot) {
+  hipLaunchKernelGGL(k_loss, dim3(nblk), dim3(NT), 0, st, P, H, Href, mask, ws, refslot, ntot);
+}
+void launch_mb_vjp(int nblk, hipStream_t st, Pools P, const double* Hpre, const double* mb0, const double* Sref,
+                   const double* lam_in, double* lam_out, int add, int base) {
+  hipLaunchKernelGGL(k_mb_vjp, dim3(nblk), dim3(NT), 0, st, P, Hpre, mb0, Sref, lam_in, lam_out, add, base);
+}
+void launch_mb_apply(int nblk, hipStream_t st, Pools P, const double* H, const double* mb0, const double* Sref,
+                     double* Hn, double* MBout, int base) {
+  hipLaunchKernelGGL(k_mb_apply, dim3(nblk), dim3(NT), 0, st, P, H, mb0, Sref, Hn, MBout, base);
+}
+void launch_law_field(hipStream_t st, LawDev L, const double* T, double* Aout, long long n) {
+  hipLaunchKernelGGL(k_law_field, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, L, T, Aout, n);
+}
+void launch_law_field_grad(int nblk, hipStream_t st, LawDev L, const double* T, const double* G, long long n,
+                           double* gscratch, double* part_theta) {
+  hipLaunchKernelGGL(k_law_field_grad, dim3(nblk), dim3(NT), 0, st, L, T, G, n, gscratch, part_theta);
+}
+void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, double* out) {
+  hipLaunchKernelGGL(k_sum_rows, dim3(Pn), dim3(64), 0, st, part, nrows, Pn, out);
+}
+void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd) {
+  hipLaunchKernelGGL(k_eval_law, dim3((unsigned)((nd + NT - 1) / NT)), dim3(NT), 0, st, P, L, U, out, gidx);
+}
+void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const double* y, double* z) {
+  hipLaunchKernelGGL(k_axpy_g, dim3(nblk), dim3(NT), 0, st, P, x, y, z);
+}
+void launch_initdt_norms(int nblk, hipStream_t st, Pools P, const double* U, const double* F0, const double* F1,
+                         double abstol, double reltol) {
+  hipLaunchKernelGGL(k_initdt_norms, dim3(nblk), dim3(NT), 0, st, P, U, F0, F1, abstol, reltol);
+}
+void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan, double dtmax, double* dt0store) {
+  hipLaunchKernelGGL(k_initdt_ctrl, dim3(G), dim3(64), 0, st, P, phase, tspan, dtmax, dt0store);
+}
+void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double dtmax, double dt_given) {
+  hipLaunchKernelGGL(k_begin, dim3((G + 63) / 64), dim3(64), 0, st, P, G, tstops, dtmax, dt_given);
+}
+}  // namespace odinn

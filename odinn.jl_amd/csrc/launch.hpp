@@ -1,0 +1,42 @@
+// launch.hpp -- host-callable launch wrappers; each law mode (LM) of the stencil kernels is
+// compiled in its own translation unit (k_fwd.hip / k_adj.hip with -DODINN_LM=0|1|2).
+#pragma once
+#include "sia2d_device.hpp"
+
+namespace odinn {
+
+#define ODINN_DECL_LM(LM)                                                                                      \
+  void launch_dhdt_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, const double* U, double* dH, int base); \
+  void launch_rk_stage_lm##LM(int stage, int nblk, hipStream_t st, Pools P, LawDev L, const double* src,       \
+                              double* dst, double* S2, double* S3, double* E, double abstol, double reltol);   \
+  void launch_vjp_H_lm##LM(int mode, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base);        \
+  void launch_vjp_theta_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base);
+ODINN_DECL_LM(0)
+ODINN_DECL_LM(1)
+ODINN_DECL_LM(2)
+#undef ODINN_DECL_LM
+
+// k_misc.hip
+void launch_controller(int G, hipStream_t st, Pools P, CtrlArgs C);
+void launch_poststep(int nblk, hipStream_t st, Pools P, PostArgs A, double* Ua, double* Ub);
+void launch_sum_part(int ng, hipStream_t st, Pools P, int slot, double* out, int accumulate, int g0);
+void launch_sum_part_theta(int Pn, int ng, hipStream_t st, Pools P, const double* part_theta, double* out,
+                           int accumulate, int g0);
+void launch_loss(int nblk, hipStream_t st, Pools P, const double* H, const double* Href, const unsigned char* mask,
+                 const double* ws, const int* refslot, long long ntot);
+void launch_mb_vjp(int nblk, hipStream_t st, Pools P, const double* Hpre, const double* mb0, const double* Sref,
+                   const double* lam_in, double* lam_out, int add, int base);
+void launch_mb_apply(int nblk, hipStream_t st, Pools P, const double* H, const double* mb0, const double* Sref,
+                     double* Hn, double* MBout, int base);
+void launch_law_field(hipStream_t st, LawDev L, const double* T, double* Aout, long long n);
+void launch_law_field_grad(int nblk, hipStream_t st, LawDev L, const double* T, const double* G, long long n,
+                           double* gscratch, double* part_theta);
+void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, double* out);
+void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd);
+void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const double* y, double* z);
+void launch_initdt_norms(int nblk, hipStream_t st, Pools P, const double* U, const double* F0, const double* F1,
+                         double abstol, double reltol);
+void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan, double dtmax, double* dt0store);
+void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double dtmax, double dt_given);
+
+}  // namespace odinn

@@ -1,0 +1,1075 @@
+// odinn_hip.hip -- host side of libodinn_hip.so: batch context, device-resident time
+// loop, discrete-adjoint reverse loop, and the C ABI declared in include/odinn_hip.h.
+// No torch types, no CPU fallback: every compute entry point needs a gfx950 device.
+#include "../../include/odinn_hip.h"
+#include "launch.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace odinn;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(x)                                                                            \
+  do {                                                                                       \
+    hipError_t e_ = (x);                                                                     \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(ODINN_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define CHK(x)                 \
+  do {                         \
+    int r_ = (x);              \
+    if (r_ != ODINN_OK) return r_; \
+  } while (0)
+
+// ---- host MLP (hoisted scalar law: evaluated once per theta, Laws.jl:339-358) --------
+double h_act(int c, double x) {
+  switch (c) {
+    case 1: return std::log1p(std::exp(-std::fabs(x))) + std::fmax(x, 0.0);
+    case 2: { double t = std::exp(-std::fabs(x)); return x >= 0 ? 1.0 / (1.0 + t) : t / (1.0 + t); }
+    case 3: { const double k = 0.7978845608028654; return 0.5 * x * (1.0 + std::tanh(k * (x + 0.044715 * x * x * x))); }
+    case 4: return std::tanh(x);
+    case 5: return std::fmax(x, 0.0);
+    default: return x;
+  }
+}
+double h_dact(int c, double x) {
+  switch (c) {
+    case 1: return h_act(2, x);
+    case 2: { double s = h_act(2, x); return s * (1.0 - s); }
+    case 3: { const double k = 0.7978845608028654; double u = k * (x + 0.044715 * x * x * x); double th = std::tanh(u);
+              double du = k * (1.0 + 3 * 0.044715 * x * x); return 0.5 * (1.0 + th) + 0.5 * x * (1.0 - th * th) * du; }
+    case 4: { double th = std::tanh(x); return 1.0 - th * th; }
+    case 5: return x > 0 ? 1.0 : 0.0;
+    default: return 1.0;
+  }
+}
+// returns post(MLP(x)); if grad != null fills d out / d theta (P entries)
+double h_mlp(const odinn_mlp_desc& m, const double* th, const double* x, double* grad) {
+  std::vector<std::vector<double>> hs(m.n_layers + 1), zs(m.n_layers);
+  std::vector<int> offs(m.n_layers + 1, 0);
+  hs[0].resize(m.widths[0]);
+  for (int i = 0; i < m.widths[0]; ++i)
+    hs[0][i] = m.has_prescale ? (x[i] - m.pre_lo[i]) / (m.pre_hi[i] - m.pre_lo[i]) - 0.5 : x[i];
+  for (int l = 0; l < m.n_layers; ++l) {
+    const int nin = m.widths[l], nout = m.widths[l + 1], off = offs[l];
+    zs[l].resize(nout);
+    hs[l + 1].resize(nout);
+    for (int o = 0; o < nout; ++o) {
+      double acc = th[off + nin * nout + o];
+      for (int i = 0; i < nin; ++i) acc = std::fma(th[off + o + nout * i], hs[l][i], acc);
+      zs[l][o] = acc;
+      hs[l + 1][o] = h_act(m.acts[l], acc);
+    }
+    offs[l + 1] = off + nout * (nin + 1);
+  }
+  const double y = hs[m.n_layers][0];
+  double out = y, dpost = 1.0;
+  switch (m.post_kind) {
+    case ODINN_POST_AFFINE: out = m.post_lo + (m.post_hi - m.post_lo) * y; dpost = m.post_hi - m.post_lo; break;
+    case ODINN_POST_EXPMAX: out = m.post_hi * std::exp((y - 1.0) / y); dpost = out / (y * y); break;
+    case ODINN_POST_SCALE: out = m.post_hi * y; dpost = m.post_hi; break;
+    default: break;
+  }
+  if (grad) {
+    std::vector<double> gv(1, dpost), gn;
+    for (int l = m.n_layers - 1; l >= 0; --l) {
+      const int nin = m.widths[l], nout = m.widths[l + 1], off = offs[l];
+      gn.assign(nin, 0.0);
+      for (int o = 0; o < nout; ++o) {
+        const double dz = gv[o] * h_dact(m.acts[l], zs[l][o]);
+        grad[off + nin * nout + o] = dz;
+        for (int i = 0; i < nin; ++i) {
+          grad[off + o + nout * i] = dz * hs[l][i];
+          gn[i] = std::fma(th[off + o + nout * i], dz, gn[i]);
+        }
+      }
+      gv = gn;
+    }
+  }
+  return out;
+}
+int mlp_nparams(const odinn_mlp_desc& m) {
+  int p = 0;
+  for (int l = 0; l < m.n_layers; ++l) p += m.widths[l + 1] * (m.widths[l] + 1);
+  return p;
+}
+
+}  // namespace
+
+struct odinn_batch {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int G = 0;
+  std::vector<odinn_glacier_desc> descs;
+  std::vector<GDev> gd;
+  long long ntot = 0, ntotd = 0;
+  int ntiles = 0;
+  // device pools
+  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr;
+  GDev* d_gd = nullptr;
+  GState* d_gs = nullptr;
+  double *d_B = nullptr, *d_H0 = nullptr, *d_Afield = nullptr, *d_Tfield = nullptr, *d_Gacc = nullptr;
+  double *d_part = nullptr, *d_U[2] = {nullptr, nullptr}, *d_S2 = nullptr, *d_S3 = nullptr, *d_E = nullptr;
+  double *d_lam[2] = {nullptr, nullptr}, *d_tmpA = nullptr, *d_tmpB = nullptr;
+  double *d_mb0 = nullptr, *d_Sref = nullptr;
+  bool any_mb = false, any_sref = false;
+  // snapshots
+  int nstops_alloc = 0, nmb_alloc = 0;
+  double *d_snaps = nullptr, *d_premb = nullptr;
+  // reference thickness data
+  std::vector<std::vector<double>> t_ref;  // per glacier
+  int nref_alloc = 0;
+  double* d_Href = nullptr;
+  unsigned char* d_mask = nullptr;
+  // law
+  int law_kind = ODINN_LAW_CONST_A;
+  odinn_mlp_desc mlp{};
+  std::vector<double> theta;
+  double* d_theta = nullptr;
+  int P = 0;
+  double nH = -1, nS = -1;
+  bool has_Afield_const = false;
+  double *d_part_theta = nullptr, *d_gscratch = nullptr, *d_dth = nullptr;
+  size_t part_theta_cap = 0, gscratch_cap = 0, dth_cap = 0;
+  // solve bookkeeping
+  std::vector<double> tstops;
+  std::vector<int> mb_flag, mb_slot;
+  double* d_tstops = nullptr;
+  int *d_mb_flag = nullptr, *d_mb_slot = nullptr, *d_nactive = nullptr;
+  double* d_dt0 = nullptr;
+  double *d_dts = nullptr, *d_ws = nullptr, *d_lossacc = nullptr, *d_Gsum = nullptr;
+  int* d_refslot = nullptr;
+  int tab_cap = 0;
+  bool solved = false;
+  bool gd_dirty = true;
+
+  // law mode of the stencil kernels: 0 integer-power fast path (n==3, C==0 for every glacier),
+  // 1 generic pow path, 2 inlined per-node MLP (Y / U laws)
+  int lm() const {
+    if (law_kind >= ODINN_LAW_NN_Y) return 2;
+    for (const GDev& r : gd)
+      if (!r.fast) return 1;
+    return 0;
+  }
+  Pools pools(bool swz = true) const {
+    Pools p;
+    p.tiles = swz ? d_tiles : d_tiles_nat;
+    p.gd = d_gd;
+    p.gs = d_gs;
+    p.B = d_B;
+    p.Afield = d_Afield;
+    p.part = d_part;
+    return p;
+  }
+  LawDev lawdev() const {
+    LawDev L{};
+    L.kind = law_kind;
+    L.n_layers = mlp.n_layers;
+    L.has_pre = mlp.has_prescale;
+    L.post_kind = mlp.post_kind;
+    L.P = P;
+    int mw = 1;
+    for (int l = 0; l <= mlp.n_layers && l < 9; ++l) { L.widths[l] = mlp.widths[l]; mw = std::max(mw, mlp.widths[l]); }
+    L.maxw = mw;
+    for (int l = 0; l < mlp.n_layers; ++l) L.acts[l] = mlp.acts[l];
+    for (int i = 0; i < 2; ++i) {
+      L.pre_lo[i] = mlp.pre_lo[i];
+      L.pre_inv[i] = mlp.has_prescale ? 1.0 / (mlp.pre_hi[i] - mlp.pre_lo[i]) : 1.0;
+    }
+    L.post_lo = mlp.post_lo;
+    L.post_hi = mlp.post_hi;
+    L.theta = d_theta;
+    return L;
+  }
+};
+
+namespace {
+
+int use_dev(odinn_batch* b) {
+  HIPCHK(hipSetDevice(b->device));
+  return ODINN_OK;
+}
+
+template <class T>
+int dalloc(T** p, size_t n) {
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+  return ODINN_OK;
+}
+template <class T>
+void dfree(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+// derived per-glacier constants + hoisted scalar law; uploads d_gd when dirty
+int refresh_gd(odinn_batch* b) {
+  if (!b->gd_dirty) return ODINN_OK;
+  for (int g = 0; g < b->G; ++g) {
+    const odinn_glacier_desc& d = b->descs[g];
+    GDev& r = b->gd[g];
+    const odinn_phys& ph = d.phys;
+    r.dx = d.dx; r.dy = d.dy; r.inv_dx = 1.0 / d.dx; r.inv_dy = 1.0 / d.dy; r.eta0 = ph.eta0;
+    r.n = ph.n; r.p = ph.p; r.q = ph.q; r.T = d.T;
+    r.Gam = 2.0 * std::pow(ph.rho * ph.g, ph.n) / (ph.n + 2.0);
+    r.Sc = ph.C * std::pow(ph.rho * ph.g, ph.p - ph.q);
+    r.fast = (ph.n == 3.0 && r.Sc == 0.0) ? 1 : 0;
+    r.nH = b->nH >= 0 ? b->nH : ph.n;
+    r.nS = b->nS >= 0 ? b->nS : ph.n;
+    r.minA = ph.minA; r.maxA = ph.maxA;
+    if (b->law_kind == ODINN_LAW_NN_A_SCALAR) {
+      r.A = h_mlp(b->mlp, b->theta.data(), &d.T, nullptr);
+      r.use_Afield = 0;
+    } else if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) {
+      r.A = 0.0;
+      r.use_Afield = 1;
+    } else if (b->law_kind == ODINN_LAW_CONST_A) {
+      r.A = d.A;
+      r.use_Afield = b->has_Afield_const ? 1 : 0;
+    } else {
+      r.A = 0.0;
+      r.use_Afield = 0;
+    }
+  }
+  HIPCHK(hipMemcpyAsync(b->d_gd, b->gd.data(), sizeof(GDev) * b->G, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  b->gd_dirty = false;
+  return ODINN_OK;
+}
+
+int refresh_law_field(odinn_batch* b) {
+  if (b->law_kind != ODINN_LAW_NN_A_GRIDDED) return ODINN_OK;
+  launch_law_field(b->stream, b->lawdev(), b->d_Tfield, b->d_Afield, b->ntotd);
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+int check_g(odinn_batch* b, int g) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
+  if (g < 0 || g >= b->G) return fail(ODINN_ERR_ARG, "glacier index %d out of range [0,%d)", g, b->G);
+  return ODINN_OK;
+}
+
+int ensure_theta_scratch(odinn_batch* b, int grid_blocks) {
+  const int P = std::max(b->P, 1);
+  const size_t need_pt = (size_t)std::max(b->ntiles, grid_blocks) * P;
+  if (need_pt > b->part_theta_cap) {
+    dfree(b->d_part_theta);
+    CHK(dalloc(&b->d_part_theta, need_pt));
+    b->part_theta_cap = need_pt;
+  }
+  const size_t need_gs = (size_t)grid_blocks * NT * P;
+  if (need_gs > b->gscratch_cap) {
+    dfree(b->d_gscratch);
+    CHK(dalloc(&b->d_gscratch, need_gs));
+    b->gscratch_cap = need_gs;
+  }
+  const size_t need_dth = (size_t)b->G * P;
+  if (need_dth > b->dth_cap) {
+    dfree(b->d_dth);
+    CHK(dalloc(&b->d_dth, need_dth));
+    b->dth_cap = need_dth;
+  }
+  return ODINN_OK;
+}
+
+// upload one glacier-sized host field into a pooled device array
+int up_field(odinn_batch* b, int g, double* dpool, const double* h, bool dual = false) {
+  const GDev& r = b->gd[g];
+  const long long n = dual ? (long long)(r.nx - 1) * (r.ny - 1) : (long long)r.nx * r.ny;
+  const long long off = dual ? r.offd : r.off;
+  HIPCHK(hipMemcpyAsync(dpool + off, h, n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ODINN_OK;
+}
+int down_field(odinn_batch* b, int g, const double* dpool, double* h, bool dual = false) {
+  const GDev& r = b->gd[g];
+  const long long n = dual ? (long long)(r.nx - 1) * (r.ny - 1) : (long long)r.nx * r.ny;
+  const long long off = dual ? r.offd : r.off;
+  HIPCHK(hipMemcpyAsync(h, dpool + off, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ODINN_OK;
+}
+
+// ---- launches -------------------------------------------------------------------------
+int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */) {
+  const Pools P = b->pools(g < 0);
+  const int base = g < 0 ? 0 : b->gd[g].tile0, n = g < 0 ? b->ntiles : b->gd[g].ntiles;
+  switch (b->lm()) {
+    case 0: launch_dhdt_lm0(n, b->stream, P, b->lawdev(), U, dH, base); break;
+    case 1: launch_dhdt_lm1(n, b->stream, P, b->lawdev(), U, dH, base); break;
+    default: launch_dhdt_lm2(n, b->stream, P, b->lawdev(), U, dH, base); break;
+  }
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+template <int S>
+void launch_stage(odinn_batch* b, const Pools& P, const LawDev& L, const double* src, double* dst, double abstol,
+                  double reltol) {
+  switch (b->lm()) {
+    case 0: launch_rk_stage_lm0(S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol); break;
+    case 1: launch_rk_stage_lm1(S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol); break;
+    default: launch_rk_stage_lm2(S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol); break;
+  }
+}
+void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawDev& L, const AdjArgs& A, int base) {
+  switch (b->lm()) {
+    case 0: launch_vjp_H_lm0(mode, nblk, b->stream, P, L, A, base); break;
+    case 1: launch_vjp_H_lm1(mode, nblk, b->stream, P, L, A, base); break;
+    default: launch_vjp_H_lm2(mode, nblk, b->stream, P, L, A, base); break;
+  }
+}
+void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L, const ThArgs& A, int base) {
+  switch (b->lm()) {
+    case 0: launch_vjp_theta_lm0(nblk, b->stream, P, L, A, base); break;
+    case 1: launch_vjp_theta_lm1(nblk, b->stream, P, L, A, base); break;
+    default: launch_vjp_theta_lm2(nblk, b->stream, P, L, A, base); break;
+  }
+}
+
+// one RDPK3Sp35 step for all glaciers: 5 fused stage kernels.  parity p: state in U[p].
+int launch_step(odinn_batch* b, int p, double abstol, double reltol) {
+  const Pools P = b->pools(true);
+  const LawDev L = b->lawdev();
+  double* Ua = b->d_U[p];
+  double* Ub = b->d_U[1 - p];
+  launch_stage<1>(b, P, L, Ua, Ub, abstol, reltol);
+  launch_stage<2>(b, P, L, Ub, Ua, abstol, reltol);
+  launch_stage<3>(b, P, L, Ua, Ub, abstol, reltol);
+  launch_stage<4>(b, P, L, Ub, Ua, abstol, reltol);
+  launch_stage<5>(b, P, L, Ua, Ub, abstol, reltol);
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+int ensure_tables(odinn_batch* b, int n_stops) {
+  if (n_stops > b->tab_cap) {
+    dfree(b->d_tstops); dfree(b->d_mb_flag); dfree(b->d_mb_slot);
+    dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
+    CHK(dalloc(&b->d_tstops, n_stops));
+    CHK(dalloc(&b->d_mb_flag, n_stops));
+    CHK(dalloc(&b->d_mb_slot, n_stops));
+    CHK(dalloc(&b->d_dts, (size_t)n_stops * b->G));
+    CHK(dalloc(&b->d_ws, (size_t)n_stops * b->G));
+    CHK(dalloc(&b->d_refslot, (size_t)n_stops * b->G));
+    b->tab_cap = n_stops;
+  }
+  return ODINN_OK;
+}
+
+// loss weights w_j and reference slots (safe_slice rule, gradient.jl:38-40,144-149)
+int upload_loss_tables(odinn_batch* b) {
+  const int k = (int)b->tstops.size();
+  std::vector<double> dts((size_t)k * b->G, 0.0), ws((size_t)k * b->G, 0.0);
+  std::vector<int> slot((size_t)k * b->G, 0);
+  for (int j = 0; j < k; ++j)
+    for (int g = 0; g < b->G; ++g) {
+      dts[(size_t)j * b->G + g] = j > 0 ? b->tstops[j] - b->tstops[j - 1] : 0.0;
+      const std::vector<double>& tr = b->t_ref[g];
+      for (size_t m = 0; m < tr.size(); ++m)
+        if (tr[m] == b->tstops[j]) {
+          slot[(size_t)j * b->G + g] = (int)m;
+          ws[(size_t)j * b->G + g] = m >= 1 ? tr[m] - tr[m - 1] : 0.0;
+          break;
+        }
+    }
+  HIPCHK(hipMemcpyAsync(b->d_dts, dts.data(), dts.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_ws, ws.data(), ws.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_refslot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ODINN_OK;
+}
+
+int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times,
+             const odinn_solver_opts* o, odinn_solve_stats* stats) {
+  if (n_stops < 2) return fail(ODINN_ERR_ARG, "need at least 2 tstops");
+  for (int j = 1; j < n_stops; ++j)
+    if (!(tstops[j] > tstops[j - 1])) return fail(ODINN_ERR_ARG, "tstops must be strictly increasing");
+  CHK(use_dev(b));
+  CHK(refresh_gd(b));
+  CHK(refresh_law_field(b));
+  odinn_solver_opts opt{1e-8, 1e-6, 0.0, 0.0, 0.0, 1000000};
+  if (o) opt = *o;
+  if (opt.maxiters <= 0) opt.maxiters = 1000000;
+  if (opt.abstol <= 0) opt.abstol = 1e-6;
+  if (opt.reltol <= 0) opt.reltol = 1e-8;
+  const bool adaptive = !(opt.fixed_dt > 0.0);
+  // stop tables
+  b->tstops.assign(tstops, tstops + n_stops);
+  b->mb_flag.assign(n_stops, 0);
+  b->mb_slot.assign(n_stops, 0);
+  int nmb = 0;
+  if (b->any_mb)
+    for (int m = 0; m < n_mb; ++m) {
+      bool found = false;
+      for (int j = 1; j < n_stops; ++j)
+        if (tstops[j] == mb_times[m]) { b->mb_flag[j] = 1; b->mb_slot[j] = nmb++; found = true; break; }
+      if (!found) return fail(ODINN_ERR_ARG, "mb_times[%d]=%g is not one of tstops[1:]", m, mb_times[m]);
+    }
+  CHK(ensure_tables(b, n_stops));
+  if (n_stops > b->nstops_alloc) {
+    dfree(b->d_snaps);
+    CHK(dalloc(&b->d_snaps, (size_t)n_stops * b->ntot));
+    b->nstops_alloc = n_stops;
+  }
+  if (nmb > b->nmb_alloc) {
+    dfree(b->d_premb);
+    CHK(dalloc(&b->d_premb, (size_t)nmb * b->ntot));
+    b->nmb_alloc = nmb;
+  }
+  HIPCHK(hipMemcpyAsync(b->d_tstops, tstops, n_stops * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_mb_flag, b->mb_flag.data(), n_stops * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_mb_slot, b->mb_slot.data(), n_stops * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  CHK(upload_loss_tables(b));
+  // initial state and first snapshot
+  const size_t fb = (size_t)b->ntot * sizeof(double);
+  HIPCHK(hipMemcpyAsync(b->d_U[0], b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_snaps, b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
+  const Pools P = b->pools(true);
+  long long nrhs_extra = 0;
+  const double tspan = tstops[n_stops - 1] - tstops[0];
+  if (adaptive && !(opt.dt0 > 0.0)) {
+    // Hairer-Wanner initial step (OrdinaryDiffEq ode_determine_initdt), all on device
+    CHK(launch_dhdt(b, b->d_U[0], b->d_S2, -1));  // f0 -> S2
+    launch_initdt_norms(b->ntiles, b->stream, P, b->d_U[0], b->d_S2, nullptr, opt.abstol, opt.reltol);
+    launch_initdt_ctrl(b->G, b->stream, P, 0, tspan, opt.dtmax, b->d_dt0);
+    launch_axpy_g(b->ntiles, b->stream, P, b->d_S2, b->d_U[0], b->d_U[1]);
+    CHK(launch_dhdt(b, b->d_U[1], b->d_E, -1));  // f1 -> E
+    launch_initdt_norms(b->ntiles, b->stream, P, b->d_U[0], b->d_S2, b->d_E, opt.abstol, opt.reltol);
+    launch_initdt_ctrl(b->G, b->stream, P, 1, tspan, opt.dtmax, b->d_dt0);
+    nrhs_extra = 2;
+  }
+  launch_begin(b->G, b->stream, P, b->d_tstops, opt.dtmax, adaptive ? opt.dt0 : opt.fixed_dt);
+  int nact = b->G;
+  HIPCHK(hipMemcpyAsync(b->d_nactive, &nact, sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipGetLastError());
+
+  CtrlArgs C;
+  C.tstops = b->d_tstops; C.n_stops = n_stops; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
+  C.dtmax = opt.dtmax; C.adaptive = adaptive ? 1 : 0; C.fixed_dt = opt.fixed_dt; C.n_active = b->d_nactive;
+  PostArgs A;
+  A.snaps = b->d_snaps; A.premb = b->d_premb; A.ntot = b->ntot; A.mb0 = b->d_mb0;
+  A.Sref = b->any_sref ? b->d_Sref : nullptr;
+  const int CHUNK = 16;  // steps between host polls of the active-glacier counter
+  long long steps = 0;
+  int p = 0;
+  while (nact > 0) {
+    for (int s = 0; s < CHUNK; ++s) {
+      CHK(launch_step(b, p, opt.abstol, opt.reltol));
+      C.next_cur = 1 - p;
+      launch_controller(b->G, b->stream, P, C);
+      launch_poststep(b->ntiles, b->stream, P, A, b->d_U[0], b->d_U[1]);
+      p = 1 - p;
+      ++steps;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&nact, b->d_nactive, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (steps >= opt.maxiters && nact > 0) return fail(ODINN_ERR_MAXITERS, "maxiters (%lld) reached with %d glaciers active", (long long)opt.maxiters, nact);
+  }
+  std::vector<GState> gs(b->G);
+  HIPCHK(hipMemcpy(gs.data(), b->d_gs, sizeof(GState) * b->G, hipMemcpyDeviceToHost));
+  for (int g = 0; g < b->G; ++g) {
+    if (gs[g].nonfinite) return fail(ODINN_ERR_NONFINITE, "non-finite error estimate in glacier %d", g);
+    if (stats) {
+      stats[g].naccept = gs[g].naccept;
+      stats[g].nreject = gs[g].nreject;
+      stats[g].nrhs = 5 * (gs[g].naccept + gs[g].nreject) + nrhs_extra;
+      stats[g].t_final = gs[g].t;
+      stats[g].dt_last = gs[g].dt;
+    }
+  }
+  b->solved = true;
+  return ODINN_OK;
+}
+
+// forward loss over the stored snapshots -> d_lossacc[g]
+int do_loss(odinn_batch* b) {
+  const int k = (int)b->tstops.size();
+  HIPCHK(hipMemsetAsync(b->d_lossacc, 0, sizeof(double) * b->G, b->stream));
+  if (!b->d_Href) return ODINN_OK;
+  const Pools P = b->pools(true);
+  for (int j = 1; j < k; ++j) {
+    launch_loss(b->ntiles, b->stream, P, b->d_snaps + (size_t)j * b->ntot, b->d_Href, b->d_mask,
+                b->d_ws + (size_t)j * b->G, b->d_refslot + (size_t)j * b->G, b->ntot);
+    launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
+  }
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+const char* odinn_last_error(void) { return g_err.c_str(); }
+
+int odinn_device_count(int* n) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  if (n) *n = c;
+  return ODINN_OK;
+}
+
+int odinn_device_name(int dev, char* buf, int buflen) {
+  hipDeviceProp_t pr;
+  HIPCHK(hipGetDeviceProperties(&pr, dev));
+  snprintf(buf, buflen, "%s (%s)", pr.name, pr.gcnArchName);
+  return ODINN_OK;
+}
+
+int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* descs, odinn_batch** out) {
+  if (!out || !descs || n_glaciers <= 0) return fail(ODINN_ERR_ARG, "bad arguments to odinn_batch_create");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(ODINN_ERR_NO_DEVICE, "no HIP device visible: libodinn_hip has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(ODINN_ERR_ARG, "device %d out of range (%d devices)", device, ndev);
+  for (int g = 0; g < n_glaciers; ++g)
+    if (descs[g].nx < 3 || descs[g].ny < 3 || !(descs[g].dx > 0) || !(descs[g].dy > 0))
+      return fail(ODINN_ERR_ARG, "glacier %d: need nx,ny >= 3 and dx,dy > 0", g);
+  odinn_batch* b = new odinn_batch();
+  b->device = device;
+  b->G = n_glaciers;
+  b->descs.assign(descs, descs + n_glaciers);
+  b->gd.resize(n_glaciers);
+  b->t_ref.resize(n_glaciers);
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreate(&b->ev0));
+  HIPCHK(hipEventCreate(&b->ev1));
+  std::vector<int4> nat;
+  long long off = 0, offd = 0;
+  for (int g = 0; g < n_glaciers; ++g) {
+    GDev& r = b->gd[g];
+    memset(&r, 0, sizeof r);
+    r.nx = descs[g].nx; r.ny = descs[g].ny;
+    r.ntx = (r.nx + TX - 1) / TX; r.nty = (r.ny + TY - 1) / TY;
+    r.tile0 = (int)nat.size(); r.ntiles = r.ntx * r.nty;
+    // 64-double alignment of every glacier so that rows of nx%64==0 grids stay 512-B aligned
+    off = (off + 63) & ~63LL; offd = (offd + 63) & ~63LL;
+    r.off = off; r.offd = offd;
+    off += (long long)r.nx * r.ny;
+    offd += (long long)(r.nx - 1) * (r.ny - 1);
+    r.mb_max = INFINITY;
+    for (int ty = 0; ty < r.nty; ++ty)
+      for (int tx = 0; tx < r.ntx; ++tx) nat.push_back(make_int4(g, tx, ty, (int)nat.size()));
+  }
+  b->ntot = off; b->ntotd = offd; b->ntiles = (int)nat.size();
+  // XCD-aware order: block k runs on XCD k%8; give each XCD a contiguous band of tiles
+  std::vector<int4> swz(nat.size());
+  {
+    const int n = (int)nat.size(), X = 8;
+    const int per = (n + X - 1) / X;
+    int k = 0;
+    std::vector<int> order;
+    order.reserve(n);
+    for (int r = 0; r < per; ++r)
+      for (int x = 0; x < X; ++x) {
+        const int t = x * per + r;
+        if (t < n) order.push_back(t);
+      }
+    for (int t : order) swz[k++] = nat[t];
+  }
+  CHK(dalloc(&b->d_tiles, nat.size()));
+  CHK(dalloc(&b->d_tiles_nat, nat.size()));
+  HIPCHK(hipMemcpy(b->d_tiles, swz.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_tiles_nat, nat.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
+  CHK(dalloc(&b->d_gd, n_glaciers));
+  CHK(dalloc(&b->d_gs, n_glaciers));
+  const size_t n = (size_t)b->ntot, nd = (size_t)b->ntotd;
+  CHK(dalloc(&b->d_B, n)); CHK(dalloc(&b->d_H0, n));
+  CHK(dalloc(&b->d_U[0], n)); CHK(dalloc(&b->d_U[1], n));
+  CHK(dalloc(&b->d_S2, n)); CHK(dalloc(&b->d_S3, n)); CHK(dalloc(&b->d_E, n));
+  CHK(dalloc(&b->d_lam[0], n)); CHK(dalloc(&b->d_lam[1], n));
+  CHK(dalloc(&b->d_tmpA, n)); CHK(dalloc(&b->d_tmpB, n));
+  CHK(dalloc(&b->d_mb0, n)); CHK(dalloc(&b->d_Sref, n));
+  CHK(dalloc(&b->d_Afield, nd)); CHK(dalloc(&b->d_Tfield, nd)); CHK(dalloc(&b->d_Gacc, nd));
+  CHK(dalloc(&b->d_part, 4 * nat.size()));
+  CHK(dalloc(&b->d_nactive, 1));
+  CHK(dalloc(&b->d_dt0, n_glaciers));
+  CHK(dalloc(&b->d_lossacc, n_glaciers));
+  CHK(dalloc(&b->d_Gsum, n_glaciers));
+  CHK(dalloc(&b->d_theta, 1));
+  b->mlp.n_layers = 0;
+  b->gd_dirty = true;
+  *out = b;
+  return ODINN_OK;
+}
+
+int odinn_batch_destroy(odinn_batch* b) {
+  if (!b) return ODINN_OK;
+  (void)hipSetDevice(b->device);
+  (void)hipStreamSynchronize(b->stream);
+  dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_gd); dfree(b->d_gs);
+  dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
+  dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
+  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0);
+  dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
+  dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
+  dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return ODINN_OK;
+}
+
+int odinn_batch_sync(odinn_batch* b) {
+  CHK(use_dev(b));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ODINN_OK;
+}
+
+int64_t odinn_batch_cells(odinn_batch* b) {
+  int64_t n = 0;
+  for (int g = 0; g < b->G; ++g) n += (int64_t)b->gd[g].nx * b->gd[g].ny;
+  return n;
+}
+
+int odinn_set_fields(odinn_batch* b, int g, const double* H0, const double* B) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!H0 || !B) return fail(ODINN_ERR_ARG, "null field");
+  CHK(up_field(b, g, b->d_H0, H0));
+  CHK(up_field(b, g, b->d_B, B));
+  b->solved = false;
+  return ODINN_OK;
+}
+
+int odinn_set_A(odinn_batch* b, int g, double A) {
+  CHK(check_g(b, g));
+  b->descs[g].A = A;
+  b->gd_dirty = true;
+  return ODINN_OK;
+}
+
+int odinn_set_A_field(odinn_batch* b, int g, const double* A_dual) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!A_dual) return fail(ODINN_ERR_ARG, "null field");
+  if (b->law_kind != ODINN_LAW_CONST_A) return fail(ODINN_ERR_STATE, "odinn_set_A_field requires ODINN_LAW_CONST_A");
+  if (!b->has_Afield_const) {
+    // every glacier reads the field once any glacier sets one: initialise all to their scalar A
+    for (int q = 0; q < b->G; ++q) {
+      const GDev& r = b->gd[q];
+      std::vector<double> a((size_t)(r.nx - 1) * (r.ny - 1), b->descs[q].A);
+      CHK(up_field(b, q, b->d_Afield, a.data(), true));
+    }
+    b->has_Afield_const = true;
+  }
+  CHK(up_field(b, g, b->d_Afield, A_dual, true));
+  b->gd_dirty = true;
+  return ODINN_OK;
+}
+
+int odinn_set_T_field(odinn_batch* b, int g, const double* T_dual) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!T_dual) return fail(ODINN_ERR_ARG, "null field");
+  return up_field(b, g, b->d_Tfield, T_dual, true);
+}
+
+int odinn_set_theta(odinn_batch* b, const double* theta, int P) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
+  CHK(use_dev(b));
+  if (b->law_kind == ODINN_LAW_CONST_A) return fail(ODINN_ERR_STATE, "no trainable law set");
+  if (P != b->P || !theta) return fail(ODINN_ERR_ARG, "theta has %d entries, law expects %d", P, b->P);
+  b->theta.assign(theta, theta + P);
+  HIPCHK(hipMemcpyAsync(b->d_theta, theta, sizeof(double) * P, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  b->gd_dirty = true;
+  return ODINN_OK;
+}
+
+int odinn_set_law(odinn_batch* b, int kind, const odinn_mlp_desc* mlp, const double* theta, int P, double n_H,
+                  double n_gradS) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
+  CHK(use_dev(b));
+  if (kind < ODINN_LAW_CONST_A || kind > ODINN_LAW_NN_U) return fail(ODINN_ERR_ARG, "unknown law kind %d", kind);
+  if (kind == ODINN_LAW_CONST_A) {
+    b->law_kind = kind;
+    b->P = 0;
+    b->mlp.n_layers = 0;
+    b->gd_dirty = true;
+    return ODINN_OK;
+  }
+  if (!mlp || !theta) return fail(ODINN_ERR_ARG, "NN law needs an MLP descriptor and theta");
+  if (mlp->n_layers < 1 || mlp->n_layers > ODINN_MAX_LAYERS) return fail(ODINN_ERR_ARG, "n_layers out of range");
+  for (int l = 0; l <= mlp->n_layers; ++l)
+    if (mlp->widths[l] < 1 || mlp->widths[l] > ODINN_MAX_WIDTH) return fail(ODINN_ERR_ARG, "layer width out of range");
+  if (mlp->widths[mlp->n_layers] != 1) return fail(ODINN_ERR_ARG, "the MLP must have one output");
+  const int nin_expected = (kind == ODINN_LAW_NN_Y || kind == ODINN_LAW_NN_U) ? 2 : 1;
+  if (mlp->widths[0] != nin_expected) return fail(ODINN_ERR_ARG, "law kind %d expects %d MLP inputs", kind, nin_expected);
+  if (mlp_nparams(*mlp) != P) return fail(ODINN_ERR_ARG, "theta has %d entries, architecture needs %d", P, mlp_nparams(*mlp));
+  if (P > MAXP) return fail(ODINN_ERR_ARG, "P=%d exceeds %d", P, MAXP);
+  b->law_kind = kind;
+  b->mlp = *mlp;
+  b->P = P;
+  b->nH = n_H; b->nS = n_gradS;
+  dfree(b->d_theta);
+  CHK(dalloc(&b->d_theta, (size_t)P));
+  return odinn_set_theta(b, theta, P);
+}
+
+int odinn_set_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, const double* H_ref, int distance) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (n_ref < 0 || (n_ref > 0 && (!t_ref || !H_ref))) return fail(ODINN_ERR_ARG, "bad reference data");
+  if (n_ref > b->nref_alloc) {
+    // grow, keeping what other glaciers already uploaded
+    double* nh = nullptr; unsigned char* nm = nullptr;
+    CHK(dalloc(&nh, (size_t)n_ref * b->ntot));
+    CHK(dalloc(&nm, (size_t)n_ref * b->ntot));
+    if (b->d_Href) {
+      HIPCHK(hipMemcpy(nh, b->d_Href, (size_t)b->nref_alloc * b->ntot * sizeof(double), hipMemcpyDeviceToDevice));
+      HIPCHK(hipMemcpy(nm, b->d_mask, (size_t)b->nref_alloc * b->ntot, hipMemcpyDeviceToDevice));
+    }
+    dfree(b->d_Href); dfree(b->d_mask);
+    b->d_Href = nh; b->d_mask = nm; b->nref_alloc = n_ref;
+  }
+  const GDev& r = b->gd[g];
+  const long long n = (long long)r.nx * r.ny;
+  b->t_ref[g].assign(t_ref, t_ref + n_ref);
+  std::vector<unsigned char> mask((size_t)n);
+  for (int m = 0; m < n_ref; ++m) {
+    const double* Hr = H_ref + (size_t)m * n;
+    // is_in_glacier(Href, distance): Href>0 on the whole (2d+1)^2 Chebyshev neighbourhood
+    for (int j = 0; j < r.ny; ++j)
+      for (int i = 0; i < r.nx; ++i) {
+        bool in = true;
+        for (int dj = -distance; dj <= distance && in; ++dj)
+          for (int di = -distance; di <= distance; ++di) {
+            const int ii = i + di, jj = j + dj;
+            if (ii < 0 || ii >= r.nx || jj < 0 || jj >= r.ny || !(Hr[ii + (size_t)r.nx * jj] > 0.0)) { in = false; break; }
+          }
+        mask[i + (size_t)r.nx * j] = in ? 1 : 0;
+      }
+    HIPCHK(hipMemcpy(b->d_Href + (size_t)m * b->ntot + r.off, Hr, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_mask + (size_t)m * b->ntot + r.off, mask.data(), (size_t)n, hipMemcpyHostToDevice));
+  }
+  return ODINN_OK;
+}
+
+int odinn_set_mass_balance(odinn_batch* b, int g, const double* mb0, double dmb_dS, const double* S_ref, double mb_max) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  GDev& r = b->gd[g];
+  if (!mb0) {
+    r.has_mb = 0;
+  } else {
+    if (dmb_dS != 0.0 && !S_ref) return fail(ODINN_ERR_ARG, "S_ref required when dmb_dS != 0");
+    CHK(up_field(b, g, b->d_mb0, mb0));
+    if (S_ref) { CHK(up_field(b, g, b->d_Sref, S_ref)); b->any_sref = true; }
+    r.has_mb = 1; r.dmb_dS = dmb_dS; r.mb_max = mb_max;
+  }
+  b->any_mb = false;
+  for (int q = 0; q < b->G; ++q) b->any_mb = b->any_mb || b->gd[q].has_mb;
+  b->gd_dirty = true;
+  return ODINN_OK;
+}
+
+// ---- seams ------------------------------------------------------------------------------
+int odinn_sia2d_dhdt(odinn_batch* b, int g, const double* H, double t, double* dH) {
+  (void)t;  // SIA2D is autonomous
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!H || !dH) return fail(ODINN_ERR_ARG, "null field");
+  CHK(refresh_gd(b)); CHK(refresh_law_field(b));
+  CHK(up_field(b, g, b->d_tmpA, H));
+  CHK(launch_dhdt(b, b->d_tmpA, b->d_tmpB, g));
+  return down_field(b, g, b->d_tmpB, dH);
+}
+
+int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H, double t, double* dlam) {
+  (void)t;
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!H || !lam || !dlam) return fail(ODINN_ERR_ARG, "null field");
+  CHK(refresh_gd(b)); CHK(refresh_law_field(b));
+  CHK(up_field(b, g, b->d_tmpA, H));
+  CHK(up_field(b, g, b->d_lam[0], lam));
+  AdjArgs A{};
+  A.H = b->d_tmpA; A.lam = b->d_lam[0]; A.out = b->d_tmpB;
+  launch_vjp_H(b, 0, b->gd[g].ntiles, b->pools(false), b->lawdev(), A, b->gd[g].tile0);
+  HIPCHK(hipGetLastError());
+  return down_field(b, g, b->d_tmpB, dlam);
+}
+
+static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
+                            bool accumulate) {
+  // g < 0: all glaciers (swizzled table); result of A-type laws lands in d_Gsum / d_Gacc,
+  // of Y/U laws in d_dth[g][P]
+  const bool nn_node = b->law_kind >= ODINN_LAW_NN_Y;
+  const int base = g < 0 ? 0 : b->gd[g].tile0, nblk = g < 0 ? b->ntiles : b->gd[g].ntiles;
+  if (nn_node) CHK(ensure_theta_scratch(b, nblk));
+  ThArgs A{};
+  A.H = H; A.lam = lam; A.scales = scales;
+  A.Gacc = (b->law_kind == ODINN_LAW_NN_A_GRIDDED) ? b->d_Gacc : nullptr;
+  A.part_theta = nn_node ? b->d_part_theta : nullptr;
+  A.gscratch = nn_node ? b->d_gscratch : nullptr;
+  const Pools P = b->pools(g < 0);
+  launch_vjp_theta(b, nblk, P, b->lawdev(), A, base);
+  const int ng = g < 0 ? b->G : 1, g0 = g < 0 ? 0 : g;
+  if (nn_node)
+    launch_sum_part_theta(b->P, ng, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g0);
+  else
+    launch_sum_part(ng, b->stream, P, 2, b->d_Gsum, accumulate ? 1 : 0, g0);
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+// gridded hoisted law: dtheta = sum_nodes Gacc * dA/dtheta(T)  over dual range [lo, lo+n)
+static int gridded_law_grad(odinn_batch* b, long long lo, long long n, double* dtheta_host) {
+  const int nblk = (int)((n + NT - 1) / NT);
+  CHK(ensure_theta_scratch(b, nblk));
+  launch_law_field_grad(nblk, b->stream, b->lawdev(), b->d_Tfield + lo, b->d_Gacc + lo, n, b->d_gscratch,
+                        b->d_part_theta);
+  launch_sum_rows(b->P, b->stream, b->d_part_theta, nblk, b->d_dth);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(dtheta_host, b->d_dth, sizeof(double) * b->P, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ODINN_OK;
+}
+
+int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double* H, double t, double* dtheta, int P) {
+  (void)t;
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!H || !lam || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
+  const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
+  if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
+  CHK(refresh_gd(b)); CHK(refresh_law_field(b));
+  CHK(up_field(b, g, b->d_tmpA, H));
+  CHK(up_field(b, g, b->d_lam[0], lam));
+  const GDev& r = b->gd[g];
+  const long long nd = (long long)(r.nx - 1) * (r.ny - 1);
+  if (b->law_kind == ODINN_LAW_NN_A_GRIDDED)
+    HIPCHK(hipMemsetAsync(b->d_Gacc + r.offd, 0, nd * sizeof(double), b->stream));
+  CHK(theta_vjp_launch(b, b->d_tmpA, b->d_lam[0], nullptr, g, false));
+  if (b->law_kind >= ODINN_LAW_NN_Y) {
+    HIPCHK(hipMemcpyAsync(dtheta, b->d_dth + (size_t)g * b->P, sizeof(double) * b->P, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return ODINN_OK;
+  }
+  if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) return gridded_law_grad(b, r.offd, nd, dtheta);
+  double Gs = 0.0;
+  HIPCHK(hipMemcpyAsync(&Gs, b->d_Gsum + g, sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->law_kind == ODINN_LAW_CONST_A) { dtheta[0] = Gs; return ODINN_OK; }
+  std::vector<double> dA(b->P);
+  h_mlp(b->mlp, b->theta.data(), &b->descs[g].T, dA.data());
+  for (int k = 0; k < b->P; ++k) dtheta[k] = dA[k] * Gs;  // cartesian_tensor contraction, target_utils.jl:156-161
+  return ODINN_OK;
+}
+
+int odinn_mb_apply(odinn_batch* b, int g, const double* H, double* H_new, double* MB_applied) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!H || !H_new) return fail(ODINN_ERR_ARG, "null field");
+  CHK(refresh_gd(b));
+  CHK(up_field(b, g, b->d_tmpA, H));
+  launch_mb_apply(b->gd[g].ntiles, b->stream, b->pools(false), b->d_tmpA, b->d_mb0,
+                  b->any_sref ? b->d_Sref : nullptr, b->d_tmpB, b->d_lam[1], b->gd[g].tile0);
+  HIPCHK(hipGetLastError());
+  CHK(down_field(b, g, b->d_tmpB, H_new));
+  if (MB_applied) CHK(down_field(b, g, b->d_lam[1], MB_applied));
+  return ODINN_OK;
+}
+
+int odinn_mb_vjp_H(odinn_batch* b, int g, const double* lam, const double* H_pre, double* out) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!lam || !H_pre || !out) return fail(ODINN_ERR_ARG, "null field");
+  CHK(refresh_gd(b));
+  CHK(up_field(b, g, b->d_tmpA, H_pre));
+  CHK(up_field(b, g, b->d_lam[0], lam));
+  launch_mb_vjp(b->gd[g].ntiles, b->stream, b->pools(false), b->d_tmpA, b->d_mb0,
+                b->any_sref ? b->d_Sref : nullptr, b->d_lam[0], b->d_tmpB, 0, b->gd[g].tile0);
+  HIPCHK(hipGetLastError());
+  return down_field(b, g, b->d_tmpB, out);
+}
+
+int odinn_eval_law(odinn_batch* b, int g, const double* H, double* out, int n_out) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  CHK(refresh_gd(b)); CHK(refresh_law_field(b));
+  const GDev& r = b->gd[g];
+  const long long nd = (long long)(r.nx - 1) * (r.ny - 1);
+  const bool scalar = (b->law_kind == ODINN_LAW_NN_A_SCALAR) || (b->law_kind == ODINN_LAW_CONST_A && !r.use_Afield);
+  if (scalar) {
+    if (n_out < 1) return fail(ODINN_ERR_ARG, "n_out too small");
+    out[0] = r.A;
+    return ODINN_OK;
+  }
+  if (n_out < nd) return fail(ODINN_ERR_ARG, "n_out=%d < %lld dual nodes", n_out, nd);
+  if (!H) return fail(ODINN_ERR_ARG, "null field");
+  CHK(up_field(b, g, b->d_tmpA, H));
+  launch_eval_law(b->stream, b->pools(false), b->lawdev(), b->d_tmpA, b->d_Gacc + r.offd, g, nd);
+  HIPCHK(hipGetLastError());
+  return down_field(b, g, b->d_Gacc, out, true);
+}
+
+// ---- time loop ----------------------------------------------------------------------------
+int odinn_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times,
+                const odinn_solver_opts* opts, odinn_solve_stats* stats) {
+  if (!b || !tstops) return fail(ODINN_ERR_ARG, "null argument");
+  return do_solve(b, n_stops, tstops, n_mb, mb_times, opts, stats);
+}
+
+int odinn_get_snapshot(odinn_batch* b, int g, int istop, double* H_out) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!b->solved) return fail(ODINN_ERR_STATE, "no solve has been run");
+  if (istop < 0 || istop >= (int)b->tstops.size()) return fail(ODINN_ERR_ARG, "istop out of range");
+  return down_field(b, g, b->d_snaps + (size_t)istop * b->ntot, H_out);
+}
+
+int odinn_get_H(odinn_batch* b, int g, double* H_out) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!b->solved) return down_field(b, g, b->d_H0, H_out);
+  return down_field(b, g, b->d_snaps + (size_t)(b->tstops.size() - 1) * b->ntot, H_out);
+}
+
+int odinn_loss(odinn_batch* b, double* loss_per_glacier) {
+  if (!b || !loss_per_glacier) return fail(ODINN_ERR_ARG, "null argument");
+  CHK(use_dev(b));
+  if (!b->solved) return fail(ODINN_ERR_STATE, "no solve has been run");
+  CHK(upload_loss_tables(b));
+  CHK(do_loss(b));
+  HIPCHK(hipMemcpyAsync(loss_per_glacier, b->d_lossacc, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ODINN_OK;
+}
+
+int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+                    const double* mb_times, const odinn_solver_opts* opts, double* loss, double* dtheta,
+                    odinn_solve_stats* stats) {
+  if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
+  CHK(use_dev(b));
+  if (theta) CHK(odinn_set_theta(b, theta, P));
+  const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
+  if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
+  if (!b->d_Href) return fail(ODINN_ERR_STATE, "no reference thickness data set");
+  CHK(do_solve(b, n_stops, tstops, n_mb, mb_times, opts, stats));
+  // ---- reverse loop: gradient.jl:191-253 -------------------------------------------------
+  const int k = n_stops;
+  const bool nn_node = b->law_kind >= ODINN_LAW_NN_Y;
+  const size_t fb = (size_t)b->ntot * sizeof(double);
+  HIPCHK(hipMemsetAsync(b->d_lam[0], 0, fb, b->stream));  // lambda_k = 0   (:140)
+  HIPCHK(hipMemsetAsync(b->d_lossacc, 0, sizeof(double) * b->G, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_Gsum, 0, sizeof(double) * b->G, b->stream));
+  if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) HIPCHK(hipMemsetAsync(b->d_Gacc, 0, (size_t)b->ntotd * sizeof(double), b->stream));
+  if (nn_node) {
+    CHK(ensure_theta_scratch(b, b->ntiles));
+    HIPCHK(hipMemsetAsync(b->d_dth, 0, sizeof(double) * b->G * b->P, b->stream));
+  }
+  const Pools Psw = b->pools(true);
+  const LawDev L = b->lawdev();
+  int cur = 0;
+  for (int j = k - 1; j >= 1; --j) {
+    double* lam = b->d_lam[cur];
+    double* lam_new = b->d_lam[1 - cur];
+    const double* Hj = b->d_snaps + (size_t)j * b->ntot;
+    if (b->any_mb && b->mb_flag[j]) {  // :201-207
+      launch_mb_vjp(b->ntiles, b->stream, Psw, b->d_premb + (size_t)b->mb_slot[j] * b->ntot, b->d_mb0,
+                    b->any_sref ? b->d_Sref : nullptr, lam, lam, 1, 0);
+    }
+    AdjArgs A{};
+    A.H = Hj; A.lam = lam; A.out = lam_new; A.Href = b->d_Href; A.mask = b->d_mask;
+    A.dts = b->d_dts + (size_t)j * b->G; A.ws = b->d_ws + (size_t)j * b->G;
+    A.refslot = b->d_refslot + (size_t)j * b->G; A.ntot = b->ntot;
+    launch_vjp_H(b, 1, b->ntiles, Psw, L, A, 0);  // :235-242
+    launch_sum_part(b->G, b->stream, Psw, 1, b->d_lossacc, 1, 0);
+    CHK(theta_vjp_launch(b, Hj, lam_new, b->d_dts + (size_t)j * b->G, -1, true));  // :245-249
+    cur = 1 - cur;
+  }
+  HIPCHK(hipGetLastError());
+  if (cur != 0) HIPCHK(hipMemcpyAsync(b->d_lam[0], b->d_lam[cur], fb, hipMemcpyDeviceToDevice, b->stream));
+  // ---- aggregate over the batch's glaciers (Model.jl:208-224) ---------------------------
+  std::vector<double> lossg(b->G), Gs(b->G);
+  HIPCHK(hipMemcpyAsync(lossg.data(), b->d_lossacc, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipMemcpyAsync(Gs.data(), b->d_Gsum, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  double Ltot = 0.0;
+  for (int g = 0; g < b->G; ++g) Ltot += lossg[g];
+  *loss = Ltot;
+  for (int q = 0; q < P; ++q) dtheta[q] = 0.0;
+  if (b->law_kind == ODINN_LAW_CONST_A) {
+    for (int g = 0; g < b->G; ++g) dtheta[0] += Gs[g];
+  } else if (b->law_kind == ODINN_LAW_NN_A_SCALAR) {
+    std::vector<double> dA(b->P);
+    for (int g = 0; g < b->G; ++g) {
+      h_mlp(b->mlp, b->theta.data(), &b->descs[g].T, dA.data());
+      for (int q = 0; q < P; ++q) dtheta[q] = std::fma(dA[q], Gs[g], dtheta[q]);
+    }
+  } else if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) {
+    CHK(gridded_law_grad(b, 0, b->ntotd, dtheta));
+  } else {
+    std::vector<double> dth((size_t)b->G * b->P);
+    HIPCHK(hipMemcpy(dth.data(), b->d_dth, dth.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int g = 0; g < b->G; ++g)
+      for (int q = 0; q < P; ++q) dtheta[q] += dth[(size_t)g * b->P + q];
+  }
+  return ODINN_OK;
+}
+
+int odinn_get_lambda0(odinn_batch* b, int g, double* lam0) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  return down_field(b, g, b->d_lam[0], lam0);
+}
+
+// ---- measurement --------------------------------------------------------------------------
+int odinn_time_kernel(odinn_batch* b, int which, int warmup, int iters, double* ms_total) {
+  if (!b || !ms_total || iters <= 0) return fail(ODINN_ERR_ARG, "bad arguments");
+  CHK(use_dev(b));
+  CHK(refresh_gd(b)); CHK(refresh_law_field(b));
+  const Pools P = b->pools(true);
+  const LawDev L = b->lawdev();
+  // state: H0 in U[0]; a fixed small dt so that the RK registers stay finite
+  const size_t fb = (size_t)b->ntot * sizeof(double);
+  HIPCHK(hipMemcpyAsync(b->d_U[0], b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_S3, b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_lam[0], b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
+  std::vector<double> ts = {0.0, 1e30};
+  CHK(ensure_tables(b, 2));
+  HIPCHK(hipMemcpyAsync(b->d_tstops, ts.data(), 2 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  launch_begin(b->G, b->stream, P, b->d_tstops, 0.0, 1e-6);
+  auto one = [&](int it) -> int {
+    switch (which) {
+      case ODINN_TIMED_DHDT: return launch_dhdt(b, b->d_U[0], b->d_tmpB, -1);
+      case ODINN_TIMED_RK_STEP: return launch_step(b, it & 1, 1e-6, 1e-8);
+      case ODINN_TIMED_RK_STAGE2: launch_stage<2>(b, P, L, b->d_U[0], b->d_U[1], 1e-6, 1e-8); return ODINN_OK;
+      case ODINN_TIMED_VJP_H: {
+        AdjArgs A{};
+        A.H = b->d_U[0]; A.lam = b->d_lam[0]; A.out = b->d_tmpB;
+        launch_vjp_H(b, 0, b->ntiles, P, L, A, 0);
+        return ODINN_OK;
+      }
+      case ODINN_TIMED_VJP_THETA: return theta_vjp_launch(b, b->d_U[0], b->d_lam[0], nullptr, -1, false);
+      default: return fail(ODINN_ERR_ARG, "unknown timed kernel %d", which);
+    }
+  };
+  for (int i = 0; i < warmup; ++i) CHK(one(i));
+  HIPCHK(hipEventRecord(b->ev0, b->stream));
+  for (int i = 0; i < iters; ++i) CHK(one(i));
+  HIPCHK(hipEventRecord(b->ev1, b->stream));
+  HIPCHK(hipEventSynchronize(b->ev1));
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+  *ms_total = ms;
+  return ODINN_OK;
+}
+
+}  // extern "C"

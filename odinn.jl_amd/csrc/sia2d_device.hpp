@@ -1,0 +1,1237 @@
+// sia2d_device.hpp -- CDNA4 (gfx950) device code of the SIA2D(+NN_theta) hot path.
+//
+// What is computed is ODINN.jl's SIA2D right-hand side and its hand-written discrete
+// adjoint (reference: src/inverse/SIA2D/adjoint.jl:52-151,199-252 and the staggered
+// transposes of src/inverse/SIA2D/inversion_utils.jl:3-66).  How it is computed is
+// not a translation of that allocation-per-operator Julia code:
+//
+//   * one fused kernel per RHS evaluation / RK stage / VJP: a 64x16-cell tile (+1 halo)
+//     of H and S=B+max(H,0) is staged once through LDS with coalesced 512-B row loads;
+//     every dual-grid quantity (grad S, Hbar, D, and for the adjoint alpha*Da,
+//     beta*gradS*Da) is evaluated ONCE per dual node into LDS -- a node depends only on
+//     its own 2x2 corner cells -- and every primal cell then gathers from its 4 nodes
+//     and its 5-point neighbourhood.  All transposes are written in gather form, so the
+//     adjoint needs no atomics and is bitwise deterministic.
+//   * all glaciers of a batch run in ONE launch: a tile table maps blockIdx -> (glacier,
+//     tile), XCD-swizzled so that the tiles one XCD's L2 sees form a contiguous band.
+//   * the adaptive time loop (RDPK3Sp35 3S*+ registers, embedded error norm, PID step
+//     controller, tstops, mass-balance source, snapshots) lives on the device: stage
+//     kernels read dt / accept flags from a per-glacier state record, block partial sums
+//     of the error norm are combined in a fixed order by a one-block-per-glacier
+//     controller kernel; the host only polls an "active glaciers" counter per chunk.
+//
+// Layout: element [i,j] of an nx*ny field at i + nx*j (i = x contiguous, as in Julia).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace odinn {
+
+constexpr int TX = 64;         // tile width  (x, contiguous)  = one wavefront
+constexpr int TY = 16;         // tile height (y)
+constexpr int NT = 256;        // threads per block (4 wavefronts)
+constexpr int NW = NT / 64;    // wavefronts per block
+constexpr int RPT = TY / NW;   // rows per thread
+constexpr int LDW = TX + 2;    // LDS row stride of cell tiles (with halo)
+constexpr int LDN = TX + 1;    // LDS row stride of node tiles
+constexpr int NNODE = (TX + 1) * (TY + 1);
+constexpr int MAXP = 2048;     // max #theta supported by the in-kernel reductions
+constexpr int MAXL = 8;        // max Dense layers
+
+// ---- RDPK3Sp35 (Ranocha, Dalcin, Parsani, Ketcheson 2022), 3S*+ form ---------------
+constexpr double c_g1[5] = {0.0, 2.587771979725733308135192812685323706e-01,
+                                          -1.324380360140723382965420909764953437e-01,
+                                          5.056033948190826045833606441415585735e-02,
+                                          5.670532000739313812633197158607642990e-01};
+constexpr double c_g2[5] = {1.0, 5.528354909301389892439698870483746541e-01,
+                                          6.731871608203061824849561782794643600e-01,
+                                          2.803103963297672407841316576323901761e-01,
+                                          5.521525447020610386070346724931300367e-01};
+constexpr double c_g3[5] = {0.0, 0.0, 0.0, 2.752563273304676380891217287572780582e-01,
+                                          -8.950526174674033822276061734289327568e-01};
+constexpr double c_dl[5] = {1.0, 3.407655879334525365094815965895763636e-01,
+                                          3.414382655003386206551709871126405331e-01,
+                                          7.229275366787987419692007421895451953e-01, 0.0};
+constexpr double c_bt[5] = {2.300298624518076223899418286314123354e-01,
+                                          3.021434166948288809034402119555380003e-01,
+                                          8.025606185416310937583009085873554681e-01,
+                                          4.362158943603440930655148245148766471e-01,
+                                          1.129272530455059129782111662594436580e-01};
+constexpr double c_bh[5] = {1.046363371354093758897668305991705199e-01,
+                                          9.520431574956758809511173383346476348e-02,
+                                          4.482446645568668405072421350300379357e-01,
+                                          2.449030295461310135957132640369862245e-01,
+                                          1.070116530120251819121660365003405564e-01};
+
+// ---- records living in device memory ------------------------------------------------
+struct GDev {  // per-glacier constants
+  int nx, ny, ntx, nty, tile0, ntiles;
+  long long off;   // offset of this glacier in the pooled primal arrays  [doubles]
+  long long offd;  // offset in the pooled dual arrays
+  double dx, dy, inv_dx, inv_dy, eta0;
+  double A;        // scalar creep coefficient in use (CONST_A or hoisted NN_A_SCALAR)
+  double Gam;      // 2 (rho g)^n / (n+2)      target_utils.jl:3-12
+  double Sc;       // C (rho g)^(p-q)          target_utils.jl:14-18
+  double n, p, q, T, nH, nS;
+  double minA, maxA;
+  int fast;        // n == 3 && Sc == 0 -> integer-power path, no sqrt/pow
+  int use_Afield;  // A read from the dual-grid field
+  int has_mb;
+  double dmb_dS, mb_max;
+};
+
+struct GState {  // per-glacier integrator state (written by the controller kernel)
+  double t, dt, e2, e3, EEst;
+  int accepted;   // last step accepted -> stage 1 reads the new state, else S3 (uprev)
+  int at_stop;    // the accepted step landed on tstops[istop-1]: post-step must run
+  int mb_now;     // ... and the mass balance is applied there
+  int mb_slot;    // index into the pre-MB snapshot store
+  int done, istop, clipped, cur;  // cur: which ping-pong buffer holds the accepted state
+  long long naccept, nreject;
+  int nonfinite;
+  int pad;
+};
+
+struct LawDev {  // passed by value to kernels
+  int kind, n_layers, has_pre, post_kind, P, maxw;
+  int widths[9];
+  int acts[8];
+  double pre_lo[2], pre_inv[2];
+  double post_lo, post_hi;
+  const double* theta;  // device
+};
+
+struct Pools {  // pooled device arrays (all glaciers concatenated)
+  const int4* tiles;
+  const GDev* gd;
+  GState* gs;
+  const double* B;
+  const double* Afield;  // dual
+  double* part;          // block partial sums, 4 doubles per tile
+};
+
+// ---- small helpers ------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+// deterministic block sum; result valid in thread 0.  red: LDS scratch of NW doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) s += red[k];
+  }
+  return s;
+}
+
+__device__ __forceinline__ double act_f(int code, double x) {
+  switch (code) {
+    case 1: return log1p(exp(-fabs(x))) + fmax(x, 0.0);                 // NNlib.softplus
+    case 2: { double t = exp(-fabs(x)); return x >= 0.0 ? 1.0 / (1.0 + t) : t / (1.0 + t); }
+    case 3: { const double c = 0.7978845608028654; return 0.5 * x * (1.0 + tanh(c * (x + 0.044715 * x * x * x))); }
+    case 4: return tanh(x);
+    case 5: return fmax(x, 0.0);
+    default: return x;
+  }
+}
+__device__ __forceinline__ double dact_f(int code, double x) {
+  switch (code) {
+    case 1: { double t = exp(-fabs(x)); return x >= 0.0 ? 1.0 / (1.0 + t) : t / (1.0 + t); }
+    case 2: { double t = exp(-fabs(x)); double s = x >= 0.0 ? 1.0 / (1.0 + t) : t / (1.0 + t); return s * (1.0 - s); }
+    case 3: { const double c = 0.7978845608028654; double u = c * (x + 0.044715 * x * x * x); double th = tanh(u);
+              double du = c * (1.0 + 3.0 * 0.044715 * x * x); return 0.5 * (1.0 + th) + 0.5 * x * (1.0 - th * th) * du; }
+    case 4: { double th = tanh(x); return 1.0 - th * th; }
+    case 5: return x > 0.0 ? 1.0 : 0.0;
+    default: return 1.0;
+  }
+}
+__device__ __forceinline__ double postscale_f(const LawDev& L, double y) {
+  switch (L.post_kind) {
+    case 1: return L.post_lo + (L.post_hi - L.post_lo) * y;
+    case 2: return L.post_hi * exp((y - 1.0) / y);
+    case 3: return L.post_hi * y;
+    default: return y;
+  }
+}
+__device__ __forceinline__ double dpostscale_f(const LawDev& L, double y) {
+  switch (L.post_kind) {
+    case 1: return L.post_hi - L.post_lo;
+    case 2: return L.post_hi * exp((y - 1.0) / y) / (y * y);
+    case 3: return L.post_hi;
+    default: return 1.0;
+  }
+}
+
+// Per-lane MLP evaluation (_pred_NN, src/laws/Laws.jl:34-36).  Weights are read with
+// wave-uniform indices (scalar loads through the constant cache); activations live in
+// registers: every index is a compile-time constant, widths are applied as uniform
+// predicates.
+template <int MAXW>
+__device__ __noinline__ double mlp_eval(const LawDev& L, double x0, double x1) {
+  double h[MAXW];
+#pragma unroll
+  for (int i = 0; i < MAXW; ++i) h[i] = 0.0;
+  h[0] = L.has_pre ? (x0 - L.pre_lo[0]) * L.pre_inv[0] - 0.5 : x0;
+  if (MAXW > 1 && L.widths[0] > 1) h[1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
+  const double* __restrict__ th = L.theta;
+  int off = 0;
+  for (int l = 0; l < L.n_layers; ++l) {
+    const int nin = L.widths[l], nout = L.widths[l + 1], a = L.acts[l];
+    double z[MAXW];
+#pragma unroll
+    for (int o = 0; o < MAXW; ++o) {
+      z[o] = 0.0;
+      if (o < nout) {
+        double acc = th[off + nin * nout + o];
+#pragma unroll
+        for (int i = 0; i < MAXW; ++i)
+          if (i < nin) acc = fma(th[off + o + nout * i], h[i], acc);
+        z[o] = act_f(a, acc);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < MAXW; ++o) h[o] = z[o];
+    off += nout * (nin + 1);
+  }
+  return postscale_f(L, h[0]);
+}
+
+// wide nets (17..32 units): activations in scratch, plain loops (rare, slow path)
+inline __device__ __noinline__ double mlp_eval_wide(const LawDev& L, double x0, double x1) {
+  double h[32], z[32];
+  h[0] = L.has_pre ? (x0 - L.pre_lo[0]) * L.pre_inv[0] - 0.5 : x0;
+  h[1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
+  const double* __restrict__ th = L.theta;
+  int off = 0;
+  for (int l = 0; l < L.n_layers; ++l) {
+    const int nin = L.widths[l], nout = L.widths[l + 1], a = L.acts[l];
+    for (int o = 0; o < nout; ++o) {
+      double acc = th[off + nin * nout + o];
+      for (int i = 0; i < nin; ++i) acc = fma(th[off + o + nout * i], h[i], acc);
+      z[o] = act_f(a, acc);
+    }
+    for (int o = 0; o < nout; ++o) h[o] = z[o];
+    off += nout * (nin + 1);
+  }
+  return postscale_f(L, h[0]);
+}
+
+__device__ __forceinline__ double mlp_eval_any(const LawDev& L, double x0, double x1) {
+  if (L.maxw <= 4) return mlp_eval<4>(L, x0, x1);
+  if (L.maxw <= 16) return mlp_eval<16>(L, x0, x1);
+  return mlp_eval_wide(L, x0, x1);
+}
+
+// g[k*stride] += wgt * d out / d theta_k at one input (exact backprop; stands in for the
+// Zygote/Mooncake pass of src/laws/auto_VJP.jl:114-122).  `g` is a thread-private
+// accumulator in global memory laid out g[k*stride] so that a wavefront's accesses coalesce.
+inline __device__ __noinline__ void mlp_grad(const LawDev& L, double x0, double x1, double wgt, double* g, long long stride) {
+  constexpr int MAXW = 32;
+  double hs[MAXL + 1][MAXW];
+  double zs[MAXL][MAXW];
+  const double* __restrict__ th = L.theta;
+  hs[0][0] = L.has_pre ? (x0 - L.pre_lo[0]) * L.pre_inv[0] - 0.5 : x0;
+  hs[0][1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
+  int offs[MAXL + 1];
+  offs[0] = 0;
+  for (int l = 0; l < L.n_layers; ++l) {
+    const int nin = L.widths[l], nout = L.widths[l + 1], a = L.acts[l];
+    const int off = offs[l];
+    for (int o = 0; o < nout; ++o) {
+      double acc = th[off + nin * nout + o];
+      for (int i = 0; i < nin; ++i) acc = fma(th[off + o + nout * i], hs[l][i], acc);
+      zs[l][o] = acc;
+      hs[l + 1][o] = act_f(a, acc);
+    }
+    offs[l + 1] = off + nout * (nin + 1);
+  }
+  double gv[MAXW], gn[MAXW];
+  gv[0] = wgt * dpostscale_f(L, hs[L.n_layers][0]);
+  for (int l = L.n_layers - 1; l >= 0; --l) {
+    const int nin = L.widths[l], nout = L.widths[l + 1], a = L.acts[l];
+    const int off = offs[l];
+    for (int i = 0; i < nin; ++i) gn[i] = 0.0;
+    for (int o = 0; o < nout; ++o) {
+      const double dz = gv[o] * dact_f(a, zs[l][o]);
+      g[(long long)(off + nin * nout + o) * stride] += dz;
+      for (int i = 0; i < nin; ++i) {
+        g[(long long)(off + o + nout * i) * stride] += dz * hs[l][i];
+        gn[i] = fma(th[off + o + nout * i], dz, gn[i]);
+      }
+    }
+    for (int i = 0; i < nin; ++i) gv[i] = gn[i];
+  }
+}
+
+// ---- diffusivity on one dual node ---------------------------------------------------
+// Returns D.  For the adjoint (ADJ) also alpha = dD/dHbar and beta (the reference's
+// "dD/dgradH", i.e. (dD/d|gradS|)/|gradS| for the closed forms) -- target_A.jl:16-62,
+// target_D_hybrid.jl:22-96,168-208, target_D_pure.jl:78-137 -- and `spat`, the spatial
+// factor of dD/dtheta (target_A.jl:71-72, target_D_hybrid.jl:117-118, target_D_pure.jl:142).
+constexpr int LM_FAST = 0, LM_POW = 1, LM_NN = 2;
+template <bool ADJ, int LM>
+__device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double Hb, double gS2, double Anode,
+                                         double& alpha, double& beta, double& spat) {
+  if (LM != LM_NN) {  // A-type laws (scalar or field A)
+    if (LM == LM_FAST) {
+      const double H2 = Hb * Hb, H4 = H2 * H2;
+      const double AG = Anode * g.Gam;
+      const double H5 = H4 * Hb;
+      if (ADJ) {
+        alpha = AG * 5.0 * H4 * gS2;
+        beta = AG * 2.0 * H5;  // (n-1) * gradS^(n-3), 0^0 = 1
+        spat = g.Gam * H5 * gS2;
+      }
+      return AG * H5 * gS2;
+    }
+    const double gS = sqrt(gS2);
+    const double hn2 = pow(Hb, g.n + 2.0), sn1 = pow(gS, g.n - 1.0);
+    double D = Anode * g.Gam * hn2 * sn1;
+    double hs = 0.0, sp1 = 0.0;
+    if (g.Sc != 0.0) {
+      hs = pow(Hb, g.p - g.q + 1.0);
+      sp1 = pow(gS, g.p - 1.0);
+      D += g.Sc * hs * sp1;
+    }
+    if (ADJ) {
+      alpha = Anode * g.Gam * (g.n + 2.0) * pow(Hb, g.n + 1.0) * sn1;
+      beta = Anode * g.Gam * (g.n - 1.0) * hn2 * pow(gS, g.n - 3.0);
+      if (g.Sc != 0.0) {
+        alpha += (g.p - g.q + 1.0) * g.Sc * pow(Hb, g.p - g.q) * sp1;
+        beta += g.Sc * (g.p - 1.0) * hs * pow(gS, g.p - 3.0);
+      }
+      spat = g.Gam * hn2 * sn1;
+    }
+    return D;
+  }
+  const double gS = sqrt(gS2);
+  if (L.kind == 3) {  // Y law, :D_hybrid
+    const double Y = mlp_eval_any(L, g.T, Hb);
+    const double geo = g.Gam * pow(Hb, g.nH + 2.0) * pow(gS, g.nS - 1.0);
+    double D = Y * geo;
+    double hs = 0.0, sp1 = 0.0;
+    if (g.Sc != 0.0) {
+      hs = pow(Hb, g.p - g.q + 1.0);
+      sp1 = pow(gS, g.p - 1.0);
+      D += g.Sc * hs * sp1;
+    }
+    if (ADJ) {
+      const double dH = 1e-4;  // target_D_hybrid.jl:58
+      const double Yp = mlp_eval_any(L, g.T, Hb + dH);
+      const double slide = g.Sc != 0.0 ? g.Sc * hs * sp1 : 0.0;
+      alpha = (g.nH + 2.0) * Y * g.Gam * pow(Hb, g.nH + 1.0) * pow(gS, g.nS - 1.0) +
+              ((slide + Yp * geo) - (slide + Y * geo)) / dH;
+      beta = g.Gam * Y * (g.nS - 1.0) * pow(Hb, g.nH + 2.0) * pow(gS, g.nS - 3.0);
+      if (g.Sc != 0.0) {
+        alpha += (g.p - g.q + 1.0) * g.Sc * pow(Hb, g.p - g.q) * sp1;
+        beta += g.Sc * (g.p - 1.0) * hs * pow(gS, g.p - 3.0);
+      }
+      spat = geo;
+    }
+    return D;
+  }
+  // U law, :D   D = Hbar * U(Hbar, gradS)
+  const double U = mlp_eval_any(L, Hb, gS);
+  if (ADJ) {
+    const double dH = 1e-4, dS = 1e-6;  // target_D_pure.jl:109,125
+    const double Dp = mlp_eval_any(L, Hb + dH, gS) * (Hb + dH);
+    const double Dm = mlp_eval_any(L, Hb - dH, gS) * (Hb - dH);
+    alpha = Hb > 0.0 ? (Dp - Dm) / (2.0 * dH) : 0.0;
+    const double Ep = mlp_eval_any(L, Hb, gS + dS) * Hb;
+    const double Em = mlp_eval_any(L, Hb, gS - dS) * Hb;
+    beta = (Ep - Em) / (2.0 * dS);
+    spat = Hb > 0.0 ? Hb : 0.0;
+  }
+  return Hb * U;
+}
+
+// ---- tile geometry -------------------------------------------------------------------
+// Load the (TX+2)x(TY+2) halo tile of src (clamped at 0) and S = B + max(src,0) into LDS.
+// Thread (tx, ty) owns interior rows r = 1 + ty + NW*m and keeps their raw values in own[].
+__device__ __forceinline__ void load_tile_HS(const double* __restrict__ U, const double* __restrict__ B, const GDev& g,
+                                             int i0, int j0, double (*sH)[LDW], double (*sS)[LDW],
+                                             double own[RPT]) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  const bool colok = gi < g.nx;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m;
+    const int gj = j0 - 1 + r;
+    double h = 0.0, b = 0.0;
+    if (colok && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      h = U[id];
+      b = B[id];
+    }
+    own[m] = h;
+    const double hc = h > 0.0 ? h : 0.0;
+    sH[r][tx + 1] = hc;
+    sS[r][tx + 1] = b + hc;
+  }
+  // halo rows 0 and TY+1 (waves 0 and 1), halo columns 0 and TX+1 (waves 2 and 3)
+  if (ty < 2) {
+    const int r = ty == 0 ? 0 : TY + 1;
+    const int gj = j0 - 1 + r;
+    double h = 0.0, b = 0.0;
+    if (colok && gj >= 0 && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      h = U[id];
+      b = B[id];
+    }
+    const double hc = h > 0.0 ? h : 0.0;
+    sH[r][tx + 1] = hc;
+    sS[r][tx + 1] = b + hc;
+  } else {
+    const int l = threadIdx.x - 128;  // 0..127
+    if (l < 2 * (TY + 2)) {
+      const int r = l >> 1, side = l & 1;
+      const int c = side ? TX + 1 : 0;
+      const int gi2 = i0 - 1 + c, gj = j0 - 1 + r;
+      double h = 0.0, b = 0.0;
+      if (gi2 >= 0 && gi2 < g.nx && gj >= 0 && gj < g.ny) {
+        const long long id = g.off + gi2 + (long long)g.nx * gj;
+        h = U[id];
+        b = B[id];
+      }
+      const double hc = h > 0.0 ? h : 0.0;
+      sH[r][c] = hc;
+      sS[r][c] = b + hc;
+    }
+  }
+}
+
+// Same for a third field kept unclamped and masked to the interior (lambda~).
+__device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, const GDev& g, int i0, int j0,
+                                              double (*sL)[LDW], double own[RPT]) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  auto ld = [&](int gi_, int gj_, double& raw) -> double {
+    raw = 0.0;
+    if (gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny) {
+      raw = Lm[g.off + gi_ + (long long)g.nx * gj_];
+      if (gi_ >= 1 && gi_ <= g.nx - 2 && gj_ >= 1 && gj_ <= g.ny - 2) return raw;
+    }
+    return 0.0;
+  };
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m;
+    sL[r][tx + 1] = ld(gi, j0 - 1 + r, own[m]);
+  }
+  double dummy;
+  if (ty < 2) {
+    const int r = ty == 0 ? 0 : TY + 1;
+    sL[r][tx + 1] = ld(gi, j0 - 1 + r, dummy);
+  } else {
+    const int l = threadIdx.x - 128;
+    if (l < 2 * (TY + 2)) {
+      const int r = l >> 1, c = (l & 1) ? TX + 1 : 0;
+      sL[r][c] = ld(i0 - 1 + c, j0 - 1 + r, dummy);
+    }
+  }
+}
+
+// D on every dual node of the tile -> sD (0 on nodes outside the glacier's dual grid).
+template <int LM>
+__device__ __forceinline__ void nodes_forward(const GDev& g, const LawDev& L, const double* __restrict__ Afield, int i0,
+                                              int j0, const double (*sH)[LDW], const double (*sS)[LDW],
+                                              double (*sD)[LDN]) {
+  for (int idx = threadIdx.x; idx < NNODE; idx += NT) {
+    const int b = idx / (TX + 1), a = idx - b * (TX + 1);
+    const int gi = i0 - 1 + a, gj = j0 - 1 + b;
+    double D = 0.0;
+    if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
+      const double s00 = sS[b][a], s10 = sS[b][a + 1], s01 = sS[b + 1][a], s11 = sS[b + 1][a + 1];
+      const double gx = 0.5 * ((s10 - s00) * g.inv_dx + (s11 - s01) * g.inv_dx);
+      const double gy = 0.5 * ((s01 - s00) * g.inv_dy + (s11 - s10) * g.inv_dy);
+      const double Hb = 0.25 * (sH[b][a] + sH[b][a + 1] + sH[b + 1][a] + sH[b + 1][a + 1]);
+      const double gS2 = gx * gx + gy * gy;
+      double An = g.A;
+      if (g.use_Afield) An = Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+      double al, be, sp;
+      D = node_D<false, LM>(g, L, Hb, gS2, An, al, be, sp);
+    }
+    sD[b][a] = D;
+  }
+}
+
+__device__ __forceinline__ double clampf(double e, double up, double lo) { return fmax(fmin(e, up), lo); }
+
+// dH/dt of the cell at halo coordinates (c, r); caller guarantees the cell is interior.
+__device__ __forceinline__ double cell_rhs(const GDev& g, int c, int r, const double (*sH)[LDW],
+                                           const double (*sS)[LDW], const double (*sD)[LDN]) {
+  const double S0 = sS[r][c], H0 = sH[r][c];
+  const double ex = g.eta0 * g.inv_dx, ey = g.eta0 * g.inv_dy;
+  const double Dsw = sD[r - 1][c - 1], Dse = sD[r - 1][c], Dnw = sD[r][c - 1], Dne = sD[r][c];
+  const double He = sH[r][c + 1], Hw = sH[r][c - 1], Hn = sH[r + 1][c], Hs = sH[r - 1][c];
+  const double e_e = clampf((sS[r][c + 1] - S0) * g.inv_dx, (g.eta0 * He) * g.inv_dx, -(g.eta0 * H0) * g.inv_dx);
+  const double e_w = clampf((S0 - sS[r][c - 1]) * g.inv_dx, (g.eta0 * H0) * g.inv_dx, -(g.eta0 * Hw) * g.inv_dx);
+  const double e_n = clampf((sS[r + 1][c] - S0) * g.inv_dy, (g.eta0 * Hn) * g.inv_dy, -(g.eta0 * H0) * g.inv_dy);
+  const double e_s = clampf((S0 - sS[r - 1][c]) * g.inv_dy, (g.eta0 * H0) * g.inv_dy, -(g.eta0 * Hs) * g.inv_dy);
+  (void)ex; (void)ey;
+  const double Fe = -(0.5 * (Dse + Dne)) * e_e;
+  const double Fw = -(0.5 * (Dsw + Dnw)) * e_w;
+  const double Fn = -(0.5 * (Dnw + Dne)) * e_n;
+  const double Fs = -(0.5 * (Dsw + Dse)) * e_s;
+  return -((Fe - Fw) * g.inv_dx + (Fn - Fs) * g.inv_dy);
+}
+
+// =====================================================================================
+// K1: RHS only.  dH = SIA2D(H)   (Huginn.SIA2D!, restated from adjoint.jl:52-97)
+// =====================================================================================
+template <int LM>
+__global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __restrict__ U, double* __restrict__ dH,
+                                             int tile_base) {
+  __shared__ double sH[TY + 2][LDW];
+  __shared__ double sS[TY + 2][LDW];
+  __shared__ double sD[TY + 1][LDN];
+  const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  double own[RPT];
+  load_tile_HS(U, P.B, g, i0, j0, sH, sS, own);
+  __syncthreads();
+  nodes_forward<LM>(g, L, P.Afield, i0, j0, sH, sS, sD);
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+    if (gi < g.nx && gj < g.ny) {
+      double k = 0.0;
+      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs(g, tx + 1, r, sH, sS, sD);
+      dH[g.off + gi + (long long)g.nx * gj] = k;
+    }
+  }
+}
+
+// =====================================================================================
+// K2: one fused RDPK3Sp35 stage (RHS + 3S*+ register update + embedded-error partial).
+//   tmp (S2), uprev (S3), utilde (E); u ping-pongs between Usrc and Udst.
+//   stage 1 : reads X = accepted ? Ucur : S3 ; writes Udst, S3 (<- X), E
+//   stage 2 : tmp_old == uprev (never stored by stage 1); writes Udst, S2, E
+//   stage 3 : reads S2, E           ; writes Udst, S2, E
+//   stage 4 : reads S2, S3, E       ; writes Udst, S2, E
+//   stage 5 : reads S2, S3, E       ; writes Udst ; error partial -> part[4*tile]
+// =====================================================================================
+template <int STAGE, int LM>
+__global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double* __restrict__ Usrc,
+                                                 double* __restrict__ Udst, double* __restrict__ S2,
+                                                 double* __restrict__ S3, double* __restrict__ E, double abstol,
+                                                 double reltol) {
+  __shared__ double sH[TY + 2][LDW];
+  __shared__ double sS[TY + 2][LDW];
+  __shared__ double sD[TY + 1][LDN];
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  if (gs->done) return;
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const double dt = gs->dt;
+  const double* __restrict__ X = Usrc;
+  if (STAGE == 1 && !gs->accepted) X = S3;  // rejected step: restart from uprev
+  double own[RPT];
+  load_tile_HS(X, P.B, g, i0, j0, sH, sS, own);
+  __syncthreads();
+  nodes_forward<LM>(g, L, P.Afield, i0, j0, sH, sS, sD);
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  constexpr int s = STAGE - 1;
+  constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
+  double errsq = 0.0;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      double k = 0.0;
+      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs(g, tx + 1, r, sH, sS, sD);
+      const double u = own[m];
+      const double dtk = dt * k;
+      if (STAGE == 1) {
+        Udst[id] = fma(bt, dtk, u);
+        if (gs->accepted) S3[id] = u;
+        E[id] = bh * dtk;
+      } else {
+        const double up = (STAGE == 2 || STAGE >= 4) ? S3[id] : 0.0;
+        const double tmp_old = (STAGE == 2) ? up : S2[id];
+        const double tmp = fma(dl, u, tmp_old);
+        double un = fma(g1, u, g2 * tmp);
+        if (STAGE >= 4) un = fma(g3, up, un);
+        un = fma(bt, dtk, un);
+        Udst[id] = un;
+        const double e = fma(bh, dtk, E[id]);
+        if (STAGE < 5) {
+          if (STAGE < 5 && dl != 0.0) S2[id] = tmp;
+          E[id] = e;
+        } else {
+          const double err = (un - up) - e;
+          const double sk = abstol + fmax(fabs(up), fabs(un)) * reltol;
+          const double q = err / sk;
+          errsq = fma(q, q, errsq);
+        }
+      }
+    }
+  }
+  if (STAGE == 5) {
+    const double tot = block_sum(errsq, red);
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w] = tot;
+  }
+}
+
+// controller: one block (64 threads) per glacier.  Sums the error partials in a fixed
+// order, applies the PID controller (beta = 0.64,-0.31,0.04; limiter 1+atan(x-1);
+// accept iff factor >= 0.81), advances t / tstops, and proposes the next dt.
+struct CtrlArgs {
+  const double* tstops;
+  int n_stops;
+  const int* mb_flag;  // per stop: 1 if the mass balance is applied there
+  const int* mb_slot;  // per stop: index of the pre-MB snapshot
+  double dtmax;
+  int adaptive;
+  double fixed_dt;
+  int* n_active;
+  int next_cur;  // ping-pong buffer that holds u_new of this step
+};
+
+#ifdef ODINN_MISC_KERNELS
+__global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
+  const int gidx = blockIdx.x;
+  GState* gs = P.gs + gidx;
+  if (gs->done) {
+    if (threadIdx.x == 0) gs->at_stop = 0;  // its final post-step already ran
+    return;
+  }
+  const GDev g = P.gd[gidx];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < g.ntiles; k += 64) s += P.part[4 * (long long)(g.tile0 + k)];
+  // fixed-shape tree: lane l holds sum of tiles l, l+64, ... ; then butterfly
+  s = wave_sum(s);
+  if (threadIdx.x != 0) return;
+  const double h = gs->dt;
+  double fac = 1.0;
+  bool accept = true;
+  if (C.adaptive) {
+    double EEst = sqrt(s / ((double)g.nx * (double)g.ny));
+    if (!(EEst == EEst) || isinf(EEst)) { gs->nonfinite = 1; EEst = 1e300; }
+    if (EEst < 2.220446049250313e-16) EEst = 2.220446049250313e-16;
+    gs->EEst = EEst;
+    const double e1 = 1.0 / EEst;
+    fac = pow(e1, 0.64 / 3.0) * pow(gs->e2, -0.31 / 3.0) * pow(gs->e3, 0.04 / 3.0);
+    fac = 1.0 + atan(fac - 1.0);
+    accept = fac >= 0.81;
+    if (accept) { gs->e3 = gs->e2; gs->e2 = e1; }
+  }
+  double t = gs->t;
+  gs->at_stop = 0;
+  gs->mb_now = 0;
+  if (accept) {
+    gs->naccept++;
+    gs->accepted = 1;
+    gs->cur = C.next_cur;
+    if (gs->clipped) {
+      t = C.tstops[gs->istop];
+      gs->at_stop = 1;
+      gs->mb_now = C.mb_flag[gs->istop];
+      gs->mb_slot = C.mb_slot[gs->istop];
+      gs->istop++;
+    } else {
+      t += h;
+    }
+    gs->t = t;
+  } else {
+    gs->nreject++;
+    gs->accepted = 0;
+  }
+  if (gs->istop >= C.n_stops) {
+    gs->done = 1;
+    atomicSub(C.n_active, 1);
+    return;
+  }
+  double dtn = C.adaptive ? h * fac : C.fixed_dt;
+  if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
+  const double rem = C.tstops[gs->istop] - t;
+  // snap to the stop when the step would end within 100 ulp of it
+  if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
+    dtn = rem;
+    gs->clipped = 1;
+  } else {
+    gs->clipped = 0;
+  }
+  gs->dt = dtn;
+}
+
+#endif  // ODINN_MISC_KERNELS
+
+// post-step: at a tstop, apply the mass balance in place (VJPs.jl:129-139) and store the
+// snapshot (and the pre-MB state for the adjoint).  Pointwise; no-op for glaciers not at a stop.
+struct PostArgs {
+  double* snaps;           // [n_stops][Ntot]
+  double* premb;           // [n_mb][Ntot]
+  long long ntot;
+  const double* mb0;       // pooled
+  const double* Sref;      // pooled (may be null)
+};
+
+__device__ __forceinline__ double mb_value(const GDev& g, double mb0, double sref, double H, double B, double& dmb) {
+  double raw = mb0;
+  dmb = 0.0;
+  if (g.dmb_dS != 0.0) {
+    raw = mb0 + g.dmb_dS * ((B + H) - sref);
+    dmb = g.dmb_dS;
+    if (raw >= g.mb_max) { raw = g.mb_max; dmb = 0.0; }
+  }
+  return raw;
+}
+
+#ifdef ODINN_MISC_KERNELS
+__global__ __launch_bounds__(NT) void k_poststep(Pools P, PostArgs A, double* __restrict__ Ua, double* __restrict__ Ub) {
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  if (!gs->at_stop) return;
+  const GDev g = P.gd[t4.x];
+  double* __restrict__ U = gs->cur ? Ub : Ua;
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  const int slot = gs->istop - 1;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = j0 + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      double h = U[id];
+      if (gs->mb_now && g.has_mb) {
+        A.premb[(long long)gs->mb_slot * A.ntot + id] = h;
+        double dmb;
+        double mb = mb_value(g, A.mb0[id], A.Sref ? A.Sref[id] : 0.0, h, P.B[id], dmb);
+        const bool mask = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
+        if (!mask) mb = 0.0;
+        if (mask && h + mb < 0.0) mb = -h;
+        h += mb;
+        U[id] = h;
+      }
+      A.snaps[(long long)slot * A.ntot + id] = h;
+    }
+  }
+}
+
+#endif  // ODINN_MISC_KERNELS
+
+// =====================================================================================
+// K5: discrete H-VJP (adjoint.jl:99-148) in gather form, optionally fused with the
+// reverse explicit-Euler update of gradient.jl:242:
+//     out = lam + dt * J_H(H)^T lam + w * 2*mask*(H - Href)/N          (MODE 1)
+//     out = J_H(H)^T lam                                               (MODE 0)
+// and the masked L2 loss partial (Losses.jl:133-141) as a by-product in MODE 1.
+// =====================================================================================
+struct AdjArgs {
+  const double* H;     // snapshot (pooled)
+  const double* lam;   // pooled
+  double* out;         // pooled
+  const double* Href;  // pooled references [slot][ntot] or null
+  const unsigned char* mask;  // pooled masks [slot][ntot] or null
+  const double* dts;   // per-glacier dt (device) or null
+  const double* ws;    // per-glacier loss weight (device) or null
+  const int* refslot;  // per-glacier reference slot for this stop
+  long long ntot;
+};
+
+template <int MODE, int LM>
+__global__ __launch_bounds__(NT) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
+  __shared__ double sH[TY + 2][LDW];
+  __shared__ double sS[TY + 2][LDW];
+  __shared__ double sL[TY + 2][LDW];
+  __shared__ double sD[TY + 1][LDN];
+  __shared__ double sAD[TY + 1][LDN];
+  __shared__ double sBX[TY + 1][LDN];
+  __shared__ double sBY[TY + 1][LDN];
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  double ownH[RPT], ownL[RPT];
+  load_tile_HS(A.H, P.B, g, i0, j0, sH, sS, ownH);
+  load_tile_lam(A.lam, g, i0, j0, sL, ownL);
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NNODE; idx += NT) {
+    const int b = idx / (TX + 1), a = idx - b * (TX + 1);
+    const int gi = i0 - 1 + a, gj = j0 - 1 + b;
+    double D = 0.0, AD = 0.0, BX = 0.0, BY = 0.0;
+    if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
+      const double s00 = sS[b][a], s10 = sS[b][a + 1], s01 = sS[b + 1][a], s11 = sS[b + 1][a + 1];
+      const double h00 = sH[b][a], h10 = sH[b][a + 1], h01 = sH[b + 1][a], h11 = sH[b + 1][a + 1];
+      const double exl = (s10 - s00) * g.inv_dx, exu = (s11 - s01) * g.inv_dx;
+      const double eyl = (s01 - s00) * g.inv_dy, eyr = (s11 - s10) * g.inv_dy;
+      const double gx = 0.5 * (exl + exu), gy = 0.5 * (eyl + eyr);
+      const double Hb = 0.25 * (h00 + h10 + h01 + h11);
+      const double gS2 = gx * gx + gy * gy;
+      double An = g.A;
+      if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+      double al, be, sp;
+      D = node_D<true, LM>(g, L, Hb, gS2, An, al, be, sp);
+      // D_adjoint of this node (adjoint.jl:99-104) from its own four edges
+      double Da = 0.0;
+      if (gj >= 1)         Da -= 0.5 * ((sL[b][a + 1] - sL[b][a]) * g.inv_dx) * clampf(exl, (g.eta0 * h10) * g.inv_dx, -(g.eta0 * h00) * g.inv_dx);
+      if (gj + 1 <= g.ny - 2) Da -= 0.5 * ((sL[b + 1][a + 1] - sL[b + 1][a]) * g.inv_dx) * clampf(exu, (g.eta0 * h11) * g.inv_dx, -(g.eta0 * h01) * g.inv_dx);
+      if (gi >= 1)         Da -= 0.5 * ((sL[b + 1][a] - sL[b][a]) * g.inv_dy) * clampf(eyl, (g.eta0 * h01) * g.inv_dy, -(g.eta0 * h00) * g.inv_dy);
+      if (gi + 1 <= g.nx - 2) Da -= 0.5 * ((sL[b + 1][a + 1] - sL[b][a + 1]) * g.inv_dy) * clampf(eyr, (g.eta0 * h11) * g.inv_dy, -(g.eta0 * h10) * g.inv_dy);
+      AD = al * Da;
+      BX = be * gx * Da;
+      BY = be * gy * Da;
+    }
+    sD[b][a] = D;
+    sAD[b][a] = AD;
+    sBX[b][a] = BX;
+    sBY[b][a] = BY;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx, c = tx + 1;
+  double dt = 1.0, w = 0.0;
+  long long roff = 0;
+  if (MODE == 1) {
+    dt = A.dts[t4.x];
+    w = A.ws ? A.ws[t4.x] : 0.0;
+    if (w != 0.0) roff = (long long)A.refslot[t4.x] * A.ntot;
+  }
+  const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
+  double lsum = 0.0;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double H0 = sH[r][c], S0 = sS[r][c], L0 = sL[r][c];
+      double v = 0.0;
+      if (H0 > 0.0) {
+        v = 0.25 * (sAD[r - 1][c - 1] + sAD[r - 1][c] + sAD[r][c - 1] + sAD[r][c]) +
+            0.5 * g.inv_dx * ((sBX[r - 1][c - 1] + sBX[r][c - 1]) - (sBX[r - 1][c] + sBX[r][c])) +
+            0.5 * g.inv_dy * ((sBY[r - 1][c - 1] + sBY[r - 1][c]) - (sBY[r][c - 1] + sBY[r][c]));
+        const double etx = g.eta0 * g.inv_dx, ety = g.eta0 * g.inv_dy;
+        if (gj >= 1 && gj <= g.ny - 2) {
+          if (gi <= g.nx - 2) {  // east edge: this cell is its left cell
+            const double Fa = (sL[r][c + 1] - L0) * g.inv_dx;
+            const double C = -Fa * (0.5 * (sD[r - 1][c] + sD[r][c]));
+            const double e = (sS[r][c + 1] - S0) * g.inv_dx;
+            const double up = (g.eta0 * sH[r][c + 1]) * g.inv_dx, lo = -(g.eta0 * H0) * g.inv_dx;
+            if (e < up && e > lo) v -= g.inv_dx * C;
+            if (e < lo) v -= etx * C;
+          }
+          if (gi >= 1) {  // west edge: this cell is its right cell
+            const double Fa = (L0 - sL[r][c - 1]) * g.inv_dx;
+            const double C = -Fa * (0.5 * (sD[r - 1][c - 1] + sD[r][c - 1]));
+            const double e = (S0 - sS[r][c - 1]) * g.inv_dx;
+            const double up = (g.eta0 * H0) * g.inv_dx, lo = -(g.eta0 * sH[r][c - 1]) * g.inv_dx;
+            if (e < up && e > lo) v += g.inv_dx * C;
+            if (e > up) v += etx * C;
+          }
+        }
+        if (gi >= 1 && gi <= g.nx - 2) {
+          if (gj <= g.ny - 2) {  // north edge
+            const double Fa = (sL[r + 1][c] - L0) * g.inv_dy;
+            const double C = -Fa * (0.5 * (sD[r][c - 1] + sD[r][c]));
+            const double e = (sS[r + 1][c] - S0) * g.inv_dy;
+            const double up = (g.eta0 * sH[r + 1][c]) * g.inv_dy, lo = -(g.eta0 * H0) * g.inv_dy;
+            if (e < up && e > lo) v -= g.inv_dy * C;
+            if (e < lo) v -= ety * C;
+          }
+          if (gj >= 1) {  // south edge
+            const double Fa = (L0 - sL[r - 1][c]) * g.inv_dy;
+            const double C = -Fa * (0.5 * (sD[r - 1][c - 1] + sD[r - 1][c]));
+            const double e = (S0 - sS[r - 1][c]) * g.inv_dy;
+            const double up = (g.eta0 * H0) * g.inv_dy, lo = -(g.eta0 * sH[r - 1][c]) * g.inv_dy;
+            if (e < up && e > lo) v += g.inv_dy * C;
+            if (e > up) v += ety * C;
+          }
+        }
+      }
+      if (MODE == 0) {
+        A.out[id] = v;
+      } else {
+        double o = fma(dt, v, ownL[m]);
+        if (w != 0.0 && A.mask[roff + id]) {
+          const double d = ownH[m] - A.Href[roff + id];
+          o = fma(w * 2.0 * Ninv, d, o);
+          lsum = fma(d, d, lsum);
+        }
+        A.out[id] = o;
+      }
+    }
+  }
+  if (MODE == 1) {
+    const double tot = block_sum(lsum, red);
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = tot * w * Ninv;
+  }
+}
+
+// =====================================================================================
+// K6: discrete theta-VJP (adjoint.jl:235-250).  For A-type laws dD/dtheta = spat * dA/dtheta
+// with dA/dtheta independent of the state, so the kernel reduces  sum_nodes spat*Da  (scalar
+// A: one partial per tile -> part[4*tile+2]) or accumulates  Gacc += scale*spat*Da  on the
+// dual grid (gridded A).  For Y/U laws the per-node law gradient is contracted in place:
+// part_theta[tile][k] = sum_nodes dlaw/dtheta_k * spat * Da.
+// =====================================================================================
+struct ThArgs {
+  const double* H;
+  const double* lam;
+  const double* scales;  // per-glacier multiplier (dt) or null (=1)
+  double* Gacc;          // dual pooled accumulator (gridded A) or null
+  double* part_theta;    // [ntiles_total][P] for Y/U laws or null
+  double* gscratch;      // thread-private gradient scratch [P][grid*NT]
+};
+
+template <int LM>
+__global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, int tile_base) {
+  __shared__ double sH[TY + 2][LDW];
+  __shared__ double sS[TY + 2][LDW];
+  __shared__ double sL[TY + 2][LDW];
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  double ownH[RPT], ownL[RPT];
+  load_tile_HS(A.H, P.B, g, i0, j0, sH, sS, ownH);
+  load_tile_lam(A.lam, g, i0, j0, sL, ownL);
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const double scale = A.scales ? A.scales[t4.x] : 1.0;
+  double acc = 0.0;
+  constexpr bool nn_node = (LM == LM_NN);
+  const long long gstride = (long long)gridDim.x * NT;
+  double* gth = A.gscratch ? A.gscratch + ((long long)blockIdx.x * NT + threadIdx.x) : nullptr;
+  if (nn_node)
+    for (int k = 0; k < L.P; ++k) gth[(long long)k * gstride] = 0.0;
+  // owned nodes: lower-left cell is an interior-of-tile cell (a = tx+1, b = r)
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int b = 1 + ty + NW * m, a = tx + 1;
+    const int gi = i0 - 1 + a, gj = j0 - 1 + b;
+    if (gi <= g.nx - 2 && gj <= g.ny - 2) {
+      const double s00 = sS[b][a], s10 = sS[b][a + 1], s01 = sS[b + 1][a], s11 = sS[b + 1][a + 1];
+      const double h00 = sH[b][a], h10 = sH[b][a + 1], h01 = sH[b + 1][a], h11 = sH[b + 1][a + 1];
+      const double exl = (s10 - s00) * g.inv_dx, exu = (s11 - s01) * g.inv_dx;
+      const double eyl = (s01 - s00) * g.inv_dy, eyr = (s11 - s10) * g.inv_dy;
+      const double gx = 0.5 * (exl + exu), gy = 0.5 * (eyl + eyr);
+      const double Hb = 0.25 * (h00 + h10 + h01 + h11);
+      const double gS2 = gx * gx + gy * gy;
+      double Da = 0.0;
+      if (gj >= 1)            Da -= 0.5 * ((sL[b][a + 1] - sL[b][a]) * g.inv_dx) * clampf(exl, (g.eta0 * h10) * g.inv_dx, -(g.eta0 * h00) * g.inv_dx);
+      if (gj + 1 <= g.ny - 2) Da -= 0.5 * ((sL[b + 1][a + 1] - sL[b + 1][a]) * g.inv_dx) * clampf(exu, (g.eta0 * h11) * g.inv_dx, -(g.eta0 * h01) * g.inv_dx);
+      if (gi >= 1)            Da -= 0.5 * ((sL[b + 1][a] - sL[b][a]) * g.inv_dy) * clampf(eyl, (g.eta0 * h01) * g.inv_dy, -(g.eta0 * h00) * g.inv_dy);
+      if (gi + 1 <= g.nx - 2) Da -= 0.5 * ((sL[b + 1][a + 1] - sL[b][a + 1]) * g.inv_dy) * clampf(eyr, (g.eta0 * h11) * g.inv_dy, -(g.eta0 * h10) * g.inv_dy);
+      double spat;
+      if (LM == LM_FAST) {
+        const double H2 = Hb * Hb;
+        spat = g.Gam * (H2 * H2 * Hb) * gS2;
+      } else if (LM == LM_POW) {
+        spat = g.Gam * pow(Hb, g.n + 2.0) * pow(sqrt(gS2), g.n - 1.0);
+      } else if (L.kind == 3) {
+        spat = g.Gam * pow(Hb, g.nH + 2.0) * pow(sqrt(gS2), g.nS - 1.0);
+      } else {
+        spat = Hb > 0.0 ? Hb : 0.0;
+      }
+      const double wgt = scale * spat * Da;
+      if (!nn_node) {
+        acc += wgt;
+        if (A.Gacc) A.Gacc[g.offd + gi + (long long)(g.nx - 1) * gj] += wgt;
+      } else if (!(L.kind == 4 && Hb == 0.0)) {  // target_D_pure.jl:166-168 skips Hbar == 0
+        // accumulate wgt * dlaw/dtheta into the thread-private scratch
+        const double x0 = (L.kind == 3) ? g.T : Hb, x1 = (L.kind == 3) ? Hb : sqrt(gS2);
+        mlp_grad(L, x0, x1, wgt, gth, gstride);
+      }
+    }
+  }
+  if (!nn_node) {
+    const double tot = block_sum(acc, red);
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 2] = tot;
+  } else {
+    for (int k = 0; k < L.P; ++k) {
+      const double tot = block_sum(gth[(long long)k * gstride], red);
+      if (threadIdx.x == 0) A.part_theta[(long long)t4.w * L.P + k] = tot;
+    }
+  }
+}
+
+#ifdef ODINN_MISC_KERNELS
+// fixed-order sum of per-tile partials of one glacier: out[g*stride_out + k]
+__global__ __launch_bounds__(64) void k_sum_part(Pools P, int slot, double* out, int accumulate, int g0) {
+  const int gidx = blockIdx.x + g0;
+  const GDev g = P.gd[gidx];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < g.ntiles; k += 64) s += P.part[4 * (long long)(g.tile0 + k) + slot];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) { if (accumulate) out[gidx] += s; else out[gidx] = s; }
+}
+// out[g*Pn + k] (+)= scale_g * sum_tiles part_theta[tile][k]
+__global__ __launch_bounds__(64) void k_sum_part_theta(Pools P, const double* part_theta, int Pn, double* out,
+                                                       int accumulate, int g0) {
+  const int gidx = blockIdx.y + g0;
+  const GDev g = P.gd[gidx];
+  const int k = blockIdx.x;
+  double s = 0.0;
+  for (int t = threadIdx.x; t < g.ntiles; t += 64) s += part_theta[(long long)(g.tile0 + t) * Pn + k];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) {
+    if (accumulate) out[(long long)gidx * Pn + k] += s; else out[(long long)gidx * Pn + k] = s;
+  }
+}
+
+// =====================================================================================
+// pointwise helpers (grid = tiles)
+// =====================================================================================
+// masked L2 loss partial of one snapshot (forward loss, inversion_utils.jl:425-461)
+__global__ __launch_bounds__(NT) void k_loss(Pools P, const double* __restrict__ H, const double* __restrict__ Href,
+                                             const unsigned char* __restrict__ mask, const double* ws,
+                                             const int* refslot, long long ntot) {
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  const double w = ws[t4.x];
+  double s = 0.0;
+  if (w != 0.0) {
+    const long long roff = (long long)refslot[t4.x] * ntot;
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) {
+      const int gj = j0 + ty + NW * m;
+      if (gi < g.nx && gj < g.ny) {
+        const long long id = g.off + gi + (long long)g.nx * gj;
+        if (mask[roff + id]) { const double d = H[id] - Href[roff + id]; s = fma(d, d, s); }
+      }
+    }
+  }
+  const double tot = block_sum(s, red);
+  if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = tot * w / ((double)g.nx * (double)g.ny);
+}
+
+// lam += VJP_MB(lam, H_pre)   (VJPs.jl:107-151), in place; flag per glacier
+__global__ __launch_bounds__(NT) void k_mb_vjp(Pools P, const double* __restrict__ Hpre, const double* __restrict__ mb0,
+                                               const double* __restrict__ Sref, const double* __restrict__ lam_in,
+                                               double* __restrict__ lam_out, int add, int tile_base) {
+  const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = j0 + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double h = Hpre[id], l = lam_in[id];
+      double v = 0.0;
+      if (g.has_mb) {
+        double dmb;
+        double mb = mb_value(g, mb0[id], Sref ? Sref[id] : 0.0, h, P.B[id], dmb);
+        const bool mask = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
+        if (mask) v = dmb * l;
+        if (mask && h + mb < 0.0) v = -l;
+      }
+      lam_out[id] = add ? l + v : v;
+    }
+  }
+}
+
+// out = H + MB(H) and the applied increment (seam for odinn_mb_apply)
+__global__ __launch_bounds__(NT) void k_mb_apply(Pools P, const double* __restrict__ H, const double* __restrict__ mb0,
+                                                 const double* __restrict__ Sref, double* __restrict__ Hn,
+                                                 double* __restrict__ MBout, int tile_base) {
+  const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = j0 + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double h = H[id];
+      double mb = 0.0;
+      if (g.has_mb) {
+        double dmb;
+        mb = mb_value(g, mb0[id], Sref ? Sref[id] : 0.0, h, P.B[id], dmb);
+        const bool mask = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
+        if (!mask) mb = 0.0;
+        if (mask && h + mb < 0.0) mb = -h;
+      }
+      Hn[id] = h + mb;
+      MBout[id] = mb;
+    }
+  }
+}
+
+// A on the dual grid from a gridded temperature: Afield = post(MLP(T))  (hoisted law)
+__global__ __launch_bounds__(NT) void k_law_field(LawDev L, const double* __restrict__ T, double* __restrict__ Aout,
+                                                  long long n) {
+  const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  if (i < n) Aout[i] = mlp_eval_any(L, T[i], 0.0);
+}
+
+// theta-gradient of the hoisted gridded law: part_theta[block][k] = sum_i G[i]*dA/dtheta_k(T[i])
+__global__ __launch_bounds__(NT) void k_law_field_grad(LawDev L, const double* __restrict__ T,
+                                                       const double* __restrict__ G, long long n,
+                                                       double* gscratch, double* part_theta) {
+  __shared__ double red[NW];
+  const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  const long long gstride = (long long)gridDim.x * NT;
+  double* gth = gscratch + ((long long)blockIdx.x * NT + threadIdx.x);
+  for (int k = 0; k < L.P; ++k) gth[(long long)k * gstride] = 0.0;
+  if (i < n) {
+    mlp_grad(L, T[i], 0.0, G[i], gth, gstride);
+  }
+  for (int k = 0; k < L.P; ++k) {
+    const double tot = block_sum(gth[(long long)k * gstride], red);
+    if (threadIdx.x == 0) part_theta[(long long)blockIdx.x * L.P + k] = tot;
+  }
+}
+__global__ __launch_bounds__(64) void k_sum_rows(const double* part, int nrows, int Pn, double* out) {
+  const int k = blockIdx.x;
+  double s = 0.0;
+  for (int t = threadIdx.x; t < nrows; t += 64) s += part[(long long)t * Pn + k];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[k] = s;
+}
+
+// value of the law on the dual grid of one glacier (seam odinn_eval_law)
+__global__ __launch_bounds__(NT) void k_eval_law(Pools P, LawDev L, const double* __restrict__ U, double* __restrict__ out,
+                                                 int gidx) {
+  const GDev g = P.gd[gidx];
+  const long long nd = (long long)(g.nx - 1) * (g.ny - 1);
+  const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  if (i >= nd) return;
+  const int a = (int)(i % (g.nx - 1)), b = (int)(i / (g.nx - 1));
+  auto Hc = [&](int ii, int jj) { double h = U[g.off + ii + (long long)g.nx * jj]; return h > 0.0 ? h : 0.0; };
+  auto Sf = [&](int ii, int jj) { return P.B[g.off + ii + (long long)g.nx * jj] + Hc(ii, jj); };
+  const double gx = 0.5 * ((Sf(a + 1, b) - Sf(a, b)) * g.inv_dx + (Sf(a + 1, b + 1) - Sf(a, b + 1)) * g.inv_dx);
+  const double gy = 0.5 * ((Sf(a, b + 1) - Sf(a, b)) * g.inv_dy + (Sf(a + 1, b + 1) - Sf(a + 1, b)) * g.inv_dy);
+  const double Hb = 0.25 * (Hc(a, b) + Hc(a + 1, b) + Hc(a, b + 1) + Hc(a + 1, b + 1));
+  double v;
+  if (L.kind == 3) v = mlp_eval_any(L, g.T, Hb);
+  else if (L.kind == 4) v = mlp_eval_any(L, Hb, sqrt(gx * gx + gy * gy));
+  else v = g.use_Afield ? P.Afield[g.offd + i] : g.A;
+  out[i] = v;
+}
+
+// ---- misc elementwise over pooled arrays ---------------------------------------------
+__global__ void k_axpy(long long n, double a, const double* __restrict__ x, const double* __restrict__ y,
+                       double* __restrict__ z) {  // z = y + a*x
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    z[i] = fma(a, x[i], y[i]);
+}
+// per-glacier z = y + dt_g * x on tiles
+__global__ __launch_bounds__(NT) void k_axpy_g(Pools P, const double* __restrict__ x, const double* __restrict__ y,
+                                               double* __restrict__ z) {
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GDev g = P.gd[t4.x];
+  const double a = P.gs[t4.x].dt;
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = j0 + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      z[id] = fma(a, x[id], y[id]);
+    }
+  }
+}
+// scaled-norm partials for the Hairer-Wanner initial step:
+//  slot0 = sum (u/sk)^2, slot1 = sum (f/sk)^2, slot2 = sum ((f1-f)/sk)^2 ; sk = abstol + |u| reltol
+__global__ __launch_bounds__(NT) void k_initdt_norms(Pools P, const double* __restrict__ U, const double* __restrict__ F0,
+                                                     const double* __restrict__ F1, double abstol, double reltol) {
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = j0 + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double u = U[id], f0 = F0[id];
+      const double sk = abstol + fabs(u) * reltol;
+      const double a = u / sk, b = f0 / sk;
+      s0 = fma(a, a, s0);
+      s1 = fma(b, b, s1);
+      if (F1) { const double c = (F1[id] - f0) / sk; s2 = fma(c, c, s2); }
+    }
+  }
+  const double t0 = block_sum(s0, red);
+  const double t1 = block_sum(s1, red);
+  const double t2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    double* p = P.part + 4 * (long long)t4.w;
+    p[0] = t0; p[1] = t1; p[2] = t2;
+  }
+}
+// phase 0: dt0 from d0,d1 ; phase 1: final dt from d1,d2   (ode_determine_initdt)
+__global__ __launch_bounds__(64) void k_initdt_ctrl(Pools P, int phase, double tspan, double dtmax, double* dt0store) {
+  const int gidx = blockIdx.x;
+  const GDev g = P.gd[gidx];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int k = threadIdx.x; k < g.ntiles; k += 64) {
+    const double* p = P.part + 4 * (long long)(g.tile0 + k);
+    s0 += p[0]; s1 += p[1]; s2 += p[2];
+  }
+  s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if (threadIdx.x != 0) return;
+  const double N = (double)g.nx * (double)g.ny;
+  const double d0 = sqrt(s0 / N), d1 = sqrt(s1 / N);
+  GState* gs = P.gs + gidx;
+  if (phase == 0) {
+    double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    dt0 = fmin(dt0, tspan);
+    if (dtmax > 0.0) dt0 = fmin(dt0, dtmax);
+    dt0store[gidx] = dt0;
+    gs->dt = dt0;
+  } else {
+    const double dt0 = dt0store[gidx];
+    const double d2 = sqrt(s2 / N) / dt0;
+    const double dm = fmax(d1, d2);
+    const double dt1 = dm <= 1e-15 ? fmax(1e-6, dt0 * 1e-3) : pow(0.01 / dm, 1.0 / 4.0);
+    double dt = fmin(fmin(100.0 * dt0, dt1), tspan);
+    if (dtmax > 0.0) dt = fmin(dt, dtmax);
+    gs->dt = dt;
+  }
+}
+
+// start of a solve: reset the integrator state; dt is already in gs->dt (given or from
+// k_initdt_ctrl) and is clipped to the first stop here.
+__global__ void k_begin(Pools P, int n, const double* tstops, double dtmax, double dt_given) {
+  const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx >= n) return;
+  GState* gs = P.gs + gidx;
+  const double t0 = tstops[0];
+  double dt = dt_given > 0.0 ? dt_given : gs->dt;
+  if (dtmax > 0.0 && dt > dtmax) dt = dtmax;
+  const double rem = tstops[1] - t0;
+  int clipped = 0;
+  if (dt >= rem || fabs(rem - dt) <= 100.0 * 2.220446049250313e-16 * fabs(t0)) { dt = rem; clipped = 1; }
+  gs->t = t0; gs->dt = dt; gs->e2 = 1.0; gs->e3 = 1.0; gs->EEst = 0.0;
+  gs->accepted = 1; gs->at_stop = 0; gs->mb_now = 0; gs->mb_slot = 0;
+  gs->done = 0; gs->istop = 1; gs->clipped = clipped; gs->cur = 0;
+  gs->naccept = 0; gs->nreject = 0; gs->nonfinite = 0;
+}
+
+#endif  // ODINN_MISC_KERNELS
+
+}  // namespace odinn

@@ -1,0 +1,42 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def odinn():
+    import _odinn_import
+
+    return _odinn_import.load()
+
+
+@pytest.fixture(scope="session")
+def gpu(odinn):
+    if odinn.device_count() < 1:
+        pytest.fail("GPU test selected but no HIP device is visible (the product path has no CPU fallback)")
+    return odinn
+
+
+def stats_err_arrays(a, b):
+    """ratio, angle, relerr exactly as the reference's test/test_utils.jl:78-83."""
+    a = np.asarray(a, float).ravel()
+    b = np.asarray(b, float).ravel()
+    na, nb = np.linalg.norm(a), np.linalg.norm(b)
+    return na / nb - 1.0, float(a @ b) / (na * nb) - 1.0, np.linalg.norm(a - b) / na
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, float)
+    b = np.asarray(b, float)
+    d = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (d if d > 0 else 1.0)

@@ -1,0 +1,437 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on
+identical seeded inputs.  fp64 tolerances are written in each test; the north-star bar is
+rel-L2 <= 1e-6 on the final H and the reference's FD thresholds on the gradients."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2, stats_err_arrays
+from oracle import sia2d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RHS_TOL = 1e-12  # one RHS / VJP evaluation, fp64, rel-L2
+A0 = 2.21e-18
+
+
+def _setup(odinn, nx, ny, dx=100.0, scale=0.4, phys=None, A=A0, valley=False):
+    if valley:
+        H0, B = O.synthetic_valley(nx, ny, dx)
+    else:
+        H0, B = O.synthetic_icecap(nx, ny, dx)
+        H0 = H0 * scale
+    ph = phys or O.Phys()
+    b = odinn.GlacierBatch([(nx, ny)], [dx], phys=[odinn.PhysicalParameters(**ph.__dict__)], A=[A])
+    b.set_fields(0, H0, B)
+    return b, H0, B, ph
+
+
+def _mlp_pair(odinn, widths, acts, prescale, post_kind, lo, hi, seed=1234):
+    om = O.MLP(widths, acts, prescale, post_kind, lo, hi)
+    th = om.init_theta(np.random.default_rng(seed))
+    # non-zero biases so that the bias gradient paths are exercised
+    th = th + 0.05 * np.random.default_rng(seed + 1).standard_normal(th.size)
+    gm = odinn.MLPSpec(widths, acts, prescale, post_kind, lo, hi)
+    return om, gm, th
+
+
+@pytest.mark.parametrize("shape", [(96, 80), (64, 16), (65, 17), (130, 50), (37, 40), (3, 3), (200, 131)])
+def test_dhdt_constA(gpu, shape):
+    nx, ny = shape
+    b, H0, B, ph = _setup(gpu, nx, ny)
+    law = O.Law(kind=O.LAW_CONST_A, A=A0)
+    ref = O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law)
+    got = b.dhdt(0, H0)
+    if np.linalg.norm(ref) == 0:
+        assert np.all(got == 0)
+    else:
+        assert rel_l2(got, ref) < RHS_TOL
+    assert np.all(got[0, :] == 0) and np.all(got[-1, :] == 0) and np.all(got[:, 0] == 0) and np.all(got[:, -1] == 0)
+    b.close()
+
+
+def test_dhdt_negative_and_random_H(gpu):
+    """max(H,0) clamp (adjoint.jl:52) and active border clamps on rough random input."""
+    nx, ny = 70, 45
+    rng = np.random.default_rng(1234)
+    b, H0, B, ph = _setup(gpu, nx, ny)
+    H = np.asfortranarray(np.abs(rng.standard_normal((nx, ny))) * 50.0 - 10.0)
+    B2 = np.asfortranarray(B + 30.0 * rng.standard_normal((nx, ny)))
+    b.set_fields(0, H, B2)
+    ref = O.sia2d_rhs(H, B2, 100.0, 100.0, ph, O.Law(kind=O.LAW_CONST_A, A=A0))
+    assert rel_l2(b.dhdt(0, H), ref) < RHS_TOL
+    b.close()
+
+
+def test_dhdt_generic_exponents_and_sliding(gpu):
+    """pow path: n != 3 and C > 0 (reference tests C = 7e-8, runtests.jl:92-94)."""
+    for n, C in [(3.0, 7e-8), (2.6, 0.0), (3.3, 7e-8)]:
+        ph = O.Phys(n=n, C=C, p=3.0, q=1.0)
+        b, H0, B, _ = _setup(gpu, 80, 60, phys=ph)
+        law = O.Law(kind=O.LAW_CONST_A, A=A0)
+        ref = O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law)
+        assert rel_l2(b.dhdt(0, H0), ref) < 1e-11
+        lam = np.random.default_rng(7).standard_normal(H0.shape)
+        assert rel_l2(b.vjp_H(0, lam, H0), O.vjp_H(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-10
+        assert rel_l2(b.vjp_theta(0, lam, H0), O.vjp_theta(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-10
+        b.close()
+
+
+@pytest.mark.parametrize("shape", [(96, 80), (65, 17), (37, 40), (3, 3), (130, 50)])
+def test_vjp_H_and_theta_constA(gpu, shape):
+    nx, ny = shape
+    b, H0, B, ph = _setup(gpu, nx, ny)
+    rng = np.random.default_rng(1234)
+    lam = rng.standard_normal((nx, ny))
+    law = O.Law(kind=O.LAW_CONST_A, A=A0)
+    ref = O.vjp_H(lam, H0, B, 100.0, 100.0, ph, law)
+    got = b.vjp_H(0, lam, H0)
+    if np.linalg.norm(ref) > 0:
+        assert rel_l2(got, ref) < 1e-11
+        rt = O.vjp_theta(lam, H0, B, 100.0, 100.0, ph, law)
+        gt = b.vjp_theta(0, lam, H0)
+        assert abs(gt[0] - rt[0]) <= 1e-11 * abs(rt[0])
+    else:
+        assert np.all(got == 0)
+    b.close()
+
+
+def test_vjp_flat_bed_ties(gpu):
+    """Halfar-like dome on a flat bed: structural ties e == eta0*H/dx at the margin must take
+    the same (strict-inequality) branch as the reference (inversion_utils.jl:24-28)."""
+    nx = ny = 60
+    dx = 2000.0 / nx / 0.4
+    x = (np.arange(nx) - nx / 2 + 0.5) * dx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    H = np.asfortranarray(O.halfar(X, Y, O.halfar_t0(1.1e-17, 400.0, 2000.0), 1.1e-17, 400.0, 2000.0))
+    B = np.zeros_like(H)
+    ph = O.Phys()
+    b = gpu.GlacierBatch([(nx, ny)], [dx], A=[1.1e-17])
+    b.set_fields(0, H, B)
+    law = O.Law(kind=O.LAW_CONST_A, A=1.1e-17)
+    lam = np.random.default_rng(3).standard_normal((nx, ny))
+    assert rel_l2(b.dhdt(0, H), O.sia2d_rhs(H, B, dx, dx, ph, law)) < RHS_TOL
+    assert rel_l2(b.vjp_H(0, lam, H), O.vjp_H(lam, H, B, dx, dx, ph, law)) < 1e-11
+    b.close()
+
+
+def test_vjp_meets_reference_fd_thresholds(gpu):
+    """The reference's own acceptance test for the discrete VJP (test/SIA2D_adjoint.jl,
+    thresholds [5e-7, 1e-6, 5e-4] runtests.jl:89-91), with the GPU RHS as the function
+    being differenced and the GPU VJP as the candidate."""
+    nx, ny = 40, 37
+    b, H0, B, ph = _setup(gpu, nx, ny, scale=0.3)
+    rng = np.random.default_rng(1234)
+    lam = rng.standard_normal((nx, ny))
+    g = b.vjp_H(0, lam, H0)
+    best = [np.inf] * 3
+    f0 = np.sum(b.dhdt(0, H0) * lam)
+    for eps in (1e-3, 1e-5, 1e-7):
+        gn = np.zeros_like(H0)
+        for i in range(nx):
+            for j in range(ny):
+                Hp = H0.copy()
+                Hp[i, j] += eps
+                gn[i, j] = (np.sum(b.dhdt(0, Hp) * lam) - f0) / eps
+        st = stats_err_arrays(g, gn)
+        best = [min(a, abs(s)) for a, s in zip(best, st)]
+    assert best[0] < 5e-7 and best[1] < 1e-6 and best[2] < 5e-4, best
+    b.close()
+
+
+def test_nn_A_scalar(gpu):
+    """LawA(nn; scalar=true): A hoisted (callback_freq = 0), dtheta = dA/dtheta * sum(spat*Da)."""
+    ph = O.Phys()
+    om, gm, th = _mlp_pair(gpu, [1, 3, 10, 3, 1], [1, 1, 1, 2], None, O.POST_AFFINE, ph.minA, ph.maxA)
+    b, H0, B, _ = _setup(gpu, 96, 80)
+    b.set_law(gpu.LAW_NN_A_SCALAR, gm, th)
+    law = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=om, theta=th, T=-5.0)
+    assert abs(b.eval_law(0) - O.law_value(law, ph, None, None)) <= 1e-13 * ph.maxA
+    assert rel_l2(b.dhdt(0, H0), O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law)) < RHS_TOL
+    lam = np.random.default_rng(5).standard_normal(H0.shape)
+    assert rel_l2(b.vjp_H(0, lam, H0), O.vjp_H(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-11
+    assert rel_l2(b.vjp_theta(0, lam, H0), O.vjp_theta(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-10
+    b.close()
+
+
+def test_nn_A_gridded(gpu):
+    ph = O.Phys()
+    om, gm, th = _mlp_pair(gpu, [1, 3, 10, 3, 1], [1, 1, 1, 2], None, O.POST_AFFINE, ph.minA, ph.maxA)
+    nx, ny = 96, 80
+    b, H0, B, _ = _setup(gpu, nx, ny)
+    S = B + H0
+    T = np.asfortranarray(-5.0 - 6.5e-3 * (O.avg(S) - S.mean()))
+    b.set_law(gpu.LAW_NN_A_GRIDDED, gm, th)
+    b.set_T_field(0, T)
+    law = O.Law(kind=O.LAW_NN_A_GRIDDED, mlp=om, theta=th, T=T)
+    assert rel_l2(b.eval_law(0, H0), O.law_value(law, ph, None, None)) < 1e-13
+    assert rel_l2(b.dhdt(0, H0), O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law)) < RHS_TOL
+    lam = np.random.default_rng(5).standard_normal(H0.shape)
+    assert rel_l2(b.vjp_H(0, lam, H0), O.vjp_H(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-11
+    assert rel_l2(b.vjp_theta(0, lam, H0), O.vjp_theta(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-10
+    b.close()
+
+
+@pytest.mark.parametrize("arch", ["default", "w16", "light", "wide"])
+def test_nn_Y_inlined(gpu, arch):
+    """LawY: per-dual-node MLP(T, Hbar) inlined in the stencil (Laws.jl:258-265), :D_hybrid."""
+    ph = O.Phys()
+    widths, acts = {
+        "default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]),
+        "w16": ([2, 16, 16, 1], [1, 1, 2]),
+        "light": ([2, 3, 1], [1, 2]),
+        "wide": ([2, 5, 8, 20, 30, 10, 1], [3, 3, 1, 1, 1, 2]),
+    }[arch]
+    om, gm, th = _mlp_pair(gpu, widths, acts, [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+    b, H0, B, _ = _setup(gpu, 80, 48)
+    b.set_law(gpu.LAW_NN_Y, gm, th)
+    law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=-5.0)
+    Hc, S, gSx, gSy, gS, Hbar, *_ = O._forward_intermediates(H0, B, 100.0, 100.0, ph)
+    assert rel_l2(b.eval_law(0, H0), O.law_value(law, ph, Hbar, gS)) < 1e-12
+    assert rel_l2(b.dhdt(0, H0), O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law)) < 1e-11
+    lam = np.random.default_rng(5).standard_normal(H0.shape)
+    # alpha contains a forward finite difference with dH = 1e-4 (target_D_hybrid.jl:58-71):
+    # (a-b)/1e-4 amplifies ulp differences of exp/log by 1e4
+    assert rel_l2(b.vjp_H(0, lam, H0), O.vjp_H(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-8
+    assert rel_l2(b.vjp_theta(0, lam, H0), O.vjp_theta(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-10
+    b.close()
+
+
+def test_nn_U_inlined(gpu):
+    """LawU: D = Hbar * NN(Hbar, gradS) (Laws.jl:114-123), target :D."""
+    ph = O.Phys()
+    om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+    b, H0, B, _ = _setup(gpu, 80, 48)
+    b.set_law(gpu.LAW_NN_U, gm, th)
+    law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th)
+    assert rel_l2(b.dhdt(0, H0), O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law)) < 1e-11
+    lam = np.random.default_rng(5).standard_normal(H0.shape)
+    # alpha, beta by central FD with 1e-4 / 1e-6 steps (target_D_pure.jl:105-137)
+    assert rel_l2(b.vjp_H(0, lam, H0), O.vjp_H(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-6
+    assert rel_l2(b.vjp_theta(0, lam, H0), O.vjp_theta(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-10
+    b.close()
+
+
+def _mb(H0, B, step=1.0 / 12.0):
+    S0 = B + np.maximum(H0, 0.0)
+    ela = np.percentile(S0[H0 > 0], 60)
+    grad = 6e-3
+    return O.MassBalance(mb0=grad * (S0 - ela) * step, dmb_dS=grad * step, S_ref=S0, mb_max=1.2 * step)
+
+
+def test_mass_balance_seams(gpu):
+    b, H0, B, ph = _setup(gpu, 96, 80)
+    mb = _mb(H0, B)
+    b.set_mass_balance(0, mb.mb0, mb.dmb_dS, mb.S_ref, mb.mb_max)
+    rng = np.random.default_rng(11)
+    H = np.asfortranarray(np.maximum(H0 + 5.0 * rng.standard_normal(H0.shape), 0.0))
+    H[H0 > 0] = np.minimum(H[H0 > 0], 0.02 + H[H0 > 0] * (rng.random(np.sum(H0 > 0)) > 0.1))  # some nearly-empty cells
+    Hn, MB = b.mb_apply(0, H)
+    Hr, MBr = O.mb_apply(mb, H, B)
+    assert np.array_equal(Hn, Hr) and np.array_equal(MB, MBr)
+    lam = rng.standard_normal(H.shape)
+    assert np.allclose(b.mb_vjp_H(0, lam, H), O.vjp_mb(mb, lam, H, B), rtol=1e-15, atol=0)
+    b.close()
+
+
+def test_solve_fixed_dt_bit_level(gpu):
+    """Non-adaptive RDPK3Sp35: same arithmetic sequence on both sides -> agreement to rounding."""
+    b, H0, B, ph = _setup(gpu, 96, 80)
+    law = O.Law(kind=O.LAW_CONST_A, A=A0)
+    ts = [0.0, 0.1, 0.25]
+    f = lambda H: O.sia2d_rhs(H, B, 100.0, 100.0, ph, law)
+    snaps, st, _ = O.solve(f, H0, ts, fixed_dt=0.01)
+    stats = b.solve(ts, fixed_dt=0.01)
+    assert stats[0].naccept == st.naccept
+    for j in range(3):
+        assert rel_l2(b.snapshot(0, j), snaps[j]) < 1e-12
+    b.close()
+
+
+@pytest.mark.parametrize("reltol", [1e-8, 1e-6])
+def test_solve_adaptive_matches_oracle(gpu, reltol):
+    """Adaptive RDPK3Sp35 + PID, all control on the device, vs the same algorithm on the CPU.
+    North-star bar: rel-L2(final H) <= 1e-6."""
+    b, H0, B, ph = _setup(gpu, 96, 80)
+    law = O.Law(kind=O.LAW_CONST_A, A=A0)
+    ts = [2010.0 + k / 12.0 for k in range(7)]
+    f = lambda H: O.sia2d_rhs(H, B, 100.0, 100.0, ph, law)
+    snaps, st, _ = O.solve(f, H0, ts, reltol=reltol)
+    stats = b.solve(ts, reltol=reltol)
+    assert abs(stats[0].naccept - st.naccept) <= max(2, st.naccept // 50)
+    for j in range(len(ts)):
+        assert rel_l2(b.snapshot(0, j), snaps[j]) < 1e-6
+    # volume conservation: no MB, ice does not touch the boundary ring
+    assert abs(b.snapshot(0, len(ts) - 1).sum() - H0.sum()) <= 1e-12 * H0.sum()
+    b.close()
+
+
+def test_solve_with_mass_balance(gpu):
+    b, H0, B, ph = _setup(gpu, 96, 80, valley=True, dx=50.0)
+    mb = _mb(H0, B)
+    b.set_mass_balance(0, mb.mb0, mb.dmb_dS, mb.S_ref, mb.mb_max)
+    law = O.Law(kind=O.LAW_CONST_A, A=A0)
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    ts = [2010.0 + k / 12.0 for k in range(5)]
+    cfg = O.SimConfig(tstops=ts, reltol=1e-8, mb=mb, mb_times=ts[1:])
+    snaps, st, inc = O.forward(gl, law, cfg)
+    b.solve(ts, mb_times=ts[1:], reltol=1e-8)
+    for j in range(len(ts)):
+        assert rel_l2(b.snapshot(0, j), snaps[j]) < 1e-6
+    b.close()
+
+
+def _inversion_case(odinn, nx, ny, use_mb=False, k=7, step=1.0 / 12.0):
+    ph = O.Phys()
+    H0, B = O.synthetic_valley(nx, ny, 50.0)
+    ts = [2010.0 + j * step for j in range(k)]
+    om = O.default_nn(1, light=False, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
+    gm = odinn.MLPSpec(om.widths, om.acts, None, O.POST_AFFINE, ph.minA, ph.maxA)
+    th_true = om.init_theta(np.random.default_rng(42))
+    th0 = om.init_theta(np.random.default_rng(1234))
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    mb = _mb(H0, B) if use_mb else None
+    cfg = O.SimConfig(tstops=ts, reltol=1e-8, mb=mb, mb_times=ts[1:] if use_mb else ())
+    ref_snaps, _, _ = O.forward(gl, O.Law(kind=O.LAW_NN_A_SCALAR, mlp=om, theta=th_true, T=-2.0), cfg)
+    return ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref_snaps
+
+
+@pytest.mark.parametrize("use_mb", [False, True])
+def test_loss_grad_matches_oracle(gpu, use_mb):
+    """odinn_loss_grad == SIA2D_grad_batch! (DiscreteAdjoint + DiscreteVJP) vs the oracle's
+    restatement of gradient.jl:129-275 on the same inputs."""
+    nx, ny = 64, 48
+    ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, use_mb)
+    law0 = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=om, theta=th0, T=-2.0)
+    Lo, go, lam0 = O.loss_and_grad(gl, law0, cfg, ref, ts)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-2.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_A_SCALAR, gm, th0)
+    b.set_reference(0, ts, ref, 3)
+    if use_mb:
+        b.set_mass_balance(0, mb.mb0, mb.dmb_dS, mb.S_ref, mb.mb_max)
+    Lg, gg = b.loss_grad(ts, theta=th0, mb_times=ts[1:] if use_mb else (), reltol=1e-8)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-9 and relerr < 1e-5, (ratio, angle, relerr)
+    assert rel_l2(b.lambda0(0), lam0) < 1e-5
+    # forward-only loss agrees with the loss recomputed in the reverse loop (gradient.jl:259, rtol 1e-8)
+    assert abs(b.loss()[0] - Lg) <= 1e-8 * abs(Lg)
+    b.close()
+
+
+def test_loss_grad_vs_finite_differences(gpu):
+    """The reference's end-to-end acceptance test (test_grad_finite_diff, thresholds
+    [5e-3, 1e-8, 5e-3] runtests.jl:116-117): dL/dtheta from the discrete adjoint vs central
+    finite differences of the GPU forward loss."""
+    nx, ny = 64, 48
+    # snapshot spacing 1/240 yr: the reference's reverse scheme is explicit Euler at snapshot
+    # resolution (gradient.jl:242) and is only first-order accurate -- at 1/12 yr it is unstable
+    # on this fast synthetic valley (the reference warns about exactly that, gradient.jl:19-24)
+    ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, False, k=13, step=1.0 / 240.0)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-2.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_A_SCALAR, gm, th0)
+    b.set_reference(0, ts, ref, 3)
+    L0, g = b.loss_grad(ts, theta=th0, reltol=1e-10)
+
+    def loss_at(th):
+        b.set_theta(th)
+        b.solve(ts, reltol=1e-10)
+        return b.loss()[0]
+
+    # A = minA + (maxA-minA) sigmoid(...) makes L depend on theta through ONE scalar, so the
+    # gradient direction is dA/dtheta: compare along it and along random directions
+    gn = np.zeros_like(g)
+    idx = np.arange(0, g.size, 5)
+    for q in idx:
+        e = np.zeros_like(g)
+        e[q] = 1e-4
+        gn[q] = (loss_at(th0 + e) - loss_at(th0 - e)) / (2 * e[q])
+    ratio, angle, relerr = stats_err_arrays(g[idx], gn[idx])
+    assert abs(ratio) < 5e-3 and abs(angle) < 1e-8 and relerr < 5e-3, (ratio, angle, relerr)
+    b.close()
+
+
+def test_batch_of_ragged_glaciers(gpu):
+    """Several glaciers of different sizes in ONE batch (one launch per stage for all of them):
+    every glacier must match its single-glacier oracle run; loss/grad are sums (Model.jl:208-224)."""
+    shapes = [(96, 80), (64, 48), (37, 40), (130, 50)]
+    ph = O.Phys()
+    ts = [2010.0 + j / 12.0 for j in range(4)]
+    Hs, Bs, As = [], [], [2.21e-18, 1e-17, 4e-18, 3e-17]
+    for (nx, ny) in shapes:
+        H0, B = O.synthetic_valley(nx, ny, 50.0)
+        Hs.append(H0)
+        Bs.append(B)
+    b = gpu.GlacierBatch(shapes, [50.0] * 4, A=As)
+    for g in range(4):
+        b.set_fields(g, Hs[g], Bs[g])
+    stats = b.solve(ts, reltol=1e-8)
+    for g in range(4):
+        law = O.Law(kind=O.LAW_CONST_A, A=As[g])
+        f = lambda H, g=g, law=law: O.sia2d_rhs(H, Bs[g], 50.0, 50.0, ph, law)
+        snaps, st, _ = O.solve(f, Hs[g], ts, reltol=1e-8)
+        assert rel_l2(b.snapshot(g, 3), snaps[3]) < 1e-6
+        assert rel_l2(b.dhdt(g, Hs[g]), f(Hs[g])) < RHS_TOL
+    b.close()
+
+
+def test_determinism(gpu):
+    """Gather-form adjoint + fixed-order reductions: two runs are bitwise identical."""
+    nx, ny = 64, 48
+    ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, False, k=4)
+    out = []
+    for _ in range(2):
+        b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-2.0])
+        b.set_fields(0, H0, B)
+        b.set_law(gpu.LAW_NN_A_SCALAR, gm, th0)
+        b.set_reference(0, ts, ref, 3)
+        out.append(b.loss_grad(ts, theta=th0, reltol=1e-8))
+        b.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+
+
+def test_halfar_known_answer(gpu):
+    """Halfar similarity solution (reference set-up
+    scripts/MWEs/inversion_diffusivity/inversion_setup.jl:44-68): dome height and volume."""
+    nx = ny = 60
+    R0, H00, A = 2000.0, 400.0, 1.1e-17
+    dx = R0 / nx / 0.4
+    x = (np.arange(nx) - nx / 2 + 0.5) * dx
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    t0 = O.halfar_t0(A, H00, R0)
+    H0 = np.asfortranarray(O.halfar(X, Y, t0, A, H00, R0))
+    b = gpu.GlacierBatch([(nx, ny)], [dx], A=[A])
+    b.set_fields(0, H0, np.zeros_like(H0))
+    b.solve([t0, t0 + 10.0], reltol=1e-8)
+    H1 = b.snapshot(0, 1)
+    exact = O.halfar(X, Y, t0 + 10.0, A, H00, R0)
+    assert abs(H1.max() - exact.max()) < 0.5  # metres; margin-resolution limited
+    assert rel_l2(H1, exact) < 3e-2
+    assert abs(H1.sum() - H0.sum()) < 1e-12 * H0.sum()
+    b.close()
+
+
+def test_full_size_properties(gpu):
+    """BASELINE sizes (512^2, 1024^2): size-independent properties -- adjoint identity
+    <lam, J v> == <J^T lam, v> through a directional FD, volume conservation of one RK step,
+    zero boundary ring, linearity of the VJP in lambda."""
+    for n in (512, 1024):
+        H0, B = O.synthetic_icecap(n, n, 100.0)
+        b = gpu.GlacierBatch([(n, n)], [100.0], A=[A0])
+        b.set_fields(0, H0, B)
+        rng = np.random.default_rng(n)
+        lam = rng.standard_normal((n, n))
+        v = rng.standard_normal((n, n)) * (H0 > 0)
+        eps = 1e-4
+        Jv = (b.dhdt(0, H0 + eps * v) - b.dhdt(0, H0 - eps * v)) / (2 * eps)
+        lhs = np.sum(lam * Jv)
+        rhs = np.sum(b.vjp_H(0, lam, H0) * v)
+        assert abs(lhs - rhs) <= 1e-6 * abs(lhs)
+        g1 = b.vjp_H(0, lam, H0)
+        g2 = b.vjp_H(0, 2.0 * lam, H0)
+        assert rel_l2(g2, 2.0 * g1) < 1e-14
+        dH = b.dhdt(0, H0)
+        assert abs(dH.sum()) <= 1e-10 * np.abs(dH).sum()  # flux form: interior divergence sums to ~0
+        assert np.all(dH[0, :] == 0) and np.all(dH[:, -1] == 0)
+        b.close()
