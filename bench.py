@@ -1,0 +1,228 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the SIA2D hot path on MI355X.
+
+Workload (BASELINE.json configs[4], the config the scaling metric is quoted on; its per-GPU
+share fits one GPU): every GPU holds 8 synthetic 1024x1024 fp64 ice caps (per-glacier random
+radius, bed phase and A in [1e-18, 4e-17], seed 1234 + global glacier index), resident in
+HBM.  A "step" is one pass of the hot path over that batch exactly as odinn_solve launches
+it: one RDPK3Sp35 time step = 5 fused RHS+stage kernels + the controller (error-norm
+reduction, PID) + the post-step kernel.  One cell-step = one cell through one fused
+RHS + stage update, so a step is 5 * cells cell-steps.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU; glaciers shard with no
+     data-path collective -> weak scaling; the only collective of the path, the all-reduce
+     of [loss, dtheta], is exercised in the untimed grad-eval leg)
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (an interior RK stage,
+56 algorithmic B/cell: read u,B,tmp,utilde; write u',tmp,utilde), timed live with HIP events
+on the library's own stream.  `cpu_baseline` is the oracle's C restatement
+(oracle/sia2d_oracle.c, OpenMP) stepping ONE of the 1024^2 glaciers on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+B_PER_CELL_STAGE2 = 56.0  # interior stage: R u,B,tmp,utilde  W u',tmp,utilde
+B_PER_CELL_STEP = 264.0  # 40 + 56 + 56 + 64 + 48 over the five stages
+B_PER_CELL_DHDT = 24.0
+B_PER_CELL_VJPH = 32.0
+
+
+def make_glacier(n, gidx, dx=100.0):
+    """Config-5 ice cap: B = 500 + 50 sin cos (random phase) + 0.01 x; H0 = max(0, 800 (1-(r/R)^2))."""
+    rng = np.random.default_rng(1234 + gidx)
+    x = (np.arange(n) * dx)[:, None]
+    y = (np.arange(n) * dx)[None, :]
+    Lx = n * dx
+    ph = rng.uniform(0, 2 * np.pi, 2)
+    B = 500.0 + 50.0 * np.sin(2 * np.pi * x / Lx + ph[0]) * np.cos(2 * np.pi * y / Lx + ph[1]) + 0.01 * x
+    R = rng.uniform(0.3, 0.42) * Lx
+    r = np.sqrt((x - Lx / 2) ** 2 + (y - Lx / 2) ** 2)
+    H0 = np.maximum(0.0, 800.0 * (1.0 - (r / R) ** 2))
+    A = 10.0 ** rng.uniform(np.log10(1e-18), np.log10(4e-17))
+    return np.asfortranarray(H0), np.asfortranarray(B + 0.0 * H0), A
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--glaciers-per-gpu", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-grad-eval", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+
+    import _odinn_import
+
+    odinn = _odinn_import.load()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        odinn.api._DIST.update(init=True, rank=rank, world=world, local=local, device=f"cuda:{local}")
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if odinn.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+
+    n, G = args.size, args.glaciers_per_gpu
+    gl = [make_glacier(n, rank * G + k) for k in range(G)]
+    b = odinn.GlacierBatch([(n, n)] * G, [100.0] * G, A=[g[2] for g in gl], device=local)
+    for k, (H0, B, A) in enumerate(gl):
+        b.set_fields(k, H0, B)
+    cells = b.cells
+
+    def barrier():
+        b.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    T = odinn._lib
+    # ---- timed region: K steps of the real per-step launch sequence ---------------------
+    b.bench_prepare()
+    b.bench_enqueue(T.TIMED_SOLVE_STEP, 0, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    b.bench_enqueue(T.TIMED_SOLVE_STEP, args.warmup, args.steps)
+    b.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.barrier()
+    cellsteps = 5.0 * cells * args.steps * world
+    value = cellsteps / elapsed
+
+    # ---- roofline of the dominant kernel (HIP events on the library stream) -------------
+    ms_stage = b.time_kernel(T.TIMED_RK_STAGE2, iters=50, warmup=5)
+    ach = B_PER_CELL_STAGE2 * cells / (ms_stage * 1e-3) / 1e9
+    ms_step = b.time_kernel(T.TIMED_RK_STEP, iters=20, warmup=3)
+    ms_dhdt = b.time_kernel(T.TIMED_DHDT, iters=50, warmup=5)
+    ms_vjp = b.time_kernel(T.TIMED_VJP_H, iters=20, warmup=3)
+    aux = {
+        "rk_step_ms": ms_step,
+        "rk_step_GBs": B_PER_CELL_STEP * cells / (ms_step * 1e-3) / 1e9,
+        "dhdt_ms": ms_dhdt,
+        "dhdt_GBs": B_PER_CELL_DHDT * cells / (ms_dhdt * 1e-3) / 1e9,
+        "vjp_H_ms": ms_vjp,
+        "vjp_H_GBs": B_PER_CELL_VJPH * cells / (ms_vjp * 1e-3) / 1e9,
+    }
+
+    # ---- untimed extra: grad-eval/s (forward solve + discrete adjoint + all-reduce) ------
+    if not args.no_grad_eval:
+        ph = odinn.PhysicalParameters()
+        nn = odinn.NeuralNetwork(odinn.Parameters(), seed=666)
+        mlp = odinn.MLPSpec(nn.widths, nn.acts, None, odinn.POST_AFFINE, ph.minA, ph.maxA)
+        b.set_law(odinn.LAW_NN_A_SCALAR, mlp, nn.theta)
+        ts = [2010.0 + k / 12.0 for k in range(4)]  # 3 monthly snapshots (bounded sample)
+        for k in range(G):
+            b.set_reference(k, ts, [gl[k][0] * (1.0 - 0.01 * j) for j in range(len(ts))], 3)
+        b.loss_grad(ts, theta=nn.theta, reltol=1e-6)  # warm
+        barrier()
+        tg0 = time.perf_counter()
+        loss, dth = b.loss_grad(ts, theta=nn.theta, reltol=1e-6)
+        loss, dth = odinn.allreduce_loss_grad(loss, dth)
+        b.sync()
+        tg = time.perf_counter() - tg0
+        st = b.last_stats
+        aux["grad_evals_per_s"] = G * world / tg
+        aux["grad_eval_sample"] = f"{G} glaciers/GPU, 3 monthly snapshots, reltol 1e-6, {st[0].naccept} RK steps (glacier 0)"
+        b.set_law(odinn.LAW_CONST_A)
+
+    # ---- CPU baseline (rank 0, N = 1 only): oracle C restatement on the host cores -------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import c_oracle as CO
+            from oracle import sia2d_oracle as O
+
+            H0, B, A = gl[0]
+            stp = CO.Stepper(H0, B, 100.0, 100.0, O.Phys(), A)
+            cores = CO.lib().oc_num_threads()
+            stp.step(1e-6)
+            tc0 = time.perf_counter()
+            nst = 0
+            while time.perf_counter() - tc0 < args.cpu_seconds:
+                stp.step(1e-6)
+                nst += 1
+            tc = time.perf_counter() - tc0
+            cpu = {
+                "value": 5.0 * n * n * nst / tc,
+                "unit": "cell-steps/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"{nst} RDPK3Sp35 steps of ONE {n}x{n} glacier of the workload "
+                          f"(oracle/sia2d_oracle.c, OpenMP {cores} threads, {tc:.1f} s)",
+            }
+        except Exception as e:  # the baseline is reported, never required
+            cpu = {"value": None, "unit": "cell-steps/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+
+    if rank == 0:
+        out = {
+            "metric": "cell-steps/s (forward SIA2D, fused RHS + RDPK3Sp35 stage)",
+            "value": value,
+            "unit": "cell-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{G} synthetic {n}x{n} fp64 ice caps per GPU (BASELINE configs[4] per-GPU share), "
+                            "constant A per glacier, one RDPK3Sp35 step = 5 fused stage kernels + controller + post-step",
+                "glaciers_per_gpu": G,
+                "grid": [n, n],
+                "cells_per_gpu": cells,
+                "parallelism": f"glacier-sharded x{world}, no data-path collective",
+                "device": odinn.device_name(local),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_rk_stage<2,LM_FAST>",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "traffic": None,
+                "ms_per_launch": ms_stage,
+                "algorithmic_bytes_per_launch": B_PER_CELL_STAGE2 * cells,
+            },
+            "cpu_baseline": cpu,
+            "aux": aux,
+        }
+        print(json.dumps(out))
+    b.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

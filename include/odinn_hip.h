@@ -172,11 +172,18 @@ enum odinn_timed {
   ODINN_TIMED_RK_STEP = 1,  /* one full RDPK3Sp35 step = 5 fused stage kernels              */
   ODINN_TIMED_VJP_H = 2,    /* read lam,H,B write dlam                        32 B/cell     */
   ODINN_TIMED_VJP_THETA = 3,/* read lam,H,B -> reduction                      24 B/cell     */
-  ODINN_TIMED_RK_STAGE2 = 4 /* one interior stage kernel (stage 2)            56 B/cell     */
+  ODINN_TIMED_RK_STAGE2 = 4,/* one interior stage kernel (stage 2)            56 B/cell     */
+  ODINN_TIMED_SOLVE_STEP = 5/* what odinn_solve launches per step: 5 stage kernels +
+                               controller (error-norm reduce, PID) + post-step  264 B/cell  */
 };
 /* runs `iters` back-to-back launches over ALL glaciers of the batch after `warmup`
  * untimed ones; *ms_total is the elapsed time of the timed launches. */
 int odinn_time_kernel(odinn_batch* b, int which, int warmup, int iters, double* ms_total);
+/* the same launches without the event bracket, for callers that time with their own clock:
+ * prepare resets the synthetic state (synchronous); enqueue launches iterations
+ * first_iter .. first_iter+n-1 asynchronously on the batch's stream (sync with odinn_batch_sync). */
+int odinn_bench_prepare(odinn_batch* b);
+int odinn_bench_enqueue(odinn_batch* b, int which, int first_iter, int n);
 /* total primal cells in the batch */
 int64_t odinn_batch_cells(odinn_batch* b);
 

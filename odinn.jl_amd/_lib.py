@@ -15,7 +15,7 @@ MAX_WIDTH = 32
 LAW_CONST_A, LAW_NN_A_SCALAR, LAW_NN_A_GRIDDED, LAW_NN_Y, LAW_NN_U = range(5)
 ACT_IDENTITY, ACT_SOFTPLUS, ACT_SIGMOID, ACT_GELU, ACT_TANH, ACT_RELU = range(6)
 POST_NONE, POST_AFFINE, POST_EXPMAX, POST_SCALE = range(4)
-TIMED_DHDT, TIMED_RK_STEP, TIMED_VJP_H, TIMED_VJP_THETA, TIMED_RK_STAGE2 = range(5)
+TIMED_DHDT, TIMED_RK_STEP, TIMED_VJP_H, TIMED_VJP_THETA, TIMED_RK_STAGE2, TIMED_SOLVE_STEP = range(6)
 
 
 class OdinnError(RuntimeError):
@@ -80,6 +80,8 @@ SIGNATURES = {
                                   C.POINTER(SolveStats)]),
     "odinn_get_lambda0": (C.c_int, [_vp, C.c_int, _dp]),
     "odinn_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+    "odinn_bench_prepare": (C.c_int, [_vp]),
+    "odinn_bench_enqueue": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "odinn_batch_cells": (C.c_int64, [_vp]),
 }
 

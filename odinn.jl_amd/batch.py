@@ -282,5 +282,11 @@ class GlacierBatch:
         L.check(L.lib().odinn_time_kernel(self._h, int(which), int(warmup), int(iters), C.byref(ms)))
         return ms.value / iters
 
+    def bench_prepare(self):
+        L.check(L.lib().odinn_bench_prepare(self._h))
+
+    def bench_enqueue(self, which, first_iter, n):
+        L.check(L.lib().odinn_bench_enqueue(self._h, int(which), int(first_iter), int(n)))
+
     def sync(self):
         L.check(L.lib().odinn_batch_sync(self._h))

@@ -1030,12 +1030,10 @@ int odinn_get_lambda0(odinn_batch* b, int g, double* lam0) {
 }
 
 // ---- measurement --------------------------------------------------------------------------
-int odinn_time_kernel(odinn_batch* b, int which, int warmup, int iters, double* ms_total) {
-  if (!b || !ms_total || iters <= 0) return fail(ODINN_ERR_ARG, "bad arguments");
+static int timed_prepare(odinn_batch* b) {
   CHK(use_dev(b));
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
   const Pools P = b->pools(true);
-  const LawDev L = b->lawdev();
   // state: H0 in U[0]; a fixed small dt so that the RK registers stay finite
   const size_t fb = (size_t)b->ntot * sizeof(double);
   HIPCHK(hipMemcpyAsync(b->d_U[0], b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
@@ -1044,25 +1042,62 @@ int odinn_time_kernel(odinn_batch* b, int which, int warmup, int iters, double* 
   std::vector<double> ts = {0.0, 1e30};
   CHK(ensure_tables(b, 2));
   HIPCHK(hipMemcpyAsync(b->d_tstops, ts.data(), 2 * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_mb_flag, 0, 2 * sizeof(int), b->stream));
+  HIPCHK(hipMemsetAsync(b->d_mb_slot, 0, 2 * sizeof(int), b->stream));
   launch_begin(b->G, b->stream, P, b->d_tstops, 0.0, 1e-6);
-  auto one = [&](int it) -> int {
-    switch (which) {
-      case ODINN_TIMED_DHDT: return launch_dhdt(b, b->d_U[0], b->d_tmpB, -1);
-      case ODINN_TIMED_RK_STEP: return launch_step(b, it & 1, 1e-6, 1e-8);
-      case ODINN_TIMED_RK_STAGE2: launch_stage<2>(b, P, L, b->d_U[0], b->d_U[1], 1e-6, 1e-8); return ODINN_OK;
-      case ODINN_TIMED_VJP_H: {
-        AdjArgs A{};
-        A.H = b->d_U[0]; A.lam = b->d_lam[0]; A.out = b->d_tmpB;
-        launch_vjp_H(b, 0, b->ntiles, P, L, A, 0);
-        return ODINN_OK;
-      }
-      case ODINN_TIMED_VJP_THETA: return theta_vjp_launch(b, b->d_U[0], b->d_lam[0], nullptr, -1, false);
-      default: return fail(ODINN_ERR_ARG, "unknown timed kernel %d", which);
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return ODINN_OK;
+}
+
+static int timed_one(odinn_batch* b, int which, int it) {
+  const Pools P = b->pools(true);
+  const LawDev L = b->lawdev();
+  switch (which) {
+    case ODINN_TIMED_SOLVE_STEP: {
+      CtrlArgs C;
+      C.tstops = b->d_tstops; C.n_stops = 2; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
+      C.dtmax = 0.0; C.adaptive = 0; C.fixed_dt = 1e-6; C.n_active = b->d_nactive;
+      PostArgs PA;
+      PA.snaps = b->d_tmpA; PA.premb = b->d_tmpB; PA.ntot = b->ntot; PA.mb0 = b->d_mb0; PA.Sref = nullptr;
+      CHK(launch_step(b, it & 1, 1e-6, 1e-8));
+      C.next_cur = 1 - (it & 1);
+      launch_controller(b->G, b->stream, P, C);
+      launch_poststep(b->ntiles, b->stream, P, PA, b->d_U[0], b->d_U[1]);
+      return ODINN_OK;
     }
-  };
-  for (int i = 0; i < warmup; ++i) CHK(one(i));
+    case ODINN_TIMED_DHDT: return launch_dhdt(b, b->d_U[0], b->d_tmpB, -1);
+    case ODINN_TIMED_RK_STEP: return launch_step(b, it & 1, 1e-6, 1e-8);
+    case ODINN_TIMED_RK_STAGE2: launch_stage<2>(b, P, L, b->d_U[0], b->d_U[1], 1e-6, 1e-8); return ODINN_OK;
+    case ODINN_TIMED_VJP_H: {
+      AdjArgs A{};
+      A.H = b->d_U[0]; A.lam = b->d_lam[0]; A.out = b->d_tmpB;
+      launch_vjp_H(b, 0, b->ntiles, P, L, A, 0);
+      return ODINN_OK;
+    }
+    case ODINN_TIMED_VJP_THETA: return theta_vjp_launch(b, b->d_U[0], b->d_lam[0], nullptr, -1, false);
+    default: return fail(ODINN_ERR_ARG, "unknown timed kernel %d", which);
+  }
+}
+
+int odinn_bench_prepare(odinn_batch* b) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
+  return timed_prepare(b);
+}
+
+int odinn_bench_enqueue(odinn_batch* b, int which, int first_iter, int n) {
+  if (!b || n < 0) return fail(ODINN_ERR_ARG, "bad arguments");
+  CHK(use_dev(b));
+  for (int i = 0; i < n; ++i) CHK(timed_one(b, which, first_iter + i));
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+int odinn_time_kernel(odinn_batch* b, int which, int warmup, int iters, double* ms_total) {
+  if (!b || !ms_total || iters <= 0) return fail(ODINN_ERR_ARG, "bad arguments");
+  CHK(timed_prepare(b));
+  for (int i = 0; i < warmup; ++i) CHK(timed_one(b, which, i));
   HIPCHK(hipEventRecord(b->ev0, b->stream));
-  for (int i = 0; i < iters; ++i) CHK(one(i));
+  for (int i = 0; i < iters; ++i) CHK(timed_one(b, which, warmup + i));
   HIPCHK(hipEventRecord(b->ev1, b->stream));
   HIPCHK(hipEventSynchronize(b->ev1));
   HIPCHK(hipGetLastError());

@@ -796,8 +796,12 @@ def solve(
         while t < ts:
             if st.naccept + st.nreject >= maxiters:
                 raise RuntimeError("maxiters reached")
-            h = min(dt, dtmax, ts - t)
-            clipped = h >= ts - t
+            h = min(dt, dtmax)
+            rem = ts - t
+            # land exactly on the stop when the step would end within 100 ulp of it
+            clipped = h >= rem or abs(rem - h) <= 100.0 * np.finfo(F).eps * abs(t)
+            if clipped:
+                h = rem
             un, ut = rdpk3sp35_step(f, u, h)
             st.nrhs += 5
             if fixed_dt is not None:
