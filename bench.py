@@ -181,6 +181,13 @@ def main():
         except Exception as e:  # the baseline is reported, never required
             cpu = {"value": None, "unit": "cell-steps/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
 
+    traffic = None
+    try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (same workload only)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        if pm.get("workload_cells") == cells:
+            traffic = pm["k_rk_stage<2,0>"]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     if rank == 0:
         out = {
             "metric": "cell-steps/s (forward SIA2D, fused RHS + RDPK3Sp35 stage)",
@@ -211,7 +218,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; FETCH x2)" if traffic else None,
                 "ms_per_launch": ms_stage,
                 "algorithmic_bytes_per_launch": B_PER_CELL_STAGE2 * cells,
             },

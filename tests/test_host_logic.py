@@ -1,0 +1,73 @@
+"""-m "not gpu": host-side logic of the reference-facing layer (no device needed)."""
+import numpy as np
+import pytest
+
+from oracle import sia2d_oracle as O
+
+
+def test_shard_glaciers_balanced_and_deterministic(odinn):
+    cells = [192 * 160, 96 * 80, 128 * 112, 160 * 128, 1024 * 1024, 512 * 512, 64 * 48, 300 * 200]
+    for world in (1, 2, 4, 8):
+        sh = odinn.shard_glaciers(cells, world)
+        assert sorted(i for s in sh for i in s) == list(range(len(cells)))
+        assert sh == odinn.shard_glaciers(cells, world)
+    sh = odinn.shard_glaciers([100] * 64, 8)
+    assert all(len(s) == 8 for s in sh)
+    loads = [sum(cells[i] for i in s) for s in odinn.shard_glaciers(cells, 2)]
+    assert max(loads) <= sum(cells) - min(loads) and max(loads) - 1024 * 1024 < sum(cells) / 2
+
+
+def test_define_callback_steps_and_tstops(odinn):
+    ts = odinn.define_callback_steps((2010.0, 2012.0), 1.0 / 12.0)
+    assert len(ts) == 25 and ts[0] == 2010.0 and ts[-1] == 2012.0  # k = 25 for 2 yr monthly
+    p = odinn.Parameters(simulation=odinn.SimulationParameters(tspan=(2010.0, 2011.0)))
+    H = np.ones((8, 8))
+    g = odinn.Glacier2D("RGI60-00.00001", H, H, 50.0, 50.0, thicknessData=odinn.ThicknessData([2010.0, 2010.5, 2011.0], [H, H, H]))
+    sim = odinn.Prediction(odinn.Model(odinn.SIA2Dmodel(p)), [g], p)
+    t = sim.tstops()
+    assert t == sorted(set(t)) and 2010.5 in t and len(t) == 13
+    assert sim.mb_times() == []
+
+
+def test_default_architectures_and_theta_layout(odinn):
+    """83 parameters for the default 1-input net, 86 for 2 inputs, 10/13 in test_mode
+    (SURVEY 8(a) a3); theta = [vec(W) column-major, b] per layer."""
+    p = odinn.Parameters()
+    assert odinn.NeuralNetwork(p).n_params == 83
+    p2 = odinn.Parameters(UDE=odinn.UDEparameters(target="D_hybrid"))
+    assert odinn.NeuralNetwork(p2).n_params == 86
+    pt = odinn.Parameters(simulation=odinn.SimulationParameters(test_mode=True))
+    assert odinn.NeuralNetwork(pt).n_params == 10
+    nn = odinn.NeuralNetwork(p, seed=1)
+    mlp = O.MLP(nn.widths, nn.acts)
+    (W1, b1), *_ = mlp.unpack(nn.theta)
+    assert W1.shape == (3, 1) and np.array_equal(W1[:, 0], nn.theta[:3]) and np.all(b1 == 0)
+    law = odinn.LawA(nn, p)
+    assert law.mlp.post_kind == odinn.POST_AFFINE and law.mlp.post_lo == 8e-21 and law.mlp.post_hi == 8e-17
+    d = law.mlp.c_struct()
+    assert d.n_layers == 4 and list(d.widths)[:5] == [1, 3, 10, 3, 1]
+
+
+def test_lawY_lawU_descriptors(odinn):
+    p = odinn.Parameters(UDE=odinn.UDEparameters(target="D_hybrid"))
+    nn = odinn.NeuralNetwork(p)
+    y = odinn.LawY(nn, p)
+    assert y.kind == odinn.LAW_NN_Y and y.mlp.prescale == ((-25.0, 0.0), (0.0, 500.0)) and y.mlp.post_hi == 8e-17
+    u = odinn.LawU(nn, p, max_NN=50.0, prescale_bounds=[(0.0, 300.0), (0.0, 0.5)])
+    assert u.kind == odinn.LAW_NN_U and u.mlp.post_kind == odinn.POST_EXPMAX
+    with pytest.raises(ValueError):
+        odinn.SIA2Dmodel(p, A=odinn.ConstantA(), Y=y)
+
+
+def test_functional_inversion_alias(odinn):
+    assert odinn.FunctionalInversion is odinn.Inversion
+
+
+def test_adam_update_rule_matches_optimisers(odinn):
+    """One Adam step as Optimisers.Adam: theta -= eta * mhat / (sqrt(vhat) + eps)."""
+    a = odinn.Adam(0.1)
+    g = np.array([1.0, -2.0])
+    m = (1 - a.beta[0]) * g
+    v = (1 - a.beta[1]) * g * g
+    step = a.eta * (m / (1 - a.beta[0])) / (np.sqrt(v / (1 - a.beta[1])) + a.eps)
+    assert np.allclose(step, 0.1 * np.sign(g), rtol=1e-6)

@@ -1,0 +1,126 @@
+"""The reference's acceptance test for the VJPs of one SIA2D! evaluation
+(test/SIA2D_adjoint.jl:2-207): lambda = randn, one-sided finite differences with
+eps in {1e-3..1e-7}, keep the best eps; metrics test/test_utils.jl:78-83."""
+import numpy as np
+import pytest
+
+from conftest import stats_err_arrays
+from oracle import sia2d_oracle as O
+
+
+def _fd_H(f, H, epss):
+    best = [np.inf] * 3
+    f0 = f(H)
+    out = {}
+    for eps in epss:
+        g = np.zeros_like(H)
+        for i in range(H.shape[0]):
+            for j in range(H.shape[1]):
+                Hp = H.copy()
+                Hp[i, j] += eps
+                g[i, j] = (f(Hp) - f0) / eps
+        out[eps] = g
+    return out
+
+
+def _best(g, fds):
+    best = [np.inf] * 3
+    for gn in fds.values():
+        st = stats_err_arrays(g, gn)
+        best = [min(a, abs(s)) for a, s in zip(best, st)]
+    return best
+
+
+@pytest.mark.parametrize("C,thres", [(0.0, (5e-7, 1e-6, 5e-4)), (7e-8, (3e-4, 2e-4, 2e-2))])
+def test_discrete_vjp_target_A(C, thres):
+    """runtests.jl:89-94."""
+    ph = O.Phys(C=C, p=3.0, q=1.0)
+    H0, B = O.synthetic_icecap(34, 31, 100.0)
+    H0 = H0 * 0.3
+    rng = np.random.default_rng(1234)
+    lam = rng.standard_normal(H0.shape)
+    mlp = O.default_nn(1, light=True, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)  # test_mode NN
+    th = mlp.init_theta(rng)
+    law = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th, T=-5.0)
+    f = lambda H: np.sum(O.sia2d_rhs(H, B, 100.0, 100.0, ph, law) * lam)
+    g = O.vjp_H(lam, H0, B, 100.0, 100.0, ph, law)
+    b = _best(g, _fd_H(f, H0, (1e-3, 1e-5, 1e-7)))
+    assert b[0] < thres[0] and b[1] < thres[1] and b[2] < thres[2], b
+    gt = O.vjp_theta(lam, H0, B, 100.0, 100.0, ph, law)
+    best = [np.inf] * 3
+    for k in range(3, 8):
+        eps = 10.0 ** (-k)
+        gn = np.zeros_like(th)
+        f0 = np.sum(O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law, th) * lam)
+        for q in range(th.size):
+            tp = th.copy()
+            tp[q] += eps
+            gn[q] = (np.sum(O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law, tp) * lam) - f0) / eps
+        st = stats_err_arrays(gt, gn)
+        best = [min(a, abs(s)) for a, s in zip(best, st)]
+    assert best[0] < thres[0] and best[1] < thres[1] and best[2] < thres[2], best
+
+
+@pytest.mark.parametrize("kind", ["gridded_A", "Y", "U"])
+def test_theta_vjp_exact_for_field_laws(kind):
+    """d/dtheta of <lambda, SIA2D(H; theta)> for laws evaluated per dual node (exact per-node
+    backprop == the reference's interpolation = :None branch)."""
+    ph = O.Phys()
+    H0, B = O.synthetic_icecap(30, 27, 100.0)
+    H0 = H0 * 0.3
+    rng = np.random.default_rng(1234)
+    lam = rng.standard_normal(H0.shape)
+    if kind == "gridded_A":
+        mlp = O.default_nn(1, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
+        T = -5.0 - 6.5e-3 * (O.avg(B + H0) - (B + H0).mean())
+        law = O.Law(kind=O.LAW_NN_A_GRIDDED, mlp=mlp, theta=mlp.init_theta(rng), T=T)
+    elif kind == "Y":
+        mlp = O.MLP([2, 3, 10, 3, 1], [1, 1, 1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+        law = O.Law(kind=O.LAW_NN_Y, mlp=mlp, theta=mlp.init_theta(rng), T=-5.0)
+    else:
+        mlp = O.MLP([2, 3, 10, 3, 1], [1, 1, 1, 2], [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+        law = O.Law(kind=O.LAW_NN_U, mlp=mlp, theta=mlp.init_theta(rng))
+    th = law.theta
+    g = O.vjp_theta(lam, H0, B, 100.0, 100.0, ph, law)
+    gn = np.zeros_like(th)
+    for q in range(th.size):
+        e = np.zeros_like(th)
+        e[q] = 1e-5
+        gn[q] = (np.sum(O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law, th + e) * lam)
+                 - np.sum(O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law, th - e) * lam)) / 2e-5
+    ratio, angle, relerr = stats_err_arrays(g, gn)
+    assert abs(ratio) < 1e-6 and abs(angle) < 1e-10 and relerr < 1e-5, (ratio, angle, relerr)
+
+
+def test_mlp_grad_matches_fd():
+    rng = np.random.default_rng(3)
+    for acts in ([1, 1, 2], [3, 3, 2], [4, 5, 0]):
+        mlp = O.MLP([2, 5, 4, 1], acts, [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX if acts[-1] == 2 else O.POST_NONE, 0.0, 50.0)
+        th = mlp.init_theta(rng) + 0.1 * rng.standard_normal(mlp.n_params)
+        X = np.stack([rng.uniform(0, 300, 7), rng.uniform(0, 0.5, 7)])
+        g = O.mlp_grad_theta(mlp, th, X)
+        for q in range(th.size):
+            e = np.zeros_like(th)
+            e[q] = 1e-6
+            fd = (O.mlp_eval(mlp, th + e, X) - O.mlp_eval(mlp, th - e, X)) / 2e-6
+            assert np.allclose(g[q], fd, rtol=2e-6, atol=1e-9 * np.abs(g).max())
+
+
+def test_mb_vjp_matches_fd():
+    """VJP_lambda_dMB/dH (VJPs.jl:107-151) vs FD away from the mask thresholds (test/MB_VJP.jl)."""
+    H0, B = O.synthetic_valley(40, 30, 50.0)
+    S0 = B + H0
+    step = 1.0 / 12.0
+    mb = O.MassBalance(mb0=6e-3 * (S0 - np.percentile(S0[H0 > 0], 60)) * step, dmb_dS=6e-3 * step, S_ref=S0, mb_max=1.2 * step)
+    rng = np.random.default_rng(1)
+    lam = rng.standard_normal(H0.shape)
+    H = H0.copy()
+    g = O.vjp_mb(mb, lam, H, B)
+    f = lambda HH: np.sum((O.mb_apply(mb, HH, B)[1]) * lam)
+    eps = 1e-6
+    for (i, j) in [(15, 12), (20, 15), (25, 10), (10, 20), (30, 14)]:
+        Hp, Hm = H.copy(), H.copy()
+        Hp[i, j] += eps
+        Hm[i, j] -= eps
+        fd = (f(Hp) - f(Hm)) / (2 * eps)
+        assert abs(fd - g[i, j]) <= 1e-6 * max(1e-3, abs(fd)), (i, j, fd, g[i, j])
