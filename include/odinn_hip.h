@@ -101,6 +101,11 @@ typedef struct odinn_solver_opts {
   double dt0;       /* <=0: Hairer-Wanner automatic initial step                            */
   double fixed_dt;  /* >0: non-adaptive RDPK3Sp35 with this step (clipped at tstops)        */
   int64_t maxiters; /* params.solver.maxiters (:567); <=0 -> 1e6                            */
+  int32_t scheme;   /* kernel schedule of one RDPK3Sp35 step (same arithmetic either way):
+                       0 auto, 1 five per-stage kernels (HBM-bound, 264 B/cell/step),
+                       2 one temporally fused kernel (~24 B/cell/step, fp64-VALU-bound).
+                       The environment variable ODINN_SCHEME=1|2 overrides 0.               */
+  int32_t reserved;
 } odinn_solver_opts;
 
 typedef struct odinn_solve_stats {
@@ -173,8 +178,10 @@ enum odinn_timed {
   ODINN_TIMED_VJP_H = 2,    /* read lam,H,B write dlam                        32 B/cell     */
   ODINN_TIMED_VJP_THETA = 3,/* read lam,H,B -> reduction                      24 B/cell     */
   ODINN_TIMED_RK_STAGE2 = 4,/* one interior stage kernel (stage 2)            56 B/cell     */
-  ODINN_TIMED_SOLVE_STEP = 5/* what odinn_solve launches per step: 5 stage kernels +
-                               controller (error-norm reduce, PID) + post-step  264 B/cell  */
+  ODINN_TIMED_SOLVE_STEP = 5,/* what odinn_solve launches per step under the default scheme:
+                               RK step kernel(s) + controller (error-norm reduce, PID) + post-step */
+  ODINN_TIMED_FUSED_STEP = 6,/* the temporally fused RDPK3Sp35 step kernel alone   24 B/cell */
+  ODINN_TIMED_SOLVE_STEP_STAGED = 7 /* SOLVE_STEP forced onto the five per-stage kernels       */
 };
 /* runs `iters` back-to-back launches over ALL glaciers of the batch after `warmup`
  * untimed ones; *ms_total is the elapsed time of the timed launches. */

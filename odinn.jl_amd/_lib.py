@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libodinn_hip.so")
+LIB_PATH = os.environ.get("ODINN_LIB") or os.path.join(_HERE, "csrc", "libodinn_hip.so")  # ODINN_LIB: A/B builds
 
 MAX_LAYERS = 8
 MAX_WIDTH = 32
@@ -15,7 +15,9 @@ MAX_WIDTH = 32
 LAW_CONST_A, LAW_NN_A_SCALAR, LAW_NN_A_GRIDDED, LAW_NN_Y, LAW_NN_U = range(5)
 ACT_IDENTITY, ACT_SOFTPLUS, ACT_SIGMOID, ACT_GELU, ACT_TANH, ACT_RELU = range(6)
 POST_NONE, POST_AFFINE, POST_EXPMAX, POST_SCALE = range(4)
-TIMED_DHDT, TIMED_RK_STEP, TIMED_VJP_H, TIMED_VJP_THETA, TIMED_RK_STAGE2, TIMED_SOLVE_STEP = range(6)
+(TIMED_DHDT, TIMED_RK_STEP, TIMED_VJP_H, TIMED_VJP_THETA, TIMED_RK_STAGE2, TIMED_SOLVE_STEP, TIMED_FUSED_STEP,
+ TIMED_SOLVE_STEP_STAGED) = range(8)
+SCHEME_AUTO, SCHEME_STAGED, SCHEME_FUSED = 0, 1, 2
 
 
 class OdinnError(RuntimeError):
@@ -39,7 +41,7 @@ class MlpDesc(C.Structure):
 
 class SolverOpts(C.Structure):
     _fields_ = [("reltol", C.c_double), ("abstol", C.c_double), ("dtmax", C.c_double), ("dt0", C.c_double),
-                ("fixed_dt", C.c_double), ("maxiters", C.c_int64)]
+                ("fixed_dt", C.c_double), ("maxiters", C.c_int64), ("scheme", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SolveStats(C.Structure):

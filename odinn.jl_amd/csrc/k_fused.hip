@@ -1,0 +1,14 @@
+// k_fused.hip -- temporally fused RDPK3Sp35 step for one law mode (-DODINN_LM=0|1|2)
+#include "launch.hpp"
+#include "sia2d_fused.hpp"
+#ifndef ODINN_LM
+#error "define ODINN_LM"
+#endif
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+namespace odinn {
+void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
+                                        double* U1, double* partF, double abstol, double reltol) {
+  hipLaunchKernelGGL(k_rk_fused<ODINN_LM>, dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
+}
+}  // namespace odinn

@@ -5,6 +5,7 @@
 #include "launch.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -125,7 +126,9 @@ struct odinn_batch {
   long long ntot = 0, ntotd = 0;
   int ntiles = 0;
   // device pools
-  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr;
+  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr;
+  int ntilesF = 0;
+  double* d_partF = nullptr;
   GDev* d_gd = nullptr;
   GState* d_gs = nullptr;
   double *d_B = nullptr, *d_H0 = nullptr, *d_Afield = nullptr, *d_Tfield = nullptr, *d_Gacc = nullptr;
@@ -231,6 +234,7 @@ int refresh_gd(odinn_batch* b) {
     GDev& r = b->gd[g];
     const odinn_phys& ph = d.phys;
     r.dx = d.dx; r.dy = d.dy; r.inv_dx = 1.0 / d.dx; r.inv_dy = 1.0 / d.dy; r.eta0 = ph.eta0;
+    r.hinv_dx = 0.5 / d.dx; r.hinv_dy = 0.5 / d.dy; r.hinv_dx2 = 0.5 / (d.dx * d.dx); r.hinv_dy2 = 0.5 / (d.dy * d.dy);
     r.n = ph.n; r.p = ph.p; r.q = ph.q; r.T = d.T;
     r.Gam = 2.0 * std::pow(ph.rho * ph.g, ph.n) / (ph.n + 2.0);
     r.Sc = ph.C * std::pow(ph.rho * ph.g, ph.p - ph.q);
@@ -364,6 +368,29 @@ int launch_step(odinn_batch* b, int p, double abstol, double reltol) {
   return ODINN_OK;
 }
 
+// scheme actually used: 1 = five per-stage kernels, 2 = one fused kernel per step
+int pick_scheme(const odinn_batch* b, int requested) {
+  int s = requested;
+  if (s == 0) {
+    const char* e = std::getenv("ODINN_SCHEME");
+    if (e && (e[0] == '1' || e[0] == '2')) s = e[0] - '0';
+  }
+  if (s == 0) s = 2;
+  if (b->lm() == 2) s = 1;  // inlined-MLP laws: per-stage kernels only (register budget)
+  return s;
+}
+
+int launch_fused_step(odinn_batch* b, double abstol, double reltol) {
+  const Pools P = b->pools(true);
+  const LawDev L = b->lawdev();
+  if (b->lm() == 0)
+    launch_rk_fused_lm0(b->ntilesF, b->stream, P, L, b->d_tilesF, b->d_U[0], b->d_U[1], b->d_partF, abstol, reltol);
+  else
+    launch_rk_fused_lm1(b->ntilesF, b->stream, P, L, b->d_tilesF, b->d_U[0], b->d_U[1], b->d_partF, abstol, reltol);
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
 int ensure_tables(odinn_batch* b, int n_stops) {
   if (n_stops > b->tab_cap) {
     dfree(b->d_tstops); dfree(b->d_mb_flag); dfree(b->d_mb_slot);
@@ -410,7 +437,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   CHK(use_dev(b));
   CHK(refresh_gd(b));
   CHK(refresh_law_field(b));
-  odinn_solver_opts opt{1e-8, 1e-6, 0.0, 0.0, 0.0, 1000000};
+  odinn_solver_opts opt{1e-8, 1e-6, 0.0, 0.0, 0.0, 1000000, 0, 0};
   if (o) opt = *o;
   if (opt.maxiters <= 0) opt.maxiters = 1000000;
   if (opt.abstol <= 0) opt.abstol = 1e-6;
@@ -466,9 +493,11 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   HIPCHK(hipMemcpyAsync(b->d_nactive, &nact, sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipGetLastError());
 
+  const int scheme = pick_scheme(b, opt.scheme);
   CtrlArgs C;
   C.tstops = b->d_tstops; C.n_stops = n_stops; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
   C.dtmax = opt.dtmax; C.adaptive = adaptive ? 1 : 0; C.fixed_dt = opt.fixed_dt; C.n_active = b->d_nactive;
+  C.errpart = scheme == 2 ? b->d_partF : b->d_part; C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? 1 : 0;
   PostArgs A;
   A.snaps = b->d_snaps; A.premb = b->d_premb; A.ntot = b->ntot; A.mb0 = b->d_mb0;
   A.Sref = b->any_sref ? b->d_Sref : nullptr;
@@ -477,8 +506,13 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   int p = 0;
   while (nact > 0) {
     for (int s = 0; s < CHUNK; ++s) {
-      CHK(launch_step(b, p, opt.abstol, opt.reltol));
-      C.next_cur = 1 - p;
+      if (scheme == 2) {
+        CHK(launch_fused_step(b, opt.abstol, opt.reltol));
+        C.next_cur = -1;
+      } else {
+        CHK(launch_step(b, p, opt.abstol, opt.reltol));
+        C.next_cur = 1 - p;
+      }
       launch_controller(b->G, b->stream, P, C);
       launch_poststep(b->ntiles, b->stream, P, A, b->d_U[0], b->d_U[1]);
       p = 1 - p;
@@ -597,6 +631,28 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   CHK(dalloc(&b->d_tiles_nat, nat.size()));
   HIPCHK(hipMemcpy(b->d_tiles, swz.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->d_tiles_nat, nat.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
+  {  // tile table of the fused-step kernel (64x32 output tiles), same XCD-banded order
+    std::vector<int4> natF;
+    for (int g = 0; g < n_glaciers; ++g) {
+      GDev& r = b->gd[g];
+      const int fx = (r.nx + FOX - 1) / FOX, fy = (r.ny + FOY - 1) / FOY;
+      r.tile0F = (int)natF.size(); r.ntilesF = fx * fy;
+      for (int ty = 0; ty < fy; ++ty)
+        for (int tx = 0; tx < fx; ++tx) natF.push_back(make_int4(g, tx, ty, (int)natF.size()));
+    }
+    const int nF = (int)natF.size(), X = 8, per = (nF + X - 1) / X;
+    std::vector<int4> swzF;
+    swzF.reserve(nF);
+    for (int r = 0; r < per; ++r)
+      for (int x = 0; x < X; ++x) {
+        const int t = x * per + r;
+        if (t < nF) swzF.push_back(natF[t]);
+      }
+    b->ntilesF = nF;
+    CHK(dalloc(&b->d_tilesF, (size_t)nF));
+    CHK(dalloc(&b->d_partF, (size_t)nF));
+    HIPCHK(hipMemcpy(b->d_tilesF, swzF.data(), sizeof(int4) * nF, hipMemcpyHostToDevice));
+  }
   CHK(dalloc(&b->d_gd, n_glaciers));
   CHK(dalloc(&b->d_gs, n_glaciers));
   const size_t n = (size_t)b->ntot, nd = (size_t)b->ntotd;
@@ -623,7 +679,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   if (!b) return ODINN_OK;
   (void)hipSetDevice(b->device);
   (void)hipStreamSynchronize(b->stream);
-  dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_gd); dfree(b->d_gs);
+  dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
   dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0);
@@ -1053,14 +1109,25 @@ static int timed_one(odinn_batch* b, int which, int it) {
   const Pools P = b->pools(true);
   const LawDev L = b->lawdev();
   switch (which) {
-    case ODINN_TIMED_SOLVE_STEP: {
+    case ODINN_TIMED_FUSED_STEP:
+      if (b->lm() == 2) return fail(ODINN_ERR_STATE, "no fused step kernel for inlined-MLP laws");
+      return launch_fused_step(b, 1e-6, 1e-8);
+    case ODINN_TIMED_SOLVE_STEP:
+    case ODINN_TIMED_SOLVE_STEP_STAGED: {
+      const int scheme = which == ODINN_TIMED_SOLVE_STEP_STAGED ? 1 : pick_scheme(b, 0);
       CtrlArgs C;
       C.tstops = b->d_tstops; C.n_stops = 2; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
       C.dtmax = 0.0; C.adaptive = 0; C.fixed_dt = 1e-6; C.n_active = b->d_nactive;
+      C.errpart = scheme == 2 ? b->d_partF : b->d_part; C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? 1 : 0;
       PostArgs PA;
       PA.snaps = b->d_tmpA; PA.premb = b->d_tmpB; PA.ntot = b->ntot; PA.mb0 = b->d_mb0; PA.Sref = nullptr;
-      CHK(launch_step(b, it & 1, 1e-6, 1e-8));
-      C.next_cur = 1 - (it & 1);
+      if (scheme == 2) {
+        CHK(launch_fused_step(b, 1e-6, 1e-8));
+        C.next_cur = -1;
+      } else {
+        CHK(launch_step(b, it & 1, 1e-6, 1e-8));
+        C.next_cur = 1 - (it & 1);
+      }
       launch_controller(b->G, b->stream, P, C);
       launch_poststep(b->ntiles, b->stream, P, PA, b->d_U[0], b->d_U[1]);
       return ODINN_OK;

@@ -37,6 +37,24 @@ constexpr int LDN = TX + 1;    // LDS row stride of node tiles
 constexpr int NNODE = (TX + 1) * (TY + 1);
 constexpr int MAXP = 2048;     // max #theta supported by the in-kernel reductions
 constexpr int MAXL = 8;        // max Dense layers
+// fused-step kernel geometry (sia2d_fused.hpp)
+constexpr int FH = 5;                 // halo = number of stages
+#ifndef ODINN_FOY
+#define ODINN_FOY 32
+#endif
+#ifndef ODINN_FNT
+#define ODINN_FNT 512
+#endif
+constexpr int FOX = 64, FOY = ODINN_FOY;  // output tile
+constexpr int FRX = FOX + 2 * FH;     // 74
+constexpr int FRY = FOY + 2 * FH;     // 42
+constexpr int FNT = ODINN_FNT;        // threads per block
+constexpr int FNW = FNT / 64;
+constexpr int FNC = FRX * FRY;        // 3108 region cells
+constexpr int FCPT = (FNC + FNT - 1) / FNT;  // 7 cells per thread
+constexpr int FLD = FRX + 1;          // LDS row stride (odd)
+
+
 
 // ---- RDPK3Sp35 (Ranocha, Dalcin, Parsani, Ketcheson 2022), 3S*+ form ---------------
 constexpr double c_g1[5] = {0.0, 2.587771979725733308135192812685323706e-01,
@@ -66,9 +84,12 @@ constexpr double c_bh[5] = {1.046363371354093758897668305991705199e-01,
 // ---- records living in device memory ------------------------------------------------
 struct GDev {  // per-glacier constants
   int nx, ny, ntx, nty, tile0, ntiles;
+  int tile0F, ntilesF;  // range in the fused-step tile table (64x32 output tiles)
   long long off;   // offset of this glacier in the pooled primal arrays  [doubles]
   long long offd;  // offset in the pooled dual arrays
   double dx, dy, inv_dx, inv_dy, eta0;
+  double hinv_dx, hinv_dy;    // 0.5/dx, 0.5/dy
+  double hinv_dx2, hinv_dy2;  // 0.5/dx^2, 0.5/dy^2
   double A;        // scalar creep coefficient in use (CONST_A or hoisted NN_A_SCALAR)
   double Gam;      // 2 (rho g)^n / (n+2)      target_utils.jl:3-12
   double Sc;       // C (rho g)^(p-q)          target_utils.jl:14-18
@@ -408,6 +429,55 @@ __device__ __forceinline__ void load_tile_HS(const double* __restrict__ U, const
   }
 }
 
+// Interleaved variant for the forward kernels: sHS[r][c] = {max(U,0), B + max(U,0)}.
+__device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, const double* __restrict__ B, const GDev& g,
+                                              int i0, int j0, double2 (*sHS)[LDW], double own[RPT]) {
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  const bool colok = gi < g.nx;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m;
+    const int gj = j0 - 1 + r;
+    double h = 0.0, b = 0.0;
+    if (colok && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      h = U[id];
+      b = B[id];
+    }
+    own[m] = h;
+    const double hc = h > 0.0 ? h : 0.0;
+    sHS[r][tx + 1] = make_double2(hc, b + hc);
+  }
+  if (ty < 2) {
+    const int r = ty == 0 ? 0 : TY + 1;
+    const int gj = j0 - 1 + r;
+    double h = 0.0, b = 0.0;
+    if (colok && gj >= 0 && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      h = U[id];
+      b = B[id];
+    }
+    const double hc = h > 0.0 ? h : 0.0;
+    sHS[r][tx + 1] = make_double2(hc, b + hc);
+  } else {
+    const int l = threadIdx.x - 128;
+    if (l < 2 * (TY + 2)) {
+      const int r = l >> 1, side = l & 1;
+      const int c = side ? TX + 1 : 0;
+      const int gi2 = i0 - 1 + c, gj = j0 - 1 + r;
+      double h = 0.0, b = 0.0;
+      if (gi2 >= 0 && gi2 < g.nx && gj >= 0 && gj < g.ny) {
+        const long long id = g.off + gi2 + (long long)g.nx * gj;
+        h = U[id];
+        b = B[id];
+      }
+      const double hc = h > 0.0 ? h : 0.0;
+      sHS[r][c] = make_double2(hc, b + hc);
+    }
+  }
+}
+
 // Same for a third field kept unclamped and masked to the interior (lambda~).
 __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, const GDev& g, int i0, int j0,
                                               double (*sL)[LDW], double own[RPT]) {
@@ -439,20 +509,46 @@ __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, con
   }
 }
 
+// ---- shared stencil arithmetic (per-stage and fused kernels use the same expressions) ------
+// The reference divides every slope by dx before clamping (adjoint.jl:87-94).  The clamp is
+// monotone and dx > 0, so  clamp(dS/dx, eta H+/dx, -eta H-/dx) == clamp(dS, eta H+, -eta H-)/dx
+// with the SAME branch taken (ties included); the 1/dx factors are applied once per cell.
+// pS/pH point at the node's lower-left cell; LD = row stride of the cell tiles.
+// Cell tiles are stored interleaved as double2 {Hc, S} (16-B aligned) so that every stencil
+// access is ONE full-rate ds_read_b128 instead of two half-rate ds_read2_b64.
+template <int LD>
+__device__ __forceinline__ void node_geom(const GDev& g, const double2* p, double& gx, double& gy, double& Hb) {
+  const double2 c00 = p[0], c10 = p[1], c01 = p[LD], c11 = p[LD + 1];
+  gx = ((c10.y - c00.y) + (c11.y - c01.y)) * g.hinv_dx;
+  gy = ((c01.y - c00.y) + (c11.y - c10.y)) * g.hinv_dy;
+  Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
+}
+// dH/dt of an interior cell: p at the cell, pD at its north-east node; LDD = node row stride.
+template <int LD, int LDD>
+__device__ __forceinline__ double cell_div(const GDev& g, const double2* p, const double* pD) {
+  const double2 c0 = p[0], ce_ = p[1], cw_ = p[-1], cn_ = p[LD], cs_ = p[-LD];
+  const double S0 = c0.y, eH0 = g.eta0 * c0.x;
+  const double Dsw = pD[-LDD - 1], Dse = pD[-LDD], Dnw = pD[-1], Dne = pD[0];
+  const double ce = fmax(fmin(ce_.y - S0, g.eta0 * ce_.x), -eH0);
+  const double cw = fmax(fmin(S0 - cw_.y, eH0), -(g.eta0 * cw_.x));
+  const double cn = fmax(fmin(cn_.y - S0, g.eta0 * cn_.x), -eH0);
+  const double cs = fmax(fmin(S0 - cs_.y, eH0), -(g.eta0 * cs_.x));
+  const double qx = (Dse + Dne) * ce - (Dsw + Dnw) * cw;
+  const double qy = (Dnw + Dne) * cn - (Dsw + Dse) * cs;
+  return fma(g.hinv_dx2, qx, g.hinv_dy2 * qy);
+}
+
 // D on every dual node of the tile -> sD (0 on nodes outside the glacier's dual grid).
 template <int LM>
 __device__ __forceinline__ void nodes_forward(const GDev& g, const LawDev& L, const double* __restrict__ Afield, int i0,
-                                              int j0, const double (*sH)[LDW], const double (*sS)[LDW],
-                                              double (*sD)[LDN]) {
+                                              int j0, const double2 (*sHS)[LDW], double (*sD)[LDN]) {
   for (int idx = threadIdx.x; idx < NNODE; idx += NT) {
     const int b = idx / (TX + 1), a = idx - b * (TX + 1);
     const int gi = i0 - 1 + a, gj = j0 - 1 + b;
     double D = 0.0;
     if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
-      const double s00 = sS[b][a], s10 = sS[b][a + 1], s01 = sS[b + 1][a], s11 = sS[b + 1][a + 1];
-      const double gx = 0.5 * ((s10 - s00) * g.inv_dx + (s11 - s01) * g.inv_dx);
-      const double gy = 0.5 * ((s01 - s00) * g.inv_dy + (s11 - s10) * g.inv_dy);
-      const double Hb = 0.25 * (sH[b][a] + sH[b][a + 1] + sH[b + 1][a] + sH[b + 1][a + 1]);
+      double gx, gy, Hb;
+      node_geom<LDW>(g, &sHS[b][a], gx, gy, Hb);
       const double gS2 = gx * gx + gy * gy;
       double An = g.A;
       if (g.use_Afield) An = Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
@@ -466,22 +562,9 @@ __device__ __forceinline__ void nodes_forward(const GDev& g, const LawDev& L, co
 __device__ __forceinline__ double clampf(double e, double up, double lo) { return fmax(fmin(e, up), lo); }
 
 // dH/dt of the cell at halo coordinates (c, r); caller guarantees the cell is interior.
-__device__ __forceinline__ double cell_rhs(const GDev& g, int c, int r, const double (*sH)[LDW],
-                                           const double (*sS)[LDW], const double (*sD)[LDN]) {
-  const double S0 = sS[r][c], H0 = sH[r][c];
-  const double ex = g.eta0 * g.inv_dx, ey = g.eta0 * g.inv_dy;
-  const double Dsw = sD[r - 1][c - 1], Dse = sD[r - 1][c], Dnw = sD[r][c - 1], Dne = sD[r][c];
-  const double He = sH[r][c + 1], Hw = sH[r][c - 1], Hn = sH[r + 1][c], Hs = sH[r - 1][c];
-  const double e_e = clampf((sS[r][c + 1] - S0) * g.inv_dx, (g.eta0 * He) * g.inv_dx, -(g.eta0 * H0) * g.inv_dx);
-  const double e_w = clampf((S0 - sS[r][c - 1]) * g.inv_dx, (g.eta0 * H0) * g.inv_dx, -(g.eta0 * Hw) * g.inv_dx);
-  const double e_n = clampf((sS[r + 1][c] - S0) * g.inv_dy, (g.eta0 * Hn) * g.inv_dy, -(g.eta0 * H0) * g.inv_dy);
-  const double e_s = clampf((S0 - sS[r - 1][c]) * g.inv_dy, (g.eta0 * H0) * g.inv_dy, -(g.eta0 * Hs) * g.inv_dy);
-  (void)ex; (void)ey;
-  const double Fe = -(0.5 * (Dse + Dne)) * e_e;
-  const double Fw = -(0.5 * (Dsw + Dnw)) * e_w;
-  const double Fn = -(0.5 * (Dnw + Dne)) * e_n;
-  const double Fs = -(0.5 * (Dsw + Dse)) * e_s;
-  return -((Fe - Fw) * g.inv_dx + (Fn - Fs) * g.inv_dy);
+__device__ __forceinline__ double cell_rhs(const GDev& g, int c, int r, const double2 (*sHS)[LDW],
+                                           const double (*sD)[LDN]) {
+  return cell_div<LDW, LDN>(g, &sHS[r][c], &sD[r][c]);
 }
 
 // =====================================================================================
@@ -490,16 +573,15 @@ __device__ __forceinline__ double cell_rhs(const GDev& g, int c, int r, const do
 template <int LM>
 __global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __restrict__ U, double* __restrict__ dH,
                                              int tile_base) {
-  __shared__ double sH[TY + 2][LDW];
-  __shared__ double sS[TY + 2][LDW];
+  __shared__ double2 sHS[TY + 2][LDW];
   __shared__ double sD[TY + 1][LDN];
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double own[RPT];
-  load_tile_HS(U, P.B, g, i0, j0, sH, sS, own);
+  load_tile_HS2(U, P.B, g, i0, j0, sHS, own);
   __syncthreads();
-  nodes_forward<LM>(g, L, P.Afield, i0, j0, sH, sS, sD);
+  nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
@@ -508,7 +590,7 @@ __global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __
     const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
     if (gi < g.nx && gj < g.ny) {
       double k = 0.0;
-      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs(g, tx + 1, r, sH, sS, sD);
+      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs(g, tx + 1, r, sHS, sD);
       dH[g.off + gi + (long long)g.nx * gj] = k;
     }
   }
@@ -528,8 +610,7 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
                                                  double* __restrict__ Udst, double* __restrict__ S2,
                                                  double* __restrict__ S3, double* __restrict__ E, double abstol,
                                                  double reltol) {
-  __shared__ double sH[TY + 2][LDW];
-  __shared__ double sS[TY + 2][LDW];
+  __shared__ double2 sHS[TY + 2][LDW];
   __shared__ double sD[TY + 1][LDN];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x];
@@ -541,9 +622,9 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
   const double* __restrict__ X = Usrc;
   if (STAGE == 1 && !gs->accepted) X = S3;  // rejected step: restart from uprev
   double own[RPT];
-  load_tile_HS(X, P.B, g, i0, j0, sH, sS, own);
+  load_tile_HS2(X, P.B, g, i0, j0, sHS, own);
   __syncthreads();
-  nodes_forward<LM>(g, L, P.Afield, i0, j0, sH, sS, sD);
+  nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
@@ -556,7 +637,7 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
     if (gi < g.nx && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
       double k = 0.0;
-      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs(g, tx + 1, r, sH, sS, sD);
+      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs(g, tx + 1, r, sHS, sD);
       const double u = own[m];
       const double dtk = dt * k;
       if (STAGE == 1) {
@@ -602,7 +683,10 @@ struct CtrlArgs {
   int adaptive;
   double fixed_dt;
   int* n_active;
-  int next_cur;  // ping-pong buffer that holds u_new of this step
+  int next_cur;  // ping-pong buffer that holds u_new of this step; -1: flip the glacier's own `cur`
+  const double* errpart;  // per-tile error partials: errpart[stride * tile]
+  int stride;
+  int fused;              // partials are indexed by the fused-step tile table
 };
 
 #ifdef ODINN_MISC_KERNELS
@@ -615,7 +699,10 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   }
   const GDev g = P.gd[gidx];
   double s = 0.0;
-  for (int k = threadIdx.x; k < g.ntiles; k += 64) s += P.part[4 * (long long)(g.tile0 + k)];
+  {
+    const int t0 = C.fused ? g.tile0F : g.tile0, nt = C.fused ? g.ntilesF : g.ntiles;
+    for (int k = threadIdx.x; k < nt; k += 64) s += C.errpart[(long long)C.stride * (t0 + k)];
+  }
   // fixed-shape tree: lane l holds sum of tiles l, l+64, ... ; then butterfly
   s = wave_sum(s);
   if (threadIdx.x != 0) return;
@@ -639,7 +726,7 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   if (accept) {
     gs->naccept++;
     gs->accepted = 1;
-    gs->cur = C.next_cur;
+    gs->cur = C.next_cur >= 0 ? C.next_cur : 1 - gs->cur;
     if (gs->clipped) {
       t = C.tstops[gs->istop];
       gs->at_stop = 1;

@@ -1,0 +1,163 @@
+// sia2d_fused.hpp -- one whole RDPK3Sp35 step in ONE kernel (temporal fusion of the 5 stages).
+//
+// The per-stage path (k_rk_stage) is HBM-bound: 264 B/cell per step.  Here a workgroup owns a
+// 64x32 output tile, loads its (64+10)x(32+10) halo region of u and B ONCE, keeps Hc = max(u,0)
+// and S = B+Hc of the region in LDS and the per-cell 3S*+ registers (u, tmp, uprev, utilde, B)
+// in VGPRs of the owning thread, and runs the five stages on regions shrinking by one ring per
+// stage.  HBM traffic drops to ~24 B/cell per step (read u,B; write u'); the price is ~1.3x
+// redundant stencil work in the halo, which the otherwise idle fp64 VALU absorbs.  A rejected
+// step needs no uprev copy: the kernel reads U[cur] and writes U[1-cur]; the controller flips
+// `cur` only on acceptance.  Arithmetic per cell is the same expression sequence as k_rk_stage.
+#pragma once
+#include "sia2d_device.hpp"
+
+namespace odinn {
+
+// meta[m]: bits 0-7 ring index of the cell inside the region (distance to the region border,
+// 0 for slots past the region), bit 8: cell inside the glacier grid, bit 9: interior cell.
+template <int S, int LM>
+__device__ __forceinline__ void fused_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield, int gi0,
+                                            int gj0, double dt, double2* sHS, double* sD,
+                                            const int (&off)[FCPT], const int (&meta)[FCPT], double (&u)[FCPT],
+                                            double (&tmp)[FCPT], const double (&up)[FCPT], double (&E)[FCPT],
+                                            const double (&bb)[FCPT]) {
+  // ---- nodes needed by region_S: a in [S-1, FRX-S), b in [S-1, FRY-S) ----------------------
+  constexpr int nxs = FRX - 2 * S + 1, nys = FRY - 2 * S + 1;
+  for (int idx = threadIdx.x; idx < nxs * nys; idx += FNT) {
+    const int bq = idx / nxs;
+    const int a = S - 1 + (idx - bq * nxs), b = S - 1 + bq;
+    const int gi = gi0 + a, gj = gj0 + b;
+    const int o = b * FLD + a;
+    double D = 0.0;
+    if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
+      double gx, gy, Hb;
+      node_geom<FLD>(g, sHS + o, gx, gy, Hb);
+      const double gS2 = gx * gx + gy * gy;
+      double An = g.A;
+      if (g.use_Afield) An = Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+      double al, be, sp;
+      D = node_D<false, LM>(g, L, Hb, gS2, An, al, be, sp);
+    }
+    sD[o] = D;
+  }
+  __syncthreads();
+  // ---- cells of region_S owned by this thread -----------------------------------------------
+  constexpr int s = S - 1;
+  constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
+#pragma unroll
+  for (int m = 0; m < FCPT; ++m) {
+    if ((meta[m] & 0xff) >= S && (meta[m] & 0x100)) {
+      double k = 0.0;
+      if (meta[m] & 0x200) k = cell_div<FLD, FLD>(g, sHS + off[m], sD + off[m]);
+      const double dtk = dt * k;
+      const double uo = u[m];
+      double un;
+      if (S == 1) {
+        un = fma(bt, dtk, uo);
+        E[m] = bh * dtk;
+      } else {
+        const double t = fma(dl, uo, tmp[m]);
+        un = fma(g1, uo, g2 * t);
+        if (S >= 4) un = fma(g3, up[m], un);
+        un = fma(bt, dtk, un);
+        if (dl != 0.0) tmp[m] = t;
+        E[m] = fma(bh, dtk, E[m]);
+      }
+      u[m] = un;
+    }
+  }
+  __syncthreads();  // every read of sH/sS of this stage is done
+  if (S < 5) {
+#pragma unroll
+    for (int m = 0; m < FCPT; ++m) {
+      if ((meta[m] & 0xff) >= S) {
+        const double hc = u[m] > 0.0 ? u[m] : 0.0;
+        sHS[off[m]] = make_double2(hc, bb[m] + hc);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int LM>
+__global__ __launch_bounds__(FNT, (FNT == 512 ? 4 : 4)) void k_rk_fused(Pools P, LawDev L, const int4* __restrict__ tilesF,
+                                                  double* __restrict__ U0, double* __restrict__ U1,
+                                                  double* __restrict__ partF, double abstol, double reltol) {
+  __shared__ double2 sHS[FRY][FLD];
+  __shared__ double sD[FRY][FLD];
+  __shared__ double red[FNW];
+  const int4 t4 = tilesF[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  if (gs->done) return;
+  const GDev g = P.gd[t4.x];
+  const double dt = gs->dt;
+  const double* __restrict__ src = gs->cur ? U1 : U0;
+  double* __restrict__ dst = gs->cur ? U0 : U1;
+  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOY - FH;
+  double u[FCPT], tmp[FCPT], up[FCPT], E[FCPT], bb[FCPT];
+  int off[FCPT], meta[FCPT];
+  double2* pHS = &sHS[0][0];
+  double* pD = &sD[0][0];
+#pragma unroll
+  for (int m = 0; m < FCPT; ++m) {
+    const int idx = threadIdx.x + FNT * m;
+    const int r = idx / FRX, c = idx - r * FRX;
+    double h = 0.0, b = 0.0;
+    int mt = 0;
+    off[m] = r * FLD + c;
+    if (idx < FNC) {
+      const int gi = gi0 + c, gj = gj0 + r;
+      int ring = min(min(c, FRX - 1 - c), min(r, FRY - 1 - r));
+      if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny) {
+        const long long id = g.off + gi + (long long)g.nx * gj;
+        h = src[id];
+        b = P.B[id];
+        mt = 0x100;
+        if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) mt |= 0x200;
+      }
+      mt |= ring;
+      const double hc = h > 0.0 ? h : 0.0;
+      pHS[off[m]] = make_double2(hc, b + hc);
+    } else {
+      off[m] = 0;
+    }
+    meta[m] = mt;
+    u[m] = h; tmp[m] = h; up[m] = h; E[m] = 0.0; bb[m] = b;
+  }
+  __syncthreads();
+  fused_stage<1, LM>(g, L, P.Afield, gi0, gj0, dt, pHS, pD, off, meta, u, tmp, up, E, bb);
+  fused_stage<2, LM>(g, L, P.Afield, gi0, gj0, dt, pHS, pD, off, meta, u, tmp, up, E, bb);
+  fused_stage<3, LM>(g, L, P.Afield, gi0, gj0, dt, pHS, pD, off, meta, u, tmp, up, E, bb);
+  fused_stage<4, LM>(g, L, P.Afield, gi0, gj0, dt, pHS, pD, off, meta, u, tmp, up, E, bb);
+  fused_stage<5, LM>(g, L, P.Afield, gi0, gj0, dt, pHS, pD, off, meta, u, tmp, up, E, bb);
+  // ---- output tile = region_5: store u', embedded error partial ---------------------------------
+  double errsq = 0.0;
+#pragma unroll
+  for (int m = 0; m < FCPT; ++m) {
+    if ((meta[m] & 0xff) >= FH && (meta[m] & 0x100)) {
+      {
+        const int idx = threadIdx.x + FNT * m;
+        const int r = idx / FRX, c = idx - r * FRX;
+        const int gi = gi0 + c, gj = gj0 + r;
+        dst[g.off + gi + (long long)g.nx * gj] = u[m];
+        const double err = (u[m] - up[m]) - E[m];
+        const double sk = abstol + fmax(fabs(up[m]), fabs(u[m])) * reltol;
+        const double q = err / sk;
+        errsq = fma(q, q, errsq);
+      }
+    }
+  }
+  // deterministic block sum over 8 wavefronts
+  errsq = wave_sum(errsq);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = errsq;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < FNW; ++k) s += red[k];
+    partF[t4.w] = s;
+  }
+}
+
+}  // namespace odinn
