@@ -14,31 +14,36 @@
 namespace odinn {
 
 // meta[m]: bits 0-7 ring index of the cell inside the region (distance to the region border,
-// 0 for slots past the region), bit 8: cell inside the glacier grid, bit 9: interior cell.
+// 0 for slots past the region), bit 8: cell inside the glacier grid, bit 9: interior cell,
+// bit 10: the node north-east of the cell exists in the glacier's dual grid,
+// bits 16-23: node ring = min(c+1, r+1, FRX-1-c, FRY-1-r) (the node is needed by stage S iff >= S).
 template <int S, int LM>
 __device__ __forceinline__ void fused_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield, int gi0,
                                             int gj0, double dt, double2* sHS, double* sD,
                                             const int (&off)[FCPT], const int (&meta)[FCPT], double (&u)[FCPT],
                                             double (&tmp)[FCPT], const double (&up)[FCPT], double (&E)[FCPT],
                                             const double (&bb)[FCPT]) {
-  // ---- nodes needed by region_S: a in [S-1, FRX-S), b in [S-1, FRY-S) ----------------------
-  constexpr int nxs = FRX - 2 * S + 1, nys = FRY - 2 * S + 1;
-  for (int idx = threadIdx.x; idx < nxs * nys; idx += FNT) {
-    const int bq = idx / nxs;
-    const int a = S - 1 + (idx - bq * nxs), b = S - 1 + bq;
-    const int gi = gi0 + a, gj = gj0 + b;
-    const int o = b * FLD + a;
-    double D = 0.0;
-    if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
-      double gx, gy, Hb;
-      node_geom<FLD>(g, sHS + o, gx, gy, Hb);
-      const double gS2 = gx * gx + gy * gy;
-      double An = g.A;
-      if (g.use_Afield) An = Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
-      double al, be, sp;
-      D = node_D<false, LM>(g, L, Hb, gS2, An, al, be, sp);
+  // ---- nodes needed by region_S: a in [S-1, FRX-S), b in [S-1, FRY-S).  Each thread evaluates
+  //      the node north-east of each of its own cells: no index arithmetic in the loop ---------
+#pragma unroll
+  for (int m = 0; m < FCPT; ++m) {
+    if (((meta[m] >> 16) & 0xff) >= S) {
+      double D = 0.0;
+      if (meta[m] & 0x400) {
+        double gx, gy, Hb;
+        node_geom<FLD>(g, sHS + off[m], gx, gy, Hb);
+        const double gS2 = gx * gx + gy * gy;
+        double An = g.A;
+        if (g.use_Afield) {
+          const int idx = threadIdx.x + FNT * m;
+          const int r = idx / FRX, c = idx - r * FRX;
+          An = Afield[g.offd + (gi0 + c) + (long long)(g.nx - 1) * (gj0 + r)];
+        }
+        double al, be, sp;
+        D = node_D<false, LM>(g, L, Hb, gS2, An, al, be, sp);
+      }
+      sD[off[m]] = D;
     }
-    sD[o] = D;
   }
   __syncthreads();
   // ---- cells of region_S owned by this thread -----------------------------------------------
@@ -116,6 +121,9 @@ __global__ __launch_bounds__(FNT, (FNT == 512 ? 4 : 4)) void k_rk_fused(Pools P,
         if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) mt |= 0x200;
       }
       mt |= ring;
+      const int nring = min(min(c + 1, FRX - 1 - c), min(r + 1, FRY - 1 - r));
+      mt |= nring << 16;
+      if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) mt |= 0x400;
       const double hc = h > 0.0 ? h : 0.0;
       pHS[off[m]] = make_double2(hc, b + hc);
     } else {
