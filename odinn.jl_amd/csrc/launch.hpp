@@ -16,6 +16,9 @@ namespace odinn {
 ODINN_DECL_LM(0)
 ODINN_DECL_LM(1)
 ODINN_DECL_LM(2)
+ODINN_DECL_LM(3)
+ODINN_DECL_LM(4)
+ODINN_DECL_LM(5)
 #undef ODINN_DECL_LM
 
 // k_misc.hip

@@ -169,7 +169,20 @@ struct odinn_batch {
   // law mode of the stencil kernels: 0 integer-power fast path (n==3, C==0 for every glacier),
   // 1 generic pow path, 2 inlined per-node MLP (Y / U laws)
   int lm() const {
-    if (law_kind >= ODINN_LAW_NN_Y) return 2;
+    if (law_kind >= ODINN_LAW_NN_Y) {
+      auto is = [&](int nl, std::initializer_list<int> w, std::initializer_list<int> a) {
+        if (mlp.n_layers != nl) return false;
+        int k = 0;
+        for (int v : w) if (mlp.widths[k++] != v) return false;
+        k = 0;
+        for (int v : a) if (mlp.acts[k++] != v) return false;
+        return true;
+      };
+      if (is(4, {2, 3, 10, 3, 1}, {1, 1, 1, 2})) return LM_NN_DEF;
+      if (is(3, {2, 16, 16, 1}, {1, 1, 2})) return LM_NN_16;
+      if (is(2, {2, 3, 1}, {1, 2})) return LM_NN_LIGHT;
+      return LM_NN;
+    }
     for (const GDev& r : gd)
       if (!r.fast) return 1;
     return 0;
@@ -320,11 +333,9 @@ int down_field(odinn_batch* b, int g, const double* dpool, double* h, bool dual 
 int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */) {
   const Pools P = b->pools(g < 0);
   const int base = g < 0 ? 0 : b->gd[g].tile0, n = g < 0 ? b->ntiles : b->gd[g].ntiles;
-  switch (b->lm()) {
-    case 0: launch_dhdt_lm0(n, b->stream, P, b->lawdev(), U, dH, base); break;
-    case 1: launch_dhdt_lm1(n, b->stream, P, b->lawdev(), U, dH, base); break;
-    default: launch_dhdt_lm2(n, b->stream, P, b->lawdev(), U, dH, base); break;
-  }
+  static void (*const tab[6])(int, hipStream_t, Pools, LawDev, const double*, double*, int) = {
+      launch_dhdt_lm0, launch_dhdt_lm1, launch_dhdt_lm2, launch_dhdt_lm3, launch_dhdt_lm4, launch_dhdt_lm5};
+  tab[b->lm()](n, b->stream, P, b->lawdev(), U, dH, base);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -332,25 +343,21 @@ int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */
 template <int S>
 void launch_stage(odinn_batch* b, const Pools& P, const LawDev& L, const double* src, double* dst, double abstol,
                   double reltol) {
-  switch (b->lm()) {
-    case 0: launch_rk_stage_lm0(S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol); break;
-    case 1: launch_rk_stage_lm1(S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol); break;
-    default: launch_rk_stage_lm2(S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol); break;
-  }
+  static void (*const tab[6])(int, int, hipStream_t, Pools, LawDev, const double*, double*, double*, double*, double*,
+                              double, double) = {launch_rk_stage_lm0, launch_rk_stage_lm1, launch_rk_stage_lm2,
+                                                 launch_rk_stage_lm3, launch_rk_stage_lm4, launch_rk_stage_lm5};
+  tab[b->lm()](S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol);
 }
 void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawDev& L, const AdjArgs& A, int base) {
-  switch (b->lm()) {
-    case 0: launch_vjp_H_lm0(mode, nblk, b->stream, P, L, A, base); break;
-    case 1: launch_vjp_H_lm1(mode, nblk, b->stream, P, L, A, base); break;
-    default: launch_vjp_H_lm2(mode, nblk, b->stream, P, L, A, base); break;
-  }
+  static void (*const tab[6])(int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
+      launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5};
+  tab[b->lm()](mode, nblk, b->stream, P, L, A, base);
 }
 void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L, const ThArgs& A, int base) {
-  switch (b->lm()) {
-    case 0: launch_vjp_theta_lm0(nblk, b->stream, P, L, A, base); break;
-    case 1: launch_vjp_theta_lm1(nblk, b->stream, P, L, A, base); break;
-    default: launch_vjp_theta_lm2(nblk, b->stream, P, L, A, base); break;
-  }
+  static void (*const tab[6])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
+      launch_vjp_theta_lm0, launch_vjp_theta_lm1, launch_vjp_theta_lm2, launch_vjp_theta_lm3, launch_vjp_theta_lm4,
+      launch_vjp_theta_lm5};
+  tab[b->lm()](nblk, b->stream, P, L, A, base);
 }
 
 // one RDPK3Sp35 step for all glaciers: 5 fused stage kernels.  parity p: state in U[p].
@@ -376,7 +383,7 @@ int pick_scheme(const odinn_batch* b, int requested) {
     if (e && (e[0] == '1' || e[0] == '2')) s = e[0] - '0';
   }
   if (s == 0) s = 2;
-  if (b->lm() == 2) s = 1;  // inlined-MLP laws: per-stage kernels only (register budget)
+  if (b->lm() >= 2) s = 1;  // inlined-MLP laws: MLP-bound, per-stage kernels (no redundant halo MLP work)
   return s;
 }
 
@@ -1110,7 +1117,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
   const LawDev L = b->lawdev();
   switch (which) {
     case ODINN_TIMED_FUSED_STEP:
-      if (b->lm() == 2) return fail(ODINN_ERR_STATE, "no fused step kernel for inlined-MLP laws");
+      if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "no fused step kernel for inlined-MLP laws");
       return launch_fused_step(b, 1e-6, 1e-8);
     case ODINN_TIMED_SOLVE_STEP:
     case ODINN_TIMED_SOLVE_STEP_STAGED: {

@@ -152,10 +152,71 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return s;
 }
 
+// ---- fast fp64 transcendentals for the activations ---------------------------------------
+// ocml's exp/log1p cost ~140 fp64 instructions each (double-double internals); an MLP node
+// evaluation is dominated by them.  softplus/sigmoid only need exp on (-inf, 0] and log1p on
+// [0, 1]; the routines below are <= 2 ulp there (checked against 40-digit arithmetic) at
+// ~20 / ~28 instructions.
+__device__ __forceinline__ double fast_div(double n, double d) {  // d normal, <= 1 ulp
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  const double q = n * r;
+  return fma(fma(-d, q, n), r, q);
+}
+__device__ __forceinline__ double exp_nonpos(double y) {  // y <= 0
+  y = fmax(y, -750.0);
+  const double n = rint(y * 1.4426950408889634);
+  double r = fma(n, -6.93147180369123816490e-01, y);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;          // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);
+  p = fma(p, r, 2.505210838544172e-08);
+  p = fma(p, r, 2.755731922398589e-07);
+  p = fma(p, r, 2.7557319223985893e-06);
+  p = fma(p, r, 2.48015873015873e-05);
+  p = fma(p, r, 1.984126984126984e-04);
+  p = fma(p, r, 1.3888888888888889e-03);
+  p = fma(p, r, 8.333333333333333e-03);
+  p = fma(p, r, 4.1666666666666664e-02);
+  p = fma(p, r, 1.6666666666666666e-01);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+__device__ __forceinline__ double log1p_01(double t) {  // 0 <= t <= 1
+  const bool big = t > 0.41421356237309503;
+  const double num = big ? t - 1.0 : t;
+  const double den = big ? t + 3.0 : t + 2.0;
+  const double s_ = fast_div(num, den);  // log1p(t) = [ln 2 +] 2 atanh(s)
+  const double z = s_ * s_;
+  double p = 1.0 / 23.0;
+  p = fma(p, z, 1.0 / 21.0);
+  p = fma(p, z, 1.0 / 19.0);
+  p = fma(p, z, 1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  p = p * z;
+  double r = fma(s_, p, s_);
+  r = r + r;
+  return big ? r + 0.6931471805599453 : r;
+}
+__device__ __forceinline__ double softplus_f(double x) { return log1p_01(exp_nonpos(-fabs(x))) + fmax(x, 0.0); }
+__device__ __forceinline__ double sigmoid_f(double x) {
+  const double t = exp_nonpos(-fabs(x));
+  return fast_div(x >= 0.0 ? 1.0 : t, 1.0 + t);
+}
+
 __device__ __forceinline__ double act_f(int code, double x) {
   switch (code) {
-    case 1: return log1p(exp(-fabs(x))) + fmax(x, 0.0);                 // NNlib.softplus
-    case 2: { double t = exp(-fabs(x)); return x >= 0.0 ? 1.0 / (1.0 + t) : t / (1.0 + t); }
+    case 1: return softplus_f(x);  // NNlib.softplus = log1p(exp(-|x|)) + relu(x)
+    case 2: return sigmoid_f(x);
     case 3: { const double c = 0.7978845608028654; return 0.5 * x * (1.0 + tanh(c * (x + 0.044715 * x * x * x))); }
     case 4: return tanh(x);
     case 5: return fmax(x, 0.0);
@@ -164,8 +225,8 @@ __device__ __forceinline__ double act_f(int code, double x) {
 }
 __device__ __forceinline__ double dact_f(int code, double x) {
   switch (code) {
-    case 1: { double t = exp(-fabs(x)); return x >= 0.0 ? 1.0 / (1.0 + t) : t / (1.0 + t); }
-    case 2: { double t = exp(-fabs(x)); double s = x >= 0.0 ? 1.0 / (1.0 + t) : t / (1.0 + t); return s * (1.0 - s); }
+    case 1: return sigmoid_f(x);
+    case 2: { const double s = sigmoid_f(x); return s * (1.0 - s); }
     case 3: { const double c = 0.7978845608028654; double u = c * (x + 0.044715 * x * x * x); double th = tanh(u);
               double du = c * (1.0 + 3.0 * 0.044715 * x * x); return 0.5 * (1.0 + th) + 0.5 * x * (1.0 - th * th) * du; }
     case 4: { double th = tanh(x); return 1.0 - th * th; }
@@ -176,7 +237,7 @@ __device__ __forceinline__ double dact_f(int code, double x) {
 __device__ __forceinline__ double postscale_f(const LawDev& L, double y) {
   switch (L.post_kind) {
     case 1: return L.post_lo + (L.post_hi - L.post_lo) * y;
-    case 2: return L.post_hi * exp((y - 1.0) / y);
+    case 2: return L.post_hi * exp_nonpos((y - 1.0) / y);  // y in (0, 1]
     case 3: return L.post_hi * y;
     default: return y;
   }
@@ -184,7 +245,7 @@ __device__ __forceinline__ double postscale_f(const LawDev& L, double y) {
 __device__ __forceinline__ double dpostscale_f(const LawDev& L, double y) {
   switch (L.post_kind) {
     case 1: return L.post_hi - L.post_lo;
-    case 2: return L.post_hi * exp((y - 1.0) / y) / (y * y);
+    case 2: return L.post_hi * exp_nonpos((y - 1.0) / y) / (y * y);
     case 3: return L.post_hi;
     default: return 1.0;
   }
@@ -291,16 +352,77 @@ inline __device__ __noinline__ void mlp_grad(const LawDev& L, double x0, double 
   }
 }
 
+// ---- law modes of the stencil kernels ---------------------------------------------------------
+// 0 integer-power A law, 1 generic-pow A law, 2 inlined MLP with run-time architecture,
+// 3..5 inlined MLP with a compile-time architecture (fully unrolled, activations in registers):
+//   3: 2 -> 3 -> 10 -> 3 -> 1, softplus x3 + sigmoid   (build_default_NN, ML_utils.jl:31-36)
+//   4: 2 -> 16 -> 16 -> 1,     softplus x2 + sigmoid   (BASELINE configs[2], "2 layers x 16 units")
+//   5: 2 -> 3 -> 1,            softplus + sigmoid      (test_mode light net, ML_utils.jl:26-29)
+constexpr int LM_FAST = 0, LM_POW = 1, LM_NN = 2, LM_NN_DEF = 3, LM_NN_16 = 4, LM_NN_LIGHT = 5;
+constexpr bool lm_is_nn(int lm) { return lm >= LM_NN; }
+
+struct ArchDef   { static constexpr int NL = 4, MAXW = 10; static constexpr int W[5] = {2, 3, 10, 3, 1}; static constexpr int A[4] = {1, 1, 1, 2}; };
+struct Arch16    { static constexpr int NL = 3, MAXW = 16; static constexpr int W[4] = {2, 16, 16, 1};   static constexpr int A[3] = {1, 1, 2}; };
+struct ArchLight { static constexpr int NL = 2, MAXW = 3;  static constexpr int W[3] = {2, 3, 1};        static constexpr int A[2] = {1, 2}; };
+
+template <class AR>
+constexpr int arch_off(int l) {
+  int o = 0;
+  for (int k = 0; k < l; ++k) o += AR::W[k + 1] * (AR::W[k] + 1);
+  return o;
+}
+
+// softplus and sigmoid share t = exp(-|x|)
+template <int CODE>
+__device__ __forceinline__ double act_c(double x) {
+  if (CODE == 1) return softplus_f(x);
+  if (CODE == 2) return sigmoid_f(x);
+  return act_f(CODE, x);
+}
+
+template <class AR, int l>
+__device__ __forceinline__ void mlp_layer_fixed(const double* __restrict__ th, const double (&hin)[AR::MAXW],
+                                                double (&hout)[AR::MAXW]) {
+  constexpr int nin = AR::W[l], nout = AR::W[l + 1], off = arch_off<AR>(l);
+#pragma unroll
+  for (int o = 0; o < nout; ++o) {
+    double acc = th[off + nin * nout + o];
+#pragma unroll
+    for (int i = 0; i < nin; ++i) acc = fma(th[off + o + nout * i], hin[i], acc);
+    hout[o] = act_c<AR::A[l]>(acc);
+  }
+}
+
+template <class AR>
+__device__ __forceinline__ double mlp_eval_fixed(const LawDev& L, double x0, double x1) {
+  double h0[AR::MAXW], h1[AR::MAXW];
+  h0[0] = L.has_pre ? (x0 - L.pre_lo[0]) * L.pre_inv[0] - 0.5 : x0;
+  h0[1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
+  const double* __restrict__ th = L.theta;
+  mlp_layer_fixed<AR, 0>(th, h0, h1);
+  if constexpr (AR::NL > 1) mlp_layer_fixed<AR, 1>(th, h1, h0);
+  if constexpr (AR::NL > 2) mlp_layer_fixed<AR, 2>(th, h0, h1);
+  if constexpr (AR::NL > 3) mlp_layer_fixed<AR, 3>(th, h1, h0);
+  return postscale_f(L, (AR::NL & 1) ? h1[0] : h0[0]);
+}
+
+template <int LM>
+__device__ __forceinline__ double mlp_eval_lm(const LawDev& L, double x0, double x1) {
+  if constexpr (LM == LM_NN_DEF) return mlp_eval_fixed<ArchDef>(L, x0, x1);
+  else if constexpr (LM == LM_NN_16) return mlp_eval_fixed<Arch16>(L, x0, x1);
+  else if constexpr (LM == LM_NN_LIGHT) return mlp_eval_fixed<ArchLight>(L, x0, x1);
+  else return mlp_eval_any(L, x0, x1);
+}
+
 // ---- diffusivity on one dual node ---------------------------------------------------
 // Returns D.  For the adjoint (ADJ) also alpha = dD/dHbar and beta (the reference's
 // "dD/dgradH", i.e. (dD/d|gradS|)/|gradS| for the closed forms) -- target_A.jl:16-62,
 // target_D_hybrid.jl:22-96,168-208, target_D_pure.jl:78-137 -- and `spat`, the spatial
 // factor of dD/dtheta (target_A.jl:71-72, target_D_hybrid.jl:117-118, target_D_pure.jl:142).
-constexpr int LM_FAST = 0, LM_POW = 1, LM_NN = 2;
 template <bool ADJ, int LM>
 __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double Hb, double gS2, double Anode,
                                          double& alpha, double& beta, double& spat) {
-  if (LM != LM_NN) {  // A-type laws (scalar or field A)
+  if (!lm_is_nn(LM)) {  // A-type laws (scalar or field A)
     if (LM == LM_FAST) {
       const double H2 = Hb * Hb, H4 = H2 * H2;
       const double AG = Anode * g.Gam;
@@ -333,8 +455,11 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
     return D;
   }
   const double gS = sqrt(gS2);
+  // On ice-free nodes (Hbar == 0) D, alpha, beta and the theta-weight vanish identically
+  // (every term carries a positive power of Hbar), so the MLP is not evaluated there.
+  const bool ice = Hb > 0.0;
   if (L.kind == 3) {  // Y law, :D_hybrid
-    const double Y = mlp_eval_any(L, g.T, Hb);
+    const double Y = ice ? mlp_eval_lm<LM>(L, g.T, Hb) : 0.0;
     const double geo = g.Gam * pow(Hb, g.nH + 2.0) * pow(gS, g.nS - 1.0);
     double D = Y * geo;
     double hs = 0.0, sp1 = 0.0;
@@ -345,7 +470,7 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
     }
     if (ADJ) {
       const double dH = 1e-4;  // target_D_hybrid.jl:58
-      const double Yp = mlp_eval_any(L, g.T, Hb + dH);
+      const double Yp = ice ? mlp_eval_lm<LM>(L, g.T, Hb + dH) : 0.0;
       const double slide = g.Sc != 0.0 ? g.Sc * hs * sp1 : 0.0;
       alpha = (g.nH + 2.0) * Y * g.Gam * pow(Hb, g.nH + 1.0) * pow(gS, g.nS - 1.0) +
               ((slide + Yp * geo) - (slide + Y * geo)) / dH;
@@ -359,16 +484,20 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
     return D;
   }
   // U law, :D   D = Hbar * U(Hbar, gradS)
-  const double U = mlp_eval_any(L, Hb, gS);
+  if (!ice) {
+    if (ADJ) { alpha = 0.0; beta = 0.0; spat = 0.0; }
+    return 0.0;
+  }
+  const double U = mlp_eval_lm<LM>(L, Hb, gS);
   if (ADJ) {
     const double dH = 1e-4, dS = 1e-6;  // target_D_pure.jl:109,125
-    const double Dp = mlp_eval_any(L, Hb + dH, gS) * (Hb + dH);
-    const double Dm = mlp_eval_any(L, Hb - dH, gS) * (Hb - dH);
-    alpha = Hb > 0.0 ? (Dp - Dm) / (2.0 * dH) : 0.0;
-    const double Ep = mlp_eval_any(L, Hb, gS + dS) * Hb;
-    const double Em = mlp_eval_any(L, Hb, gS - dS) * Hb;
+    const double Dp = mlp_eval_lm<LM>(L, Hb + dH, gS) * (Hb + dH);
+    const double Dm = mlp_eval_lm<LM>(L, Hb - dH, gS) * (Hb - dH);
+    alpha = (Dp - Dm) / (2.0 * dH);
+    const double Ep = mlp_eval_lm<LM>(L, Hb, gS + dS) * Hb;
+    const double Em = mlp_eval_lm<LM>(L, Hb, gS - dS) * Hb;
     beta = (Ep - Em) / (2.0 * dS);
-    spat = Hb > 0.0 ? Hb : 0.0;
+    spat = Hb;
   }
   return Hb * U;
 }
@@ -995,7 +1124,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const double scale = A.scales ? A.scales[t4.x] : 1.0;
   double acc = 0.0;
-  constexpr bool nn_node = (LM == LM_NN);
+  constexpr bool nn_node = lm_is_nn(LM);
   const long long gstride = (long long)gridDim.x * NT;
   double* gth = A.gscratch ? A.gscratch + ((long long)blockIdx.x * NT + threadIdx.x) : nullptr;
   if (nn_node)
