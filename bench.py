@@ -5,18 +5,23 @@ Workload (BASELINE.json configs[4], the config the scaling metric is quoted on; 
 share fits one GPU): every GPU holds 8 synthetic 1024x1024 fp64 ice caps (per-glacier random
 radius, bed phase and A in [1e-18, 4e-17], seed 1234 + global glacier index), resident in
 HBM.  A "step" is one pass of the hot path over that batch exactly as odinn_solve launches
-it: one RDPK3Sp35 time step = 5 fused RHS+stage kernels + the controller (error-norm
+it: one RDPK3Sp35 time step (5 RHS + stage updates per cell) + the controller (error-norm
 reduction, PID) + the post-step kernel.  One cell-step = one cell through one fused
-RHS + stage update, so a step is 5 * cells cell-steps.
+RHS + stage update, so a step is 5 * cells cell-steps.  Two schedules of the same arithmetic
+exist: the default runs the five stages temporally fused in ONE kernel
+(k_rk_fused, ~24 B/cell of HBM traffic per step, fp64-VALU-bound); scheme 1 runs five per-stage
+kernels (k_rk_stage, 264 B/cell per step, HBM-bound).  `value` is the default schedule; both
+are timed and reported.
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU; glaciers shard with no
      data-path collective -> weak scaling; the only collective of the path, the all-reduce
      of [loss, dtheta], is exercised in the untimed grad-eval leg)
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (an interior RK stage,
-56 algorithmic B/cell: read u,B,tmp,utilde; write u',tmp,utilde), timed live with HIP events
-on the library's own stream.  `cpu_baseline` is the oracle's C restatement
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the timed region
+(k_rk_fused: 24 algorithmic B/cell per launch -- read u,B; write u'), `roofline_per_stage` for
+the dominant kernel of the HBM-bound schedule (k_rk_stage<2>: 56 B/cell -- read u,B,tmp,utilde;
+write u',tmp,utilde); both timed live with HIP events on the library's own stream.  `cpu_baseline` is the oracle's C restatement
 (oracle/sia2d_oracle.c, OpenMP) stepping ONE of the 1024^2 glaciers on the host cores.
 """
 import argparse
@@ -36,6 +41,9 @@ B_PER_CELL_STAGE2 = 56.0  # interior stage: R u,B,tmp,utilde  W u',tmp,utilde
 B_PER_CELL_STEP = 264.0  # 40 + 56 + 56 + 64 + 48 over the five stages
 B_PER_CELL_DHDT = 24.0
 B_PER_CELL_VJPH = 32.0
+B_PER_CELL_FUSED = 24.0  # fused step kernel: R u,B  W u'
+FLOP_PER_CELL_STAGE = 64.0  # algorithmic fp64 flops of one RHS + stage update
+FP64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector (= matrix) peak, vendor figure
 
 
 def make_glacier(n, gidx, dx=100.0):
@@ -117,19 +125,27 @@ def main():
     cellsteps = 5.0 * cells * args.steps * world
     value = cellsteps / elapsed
 
-    # ---- roofline of the dominant kernel (HIP events on the library stream) -------------
+    # ---- rooflines (HIP events on the library stream) --------------------------------------
+    ms_fused = b.time_kernel(T.TIMED_FUSED_STEP, iters=30, warmup=5)
     ms_stage = b.time_kernel(T.TIMED_RK_STAGE2, iters=50, warmup=5)
     ach = B_PER_CELL_STAGE2 * cells / (ms_stage * 1e-3) / 1e9
+    ach_fused = B_PER_CELL_FUSED * cells / (ms_fused * 1e-3) / 1e9
     ms_step = b.time_kernel(T.TIMED_RK_STEP, iters=20, warmup=3)
+    ms_solve_staged = b.time_kernel(T.TIMED_SOLVE_STEP_STAGED, iters=20, warmup=3)
     ms_dhdt = b.time_kernel(T.TIMED_DHDT, iters=50, warmup=5)
     ms_vjp = b.time_kernel(T.TIMED_VJP_H, iters=20, warmup=3)
+    ms_vjpt = b.time_kernel(T.TIMED_VJP_THETA, iters=20, warmup=3)
     aux = {
-        "rk_step_ms": ms_step,
-        "rk_step_GBs": B_PER_CELL_STEP * cells / (ms_step * 1e-3) / 1e9,
+        "per_stage_schedule_ms_per_step": ms_solve_staged,
+        "per_stage_schedule_cellsteps_per_s": 5.0 * cells * world / (ms_solve_staged * 1e-3),
+        "rk_5stage_kernels_ms": ms_step,
+        "rk_5stage_kernels_GBs": B_PER_CELL_STEP * cells / (ms_step * 1e-3) / 1e9,
         "dhdt_ms": ms_dhdt,
         "dhdt_GBs": B_PER_CELL_DHDT * cells / (ms_dhdt * 1e-3) / 1e9,
         "vjp_H_ms": ms_vjp,
         "vjp_H_GBs": B_PER_CELL_VJPH * cells / (ms_vjp * 1e-3) / 1e9,
+        "vjp_theta_ms": ms_vjpt,
+        "vjp_theta_GBs": 24.0 * cells / (ms_vjpt * 1e-3) / 1e9,
     }
 
     # ---- untimed extra: grad-eval/s (forward solve + discrete adjoint + all-reduce) ------
@@ -151,6 +167,13 @@ def main():
         st = b.last_stats
         aux["grad_evals_per_s"] = G * world / tg
         aux["grad_eval_sample"] = f"{G} glaciers/GPU, 3 monthly snapshots, reltol 1e-6, {st[0].naccept} RK steps (glacier 0)"
+        # BASELINE configs[2]: same grids with a 2-layer/16-unit NN_theta law inlined per dual node
+        mlp16 = odinn.MLPSpec([2, 16, 16, 1], [odinn.ACT_SOFTPLUS, odinn.ACT_SOFTPLUS, odinn.ACT_SIGMOID],
+                              [(-25.0, 0.0), (0.0, 500.0)], odinn.POST_EXPMAX, 0.0, ph.maxA)
+        b.set_law(odinn.LAW_NN_Y, mlp16, np.random.default_rng(1234).uniform(-0.5, 0.5, mlp16.n_params))
+        ms_nn = b.time_kernel(T.TIMED_SOLVE_STEP, iters=3, warmup=1)
+        aux["nn_inlined_2x16_ms_per_step"] = ms_nn
+        aux["nn_inlined_2x16_cellsteps_per_s"] = 5.0 * cells * world / (ms_nn * 1e-3)
         b.set_law(odinn.LAW_CONST_A)
 
     # ---- CPU baseline (rank 0, N = 1 only): oracle C restatement on the host cores -------
@@ -181,16 +204,17 @@ def main():
         except Exception as e:  # the baseline is reported, never required
             cpu = {"value": None, "unit": "cell-steps/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
 
-    traffic = None
-    try:  # HBM bytes per launch of the dominant kernel from the committed PMC passes (same workload only)
+    traffic = traffic_stage = None
+    try:  # HBM bytes per launch from the committed PMC passes (same workload only)
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
         if pm.get("workload_cells") == cells:
-            traffic = pm["k_rk_stage<2,0>"]["hbm_bytes_per_launch"]
+            traffic_stage = pm["k_rk_stage<2,0>"]["hbm_bytes_per_launch"]
+            traffic = pm.get("k_rk_fused<0>", {}).get("hbm_bytes_per_launch")
     except Exception:
-        traffic = None
+        pass
     if rank == 0:
         out = {
-            "metric": "cell-steps/s (forward SIA2D, fused RHS + RDPK3Sp35 stage)",
+            "metric": "cell-steps/s (forward SIA2D, fused RHS + RDPK3Sp35 stage update)",
             "value": value,
             "unit": "cell-steps/s",
             "n_gpus": world,
@@ -204,7 +228,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{G} synthetic {n}x{n} fp64 ice caps per GPU (BASELINE configs[4] per-GPU share), "
-                            "constant A per glacier, one RDPK3Sp35 step = 5 fused stage kernels + controller + post-step",
+                            "constant A per glacier, one RDPK3Sp35 step (5 cell-steps per cell) = RK step kernel + controller + post-step",
                 "glaciers_per_gpu": G,
                 "grid": [n, n],
                 "cells_per_gpu": cells,
@@ -213,13 +237,29 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_rk_stage<2,LM_FAST>",
+                "kernel": "k_rk_fused<LM_FAST> (whole RDPK3Sp35 step, 5 stages temporally fused)",
+                "achieved": ach_fused,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": ach_fused / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; FETCH x2)" if traffic else None,
+                "ms_per_launch": ms_fused,
+                "algorithmic_bytes_per_launch": B_PER_CELL_FUSED * cells,
+                "note": "temporal fusion moved this kernel off the HBM roofline: it is fp64-VALU-bound "
+                        "(see fp64_* below); the HBM-bound schedule of the same arithmetic is in roofline_per_stage",
+                "fp64_TFLOPs": FLOP_PER_CELL_STAGE * 5.0 * cells / (ms_fused * 1e-3) / 1e12,
+                "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS,
+                "fp64_frac": FLOP_PER_CELL_STAGE * 5.0 * cells / (ms_fused * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            },
+            "roofline_per_stage": {
+                "bound": "hbm",
+                "kernel": "k_rk_stage<2,LM_FAST> (one RK stage, scheme 1)",
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE; FETCH x2)" if traffic else None,
+                "traffic": traffic_stage,
                 "ms_per_launch": ms_stage,
                 "algorithmic_bytes_per_launch": B_PER_CELL_STAGE2 * cells,
             },

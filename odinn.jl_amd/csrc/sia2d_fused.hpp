@@ -138,21 +138,30 @@ __global__ __launch_bounds__(FNT, (FNT == 512 ? 4 : 4)) void k_rk_fused(Pools P,
   fused_stage<3, LM>(g, L, P.Afield, gi0, gj0, dt, pHS, pD, off, meta, u, tmp, up, E, bb);
   fused_stage<4, LM>(g, L, P.Afield, gi0, gj0, dt, pHS, pD, off, meta, u, tmp, up, E, bb);
   fused_stage<5, LM>(g, L, P.Afield, gi0, gj0, dt, pHS, pD, off, meta, u, tmp, up, E, bb);
-  // ---- output tile = region_5: store u', embedded error partial ---------------------------------
+  // ---- output tile = region_5: embedded error partial; u' is staged through LDS so that the
+  //      global stores are full, aligned 512-B rows (the region mapping is 74 wide) ------------
   double errsq = 0.0;
+  __syncthreads();  // stage 5 is done with sD
 #pragma unroll
   for (int m = 0; m < FCPT; ++m) {
-    if ((meta[m] & 0xff) >= FH && (meta[m] & 0x100)) {
-      {
-        const int idx = threadIdx.x + FNT * m;
-        const int r = idx / FRX, c = idx - r * FRX;
-        const int gi = gi0 + c, gj = gj0 + r;
-        dst[g.off + gi + (long long)g.nx * gj] = u[m];
+    if ((meta[m] & 0xff) >= FH) {
+      pD[off[m]] = u[m];
+      if (meta[m] & 0x100) {
         const double err = (u[m] - up[m]) - E[m];
         const double sk = abstol + fmax(fabs(up[m]), fabs(u[m])) * reltol;
         const double q = err / sk;
         errsq = fma(q, q, errsq);
       }
+    }
+  }
+  __syncthreads();
+  {
+    const int tx = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const int gi = gi0 + FH + tx;
+#pragma unroll
+    for (int rr = wy; rr < FOY; rr += FNW) {
+      const int gj = gj0 + FH + rr;
+      if (gi < g.nx && gj < g.ny) dst[g.off + gi + (long long)g.nx * gj] = sD[FH + rr][FH + tx];
     }
   }
   // deterministic block sum over 8 wavefronts
