@@ -7,8 +7,8 @@
 #define CAT(a, b) CAT_(a, b)
 namespace odinn {
 void CAT(launch_vjp_H_lm, ODINN_LM)(int mode, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base) {
-  if (mode == 0) hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
-  else hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+  if (mode == 0) hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM>), dim3(nblk), dim3(NTA), 0, st, P, L, A, base);
+  else hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM>), dim3(nblk), dim3(NTA), 0, st, P, L, A, base);
 }
 void CAT(launch_vjp_theta_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base) {
   hipLaunchKernelGGL(k_vjp_theta<ODINN_LM>, dim3(nblk), dim3(NT), 0, st, P, L, A, base);

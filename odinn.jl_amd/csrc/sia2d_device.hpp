@@ -559,14 +559,15 @@ __device__ __forceinline__ void load_tile_HS(const double* __restrict__ U, const
 }
 
 // Interleaved variant for the forward kernels: sHS[r][c] = {max(U,0), B + max(U,0)}.
+template <int NWV = NW>
 __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, const double* __restrict__ B, const GDev& g,
-                                              int i0, int j0, double2 (*sHS)[LDW], double own[RPT]) {
+                                              int i0, int j0, double2 (*sHS)[LDW], double (&own)[TY / NWV]) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
   const bool colok = gi < g.nx;
 #pragma unroll
-  for (int m = 0; m < RPT; ++m) {
-    const int r = 1 + ty + NW * m;
+  for (int m = 0; m < TY / NWV; ++m) {
+    const int r = 1 + ty + NWV * m;
     const int gj = j0 - 1 + r;
     double h = 0.0, b = 0.0;
     if (colok && gj < g.ny) {
@@ -589,7 +590,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
     }
     const double hc = h > 0.0 ? h : 0.0;
     sHS[r][tx + 1] = make_double2(hc, b + hc);
-  } else {
+  } else if (ty < 4) {
     const int l = threadIdx.x - 128;
     if (l < 2 * (TY + 2)) {
       const int r = l >> 1, side = l & 1;
@@ -608,8 +609,9 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
 }
 
 // Same for a third field kept unclamped and masked to the interior (lambda~).
+template <int NWV = NW>
 __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, const GDev& g, int i0, int j0,
-                                              double (*sL)[LDW], double own[RPT]) {
+                                              double (*sL)[LDW], double (&own)[TY / NWV]) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
   auto ld = [&](int gi_, int gj_, double& raw) -> double {
@@ -621,15 +623,15 @@ __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, con
     return 0.0;
   };
 #pragma unroll
-  for (int m = 0; m < RPT; ++m) {
-    const int r = 1 + ty + NW * m;
+  for (int m = 0; m < TY / NWV; ++m) {
+    const int r = 1 + ty + NWV * m;
     sL[r][tx + 1] = ld(gi, j0 - 1 + r, own[m]);
   }
   double dummy;
   if (ty < 2) {
     const int r = ty == 0 ? 0 : TY + 1;
     sL[r][tx + 1] = ld(gi, j0 - 1 + r, dummy);
-  } else {
+  } else if (ty < 4) {
     const int l = threadIdx.x - 128;
     if (l < 2 * (TY + 2)) {
       const int r = l >> 1, c = (l & 1) ? TX + 1 : 0;
@@ -945,6 +947,27 @@ __global__ __launch_bounds__(NT) void k_poststep(Pools P, PostArgs A, double* __
 
 #endif  // ODINN_MISC_KERNELS
 
+// D_adjoint of a dual node (adjoint.jl:99-104) from its own four edges, slopes unscaled:
+//   Da = -(0.5/dx^2) sum_xedges dlam*clamp(dS) - (0.5/dy^2) sum_yedges dlam*clamp(dS)
+// p: {Hc,S} at the node's lower-left cell, pl: lambda~ there; vxl/vxu/vyl/vyr: edge validity.
+template <int LD>
+__device__ __forceinline__ double node_Da(const GDev& g, const double2* p, const double* pl, bool vxl, bool vxu,
+                                          bool vyl, bool vyr, double& gx, double& gy, double& Hb) {
+  const double2 c00 = p[0], c10 = p[1], c01 = p[LD], c11 = p[LD + 1];
+  const double l00 = pl[0], l10 = pl[1], l01 = pl[LD], l11 = pl[LD + 1];
+  const double dxl = c10.y - c00.y, dxu = c11.y - c01.y, dyl = c01.y - c00.y, dyr = c11.y - c10.y;
+  gx = (dxl + dxu) * g.hinv_dx;
+  gy = (dyl + dyr) * g.hinv_dy;
+  Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
+  const double e00 = g.eta0 * c00.x, e10 = g.eta0 * c10.x, e01 = g.eta0 * c01.x, e11 = g.eta0 * c11.x;
+  double ax = 0.0, ay = 0.0;
+  if (vxl) ax = (l10 - l00) * fmax(fmin(dxl, e10), -e00);
+  if (vxu) ax = fma(l11 - l01, fmax(fmin(dxu, e11), -e01), ax);
+  if (vyl) ay = (l01 - l00) * fmax(fmin(dyl, e01), -e00);
+  if (vyr) ay = fma(l11 - l10, fmax(fmin(dyr, e11), -e10), ay);
+  return -fma(g.hinv_dx2, ax, g.hinv_dy2 * ay);
+}
+
 // =====================================================================================
 // K5: discrete H-VJP (adjoint.jl:99-148) in gather form, optionally fused with the
 // reverse explicit-Euler update of gradient.jl:242:
@@ -964,53 +987,46 @@ struct AdjArgs {
   long long ntot;
 };
 
+#ifndef ODINN_NTA
+#define ODINN_NTA 512
+#endif
+constexpr int NTA = ODINN_NTA;   // threads per block of k_vjp_H (its 64 KB of LDS allow 2 blocks/CU:
+constexpr int NWA = NTA / 64;    // 8 wavefronts per block keep 16 waves/CU resident)
+constexpr int RPTA = TY / NWA;
 template <int MODE, int LM>
-__global__ __launch_bounds__(NT) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
-  __shared__ double sH[TY + 2][LDW];
-  __shared__ double sS[TY + 2][LDW];
-  __shared__ double sL[TY + 2][LDW];
-  __shared__ double sD[TY + 1][LDN];
-  __shared__ double sAD[TY + 1][LDN];
-  __shared__ double sBX[TY + 1][LDN];
-  __shared__ double sBY[TY + 1][LDN];
-  __shared__ double red[NW];
+__global__ __launch_bounds__(NTA) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
+  __shared__ double2 sHS[TY + 2][LDW];   // {max(H,0), S}
+  __shared__ double sL[TY + 2][LDW];     // lambda masked to the interior
+  __shared__ double2 sN1[TY + 1][LDN];   // {D, alpha*Da}
+  __shared__ double2 sN2[TY + 1][LDN];   // {beta*gx*Da, beta*gy*Da}
+  __shared__ double red[NWA];
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
-  double ownH[RPT], ownL[RPT];
-  load_tile_HS(A.H, P.B, g, i0, j0, sH, sS, ownH);
-  load_tile_lam(A.lam, g, i0, j0, sL, ownL);
+  double ownH[RPTA], ownL[RPTA];
+  load_tile_HS2<NWA>(A.H, P.B, g, i0, j0, sHS, ownH);
+  load_tile_lam<NWA>(A.lam, g, i0, j0, sL, ownL);
   __syncthreads();
-  for (int idx = threadIdx.x; idx < NNODE; idx += NT) {
+  for (int idx = threadIdx.x; idx < NNODE; idx += NTA) {
     const int b = idx / (TX + 1), a = idx - b * (TX + 1);
     const int gi = i0 - 1 + a, gj = j0 - 1 + b;
     double D = 0.0, AD = 0.0, BX = 0.0, BY = 0.0;
     if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
-      const double s00 = sS[b][a], s10 = sS[b][a + 1], s01 = sS[b + 1][a], s11 = sS[b + 1][a + 1];
-      const double h00 = sH[b][a], h10 = sH[b][a + 1], h01 = sH[b + 1][a], h11 = sH[b + 1][a + 1];
-      const double exl = (s10 - s00) * g.inv_dx, exu = (s11 - s01) * g.inv_dx;
-      const double eyl = (s01 - s00) * g.inv_dy, eyr = (s11 - s10) * g.inv_dy;
-      const double gx = 0.5 * (exl + exu), gy = 0.5 * (eyl + eyr);
-      const double Hb = 0.25 * (h00 + h10 + h01 + h11);
+      double gx, gy, Hb;
+      const double Da = node_Da<LDW>(g, &sHS[b][a], &sL[b][a], gj >= 1, gj + 1 <= g.ny - 2, gi >= 1,
+                                     gi + 1 <= g.nx - 2, gx, gy, Hb);
       const double gS2 = gx * gx + gy * gy;
       double An = g.A;
       if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
       double al, be, sp;
       D = node_D<true, LM>(g, L, Hb, gS2, An, al, be, sp);
-      // D_adjoint of this node (adjoint.jl:99-104) from its own four edges
-      double Da = 0.0;
-      if (gj >= 1)         Da -= 0.5 * ((sL[b][a + 1] - sL[b][a]) * g.inv_dx) * clampf(exl, (g.eta0 * h10) * g.inv_dx, -(g.eta0 * h00) * g.inv_dx);
-      if (gj + 1 <= g.ny - 2) Da -= 0.5 * ((sL[b + 1][a + 1] - sL[b + 1][a]) * g.inv_dx) * clampf(exu, (g.eta0 * h11) * g.inv_dx, -(g.eta0 * h01) * g.inv_dx);
-      if (gi >= 1)         Da -= 0.5 * ((sL[b + 1][a] - sL[b][a]) * g.inv_dy) * clampf(eyl, (g.eta0 * h01) * g.inv_dy, -(g.eta0 * h00) * g.inv_dy);
-      if (gi + 1 <= g.nx - 2) Da -= 0.5 * ((sL[b + 1][a + 1] - sL[b][a + 1]) * g.inv_dy) * clampf(eyr, (g.eta0 * h11) * g.inv_dy, -(g.eta0 * h10) * g.inv_dy);
       AD = al * Da;
-      BX = be * gx * Da;
-      BY = be * gy * Da;
+      const double bd = be * Da;
+      BX = bd * gx;
+      BY = bd * gy;
     }
-    sD[b][a] = D;
-    sAD[b][a] = AD;
-    sBX[b][a] = BX;
-    sBY[b][a] = BY;
+    sN1[b][a] = make_double2(D, AD);
+    sN2[b][a] = make_double2(BX, BY);
   }
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -1025,53 +1041,53 @@ __global__ __launch_bounds__(NT) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int 
   const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
   double lsum = 0.0;
 #pragma unroll
-  for (int m = 0; m < RPT; ++m) {
-    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+  for (int m = 0; m < RPTA; ++m) {
+    const int r = 1 + ty + NWA * m, gj = j0 - 1 + r;
     if (gi < g.nx && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
-      const double H0 = sH[r][c], S0 = sS[r][c], L0 = sL[r][c];
+      const double2 c0 = sHS[r][c];
       double v = 0.0;
-      if (H0 > 0.0) {
-        v = 0.25 * (sAD[r - 1][c - 1] + sAD[r - 1][c] + sAD[r][c - 1] + sAD[r][c]) +
-            0.5 * g.inv_dx * ((sBX[r - 1][c - 1] + sBX[r][c - 1]) - (sBX[r - 1][c] + sBX[r][c])) +
-            0.5 * g.inv_dy * ((sBY[r - 1][c - 1] + sBY[r - 1][c]) - (sBY[r][c - 1] + sBY[r][c]));
-        const double etx = g.eta0 * g.inv_dx, ety = g.eta0 * g.inv_dy;
+      if (c0.x > 0.0) {
+        const double2 nsw1 = sN1[r - 1][c - 1], nse1 = sN1[r - 1][c], nnw1 = sN1[r][c - 1], nne1 = sN1[r][c];
+        const double2 nsw2 = sN2[r - 1][c - 1], nse2 = sN2[r - 1][c], nnw2 = sN2[r][c - 1], nne2 = sN2[r][c];
+        // first term (adjoint.jl:123-127): avg^T(alpha Da) + dx^T(ay^T(bx Da))/dx + dy^T(ax^T(by Da))/dy
+        v = 0.25 * ((nsw1.y + nse1.y) + (nnw1.y + nne1.y));
+        v = fma(g.hinv_dx, (nsw2.x + nnw2.x) - (nse2.x + nne2.x), v);
+        v = fma(g.hinv_dy, (nsw2.y + nse2.y) - (nnw2.y + nne2.y), v);
+        // second term (adjoint.jl:130-144 with inversion_utils.jl:22-43): per edge
+        //   weight = 1 inside the clamp interval, eta0 where the clamp on THIS cell's H is active
+        const double S0 = c0.y, L0 = sL[r][c], eH0 = g.eta0 * c0.x;
+        double tx2 = 0.0, ty2 = 0.0;
         if (gj >= 1 && gj <= g.ny - 2) {
-          if (gi <= g.nx - 2) {  // east edge: this cell is its left cell
-            const double Fa = (sL[r][c + 1] - L0) * g.inv_dx;
-            const double C = -Fa * (0.5 * (sD[r - 1][c] + sD[r][c]));
-            const double e = (sS[r][c + 1] - S0) * g.inv_dx;
-            const double up = (g.eta0 * sH[r][c + 1]) * g.inv_dx, lo = -(g.eta0 * H0) * g.inv_dx;
-            if (e < up && e > lo) v -= g.inv_dx * C;
-            if (e < lo) v -= etx * C;
+          if (gi <= g.nx - 2) {  // east edge: this cell is its left cell (lower bound -eta H0)
+            const double2 ce = sHS[r][c + 1];
+            const double dS = ce.y - S0, up = g.eta0 * ce.x;
+            const double wgt = (dS < up && dS > -eH0) ? 1.0 : (dS < -eH0 ? g.eta0 : 0.0);
+            tx2 = (sL[r][c + 1] - L0) * (nse1.x + nne1.x) * wgt;
           }
-          if (gi >= 1) {  // west edge: this cell is its right cell
-            const double Fa = (L0 - sL[r][c - 1]) * g.inv_dx;
-            const double C = -Fa * (0.5 * (sD[r - 1][c - 1] + sD[r][c - 1]));
-            const double e = (S0 - sS[r][c - 1]) * g.inv_dx;
-            const double up = (g.eta0 * H0) * g.inv_dx, lo = -(g.eta0 * sH[r][c - 1]) * g.inv_dx;
-            if (e < up && e > lo) v += g.inv_dx * C;
-            if (e > up) v += etx * C;
+          if (gi >= 1) {  // west edge: this cell is its right cell (upper bound eta H0)
+            const double2 cw = sHS[r][c - 1];
+            const double dS = S0 - cw.y, lo = -(g.eta0 * cw.x);
+            const double wgt = (dS < eH0 && dS > lo) ? 1.0 : (dS > eH0 ? g.eta0 : 0.0);
+            tx2 = fma(-(L0 - sL[r][c - 1]) * (nsw1.x + nnw1.x), wgt, tx2);
           }
         }
         if (gi >= 1 && gi <= g.nx - 2) {
           if (gj <= g.ny - 2) {  // north edge
-            const double Fa = (sL[r + 1][c] - L0) * g.inv_dy;
-            const double C = -Fa * (0.5 * (sD[r][c - 1] + sD[r][c]));
-            const double e = (sS[r + 1][c] - S0) * g.inv_dy;
-            const double up = (g.eta0 * sH[r + 1][c]) * g.inv_dy, lo = -(g.eta0 * H0) * g.inv_dy;
-            if (e < up && e > lo) v -= g.inv_dy * C;
-            if (e < lo) v -= ety * C;
+            const double2 cn = sHS[r + 1][c];
+            const double dS = cn.y - S0, up = g.eta0 * cn.x;
+            const double wgt = (dS < up && dS > -eH0) ? 1.0 : (dS < -eH0 ? g.eta0 : 0.0);
+            ty2 = (sL[r + 1][c] - L0) * (nnw1.x + nne1.x) * wgt;
           }
           if (gj >= 1) {  // south edge
-            const double Fa = (L0 - sL[r - 1][c]) * g.inv_dy;
-            const double C = -Fa * (0.5 * (sD[r - 1][c - 1] + sD[r - 1][c]));
-            const double e = (S0 - sS[r - 1][c]) * g.inv_dy;
-            const double up = (g.eta0 * H0) * g.inv_dy, lo = -(g.eta0 * sH[r - 1][c]) * g.inv_dy;
-            if (e < up && e > lo) v += g.inv_dy * C;
-            if (e > up) v += ety * C;
+            const double2 cs = sHS[r - 1][c];
+            const double dS = S0 - cs.y, lo = -(g.eta0 * cs.x);
+            const double wgt = (dS < eH0 && dS > lo) ? 1.0 : (dS > eH0 ? g.eta0 : 0.0);
+            ty2 = fma(-(L0 - sL[r - 1][c]) * (nsw1.x + nse1.x), wgt, ty2);
           }
         }
+        v = fma(g.hinv_dx2, tx2, v);
+        v = fma(g.hinv_dy2, ty2, v);
       }
       if (MODE == 0) {
         A.out[id] = v;
@@ -1087,8 +1103,16 @@ __global__ __launch_bounds__(NT) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int 
     }
   }
   if (MODE == 1) {
-    const double tot = block_sum(lsum, red);
-    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = tot * w * Ninv;
+    double tot = wave_sum(lsum);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < NWA; ++k) tot += red[k];
+      P.part[4 * (long long)t4.w + 1] = tot * w * Ninv;
+    }
   }
 }
 
@@ -1110,15 +1134,14 @@ struct ThArgs {
 
 template <int LM>
 __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, int tile_base) {
-  __shared__ double sH[TY + 2][LDW];
-  __shared__ double sS[TY + 2][LDW];
+  __shared__ double2 sHS[TY + 2][LDW];
   __shared__ double sL[TY + 2][LDW];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double ownH[RPT], ownL[RPT];
-  load_tile_HS(A.H, P.B, g, i0, j0, sH, sS, ownH);
+  load_tile_HS2(A.H, P.B, g, i0, j0, sHS, ownH);
   load_tile_lam(A.lam, g, i0, j0, sL, ownL);
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -1135,18 +1158,10 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
     const int b = 1 + ty + NW * m, a = tx + 1;
     const int gi = i0 - 1 + a, gj = j0 - 1 + b;
     if (gi <= g.nx - 2 && gj <= g.ny - 2) {
-      const double s00 = sS[b][a], s10 = sS[b][a + 1], s01 = sS[b + 1][a], s11 = sS[b + 1][a + 1];
-      const double h00 = sH[b][a], h10 = sH[b][a + 1], h01 = sH[b + 1][a], h11 = sH[b + 1][a + 1];
-      const double exl = (s10 - s00) * g.inv_dx, exu = (s11 - s01) * g.inv_dx;
-      const double eyl = (s01 - s00) * g.inv_dy, eyr = (s11 - s10) * g.inv_dy;
-      const double gx = 0.5 * (exl + exu), gy = 0.5 * (eyl + eyr);
-      const double Hb = 0.25 * (h00 + h10 + h01 + h11);
+      double gx, gy, Hb;
+      const double Da = node_Da<LDW>(g, &sHS[b][a], &sL[b][a], gj >= 1, gj + 1 <= g.ny - 2, gi >= 1,
+                                     gi + 1 <= g.nx - 2, gx, gy, Hb);
       const double gS2 = gx * gx + gy * gy;
-      double Da = 0.0;
-      if (gj >= 1)            Da -= 0.5 * ((sL[b][a + 1] - sL[b][a]) * g.inv_dx) * clampf(exl, (g.eta0 * h10) * g.inv_dx, -(g.eta0 * h00) * g.inv_dx);
-      if (gj + 1 <= g.ny - 2) Da -= 0.5 * ((sL[b + 1][a + 1] - sL[b + 1][a]) * g.inv_dx) * clampf(exu, (g.eta0 * h11) * g.inv_dx, -(g.eta0 * h01) * g.inv_dx);
-      if (gi >= 1)            Da -= 0.5 * ((sL[b + 1][a] - sL[b][a]) * g.inv_dy) * clampf(eyl, (g.eta0 * h01) * g.inv_dy, -(g.eta0 * h00) * g.inv_dy);
-      if (gi + 1 <= g.nx - 2) Da -= 0.5 * ((sL[b + 1][a + 1] - sL[b][a + 1]) * g.inv_dy) * clampf(eyr, (g.eta0 * h11) * g.inv_dy, -(g.eta0 * h10) * g.inv_dy);
       double spat;
       if (LM == LM_FAST) {
         const double H2 = Hb * Hb;
