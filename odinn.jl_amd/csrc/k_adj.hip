@@ -1,5 +1,6 @@
 // k_adj.hip -- discrete-adjoint stencil kernels for one law mode (-DODINN_LM=0|1|2)
 #include "launch.hpp"
+#include "sia2d_nn_grad.hpp"
 #ifndef ODINN_LM
 #error "define ODINN_LM"
 #endif
@@ -11,6 +12,14 @@ void CAT(launch_vjp_H_lm, ODINN_LM)(int mode, int nblk, hipStream_t st, Pools P,
   else hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM>), dim3(nblk), dim3(NTA), 0, st, P, L, A, base);
 }
 void CAT(launch_vjp_theta_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base) {
+#if ODINN_LM == 3
+  hipLaunchKernelGGL(k_vjp_theta_nn<ArchDef>, dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+#elif ODINN_LM == 4
+  hipLaunchKernelGGL(k_vjp_theta_nn<Arch16>, dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+#elif ODINN_LM == 5
+  hipLaunchKernelGGL(k_vjp_theta_nn<ArchLight>, dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+#else
   hipLaunchKernelGGL(k_vjp_theta<ODINN_LM>, dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+#endif
 }
 }  // namespace odinn
