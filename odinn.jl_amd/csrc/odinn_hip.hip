@@ -251,7 +251,7 @@ int refresh_gd(odinn_batch* b) {
     r.n = ph.n; r.p = ph.p; r.q = ph.q; r.T = d.T;
     r.Gam = 2.0 * std::pow(ph.rho * ph.g, ph.n) / (ph.n + 2.0);
     r.Sc = ph.C * std::pow(ph.rho * ph.g, ph.p - ph.q);
-    r.fast = (ph.n == 3.0 && r.Sc == 0.0) ? 1 : 0;
+    r.fast = (ph.n == 3.0 && r.Sc == 0.0 && ph.eta0 == 1.0) ? 1 : 0;
     r.nH = b->nH >= 0 ? b->nH : ph.n;
     r.nS = b->nS >= 0 ? b->nS : ph.n;
     r.minA = ph.minA; r.maxA = ph.maxA;

@@ -95,7 +95,7 @@ struct GDev {  // per-glacier constants
   double Sc;       // C (rho g)^(p-q)          target_utils.jl:14-18
   double n, p, q, T, nH, nS;
   double minA, maxA;
-  int fast;        // n == 3 && Sc == 0 -> integer-power path, no sqrt/pow
+  int fast;        // n == 3 && Sc == 0 && eta0 == 1 -> integer-power path, no sqrt/pow, no eta0 products
   int use_Afield;  // A read from the dual-grid field
   int has_mb;
   double dmb_dS, mb_max;
@@ -655,15 +655,17 @@ __device__ __forceinline__ void node_geom(const GDev& g, const double2* p, doubl
   Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
 }
 // dH/dt of an interior cell: p at the cell, pD at its north-east node; LDD = node row stride.
-template <int LD, int LDD>
+// ETA1: eta0 == 1 (the integer-power law mode requires it), so eta0*H is H bit for bit.
+template <int LD, int LDD, bool ETA1 = false>
 __device__ __forceinline__ double cell_div(const GDev& g, const double2* p, const double* pD) {
   const double2 c0 = p[0], ce_ = p[1], cw_ = p[-1], cn_ = p[LD], cs_ = p[-LD];
-  const double S0 = c0.y, eH0 = g.eta0 * c0.x;
+  const double e0 = ETA1 ? 1.0 : g.eta0;
+  const double S0 = c0.y, eH0 = ETA1 ? c0.x : e0 * c0.x;
   const double Dsw = pD[-LDD - 1], Dse = pD[-LDD], Dnw = pD[-1], Dne = pD[0];
-  const double ce = fmax(fmin(ce_.y - S0, g.eta0 * ce_.x), -eH0);
-  const double cw = fmax(fmin(S0 - cw_.y, eH0), -(g.eta0 * cw_.x));
-  const double cn = fmax(fmin(cn_.y - S0, g.eta0 * cn_.x), -eH0);
-  const double cs = fmax(fmin(S0 - cs_.y, eH0), -(g.eta0 * cs_.x));
+  const double ce = fmax(fmin(ce_.y - S0, ETA1 ? ce_.x : e0 * ce_.x), -eH0);
+  const double cw = fmax(fmin(S0 - cw_.y, eH0), -(ETA1 ? cw_.x : e0 * cw_.x));
+  const double cn = fmax(fmin(cn_.y - S0, ETA1 ? cn_.x : e0 * cn_.x), -eH0);
+  const double cs = fmax(fmin(S0 - cs_.y, eH0), -(ETA1 ? cs_.x : e0 * cs_.x));
   const double qx = (Dse + Dne) * ce - (Dsw + Dnw) * cw;
   const double qy = (Dnw + Dne) * cn - (Dsw + Dse) * cs;
   return fma(g.hinv_dx2, qx, g.hinv_dy2 * qy);
@@ -693,9 +695,10 @@ __device__ __forceinline__ void nodes_forward(const GDev& g, const LawDev& L, co
 __device__ __forceinline__ double clampf(double e, double up, double lo) { return fmax(fmin(e, up), lo); }
 
 // dH/dt of the cell at halo coordinates (c, r); caller guarantees the cell is interior.
+template <int LM>
 __device__ __forceinline__ double cell_rhs(const GDev& g, int c, int r, const double2 (*sHS)[LDW],
                                            const double (*sD)[LDN]) {
-  return cell_div<LDW, LDN>(g, &sHS[r][c], &sD[r][c]);
+  return cell_div<LDW, LDN, LM == LM_FAST>(g, &sHS[r][c], &sD[r][c]);
 }
 
 // =====================================================================================
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __
     const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
     if (gi < g.nx && gj < g.ny) {
       double k = 0.0;
-      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs(g, tx + 1, r, sHS, sD);
+      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs<LM>(g, tx + 1, r, sHS, sD);
       dH[g.off + gi + (long long)g.nx * gj] = k;
     }
   }
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
     if (gi < g.nx && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
       double k = 0.0;
-      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs(g, tx + 1, r, sHS, sD);
+      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs<LM>(g, tx + 1, r, sHS, sD);
       const double u = own[m];
       const double dtk = dt * k;
       if (STAGE == 1) {

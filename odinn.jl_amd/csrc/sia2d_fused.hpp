@@ -53,7 +53,7 @@ __device__ __forceinline__ void fused_stage(const GDev& g, const LawDev& L, cons
   for (int m = 0; m < FCPT; ++m) {
     if ((meta[m] & 0xff) >= S && (meta[m] & 0x100)) {
       double k = 0.0;
-      if (meta[m] & 0x200) k = cell_div<FLD, FLD>(g, sHS + off[m], sD + off[m]);
+      if (meta[m] & 0x200) k = cell_div<FLD, FLD, LM == LM_FAST>(g, sHS + off[m], sD + off[m]);
       const double dtk = dt * k;
       const double uo = u[m];
       double un;

@@ -64,8 +64,8 @@ def test_dhdt_negative_and_random_H(gpu):
 
 def test_dhdt_generic_exponents_and_sliding(gpu):
     """pow path: n != 3 and C > 0 (reference tests C = 7e-8, runtests.jl:92-94)."""
-    for n, C in [(3.0, 7e-8), (2.6, 0.0), (3.3, 7e-8)]:
-        ph = O.Phys(n=n, C=C, p=3.0, q=1.0)
+    for n, C, eta0 in [(3.0, 7e-8, 1.0), (2.6, 0.0, 1.0), (3.3, 7e-8, 1.0), (3.0, 0.0, 0.7)]:
+        ph = O.Phys(n=n, C=C, p=3.0, q=1.0, eta0=eta0)
         b, H0, B, _ = _setup(gpu, 80, 60, phys=ph)
         law = O.Law(kind=O.LAW_CONST_A, A=A0)
         ref = O.sia2d_rhs(H0, B, 100.0, 100.0, ph, law)

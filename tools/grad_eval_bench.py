@@ -6,7 +6,17 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import _odinn_import
 odinn = _odinn_import.load()
-from oracle import sia2d_oracle as O
+
+
+def synthetic_alpine(nx, ny, dx=50.0, hmax=110.0, slope=0.08):
+    """Gentle valley glacier (same formula as the test inputs; tools never import the oracle)."""
+    x = (np.arange(nx) * dx)[:, None]
+    y = (np.arange(ny) * dx)[None, :]
+    yc = ny * dx / 2
+    B = 2200.0 - slope * x + 300.0 * ((y - yc) / yc) ** 2
+    ell = ((x - 0.45 * nx * dx) / (0.38 * nx * dx)) ** 2 + ((y - yc) / (0.30 * ny * dx)) ** 2
+    return np.asfortranarray(np.maximum(0.0, hmax * (1.0 - ell))), np.asfortranarray(B + 0.0 * ell)
+
 shapes4 = [(96, 80), (128, 112), (160, 128), (192, 160)]
 ph = odinn.PhysicalParameters()
 for G in [int(a) for a in (sys.argv[1:] or ["4", "64", "512"])]:
@@ -18,7 +28,7 @@ for G in [int(a) for a in (sys.argv[1:] or ["4", "64", "512"])]:
     cache = {}
     for k, (nx, ny) in enumerate(shapes):
         if (nx, ny) not in cache:
-            cache[(nx, ny)] = O.synthetic_alpine(nx, ny)
+            cache[(nx, ny)] = synthetic_alpine(nx, ny)
         b.set_fields(k, *cache[(nx, ny)])
     ts = [2010.0 + j / 12.0 for j in range(25)]
     b.set_law(odinn.LAW_NN_A_SCALAR, mlp, nn.theta)
