@@ -13,6 +13,9 @@
  *   odinn_sia2d_vjp_theta   <- VJP_lambda_dSIAdtheta(::DiscreteVJP, ...)
  *                              src/inverse/SIA2D/VJPs.jl:30-33 -> adjoint.jl:178-255
  *   odinn_mb_vjp_H          <- VJP_lambda_dMBdH(::DiscreteVJP, ...)  VJPs.jl:107-151
+ *   odinn_surface_V         <- Huginn.surface_V / V_from_H (called src/losses/Losses.jl:314,358)
+ *   odinn_surface_V_vjp_H/_theta <- VJP_lambda_dsurface_VdH / dtheta (::DiscreteVJP)
+ *                              src/inverse/SIA2D/VJPs.jl:61-69 -> adjoint.jl:268-413
  *   odinn_solve             <- _batch_iceflow_UDE / simulate_iceflow_UDE!
  *                              src/simulations/inversions/inversion_utils.jl:472-572
  *   odinn_loss              <- batch_loss_iceflow_transient  inversion_utils.jl:383-461
@@ -141,12 +144,28 @@ int odinn_set_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, c
 int odinn_set_mass_balance(odinn_batch* b, int g, const double* mb0, double dmb_dS,
                            const double* S_ref, double mb_max);
 
+/* surface-velocity data glacier.velocityData: n_ref triples (|V|, Vx, Vy) of nx*ny fields at times
+ * t_ref; the loss mask is V_ref > 0 (Losses.jl:316,361).  Pass n_ref = 0 to clear. */
+int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, const double* Vabs,
+                                 const double* Vx, const double* Vy);
+/* empirical loss function (src/losses/Losses.jl): LossH(L2Sum) [default], LossV(L2Sum, component,
+ * scale_loss) :293-390, LossHV(hLoss, vLoss, scaling) :395-440 */
+enum odinn_loss_kind { ODINN_LOSS_H = 0, ODINN_LOSS_V = 1, ODINN_LOSS_HV = 2 };
+int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_loss, double hv_scaling);
+
 /* ---- fine-grained seams (host in / host out; parity + drop-in, not the fast path) ---- */
 int odinn_sia2d_dhdt(odinn_batch* b, int g, const double* H, double t, double* dH);
 int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H, double t, double* dlam);
 /* dtheta has P entries (P = 1 for CONST_A: d/dA) */
 int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double* H, double t,
                           double* dtheta, int P);
+/* Huginn.surface_V / V_from_H (restated from adjoint.jl:268-350): Vx, Vy are nx*ny with the
+ * reference's inn1 pairing (dual node (i,j) at element [i,j]; last row and column 0).  A-type laws. */
+int odinn_surface_V(odinn_batch* b, int g, const double* H, double* Vx, double* Vy);
+/* VJP_lambda_dsurface_V/dH and /dtheta (DiscreteVJP), src/inverse/SIA2D/VJPs.jl:61-69 */
+int odinn_surface_V_vjp_H(odinn_batch* b, int g, const double* dVx, const double* dVy, const double* H, double* out);
+int odinn_surface_V_vjp_theta(odinn_batch* b, int g, const double* dVx, const double* dVy, const double* H,
+                              double* dtheta, int P);
 int odinn_mb_apply(odinn_batch* b, int g, const double* H, double* H_new, double* MB_applied);
 int odinn_mb_vjp_H(odinn_batch* b, int g, const double* lam, const double* H_pre, double* out);
 /* value of the law on the dual grid (scalar laws: out[0]) */

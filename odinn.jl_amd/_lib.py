@@ -18,6 +18,7 @@ POST_NONE, POST_AFFINE, POST_EXPMAX, POST_SCALE = range(4)
 (TIMED_DHDT, TIMED_RK_STEP, TIMED_VJP_H, TIMED_VJP_THETA, TIMED_RK_STAGE2, TIMED_SOLVE_STEP, TIMED_FUSED_STEP,
  TIMED_SOLVE_STEP_STAGED) = range(8)
 SCHEME_AUTO, SCHEME_STAGED, SCHEME_FUSED = 0, 1, 2
+LOSS_H, LOSS_V, LOSS_HV = 0, 1, 2
 
 
 class OdinnError(RuntimeError):
@@ -68,6 +69,11 @@ SIGNATURES = {
     "odinn_set_theta": (C.c_int, [_vp, _dp, C.c_int]),
     "odinn_set_reference": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int]),
     "odinn_set_mass_balance": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp, C.c_double]),
+    "odinn_set_velocity_reference": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp]),
+    "odinn_set_loss": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "odinn_surface_V": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "odinn_surface_V_vjp_H": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
+    "odinn_surface_V_vjp_theta": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]),
     "odinn_sia2d_dhdt": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp]),
     "odinn_sia2d_vjp_H": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_double, _dp]),
     "odinn_sia2d_vjp_theta": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_double, _dp, C.c_int]),

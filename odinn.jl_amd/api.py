@@ -35,7 +35,7 @@ __all__ = [
     "Parameters", "SimulationParameters", "SolverParameters", "Hyperparameters", "UDEparameters",
     "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
     "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "DiscreteVJP",
-    "LossH", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
+    "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad",
 ]
@@ -95,6 +95,24 @@ class LossH:
 
 
 @dataclass
+class LossV:
+    """src/losses/Losses.jl:66-81,293-390 (target :A)"""
+
+    loss: L2Sum = field(default_factory=L2Sum)
+    component: str = "xy"  # :xy | :abs
+    scale_loss: bool = True
+
+
+@dataclass
+class LossHV:
+    """src/losses/Losses.jl:86-112,395-440"""
+
+    hLoss: LossH = field(default_factory=LossH)
+    vLoss: LossV = field(default_factory=LossV)
+    scaling: float = 1.0
+
+
+@dataclass
 class Adam:
     """Optimisers.Adam(eta, (beta1, beta2), eps)"""
 
@@ -122,7 +140,7 @@ class UDEparameters:
     """src/parameters/UDEparameters.jl:60-80 (only the manual discrete adjoint is provided)."""
 
     grad: DiscreteAdjoint = field(default_factory=DiscreteAdjoint)
-    empirical_loss_function: LossH = field(default_factory=LossH)
+    empirical_loss_function: object = field(default_factory=LossH)  # LossH | LossV | LossHV
     target: str = "A"  # :A | :D_hybrid | :D
     optimization_method: str = "AD+AD"
 
@@ -148,6 +166,16 @@ class ThicknessData:
 
 
 @dataclass
+class VelocityData:
+    """glacier.velocityData: absolute value and components at dates t (nx*ny fields)."""
+
+    t: Sequence[float]
+    vabs: Sequence[np.ndarray]
+    vx: Sequence[np.ndarray]
+    vy: Sequence[np.ndarray]
+
+
+@dataclass
 class Glacier2D:
     """POD stand-in for Sleipnir.Glacier2D (kwargs as test/test_grad_loss.jl:595-597)."""
 
@@ -161,6 +189,7 @@ class Glacier2D:
     n: float = 3.0
     T: float = -5.0  # long-term air temperature (iAvgScalarTemp)
     thicknessData: Optional[ThicknessData] = None
+    velocityData: Optional[VelocityData] = None
 
     @property
     def nx(self):
@@ -388,6 +417,8 @@ class _Simulation:
         for g in self.glaciers:
             if g.thicknessData is not None:
                 ts |= set(float(t) for t in g.thicknessData.t)
+            if g.velocityData is not None:
+                ts |= set(float(t) for t in g.velocityData.t)
         return sorted(t for t in ts if p.simulation.tspan[0] <= t <= p.simulation.tspan[1])
 
     def mb_times(self):
@@ -417,9 +448,20 @@ class _Simulation:
         law = self.model.iceflow.law
         for k, g in enumerate(gl):
             b.set_fields(k, g.H0, g.B)
+            lf = p.UDE.empirical_loss_function
+            dist_ = (lf.hLoss.loss.distance if isinstance(lf, LossHV) else lf.loss.distance)
             if g.thicknessData is not None:
-                b.set_reference(k, g.thicknessData.t, g.thicknessData.H,
-                                p.UDE.empirical_loss_function.loss.distance)
+                b.set_reference(k, g.thicknessData.t, g.thicknessData.H, dist_)
+            if g.velocityData is not None:
+                v = g.velocityData
+                b.set_velocity_reference(k, v.t, v.vabs, v.vx, v.vy)
+        lf = p.UDE.empirical_loss_function
+        if isinstance(lf, LossHV):
+            b.set_loss(L.LOSS_HV, lf.vLoss.component, lf.vLoss.scale_loss, lf.scaling)
+        elif isinstance(lf, LossV):
+            b.set_loss(L.LOSS_V, lf.component, lf.scale_loss)
+        for k, g in enumerate(gl):
+            pass
         if law.kind == L.LAW_CONST_A:
             if law.value is not None:
                 for k in range(len(gl)):
@@ -477,6 +519,15 @@ def VJP_lambda_dSIAdtheta(VJPMode: DiscreteVJP, lam, H, theta, dH_H, simulation:
     if theta is not None and b.P:
         b.set_theta(theta)
     return b.vjp_theta(glacier_idx, lam, H, t)
+
+
+def V_from_H(simulation: _Simulation, H, t, theta=None, glacier_idx: int = 0):
+    """Huginn.V_from_H(simulation, H, t, θ) -> (Vx, Vy, V) on the nx*ny grid (called Losses.jl:314,358)."""
+    b = simulation.batch()
+    if theta is not None and b.P:
+        b.set_theta(theta)
+    Vx, Vy = b.surface_V(glacier_idx, H)
+    return Vx, Vy, np.sqrt(Vx ** 2 + Vy ** 2)
 
 
 def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):

@@ -180,6 +180,38 @@ class GlacierBatch:
             sp = _p(S_ref)
         L.check(L.lib().odinn_set_mass_balance(self._h, g, _p(mb0), float(dmb_dS), sp, float(mb_max)))
 
+    def set_velocity_reference(self, g, t_ref, Vabs, Vx, Vy):
+        """glacier.velocityData: fields are nx*ny (inn1 pairing with the dual grid)."""
+        t = np.ascontiguousarray(t_ref, dtype=np.float64)
+        nx, ny = self.shapes[g]
+        pack = lambda fs: np.ascontiguousarray(np.stack([_f(f, (nx, ny)).ravel(order="F") for f in fs]))
+        a, x, y = pack(Vabs), pack(Vx), pack(Vy)
+        L.check(L.lib().odinn_set_velocity_reference(self._h, g, len(t), _p(t), _p(a), _p(x), _p(y)))
+
+    def set_loss(self, kind=L.LOSS_H, component="xy", scale_loss=True, scaling=1.0):
+        """LossH | LossV(component, scale_loss) | LossHV(scaling)  (src/losses/Losses.jl)."""
+        L.check(L.lib().odinn_set_loss(self._h, int(kind), 1 if component == "abs" else 0, 1 if scale_loss else 0,
+                                       float(scaling)))
+
+    def surface_V(self, g, H):
+        H = _f(H, self.shapes[g])
+        Vx, Vy = np.empty_like(H), np.empty_like(H)
+        L.check(L.lib().odinn_surface_V(self._h, g, _p(H), _p(Vx), _p(Vy)))
+        return Vx, Vy
+
+    def surface_V_vjp_H(self, g, dVx, dVy, H):
+        H, dVx, dVy = _f(H, self.shapes[g]), _f(dVx, self.shapes[g]), _f(dVy, self.shapes[g])
+        out = np.empty_like(H)
+        L.check(L.lib().odinn_surface_V_vjp_H(self._h, g, _p(dVx), _p(dVy), _p(H), _p(out)))
+        return out
+
+    def surface_V_vjp_theta(self, g, dVx, dVy, H):
+        H, dVx, dVy = _f(H, self.shapes[g]), _f(dVx, self.shapes[g]), _f(dVy, self.shapes[g])
+        P = 1 if self.law_kind == L.LAW_CONST_A else self.P
+        out = np.empty(P)
+        L.check(L.lib().odinn_surface_V_vjp_theta(self._h, g, _p(dVx), _p(dVy), _p(H), _p(out), P))
+        return out
+
     # -- seams (== Huginn.SIA2D!, VJP_lambda_dSIA/dH, VJP_lambda_dSIA/dtheta) -----------
     def dhdt(self, g, H, t=0.0):
         H = _f(H, self.shapes[g])

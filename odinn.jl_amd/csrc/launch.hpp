@@ -21,6 +21,11 @@ ODINN_DECL_LM(4)
 ODINN_DECL_LM(5)
 #undef ODINN_DECL_LM
 
+// k_vel.hip (A-type law modes 0/1 only)
+struct VArgs;
+void launch_surface_V(int lm, int nblk, hipStream_t st, Pools P, const double* U, double* Vx, double* Vy, int base);
+void launch_surfV_vjp(int lm, int mode, int nblk, hipStream_t st, Pools P, const VArgs& A, int base);
+
 // k_misc.hip
 void launch_controller(int G, hipStream_t st, Pools P, CtrlArgs C);
 void launch_poststep(int nblk, hipStream_t st, Pools P, PostArgs A, double* Ua, double* Ub);

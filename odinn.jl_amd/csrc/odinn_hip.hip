@@ -3,6 +3,7 @@
 // No torch types, no CPU fallback: every compute entry point needs a gfx950 device.
 #include "../../include/odinn_hip.h"
 #include "launch.hpp"
+#include "sia2d_velocity.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -144,6 +145,18 @@ struct odinn_batch {
   int nref_alloc = 0;
   double* d_Href = nullptr;
   unsigned char* d_mask = nullptr;
+  // surface-velocity data and loss selection
+  std::vector<std::vector<double>> t_vref;                // per glacier
+  std::vector<std::vector<double>> v_scale, v_cxy, v_cabs;  // per glacier per slot: 1/sqrt(mean|Vref|^2),
+                                                           // constant loss of the last row/column (:xy, :abs)
+  int nvref_alloc = 0;
+  double *d_Vabs = nullptr, *d_Vxr = nullptr, *d_Vyr = nullptr;
+  int loss_kind = ODINN_LOSS_H, v_abs = 0, v_scale_loss = 1;
+  double hv_scaling = 1.0;
+  double *d_wv = nullptr, *d_vsc = nullptr;
+  int* d_vslot = nullptr;
+  std::vector<double> wv_h, vsc_h;  // [k][G] host copies
+  std::vector<int> vslot_h;
   // law
   int law_kind = ODINN_LAW_CONST_A;
   odinn_mlp_desc mlp{};
@@ -401,7 +414,10 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol) {
 int ensure_tables(odinn_batch* b, int n_stops) {
   if (n_stops > b->tab_cap) {
     dfree(b->d_tstops); dfree(b->d_mb_flag); dfree(b->d_mb_slot);
-    dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
+    dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot); dfree(b->d_wv); dfree(b->d_vsc); dfree(b->d_vslot);
+    CHK(dalloc(&b->d_wv, (size_t)n_stops * b->G));
+    CHK(dalloc(&b->d_vsc, (size_t)n_stops * b->G));
+    CHK(dalloc(&b->d_vslot, (size_t)n_stops * b->G));
     CHK(dalloc(&b->d_tstops, n_stops));
     CHK(dalloc(&b->d_mb_flag, n_stops));
     CHK(dalloc(&b->d_mb_slot, n_stops));
@@ -413,26 +429,77 @@ int ensure_tables(odinn_batch* b, int n_stops) {
   return ODINN_OK;
 }
 
-// loss weights w_j and reference slots (safe_slice rule, gradient.jl:38-40,144-149)
+// loss weights and reference slots per stop and glacier (safe_slice rule, gradient.jl:38-40,144-149).
+// LossH: wH = dtH; LossV: wV = dtV; LossHV: wH = dtH^2, wV = scaling*dtV^2 (Losses.jl:407,424-431
+// multiply by Dt once more on top of the inner losses).
 int upload_loss_tables(odinn_batch* b) {
   const int k = (int)b->tstops.size();
-  std::vector<double> dts((size_t)k * b->G, 0.0), ws((size_t)k * b->G, 0.0);
-  std::vector<int> slot((size_t)k * b->G, 0);
+  const size_t n = (size_t)k * b->G;
+  std::vector<double> dts(n, 0.0), ws(n, 0.0);
+  std::vector<int> slot(n, 0);
+  b->wv_h.assign(n, 0.0); b->vsc_h.assign(n, 1.0); b->vslot_h.assign(n, 0);
+  const bool useH = b->loss_kind != ODINN_LOSS_V, useV = b->loss_kind != ODINN_LOSS_H;
   for (int j = 0; j < k; ++j)
     for (int g = 0; g < b->G; ++g) {
-      dts[(size_t)j * b->G + g] = j > 0 ? b->tstops[j] - b->tstops[j - 1] : 0.0;
-      const std::vector<double>& tr = b->t_ref[g];
-      for (size_t m = 0; m < tr.size(); ++m)
-        if (tr[m] == b->tstops[j]) {
-          slot[(size_t)j * b->G + g] = (int)m;
-          ws[(size_t)j * b->G + g] = m >= 1 ? tr[m] - tr[m - 1] : 0.0;
-          break;
-        }
+      const size_t q = (size_t)j * b->G + g;
+      dts[q] = j > 0 ? b->tstops[j] - b->tstops[j - 1] : 0.0;
+      if (useH) {
+        const std::vector<double>& tr = b->t_ref[g];
+        for (size_t m = 0; m < tr.size(); ++m)
+          if (tr[m] == b->tstops[j]) {
+            slot[q] = (int)m;
+            const double d = m >= 1 ? tr[m] - tr[m - 1] : 0.0;
+            ws[q] = b->loss_kind == ODINN_LOSS_HV ? d * d : d;
+            break;
+          }
+      }
+      if (useV) {
+        const std::vector<double>& tv = b->t_vref[g];
+        for (size_t m = 0; m < tv.size(); ++m)
+          if (tv[m] == b->tstops[j]) {
+            b->vslot_h[q] = (int)m;
+            const double d = m >= 1 ? tv[m] - tv[m - 1] : 0.0;
+            b->wv_h[q] = b->loss_kind == ODINN_LOSS_HV ? b->hv_scaling * d * d : d;
+            b->vsc_h[q] = b->v_scale_loss ? b->v_scale[g][m] : 1.0;
+            break;
+          }
+      }
     }
-  HIPCHK(hipMemcpyAsync(b->d_dts, dts.data(), dts.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_ws, ws.data(), ws.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_refslot, slot.data(), slot.size() * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_dts, dts.data(), n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_ws, ws.data(), n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_refslot, slot.data(), n * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_wv, b->wv_h.data(), n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_vsc, b->vsc_h.data(), n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_vslot, b->vslot_h.data(), n * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
+  return ODINN_OK;
+}
+
+// LossV contribution of stop j: accumulates wV * dl/dH into `out`, the loss partial into d_lossacc
+// and the theta weight into d_Gsum / d_Gacc.  Returns the constant loss of the last row/column.
+int launch_lossV(odinn_batch* b, int j, const double* Hj, double* out, bool with_grad, double* const_loss) {
+  *const_loss = 0.0;
+  bool any = false;
+  for (int g = 0; g < b->G; ++g) {
+    const size_t q = (size_t)j * b->G + g;
+    if (b->wv_h[q] != 0.0) {
+      any = true;
+      const int m = b->vslot_h[q];
+      *const_loss += b->wv_h[q] * b->vsc_h[q] * (b->v_abs ? b->v_cabs[g][m] : b->v_cxy[g][m]);
+    }
+  }
+  if (!any) return ODINN_OK;
+  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "LossV needs an A-type law (target :A)");
+  VArgs A{};
+  A.H = Hj; A.out = out; A.Vabs = b->d_Vabs; A.Vxr = b->d_Vxr; A.Vyr = b->d_Vyr;
+  A.wv = b->d_wv + (size_t)j * b->G; A.scale = b->d_vsc + (size_t)j * b->G; A.refslot = b->d_vslot + (size_t)j * b->G;
+  A.ntot = b->ntot; A.component_abs = b->v_abs;
+  A.Gacc = (with_grad && b->law_kind == ODINN_LAW_NN_A_GRIDDED) ? b->d_Gacc : nullptr;
+  const Pools P = b->pools(true);
+  launch_surfV_vjp(b->lm(), 1, b->ntiles, b->stream, P, A, 0);
+  launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
+  if (with_grad) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
+  HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
 
@@ -546,16 +613,23 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   return ODINN_OK;
 }
 
-// forward loss over the stored snapshots -> d_lossacc[g]
-int do_loss(odinn_batch* b) {
+// forward loss over the stored snapshots -> d_lossacc[g]; *const_loss: data-only part of LossV
+int do_loss(odinn_batch* b, double* const_loss) {
   const int k = (int)b->tstops.size();
+  *const_loss = 0.0;
   HIPCHK(hipMemsetAsync(b->d_lossacc, 0, sizeof(double) * b->G, b->stream));
-  if (!b->d_Href) return ODINN_OK;
   const Pools P = b->pools(true);
   for (int j = 1; j < k; ++j) {
-    launch_loss(b->ntiles, b->stream, P, b->d_snaps + (size_t)j * b->ntot, b->d_Href, b->d_mask,
-                b->d_ws + (size_t)j * b->G, b->d_refslot + (size_t)j * b->G, b->ntot);
-    launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
+    if (b->d_Href && b->loss_kind != ODINN_LOSS_V) {
+      launch_loss(b->ntiles, b->stream, P, b->d_snaps + (size_t)j * b->ntot, b->d_Href, b->d_mask,
+                  b->d_ws + (size_t)j * b->G, b->d_refslot + (size_t)j * b->G, b->ntot);
+      launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
+    }
+    if (b->d_Vabs && b->loss_kind != ODINN_LOSS_H) {
+      double c = 0.0;
+      CHK(launch_lossV(b, j, b->d_snaps + (size_t)j * b->ntot, b->d_tmpB, false, &c));
+      *const_loss += c;
+    }
   }
   HIPCHK(hipGetLastError());
   return ODINN_OK;
@@ -597,6 +671,7 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   b->descs.assign(descs, descs + n_glaciers);
   b->gd.resize(n_glaciers);
   b->t_ref.resize(n_glaciers);
+  b->t_vref.resize(n_glaciers); b->v_scale.resize(n_glaciers); b->v_cxy.resize(n_glaciers); b->v_cabs.resize(n_glaciers);
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&b->ev0));
@@ -693,6 +768,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
   dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
+  dfree(b->d_Vabs); dfree(b->d_Vxr); dfree(b->d_Vyr); dfree(b->d_wv); dfree(b->d_vsc); dfree(b->d_vslot);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -940,6 +1016,116 @@ int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double
   return ODINN_OK;
 }
 
+int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_loss, double hv_scaling) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
+  if (kind < ODINN_LOSS_H || kind > ODINN_LOSS_HV) return fail(ODINN_ERR_ARG, "unknown loss kind %d", kind);
+  b->loss_kind = kind; b->v_abs = v_component_abs ? 1 : 0; b->v_scale_loss = v_scale_loss ? 1 : 0;
+  b->hv_scaling = hv_scaling;
+  return ODINN_OK;
+}
+
+int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, const double* Vabs,
+                                 const double* Vx, const double* Vy) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (n_ref < 0 || (n_ref > 0 && (!t_ref || !Vabs || !Vx || !Vy))) return fail(ODINN_ERR_ARG, "bad velocity data");
+  if (n_ref > b->nvref_alloc) {
+    double *na = nullptr, *nx_ = nullptr, *ny_ = nullptr;
+    const size_t nb = (size_t)n_ref * b->ntot;
+    CHK(dalloc(&na, nb)); CHK(dalloc(&nx_, nb)); CHK(dalloc(&ny_, nb));
+    if (b->d_Vabs) {
+      const size_t ob = (size_t)b->nvref_alloc * b->ntot * sizeof(double);
+      HIPCHK(hipMemcpy(na, b->d_Vabs, ob, hipMemcpyDeviceToDevice));
+      HIPCHK(hipMemcpy(nx_, b->d_Vxr, ob, hipMemcpyDeviceToDevice));
+      HIPCHK(hipMemcpy(ny_, b->d_Vyr, ob, hipMemcpyDeviceToDevice));
+    }
+    dfree(b->d_Vabs); dfree(b->d_Vxr); dfree(b->d_Vyr);
+    b->d_Vabs = na; b->d_Vxr = nx_; b->d_Vyr = ny_; b->nvref_alloc = n_ref;
+  }
+  const GDev& r = b->gd[g];
+  const size_t n = (size_t)r.nx * r.ny;
+  b->t_vref[g].assign(t_ref, t_ref + n_ref);
+  b->v_scale[g].assign(n_ref, 1.0); b->v_cxy[g].assign(n_ref, 0.0); b->v_cabs[g].assign(n_ref, 0.0);
+  for (int m = 0; m < n_ref; ++m) {
+    const double *va = Vabs + m * n, *vx = Vx + m * n, *vy = Vy + m * n;
+    double s2 = 0.0, cxy = 0.0, cabs = 0.0;
+    long long cnt = 0;
+    for (int j = 0; j < r.ny; ++j)
+      for (int i = 0; i < r.nx; ++i) {
+        const size_t c = i + (size_t)r.nx * j;
+        if (va[c] > 0.0) {
+          s2 += vx[c] * vx[c] + vy[c] * vy[c];
+          ++cnt;
+          if (i == r.nx - 1 || j == r.ny - 1) { cxy += vx[c] * vx[c] + vy[c] * vy[c]; cabs += va[c] * va[c]; }
+        }
+      }
+    b->v_scale[g][m] = cnt > 0 ? 1.0 / std::sqrt(s2 / (double)cnt) : 1.0;
+    b->v_cxy[g][m] = cxy / (double)n;
+    b->v_cabs[g][m] = cabs / (double)n;
+    HIPCHK(hipMemcpy(b->d_Vabs + (size_t)m * b->ntot + r.off, va, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_Vxr + (size_t)m * b->ntot + r.off, vx, n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_Vyr + (size_t)m * b->ntot + r.off, vy, n * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return ODINN_OK;
+}
+
+int odinn_surface_V(odinn_batch* b, int g, const double* H, double* Vx, double* Vy) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!H || !Vx || !Vy) return fail(ODINN_ERR_ARG, "null field");
+  CHK(refresh_gd(b)); CHK(refresh_law_field(b));
+  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "surface velocity needs an A-type law (target :A)");
+  CHK(up_field(b, g, b->d_tmpA, H));
+  launch_surface_V(b->lm(), b->gd[g].ntiles, b->stream, b->pools(false), b->d_tmpA, b->d_tmpB, b->d_lam[1], b->gd[g].tile0);
+  HIPCHK(hipGetLastError());
+  CHK(down_field(b, g, b->d_tmpB, Vx));
+  return down_field(b, g, b->d_lam[1], Vy);
+}
+
+static int surfV_vjp_common(odinn_batch* b, int g, const double* dVx, const double* dVy, const double* H) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!H || !dVx || !dVy) return fail(ODINN_ERR_ARG, "null field");
+  CHK(refresh_gd(b)); CHK(refresh_law_field(b));
+  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "surface velocity needs an A-type law (target :A)");
+  CHK(up_field(b, g, b->d_tmpA, H));
+  CHK(up_field(b, g, b->d_lam[0], dVx));
+  CHK(up_field(b, g, b->d_lam[1], dVy));
+  const GDev& r = b->gd[g];
+  if (b->law_kind == ODINN_LAW_NN_A_GRIDDED)
+    HIPCHK(hipMemsetAsync(b->d_Gacc + r.offd, 0, (size_t)(r.nx - 1) * (r.ny - 1) * sizeof(double), b->stream));
+  VArgs A{};
+  A.H = b->d_tmpA; A.dVx = b->d_lam[0]; A.dVy = b->d_lam[1]; A.out = b->d_tmpB;
+  A.Gacc = b->law_kind == ODINN_LAW_NN_A_GRIDDED ? b->d_Gacc : nullptr;
+  const Pools P = b->pools(false);
+  launch_surfV_vjp(b->lm(), 0, r.ntiles, b->stream, P, A, r.tile0);
+  launch_sum_part(1, b->stream, P, 3, b->d_Gsum, 0, g);
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+int odinn_surface_V_vjp_H(odinn_batch* b, int g, const double* dVx, const double* dVy, const double* H, double* out) {
+  if (!out) return fail(ODINN_ERR_ARG, "null field");
+  CHK(surfV_vjp_common(b, g, dVx, dVy, H));
+  return down_field(b, g, b->d_tmpB, out);
+}
+
+int odinn_surface_V_vjp_theta(odinn_batch* b, int g, const double* dVx, const double* dVy, const double* H,
+                              double* dtheta, int P) {
+  if (!dtheta) return fail(ODINN_ERR_ARG, "null argument");
+  CHK(check_g(b, g));
+  const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
+  if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
+  CHK(surfV_vjp_common(b, g, dVx, dVy, H));
+  const GDev& r = b->gd[g];
+  if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) return gridded_law_grad(b, r.offd, (long long)(r.nx - 1) * (r.ny - 1), dtheta);
+  double Gs = 0.0;
+  HIPCHK(hipMemcpyAsync(&Gs, b->d_Gsum + g, sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (b->law_kind == ODINN_LAW_CONST_A) { dtheta[0] = Gs; return ODINN_OK; }
+  std::vector<double> dA(b->P);
+  h_mlp(b->mlp, b->theta.data(), &b->descs[g].T, dA.data());
+  for (int k = 0; k < b->P; ++k) dtheta[k] = dA[k] * Gs;
+  return ODINN_OK;
+}
+
 int odinn_mb_apply(odinn_batch* b, int g, const double* H, double* H_new, double* MB_applied) {
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!H || !H_new) return fail(ODINN_ERR_ARG, "null field");
@@ -1009,9 +1195,18 @@ int odinn_loss(odinn_batch* b, double* loss_per_glacier) {
   CHK(use_dev(b));
   if (!b->solved) return fail(ODINN_ERR_STATE, "no solve has been run");
   CHK(upload_loss_tables(b));
-  CHK(do_loss(b));
+  double cl = 0.0;
+  CHK(do_loss(b, &cl));
   HIPCHK(hipMemcpyAsync(loss_per_glacier, b->d_lossacc, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
+  // data-only part of LossV (cells of the last row / column, where V_pred is 0 by construction)
+  const int k = (int)b->tstops.size();
+  for (int j = 1; j < k; ++j)
+    for (int g = 0; g < b->G; ++g) {
+      const size_t q = (size_t)j * b->G + g;
+      if (b->loss_kind != ODINN_LOSS_H && b->wv_h[q] != 0.0)
+        loss_per_glacier[g] += b->wv_h[q] * b->vsc_h[q] * (b->v_abs ? b->v_cabs[g][b->vslot_h[q]] : b->v_cxy[g][b->vslot_h[q]]);
+    }
   return ODINN_OK;
 }
 
@@ -1023,7 +1218,8 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
   if (theta) CHK(odinn_set_theta(b, theta, P));
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
-  if (!b->d_Href) return fail(ODINN_ERR_STATE, "no reference thickness data set");
+  if (b->loss_kind != ODINN_LOSS_V && !b->d_Href) return fail(ODINN_ERR_STATE, "no reference thickness data set");
+  if (b->loss_kind != ODINN_LOSS_H && !b->d_Vabs) return fail(ODINN_ERR_STATE, "no reference velocity data set");
   CHK(do_solve(b, n_stops, tstops, n_mb, mb_times, opts, stats));
   // ---- reverse loop: gradient.jl:191-253 -------------------------------------------------
   const int k = n_stops;
@@ -1040,6 +1236,7 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
   const Pools Psw = b->pools(true);
   const LawDev L = b->lawdev();
   int cur = 0;
+  double const_loss = 0.0;
   for (int j = k - 1; j >= 1; --j) {
     double* lam = b->d_lam[cur];
     double* lam_new = b->d_lam[1 - cur];
@@ -1054,6 +1251,11 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
     A.refslot = b->d_refslot + (size_t)j * b->G; A.ntot = b->ntot;
     launch_vjp_H(b, 1, b->ntiles, Psw, L, A, 0);  // :235-242
     launch_sum_part(b->G, b->stream, Psw, 1, b->d_lossacc, 1, 0);
+    if (b->loss_kind != ODINN_LOSS_H) {  // backward_loss(::LossV): dl/dH into lambda_{j-1}, dl/dtheta into dtheta
+      double c = 0.0;
+      CHK(launch_lossV(b, j, Hj, lam_new, true, &c));
+      const_loss += c;
+    }
     CHK(theta_vjp_launch(b, Hj, lam_new, b->d_dts + (size_t)j * b->G, -1, true));  // :245-249
     cur = 1 - cur;
   }
@@ -1064,7 +1266,7 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
   HIPCHK(hipMemcpyAsync(lossg.data(), b->d_lossacc, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipMemcpyAsync(Gs.data(), b->d_Gsum, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
-  double Ltot = 0.0;
+  double Ltot = const_loss;
   for (int g = 0; g < b->G; ++g) Ltot += lossg[g];
   *loss = Ltot;
   for (int q = 0; q < P; ++q) dtheta[q] = 0.0;

@@ -1,0 +1,192 @@
+// sia2d_velocity.hpp -- surface-velocity path for A-type laws:
+//   k_surface_V   : (Vx, Vy) = -Velocity^(Hbar, |grad S|) * grad S on the dual grid, stored in
+//                   nx*ny arrays with the reference's inn1 pairing (last row / column 0)
+//                   [Huginn.surface_V / V_from_H, restated from adjoint.jl:268-350]
+//   k_surfV_vjp<0>: VJP_lambda_dsurface_V/dH_discrete (adjoint.jl:268-350) in gather form and the
+//                   reduction of VJP_lambda_dsurface_V/dtheta_discrete (adjoint.jl:352-413)
+//   k_surfV_vjp<1>: the same with the cotangent taken from LossV on the fly
+//                   (backward_loss(::LossV), Losses.jl:338-390: L2Sum on :xy or :abs, mask
+//                   V_ref > 0, optional scaling) and accumulated into the adjoint state.
+#pragma once
+#include "sia2d_device.hpp"
+
+namespace odinn {
+
+// Velocity^ and its partials on one node (target_A.jl:94-142).  spat = d Velocity^/dA.
+template <int LM>
+__device__ __forceinline__ double node_Vup(const GDev& g, double Hb, double gS2, double An, double& alpha,
+                                           double& beta, double& spat) {
+  const double Gu = g.Gam * (g.n + 2.0) / (g.n + 1.0);  // 2 (rho g)^n / (n+1)
+  if (LM == LM_FAST) {
+    const double H2 = Hb * Hb, H3 = H2 * Hb, H4 = H2 * H2;
+    const double AG = An * Gu;
+    alpha = AG * 4.0 * H3 * gS2;
+    beta = AG * 2.0 * H4;
+    spat = Gu * H4 * gS2;
+    return AG * H4 * gS2;
+  }
+  const double gS = sqrt(gS2);
+  const double hn1 = pow(Hb, g.n + 1.0), sn1 = pow(gS, g.n - 1.0), sn3 = pow(gS, g.n - 3.0);
+  double D = An * Gu * hn1 * sn1;
+  alpha = An * Gu * (g.n + 1.0) * pow(Hb, g.n) * sn1;
+  beta = An * Gu * (g.n - 1.0) * hn1 * sn3;
+  spat = Gu * hn1 * sn1;
+  if (g.Sc != 0.0) {  // sliding terms exactly as the reference writes them
+    const double k = g.Sc * (g.p - g.q + 2.0);
+    D += k * pow(Hb, g.p - g.q + 1.0) * sn1;
+    alpha += k * pow(Hb, g.p - g.q) * sn1;
+    beta += k * (g.p - 1.0) * pow(Hb, g.p - g.q + 1.0) * sn3;
+  }
+  return D;
+}
+
+template <int LM>
+__global__ __launch_bounds__(NT) void k_surface_V(Pools P, const double* __restrict__ U, double* __restrict__ Vx,
+                                                  double* __restrict__ Vy, int tile_base) {
+  __shared__ double2 sHS[TY + 2][LDW];
+  const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  double own[RPT];
+  load_tile_HS2(U, P.B, g, i0, j0, sHS, own);
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+    if (gi < g.nx && gj < g.ny) {
+      double vx = 0.0, vy = 0.0;
+      if (gi <= g.nx - 2 && gj <= g.ny - 2) {  // node whose lower-left cell is (gi, gj)
+        double gx, gy, Hb;
+        node_geom<LDW>(g, &sHS[r][tx + 1], gx, gy, Hb);
+        double An = g.A;
+        if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+        double al, be, sp;
+        const double D = node_Vup<LM>(g, Hb, gx * gx + gy * gy, An, al, be, sp);
+        vx = -D * gx;
+        vy = -D * gy;
+      }
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      Vx[id] = vx;
+      Vy[id] = vy;
+    }
+  }
+}
+
+struct VArgs {
+  const double* H;        // state (pooled)
+  const double* dVx;      // MODE 0: cotangents (pooled, nx*ny, inn1 pairing)
+  const double* dVy;
+  double* out;            // MODE 0: written; MODE 1: accumulated (+=)
+  // MODE 1: LossV data
+  const double* Vabs;     // [slot][ntot]
+  const double* Vxr;
+  const double* Vyr;
+  const double* wv;       // per-glacier weight (0: skip the glacier)
+  const double* scale;    // per-glacier 1/sqrt(mean |V_ref|^2) or 1
+  const int* refslot;     // per-glacier slot
+  long long ntot;
+  int component_abs;      // 0: :xy, 1: :abs
+  double* Gacc;           // gridded-A accumulator or null
+};
+
+template <int MODE, int LM>
+__global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_base) {
+  __shared__ double2 sHS[TY + 2][LDW];
+  __shared__ double2 sQ[TY + 1][LDN];   // {Qx, Qy}
+  __shared__ double sAW[TY + 1][LDN];   // alpha * W
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const GDev g = P.gd[t4.x];
+  double wv = 1.0, sc = 1.0;
+  long long roff = 0;
+  if (MODE == 1) {
+    wv = A.wv[t4.x];
+    if (wv == 0.0) {  // no velocity data at this stop for this glacier
+      if (threadIdx.x == 0) { P.part[4 * (long long)t4.w + 3] = 0.0; P.part[4 * (long long)t4.w + 1] = 0.0; }
+      return;
+    }
+    sc = A.scale[t4.x];
+    roff = (long long)A.refslot[t4.x] * A.ntot;
+  }
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  double own[RPT];
+  load_tile_HS2(A.H, P.B, g, i0, j0, sHS, own);
+  __syncthreads();
+  const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
+  double gsum = 0.0, lsum = 0.0;
+  for (int idx = threadIdx.x; idx < NNODE; idx += NT) {
+    const int b = idx / (TX + 1), a = idx - b * (TX + 1);
+    const int gi = i0 - 1 + a, gj = j0 - 1 + b;
+    double aW = 0.0, Qx = 0.0, Qy = 0.0;
+    if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
+      double gx, gy, Hb;
+      node_geom<LDW>(g, &sHS[b][a], gx, gy, Hb);
+      double An = g.A;
+      if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+      double al, be, sp;
+      const double D = node_Vup<LM>(g, Hb, gx * gx + gy * gy, An, al, be, sp);
+      const long long id = g.off + gi + (long long)g.nx * gj;  // inn1 pairing: node (gi,gj) <-> element [gi,gj]
+      const bool owned = (a >= 1 && b >= 1);  // lower-left cell inside the tile interior: reduced here
+      double dvx, dvy;
+      if (MODE == 0) {
+        dvx = A.dVx[id];
+        dvy = A.dVy[id];
+      } else {
+        dvx = 0.0; dvy = 0.0;
+        const double va = A.Vabs[roff + id];
+        if (va > 0.0) {  // mask = V_ref > 0 (Losses.jl:361)
+          const double vx = -D * gx, vy = -D * gy;
+          const double ex = vx - A.Vxr[roff + id], ey = vy - A.Vyr[roff + id];
+          if (!A.component_abs) {
+            dvx = 2.0 * ex * Ninv * sc;
+            dvy = 2.0 * ey * Ninv * sc;
+            if (owned) lsum = fma(ex, ex, fma(ey, ey, lsum));
+          } else {
+            const double v = sqrt(vx * vx + vy * vy), ev = v - va;
+            const double dv = 2.0 * ev * Ninv;
+            dvx = dv * ex / ev * sc;  // as the reference writes it (Losses.jl:367-368)
+            dvy = dv * ey / ev * sc;
+            if (owned) lsum = fma(ev, ev, lsum);
+          }
+        }
+      }
+      const double W = gx * dvx + gy * dvy;
+      aW = al * W;
+      Qx = fma(be * gx, W, D * dvx);
+      Qy = fma(be * gy, W, D * dvy);
+      if (owned) {
+        const double t = sp * W;
+        gsum += t;
+        if (A.Gacc) A.Gacc[g.offd + gi + (long long)(g.nx - 1) * gj] -= wv * t;
+      }
+    }
+    sAW[b][a] = aW;
+    sQ[b][a] = make_double2(Qx, Qy);
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx, c = tx + 1;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+    if (gi < g.nx && gj < g.ny) {
+      const double2 qsw = sQ[r - 1][c - 1], qse = sQ[r - 1][c], qnw = sQ[r][c - 1], qne = sQ[r][c];
+      double v = 0.25 * ((sAW[r - 1][c - 1] + sAW[r - 1][c]) + (sAW[r][c - 1] + sAW[r][c]));
+      v = fma(g.inv_dx * 0.5, (qsw.x + qnw.x) - (qse.x + qne.x), v);
+      v = fma(g.inv_dy * 0.5, (qsw.y + qse.y) - (qnw.y + qne.y), v);
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      if (MODE == 0) A.out[id] = -v;
+      else A.out[id] = fma(-wv, v, A.out[id]);
+    }
+  }
+  const double gt = block_sum(gsum, red);
+  const double lt = (MODE == 1) ? block_sum(lsum, red) : 0.0;
+  if (threadIdx.x == 0) {
+    P.part[4 * (long long)t4.w + 3] = -wv * gt;             // enters dtheta as (dA/dtheta) * sum
+    if (MODE == 1) P.part[4 * (long long)t4.w + 1] = lt * Ninv * sc * wv;
+  }
+}
+
+}  // namespace odinn

@@ -988,3 +988,190 @@ def synthetic_alpine(nx, ny, dx=50.0, hmax=110.0, slope=0.08):
     ell = ((x - 0.45 * nx * dx) / (0.38 * nx * dx)) ** 2 + ((y - yc) / (0.30 * ny * dx)) ** 2
     H0 = np.maximum(0.0, hmax * (1.0 - ell))
     return np.asfortranarray(H0), np.asfortranarray(B + 0.0 * H0)
+
+
+# ----------------------------------------------------------------------------
+# Surface-velocity path: Huginn.surface_V / V_from_H are out of tree; the
+# forward is what the reference's discrete VJPs re-execute (adjoint.jl:268-413) and what its
+# test differentiates (test/SIA2D_adjoint.jl:209-330:  <Vx, inn1(w1)> + <Vy, inn1(w2)>).
+# Target :A only (the reference's Velocity^ family for the other targets is "not correct"
+# by its own comment, target_D_pure.jl).
+# ----------------------------------------------------------------------------
+
+
+def gamma_up_no_A(ph: Phys):
+    """Gamma^(...; include_A=false) = 2 (rho g)^n/(n+1)  (target_utils.jl:20-29)."""
+    return 2.0 * (ph.rho * ph.g) ** ph.n / (ph.n + 1.0)
+
+
+def inn1(a):
+    """Huginn.inn1: A[1:end-1, 1:end-1] (pairs the dual grid with an nx*ny array)."""
+    return a[:-1, :-1]
+
+
+def _A_dual(law: Law, ph: Phys, theta=None):
+    if law.kind not in (LAW_CONST_A, LAW_NN_A_SCALAR, LAW_NN_A_GRIDDED):
+        raise ValueError("surface velocity is provided for the :A target only")
+    return law_value(law, ph, None, None, theta)
+
+
+def velocity_up(law: Law, ph: Phys, Hbar, gradS, theta=None):
+    """Velocity^ (target_A.jl:94-108), sliding term exactly as written there."""
+    A = _A_dual(law, ph, theta)
+    D = A * gamma_up_no_A(ph) * _pow(Hbar, ph.n + 1.0) * _pow(gradS, ph.n - 1.0)
+    Sc = sliding_S(ph)
+    if Sc != 0.0:
+        D = D + Sc * (ph.p - ph.q + 2.0) * _pow(Hbar, ph.p - ph.q + 1.0) * _pow(gradS, ph.n - 1.0)
+    return D
+
+
+def d_velocity_up_dH(law: Law, ph: Phys, Hbar, gradS, theta=None):
+    """dVelocity^/dH (target_A.jl:110-125)."""
+    A = _A_dual(law, ph, theta)
+    out = A * gamma_up_no_A(ph) * (ph.n + 1.0) * _pow(Hbar, ph.n) * _pow(gradS, ph.n - 1.0)
+    Sc = sliding_S(ph)
+    if Sc != 0.0:
+        out = out + Sc * (ph.p - ph.q + 2.0) * _pow(Hbar, ph.p - ph.q) * _pow(gradS, ph.n - 1.0)
+    return out
+
+
+def d_velocity_up_dgradS(law: Law, ph: Phys, Hbar, gradS, theta=None):
+    """dVelocity^/dgradH (target_A.jl:127-142)."""
+    A = _A_dual(law, ph, theta)
+    out = A * gamma_up_no_A(ph) * (ph.n - 1.0) * _pow(Hbar, ph.n + 1.0) * _pow(gradS, ph.n - 3.0)
+    Sc = sliding_S(ph)
+    if Sc != 0.0:
+        out = out + Sc * (ph.p - ph.q + 2.0) * (ph.p - 1.0) * _pow(Hbar, ph.p - ph.q + 1.0) * _pow(gradS, ph.n - 3.0)
+    return out
+
+
+def surface_V(H, B, dx, dy, ph: Phys, law: Law, theta=None):
+    """(Vx, Vy) on the dual grid: V = -Velocity^ * grad S."""
+    Hc, S, gSx, gSy, gS, Hbar, *_ = _forward_intermediates(H, B, dx, dy, ph)
+    D = velocity_up(law, ph, Hbar, gS, theta)
+    return -D * gSx, -D * gSy
+
+
+def V_from_H(H, B, dx, dy, ph: Phys, law: Law, theta=None):
+    """(Vx, Vy, V) as nx*ny arrays with inn1(.) = surface_V, 0 on the last row / column."""
+    vx, vy = surface_V(H, B, dx, dy, ph, law, theta)
+    Vx = np.zeros_like(H)
+    Vy = np.zeros_like(H)
+    Vx[:-1, :-1] = vx
+    Vy[:-1, :-1] = vy
+    return Vx, Vy, np.sqrt(Vx ** 2 + Vy ** 2)
+
+
+def vjp_surface_V_H(dVx, dVy, H, B, dx, dy, ph: Phys, law: Law, theta=None):
+    """VJP_lambda_dsurface_V/dH_discrete (adjoint.jl:268-350).  dVx, dVy are nx*ny."""
+    Hc, S, gSx, gSy, gS, Hbar, *_ = _forward_intermediates(H, B, dx, dy, ph)
+    alpha = d_velocity_up_dH(law, ph, Hbar, gS, theta)
+    beta = d_velocity_up_dgradS(law, ph, Hbar, gS, theta)
+    wx, wy = inn1(dVx), inn1(dVy)
+    gSdV = gSx * wx + gSy * wy
+    dDdH = (avg_adjoint(alpha * gSdV) + diff_x_adjoint(avg_y_adjoint(beta * gSx * gSdV), dx)
+            + diff_y_adjoint(avg_x_adjoint(beta * gSy * gSdV), dy))
+    D = velocity_up(law, ph, Hbar, gS, theta)
+    dgS = diff_x_adjoint(avg_y_adjoint(D * wx), dx) + diff_y_adjoint(avg_x_adjoint(D * wy), dy)
+    return -(dDdH + dgS)
+
+
+def vjp_surface_V_theta(dVx, dVy, H, B, dx, dy, ph: Phys, law: Law, theta=None):
+    """VJP_lambda_dsurface_V/dtheta_discrete (adjoint.jl:352-413)."""
+    Hc, S, gSx, gSy, gS, Hbar, *_ = _forward_intermediates(H, B, dx, dy, ph)
+    gSdV = gSx * inn1(dVx) + gSy * inn1(dVy)
+    spatial = gamma_up_no_A(ph) * _pow(Hbar, ph.n + 1.0) * _pow(gS, ph.n - 1.0) * gSdV
+    if law.kind == LAW_CONST_A:
+        return -np.array([np.sum(spatial)])
+    g = law_grad_theta(law, ph, Hbar, gS, theta)
+    if law.kind == LAW_NN_A_SCALAR:
+        return -g.reshape(-1) * np.sum(spatial)
+    return -np.tensordot(g, spatial, axes=([1, 2], [0, 1]))
+
+
+@dataclass
+class LossVSpec:
+    """LossV(loss=L2Sum, component, scale_loss)  (Losses.jl:66-81)."""
+
+    component: str = "xy"
+    scale_loss: bool = True
+
+
+def _lossV_scale(spec: LossVSpec, Vx_ref, Vy_ref, mask):
+    if not spec.scale_loss:
+        return 1.0
+    return 1.0 / math.sqrt(np.mean(Vx_ref[mask] ** 2 + Vy_ref[mask] ** 2))
+
+
+def loss_V(spec: LossVSpec, H, B, dx, dy, ph, law, Vabs_ref, Vx_ref, Vy_ref, normalization, theta=None):
+    """loss(::LossV, ...) without the Dt factor (Losses.jl:293-337)."""
+    Vx, Vy, V = V_from_H(H, B, dx, dy, ph, law, theta)
+    mask = Vabs_ref > 0.0
+    if spec.component == "xy":
+        l = l2sum_loss(Vx, Vx_ref, mask, normalization) + l2sum_loss(Vy, Vy_ref, mask, normalization)
+    else:
+        l = l2sum_loss(V, Vabs_ref, mask, normalization)
+    return l * _lossV_scale(spec, Vx_ref, Vy_ref, mask)
+
+
+def backward_loss_V(spec: LossVSpec, H, B, dx, dy, ph, law, Vabs_ref, Vx_ref, Vy_ref, normalization, theta=None):
+    """backward_loss(::LossV, ...) without the Dt factor (Losses.jl:338-390): (dL/dH, dL/dtheta)."""
+    Vx, Vy, V = V_from_H(H, B, dx, dy, ph, law, theta)
+    mask = Vabs_ref > 0.0
+    if spec.component == "xy":
+        dVx = l2sum_backward(Vx, Vx_ref, mask, normalization)
+        dVy = l2sum_backward(Vy, Vy_ref, mask, normalization)
+    else:
+        dV = l2sum_backward(V, Vabs_ref, mask, normalization)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dVx = np.where(mask, dV * (Vx - Vx_ref) / (V - Vabs_ref), 0.0)
+            dVy = np.where(mask, dV * (Vy - Vy_ref) / (V - Vabs_ref), 0.0)
+    sc = _lossV_scale(spec, Vx_ref, Vy_ref, mask)
+    dVx, dVy = dVx * sc, dVy * sc
+    return (vjp_surface_V_H(dVx, dVy, H, B, dx, dy, ph, law, theta),
+            vjp_surface_V_theta(dVx, dVy, H, B, dx, dy, ph, law, theta))
+
+
+def loss_and_grad_HV(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, V_ref=None, tV_ref=(), vspec=None,
+                     loss_kind="H", scaling=1.0, theta=None):
+    """SIA2D_grad_batch! (gradient.jl:45-275) with LossH, LossV or LossHV (Losses.jl:395-440).
+    V_ref = list of (Vabs, Vx, Vy) at times tV_ref.  Weights: LossH wH = dtH; LossV wV = dtV;
+    LossHV wH = dtH^2, wV = scaling*dtV^2 (the reference multiplies by Dt twice, Losses.jl:407,424-431)."""
+    snaps, st, inc = forward(gl, law, cfg, theta)
+    t = list(cfg.tstops)
+    k = len(t)
+    N = float(gl.B.size)
+    dtH = loss_weights(t, tH_ref) if loss_kind in ("H", "HV") else [0.0] * k
+    dtV = loss_weights(t, tV_ref) if loss_kind in ("V", "HV") else [0.0] * k
+    wH = [d * d if loss_kind == "HV" else d for d in dtH]
+    wV = [scaling * d * d if loss_kind == "HV" else d for d in dtV]
+    tH, tV = list(tH_ref), list(tV_ref)
+    P = 1 if law.kind == LAW_CONST_A else law.mlp.n_params
+    dLdtheta = np.zeros(P)
+    lam = [np.zeros_like(gl.B) for _ in range(k)]
+    loss_tot = 0.0
+    for j in reversed(range(k)):
+        tj = t[j]
+        if cfg.mb is not None and tj in cfg.mb_times:
+            H_pre = snaps[j] - inc[tj]
+            lam[j] = lam[j] + vjp_mb(cfg.mb, lam[j], H_pre, gl.B)
+        dl = np.zeros_like(gl.B)
+        dth = np.zeros(P)
+        if wH[j] != 0.0:
+            Hr = H_ref[tH.index(tj)]
+            mask = is_in_glacier(Hr, cfg.loss_distance)
+            dl = dl + l2sum_backward(snaps[j], Hr, mask, N) * wH[j]
+            loss_tot += l2sum_loss(snaps[j], Hr, mask, N) * wH[j]
+        if wV[j] != 0.0:
+            Va, Vxr, Vyr = V_ref[tV.index(tj)]
+            gH, gth = backward_loss_V(vspec, snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, Va, Vxr, Vyr, N, theta)
+            dl = dl + gH * wV[j]
+            dth = dth + gth * wV[j]
+            loss_tot += loss_V(vspec, snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, Va, Vxr, Vyr, N, theta) * wV[j]
+        g = vjp_H(lam[j], snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, theta)
+        if j > 0:
+            dt = t[j] - t[j - 1]
+            lam[j - 1] = lam[j] + dt * g + dl
+            dLdtheta += dt * vjp_theta(lam[j - 1], snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, theta)
+        dLdtheta += dth  # gradient.jl:252
+    return loss_tot, dLdtheta, lam[0]

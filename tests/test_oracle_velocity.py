@@ -1,0 +1,88 @@
+"""Pins the oracle's surface-velocity restatement with the reference's own test
+(test_adjoint_surface_V, test/SIA2D_adjoint.jl:209-330; thresholds [2e-4, 2e-4, 2e-2])
+and LossV / LossHV gradients against finite differences."""
+import numpy as np
+import pytest
+
+from conftest import stats_err_arrays
+from oracle import sia2d_oracle as O
+
+
+@pytest.mark.parametrize("C", [0.0, 7e-8])
+def test_surface_V_vjps_vs_fd(C):
+    ph = O.Phys(maxA=8e-18, C=C, q=1.0)
+    H0, B = O.synthetic_alpine(36, 31)
+    rng = np.random.default_rng(1234)
+    mlp = O.default_nn(1, light=True, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
+    th = mlp.init_theta(rng)
+    law = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th, T=-5.0)
+    w1, w2 = rng.standard_normal(H0.shape), rng.standard_normal(H0.shape)
+
+    def f(H, t=th):
+        vx, vy = O.surface_V(H, B, 50.0, 50.0, ph, law, t)
+        return np.sum(vx * O.inn1(w1) + vy * O.inn1(w2))
+
+    g = O.vjp_surface_V_H(w1, w2, H0, B, 50.0, 50.0, ph, law)
+    best = [np.inf] * 3
+    f0 = f(H0)
+    for eps in (1e-3, 1e-5, 1e-7):
+        gn = np.zeros_like(H0)
+        for i in range(H0.shape[0]):
+            for j in range(H0.shape[1]):
+                Hp = H0.copy()
+                Hp[i, j] += eps
+                gn[i, j] = (f(Hp) - f0) / eps
+        best = [min(a, abs(s)) for a, s in zip(best, stats_err_arrays(g, gn))]
+    assert best[0] < 2e-4 and best[1] < 2e-4 and best[2] < 2e-2, best
+    gt = O.vjp_surface_V_theta(w1, w2, H0, B, 50.0, 50.0, ph, law)
+    gn = np.zeros_like(th)
+    for q in range(th.size):
+        e = np.zeros_like(th)
+        e[q] = 1e-6
+        gn[q] = (f(H0, th + e) - f(H0, th - e)) / 2e-6
+    ratio, angle, relerr = stats_err_arrays(gt, gn)
+    assert abs(ratio) < 2e-4 and abs(angle) < 2e-4 and relerr < 2e-2
+
+
+def test_V_from_H_inn1_pairing():
+    ph = O.Phys()
+    H0, B = O.synthetic_alpine(20, 17)
+    law = O.Law(kind=O.LAW_CONST_A, A=2e-17)
+    Vx, Vy, V = O.V_from_H(H0, B, 50.0, 50.0, ph, law)
+    vx, vy = O.surface_V(H0, B, 50.0, 50.0, ph, law)
+    assert Vx.shape == H0.shape and np.array_equal(Vx[:-1, :-1], vx) and np.all(Vx[-1, :] == 0) and np.all(Vy[:, -1] == 0)
+    assert np.allclose(V, np.hypot(Vx, Vy))
+
+
+@pytest.mark.parametrize("kind,component,scale", [("V", "xy", True), ("V", "abs", True), ("HV", "xy", False)])
+def test_velocity_losses_gradient_vs_fd(kind, component, scale):
+    ph = O.Phys()
+    H0, B = O.synthetic_alpine(40, 33, hmax=160.0, slope=0.1)
+    ts = [2010.0 + j / 96.0 for j in range(7)]
+    mlp = O.default_nn(1, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
+    th_true, th0 = mlp.init_theta(np.random.default_rng(42)), mlp.init_theta(np.random.default_rng(1234))
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    cfg = O.SimConfig(tstops=ts, reltol=1e-10)
+    law_t = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th_true, T=-3.0)
+    ref, _, _ = O.forward(gl, law_t, cfg)
+    tV = ts[2::2]
+    Vref = []
+    for t in tV:
+        Vx, Vy, V = O.V_from_H(ref[ts.index(t)], B, 50.0, 50.0, ph, law_t)
+        Vref.append((V, Vx, Vy))
+    vs = O.LossVSpec(component, scale)
+    L, g, _ = O.loss_and_grad_HV(gl, O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th0, T=-3.0), cfg, ref, ts, Vref, tV, vs,
+                                 loss_kind=kind, scaling=2.5)
+
+    def loss_at(th):
+        return O.loss_and_grad_HV(gl, O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th, T=-3.0), cfg, ref, ts, Vref, tV, vs,
+                                  loss_kind=kind, scaling=2.5)[0]
+
+    idx = np.arange(0, g.size, 11)
+    gn = np.zeros_like(g)
+    for q in idx:
+        e = np.zeros_like(g)
+        e[q] = 1e-4
+        gn[q] = (loss_at(th0 + e) - loss_at(th0 - e)) / 2e-4
+    ratio, angle, relerr = stats_err_arrays(g[idx], gn[idx])
+    assert abs(ratio) < 1e-2 and abs(angle) < 1e-7 and relerr < 1e-2, (ratio, angle, relerr)
