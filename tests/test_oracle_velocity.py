@@ -8,9 +8,11 @@ from conftest import stats_err_arrays
 from oracle import sia2d_oracle as O
 
 
-@pytest.mark.parametrize("C", [0.0, 7e-8])
-def test_surface_V_vjps_vs_fd(C):
-    ph = O.Phys(maxA=8e-18, C=C, q=1.0)
+def test_surface_V_vjps_vs_fd():
+    # C = 0 as in the reference's test; with sliding the reference's dVelocity^/dH and /dgradH
+    # (target_A.jl:110-142) are not the derivatives of its Velocity^ (:94-108) -- they are restated
+    # as written (GPU == oracle is tested with C > 0), so no FD claim is made there.
+    ph = O.Phys(maxA=8e-18)
     H0, B = O.synthetic_alpine(36, 31)
     rng = np.random.default_rng(1234)
     mlp = O.default_nn(1, light=True, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
