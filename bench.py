@@ -127,6 +127,7 @@ def main():
 
     # ---- rooflines (HIP events on the library stream) --------------------------------------
     ms_fused = b.time_kernel(T.TIMED_FUSED_STEP, iters=30, warmup=5)
+    ms_fused_skip = b.time_kernel(T.TIMED_FUSED_STEP_SKIP, iters=30, warmup=5)
     ms_stage = b.time_kernel(T.TIMED_RK_STAGE2, iters=50, warmup=5)
     ach = B_PER_CELL_STAGE2 * cells / (ms_stage * 1e-3) / 1e9
     ach_fused = B_PER_CELL_FUSED * cells / (ms_fused * 1e-3) / 1e9
@@ -136,6 +137,10 @@ def main():
     ms_vjp = b.time_kernel(T.TIMED_VJP_H, iters=20, warmup=3)
     ms_vjpt = b.time_kernel(T.TIMED_VJP_THETA, iters=20, warmup=3)
     aux = {
+        "fused_step_with_ice_free_shortcut_ms": ms_fused_skip,
+        "fused_step_with_ice_free_shortcut_cellsteps_per_s": 5.0 * cells * world / (ms_fused_skip * 1e-3),
+        "ice_free_shortcut_note": "odinn_solve's default: workgroups whose halo region has u == 0 skip the stages "
+                                  "(bit-identical); `value` is measured with the shortcut OFF (dense work)",
         "per_stage_schedule_ms_per_step": ms_solve_staged,
         "per_stage_schedule_cellsteps_per_s": 5.0 * cells * world / (ms_solve_staged * 1e-3),
         "rk_5stage_kernels_ms": ms_step,

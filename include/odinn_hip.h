@@ -108,7 +108,9 @@ typedef struct odinn_solver_opts {
                        0 auto, 1 five per-stage kernels (HBM-bound, 264 B/cell/step),
                        2 one temporally fused kernel (~24 B/cell/step, fp64-VALU-bound).
                        The environment variable ODINN_SCHEME=1|2 overrides 0.               */
-  int32_t reserved;
+  int32_t dense;    /* 0 (default): workgroups of the fused step whose whole halo region is ice-free
+                       (u == 0) take an exact shortcut (bit-identical result); 1: always run the
+                       five stages (what bench.py times for `value`)                              */
 } odinn_solver_opts;
 
 typedef struct odinn_solve_stats {
@@ -200,7 +202,8 @@ enum odinn_timed {
   ODINN_TIMED_SOLVE_STEP = 5,/* what odinn_solve launches per step under the default scheme:
                                RK step kernel(s) + controller (error-norm reduce, PID) + post-step */
   ODINN_TIMED_FUSED_STEP = 6,/* the temporally fused RDPK3Sp35 step kernel alone   24 B/cell */
-  ODINN_TIMED_SOLVE_STEP_STAGED = 7 /* SOLVE_STEP forced onto the five per-stage kernels       */
+  ODINN_TIMED_SOLVE_STEP_STAGED = 7,/* SOLVE_STEP forced onto the five per-stage kernels       */
+  ODINN_TIMED_FUSED_STEP_SKIP = 8   /* fused step kernel with the ice-free-tile shortcut enabled */
 };
 /* runs `iters` back-to-back launches over ALL glaciers of the batch after `warmup`
  * untimed ones; *ms_total is the elapsed time of the timed launches. */

@@ -12,7 +12,7 @@ namespace odinn {
   void launch_vjp_H_lm##LM(int mode, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base);        \
   void launch_vjp_theta_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base);           \
   void launch_rk_fused_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,     \
-                              double* U1, double* partF, double abstol, double reltol);
+                              double* U1, double* partF, double abstol, double reltol, int skip);
 ODINN_DECL_LM(0)
 ODINN_DECL_LM(1)
 ODINN_DECL_LM(2)

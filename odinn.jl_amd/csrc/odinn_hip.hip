@@ -400,13 +400,13 @@ int pick_scheme(const odinn_batch* b, int requested) {
   return s;
 }
 
-int launch_fused_step(odinn_batch* b, double abstol, double reltol) {
+int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip) {
   const Pools P = b->pools(true);
   const LawDev L = b->lawdev();
   if (b->lm() == 0)
-    launch_rk_fused_lm0(b->ntilesF, b->stream, P, L, b->d_tilesF, b->d_U[0], b->d_U[1], b->d_partF, abstol, reltol);
+    launch_rk_fused_lm0(b->ntilesF, b->stream, P, L, b->d_tilesF, b->d_U[0], b->d_U[1], b->d_partF, abstol, reltol, skip);
   else
-    launch_rk_fused_lm1(b->ntilesF, b->stream, P, L, b->d_tilesF, b->d_U[0], b->d_U[1], b->d_partF, abstol, reltol);
+    launch_rk_fused_lm1(b->ntilesF, b->stream, P, L, b->d_tilesF, b->d_U[0], b->d_U[1], b->d_partF, abstol, reltol, skip);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -511,7 +511,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   CHK(use_dev(b));
   CHK(refresh_gd(b));
   CHK(refresh_law_field(b));
-  odinn_solver_opts opt{1e-8, 1e-6, 0.0, 0.0, 0.0, 1000000, 0, 0};
+  odinn_solver_opts opt{1e-8, 1e-6, 0.0, 0.0, 0.0, 1000000, 0, 0};  // dense = 0: ice-free tiles take the exact shortcut
   if (o) opt = *o;
   if (opt.maxiters <= 0) opt.maxiters = 1000000;
   if (opt.abstol <= 0) opt.abstol = 1e-6;
@@ -581,7 +581,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   while (nact > 0) {
     for (int s = 0; s < CHUNK; ++s) {
       if (scheme == 2) {
-        CHK(launch_fused_step(b, opt.abstol, opt.reltol));
+        CHK(launch_fused_step(b, opt.abstol, opt.reltol, opt.dense ? 0 : 1));
         C.next_cur = -1;
       } else {
         CHK(launch_step(b, p, opt.abstol, opt.reltol));
@@ -1320,7 +1320,10 @@ static int timed_one(odinn_batch* b, int which, int it) {
   switch (which) {
     case ODINN_TIMED_FUSED_STEP:
       if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "no fused step kernel for inlined-MLP laws");
-      return launch_fused_step(b, 1e-6, 1e-8);
+      return launch_fused_step(b, 1e-6, 1e-8, 0);
+    case ODINN_TIMED_FUSED_STEP_SKIP:
+      if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "no fused step kernel for inlined-MLP laws");
+      return launch_fused_step(b, 1e-6, 1e-8, 1);
     case ODINN_TIMED_SOLVE_STEP:
     case ODINN_TIMED_SOLVE_STEP_STAGED: {
       const int scheme = which == ODINN_TIMED_SOLVE_STEP_STAGED ? 1 : pick_scheme(b, 0);
@@ -1331,7 +1334,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
       PostArgs PA;
       PA.snaps = b->d_tmpA; PA.premb = b->d_tmpB; PA.ntot = b->ntot; PA.mb0 = b->d_mb0; PA.Sref = nullptr;
       if (scheme == 2) {
-        CHK(launch_fused_step(b, 1e-6, 1e-8));
+        CHK(launch_fused_step(b, 1e-6, 1e-8, 0));
         C.next_cur = -1;
       } else {
         CHK(launch_step(b, it & 1, 1e-6, 1e-8));

@@ -437,3 +437,22 @@ def test_full_size_properties(gpu):
         assert abs(dH.sum()) <= 1e-10 * np.abs(dH).sum()  # flux form: interior divergence sums to ~0
         assert np.all(dH[0, :] == 0) and np.all(dH[:, -1] == 0)
         b.close()
+
+
+def test_ice_free_tile_shortcut_is_bitwise_exact(gpu):
+    """The fused step kernel skips workgroups whose whole halo region has u == 0; the result must be
+    bit-identical to running all five stages everywhere (opts.dense = 1)."""
+    n = 320
+    H0, B = O.synthetic_icecap(n, n, 100.0)
+    H0 = np.where(H0 > 500.0, H0 - 500.0, 0.0)  # small cap: most tiles ice-free
+    ts = [0.0, 0.5, 1.0]
+    out = []
+    for dense in (0, 1):
+        b = gpu.GlacierBatch([(n, n)], [100.0], A=[4e-17])
+        b.set_fields(0, np.asfortranarray(H0), B)
+        st = b.solve(ts, reltol=1e-8, dense=dense)
+        out.append((b.snapshot(0, 1), b.snapshot(0, 2), st[0].naccept, st[0].nreject))
+        b.close()
+    assert out[0][2:] == out[1][2:]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert (out[0][1] > 0).sum() > (H0 > 0).sum()  # the cap spread into previously ice-free cells
