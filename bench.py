@@ -192,22 +192,23 @@ def main():
             from oracle import sia2d_oracle as O
 
             H0, B, A = gl[0]
-            stp = CO.Stepper(H0, B, 100.0, 100.0, O.Phys(), A)
             cores = CO.lib().oc_num_threads()
-            stp.step(1e-6)
+            ms = CO.MultiStepper(cores, H0, B, 100.0, 100.0, O.Phys(), A)  # one glacier per host thread
+            ms.run(1, 1e-6)
             tc0 = time.perf_counter()
             nst = 0
             while time.perf_counter() - tc0 < args.cpu_seconds:
-                stp.step(1e-6)
-                nst += 1
+                ms.run(2, 1e-6)
+                nst += 2
             tc = time.perf_counter() - tc0
             cpu = {
-                "value": 5.0 * n * n * nst / tc,
+                "value": 5.0 * n * n * nst * cores / tc,
                 "unit": "cell-steps/s",
                 "cores": cores,
                 "kind": "port",
-                "sample": f"{nst} RDPK3Sp35 steps of ONE {n}x{n} glacier of the workload "
-                          f"(oracle/sia2d_oracle.c, OpenMP {cores} threads, {tc:.1f} s)",
+                "sample": f"{cores} copies of ONE {n}x{n} glacier of the workload, one host thread each "
+                          f"(the reference's pmap-over-glaciers pattern), {nst} RDPK3Sp35 steps each, "
+                          f"oracle/sia2d_oracle.c, {tc:.1f} s",
             }
         except Exception as e:  # the baseline is reported, never required
             cpu = {"value": None, "unit": "cell-steps/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}

@@ -30,6 +30,8 @@ def lib():
         _lib.oc_rdpk3sp35_step.restype = C.c_double
         _lib.oc_rdpk3sp35_step.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double, C.POINTER(OcPhys),
                                            C.c_double, C.c_double, C.c_double, C.c_double, _dp]
+        _lib.oc_multi_steps.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_dp), _dp, C.c_double, C.c_double,
+                                        C.POINTER(OcPhys), C.c_double, C.c_double, C.POINTER(_dp)]
         _lib.oc_vjp_H.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.POINTER(OcPhys),
                                   C.c_double, _dp, _dp]
     return _lib
@@ -77,3 +79,23 @@ class Stepper:
     def step(self, dt, abstol=1e-6, reltol=1e-8):
         return lib().oc_rdpk3sp35_step(self.nx, self.ny, _p(self.u), _p(self.B), self.dx, self.dy, C.byref(self.ph),
                                        self.A, dt, abstol, reltol, _p(self.work))
+
+
+class MultiStepper:
+    """G copies of one glacier, one host thread each (the reference's pmap-over-glaciers use of a
+    multi-core host); used by bench.py's cpu_baseline leg."""
+
+    def __init__(self, G, H0, B, dx, dy, ph, A):
+        self.G = G
+        self.nx, self.ny = H0.shape
+        self.us = [np.asfortranarray(H0, dtype=np.float64).copy(order="F") for _ in range(G)]
+        self.works = [np.empty(7 * self.nx * self.ny) for _ in range(G)]
+        self.B = np.asfortranarray(B, dtype=np.float64)
+        self.dx, self.dy, self.A = dx, dy, A
+        self.ph = _phys(ph)
+        self._up = (_dp * G)(*[_p(u) for u in self.us])
+        self._wp = (_dp * G)(*[_p(w) for w in self.works])
+
+    def run(self, nsteps, dt):
+        lib().oc_multi_steps(self.G, nsteps, self.nx, self.ny, self._up, _p(self.B), self.dx, self.dy,
+                             C.byref(self.ph), self.A, dt, self._wp)

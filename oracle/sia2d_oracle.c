@@ -249,3 +249,15 @@ void oc_vjp_H(int nx, int ny, const double* lam, const double* H, const double* 
     }
   for (size_t c = 0; c < N; ++c) dlam[c] = (Hc[c] > 0.0) ? (T[c] + U[c]) : 0.0;
 }
+
+/* G independent glaciers advanced `nsteps` RDPK3Sp35 steps each, ONE THREAD PER GLACIER (the inner
+ * `parallel for`s run serially inside this parallel region: nested parallelism is off).  This is how
+ * the reference uses a multi-core host -- one glacier per worker process (pmap, gradient.jl:9-10,
+ * src/setup/config.jl:97-139) -- and it is the CPU baseline bench.py reports.
+ * u, work: arrays of G pointers (nx*ny and 7*nx*ny doubles each); B shared. */
+void oc_multi_steps(int G, int nsteps, int nx, int ny, double** u, const double* B, double dx, double dy,
+                    const oc_phys* ph, double A, double dt, double** work) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int g = 0; g < G; ++g)
+    for (int s = 0; s < nsteps; ++s) oc_rdpk3sp35_step(nx, ny, u[g], B, dx, dy, ph, A, dt, 1e-6, 1e-8, work[g]);
+}
