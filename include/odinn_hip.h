@@ -191,6 +191,12 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
                     int n_mb, const double* mb_times, const odinn_solver_opts* opts,
                     double* loss, double* dtheta, odinn_solve_stats* stats);
 int odinn_get_lambda0(odinn_batch* b, int g, double* lam0);
+/* Per-glacier pieces of the last odinn_loss_grad, for per-glacier parameters (PerGlacierModel:
+ * GlacierWideInv / GriddedInv, classical LawA(params), Laws.jl:402-460; aggregate rule
+ * Model.jl:208-224):  loss_g, and G_g = dL/dA_g for a glacier-wide scalar A.  With a gridded A
+ * (odinn_set_A_field or NN_A_GRIDDED) odinn_get_grad_field returns dL/dA on the dual grid. */
+int odinn_get_grad_parts(odinn_batch* b, double* loss_per_glacier, double* G_per_glacier);
+int odinn_get_grad_field(odinn_batch* b, int g, double* dLdA_dual);
 
 /* ---- measurement (HIP events on the batch's own stream, state already in HBM) -------- */
 enum odinn_timed {

@@ -87,6 +87,8 @@ SIGNATURES = {
     "odinn_loss_grad": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.POINTER(SolverOpts), _dp, _dp,
                                   C.POINTER(SolveStats)]),
     "odinn_get_lambda0": (C.c_int, [_vp, C.c_int, _dp]),
+    "odinn_get_grad_parts": (C.c_int, [_vp, _dp, _dp]),
+    "odinn_get_grad_field": (C.c_int, [_vp, C.c_int, _dp]),
     "odinn_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "odinn_bench_prepare": (C.c_int, [_vp]),
     "odinn_bench_enqueue": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),

@@ -34,7 +34,7 @@ from .batch import GlacierBatch, MLPSpec, PhysicalParameters
 __all__ = [
     "Parameters", "SimulationParameters", "SolverParameters", "Hyperparameters", "UDEparameters",
     "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
-    "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "DiscreteVJP",
+    "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "DiscreteVJP",
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad",
@@ -243,6 +243,34 @@ class NeuralNetwork:
         return self.theta.size
 
 
+class GlacierWideInv:
+    """One scalar parameter per glacier (PerGlacierModel, GlacierWideInv.jl): theta_g =
+    atanh((A_g - minA) * 2/(maxA - minA) - 1), initialised from glacier.A."""
+
+    def __init__(self, params: Parameters, glaciers: Sequence["Glacier2D"], var: str = "A"):
+        lo, hi = params.physical.minA, params.physical.maxA
+        self.sizes = [1] * len(glaciers)
+        self.theta = np.array([math.atanh((getattr(g, var) - lo) * 2.0 / (hi - lo) - 1.0) for g in glaciers])
+
+    @property
+    def n_params(self):
+        return self.theta.size
+
+
+class GriddedInv:
+    """One parameter per dual-grid node per glacier (PerGlacierModel, GriddedInv.jl)."""
+
+    def __init__(self, params: Parameters, glaciers: Sequence["Glacier2D"], var: str = "A"):
+        lo, hi = params.physical.minA, params.physical.maxA
+        self.sizes = [(g.nx - 1) * (g.ny - 1) for g in glaciers]
+        self.theta = np.concatenate([np.full(n, math.atanh((getattr(g, var) - lo) * 2.0 / (hi - lo) - 1.0))
+                                     for n, g in zip(self.sizes, glaciers)])
+
+    @property
+    def n_params(self):
+        return self.theta.size
+
+
 @dataclass
 class _Law:
     kind: int
@@ -251,6 +279,8 @@ class _Law:
     n_H: float = -1.0
     n_gradS: float = -1.0
     value: Optional[float] = None
+    classical: Optional[str] = None  # "scalar" | "gridded": LawA(params; scalar) of Laws.jl:402-460
+    bounds: Tuple[float, float] = (0.0, 1.0)
 
 
 def ConstantA(A=2.21e-18):
@@ -258,9 +288,14 @@ def ConstantA(A=2.21e-18):
     return _Law(L.LAW_CONST_A, value=A)
 
 
-def LawA(nn_model: NeuralNetwork, params: Parameters, scalar: bool = True):
-    """A = minA + (maxA-minA) * NN(T)  (Laws.jl:323-386); evaluated once per simulation
-    (callback_freq = 0 with the manual adjoints, Laws.jl:339-347)."""
+def LawA(nn_model, params: Optional[Parameters] = None, scalar: bool = True):
+    """LawA(nn_model, params; scalar): A = minA + (maxA-minA) * NN(T)  (Laws.jl:323-386), evaluated
+    once per simulation (callback_freq = 0 with the manual adjoints, Laws.jl:339-347).
+    LawA(params; scalar): the classical per-glacier law A = minA + (maxA-minA)(tanh(theta)+1)/2,
+    glacier-wide or gridded (Laws.jl:402-460)."""
+    if isinstance(nn_model, Parameters):
+        ph = nn_model.physical
+        return _Law(L.LAW_CONST_A, classical="scalar" if scalar else "gridded", bounds=(ph.minA, ph.maxA))
     ph = params.physical
     mlp = MLPSpec(nn_model.widths, nn_model.acts, None, L.POST_AFFINE, ph.minA, ph.maxA)
     return _Law(L.LAW_NN_A_SCALAR if scalar else L.LAW_NN_A_GRIDDED, nn_model, mlp)
@@ -320,6 +355,13 @@ class Model:
         self.regressors = regressors or {}
         law = iceflow.law
         self.theta = None if law.nn is None else law.nn.theta.copy()  # trainable_components.θ
+        self.per_glacier = None
+        if law.classical is not None:
+            reg = self.regressors.get("A")
+            if reg is None or not hasattr(reg, "sizes"):
+                raise ValueError("classical LawA needs regressors={'A': GlacierWideInv|GriddedInv}")
+            self.per_glacier = reg
+            self.theta = reg.theta.copy()
 
 
 # ----------------------------------------------------------------------------------------
@@ -462,7 +504,10 @@ class _Simulation:
             b.set_loss(L.LOSS_V, lf.component, lf.scale_loss)
         for k, g in enumerate(gl):
             pass
-        if law.kind == L.LAW_CONST_A:
+        if law.classical is not None:
+            self._batch = b
+            self._apply_classical(self.model.theta)
+        elif law.kind == L.LAW_CONST_A:
             if law.value is not None:
                 for k in range(len(gl)):
                     b.set_A(k, gl[k].A if gl[k].A is not None else law.value)
@@ -479,6 +524,25 @@ class _Simulation:
                     b.set_mass_balance(k, mb.fields[self._mine[k]])
         self._batch = b
         return b
+
+    # classical per-glacier law: theta slots of glacier i are [offs[i], offs[i+1])
+    def _slots(self):
+        sizes = self.model.per_glacier.sizes
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        return sizes, offs
+
+    def _apply_classical(self, theta):
+        law = self.model.iceflow.law
+        lo, hi = law.bounds
+        sizes, offs = self._slots()
+        for k, gi in enumerate(self._mine):
+            th = np.asarray(theta[offs[gi]:offs[gi + 1]])
+            A = lo + (hi - lo) * (np.tanh(th) + 1.0) / 2.0
+            if law.classical == "scalar":
+                self._batch.set_A(k, float(A[0]))
+            else:
+                g = self.glaciers[gi]
+                self._batch.set_A_field(k, A.reshape((g.nx - 1, g.ny - 1), order="F"))
 
     def _solver_opts(self):
         s = self.parameters.solver
@@ -534,8 +598,23 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
     """SIA2D_grad!(dθ, θ, simulation): loss and gradient over ALL glaciers of ALL ranks
     (gradient.jl:6-31).  Returns the loss; dθ is written in place."""
     b = simulation.batch()
-    loss, dth = b.loss_grad(simulation.tstops(), theta=theta, mb_times=simulation.mb_times(),
-                            **simulation._solver_opts())
+    law = simulation.model.iceflow.law
+    if law.classical is not None:
+        # PerGlacierModel: every theta slot has a single owner (Model.jl:214-216); dL/dtheta = dL/dA * dA/dtheta
+        simulation._apply_classical(theta)
+        loss, _ = b.loss_grad(simulation.tstops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
+        lo, hi = law.bounds
+        sizes, offs = simulation._slots()
+        dth = np.zeros_like(np.asarray(theta, dtype=np.float64))
+        _, Gg = b.grad_parts()
+        for k, gi in enumerate(simulation._mine):
+            th = np.asarray(theta[offs[gi]:offs[gi + 1]])
+            dA = (hi - lo) / 2.0 * (1.0 - np.tanh(th) ** 2)
+            dLdA = Gg[k] if law.classical == "scalar" else b.grad_field(k).ravel(order="F")
+            dth[offs[gi]:offs[gi + 1]] = dLdA * dA
+    else:
+        loss, dth = b.loss_grad(simulation.tstops(), theta=theta, mb_times=simulation.mb_times(),
+                                **simulation._solver_opts())
     loss, dth = allreduce_loss_grad(loss, dth)
     if np.linalg.norm(dth) > 1e7:  # gradient.jl:19-24
         import warnings
@@ -593,9 +672,13 @@ def _run_inversion(sim: Inversion, callback: Optional[Callable] = None):
         theta = res.x
         st.niter = len(st.losses)
     sim.model.theta = theta
-    sim.model.iceflow.law.nn.theta = theta.copy()
     st.θ = theta.copy()
-    sim.batch().set_theta(theta)
+    if sim.model.iceflow.law.classical is not None:
+        sim.model.per_glacier.theta = theta.copy()
+        sim._apply_classical(theta)
+    else:
+        sim.model.iceflow.law.nn.theta = theta.copy()
+        sim.batch().set_theta(theta)
     return st
 
 

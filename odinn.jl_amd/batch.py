@@ -303,6 +303,18 @@ class GlacierBatch:
         self.last_stats = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
         return float(loss.value), dth
 
+    def grad_parts(self):
+        """(loss_g, G_g = dL/dA_g) per glacier of the last loss_grad (PerGlacierModel plumbing)."""
+        lg, Gg = np.empty(self.G), np.empty(self.G)
+        L.check(L.lib().odinn_get_grad_parts(self._h, _p(lg), _p(Gg)))
+        return lg, Gg
+
+    def grad_field(self, g):
+        """dL/dA on the dual grid of glacier g (gridded A)."""
+        out = np.empty(self._dual(g), order="F")
+        L.check(L.lib().odinn_get_grad_field(self._h, g, _p(out)))
+        return out
+
     def lambda0(self, g):
         out = np.empty(self.shapes[g], order="F")
         L.check(L.lib().odinn_get_lambda0(self._h, g, _p(out)))

@@ -178,6 +178,8 @@ struct odinn_batch {
   int tab_cap = 0;
   bool solved = false;
   bool gd_dirty = true;
+  std::vector<double> last_loss_g, last_G_g;
+  bool grad_field_valid = false;
 
   // law mode of the stencil kernels: 0 integer-power fast path (n==3, C==0 for every glacier),
   // 1 generic pow path, 2 inlined per-node MLP (Y / U laws)
@@ -199,6 +201,10 @@ struct odinn_batch {
     for (const GDev& r : gd)
       if (!r.fast) return 1;
     return 0;
+  }
+  // dL/dA is accumulated on the dual grid when A is a field (hoisted NN or prescribed)
+  bool wants_Gacc() const {
+    return law_kind == ODINN_LAW_NN_A_GRIDDED || (law_kind == ODINN_LAW_CONST_A && has_Afield_const);
   }
   Pools pools(bool swz = true) const {
     Pools p;
@@ -494,7 +500,7 @@ int launch_lossV(odinn_batch* b, int j, const double* Hj, double* out, bool with
   A.H = Hj; A.out = out; A.Vabs = b->d_Vabs; A.Vxr = b->d_Vxr; A.Vyr = b->d_Vyr;
   A.wv = b->d_wv + (size_t)j * b->G; A.scale = b->d_vsc + (size_t)j * b->G; A.refslot = b->d_vslot + (size_t)j * b->G;
   A.ntot = b->ntot; A.component_abs = b->v_abs;
-  A.Gacc = (with_grad && b->law_kind == ODINN_LAW_NN_A_GRIDDED) ? b->d_Gacc : nullptr;
+  A.Gacc = (with_grad && b->wants_Gacc()) ? b->d_Gacc : nullptr;
   const Pools P = b->pools(true);
   launch_surfV_vjp(b->lm(), 1, b->ntiles, b->stream, P, A, 0);
   launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
@@ -959,7 +965,7 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   if (nn_node) CHK(ensure_theta_scratch(b, nblk));
   ThArgs A{};
   A.H = H; A.lam = lam; A.scales = scales;
-  A.Gacc = (b->law_kind == ODINN_LAW_NN_A_GRIDDED) ? b->d_Gacc : nullptr;
+  A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
   A.part_theta = nn_node ? b->d_part_theta : nullptr;
   A.gscratch = nn_node ? b->d_gscratch : nullptr;
   const Pools P = b->pools(g < 0);
@@ -1228,7 +1234,8 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
   HIPCHK(hipMemsetAsync(b->d_lam[0], 0, fb, b->stream));  // lambda_k = 0   (:140)
   HIPCHK(hipMemsetAsync(b->d_lossacc, 0, sizeof(double) * b->G, b->stream));
   HIPCHK(hipMemsetAsync(b->d_Gsum, 0, sizeof(double) * b->G, b->stream));
-  if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) HIPCHK(hipMemsetAsync(b->d_Gacc, 0, (size_t)b->ntotd * sizeof(double), b->stream));
+  if (b->wants_Gacc()) HIPCHK(hipMemsetAsync(b->d_Gacc, 0, (size_t)b->ntotd * sizeof(double), b->stream));
+  b->grad_field_valid = b->wants_Gacc();
   if (nn_node) {
     CHK(ensure_theta_scratch(b, b->ntiles));
     HIPCHK(hipMemsetAsync(b->d_dth, 0, sizeof(double) * b->G * b->P, b->stream));
@@ -1266,6 +1273,15 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
   HIPCHK(hipMemcpyAsync(lossg.data(), b->d_lossacc, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipMemcpyAsync(Gs.data(), b->d_Gsum, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
+  b->last_loss_g = lossg;
+  b->last_G_g = Gs;
+  for (int g = 0; g < b->G; ++g) {  // data-only LossV terms belong to their glacier
+    for (int j = 1; j < k; ++j) {
+      const size_t q = (size_t)j * b->G + g;
+      if (b->loss_kind != ODINN_LOSS_H && b->wv_h[q] != 0.0)
+        b->last_loss_g[g] += b->wv_h[q] * b->vsc_h[q] * (b->v_abs ? b->v_cabs[g][b->vslot_h[q]] : b->v_cxy[g][b->vslot_h[q]]);
+    }
+  }
   double Ltot = const_loss;
   for (int g = 0; g < b->G; ++g) Ltot += lossg[g];
   *loss = Ltot;
@@ -1287,6 +1303,23 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
       for (int q = 0; q < P; ++q) dtheta[q] += dth[(size_t)g * b->P + q];
   }
   return ODINN_OK;
+}
+
+int odinn_get_grad_parts(odinn_batch* b, double* loss_per_glacier, double* G_per_glacier) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
+  if ((int)b->last_loss_g.size() != b->G) return fail(ODINN_ERR_STATE, "no odinn_loss_grad has been run");
+  for (int g = 0; g < b->G; ++g) {
+    if (loss_per_glacier) loss_per_glacier[g] = b->last_loss_g[g];
+    if (G_per_glacier) G_per_glacier[g] = b->last_G_g[g];
+  }
+  return ODINN_OK;
+}
+
+int odinn_get_grad_field(odinn_batch* b, int g, double* dLdA_dual) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!dLdA_dual) return fail(ODINN_ERR_ARG, "null field");
+  if (!b->grad_field_valid) return fail(ODINN_ERR_STATE, "no gridded-A gradient available (set an A field and run odinn_loss_grad)");
+  return down_field(b, g, b->d_Gacc, dLdA_dual, true);
 }
 
 int odinn_get_lambda0(odinn_batch* b, int g, double* lam0) {
