@@ -559,14 +559,14 @@ __device__ __forceinline__ void load_tile_HS(const double* __restrict__ U, const
 }
 
 // Interleaved variant for the forward kernels: sHS[r][c] = {max(U,0), B + max(U,0)}.
-template <int NWV = NW>
+template <int NWV = NW, int TYV = TY>
 __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, const double* __restrict__ B, const GDev& g,
-                                              int i0, int j0, double2 (*sHS)[LDW], double (&own)[TY / NWV]) {
+                                              int i0, int j0, double2 (*sHS)[LDW], double (&own)[TYV / NWV]) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
   const bool colok = gi < g.nx;
 #pragma unroll
-  for (int m = 0; m < TY / NWV; ++m) {
+  for (int m = 0; m < TYV / NWV; ++m) {
     const int r = 1 + ty + NWV * m;
     const int gj = j0 - 1 + r;
     double h = 0.0, b = 0.0;
@@ -580,7 +580,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
     sHS[r][tx + 1] = make_double2(hc, b + hc);
   }
   if (ty < 2) {
-    const int r = ty == 0 ? 0 : TY + 1;
+    const int r = ty == 0 ? 0 : TYV + 1;
     const int gj = j0 - 1 + r;
     double h = 0.0, b = 0.0;
     if (colok && gj >= 0 && gj < g.ny) {
@@ -592,7 +592,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
     sHS[r][tx + 1] = make_double2(hc, b + hc);
   } else if (ty < 4) {
     const int l = threadIdx.x - 128;
-    if (l < 2 * (TY + 2)) {
+    if (l < 2 * (TYV + 2)) {
       const int r = l >> 1, side = l & 1;
       const int c = side ? TX + 1 : 0;
       const int gi2 = i0 - 1 + c, gj = j0 - 1 + r;
@@ -609,9 +609,9 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
 }
 
 // Same for a third field kept unclamped and masked to the interior (lambda~).
-template <int NWV = NW>
+template <int NWV = NW, int TYV = TY>
 __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, const GDev& g, int i0, int j0,
-                                              double (*sL)[LDW], double (&own)[TY / NWV]) {
+                                              double (*sL)[LDW], double (&own)[TYV / NWV]) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
   auto ld = [&](int gi_, int gj_, double& raw) -> double {
@@ -623,17 +623,17 @@ __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, con
     return 0.0;
   };
 #pragma unroll
-  for (int m = 0; m < TY / NWV; ++m) {
+  for (int m = 0; m < TYV / NWV; ++m) {
     const int r = 1 + ty + NWV * m;
     sL[r][tx + 1] = ld(gi, j0 - 1 + r, own[m]);
   }
   double dummy;
   if (ty < 2) {
-    const int r = ty == 0 ? 0 : TY + 1;
+    const int r = ty == 0 ? 0 : TYV + 1;
     sL[r][tx + 1] = ld(gi, j0 - 1 + r, dummy);
   } else if (ty < 4) {
     const int l = threadIdx.x - 128;
-    if (l < 2 * (TY + 2)) {
+    if (l < 2 * (TYV + 2)) {
       const int r = l >> 1, c = (l & 1) ? TX + 1 : 0;
       sL[r][c] = ld(i0 - 1 + c, j0 - 1 + r, dummy);
     }
@@ -994,48 +994,123 @@ struct AdjArgs {
 };
 
 #ifndef ODINN_NTA
-#define ODINN_NTA 512
+#define ODINN_NTA 256
 #endif
-constexpr int NTA = ODINN_NTA;   // threads per block of k_vjp_H (its 64 KB of LDS allow 2 blocks/CU:
-constexpr int NWA = NTA / 64;    // 8 wavefronts per block keep 16 waves/CU resident)
-constexpr int RPTA = TY / NWA;
+#ifndef ODINN_TYA
+#define ODINN_TYA 8
+#endif
+constexpr int NTA = ODINN_NTA;   // threads per block of k_vjp_H
+constexpr int NWA = NTA / 64;
+constexpr int TYA = ODINN_TYA;   // k_vjp_H works on 64 x TYA sub-tiles (TY/TYA blocks per table tile): its
+constexpr int NHALF = TY / TYA;  // seven LDS arrays then fit 4 blocks/CU instead of 2
+constexpr int RPTA = TYA / NWA;
+constexpr int NNODEA = (TX + 1) * (TYA + 1);
+// One dual node of k_vjp_H: what node (a,b) of the tile contributes to the VJP of its four corner
+// cells {SW, SE, NW, NE} -- the diffusivity term (adjoint.jl:123-127) AND its share D_node of the
+// clamp/flux term of its four edges (adjoint.jl:130-144, inversion_utils.jl:22-43); the clamped
+// slopes and their bounds are already at hand from D_adjoint (adjoint.jl:99-104).
+template <int LM>
+__device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const Pools& P, const double2 (*sHS)[LDW],
+                                          const double (*sL)[LDW], int i0, int j0, int a, int b, double (&k)[4]) {
+  const int gi = i0 - 1 + a, gj = j0 - 1 + b;
+  k[0] = k[1] = k[2] = k[3] = 0.0;
+  if (gi < 0 || gi > g.nx - 2 || gj < 0 || gj > g.ny - 2) return;
+  const double2* p = &sHS[b][a];
+  const double* pl = &sL[b][a];
+  const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
+  const double l00 = pl[0], l10 = pl[1], l01 = pl[LDW], l11 = pl[LDW + 1];
+  const double dxl = c10.y - c00.y, dxu = c11.y - c01.y, dyl = c01.y - c00.y, dyr = c11.y - c10.y;
+  const double gx = (dxl + dxu) * g.hinv_dx, gy = (dyl + dyr) * g.hinv_dy;
+  const double Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
+  const double e00 = g.eta0 * c00.x, e10 = g.eta0 * c10.x, e01 = g.eta0 * c01.x, e11 = g.eta0 * c11.x;
+  // lambda differences along the four edges (0 on edges that do not exist)
+  const double qxl = gj >= 1 ? l10 - l00 : 0.0, qxu = gj + 1 <= g.ny - 2 ? l11 - l01 : 0.0;
+  const double qyl = gi >= 1 ? l01 - l00 : 0.0, qyr = gi + 1 <= g.nx - 2 ? l11 - l10 : 0.0;
+  const double ax = fma(qxu, fmax(fmin(dxu, e11), -e01), qxl * fmax(fmin(dxl, e10), -e00));
+  const double ay = fma(qyr, fmax(fmin(dyr, e11), -e10), qyl * fmax(fmin(dyl, e01), -e00));
+  const double Da = -fma(g.hinv_dx2, ax, g.hinv_dy2 * ay);
+  double An = g.A;
+  if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+  double al, be, sp;
+  const double D = node_D<true, LM>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
+  // first term: avg^T(alpha Da) + dx^T(ay^T(beta gx Da))/dx + dy^T(ax^T(beta gy Da))/dy
+  const double ad = 0.25 * al * Da, bd = be * Da;
+  const double bx = g.hinv_dx * (bd * gx), by = g.hinv_dy * (bd * gy);
+  k[0] = ad - bx - by; k[1] = ad + bx - by; k[2] = ad - bx + by; k[3] = ad + bx + by;
+  // second term.  Edge between a "minus" cell (bound -eta H-) and a "plus" cell (bound eta H+):
+  // weight 1 for both inside the open interval; eta0 for the minus cell where dS < -eta H-, eta0 for
+  // the plus cell where dS > eta H+ (strict inequalities, inversion_utils.jl:24-28).
+  const double Dx = D * g.hinv_dx2, Dy = D * g.hinv_dy2, eta = g.eta0;
+#define ODINN_EDGE(dS, em, ep, q, Dd, KM, KP)                              \
+  {                                                                        \
+    const bool in = dS < ep && dS > -em;                                   \
+    const double t = Dd * q;                                               \
+    k[KM] = fma(t, in ? 1.0 : (dS < -em ? eta : 0.0), k[KM]);              \
+    k[KP] = fma(-t, in ? 1.0 : (dS > ep ? eta : 0.0), k[KP]);              \
+  }
+  ODINN_EDGE(dxl, e00, e10, qxl, Dx, 0, 1)
+  ODINN_EDGE(dxu, e01, e11, qxu, Dx, 2, 3)
+  ODINN_EDGE(dyl, e00, e01, qyl, Dy, 0, 2)
+  ODINN_EDGE(dyr, e10, e11, qyr, Dy, 1, 3)
+#undef ODINN_EDGE
+}
+
 template <int MODE, int LM>
-__global__ __launch_bounds__(NTA) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
-  __shared__ double2 sHS[TY + 2][LDW];   // {max(H,0), S}
-  __shared__ double sL[TY + 2][LDW];     // lambda masked to the interior
-  __shared__ double2 sN1[TY + 1][LDN];   // {D, alpha*Da}
-  __shared__ double2 sN2[TY + 1][LDN];   // {beta*gx*Da, beta*gy*Da}
-  __shared__ double red[NWA];
+__global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
+  // phase A: {Hc,S} and lambda tiles in LDS, every thread evaluates its (up to 5) nodes into
+  // registers; phase B: the same LDS is reused for the node->corner contributions and every cell
+  // adds the four numbers its corner nodes left for it.  35 KB -> 4 blocks / CU.
+  // The MLP laws (LM >= 2) are VALU-bound: they keep both phases in LDS side by side (2 blocks/CU)
+  // and a rolled node loop, so the inlined network is instantiated once.
+  constexpr bool ALIAS = LM <= LM_POW;
+  constexpr int A_D2 = (TY + 2) * LDW + ((TY + 2) * LDW + 1) / 2;  // in double2 units
+  constexpr int B_D2 = 2 * (TY + 1) * LDN;
+  __shared__ double2 smem[ALIAS ? (A_D2 > B_D2 ? A_D2 : B_D2) : A_D2 + B_D2];
+  __shared__ double red[NW];
+  double2(*sHS)[LDW] = reinterpret_cast<double2(*)[LDW]>(smem);
+  double(*sL)[LDW] = reinterpret_cast<double(*)[LDW]>(smem + (TY + 2) * LDW);
+  double2* cbase = ALIAS ? smem : smem + A_D2;
+  double2(*sCa)[LDN] = reinterpret_cast<double2(*)[LDN]>(cbase);                    // {SW, SE}
+  double2(*sCb)[LDN] = reinterpret_cast<double2(*)[LDN]>(cbase + (TY + 1) * LDN);   // {NW, NE}
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
-  double ownH[RPTA], ownL[RPTA];
-  load_tile_HS2<NWA>(A.H, P.B, g, i0, j0, sHS, ownH);
-  load_tile_lam<NWA>(A.lam, g, i0, j0, sL, ownL);
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < NNODE; idx += NTA) {
-    const int b = idx / (TX + 1), a = idx - b * (TX + 1);
-    const int gi = i0 - 1 + a, gj = j0 - 1 + b;
-    double D = 0.0, AD = 0.0, BX = 0.0, BY = 0.0;
-    if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
-      double gx, gy, Hb;
-      const double Da = node_Da<LDW>(g, &sHS[b][a], &sL[b][a], gj >= 1, gj + 1 <= g.ny - 2, gi >= 1,
-                                     gi + 1 <= g.nx - 2, gx, gy, Hb);
-      const double gS2 = gx * gx + gy * gy;
-      double An = g.A;
-      if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
-      double al, be, sp;
-      D = node_D<true, LM>(g, L, Hb, gS2, An, al, be, sp);
-      AD = al * Da;
-      const double bd = be * Da;
-      BX = bd * gx;
-      BY = bd * gy;
-    }
-    sN1[b][a] = make_double2(D, AD);
-    sN2[b][a] = make_double2(BX, BY);
-  }
+  double ownH[RPT], ownL[RPT];
+  load_tile_HS2(A.H, P.B, g, i0, j0, sHS, ownH);
+  load_tile_lam(A.lam, g, i0, j0, sL, ownL);
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // the 65th column and 17th row of nodes: wavefront 0 takes the row, wavefront 1 the column
+  const int ea = ty == 0 ? tx : TX, eb = ty == 0 ? TY : tx;
+  const bool extra = ty == 0 || (ty == 1 && tx <= TY);
+  if constexpr (ALIAS) {
+    double kk[RPT + 1][4];
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) vjpH_node<LM>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m]);
+    if (extra) vjpH_node<LM>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT]);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) {
+      sCa[ty + NW * m][tx] = make_double2(kk[m][0], kk[m][1]);
+      sCb[ty + NW * m][tx] = make_double2(kk[m][2], kk[m][3]);
+    }
+    if (extra) {
+      sCa[eb][ea] = make_double2(kk[RPT][0], kk[RPT][1]);
+      sCb[eb][ea] = make_double2(kk[RPT][2], kk[RPT][3]);
+    }
+  } else {
+#pragma unroll 1
+    for (int m = 0; m <= RPT; ++m) {
+      const int a = m < RPT ? tx : ea, b = m < RPT ? ty + NW * m : eb;
+      if (m < RPT || extra) {
+        double k[4];
+        vjpH_node<LM>(g, L, P, sHS, sL, i0, j0, a, b, k);
+        sCa[b][a] = make_double2(k[0], k[1]);
+        sCb[b][a] = make_double2(k[2], k[3]);
+      }
+    }
+  }
+  __syncthreads();
   const int gi = i0 + tx, c = tx + 1;
   double dt = 1.0, w = 0.0;
   long long roff = 0;
@@ -1047,54 +1122,13 @@ __global__ __launch_bounds__(NTA) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int
   const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
   double lsum = 0.0;
 #pragma unroll
-  for (int m = 0; m < RPTA; ++m) {
-    const int r = 1 + ty + NWA * m, gj = j0 - 1 + r;
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
     if (gi < g.nx && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
-      const double2 c0 = sHS[r][c];
       double v = 0.0;
-      if (c0.x > 0.0) {
-        const double2 nsw1 = sN1[r - 1][c - 1], nse1 = sN1[r - 1][c], nnw1 = sN1[r][c - 1], nne1 = sN1[r][c];
-        const double2 nsw2 = sN2[r - 1][c - 1], nse2 = sN2[r - 1][c], nnw2 = sN2[r][c - 1], nne2 = sN2[r][c];
-        // first term (adjoint.jl:123-127): avg^T(alpha Da) + dx^T(ay^T(bx Da))/dx + dy^T(ax^T(by Da))/dy
-        v = 0.25 * ((nsw1.y + nse1.y) + (nnw1.y + nne1.y));
-        v = fma(g.hinv_dx, (nsw2.x + nnw2.x) - (nse2.x + nne2.x), v);
-        v = fma(g.hinv_dy, (nsw2.y + nse2.y) - (nnw2.y + nne2.y), v);
-        // second term (adjoint.jl:130-144 with inversion_utils.jl:22-43): per edge
-        //   weight = 1 inside the clamp interval, eta0 where the clamp on THIS cell's H is active
-        const double S0 = c0.y, L0 = sL[r][c], eH0 = g.eta0 * c0.x;
-        double tx2 = 0.0, ty2 = 0.0;
-        if (gj >= 1 && gj <= g.ny - 2) {
-          if (gi <= g.nx - 2) {  // east edge: this cell is its left cell (lower bound -eta H0)
-            const double2 ce = sHS[r][c + 1];
-            const double dS = ce.y - S0, up = g.eta0 * ce.x;
-            const double wgt = (dS < up && dS > -eH0) ? 1.0 : (dS < -eH0 ? g.eta0 : 0.0);
-            tx2 = (sL[r][c + 1] - L0) * (nse1.x + nne1.x) * wgt;
-          }
-          if (gi >= 1) {  // west edge: this cell is its right cell (upper bound eta H0)
-            const double2 cw = sHS[r][c - 1];
-            const double dS = S0 - cw.y, lo = -(g.eta0 * cw.x);
-            const double wgt = (dS < eH0 && dS > lo) ? 1.0 : (dS > eH0 ? g.eta0 : 0.0);
-            tx2 = fma(-(L0 - sL[r][c - 1]) * (nsw1.x + nnw1.x), wgt, tx2);
-          }
-        }
-        if (gi >= 1 && gi <= g.nx - 2) {
-          if (gj <= g.ny - 2) {  // north edge
-            const double2 cn = sHS[r + 1][c];
-            const double dS = cn.y - S0, up = g.eta0 * cn.x;
-            const double wgt = (dS < up && dS > -eH0) ? 1.0 : (dS < -eH0 ? g.eta0 : 0.0);
-            ty2 = (sL[r + 1][c] - L0) * (nnw1.x + nne1.x) * wgt;
-          }
-          if (gj >= 1) {  // south edge
-            const double2 cs = sHS[r - 1][c];
-            const double dS = S0 - cs.y, lo = -(g.eta0 * cs.x);
-            const double wgt = (dS < eH0 && dS > lo) ? 1.0 : (dS > eH0 ? g.eta0 : 0.0);
-            ty2 = fma(-(L0 - sL[r - 1][c]) * (nsw1.x + nse1.x), wgt, ty2);
-          }
-        }
-        v = fma(g.hinv_dx2, tx2, v);
-        v = fma(g.hinv_dy2, ty2, v);
-      }
+      if (ownH[m] > 0.0)  // dlam .* (H .> 0)  (adjoint.jl:148)
+        v = (sCb[r - 1][c - 1].y + sCb[r - 1][c].x) + (sCa[r][c - 1].y + sCa[r][c].x);
       if (MODE == 0) {
         A.out[id] = v;
       } else {
@@ -1109,16 +1143,8 @@ __global__ __launch_bounds__(NTA) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int
     }
   }
   if (MODE == 1) {
-    double tot = wave_sum(lsum);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      tot = 0.0;
-#pragma unroll
-      for (int k = 0; k < NWA; ++k) tot += red[k];
-      P.part[4 * (long long)t4.w + 1] = tot * w * Ninv;
-    }
+    const double tot = block_sum(lsum, red);
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = tot * w * Ninv;
   }
 }
 
