@@ -51,6 +51,7 @@ extern "C" {
 #define ODINN_ERR_STATE 4
 #define ODINN_ERR_MAXITERS 5
 #define ODINN_ERR_NONFINITE 6
+#define ODINN_ERR_UNSUPPORTED 7
 
 #define ODINN_MAX_LAYERS 8
 #define ODINN_MAX_WIDTH 32
@@ -117,6 +118,18 @@ typedef struct odinn_solve_stats {
   int64_t naccept, nreject, nrhs;
   double t_final, dt_last;
 } odinn_solve_stats;
+
+/* options of the reverse solve of the continuous adjoint; defaults = ContinuousAdjoint()
+ * (src/inverse/AdjointTypes.jl:58-67): RDPK3Sp35, reltol = abstol = 1e-8, dtmax = 1/12,
+ * linear interpolation of H in time, n_quadrature = 200.  Fields <= 0 take the default. */
+typedef struct odinn_adjoint_opts {
+  double reltol;
+  double abstol;
+  double dtmax;
+  int32_t n_quadrature;
+  int32_t reserved;
+  int64_t maxiters; /* params.solver.maxiters (gradient.jl:468) */
+} odinn_adjoint_opts;
 
 typedef struct odinn_batch odinn_batch;
 
@@ -190,6 +203,17 @@ int odinn_loss(odinn_batch* b, double* loss_per_glacier);
 int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops,
                     int n_mb, const double* mb_times, const odinn_solver_opts* opts,
                     double* loss, double* dtheta, odinn_solve_stats* stats);
+/* Same contract with the reference's DEFAULT gradient method (UDEparameters.jl:63):
+ * ContinuousAdjoint(VJP_method = DiscreteVJP()) of SIA2D_grad_batch! (gradient.jl:276-539):
+ * reverse ODE dlam/dtau = J_H(H_itp(-tau))^T lam integrated on the device with adaptive RDPK3Sp35,
+ * H interpolated linearly between the forward snapshots (:287), loss and mass-balance terms added
+ * at the snapshot times (:331-365, :413-432), dL/dtheta = Gauss-Legendre quadrature of
+ * J_theta(H_itp(t))^T lam(t) (:497-503).  LossH only (ODINN_ERR_UNSUPPORTED otherwise).
+ * stats / stats_rev: forward / reverse solve statistics per glacier (may be NULL). */
+int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops,
+                               int n_mb, const double* mb_times, const odinn_solver_opts* opts,
+                               const odinn_adjoint_opts* adjoint_opts, double* loss, double* dtheta,
+                               odinn_solve_stats* stats, odinn_solve_stats* stats_rev);
 int odinn_get_lambda0(odinn_batch* b, int g, double* lam0);
 /* Per-glacier pieces of the last odinn_loss_grad, for per-glacier parameters (PerGlacierModel:
  * GlacierWideInv / GriddedInv, classical LawA(params), Laws.jl:402-460; aggregate rule

@@ -50,6 +50,12 @@ class SolveStats(C.Structure):
                 ("dt_last", C.c_double)]
 
 
+class AdjointOpts(C.Structure):
+    """odinn_adjoint_opts: reverse solve of the continuous adjoint (AdjointTypes.jl:58-67)."""
+    _fields_ = [("reltol", C.c_double), ("abstol", C.c_double), ("dtmax", C.c_double), ("n_quadrature", C.c_int32),
+                ("reserved", C.c_int32), ("maxiters", C.c_int64)]
+
+
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
@@ -86,6 +92,9 @@ SIGNATURES = {
     "odinn_loss": (C.c_int, [_vp, _dp]),
     "odinn_loss_grad": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.POINTER(SolverOpts), _dp, _dp,
                                   C.POINTER(SolveStats)]),
+    "odinn_loss_grad_continuous": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.POINTER(SolverOpts),
+                                             C.POINTER(AdjointOpts), _dp, _dp, C.POINTER(SolveStats),
+                                             C.POINTER(SolveStats)]),
     "odinn_get_lambda0": (C.c_int, [_vp, C.c_int, _dp]),
     "odinn_get_grad_parts": (C.c_int, [_vp, _dp, _dp]),
     "odinn_get_grad_field": (C.c_int, [_vp, C.c_int, _dp]),

@@ -34,7 +34,7 @@ from .batch import GlacierBatch, MLPSpec, PhysicalParameters
 __all__ = [
     "Parameters", "SimulationParameters", "SolverParameters", "Hyperparameters", "UDEparameters",
     "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
-    "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "DiscreteVJP",
+    "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DiscreteVJP",
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad",
@@ -78,6 +78,27 @@ class DiscreteAdjoint:
 
     VJP_method: DiscreteVJP = field(default_factory=DiscreteVJP)
     MB_VJP: DiscreteVJP = field(default_factory=DiscreteVJP)
+
+
+@dataclass
+class ContinuousAdjoint:
+    """src/inverse/AdjointTypes.jl:53-67 -- the reference's default `grad` (UDEparameters.jl:63).
+    Only VJP_method = DiscreteVJP() and interpolation = :Linear are provided."""
+
+    VJP_method: DiscreteVJP = field(default_factory=DiscreteVJP)
+    solver: str = "RDPK3Sp35"
+    reltol: float = 1e-8
+    abstol: float = 1e-8
+    dtmax: float = 1.0 / 12.0
+    interpolation: str = "Linear"
+    n_quadrature: int = 200
+    MB_VJP: DiscreteVJP = field(default_factory=DiscreteVJP)
+
+    def __post_init__(self):
+        if self.interpolation != "Linear":
+            raise ValueError("Interpolation method for continuous adjoint not defined.")  # gradient.jl:302
+        if self.solver != "RDPK3Sp35":
+            raise ValueError("only RDPK3Sp35 is provided for the reverse solve")
 
 
 @dataclass
@@ -137,9 +158,10 @@ class Hyperparameters:
 
 @dataclass
 class UDEparameters:
-    """src/parameters/UDEparameters.jl:60-80 (only the manual discrete adjoint is provided)."""
+    """src/parameters/UDEparameters.jl:60-80.  grad: DiscreteAdjoint() or ContinuousAdjoint() (the
+    reference's default), both with the hand-written DiscreteVJP stencils."""
 
-    grad: DiscreteAdjoint = field(default_factory=DiscreteAdjoint)
+    grad: object = field(default_factory=DiscreteAdjoint)
     empirical_loss_function: object = field(default_factory=LossH)  # LossH | LossV | LossHV
     target: str = "A"  # :A | :D_hybrid | :D
     optimization_method: str = "AD+AD"
@@ -599,10 +621,20 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
     (gradient.jl:6-31).  Returns the loss; dθ is written in place."""
     b = simulation.batch()
     law = simulation.model.iceflow.law
+    grad = simulation.parameters.UDE.grad
+    if isinstance(grad, ContinuousAdjoint):  # gradient.jl:276
+        def loss_grad(*a, **kw):
+            return b.loss_grad_continuous(*a, adj_reltol=grad.reltol, adj_abstol=grad.abstol, adj_dtmax=grad.dtmax,
+                                          n_quadrature=grad.n_quadrature,
+                                          adj_maxiters=simulation.parameters.solver.maxiters, **kw)
+    elif isinstance(grad, DiscreteAdjoint):  # gradient.jl:129
+        loss_grad = b.loss_grad
+    else:
+        raise TypeError(f"adjoint method {type(grad).__name__} is not provided")
     if law.classical is not None:
         # PerGlacierModel: every theta slot has a single owner (Model.jl:214-216); dL/dtheta = dL/dA * dA/dtheta
         simulation._apply_classical(theta)
-        loss, _ = b.loss_grad(simulation.tstops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
+        loss, _ = loss_grad(simulation.tstops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
         lo, hi = law.bounds
         sizes, offs = simulation._slots()
         dth = np.zeros_like(np.asarray(theta, dtype=np.float64))
@@ -613,8 +645,8 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
             dLdA = Gg[k] if law.classical == "scalar" else b.grad_field(k).ravel(order="F")
             dth[offs[gi]:offs[gi + 1]] = dLdA * dA
     else:
-        loss, dth = b.loss_grad(simulation.tstops(), theta=theta, mb_times=simulation.mb_times(),
-                                **simulation._solver_opts())
+        loss, dth = loss_grad(simulation.tstops(), theta=theta, mb_times=simulation.mb_times(),
+                              **simulation._solver_opts())
     loss, dth = allreduce_loss_grad(loss, dth)
     if np.linalg.norm(dth) > 1e7:  # gradient.jl:19-24
         import warnings

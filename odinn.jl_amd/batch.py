@@ -303,6 +303,28 @@ class GlacierBatch:
         self.last_stats = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
         return float(loss.value), dth
 
+    def loss_grad_continuous(self, tstops, theta=None, mb_times=(), adj_reltol=1e-8, adj_abstol=1e-8,
+                             adj_dtmax=1.0 / 12.0, n_quadrature=200, adj_maxiters=10 ** 6, **opts):
+        """(loss, dtheta) with the continuous adjoint (ContinuousAdjoint(VJP_method = DiscreteVJP()),
+        gradient.jl:276-539): reverse ODE + Gauss-Legendre quadrature, all on the device."""
+        ts = np.ascontiguousarray(tstops, dtype=np.float64)
+        mb = np.ascontiguousarray(mb_times, dtype=np.float64)
+        o = self._opts(**opts)
+        ao = L.AdjointOpts(adj_reltol, adj_abstol, adj_dtmax, int(n_quadrature), 0, int(adj_maxiters))
+        P = 1 if self.law_kind == L.LAW_CONST_A else self.P
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        loss = C.c_double(0.0)
+        dth = np.zeros(P)
+        st = (L.SolveStats * self.G)()
+        sr = (L.SolveStats * self.G)()
+        L.check(L.lib().odinn_loss_grad_continuous(
+            self._h, _p(th) if th is not None else None, P, ts.size, _p(ts), mb.size, _p(mb) if mb.size else None,
+            C.byref(o), C.byref(ao), C.byref(loss), _p(dth), st, sr))
+        self.tstops = ts
+        self.last_stats = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
+        self.last_stats_rev = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in sr]
+        return float(loss.value), dth
+
     def grad_parts(self):
         """(loss_g, G_g = dL/dA_g) per glacier of the last loss_grad (PerGlacierModel plumbing)."""
         lg, Gg = np.empty(self.G), np.empty(self.G)

@@ -8,8 +8,17 @@
 #define CAT(a, b) CAT_(a, b)
 namespace odinn {
 void CAT(launch_vjp_H_lm, ODINN_LM)(int mode, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base) {
-  if (mode == 0) hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM>), dim3(nblk), dim3(NTA), 0, st, P, L, A, base);
-  else hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM>), dim3(nblk), dim3(NTA), 0, st, P, L, A, base);
+  if (mode == 0) hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+  else hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+}
+void CAT(launch_adj_stage_lm, ODINN_LM)(int stage, int nblk, hipStream_t st, Pools P, LawDev L, AdjStageArgs A) {
+  switch (stage) {
+    case 1: hipLaunchKernelGGL((k_adj_stage<1, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+    case 2: hipLaunchKernelGGL((k_adj_stage<2, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+    case 3: hipLaunchKernelGGL((k_adj_stage<3, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+    case 4: hipLaunchKernelGGL((k_adj_stage<4, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+    default: hipLaunchKernelGGL((k_adj_stage<5, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+  }
 }
 void CAT(launch_vjp_theta_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base) {
 #if ODINN_LM == 3

@@ -51,4 +51,13 @@ void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan,
 void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double dtmax, double dt_given) {
   hipLaunchKernelGGL(k_begin, dim3((G + 63) / 64), dim3(64), 0, st, P, G, tstops, dtmax, dt_given);
 }
+void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot) {
+  hipLaunchKernelGGL(k_adj_begin, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, n_snap, tau0, mb_flag, mb_slot);
+}
+void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, int all_at_end) {
+  hipLaunchKernelGGL(k_adj_itp, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, tsnap, all_at_end);
+}
+void launch_adj_poststep(int nblk, hipStream_t st, Pools P, AdjPostArgs A, double* Ua, double* Ub) {
+  hipLaunchKernelGGL(k_adj_poststep, dim3(nblk), dim3(NT), 0, st, P, A, Ua, Ub);
+}
 }  // namespace odinn

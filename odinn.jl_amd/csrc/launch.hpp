@@ -11,6 +11,7 @@ namespace odinn {
                               double* dst, double* S2, double* S3, double* E, double abstol, double reltol);   \
   void launch_vjp_H_lm##LM(int mode, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base);        \
   void launch_vjp_theta_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base);           \
+  void launch_adj_stage_lm##LM(int stage, int nblk, hipStream_t st, Pools P, LawDev L, AdjStageArgs A);        \
   void launch_rk_fused_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,     \
                               double* U1, double* partF, double abstol, double reltol, int skip);
 ODINN_DECL_LM(0)
@@ -48,5 +49,8 @@ void launch_initdt_norms(int nblk, hipStream_t st, Pools P, const double* U, con
                          double abstol, double reltol);
 void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan, double dtmax, double* dt0store);
 void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double dtmax, double dt_given);
+void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot);
+void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, int all_at_end);
+void launch_adj_poststep(int nblk, hipStream_t st, Pools P, AdjPostArgs A, double* Ua, double* Ub);
 
 }  // namespace odinn

@@ -176,6 +176,11 @@ struct odinn_batch {
   double *d_dts = nullptr, *d_ws = nullptr, *d_lossacc = nullptr, *d_Gsum = nullptr;
   int* d_refslot = nullptr;
   int tab_cap = 0;
+  // reverse (continuous-adjoint) solve tables
+  double *d_rtau = nullptr, *d_rqw = nullptr, *d_tsnap = nullptr, *d_qw = nullptr;
+  int *d_rsnap = nullptr, *d_rmbf = nullptr, *d_rmbs = nullptr;
+  AdjState* d_adj = nullptr;
+  int rev_cap = 0, tsnap_cap = 0;
   bool solved = false;
   bool gd_dirty = true;
   std::vector<double> last_loss_g, last_G_g;
@@ -371,6 +376,12 @@ void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawD
   static void (*const tab[6])(int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
       launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5};
   tab[b->lm()](mode, nblk, b->stream, P, L, A, base);
+}
+void launch_adj_stage(int lm, int stage, int nblk, hipStream_t st, const Pools& P, const LawDev& L, const AdjStageArgs& A) {
+  static void (*const tab[6])(int, int, hipStream_t, Pools, LawDev, AdjStageArgs) = {
+      launch_adj_stage_lm0, launch_adj_stage_lm1, launch_adj_stage_lm2, launch_adj_stage_lm3, launch_adj_stage_lm4,
+      launch_adj_stage_lm5};
+  tab[lm](stage, nblk, st, P, L, A);
 }
 void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L, const ThArgs& A, int base) {
   static void (*const tab[6])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
@@ -574,11 +585,11 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   HIPCHK(hipGetLastError());
 
   const int scheme = pick_scheme(b, opt.scheme);
-  CtrlArgs C;
+  CtrlArgs C{};
   C.tstops = b->d_tstops; C.n_stops = n_stops; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
   C.dtmax = opt.dtmax; C.adaptive = adaptive ? 1 : 0; C.fixed_dt = opt.fixed_dt; C.n_active = b->d_nactive;
   C.errpart = scheme == 2 ? b->d_partF : b->d_part; C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? 1 : 0;
-  PostArgs A;
+  PostArgs A{};
   A.snaps = b->d_snaps; A.premb = b->d_premb; A.ntot = b->ntot; A.mb0 = b->d_mb0;
   A.Sref = b->any_sref ? b->d_Sref : nullptr;
   const int CHUNK = 16;  // steps between host polls of the active-glacier counter
@@ -771,6 +782,8 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
   dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0);
+  dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
+  dfree(b->d_rmbs); dfree(b->d_adj);
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
   dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
@@ -1216,10 +1229,9 @@ int odinn_loss(odinn_batch* b, double* loss_per_glacier) {
   return ODINN_OK;
 }
 
-int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
-                    const double* mb_times, const odinn_solver_opts* opts, double* loss, double* dtheta,
-                    odinn_solve_stats* stats) {
-  if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
+// forward solve + zeroed gradient accumulators (common to both adjoints)
+static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+                        const double* mb_times, const odinn_solver_opts* opts, odinn_solve_stats* stats) {
   CHK(use_dev(b));
   if (theta) CHK(odinn_set_theta(b, theta, P));
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
@@ -1227,19 +1239,28 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
   if (b->loss_kind != ODINN_LOSS_V && !b->d_Href) return fail(ODINN_ERR_STATE, "no reference thickness data set");
   if (b->loss_kind != ODINN_LOSS_H && !b->d_Vabs) return fail(ODINN_ERR_STATE, "no reference velocity data set");
   CHK(do_solve(b, n_stops, tstops, n_mb, mb_times, opts, stats));
-  // ---- reverse loop: gradient.jl:191-253 -------------------------------------------------
-  const int k = n_stops;
-  const bool nn_node = b->law_kind >= ODINN_LAW_NN_Y;
   const size_t fb = (size_t)b->ntot * sizeof(double);
-  HIPCHK(hipMemsetAsync(b->d_lam[0], 0, fb, b->stream));  // lambda_k = 0   (:140)
+  HIPCHK(hipMemsetAsync(b->d_lam[0], 0, fb, b->stream));  // lambda_k = 0   (gradient.jl:140)
   HIPCHK(hipMemsetAsync(b->d_lossacc, 0, sizeof(double) * b->G, b->stream));
   HIPCHK(hipMemsetAsync(b->d_Gsum, 0, sizeof(double) * b->G, b->stream));
   if (b->wants_Gacc()) HIPCHK(hipMemsetAsync(b->d_Gacc, 0, (size_t)b->ntotd * sizeof(double), b->stream));
   b->grad_field_valid = b->wants_Gacc();
-  if (nn_node) {
+  if (b->law_kind >= ODINN_LAW_NN_Y) {
     CHK(ensure_theta_scratch(b, b->ntiles));
     HIPCHK(hipMemsetAsync(b->d_dth, 0, sizeof(double) * b->G * b->P, b->stream));
   }
+  return ODINN_OK;
+}
+static int grad_finish(odinn_batch* b, int k, int P, double const_loss, double* loss, double* dtheta);
+
+int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+                    const double* mb_times, const odinn_solver_opts* opts, double* loss, double* dtheta,
+                    odinn_solve_stats* stats) {
+  if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
+  CHK(grad_prepare(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, stats));
+  // ---- reverse loop: gradient.jl:191-253 -------------------------------------------------
+  const int k = n_stops;
+  const size_t fb = (size_t)b->ntot * sizeof(double);
   const Pools Psw = b->pools(true);
   const LawDev L = b->lawdev();
   int cur = 0;
@@ -1268,7 +1289,11 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
   }
   HIPCHK(hipGetLastError());
   if (cur != 0) HIPCHK(hipMemcpyAsync(b->d_lam[0], b->d_lam[cur], fb, hipMemcpyDeviceToDevice, b->stream));
-  // ---- aggregate over the batch's glaciers (Model.jl:208-224) ---------------------------
+  return grad_finish(b, k, P, const_loss, loss, dtheta);
+}
+
+// ---- aggregate over the batch's glaciers (Model.jl:208-224) -----------------------------
+static int grad_finish(odinn_batch* b, int k, int P, double const_loss, double* loss, double* dtheta) {
   std::vector<double> lossg(b->G), Gs(b->G);
   HIPCHK(hipMemcpyAsync(lossg.data(), b->d_lossacc, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipMemcpyAsync(Gs.data(), b->d_Gsum, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
@@ -1303,6 +1328,194 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
       for (int q = 0; q < P; ++q) dtheta[q] += dth[(size_t)g * b->P + q];
   }
   return ODINN_OK;
+}
+
+// Gauss-Legendre nodes (ascending) and weights on [-1, 1] by Newton iteration on P_n.
+static void gauss_legendre(int n, std::vector<double>& x, std::vector<double>& w) {
+  x.assign(n, 0.0); w.assign(n, 0.0);
+  const double pi = 3.14159265358979323846;
+  for (int i = 0; i < (n + 1) / 2; ++i) {
+    double z = std::cos(pi * (i + 0.75) / (n + 0.5)), pp = 1.0;
+    for (int it = 0; it < 100; ++it) {
+      double p1 = 1.0, p2 = 0.0;
+      for (int j = 0; j < n; ++j) {
+        const double p3 = p2;
+        p2 = p1;
+        p1 = ((2.0 * j + 1.0) * z * p2 - j * p3) / (j + 1.0);
+      }
+      pp = n * (z * p1 - p2) / (z * z - 1.0);
+      const double z1 = z;
+      z = z1 - p1 / pp;
+      if (std::fabs(z - z1) <= 1e-16 * std::fabs(z)) break;
+    }
+    {  // derivative at the converged root
+      double p1 = 1.0, p2 = 0.0;
+      for (int j = 0; j < n; ++j) {
+        const double p3 = p2;
+        p2 = p1;
+        p1 = ((2.0 * j + 1.0) * z * p2 - j * p3) / (j + 1.0);
+      }
+      pp = n * (z * p1 - p2) / (z * z - 1.0);
+    }
+    x[i] = -z; x[n - 1 - i] = z;
+    w[i] = w[n - 1 - i] = 2.0 / ((1.0 - z * z) * pp * pp);
+  }
+  if (n % 2 == 1) x[n / 2] = 0.0;
+}
+
+// SIA2D_grad_batch! with ContinuousAdjoint(VJP_method = DiscreteVJP()) (gradient.jl:276-539).
+// The reverse ODE dlam/dtau = J_H(H_itp(-tau))^T lam runs on the same device-side RDPK3Sp35 + PID
+// machinery as the forward solve (one k_adj_stage per stage); its stops are the snapshot times
+// (loss and mass-balance callbacks) and the Gauss-Legendre nodes (theta-VJP quadrature).
+int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+                               const double* mb_times, const odinn_solver_opts* opts, const odinn_adjoint_opts* aopts,
+                               double* loss, double* dtheta, odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
+  if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
+  if (b->loss_kind != ODINN_LOSS_H)
+    return fail(ODINN_ERR_UNSUPPORTED, "the continuous adjoint is implemented for LossH only");
+  odinn_adjoint_opts ao{1e-8, 1e-8, 1.0 / 12.0, 200, 0, 1000000};  // AdjointTypes.jl:58-67
+  if (aopts) ao = *aopts;
+  if (ao.reltol <= 0) ao.reltol = 1e-8;
+  if (ao.abstol <= 0) ao.abstol = 1e-8;
+  if (ao.n_quadrature <= 0) ao.n_quadrature = 200;
+  if (ao.maxiters <= 0) ao.maxiters = 1000000;
+  CHK(grad_prepare(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, stats));
+  double const_loss = 0.0;
+  CHK(do_loss(b, &const_loss));  // forward loss over the snapshots -> d_lossacc
+  const int k = n_stops, G = b->G;
+  const double t0 = tstops[0], t1 = tstops[k - 1];
+  // ---- reverse stop table: tau = -t ascending over snapshots and quadrature nodes (:457) ----
+  std::vector<double> gx, gw;
+  gauss_legendre(ao.n_quadrature, gx, gw);
+  struct Stop { double tau; int snap; double qw; };
+  std::vector<Stop> st;
+  st.reserve(k + ao.n_quadrature);
+  for (int j = 0; j < k; ++j) st.push_back({-tstops[j], j, 0.0});
+  for (int i = 0; i < ao.n_quadrature; ++i)  // GaussQuadrature, :560-566
+    st.push_back({-((t0 + t1) / 2.0 + gx[i] * (t1 - t0) / 2.0), -1, (t1 - t0) / 2.0 * gw[i]});
+  std::stable_sort(st.begin(), st.end(), [](const Stop& a, const Stop& c) { return a.tau < c.tau; });
+  for (size_t i = 1; i < st.size(); ++i)
+    if (!(st[i].tau > st[i - 1].tau)) return fail(ODINN_ERR_ARG, "a quadrature node coincides with a snapshot time");
+  const int nr = (int)st.size();
+  std::vector<double> h_tau(nr), h_qw(nr);
+  std::vector<int> h_snap(nr), h_mbf(nr, 0), h_mbs(nr, 0);
+  for (int i = 0; i < nr; ++i) {
+    h_tau[i] = st[i].tau; h_qw[i] = st[i].qw; h_snap[i] = st[i].snap;
+    if (st[i].snap >= 1 && b->any_mb && b->mb_flag[st[i].snap]) { h_mbf[i] = 1; h_mbs[i] = b->mb_slot[st[i].snap]; }
+  }
+  if (nr > b->rev_cap) {
+    dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_rsnap); dfree(b->d_rmbf); dfree(b->d_rmbs);
+    CHK(dalloc(&b->d_rtau, nr)); CHK(dalloc(&b->d_rqw, nr)); CHK(dalloc(&b->d_rsnap, nr));
+    CHK(dalloc(&b->d_rmbf, nr)); CHK(dalloc(&b->d_rmbs, nr));
+    b->rev_cap = nr;
+  }
+  if (k > b->tsnap_cap) { dfree(b->d_tsnap); CHK(dalloc(&b->d_tsnap, k)); b->tsnap_cap = k; }
+  if (!b->d_adj) { CHK(dalloc(&b->d_adj, G)); CHK(dalloc(&b->d_qw, G)); }
+  HIPCHK(hipMemcpyAsync(b->d_rtau, h_tau.data(), nr * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rqw, h_qw.data(), nr * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rsnap, h_snap.data(), nr * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rmbf, h_mbf.data(), nr * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rmbs, h_mbs.data(), nr * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_tsnap, tstops, k * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_qw, 0, sizeof(double) * G, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));  // the staging vectors die with this scope
+
+  const Pools Pl = b->pools(true);
+  const LawDev L = b->lawdev();
+  const int lm = b->lm();
+  // ---- lambda(t1): loss term of the last snapshot, then the mass-balance VJP (:441-446, :431) ----
+  AdjPostArgs AP{};
+  AP.adj = b->d_adj; AP.snaps = b->d_snaps; AP.premb = b->d_premb; AP.ntot = b->ntot; AP.mb0 = b->d_mb0;
+  AP.Sref = b->any_sref ? b->d_Sref : nullptr; AP.Href = b->d_Href; AP.mask = b->d_mask; AP.ws = b->d_ws;
+  AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = b->d_tmpA;
+  const bool mb_last = b->any_mb && b->mb_flag[k - 1];
+  launch_adj_begin(G, b->stream, Pl, b->d_adj, k, h_tau[0], mb_last ? 1 : 0, mb_last ? b->mb_slot[k - 1] : 0);
+  launch_adj_poststep(b->ntiles, b->stream, Pl, AP, b->d_lam[0], b->d_lam[1]);
+  AP.loss_first = 0;
+  // ---- initial step (ode_determine_initdt on the reverse problem) ----
+  const double tspan = t1 - t0;
+  long long nrhs_extra = 0;
+  {
+    AdjArgs A{};
+    A.H = b->d_snaps + (size_t)(k - 1) * b->ntot; A.lam = b->d_lam[0]; A.out = b->d_S2; A.ntot = b->ntot;
+    launch_vjp_H(b, 0, b->ntiles, Pl, L, A, 0);  // f0
+    launch_initdt_norms(b->ntiles, b->stream, Pl, b->d_lam[0], b->d_S2, nullptr, ao.abstol, ao.reltol);
+    launch_initdt_ctrl(G, b->stream, Pl, 0, tspan, ao.dtmax, b->d_dt0);
+    launch_adj_itp(G, b->stream, Pl, b->d_adj, b->d_tsnap, 1);
+    launch_axpy_g(b->ntiles, b->stream, Pl, b->d_S2, b->d_lam[0], b->d_lam[1]);
+    A.snaps = b->d_snaps; A.adj = b->d_adj; A.lam = b->d_lam[1]; A.out = b->d_E;
+    launch_vjp_H(b, 0, b->ntiles, Pl, L, A, 0);  // f1 at tau0 + dt0
+    launch_initdt_norms(b->ntiles, b->stream, Pl, b->d_lam[0], b->d_S2, b->d_E, ao.abstol, ao.reltol);
+    launch_initdt_ctrl(G, b->stream, Pl, 1, tspan, ao.dtmax, b->d_dt0);
+    nrhs_extra = 2;
+  }
+  launch_begin(G, b->stream, Pl, b->d_rtau, ao.dtmax, 0.0);
+  launch_adj_itp(G, b->stream, Pl, b->d_adj, b->d_tsnap, 0);
+  int nact = G;
+  HIPCHK(hipMemcpyAsync(b->d_nactive, &nact, sizeof(int), hipMemcpyHostToDevice, b->stream));
+  CtrlArgs C{};
+  C.tstops = b->d_rtau; C.n_stops = nr; C.mb_flag = b->d_rmbf; C.mb_slot = b->d_rmbs; C.dtmax = ao.dtmax;
+  C.adaptive = 1; C.fixed_dt = 0.0; C.n_active = b->d_nactive; C.errpart = b->d_part; C.stride = 4; C.fused = 0;
+  C.adj = b->d_adj; C.tsnap = b->d_tsnap; C.stop_snap = b->d_rsnap; C.stop_qw = b->d_rqw; C.qw_out = b->d_qw;
+  AdjStageArgs SA{};
+  SA.snaps = b->d_snaps; SA.ntot = b->ntot; SA.adj = b->d_adj; SA.S2 = b->d_S2; SA.S3 = b->d_S3; SA.E = b->d_E;
+  SA.abstol = ao.abstol; SA.reltol = ao.reltol;
+  const int CHUNK = 16;
+  long long steps = 0;
+  int p = 0;
+  while (nact > 0) {
+    for (int s_ = 0; s_ < CHUNK; ++s_) {
+      double* a0 = b->d_lam[p];
+      double* a1 = b->d_lam[1 - p];
+      // five stages ping-pong lam[p] -> lam[1-p] -> ... ; the step's result lands in lam[1-p]
+      const double* src = a0;
+      double* dst = a1;
+      for (int stg = 1; stg <= 5; ++stg) {
+        SA.src = src; SA.dst = dst;
+        launch_adj_stage(lm, stg, b->ntiles, b->stream, Pl, L, SA);
+        double* t_ = const_cast<double*>(src);
+        src = dst;
+        dst = t_;
+      }
+      C.next_cur = 1 - p;
+      launch_controller(G, b->stream, Pl, C);
+      launch_adj_poststep(b->ntiles, b->stream, Pl, AP, b->d_lam[0], b->d_lam[1]);
+      // quadrature node reached: dtheta += w * J_theta(H_itp(t))^T lam(t)  (:497-503)
+      CHK(theta_vjp_launch(b, b->d_tmpA, a1, b->d_qw, -1, true));
+      p = 1 - p;
+      ++steps;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&nact, b->d_nactive, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (steps >= ao.maxiters && nact > 0)
+      return fail(ODINN_ERR_MAXITERS, "maxiters (%lld) reached in the reverse solve with %d glaciers active",
+                  (long long)ao.maxiters, nact);
+  }
+  std::vector<GState> gs(G);
+  HIPCHK(hipMemcpy(gs.data(), b->d_gs, sizeof(GState) * G, hipMemcpyDeviceToHost));
+  bool mixed = false;
+  for (int g = 0; g < G; ++g) {
+    if (gs[g].nonfinite) return fail(ODINN_ERR_NONFINITE, "non-finite error estimate in the reverse solve of glacier %d", g);
+    if (gs[g].cur != gs[0].cur) mixed = true;
+    if (stats_rev) {
+      stats_rev[g].naccept = gs[g].naccept;
+      stats_rev[g].nreject = gs[g].nreject;
+      stats_rev[g].nrhs = 5 * (gs[g].naccept + gs[g].nreject) + nrhs_extra;
+      stats_rev[g].t_final = -gs[g].t;
+      stats_rev[g].dt_last = gs[g].dt;
+    }
+  }
+  // lambda(t0) of every glacier -> d_lam[0] (glaciers finish in different ping-pong buffers)
+  if (mixed || gs[0].cur != 0) {
+    for (int g = 0; g < G; ++g)
+      if (gs[g].cur != 0) {
+        const GDev& r = b->gd[g];
+        HIPCHK(hipMemcpyAsync(b->d_lam[0] + r.off, b->d_lam[1] + r.off, (size_t)r.nx * r.ny * sizeof(double),
+                              hipMemcpyDeviceToDevice, b->stream));
+      }
+  }
+  return grad_finish(b, k, P, const_loss, loss, dtheta);
 }
 
 int odinn_get_grad_parts(odinn_batch* b, double* loss_per_glacier, double* G_per_glacier) {
@@ -1360,7 +1573,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
     case ODINN_TIMED_SOLVE_STEP:
     case ODINN_TIMED_SOLVE_STEP_STAGED: {
       const int scheme = which == ODINN_TIMED_SOLVE_STEP_STAGED ? 1 : pick_scheme(b, 0);
-      CtrlArgs C;
+      CtrlArgs C{};
       C.tstops = b->d_tstops; C.n_stops = 2; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
       C.dtmax = 0.0; C.adaptive = 0; C.fixed_dt = 1e-6; C.n_active = b->d_nactive;
       C.errpart = scheme == 2 ? b->d_partF : b->d_part; C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? 1 : 0;

@@ -81,6 +81,12 @@ constexpr double c_bh[5] = {1.046363371354093758897668305991705199e-01,
                                           2.449030295461310135957132640369862245e-01,
                                           1.070116530120251819121660365003405564e-01};
 
+// stage times c_i of RDPK3Sp35 (only the reverse ODE of the continuous adjoint is non-autonomous)
+constexpr double c_cc[5] = {0.0, 2.300298624518076223899418286314123354e-01,
+                                          4.050046072094990912268498160116125481e-01,
+                                          8.947822893693433545220710894560512805e-01,
+                                          7.235136928826589010272834603680114769e-01};
+
 // ---- records living in device memory ------------------------------------------------
 struct GDev {  // per-glacier constants
   int nx, ny, ntx, nty, tile0, ntiles;
@@ -111,6 +117,16 @@ struct GState {  // per-glacier integrator state (written by the controller kern
   long long naccept, nreject;
   int nonfinite;
   int pad;
+};
+
+struct AdjState {  // per-glacier state of the reverse (continuous-adjoint) solve, written by the controller
+  int seg;        // H_itp segment [tsnap[seg], tsnap[seg+1]] that contains the coming step
+  int seg_stop;   // segment that contains the stop just reached
+  int snapj;      // forward snapshot index of the stop just reached (-1: not a snapshot time)
+  int pad;
+  double qw;      // Gauss-Legendre weight of the stop just reached (0: not a quadrature node)
+  double s_stop;  // interpolation weight of the stop inside seg_stop
+  double sitp[5]; // interpolation weights at the five stage times tau + c_i dt of the coming step
 };
 
 struct LawDev {  // passed by value to kernels
@@ -561,7 +577,9 @@ __device__ __forceinline__ void load_tile_HS(const double* __restrict__ U, const
 // Interleaved variant for the forward kernels: sHS[r][c] = {max(U,0), B + max(U,0)}.
 template <int NWV = NW, int TYV = TY>
 __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, const double* __restrict__ B, const GDev& g,
-                                              int i0, int j0, double2 (*sHS)[LDW], double (&own)[TYV / NWV]) {
+                                              int i0, int j0, double2 (*sHS)[LDW], double (&own)[TYV / NWV],
+                                              const double* __restrict__ U2 = nullptr, double sw = 0.0) {
+  // U2 != null: the field is U + sw (U2 - U)  (H_itp of the continuous adjoint, gradient.jl:287)
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
   const bool colok = gi < g.nx;
@@ -573,6 +591,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
     if (colok && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
       h = U[id];
+      if (U2) h = fma(sw, U2[id] - h, h);
       b = B[id];
     }
     own[m] = h;
@@ -586,6 +605,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
     if (colok && gj >= 0 && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
       h = U[id];
+      if (U2) h = fma(sw, U2[id] - h, h);
       b = B[id];
     }
     const double hc = h > 0.0 ? h : 0.0;
@@ -600,6 +620,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
       if (gi2 >= 0 && gi2 < g.nx && gj >= 0 && gj < g.ny) {
         const long long id = g.off + gi2 + (long long)g.nx * gj;
         h = U[id];
+        if (U2) h = fma(sw, U2[id] - h, h);
         b = B[id];
       }
       const double hc = h > 0.0 ? h : 0.0;
@@ -824,14 +845,35 @@ struct CtrlArgs {
   const double* errpart;  // per-tile error partials: errpart[stride * tile]
   int stride;
   int fused;              // partials are indexed by the fused-step tile table
+  // reverse (continuous-adjoint) solve only; adj == null in the forward solve.  tstops are then
+  // tau = -t ascending, the union of the snapshot times and the Gauss-Legendre nodes.
+  AdjState* adj;
+  const double* tsnap;    // forward snapshot times t_0 < ... < t_{k-1}
+  const int* stop_snap;   // per stop: forward snapshot index, -1 for a quadrature node
+  const double* stop_qw;  // per stop: quadrature weight, 0 for a snapshot time
+  double* qw_out;         // per glacier: weight of the node reached by this step (0 otherwise)
 };
+
+// interpolation weights of H_itp at the five stage times of the step [tau, tau + dt]
+__device__ __forceinline__ void adj_stage_weights(AdjState* a, const double* tsnap, double tau, double dt,
+                                                  bool all_at_end) {
+  const double ta = tsnap[a->seg], inv = 1.0 / (tsnap[a->seg + 1] - ta);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double t = -(tau + (all_at_end ? 1.0 : c_cc[i]) * dt);
+    a->sitp[i] = fmin(fmax((t - ta) * inv, 0.0), 1.0);
+  }
+}
 
 #ifdef ODINN_MISC_KERNELS
 __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   const int gidx = blockIdx.x;
   GState* gs = P.gs + gidx;
   if (gs->done) {
-    if (threadIdx.x == 0) gs->at_stop = 0;  // its final post-step already ran
+    if (threadIdx.x == 0) {
+      gs->at_stop = 0;  // its final post-step already ran
+      if (C.qw_out) C.qw_out[gidx] = 0.0;
+    }
     return;
   }
   const GDev g = P.gd[gidx];
@@ -860,6 +902,7 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   double t = gs->t;
   gs->at_stop = 0;
   gs->mb_now = 0;
+  if (C.adj) { C.adj[gidx].qw = 0.0; C.adj[gidx].snapj = -1; }
   if (accept) {
     gs->naccept++;
     gs->accepted = 1;
@@ -869,6 +912,15 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
       gs->at_stop = 1;
       gs->mb_now = C.mb_flag[gs->istop];
       gs->mb_slot = C.mb_slot[gs->istop];
+      if (C.adj) {
+        AdjState* a = C.adj + gidx;
+        a->snapj = C.stop_snap[gs->istop];
+        a->qw = C.stop_qw[gs->istop];
+        a->seg_stop = a->seg;
+        const double ta = C.tsnap[a->seg];
+        a->s_stop = a->snapj >= 0 ? (a->snapj == a->seg ? 0.0 : 1.0) : (-t - ta) / (C.tsnap[a->seg + 1] - ta);
+        if (a->snapj >= 1) a->seg = a->snapj - 1;  // the next steps run below snapshot j
+      }
       gs->istop++;
     } else {
       t += h;
@@ -878,6 +930,7 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
     gs->nreject++;
     gs->accepted = 0;
   }
+  if (C.qw_out) C.qw_out[gidx] = C.adj[gidx].qw;
   if (gs->istop >= C.n_stops) {
     gs->done = 1;
     atomicSub(C.n_active, 1);
@@ -894,6 +947,7 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
     gs->clipped = 0;
   }
   gs->dt = dtn;
+  if (C.adj) adj_stage_weights(C.adj + gidx, C.tsnap, t, dtn, false);
 }
 
 #endif  // ODINN_MISC_KERNELS
@@ -906,6 +960,23 @@ struct PostArgs {
   long long ntot;
   const double* mb0;       // pooled
   const double* Sref;      // pooled (may be null)
+};
+
+// post-step arguments of the reverse (continuous-adjoint) solve, see k_adj_poststep
+struct AdjPostArgs {
+  const AdjState* adj;
+  const double* snaps;
+  const double* premb;
+  long long ntot;
+  const double* mb0;
+  const double* Sref;
+  const double* Href;
+  const unsigned char* mask;
+  const double* ws;      // [n_snap][G] loss weights
+  const int* refslot;    // [n_snap][G]
+  int G;
+  int loss_first;
+  double* Hq;
 };
 
 __device__ __forceinline__ double mb_value(const GDev& g, double mb0, double sref, double H, double B, double& dmb) {
@@ -991,6 +1062,9 @@ struct AdjArgs {
   const double* ws;    // per-glacier loss weight (device) or null
   const int* refslot;  // per-glacier reference slot for this stop
   long long ntot;
+  // MODE 0 only, continuous adjoint: H = H_itp at stage time 0 of each glacier's AdjState
+  const double* snaps; // forward snapshots [n_snap][ntot] or null (then H is used)
+  const AdjState* adj;
 };
 
 #ifndef ODINN_NTA
@@ -1055,35 +1129,39 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
 #undef ODINN_EDGE
 }
 
-template <int MODE, int LM>
-__global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
-  // phase A: {Hc,S} and lambda tiles in LDS, every thread evaluates its (up to 5) nodes into
-  // registers; phase B: the same LDS is reused for the node->corner contributions and every cell
-  // adds the four numbers its corner nodes left for it.  35 KB -> 4 blocks / CU.
-  // The MLP laws (LM >= 2) are VALU-bound: they keep both phases in LDS side by side (2 blocks/CU)
-  // and a rolled node loop, so the inlined network is instantiated once.
-  constexpr bool ALIAS = LM <= LM_POW;
-  constexpr int A_D2 = (TY + 2) * LDW + ((TY + 2) * LDW + 1) / 2;  // in double2 units
-  constexpr int B_D2 = 2 * (TY + 1) * LDN;
-  __shared__ double2 smem[ALIAS ? (A_D2 > B_D2 ? A_D2 : B_D2) : A_D2 + B_D2];
-  __shared__ double red[NW];
-  double2(*sHS)[LDW] = reinterpret_cast<double2(*)[LDW]>(smem);
-  double(*sL)[LDW] = reinterpret_cast<double(*)[LDW]>(smem + (TY + 2) * LDW);
-  double2* cbase = ALIAS ? smem : smem + A_D2;
+// LDS of the H-VJP kernels.  Phase A: {Hc,S} and lambda tiles; phase B: the node->corner
+// contributions.  The closed-form laws reuse the same 35 KB for both (4 blocks / CU); the MLP laws
+// (LM >= 2) are VALU-bound: they keep both side by side (2 blocks / CU) and a rolled node loop, so
+// the inlined network is instantiated once.
+template <int LM>
+struct VjpHLds {
+  static constexpr bool ALIAS = LM <= LM_POW;
+  static constexpr int A_D2 = (TY + 2) * LDW + ((TY + 2) * LDW + 1) / 2;  // in double2 units
+  static constexpr int B_D2 = 2 * (TY + 1) * LDN;
+  static constexpr int SIZE = ALIAS ? (A_D2 > B_D2 ? A_D2 : B_D2) : A_D2 + B_D2;
+  static __device__ __forceinline__ double2 (*hs(double2* m))[LDW] { return reinterpret_cast<double2(*)[LDW]>(m); }
+  static __device__ __forceinline__ double (*lam(double2* m))[LDW] {
+    return reinterpret_cast<double(*)[LDW]>(m + (TY + 2) * LDW);
+  }
+};
+
+// v[m] = (J_H(H)^T lam)[cell m of this thread] from tiles already in LDS (and synchronised).
+// Phase A: every thread evaluates its (up to 5) nodes; phase B: every cell adds the four numbers
+// its corner nodes left for it, masked by H > 0 (adjoint.jl:148).
+template <int LM>
+__device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const Pools& P, double2* smem, int i0,
+                                          int j0, const double (&ownH)[RPT], double (&v)[RPT]) {
+  using S = VjpHLds<LM>;
+  double2(*sHS)[LDW] = S::hs(smem);
+  double(*sL)[LDW] = S::lam(smem);
+  double2* cbase = S::ALIAS ? smem : smem + S::A_D2;
   double2(*sCa)[LDN] = reinterpret_cast<double2(*)[LDN]>(cbase);                    // {SW, SE}
   double2(*sCb)[LDN] = reinterpret_cast<double2(*)[LDN]>(cbase + (TY + 1) * LDN);   // {NW, NE}
-  const int4 t4 = P.tiles[blockIdx.x + tile_base];
-  const GDev g = P.gd[t4.x];
-  const int i0 = t4.y * TX, j0 = t4.z * TY;
-  double ownH[RPT], ownL[RPT];
-  load_tile_HS2(A.H, P.B, g, i0, j0, sHS, ownH);
-  load_tile_lam(A.lam, g, i0, j0, sL, ownL);
-  __syncthreads();
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   // the 65th column and 17th row of nodes: wavefront 0 takes the row, wavefront 1 the column
   const int ea = ty == 0 ? tx : TX, eb = ty == 0 ? TY : tx;
   const bool extra = ty == 0 || (ty == 1 && tx <= TY);
-  if constexpr (ALIAS) {
+  if constexpr (S::ALIAS) {
     double kk[RPT + 1][4];
 #pragma unroll
     for (int m = 0; m < RPT; ++m) vjpH_node<LM>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m]);
@@ -1111,7 +1189,36 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_vjp_H(Pools P, 
     }
   }
   __syncthreads();
-  const int gi = i0 + tx, c = tx + 1;
+  const int c = tx + 1;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m;
+    v[m] = 0.0;
+    if (ownH[m] > 0.0)  // dlam .* (H .> 0)  (adjoint.jl:148)
+      v[m] = (sCb[r - 1][c - 1].y + sCb[r - 1][c].x) + (sCa[r][c - 1].y + sCa[r][c].x);
+  }
+}
+
+template <int MODE, int LM>
+__global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
+  __shared__ double2 smem[VjpHLds<LM>::SIZE];
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  double ownH[RPT], ownL[RPT], v[RPT];
+  if (MODE == 0 && A.snaps) {
+    const AdjState a = A.adj[t4.x];
+    const double* Ha = A.snaps + (long long)a.seg * A.ntot;
+    load_tile_HS2(Ha, P.B, g, i0, j0, VjpHLds<LM>::hs(smem), ownH, Ha + A.ntot, a.sitp[0]);
+  } else {
+    load_tile_HS2(A.H, P.B, g, i0, j0, VjpHLds<LM>::hs(smem), ownH);
+  }
+  load_tile_lam(A.lam, g, i0, j0, VjpHLds<LM>::lam(smem), ownL);
+  __syncthreads();
+  vjpH_tile<LM>(g, L, P, smem, i0, j0, ownH, v);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
   double dt = 1.0, w = 0.0;
   long long roff = 0;
   if (MODE == 1) {
@@ -1123,16 +1230,13 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_vjp_H(Pools P, 
   double lsum = 0.0;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
-    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+    const int gj = j0 + ty + NW * m;
     if (gi < g.nx && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
-      double v = 0.0;
-      if (ownH[m] > 0.0)  // dlam .* (H .> 0)  (adjoint.jl:148)
-        v = (sCb[r - 1][c - 1].y + sCb[r - 1][c].x) + (sCa[r][c - 1].y + sCa[r][c].x);
       if (MODE == 0) {
-        A.out[id] = v;
+        A.out[id] = v[m];
       } else {
-        double o = fma(dt, v, ownL[m]);
+        double o = fma(dt, v[m], ownL[m]);
         if (w != 0.0 && A.mask[roff + id]) {
           const double d = ownH[m] - A.Href[roff + id];
           o = fma(w * 2.0 * Ninv, d, o);
@@ -1145,6 +1249,92 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_vjp_H(Pools P, 
   if (MODE == 1) {
     const double tot = block_sum(lsum, red);
     if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = tot * w * Ninv;
+  }
+}
+
+// =====================================================================================
+// K5b: one RDPK3Sp35 stage of the reverse ODE of the continuous adjoint
+//     dlam/dtau = J_H(H_itp(-tau))^T lam            (gradient.jl:316-324)
+// = k_rk_stage with the H-VJP as right-hand side and H interpolated linearly in time between
+// the two forward snapshots that bracket the stage time (weights from the controller).
+// =====================================================================================
+struct AdjStageArgs {
+  const double* snaps;  // forward snapshots [n_snap][ntot]
+  long long ntot;
+  const AdjState* adj;
+  const double* src;    // lambda ping-pong
+  double* dst;
+  double* S2;
+  double* S3;
+  double* E;
+  double abstol, reltol;
+};
+
+template <int STAGE, int LM>
+__global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_adj_stage(Pools P, LawDev L, AdjStageArgs A) {
+  __shared__ double2 smem[VjpHLds<LM>::SIZE];
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  if (gs->done) return;
+  const GDev g = P.gd[t4.x];
+  const AdjState a = A.adj[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const double dt = gs->dt;
+  const double* __restrict__ X = A.src;
+  if (STAGE == 1 && !gs->accepted) X = A.S3;  // rejected step: restart from uprev
+  double ownH[RPT], ownL[RPT], v[RPT];
+  {
+    const double* Ha = A.snaps + (long long)a.seg * A.ntot;
+    load_tile_HS2(Ha, P.B, g, i0, j0, VjpHLds<LM>::hs(smem), ownH, Ha + A.ntot, a.sitp[STAGE - 1]);
+  }
+  load_tile_lam(X, g, i0, j0, VjpHLds<LM>::lam(smem), ownL);
+  __syncthreads();
+  vjpH_tile<LM>(g, L, P, smem, i0, j0, ownH, v);
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  constexpr int s = STAGE - 1;
+  constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
+  double errsq = 0.0;
+  double* __restrict__ Udst = A.dst;
+  double* __restrict__ S2 = A.S2;
+  double* __restrict__ S3 = A.S3;
+  double* __restrict__ E = A.E;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = j0 + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double u = ownL[m];
+      const double dtk = dt * v[m];
+      if (STAGE == 1) {
+        Udst[id] = fma(bt, dtk, u);
+        if (gs->accepted) __builtin_nontemporal_store(u, &S3[id]);
+        __builtin_nontemporal_store(bh * dtk, &E[id]);
+      } else {
+        const double up = (STAGE == 2 || STAGE >= 4) ? __builtin_nontemporal_load(&S3[id]) : 0.0;
+        const double tmp_old = (STAGE == 2) ? up : __builtin_nontemporal_load(&S2[id]);
+        const double tmp = fma(dl, u, tmp_old);
+        double un = fma(g1, u, g2 * tmp);
+        if (STAGE >= 4) un = fma(g3, up, un);
+        un = fma(bt, dtk, un);
+        Udst[id] = un;
+        const double e = fma(bh, dtk, __builtin_nontemporal_load(&E[id]));
+        if (STAGE < 5) {
+          if (dl != 0.0) __builtin_nontemporal_store(tmp, &S2[id]);
+          __builtin_nontemporal_store(e, &E[id]);
+        } else {
+          const double err = (un - up) - e;
+          const double sk = A.abstol + fmax(fabs(up), fabs(un)) * A.reltol;
+          const double q = err / sk;
+          errsq = fma(q, q, errsq);
+        }
+      }
+    }
+  }
+  if (STAGE == 5) {
+    const double tot = block_sum(errsq, red);
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w] = tot;
   }
 }
 
@@ -1170,6 +1360,16 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   __shared__ double sL[TY + 2][LDW];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const double scale = A.scales ? A.scales[t4.x] : 1.0;
+  constexpr bool nn_node = lm_is_nn(LM);
+  if (scale == 0.0) {  // this glacier contributes nothing now (e.g. not at a quadrature node)
+    if (!nn_node) {
+      if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 2] = 0.0;
+    } else {
+      for (int k = threadIdx.x; k < L.P; k += NT) A.part_theta[(long long)t4.w * L.P + k] = 0.0;
+    }
+    return;
+  }
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double ownH[RPT], ownL[RPT];
@@ -1177,9 +1377,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   load_tile_lam(A.lam, g, i0, j0, sL, ownL);
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const double scale = A.scales ? A.scales[t4.x] : 1.0;
   double acc = 0.0;
-  constexpr bool nn_node = lm_is_nn(LM);
   const long long gstride = (long long)gridDim.x * NT;
   double* gth = A.gscratch ? A.gscratch + ((long long)blockIdx.x * NT + threadIdx.x) : nullptr;
   if (nn_node)
@@ -1493,6 +1691,89 @@ __global__ void k_begin(Pools P, int n, const double* tstops, double dtmax, doub
   gs->accepted = 1; gs->at_stop = 0; gs->mb_now = 0; gs->mb_slot = 0;
   gs->done = 0; gs->istop = 1; gs->clipped = clipped; gs->cur = 0;
   gs->naccept = 0; gs->nreject = 0; gs->nonfinite = 0;
+}
+
+
+// ---- continuous adjoint: reverse-solve bookkeeping --------------------------------------
+// start of the reverse solve: the glacier sits on stop 0 (tau_0 = -t_{k-1}, the last snapshot), marked
+// as "just reached" so that the post-step kernel adds the loss term of t_{k-1} and then the
+// mass-balance VJP (gradient.jl:441-446 and PeriodicCallback(initial_affect = true) :431-432).
+// seg starts in the last snapshot interval; k_begin later resets the integrator state proper.
+__global__ void k_adj_begin(Pools P, int n, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot) {
+  const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx >= n) return;
+  GState* gs = P.gs + gidx;
+  AdjState* a = adj + gidx;
+  a->seg = n_snap - 2; a->seg_stop = n_snap - 2; a->snapj = n_snap - 1; a->pad = 0;
+  a->qw = 0.0; a->s_stop = 1.0;
+  for (int i = 0; i < 5; ++i) a->sitp[i] = 1.0;
+  gs->t = tau0; gs->done = 0; gs->at_stop = 1; gs->cur = 0; gs->mb_now = mb_flag; gs->mb_slot = mb_slot;
+  gs->accepted = 1;
+}
+// weights for the coming step (all_at_end: every weight at tau + dt, used for the second RHS of
+// the initial-step heuristic)
+__global__ void k_adj_itp(Pools P, int n, AdjState* adj, const double* tsnap, int all_at_end) {
+  const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx >= n) return;
+  const GState* gs = P.gs + gidx;
+  adj_stage_weights(adj + gidx, tsnap, gs->t, gs->dt, all_at_end != 0);
+}
+
+// post-step of the reverse solve (pointwise, no-op for glaciers not at a stop):
+//  * snapshot time t_j: lam += VJP_MB(lam, H_j - MB_j) (:413-425) and lam += w_j dl/dH(H_j) (:331-365),
+//    mass balance first (CallbackSet order :437) except at the very first stop (loss_first);
+//  * quadrature node: Hq = H_itp(t_node) for the theta-VJP that follows (:497-503).
+
+__global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, double* __restrict__ Ua,
+                                                     double* __restrict__ Ub) {
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  if (!gs->at_stop) return;
+  const GDev g = P.gd[t4.x];
+  const AdjState a = A.adj[t4.x];
+  double* __restrict__ U = gs->cur ? Ub : Ua;
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
+  double w = 0.0;
+  long long roff = 0;
+  if (a.snapj >= 0 && A.ws) {
+    w = A.ws[(long long)a.snapj * A.G + t4.x];
+    if (w != 0.0) roff = (long long)A.refslot[(long long)a.snapj * A.G + t4.x] * A.ntot;
+  }
+  const bool do_mb = a.snapj >= 0 && gs->mb_now && g.has_mb;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = j0 + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      if (a.snapj >= 0) {
+        double l = U[id];
+        double dl = 0.0;
+        if (w != 0.0 && A.mask[roff + id])
+          dl = w * 2.0 * Ninv * (A.snaps[(long long)a.snapj * A.ntot + id] - A.Href[roff + id]);
+        if (A.loss_first) l += dl;
+        if (do_mb) {
+          const double h = A.premb[(long long)gs->mb_slot * A.ntot + id];
+          double dmb;
+          const double mb = mb_value(g, A.mb0[id], A.Sref ? A.Sref[id] : 0.0, h, P.B[id], dmb);
+          const bool msk = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
+          double vv = 0.0;
+          if (msk) vv = dmb * l;
+          if (msk && h + mb < 0.0) vv = -l;
+          l += vv;
+        }
+        if (!A.loss_first) l += dl;
+        U[id] = l;
+      }
+      if (a.qw != 0.0) {
+        const double ha = A.snaps[(long long)a.seg_stop * A.ntot + id];
+        const double hb = A.snaps[(long long)(a.seg_stop + 1) * A.ntot + id];
+        A.Hq[id] = fma(a.s_stop, hb - ha, ha);
+      }
+    }
+  }
 }
 
 #endif  // ODINN_MISC_KERNELS

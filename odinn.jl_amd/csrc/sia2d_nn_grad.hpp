@@ -118,6 +118,11 @@ __global__ __launch_bounds__(NT) void k_vjp_theta_nn(Pools P, LawDev L, ThArgs A
   double2(*sHS)[LDW] = reinterpret_cast<double2(*)[LDW]>(smem);
   double(*sL)[LDW] = reinterpret_cast<double(*)[LDW]>(smem + (TY + 2) * LDW * 2);
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  const double scale = A.scales ? A.scales[t4.x] : 1.0;
+  if (scale == 0.0) {  // this glacier contributes nothing now (e.g. not at a quadrature node)
+    for (int k = threadIdx.x; k < G::P; k += NT) A.part_theta[(long long)t4.w * G::P + k] = 0.0;
+    return;
+  }
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double ownH[RPT], ownL[RPT];
@@ -126,7 +131,6 @@ __global__ __launch_bounds__(NT) void k_vjp_theta_nn(Pools P, LawDev L, ThArgs A
   if (threadIdx.x == 0) any_active = 0;
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const double scale = A.scales ? A.scales[t4.x] : 1.0;
   double wgt[RPT], x0[RPT], x1[RPT];
   bool act = false;
 #pragma unroll

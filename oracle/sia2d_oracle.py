@@ -711,20 +711,20 @@ PID_ACCEPT_SAFETY = 0.81
 RDPK_ORDER_K = 3.0  # min(order, embedded order) + 1
 
 
-def rdpk3sp35_step(f, u, dt):
-    """One step.  Returns (u_new, utilde) with utilde = dt*sum(bhat_i k_i), so the
+def rdpk3sp35_step(f, u, dt, t=None):
+    """One step (t given: f is called as f(u, t + c_i*dt), OrdinaryDiffEq's stage times).  Returns (u_new, utilde) with utilde = dt*sum(bhat_i k_i), so the
     embedded error estimate is (u_new - u) - utilde.
 
     Register form (3S*+):  tmp=S2, u=S1, uprev=S3:
         tmp += delta_i*u ; u = g1_i*u + g2_i*tmp + g3_i*uprev + beta_i*dt*f(u)
     """
     uprev = u
-    k = f(u)
+    k = f(u) if t is None else f(u, t)
     tmp = uprev.copy()
     u = tmp + RDPK_BETA[0] * dt * k
     ut = RDPK_BHAT[0] * dt * k
     for i in range(1, 5):
-        k = f(u)
+        k = f(u) if t is None else f(u, t + RDPK_C[i] * dt)
         tmp = tmp + RDPK_DELTA[i] * u
         u = RDPK_G1[i] * u + RDPK_G2[i] * tmp + RDPK_G3[i] * uprev + RDPK_BETA[i] * dt * k
         ut = ut + RDPK_BHAT[i] * dt * k
@@ -737,14 +737,20 @@ def _rms_scaled(err, u0, u1, abstol, reltol):
     return math.sqrt(np.mean((err / sk) ** 2))
 
 
-def initial_dt(f, u0, tspan_len, abstol, reltol, dtmax, order=3):
-    """Hairer-Wanner starting step as used by OrdinaryDiffEq (ode_determine_initdt)."""
+def initial_dt(f, u0, tspan_len, abstol, reltol, dtmax, order=3, t0=None):
+    """Hairer-Wanner starting step as used by OrdinaryDiffEq (ode_determine_initdt).
+    t0 given: f is f(u, t) and the second evaluation is at t0 + dt0."""
+    if t0 is not None:
+        g, tt = f, [t0]
+        f = lambda u: g(u, tt[0])
     sk = abstol + np.abs(u0) * reltol
     d0 = math.sqrt(np.mean((u0 / sk) ** 2))
     f0 = f(u0)
     d1 = math.sqrt(np.mean((f0 / sk) ** 2))
     dt0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
     dt0 = min(dt0, dtmax, tspan_len)
+    if t0 is not None:
+        tt[0] = t0 + dt0
     f1 = f(u0 + dt0 * f0)
     d2 = math.sqrt(np.mean(((f1 - f0) / sk) ** 2)) / dt0
     dm = max(d1, d2)
@@ -771,6 +777,7 @@ def solve(
     callback_times: Sequence[float] = (),
     dt0: Optional[float] = None,
     fixed_dt: Optional[float] = None,
+    time_dependent: bool = False,
 ):
     """Adaptive RDPK3Sp35 + PID solve, saving u at every tstop (tstops[0] = t0).
 
@@ -787,7 +794,8 @@ def solve(
     cb_inc = {}
     st = SolveStats()
     if fixed_dt is None:
-        dt = initial_dt(f, u, tstops[-1] - tstops[0], abstol, reltol, dtmax) if dt0 is None else dt0
+        dt = (initial_dt(f, u, tstops[-1] - tstops[0], abstol, reltol, dtmax, t0=t if time_dependent else None)
+              if dt0 is None else dt0)
         st.nrhs += 2
     else:
         dt = fixed_dt
@@ -802,7 +810,7 @@ def solve(
             clipped = h >= rem or abs(rem - h) <= 100.0 * np.finfo(F).eps * abs(t)
             if clipped:
                 h = rem
-            un, ut = rdpk3sp35_step(f, u, h)
+            un, ut = rdpk3sp35_step(f, u, h, t if time_dependent else None)
             st.nrhs += 5
             if fixed_dt is not None:
                 u = un
@@ -924,6 +932,87 @@ def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=No
     loss_fwd = loss_H(snaps, t, H_ref, tH_ref, cfg.loss_distance)
     assert math.isclose(loss_rev, loss_fwd, rel_tol=1e-8, abs_tol=0.0) or loss_fwd == 0.0  # :259
     return loss_fwd, dLdtheta, lam[0]
+
+
+# ----------------------------------------------------------------------------
+# Continuous adjoint (gradient.jl:276-539; defaults AdjointTypes.jl:53-67) with the
+# DiscreteVJP stencils: reverse ODE  dlam/dtau = J_H(H_itp(-tau))^T lam  solved with the same
+# adaptive RDPK3Sp35, loss / mass-balance contributions as callbacks at the snapshot times,
+# dL/dtheta by Gauss-Legendre quadrature of  J_theta(H_itp(t))^T lam(t).
+# ----------------------------------------------------------------------------
+
+
+@dataclass
+class ContinuousAdjointCfg:  # AdjointTypes.jl:58-67
+    reltol: float = 1e-8
+    abstol: float = 1e-8
+    dtmax: float = 1.0 / 12.0
+    n_quadrature: int = 200
+    maxiters: int = 10 ** 6
+
+
+def gauss_quadrature(t0, t1, n):
+    """GaussQuadrature (gradient.jl:560-566): Gauss-Legendre nodes / weights mapped to [t0,t1]."""
+    x, w = np.polynomial.legendre.leggauss(n)
+    return (t0 + t1) / 2.0 + x * (t1 - t0) / 2.0, (t1 - t0) / 2.0 * w
+
+
+def linear_itp(ts, fields, t):
+    """interpolate((t,), H, Gridded(Linear())) (gradient.jl:287)."""
+    k = len(ts)
+    j = min(max(int(np.searchsorted(ts, t, side="right")) - 1, 0), k - 2)
+    s = (t - ts[j]) / (ts[j + 1] - ts[j])
+    if s == 0.0:
+        return fields[j]
+    if s == 1.0:
+        return fields[j + 1]
+    return (1.0 - s) * fields[j] + s * fields[j + 1]
+
+
+def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, adj: ContinuousAdjointCfg = None,
+                             theta=None):
+    """SIA2D_grad_batch! with ContinuousAdjoint(VJP_method = DiscreteVJP()) and LossH
+    (gradient.jl:276-539).  Returns (loss, dL/dtheta, lambda(t0), stats of the reverse solve)."""
+    adj = adj or ContinuousAdjointCfg()
+    snaps, st, inc = forward(gl, law, cfg, theta)
+    t = [float(x) for x in cfg.tstops]
+    k = len(t)
+    N = float(gl.B.size)
+    w = loss_weights(t, tH_ref)
+    tH = [float(x) for x in tH_ref]
+    mbt = set(float(x) for x in cfg.mb_times) if cfg.mb is not None else set()
+    H_itp = lambda tt: linear_itp(t, snaps, tt)  # :287
+
+    def effect_loss(tt, u):  # :331-365; dt weight included, first data time has weight 0
+        if tt in tH:
+            j = t.index(tt)
+            if w[j] != 0.0:
+                Hr = H_ref[tH.index(tt)]
+                return u + l2sum_backward(H_itp(tt), Hr, is_in_glacier(Hr, cfg.loss_distance), N) * w[j]
+        return u
+
+    def effect_mb(tt, u):  # :413-425
+        if tt in mbt:
+            return u + vjp_mb(cfg.mb, u, H_itp(tt) - inc[tt], gl.B)
+        return u
+
+    f_rev = lambda lam, tau: vjp_H(lam, H_itp(-tau), gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # :316-324
+    nodes, wts = gauss_quadrature(t[0], t[-1], adj.n_quadrature)  # :307-308
+    lam1 = effect_loss(t[-1], np.zeros_like(gl.B))  # :441-446 (not covered by the discrete callback)
+    lam1 = effect_mb(t[-1], lam1)  # PeriodicCallback(initial_affect = true) :431-432
+    snap_tau = [-x for x in reversed(t)]
+    stops = sorted(set(snap_tau) | set(-float(x) for x in nodes))  # :457
+    cb = lambda u, tau: effect_loss(-tau, effect_mb(-tau, u))  # CallbackSet order: MB, then loss :437
+    lam_s, st_rev, _ = solve(f_rev, lam1, stops, adj.reltol, adj.abstol, adj.dtmax, adj.maxiters,
+                             callback=cb, callback_times=snap_tau[1:], time_dependent=True)
+    P = 1 if law.kind == LAW_CONST_A else law.mlp.n_params
+    dLdtheta = np.zeros(P)
+    at = {tau: i for i, tau in enumerate(stops)}
+    for tn, wn in zip(nodes, wts):  # :497-503
+        lam = lam_s[at[-float(tn)]]
+        dLdtheta += wn * vjp_theta(lam, H_itp(float(tn)), gl.B, gl.dx, gl.dy, gl.phys, law, theta)
+    loss = loss_H(snaps, t, H_ref, tH_ref, cfg.loss_distance)
+    return loss, dLdtheta, lam_s[-1], st_rev
 
 
 # ----------------------------------------------------------------------------

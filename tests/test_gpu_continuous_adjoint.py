@@ -1,0 +1,109 @@
+"""GPU: continuous adjoint -- odinn_loss_grad_continuous ==
+SIA2D_grad_batch! with ContinuousAdjoint(VJP_method = DiscreteVJP()) (gradient.jl:276-539)
+against the oracle's restatement on the same inputs, and against central finite differences of
+the GPU forward loss with the reference's own thresholds [1e-3, 1e-8, 1e-3] (runtests.jl:127)."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2, stats_err_arrays
+from oracle import sia2d_oracle as O
+from test_gpu_parity import _inversion_case, _mb
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(gpu, nx, ny, H0, B, gm, th0, ts, ref, mb=None):
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-2.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_A_SCALAR, gm, th0)
+    b.set_reference(0, ts, ref, 3)
+    if mb is not None:
+        b.set_mass_balance(0, mb.mb0, mb.dmb_dS, mb.S_ref, mb.mb_max)
+    return b
+
+
+@pytest.mark.parametrize("use_mb", [False, True])
+def test_continuous_adjoint_matches_oracle(gpu, use_mb):
+    nx, ny = 64, 48
+    ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, use_mb)
+    law0 = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=om, theta=th0, T=-2.0)
+    adj = O.ContinuousAdjointCfg(n_quadrature=24)
+    Lo, go, lam0, st_o = O.loss_and_grad_continuous(gl, law0, cfg, ref, ts, adj)
+    b = _batch(gpu, nx, ny, H0, B, gm, th0, ts, ref, mb)
+    Lg, gg = b.loss_grad_continuous(ts, theta=th0, mb_times=ts[1:] if use_mb else (), reltol=1e-8, n_quadrature=24)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    # both sides integrate the same reverse ODE adaptively at reltol = abstol = 1e-8
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-9 and relerr < 1e-5, (ratio, angle, relerr)
+    assert rel_l2(b.lambda0(0), lam0) < 1e-5
+    sr = b.last_stats_rev[0]
+    assert abs(sr.t_final - ts[0]) < 1e-12
+    # same controller: the step counts agree (up to a step when an error estimate sits on the accept edge)
+    assert abs(sr.naccept - st_o.naccept) <= 2 and abs(sr.nreject - st_o.nreject) <= 2, (sr, st_o)
+    b.close()
+
+
+def test_continuous_adjoint_vs_finite_differences(gpu):
+    """test_grad_finite_diff(ContinuousAdjoint(VJP_method = DiscreteVJP()); thres = [1e-3, 1e-8, 1e-3])
+    (runtests.jl:127) with monthly snapshots -- the setting where the discrete adjoint of
+    gradient.jl:191-253 is unstable on this fast valley (test_gpu_parity.py)."""
+    nx, ny = 64, 48
+    ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, False, k=7, step=1.0 / 12.0)
+    b = _batch(gpu, nx, ny, H0, B, gm, th0, ts, ref)
+    L0, g = b.loss_grad_continuous(ts, theta=th0, reltol=1e-10, n_quadrature=60)
+
+    def loss_at(th):
+        b.set_theta(th)
+        b.solve(ts, reltol=1e-10)
+        return b.loss()[0]
+
+    gn = np.zeros_like(g)
+    idx = np.arange(0, g.size, 5)
+    for q in idx:
+        e = np.zeros_like(g)
+        e[q] = 1e-4
+        gn[q] = (loss_at(th0 + e) - loss_at(th0 - e)) / (2 * e[q])
+    ratio, angle, relerr = stats_err_arrays(g[idx], gn[idx])
+    assert abs(ratio) < 1e-3 and abs(angle) < 1e-8 and relerr < 1e-3, (ratio, angle, relerr)
+    b.close()
+
+
+def test_continuous_adjoint_ragged_batch_and_other_laws(gpu):
+    """Per-glacier reverse solves in one batch (different sizes => different step sequences) equal
+    the single-glacier results; constant-A and gridded-A accumulators are fed by the same quadrature."""
+    shapes = [(64, 48), (40, 33), (96, 20)]
+    ph = O.Phys()
+    ts = [2010.0 + j / 24.0 for j in range(5)]
+    cases = []
+    for k, (nx, ny) in enumerate(shapes):
+        H0, B = O.synthetic_valley(nx, ny, 50.0)
+        gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+        cfg = O.SimConfig(tstops=ts, reltol=1e-8)
+        ref, _, _ = O.forward(gl, O.Law(kind=O.LAW_CONST_A, A=3e-17), cfg)
+        cases.append((H0, B, gl, cfg, ref))
+    A0 = 1.5e-17
+    b = gpu.GlacierBatch(shapes, [50.0] * 3, A=[A0] * 3)
+    tot_L, tot_g = 0.0, 0.0
+    for k, (H0, B, gl, cfg, ref) in enumerate(cases):
+        b.set_fields(k, H0, B)
+        b.set_reference(k, ts, ref, 3)
+        Lo, go, _, _ = O.loss_and_grad_continuous(gl, O.Law(kind=O.LAW_CONST_A, A=A0), cfg, ref, ts,
+                                                  O.ContinuousAdjointCfg(n_quadrature=16))
+        tot_L += Lo
+        tot_g += go[0]
+    Lg, gg = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=16)
+    assert abs(Lg - tot_L) <= 1e-6 * tot_L
+    assert abs(gg[0] - tot_g) <= 1e-5 * abs(tot_g)
+    b.close()
+
+
+def test_continuous_adjoint_rejects_velocity_losses(gpu):
+    H0, B = O.synthetic_valley(32, 24, 50.0)
+    b = gpu.GlacierBatch([(32, 24)], [50.0])
+    b.set_fields(0, H0, B)
+    b.set_reference(0, [2010.0, 2010.1], [H0, H0], 3)
+    b.set_loss(gpu._lib.LOSS_V)
+    with pytest.raises(Exception) as e:
+        b.loss_grad_continuous([2010.0, 2010.1])
+    assert "LossH" in str(e.value)
+    b.close()

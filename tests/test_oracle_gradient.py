@@ -93,3 +93,35 @@ def test_inversion_recovers_A():
     A_fit = O.law_value(O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=res.x, T=-2.0), ph, None, None)
     assert min(hist) < 1e-6 * hist[0]
     assert abs(A_fit - A_true) / A_true < 1e-3
+
+
+def test_continuous_adjoint_vs_finite_differences():
+    """Oracle restatement of ContinuousAdjoint(VJP_method = DiscreteVJP()) (gradient.jl:276-539) vs
+    central finite differences with the reference's thresholds [1e-3, 1e-8, 1e-3] (runtests.jl:127),
+    monthly snapshots."""
+    ph, gl, mlp, th_true, th0, ts, cfg, ref = _case(1.0 / 12.0, 7, False)
+    law = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th0, T=-2.0)
+    L, g, lam0, st = O.loss_and_grad_continuous(gl, law, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=60))
+
+    def loss_at(th):
+        s, _, _ = O.forward(gl, O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th, T=-2.0), cfg)
+        return O.loss_H(s, ts, ref, ts, 3)
+
+    idx = np.arange(0, g.size, 6)
+    gn = np.zeros_like(g)
+    for q in idx:
+        e = np.zeros_like(g)
+        e[q] = 1e-4
+        gn[q] = (loss_at(th0 + e) - loss_at(th0 - e)) / 2e-4
+    ratio, angle, relerr = stats_err_arrays(g[idx], gn[idx])
+    assert abs(ratio) < 1e-3 and abs(angle) < 1e-8 and relerr < 1e-3, (ratio, angle, relerr)
+    assert abs(L - loss_at(th0)) <= 1e-12 * L
+
+
+def test_gauss_quadrature_nodes():
+    """GaussQuadrature (gradient.jl:560-566): exact for polynomials up to degree 2n-1, weights sum to t1-t0."""
+    x, w = O.gauss_quadrature(2010.0, 2012.0, 7)
+    assert abs(w.sum() - 2.0) < 1e-14
+    for d in range(14):
+        exact = ((2012.0 - 2011.0) ** (d + 1) - (2010.0 - 2011.0) ** (d + 1)) / (d + 1)
+        assert abs(np.sum(w * (x - 2011.0) ** d) - exact) < 5e-12  # ulp(2011) = 2.3e-13
