@@ -46,6 +46,17 @@ for G in [int(a) for a in (sys.argv[1:] or ["4", "64", "512"])]:
         b.solve(ts, reltol=1e-8)
     dtf = (time.perf_counter() - t0) / n
     steps = max(s.naccept + s.nreject for s in b.last_stats)
+    # the reference's default gradient: continuous adjoint, 200 quadrature nodes, reltol = abstol = 1e-8
+    b.loss_grad_continuous(ts, theta=th0, reltol=1e-8)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        Lc, gc = b.loss_grad_continuous(ts, theta=th0, reltol=1e-8)
+    dtc = (time.perf_counter() - t0) / n
+    rsteps = max(s.naccept + s.nreject for s in b.last_stats_rev)
+    cosang = float(np.dot(g, gc) / (np.linalg.norm(g) * np.linalg.norm(gc)))
     print(json.dumps({"G": G, "cells": b.cells, "grad_eval_ms": dt * 1e3, "forward_ms": dtf * 1e3, "grad_evals_per_s": G / dt,
-                      "max_steps": steps, "us_per_step": dtf * 1e6 / steps}))
+                      "max_steps": steps, "us_per_step": dtf * 1e6 / steps,
+                      "continuous_grad_eval_ms": dtc * 1e3, "continuous_grad_evals_per_s": G / dtc,
+                      "continuous_rev_steps": rsteps, "continuous_us_per_rev_step": (dtc - dtf) * 1e6 / rsteps,
+                      "cos_discrete_vs_continuous": cosang, "norm_ratio": float(np.linalg.norm(gc) / np.linalg.norm(g))}))
     b.close()
