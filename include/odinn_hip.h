@@ -215,6 +215,12 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
                                const odinn_adjoint_opts* adjoint_opts, double* loss, double* dtheta,
                                odinn_solve_stats* stats, odinn_solve_stats* stats_rev);
 int odinn_get_lambda0(odinn_batch* b, int g, double* lam0);
+/* TikhonovRegularization(operator = :laplacian) of src/losses/Regularization.jl:92-126 on one field
+ * a[nx*ny] (column-major): *loss = sum_mask (lap a)^2 with lap = the reference's staggered Laplacian
+ * (:330-352), grad = VJP_lap(2 mask lap a) (:372-382).  mask: nx*ny bytes or NULL (all true).
+ * Used for InitialThicknessRegularization (a = H0) and RheologyRegularization (a = A on the dual grid). */
+int odinn_tikhonov(odinn_batch* b, int nx, int ny, double dx, double dy, const double* a,
+                   const unsigned char* mask, double* loss, double* grad);
 /* Per-glacier pieces of the last odinn_loss_grad, for per-glacier parameters (PerGlacierModel:
  * GlacierWideInv / GriddedInv, classical LawA(params), Laws.jl:402-460; aggregate rule
  * Model.jl:208-224):  loss_g, and G_g = dL/dA_g for a glacier-wide scalar A.  With a gridded A

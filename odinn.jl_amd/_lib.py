@@ -92,6 +92,7 @@ SIGNATURES = {
     "odinn_loss": (C.c_int, [_vp, _dp]),
     "odinn_loss_grad": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.POINTER(SolverOpts), _dp, _dp,
                                   C.POINTER(SolveStats)]),
+    "odinn_tikhonov": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, _dp, C.c_void_p, _dp, _dp]),
     "odinn_loss_grad_continuous": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.POINTER(SolverOpts),
                                              C.POINTER(AdjointOpts), _dp, _dp, C.POINTER(SolveStats),
                                              C.POINTER(SolveStats)]),

@@ -34,7 +34,9 @@ from .batch import GlacierBatch, MLPSpec, PhysicalParameters
 __all__ = [
     "Parameters", "SimulationParameters", "SolverParameters", "Hyperparameters", "UDEparameters",
     "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
-    "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DiscreteVJP",
+    "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DiscreteVJP", "MultiLoss", "TikhonovRegularization",
+    "InitialThicknessRegularization", "RheologyRegularization", "InitialCondition", "evaluate_H0", "evaluate_dH0",
+    "sigma_zang", "dsigma_zang",
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad",
@@ -134,6 +136,61 @@ class LossHV:
 
 
 @dataclass
+class TikhonovRegularization:
+    """src/losses/Regularization.jl:24-45: sum over a mask of (nabla^2 a)^2 with the staggered Laplacian
+    (:330-352) and its hand-written VJP (:372-382); evaluated on the device (odinn_tikhonov)."""
+
+    operator: str = "laplacian"
+    distance: int = 3
+
+    def __post_init__(self):
+        if self.operator != "laplacian":
+            raise ValueError(f"Operator named {self.operator} not implemented inside Tikhonov regularization")
+
+
+@dataclass
+class InitialThicknessRegularization:
+    """src/losses/Regularization.jl:47-61,128-190: Tikhonov term on H0 = evaluate_H0(theta.IC) at t0."""
+
+    reg: TikhonovRegularization = field(default_factory=TikhonovRegularization)
+    t0: float = 1994.0
+
+
+@dataclass
+class RheologyRegularization:
+    """src/losses/Regularization.jl:79-89,252-310: Tikhonov term on the gridded A of a classical inversion."""
+
+    reg: TikhonovRegularization = field(default_factory=TikhonovRegularization)
+
+
+@dataclass
+class MultiLoss:
+    """src/losses/MultiLoss.jl:22-35: sum_k lambdas[k] * losses[k].  One data term (LossH | LossV |
+    LossHV, evaluated by the device adjoint) plus any number of regularisers."""
+
+    losses: Tuple = field(default_factory=lambda: (LossH(),))
+    lambdas: Tuple = (1.0,)  # λs
+
+    def __post_init__(self):
+        if len(self.losses) != len(self.lambdas):
+            raise ValueError("You need to provide an hyperparameter for each loss term defined.")  # MultiLoss.jl:29
+
+
+def _split_loss(lf):
+    """(data loss, its weight, [(regulariser, weight)]) of a loss specification."""
+    if not isinstance(lf, MultiLoss):
+        return lf, 1.0, []
+    data = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if isinstance(l, (LossH, LossV, LossHV))]
+    regs = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if not isinstance(l, (LossH, LossV, LossHV))]
+    if len(data) != 1:
+        raise ValueError("MultiLoss needs exactly one data term (LossH, LossV or LossHV)")
+    for r, _ in regs:
+        if not isinstance(r, (InitialThicknessRegularization, RheologyRegularization)):
+            raise TypeError(f"loss term {type(r).__name__} is not provided")
+    return data[0][0], float(data[0][1]), regs
+
+
+@dataclass
 class Adam:
     """Optimisers.Adam(eta, (beta1, beta2), eps)"""
 
@@ -165,6 +222,7 @@ class UDEparameters:
     empirical_loss_function: object = field(default_factory=LossH)  # LossH | LossV | LossHV
     target: str = "A"  # :A | :D_hybrid | :D
     optimization_method: str = "AD+AD"
+    initial_condition_filter: str = "identity"  # :identity | :softplus | :Zang1980 (UDEparameters.jl:67)
 
 
 @dataclass
@@ -212,6 +270,11 @@ class Glacier2D:
     T: float = -5.0  # long-term air temperature (iAvgScalarTemp)
     thicknessData: Optional[ThicknessData] = None
     velocityData: Optional[VelocityData] = None
+    mask: Optional[np.ndarray] = None  # True OUTSIDE the glacier (Sleipnir builds it from the outline); default H0 <= 0
+
+    def __post_init__(self):
+        if self.mask is None:
+            self.mask = np.asarray(self.H0) <= 0.0
 
     @property
     def nx(self):
@@ -291,6 +354,65 @@ class GriddedInv:
     @property
     def n_params(self):
         return self.theta.size
+
+
+class InitialCondition:
+    """Per-glacier initial-thickness matrices as trainable parameters (InitialCondition.jl:33-76);
+    initialization :Farinotti2019 = glacier.H0."""
+
+    def __init__(self, params: Parameters, glaciers: Sequence["Glacier2D"], initialization: str = "Farinotti2019"):
+        if initialization != "Farinotti2019":
+            raise ValueError("Strategy for initialization of ice thicknesses not found.")
+        self.sizes = [g.nx * g.ny for g in glaciers]
+        self.theta = np.concatenate([np.asarray(g.H0, dtype=np.float64).ravel(order="F") for g in glaciers])
+
+    @property
+    def n_params(self):
+        return self.theta.size
+
+
+def sigma_zang(x, beta=2.0):
+    """σ_zang (InitialCondition_utils.jl:92-100)"""
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(x < -beta / 2, 0.0, np.where(x < beta / 2, (x + beta / 2) ** 2 / (2 * beta), x))
+
+
+def dsigma_zang(x, beta=2.0):
+    """∂σ_zang (InitialCondition_utils.jl:112-120)"""
+    x = np.asarray(x, dtype=np.float64)
+    return np.where(x < -beta / 2, 0.0, np.where(x < beta / 2, x / beta + 0.5, 1.0))
+
+
+def evaluate_H0(theta_ic, glacier: "Glacier2D", filter: str = "identity"):
+    """evaluate_H₀ (InitialCondition_utils.jl:30-46)"""
+    x = np.asarray(theta_ic, dtype=np.float64).reshape((glacier.nx, glacier.ny), order="F")
+    if filter == "identity":
+        H0 = x.copy()
+    elif filter == "softplus":
+        H0 = np.log(1.0 + np.exp(x))
+    elif filter == "Zang1980":
+        H0 = sigma_zang(x)
+    else:
+        raise ValueError(f"unknown initial_condition_filter {filter}")
+    H0 = np.asfortranarray(H0)
+    H0[glacier.mask] = 0.0
+    return H0
+
+
+def evaluate_dH0(theta_ic, glacier: "Glacier2D", filter: str = "identity"):
+    """evaluate_∂H₀ (InitialCondition_utils.jl:73-89)"""
+    x = np.asarray(theta_ic, dtype=np.float64).reshape((glacier.nx, glacier.ny), order="F")
+    if filter == "identity":
+        d = np.ones_like(x)
+    elif filter == "softplus":
+        d = 1.0 / (1.0 + np.exp(-x))
+    elif filter == "Zang1980":
+        d = dsigma_zang(x)
+    else:
+        raise ValueError(f"unknown initial_condition_filter {filter}")
+    d = np.asfortranarray(d)
+    d[glacier.mask] = 0.0
+    return d
 
 
 @dataclass
@@ -384,6 +506,12 @@ class Model:
                 raise ValueError("classical LawA needs regressors={'A': GlacierWideInv|GriddedInv}")
             self.per_glacier = reg
             self.theta = reg.theta.copy()
+        # θ = (A = ..., IC = ...): the law's parameters first, then one H0 matrix per glacier (Model.jl:155-165)
+        self.IC = self.regressors.get("IC")
+        self.n_main = 0 if self.theta is None else self.theta.size
+        if self.IC is not None:
+            main = np.zeros(0) if self.theta is None else self.theta
+            self.theta = np.concatenate([main, self.IC.theta])
 
 
 # ----------------------------------------------------------------------------------------
@@ -512,29 +640,27 @@ class _Simulation:
         law = self.model.iceflow.law
         for k, g in enumerate(gl):
             b.set_fields(k, g.H0, g.B)
-            lf = p.UDE.empirical_loss_function
+            lf, _, _ = _split_loss(p.UDE.empirical_loss_function)
             dist_ = (lf.hLoss.loss.distance if isinstance(lf, LossHV) else lf.loss.distance)
             if g.thicknessData is not None:
                 b.set_reference(k, g.thicknessData.t, g.thicknessData.H, dist_)
             if g.velocityData is not None:
                 v = g.velocityData
                 b.set_velocity_reference(k, v.t, v.vabs, v.vx, v.vy)
-        lf = p.UDE.empirical_loss_function
+        lf, _, _ = _split_loss(p.UDE.empirical_loss_function)
         if isinstance(lf, LossHV):
             b.set_loss(L.LOSS_HV, lf.vLoss.component, lf.vLoss.scale_loss, lf.scaling)
         elif isinstance(lf, LossV):
             b.set_loss(L.LOSS_V, lf.component, lf.scale_loss)
-        for k, g in enumerate(gl):
-            pass
         if law.classical is not None:
             self._batch = b
-            self._apply_classical(self.model.theta)
+            self._apply_classical(self.model.theta[:self.model.n_main])
         elif law.kind == L.LAW_CONST_A:
             if law.value is not None:
                 for k in range(len(gl)):
                     b.set_A(k, gl[k].A if gl[k].A is not None else law.value)
         else:
-            b.set_law(law.kind, law.mlp, self.model.theta, law.n_H, law.n_gradS)
+            b.set_law(law.kind, law.mlp, self.model.theta[:self.model.n_main], law.n_H, law.n_gradS)
         mb = self.model.mass_balance
         if p.simulation.use_MB and mb is not None:
             for k, g in enumerate(gl):
@@ -552,6 +678,18 @@ class _Simulation:
         sizes = self.model.per_glacier.sizes
         offs = np.concatenate([[0], np.cumsum(sizes)])
         return sizes, offs
+
+    def _ic_slots(self):
+        offs = np.concatenate([[0], np.cumsum(self.model.IC.sizes)]) + self.model.n_main
+        return offs
+
+    def _apply_IC(self, theta):
+        """H0 of every glacier of this rank from theta.IC (simulate_iceflow_UDE!, inversion_utils.jl:591-597)."""
+        offs = self._ic_slots()
+        filt = self.parameters.UDE.initial_condition_filter
+        for k, gi in enumerate(self._mine):
+            g = self.glaciers[gi]
+            self._batch.set_fields(k, evaluate_H0(theta[offs[gi]:offs[gi + 1]], g, filt), g.B)
 
     def _apply_classical(self, theta):
         law = self.model.iceflow.law
@@ -618,35 +756,78 @@ def V_from_H(simulation: _Simulation, H, t, theta=None, glacier_idx: int = 0):
 
 def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
     """SIA2D_grad!(dθ, θ, simulation): loss and gradient over ALL glaciers of ALL ranks
-    (gradient.jl:6-31).  Returns the loss; dθ is written in place."""
+    (gradient.jl:6-31).  Returns the loss; dθ is written in place.  θ = [law parameters, IC matrices]."""
     b = simulation.batch()
-    law = simulation.model.iceflow.law
-    grad = simulation.parameters.UDE.grad
+    model = simulation.model
+    law = model.iceflow.law
+    p = simulation.parameters
+    grad = p.UDE.grad
+    _, w_data, regs = _split_loss(p.UDE.empirical_loss_function)
     if isinstance(grad, ContinuousAdjoint):  # gradient.jl:276
         def loss_grad(*a, **kw):
             return b.loss_grad_continuous(*a, adj_reltol=grad.reltol, adj_abstol=grad.abstol, adj_dtmax=grad.dtmax,
-                                          n_quadrature=grad.n_quadrature,
-                                          adj_maxiters=simulation.parameters.solver.maxiters, **kw)
+                                          n_quadrature=grad.n_quadrature, adj_maxiters=p.solver.maxiters, **kw)
     elif isinstance(grad, DiscreteAdjoint):  # gradient.jl:129
         loss_grad = b.loss_grad
     else:
         raise TypeError(f"adjoint method {type(grad).__name__} is not provided")
+    theta = np.asarray(theta, dtype=np.float64)
+    th_main = theta[:model.n_main]
+    dth = np.zeros_like(theta)
+    if model.IC is not None:
+        simulation._apply_IC(theta)
     if law.classical is not None:
         # PerGlacierModel: every theta slot has a single owner (Model.jl:214-216); dL/dtheta = dL/dA * dA/dtheta
-        simulation._apply_classical(theta)
+        simulation._apply_classical(th_main)
         loss, _ = loss_grad(simulation.tstops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
         lo, hi = law.bounds
         sizes, offs = simulation._slots()
-        dth = np.zeros_like(np.asarray(theta, dtype=np.float64))
         _, Gg = b.grad_parts()
         for k, gi in enumerate(simulation._mine):
             th = np.asarray(theta[offs[gi]:offs[gi + 1]])
             dA = (hi - lo) / 2.0 * (1.0 - np.tanh(th) ** 2)
             dLdA = Gg[k] if law.classical == "scalar" else b.grad_field(k).ravel(order="F")
             dth[offs[gi]:offs[gi + 1]] = dLdA * dA
-    else:
-        loss, dth = loss_grad(simulation.tstops(), theta=theta, mb_times=simulation.mb_times(),
-                              **simulation._solver_opts())
+    elif model.n_main:
+        loss, dth[:model.n_main] = loss_grad(simulation.tstops(), theta=th_main, mb_times=simulation.mb_times(),
+                                             **simulation._solver_opts())
+    else:  # only the initial condition is trainable
+        loss, _ = loss_grad(simulation.tstops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
+    if model.IC is not None:  # dL/dθ.IC = λ(t0) ⊙ ∂H0/∂θ.IC  (gradient.jl:262-271, :507-516)
+        offs = simulation._ic_slots()
+        for k, gi in enumerate(simulation._mine):
+            g = simulation.glaciers[gi]
+            s0 = evaluate_dH0(theta[offs[gi]:offs[gi + 1]], g, p.UDE.initial_condition_filter)
+            dth[offs[gi]:offs[gi + 1]] = (b.lambda0(k) * s0).ravel(order="F")
+    loss *= w_data  # MultiLoss: sum_k λ_k loss_k, same weights on the gradients (MultiLoss.jl:75-98,148-180)
+    dth *= w_data
+    tspan = p.simulation.tspan
+    for reg, w in regs:
+        if isinstance(reg, InitialThicknessRegularization):
+            if model.IC is None:
+                raise ValueError("Regularization with respect to initial condition requires to set initial "
+                                 "condition as a trainable parameter.")  # Regularization.jl:152
+            if reg.t0 != tspan[0]:
+                continue  # evaluated only at t == t0, which discreteLossSteps adds to the stops (:153,:189)
+            offs = simulation._ic_slots()
+            for k, gi in enumerate(simulation._mine):
+                g = simulation.glaciers[gi]
+                H0 = evaluate_H0(theta[offs[gi]:offs[gi + 1]], g, p.UDE.initial_condition_filter)
+                l, gH = b.tikhonov(H0, g.dx, g.dy)  # mask = trues (:157)
+                loss += w * l
+                dth[offs[gi]:offs[gi + 1]] += w * gH.ravel(order="F")  # as written: no filter chain rule (:185)
+        elif isinstance(reg, RheologyRegularization):
+            if law.classical != "gridded":
+                raise ValueError("RheologyRegularization needs the gridded classical law LawA(params; scalar=false)")
+            lo, hi = law.bounds
+            sizes, offs = simulation._slots()
+            for k, gi in enumerate(simulation._mine):
+                g = simulation.glaciers[gi]
+                th = theta[offs[gi]:offs[gi + 1]]
+                A = (lo + (hi - lo) * (np.tanh(th) + 1.0) / 2.0).reshape((g.nx - 1, g.ny - 1), order="F")
+                l, gA = b.tikhonov(A, g.dx, g.dy)  # mask = trues(size(H) .- 1)  (:272)
+                loss += w * l
+                dth[offs[gi]:offs[gi + 1]] += w * gA.ravel(order="F") * (hi - lo) * (1.0 - np.tanh(th) ** 2) / 2.0
     loss, dth = allreduce_loss_grad(loss, dth)
     if np.linalg.norm(dth) > 1e7:  # gradient.jl:19-24
         import warnings
@@ -705,12 +886,16 @@ def _run_inversion(sim: Inversion, callback: Optional[Callable] = None):
         st.niter = len(st.losses)
     sim.model.theta = theta
     st.θ = theta.copy()
+    nm = sim.model.n_main
     if sim.model.iceflow.law.classical is not None:
-        sim.model.per_glacier.theta = theta.copy()
-        sim._apply_classical(theta)
-    else:
-        sim.model.iceflow.law.nn.theta = theta.copy()
-        sim.batch().set_theta(theta)
+        sim.model.per_glacier.theta = theta[:nm].copy()
+        sim._apply_classical(theta[:nm])
+    elif nm:
+        sim.model.iceflow.law.nn.theta = theta[:nm].copy()
+        sim.batch().set_theta(theta[:nm])
+    if sim.model.IC is not None:
+        sim.model.IC.theta = theta[nm:].copy()
+        sim._apply_IC(theta)
     return st
 
 
@@ -718,6 +903,6 @@ def run_b(simulation: _Simulation, callback: Optional[Callable] = None):
     """run!(simulation) for Prediction and Inversion (inversion_utils.jl:21-88)."""
     if isinstance(simulation, Inversion):
         if simulation.model.theta is None:
-            raise ValueError("Inversion needs a trainable law (LawA/LawY/LawU)")
+            raise ValueError("Inversion needs a trainable law (LawA/LawY/LawU) or a trainable initial condition")
         return _run_inversion(simulation, callback)
     return _run_prediction(simulation)

@@ -325,6 +325,16 @@ class GlacierBatch:
         self.last_stats_rev = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in sr]
         return float(loss.value), dth
 
+    def tikhonov(self, a, dx, dy, mask=None):
+        """(loss, grad) of TikhonovRegularization(:laplacian) on one field (Regularization.jl:92-126)."""
+        a = np.asfortranarray(a, dtype=np.float64)
+        g = np.empty(a.shape, order="F")
+        loss = C.c_double(0.0)
+        m = None if mask is None else np.asfortranarray(mask, dtype=np.uint8)
+        L.check(L.lib().odinn_tikhonov(self._h, a.shape[0], a.shape[1], float(dx), float(dy), _p(a),
+                                       m.ctypes.data_as(C.c_void_p) if m is not None else None, C.byref(loss), _p(g)))
+        return float(loss.value), g
+
     def grad_parts(self):
         """(loss_g, G_g = dL/dA_g) per glacier of the last loss_grad (PerGlacierModel plumbing)."""
         lg, Gg = np.empty(self.G), np.empty(self.G)

@@ -60,4 +60,11 @@ void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double*
 void launch_adj_poststep(int nblk, hipStream_t st, Pools P, AdjPostArgs A, double* Ua, double* Ub) {
   hipLaunchKernelGGL(k_adj_poststep, dim3(nblk), dim3(NT), 0, st, P, A, Ua, Ub);
 }
+void launch_tikhonov(hipStream_t st, const double* a, const unsigned char* mask, double* r, double* grad,
+                     double* partial, int nx, int ny, double dx, double dy) {
+  const dim3 grid((nx + 63) / 64, (ny + NW - 1) / NW);
+  const double wx = 0.25 / (dx * dx), wy = 0.25 / (dy * dy);
+  hipLaunchKernelGGL(k_tikhonov_fwd, grid, dim3(NT), 0, st, a, mask, r, partial, nx, ny, wx, wy);
+  hipLaunchKernelGGL(k_tikhonov_bwd, grid, dim3(NT), 0, st, r, grad, nx, ny, wx, wy);
+}
 }  // namespace odinn

@@ -51,6 +51,8 @@ void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan,
 void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double dtmax, double dt_given);
 void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot);
 void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, int all_at_end);
+void launch_tikhonov(hipStream_t st, const double* a, const unsigned char* mask, double* r, double* grad,
+                     double* partial, int nx, int ny, double dx, double dy);
 void launch_adj_poststep(int nblk, hipStream_t st, Pools P, AdjPostArgs A, double* Ua, double* Ub);
 
 }  // namespace odinn

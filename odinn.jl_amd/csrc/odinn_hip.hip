@@ -176,6 +176,10 @@ struct odinn_batch {
   double *d_dts = nullptr, *d_ws = nullptr, *d_lossacc = nullptr, *d_Gsum = nullptr;
   int* d_refslot = nullptr;
   int tab_cap = 0;
+  // Tikhonov regulariser scratch
+  double *d_rega = nullptr, *d_regr = nullptr, *d_regg = nullptr, *d_regp = nullptr;
+  unsigned char* d_regm = nullptr;
+  size_t reg_cap = 0, regp_cap = 0;
   // reverse (continuous-adjoint) solve tables
   double *d_rtau = nullptr, *d_rqw = nullptr, *d_tsnap = nullptr, *d_qw = nullptr;
   int *d_rsnap = nullptr, *d_rmbf = nullptr, *d_rmbs = nullptr;
@@ -784,6 +788,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0);
   dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
   dfree(b->d_rmbs); dfree(b->d_adj);
+  dfree(b->d_rega); dfree(b->d_regr); dfree(b->d_regg); dfree(b->d_regp); dfree(b->d_regm);
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
   dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
@@ -1516,6 +1521,36 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       }
   }
   return grad_finish(b, k, P, const_loss, loss, dtheta);
+}
+
+// TikhonovRegularization(operator = :laplacian): loss = sum_mask (lap a)^2, grad = VJP_lap(2 mask lap a)
+// (Regularization.jl:92-126, 330-382) for one host field of any size (H0 on the primal grid for
+// InitialThicknessRegularization, A on the dual grid for RheologyRegularization).
+int odinn_tikhonov(odinn_batch* b, int nx, int ny, double dx, double dy, const double* a, const unsigned char* mask,
+                   double* loss, double* grad) {
+  if (!b || !a || !loss || !grad) return fail(ODINN_ERR_ARG, "null argument");
+  if (nx < 3 || ny < 3 || !(dx > 0.0) || !(dy > 0.0)) return fail(ODINN_ERR_ARG, "bad grid %dx%d", nx, ny);
+  CHK(use_dev(b));
+  const size_t n = (size_t)nx * ny;
+  const int nblk = ((nx + 63) / 64) * ((ny + NW - 1) / NW);
+  if (n > b->reg_cap) {
+    dfree(b->d_rega); dfree(b->d_regr); dfree(b->d_regg); dfree(b->d_regm);
+    CHK(dalloc(&b->d_rega, n)); CHK(dalloc(&b->d_regr, n)); CHK(dalloc(&b->d_regg, n)); CHK(dalloc(&b->d_regm, n));
+    b->reg_cap = n;
+  }
+  if ((size_t)nblk > b->regp_cap) { dfree(b->d_regp); CHK(dalloc(&b->d_regp, nblk)); b->regp_cap = nblk; }
+  HIPCHK(hipMemcpyAsync(b->d_rega, a, n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  if (mask) HIPCHK(hipMemcpyAsync(b->d_regm, mask, n, hipMemcpyHostToDevice, b->stream));
+  launch_tikhonov(b->stream, b->d_rega, mask ? b->d_regm : nullptr, b->d_regr, b->d_regg, b->d_regp, nx, ny, dx, dy);
+  HIPCHK(hipGetLastError());
+  std::vector<double> part(nblk);
+  HIPCHK(hipMemcpyAsync(grad, b->d_regg, n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipMemcpyAsync(part.data(), b->d_regp, nblk * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  double s_ = 0.0;
+  for (int k = 0; k < nblk; ++k) s_ += part[k];  // fixed order
+  *loss = s_;
+  return ODINN_OK;
 }
 
 int odinn_get_grad_parts(odinn_batch* b, double* loss_per_glacier, double* G_per_glacier) {

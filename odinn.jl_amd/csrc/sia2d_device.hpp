@@ -1776,6 +1776,54 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
   }
 }
 
+
+// ---- Tikhonov regularisation (Regularization.jl:92-126, 330-382) ---------------------------
+// The reference's Laplacian  avg_y(diff_x(avg_y(diff_x a))) + avg_x(diff_y(avg_x(diff_y a)))  on the
+// interior is the 3x3 stencil  [1 2 1]^T/4 (x) d_xx/dx^2 + d_yy/dy^2 (x) [1 2 1]/4 ; its VJP
+// (diff/avg adjoints of inversion_utils.jl:3-66 composed) is the same symmetric stencil applied to
+// the cotangent zeroed outside the interior, evaluated on every cell.
+__device__ __forceinline__ double lap9(const double* __restrict__ a, int nx, int i, int j, double wx, double wy,
+                                       bool interior_only_src, int ny) {
+  auto at = [&](int ii, int jj) -> double {
+    if (ii < 0 || ii >= nx || jj < 0 || jj >= ny) return 0.0;
+    if (interior_only_src && (ii < 1 || ii > nx - 2 || jj < 1 || jj > ny - 2)) return 0.0;
+    return a[ii + (long long)nx * jj];
+  };
+  double sx = 0.0, sy = 0.0;
+#pragma unroll
+  for (int q = -1; q <= 1; ++q) {
+    const double w = q == 0 ? 2.0 : 1.0;
+    sx = fma(w, (at(i + 1, j + q) - 2.0 * at(i, j + q)) + at(i - 1, j + q), sx);
+    sy = fma(w, (at(i + q, j + 1) - 2.0 * at(i + q, j)) + at(i + q, j - 1), sy);
+  }
+  return fma(wx, sx, wy * sy);
+}
+// pass 1: r = 2 * mask * lap(a) on the interior (0 elsewhere), partial[block] = sum mask * lap(a)^2
+__global__ __launch_bounds__(NT) void k_tikhonov_fwd(const double* __restrict__ a, const unsigned char* __restrict__ mask,
+                                                     double* __restrict__ r, double* __restrict__ partial, int nx,
+                                                     int ny, double wx, double wy) {
+  __shared__ double red[NW];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * NW + (threadIdx.x >> 6);
+  double sq = 0.0;
+  if (i < nx && j < ny) {
+    double v = 0.0;
+    if (i >= 1 && i <= nx - 2 && j >= 1 && j <= ny - 2 && (!mask || mask[i + (long long)nx * j])) {
+      const double l = lap9(a, nx, i, j, wx, wy, false, ny);
+      v = 2.0 * l;
+      sq = l * l;
+    }
+    r[i + (long long)nx * j] = v;
+  }
+  const double tot = block_sum(sq, red);
+  if (threadIdx.x == 0) partial[blockIdx.x + (long long)gridDim.x * blockIdx.y] = tot;
+}
+// pass 2: grad = L^T r
+__global__ __launch_bounds__(NT) void k_tikhonov_bwd(const double* __restrict__ r, double* __restrict__ grad, int nx,
+                                                     int ny, double wx, double wy) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * NW + (threadIdx.x >> 6);
+  if (i < nx && j < ny) grad[i + (long long)nx * j] = lap9(r, nx, i, j, wx, wy, true, ny);
+}
+
 #endif  // ODINN_MISC_KERNELS
 
 }  // namespace odinn

@@ -1016,6 +1016,82 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
 
 
 # ----------------------------------------------------------------------------
+# Tikhonov regularisation (src/losses/Regularization.jl:92-126, 330-382) and the
+# initial-condition filters (src/models/trainable_components/InitialCondition_utils.jl:30-141)
+# ----------------------------------------------------------------------------
+
+
+def laplacian(a, dx, dy):
+    """nabla^2 (Regularization.jl:330-352): staggered second differences averaged back to the primal
+    interior; 0 on the boundary ring."""
+    d2x = avg_y(diff_x(avg_y(diff_x(a) / dx)) / dx)
+    d2y = avg_x(diff_y(avg_x(diff_y(a) / dy)) / dy)
+    out = np.zeros_like(a)
+    out[1:-1, 1:-1] = d2x + d2y
+    return out
+
+
+def vjp_laplacian(lam, dx, dy):
+    """VJP_lambda_dnabla2a_da (Regularization.jl:372-382)."""
+    li = lam[1:-1, 1:-1]
+    gx = diff_x_adjoint(avg_y_adjoint(diff_x_adjoint(avg_y_adjoint(li), dx)), dx)
+    gy = diff_y_adjoint(avg_x_adjoint(diff_y_adjoint(avg_x_adjoint(li), dy)), dy)
+    return gx + gy
+
+
+def tikhonov_loss(a, dx, dy, mask):
+    """loss(::TikhonovRegularization) (Regularization.jl:92-101): sum over mask of (nabla^2 a)^2."""
+    return float(np.sum(laplacian(a, dx, dy)[mask] ** 2))
+
+
+def tikhonov_backward(a, dx, dy, mask):
+    """backward_loss(::TikhonovRegularization) (Regularization.jl:102-115)."""
+    g = np.zeros_like(a)
+    g[mask] = 2.0 * laplacian(a, dx, dy)[mask]
+    return vjp_laplacian(g, dx, dy)
+
+
+def sigma_zang(x, beta=2.0):
+    """InitialCondition_utils.jl:92-100."""
+    return np.where(x < -beta / 2, 0.0, np.where(x < beta / 2, (x + beta / 2) ** 2 / (2 * beta), x))
+
+
+def dsigma_zang(x, beta=2.0):
+    """InitialCondition_utils.jl:112-120."""
+    return np.where(x < -beta / 2, 0.0, np.where(x < beta / 2, x / beta + 0.5, 1.0))
+
+
+def evaluate_H0(theta_ic, outside_mask, filt="identity"):
+    """evaluate_H0 (InitialCondition_utils.jl:30-46): filter, then zero outside the glacier."""
+    if filt == "identity":
+        H0 = np.array(theta_ic, F, copy=True)
+    elif filt == "softplus":
+        H0 = np.log(1.0 + np.exp(theta_ic))
+    elif filt == "Zang1980":
+        H0 = sigma_zang(np.asarray(theta_ic, F))
+    else:
+        raise ValueError(filt)
+    H0 = np.array(H0, F)
+    H0[outside_mask] = 0.0
+    return H0
+
+
+def evaluate_dH0(theta_ic, outside_mask, filt="identity"):
+    """evaluate_dH0 (InitialCondition_utils.jl:73-89)."""
+    if filt == "identity":
+        d = np.ones_like(np.asarray(theta_ic, F))
+    elif filt == "softplus":
+        d = 1.0 / (1.0 + np.exp(-np.asarray(theta_ic, F)))
+    elif filt == "Zang1980":
+        d = dsigma_zang(np.asarray(theta_ic, F))
+    else:
+        raise ValueError(filt)
+    d = np.array(d, F)
+    d[outside_mask] = 0.0
+    return d
+
+
+# ----------------------------------------------------------------------------
 # Known answer: Halfar (1983) similarity solution, n=3, flat bed, no MB
 # (SURVEY App. A.7; reference set-up test/test_grad_loss.jl:526-539)
 # ----------------------------------------------------------------------------

@@ -71,3 +71,33 @@ def test_adam_update_rule_matches_optimisers(odinn):
     v = (1 - a.beta[1]) * g * g
     step = a.eta * (m / (1 - a.beta[0])) / (np.sqrt(v / (1 - a.beta[1])) + a.eps)
     assert np.allclose(step, 0.1 * np.sign(g), rtol=1e-6)
+
+
+def test_initial_condition_and_multiloss_host_logic(odinn):
+    """θ layout (law parameters, then one H0 matrix per glacier), filters equal to the oracle's
+    restatement, MultiLoss bookkeeping (MultiLoss.jl:22-35)."""
+    H0, B = O.synthetic_valley(20, 16, 50.0)
+    H1, B1 = O.synthetic_valley(24, 12, 50.0)
+    gl = [odinn.Glacier2D("a", H0, B, 50.0, 50.0), odinn.Glacier2D("b", H1, B1, 50.0, 50.0)]
+    p = odinn.Parameters()
+    ic = odinn.InitialCondition(p, gl)
+    assert ic.sizes == [320, 288] and ic.n_params == 608
+    nn = odinn.NeuralNetwork(p)
+    m = odinn.Model(odinn.SIA2Dmodel(p, A=odinn.LawA(nn, p)), regressors={"A": nn, "IC": ic})
+    assert m.n_main == nn.n_params and m.theta.size == nn.n_params + 608
+    assert np.array_equal(m.theta[m.n_main:m.n_main + 320], H0.ravel(order="F"))
+    x = np.random.default_rng(0).uniform(-3, 3, 320)
+    for f in ("identity", "softplus", "Zang1980"):
+        assert np.array_equal(odinn.evaluate_H0(x, gl[0], f), O.evaluate_H0(x.reshape((20, 16), order="F"), gl[0].mask, f))
+        assert np.array_equal(odinn.evaluate_dH0(x, gl[0], f), O.evaluate_dH0(x.reshape((20, 16), order="F"), gl[0].mask, f))
+    with pytest.raises(ValueError):
+        odinn.MultiLoss(losses=(odinn.LossH(),), lambdas=(1.0, 2.0))
+    from odinn_jl_amd.api import _split_loss
+
+    d, w, regs = _split_loss(odinn.MultiLoss(losses=(odinn.LossH(), odinn.InitialThicknessRegularization(t0=2010.0)),
+                                             lambdas=(2.0, 1e-3)))
+    assert isinstance(d, odinn.LossH) and w == 2.0 and len(regs) == 1 and regs[0][1] == 1e-3
+    with pytest.raises(ValueError):
+        odinn.TikhonovRegularization(operator="gradient")
+    with pytest.raises(ValueError):
+        odinn.ContinuousAdjoint(interpolation="Cubic")

@@ -77,3 +77,43 @@ def test_is_in_glacier_erosion():
     m = O.is_in_glacier(H, 2)
     assert m.sum() == 9 and m[4, 4] and m[3, 3] and not m[2, 2]
     assert np.array_equal(O.is_in_glacier(H, 0), H > 0)
+
+
+def test_laplacian_transpose_and_tikhonov_gradient():
+    """test_grad_TikhonovRegularization (test/test_grad_loss.jl:449-487): 9x10 field, dx=1.2, dy=1.8,
+    random mask; backward_loss == exact gradient (the loss is quadratic, so central differences are
+    exact up to rounding) and <lap a, lam> == <a, VJP lam>."""
+    rng = np.random.default_rng(3)
+    nx, ny, dx, dy = 9, 10, 1.2, 1.8
+    a = rng.standard_normal((nx, ny))
+    a[:2, :] = 0; a[-2:, :] = 0; a[:, :2] = 0; a[:, -2:] = 0
+    lam = rng.standard_normal((nx, ny))
+    assert abs(np.sum(O.laplacian(a, dx, dy) * lam) - np.sum(a * O.vjp_laplacian(lam, dx, dy))) < 1e-12
+    mask = rng.standard_normal((nx, ny)) >= 0
+    g = O.tikhonov_backward(a, dx, dy, mask)
+    gn = np.zeros_like(a)
+    for i in range(nx):
+        for j in range(ny):
+            e = np.zeros_like(a)
+            e[i, j] = 1e-3
+            gn[i, j] = (O.tikhonov_loss(a + e, dx, dy, mask) - O.tikhonov_loss(a - e, dx, dy, mask)) / 2e-3
+    assert np.abs(g - gn).max() <= 1e-11 * np.abs(g).max()
+    # boundary ring of the Laplacian is zero
+    L = O.laplacian(a, dx, dy)
+    assert not L[0, :].any() and not L[-1, :].any() and not L[:, 0].any() and not L[:, -1].any()
+
+
+def test_initial_condition_filters():
+    """evaluate_H0 / evaluate_dH0 (InitialCondition_utils.jl:30-141): derivative == d(filter)/dx, mask zeroed."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-3, 3, (7, 6))
+    outside = rng.uniform(size=x.shape) < 0.3
+    for f in ("identity", "softplus", "Zang1980"):
+        H = O.evaluate_H0(x, outside, f)
+        d = O.evaluate_dH0(x, outside, f)
+        e = 1e-6
+        fd = (O.evaluate_H0(x + e, outside, f) - O.evaluate_H0(x - e, outside, f)) / (2 * e)
+        assert np.abs(fd - d).max() < 1e-6
+        assert not H[outside].any() and not d[outside].any()
+    assert O.sigma_zang(np.array([-1.0]))[0] == 0.0 and O.sigma_zang(np.array([1.0]))[0] == 1.0  # C1 joins
+    assert abs(O.sigma_zang(np.array([0.0]))[0] - 0.25) < 1e-15
