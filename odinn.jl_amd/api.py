@@ -36,7 +36,8 @@ __all__ = [
     "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
     "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DiscreteVJP", "MultiLoss", "TikhonovRegularization",
     "InitialThicknessRegularization", "RheologyRegularization", "InitialCondition", "evaluate_H0", "evaluate_dH0",
-    "sigma_zang", "dsigma_zang",
+    "sigma_zang", "dsigma_zang", "TrainingResult", "save_inversion_file", "load_inversion_file", "ScalarLogger",
+    "callback_diagnosis",
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad",
@@ -574,12 +575,119 @@ def allreduce_loss_grad(loss: float, dtheta: np.ndarray):
 # ----------------------------------------------------------------------------------------
 @dataclass
 class TrainingStats:
+    """src/simulations/results/Results.jl:19-28"""
+
+    retcode: Optional[str] = None
     losses: List[float] = field(default_factory=list)
     niter: int = 0
+    θ: Optional[np.ndarray] = None
     θ_hist: List[np.ndarray] = field(default_factory=list)
+    grad_hist: List[np.ndarray] = field(default_factory=list)  # ∇θ_hist
+    initial_conditions: Optional[dict] = None
     grad_norms: List[float] = field(default_factory=list)
     time_per_iter: List[float] = field(default_factory=list)
-    θ: Optional[np.ndarray] = None
+
+
+@dataclass
+class TrainingResult:
+    """src/results/TrainingResults.jl:6-12: what save_inversion_file! writes."""
+
+    θ: np.ndarray
+    θ_hist: List[np.ndarray]
+    grad_hist: List[np.ndarray]  # ∇θ_hist
+    losses: List[float]
+    params: dict
+
+
+def _params_dict(p):
+    import dataclasses
+
+    def conv(o):
+        if dataclasses.is_dataclass(o) and not isinstance(o, type):
+            return {"__type__": type(o).__name__, **{f.name: conv(getattr(o, f.name)) for f in dataclasses.fields(o)}}
+        if isinstance(o, (list, tuple)):
+            return [conv(x) for x in o]
+        if isinstance(o, np.ndarray):
+            return o.tolist()
+        if isinstance(o, (int, float, str, bool)) or o is None:
+            return o
+        return repr(o)
+
+    return conv(p)
+
+
+def save_inversion_file(theta, simulation, path: Optional[str] = None, file_name: Optional[str] = None):
+    """save_inversion_file!(sol, simulation; path, file_name) (src/results/trainingresult_utils.jl:4-33).
+    Same record (θ, θ_hist, ∇θ_hist, losses, params); the container is NumPy .npz with the parameters as
+    JSON because JLD2 cannot be written without Julia.  Returns the file path."""
+    import json
+    import os
+
+    path = path or os.path.join(os.getcwd(), "data", "results", "inversions")
+    os.makedirs(path, exist_ok=True)
+    file_name = file_name or "_inversion_result.npz"
+    st = simulation.stats
+    out = os.path.join(path, file_name)
+    np.savez(out, theta=np.asarray(theta, dtype=np.float64),
+             theta_hist=np.asarray(st.θ_hist, dtype=np.float64).reshape(len(st.θ_hist), -1),
+             grad_hist=np.asarray(st.grad_hist, dtype=np.float64).reshape(len(st.grad_hist), -1),
+             losses=np.asarray(st.losses, dtype=np.float64),
+             params=np.array(json.dumps(_params_dict(simulation.parameters))))
+    return out if out.endswith(".npz") else out + ".npz"
+
+
+def load_inversion_file(file: str) -> TrainingResult:
+    """Read a record written by save_inversion_file (checkpoint / resume: pass result.θ as the
+    regressor's theta)."""
+    import json
+
+    z = np.load(file, allow_pickle=False)
+    return TrainingResult(z["theta"], list(z["theta_hist"]), list(z["grad_hist"]), list(z["losses"]),
+                          json.loads(str(z["params"])))
+
+
+class ScalarLogger:
+    """Stand-in for the TensorBoardLogger of callback_diagnosis (callback_utils.jl:84-98): the same
+    tags (train/loss, train/norm_grad, train/time_per_iter) and steps, one JSON object per line."""
+
+    def __init__(self, file: str):
+        import os
+
+        os.makedirs(os.path.dirname(os.path.abspath(file)), exist_ok=True)
+        self.file = file
+        self._f = open(file, "a")
+
+    def log_value(self, tag: str, value: float, step: int):
+        import json
+
+        self._f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+        self._f.flush()
+
+    def close(self):
+        self._f.close()
+
+
+def callback_diagnosis(theta, loss, grad, simulation, save: bool = False, tbLogger: Optional[ScalarLogger] = None,
+                       path: Optional[str] = None):
+    """callback_diagnosis(θ, l, simulation; save, tbLogger) (callback_utils.jl:60-110)."""
+    st = simulation.stats
+    now = time.perf_counter()
+    st.losses.append(float(loss))
+    st.θ_hist.append(np.array(theta, dtype=np.float64, copy=True))
+    st.grad_hist.append(np.array(grad, dtype=np.float64, copy=True))
+    st.grad_norms.append(float(np.linalg.norm(grad)))
+    it = len(st.losses)
+    last = getattr(st, "_lastCall", None)
+    if last is not None:
+        st.time_per_iter.append(now - last)
+    if tbLogger is not None:
+        tbLogger.log_value("train/loss", loss, it)
+        tbLogger.log_value("train/norm_grad", np.linalg.norm(grad), it)
+        if last is not None:
+            tbLogger.log_value("train/time_per_iter", now - last, it)
+    st._lastCall = now
+    if save:
+        save_inversion_file(theta, simulation, path=path, file_name="_inversion_result.npz")
 
 
 @dataclass
@@ -847,8 +955,10 @@ def _run_prediction(sim: Prediction):
     return sim.results
 
 
-def _run_inversion(sim: Inversion, callback: Optional[Callable] = None):
-    """train_UDE! (inversion_utils.jl:112-238): Adam or LBFGS over loss/grad callbacks."""
+def _run_inversion(sim: Inversion, callback: Optional[Callable] = None, save: bool = False,
+                   tbLogger: Optional[ScalarLogger] = None, path: Optional[str] = None):
+    """train_UDE! (inversion_utils.jl:112-238): Adam or LBFGS over loss/grad callbacks, with
+    callback_diagnosis bookkeeping (losses, θ_hist, ∇θ_hist, scalar log, intermediate saves)."""
     hyper = sim.parameters.hyper
     theta = sim.model.theta.copy()
     dth = np.zeros_like(theta)
@@ -859,31 +969,28 @@ def _run_inversion(sim: Inversion, callback: Optional[Callable] = None):
         v = np.zeros_like(theta)
         b1, b2 = opt.beta
         for it in range(1, hyper.epochs + 1):
-            t0 = time.perf_counter()
             loss = SIA2D_grad_b(dth, theta, sim)
+            callback_diagnosis(theta, loss, dth, sim, save=save, tbLogger=tbLogger, path=path)
             m = b1 * m + (1 - b1) * dth
             v = b2 * v + (1 - b2) * dth * dth
             theta = theta - opt.eta * (m / (1 - b1 ** it)) / (np.sqrt(v / (1 - b2 ** it)) + opt.eps)
-            st.losses.append(loss)
-            st.grad_norms.append(float(np.linalg.norm(dth)))
-            st.time_per_iter.append(time.perf_counter() - t0)
-            st.θ_hist.append(theta.copy())
             st.niter = it
             if callback is not None:
                 callback(it, loss, theta)
+        st.retcode = "Default"
     else:
         from scipy.optimize import minimize
 
         def fg(x):
             loss = SIA2D_grad_b(dth, x, sim)
-            st.losses.append(loss)
-            st.grad_norms.append(float(np.linalg.norm(dth)))
+            callback_diagnosis(x, loss, dth, sim, save=save, tbLogger=tbLogger, path=path)
             return loss, dth.copy()
 
         res = minimize(fg, theta, jac=True, method="L-BFGS-B",
                        options=dict(maxiter=hyper.epochs, maxcor=opt.m, ftol=0.0, gtol=0.0))
         theta = res.x
         st.niter = len(st.losses)
+        st.retcode = "Success" if res.success else str(res.message)
     sim.model.theta = theta
     st.θ = theta.copy()
     nm = sim.model.n_main
@@ -899,10 +1006,14 @@ def _run_inversion(sim: Inversion, callback: Optional[Callable] = None):
     return st
 
 
-def run_b(simulation: _Simulation, callback: Optional[Callable] = None):
-    """run!(simulation) for Prediction and Inversion (inversion_utils.jl:21-88)."""
+def run_b(simulation: _Simulation, callback: Optional[Callable] = None, save: bool = False,
+          tbLogger: Optional[ScalarLogger] = None, path: Optional[str] = None):
+    """run!(simulation; save, tbLogger) for Prediction and Inversion (inversion_utils.jl:21-88)."""
     if isinstance(simulation, Inversion):
         if simulation.model.theta is None:
             raise ValueError("Inversion needs a trainable law (LawA/LawY/LawU) or a trainable initial condition")
-        return _run_inversion(simulation, callback)
+        st = _run_inversion(simulation, callback, save=save, tbLogger=tbLogger, path=path)
+        if save:
+            save_inversion_file(st.θ, simulation, path=path, file_name="_inversion_result.npz")
+        return st
     return _run_prediction(simulation)

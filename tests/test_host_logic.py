@@ -101,3 +101,26 @@ def test_initial_condition_and_multiloss_host_logic(odinn):
         odinn.TikhonovRegularization(operator="gradient")
     with pytest.raises(ValueError):
         odinn.ContinuousAdjoint(interpolation="Cubic")
+
+
+def test_training_result_file_and_scalar_log(odinn, tmp_path):
+    """callback_diagnosis + save_inversion_file! record (callback_utils.jl:60-110,
+    trainingresult_utils.jl:4-33): θ, θ_hist, ∇θ_hist, losses, params; scalar tags of the logger."""
+    import json
+    import types
+
+    p = odinn.Parameters()
+    sim = types.SimpleNamespace(stats=odinn.TrainingStats(), parameters=p)
+    log = odinn.ScalarLogger(str(tmp_path / "run" / "scalars.jsonl"))
+    th = np.arange(5.0)
+    for it in range(3):
+        odinn.callback_diagnosis(th + it, 10.0 / (it + 1), np.full(5, 0.5 * it), sim, save=(it == 2), tbLogger=log,
+                                 path=str(tmp_path))
+    log.close()
+    res = odinn.load_inversion_file(str(tmp_path / "_inversion_result.npz"))
+    assert np.array_equal(res.θ, th + 2) and len(res.θ_hist) == 3 and len(res.grad_hist) == 3
+    assert res.losses == [10.0, 5.0, 10.0 / 3] and np.array_equal(res.grad_hist[2], np.full(5, 1.0))
+    assert res.params["solver"]["reltol"] == p.solver.reltol and res.params["UDE"]["grad"]["__type__"] == "DiscreteAdjoint"
+    rows = [json.loads(l) for l in open(tmp_path / "run" / "scalars.jsonl")]
+    assert [r["tag"] for r in rows[:2]] == ["train/loss", "train/norm_grad"] and rows[0]["step"] == 1
+    assert sum(r["tag"] == "train/time_per_iter" for r in rows) == 2  # not on the first call (callback_utils.jl:93)
