@@ -1656,6 +1656,29 @@ int odinn_time_kernel(odinn_batch* b, int which, int warmup, int iters, double* 
   if (!b || !ms_total || iters <= 0) return fail(ODINN_ERR_ARG, "bad arguments");
   CHK(timed_prepare(b));
   for (int i = 0; i < warmup; ++i) CHK(timed_one(b, which, i));
+  const char* eg = std::getenv("ODINN_TIME_GRAPH");
+  if (eg && eg[0] == '1') {
+    // measurement aid (tools/graph_probe.py): the same `iters` launches captured once into a hipGraph
+    // and replayed.  Finding on MI355X / ROCm 7.2: no gain (24.0 -> 23.6 us per 3-kernel step at G = 4);
+    // dependent kernels cost ~5 us each either way, so the solve loop stays on plain stream launches.
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIPCHK(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < iters; ++i) CHK(timed_one(b, which, warmup + i));
+    HIPCHK(hipStreamEndCapture(b->stream, &graph));
+    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphLaunch(exec, b->stream));  // warm
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    HIPCHK(hipGraphLaunch(exec, b->stream));
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    HIPCHK(hipEventSynchronize(b->ev1));
+    HIPCHK(hipGraphExecDestroy(exec));
+    HIPCHK(hipGraphDestroy(graph));
+    float msg = 0.f;
+    HIPCHK(hipEventElapsedTime(&msg, b->ev0, b->ev1));
+    *ms_total = msg;
+    return ODINN_OK;
+  }
   HIPCHK(hipEventRecord(b->ev0, b->stream));
   for (int i = 0; i < iters; ++i) CHK(timed_one(b, which, warmup + i));
   HIPCHK(hipEventRecord(b->ev1, b->stream));
