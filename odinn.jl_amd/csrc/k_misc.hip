@@ -9,6 +9,10 @@ void launch_poststep(int nblk, hipStream_t st, Pools P, PostArgs A, double* Ua, 
 void launch_sum_part(int ng, hipStream_t st, Pools P, int slot, double* out, int accumulate, int g0) {
   hipLaunchKernelGGL(k_sum_part, dim3(ng), dim3(64), 0, st, P, slot, out, accumulate, g0);
 }
+void launch_sum_part_steps(int ng, hipStream_t st, Pools P, const double* base, long long stride, int jhi, int jlo,
+                           int slot, double* out) {
+  hipLaunchKernelGGL(k_sum_part_steps, dim3(ng), dim3(64), 0, st, P, base, stride, jhi, jlo, slot, out);
+}
 void launch_sum_part_theta(int Pn, int ng, hipStream_t st, Pools P, const double* part_theta, double* out,
                            int accumulate, int g0) {
   hipLaunchKernelGGL(k_sum_part_theta, dim3(Pn, ng), dim3(64), 0, st, P, part_theta, Pn, out, accumulate, g0);

@@ -31,6 +31,8 @@ void launch_surfV_vjp(int lm, int mode, int nblk, hipStream_t st, Pools P, const
 void launch_controller(int G, hipStream_t st, Pools P, CtrlArgs C);
 void launch_poststep(int nblk, hipStream_t st, Pools P, PostArgs A, double* Ua, double* Ub);
 void launch_sum_part(int ng, hipStream_t st, Pools P, int slot, double* out, int accumulate, int g0);
+void launch_sum_part_steps(int ng, hipStream_t st, Pools P, const double* base, long long stride, int jhi, int jlo,
+                           int slot, double* out);
 void launch_sum_part_theta(int Pn, int ng, hipStream_t st, Pools P, const double* part_theta, double* out,
                            int accumulate, int g0);
 void launch_loss(int nblk, hipStream_t st, Pools P, const double* H, const double* Href, const unsigned char* mask,

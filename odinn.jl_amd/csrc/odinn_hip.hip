@@ -176,6 +176,8 @@ struct odinn_batch {
   double *d_dts = nullptr, *d_ws = nullptr, *d_lossacc = nullptr, *d_Gsum = nullptr;
   int* d_refslot = nullptr;
   int tab_cap = 0;
+  double* d_partsteps = nullptr;  // [k][4*ntiles] per-step partials of the discrete reverse loop
+  size_t partsteps_cap = 0;
   // Tikhonov regulariser scratch
   double *d_rega = nullptr, *d_regr = nullptr, *d_regg = nullptr, *d_regp = nullptr;
   unsigned char* d_regm = nullptr;
@@ -596,11 +598,14 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   PostArgs A{};
   A.snaps = b->d_snaps; A.premb = b->d_premb; A.ntot = b->ntot; A.mb0 = b->d_mb0;
   A.Sref = b->any_sref ? b->d_Sref : nullptr;
-  const int CHUNK = 16;  // steps between host polls of the active-glacier counter
+  // steps between host polls of the active-glacier counter: at least one step per stop is needed, so
+  // the first batch is n_stops-1 steps (short solves that land on a stop every step finish with one
+  // poll and no wasted launches); afterwards 16, with parity kept even for the ping-pong buffers
   long long steps = 0;
   int p = 0;
+  int chunk = std::max(2, std::min(256, (n_stops - 1 + 1) & ~1));
   while (nact > 0) {
-    for (int s = 0; s < CHUNK; ++s) {
+    for (int s = 0; s < chunk; ++s) {
       if (scheme == 2) {
         CHK(launch_fused_step(b, opt.abstol, opt.reltol, opt.dense ? 0 : 1));
         C.next_cur = -1;
@@ -617,6 +622,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
     HIPCHK(hipMemcpyAsync(&nact, b->d_nactive, sizeof(int), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (steps >= opt.maxiters && nact > 0) return fail(ODINN_ERR_MAXITERS, "maxiters (%lld) reached with %d glaciers active", (long long)opt.maxiters, nact);
+    chunk = 16;
   }
   std::vector<GState> gs(b->G);
   HIPCHK(hipMemcpy(gs.data(), b->d_gs, sizeof(GState) * b->G, hipMemcpyDeviceToHost));
@@ -788,6 +794,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0);
   dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
   dfree(b->d_rmbs); dfree(b->d_adj);
+  dfree(b->d_partsteps);
   dfree(b->d_rega); dfree(b->d_regr); dfree(b->d_regg); dfree(b->d_regp); dfree(b->d_regm);
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
@@ -975,7 +982,8 @@ int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H,
 }
 
 static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
-                            bool accumulate) {
+                            bool accumulate, double* part_deferred = nullptr) {
+  // part_deferred (A-type laws only): the per-tile partials go there and are NOT summed here
   // g < 0: all glaciers (swizzled table); result of A-type laws lands in d_Gsum / d_Gacc,
   // of Y/U laws in d_dth[g][P]
   const bool nn_node = b->law_kind >= ODINN_LAW_NN_Y;
@@ -986,10 +994,12 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
   A.part_theta = nn_node ? b->d_part_theta : nullptr;
   A.gscratch = nn_node ? b->d_gscratch : nullptr;
-  const Pools P = b->pools(g < 0);
+  Pools P = b->pools(g < 0);
+  if (part_deferred) P.part = part_deferred;
   launch_vjp_theta(b, nblk, P, b->lawdev(), A, base);
   const int ng = g < 0 ? b->G : 1, g0 = g < 0 ? 0 : g;
-  if (nn_node)
+  if (part_deferred) {
+  } else if (nn_node)
     launch_sum_part_theta(b->P, ng, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g0);
   else
     launch_sum_part(ng, b->stream, P, 2, b->d_Gsum, accumulate ? 1 : 0, g0);
@@ -1270,6 +1280,15 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
   const LawDev L = b->lawdev();
   int cur = 0;
   double const_loss = 0.0;
+  // LossH with an A-type law: the loss and dL/dA partials of all steps are reduced by ONE kernel after
+  // the loop (same summation order) instead of two dependent ~5 us launches per reverse step
+  const bool defer = b->loss_kind == ODINN_LOSS_H && b->law_kind < ODINN_LAW_NN_Y;
+  const long long pstride = 4LL * b->ntiles;
+  if (defer && (size_t)k * pstride > b->partsteps_cap) {
+    dfree(b->d_partsteps);
+    CHK(dalloc(&b->d_partsteps, (size_t)k * pstride));
+    b->partsteps_cap = (size_t)k * pstride;
+  }
   for (int j = k - 1; j >= 1; --j) {
     double* lam = b->d_lam[cur];
     double* lam_new = b->d_lam[1 - cur];
@@ -1282,15 +1301,21 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
     A.H = Hj; A.lam = lam; A.out = lam_new; A.Href = b->d_Href; A.mask = b->d_mask;
     A.dts = b->d_dts + (size_t)j * b->G; A.ws = b->d_ws + (size_t)j * b->G;
     A.refslot = b->d_refslot + (size_t)j * b->G; A.ntot = b->ntot;
-    launch_vjp_H(b, 1, b->ntiles, Psw, L, A, 0);  // :235-242
-    launch_sum_part(b->G, b->stream, Psw, 1, b->d_lossacc, 1, 0);
+    Pools Pj = Psw;
+    if (defer) Pj.part = b->d_partsteps + (size_t)j * pstride;
+    launch_vjp_H(b, 1, b->ntiles, Pj, L, A, 0);  // :235-242
+    if (!defer) launch_sum_part(b->G, b->stream, Psw, 1, b->d_lossacc, 1, 0);
     if (b->loss_kind != ODINN_LOSS_H) {  // backward_loss(::LossV): dl/dH into lambda_{j-1}, dl/dtheta into dtheta
       double c = 0.0;
       CHK(launch_lossV(b, j, Hj, lam_new, true, &c));
       const_loss += c;
     }
-    CHK(theta_vjp_launch(b, Hj, lam_new, b->d_dts + (size_t)j * b->G, -1, true));  // :245-249
+    CHK(theta_vjp_launch(b, Hj, lam_new, b->d_dts + (size_t)j * b->G, -1, true, defer ? Pj.part : nullptr));  // :245-249
     cur = 1 - cur;
+  }
+  if (defer && k > 1) {
+    launch_sum_part_steps(b->G, b->stream, Psw, b->d_partsteps, pstride, k - 1, 1, 1, b->d_lossacc);
+    launch_sum_part_steps(b->G, b->stream, Psw, b->d_partsteps, pstride, k - 1, 1, 2, b->d_Gsum);
   }
   HIPCHK(hipGetLastError());
   if (cur != 0) HIPCHK(hipMemcpyAsync(b->d_lam[0], b->d_lam[cur], fb, hipMemcpyDeviceToDevice, b->stream));

@@ -1435,6 +1435,23 @@ __global__ __launch_bounds__(64) void k_sum_part(Pools P, int slot, double* out,
   s = wave_sum(s);
   if (threadIdx.x == 0) { if (accumulate) out[gidx] += s; else out[gidx] = s; }
 }
+// the same for a whole reverse loop at once: partials of step j live at base + j*stride; steps are
+// added in the order jhi, jhi-1, ..., jlo -- exactly the sequence of per-step k_sum_part(accumulate)
+// launches it replaces (2 dependent launches fewer per reverse step)
+__global__ __launch_bounds__(64) void k_sum_part_steps(Pools P, const double* base, long long stride, int jhi, int jlo,
+                                                       int slot, double* out) {
+  const int gidx = blockIdx.x;
+  const GDev g = P.gd[gidx];
+  double acc = out[gidx];
+  for (int j = jhi; j >= jlo; --j) {
+    const double* p = base + (long long)j * stride;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < g.ntiles; k += 64) s += p[4 * (long long)(g.tile0 + k) + slot];
+    s = wave_sum(s);
+    acc += s;
+  }
+  if (threadIdx.x == 0) out[gidx] = acc;
+}
 // out[g*Pn + k] (+)= scale_g * sum_tiles part_theta[tile][k]
 __global__ __launch_bounds__(64) void k_sum_part_theta(Pools P, const double* part_theta, int Pn, double* out,
                                                        int accumulate, int g0) {
