@@ -119,6 +119,14 @@ typedef struct odinn_solve_stats {
   double t_final, dt_last;
 } odinn_solve_stats;
 
+/* H-VJP stencil used by odinn_sia2d_vjp_H and inside both adjoints (VJPTypes.jl:29-50):
+ * DiscreteVJP = exact transpose of the discretised RHS (adjoint.jl:31-151);
+ * ContinuousVJP = discretisation of the continuous adjoint operator (adjoint.jl:442-553; target :A only).
+ * VJP_lambda_dSIA/dtheta_continuous (adjoint.jl:583-662) is the forward form of the same bilinear
+ * expression as the discrete theta-VJP, so odinn_sia2d_vjp_theta serves both methods. */
+#define ODINN_VJP_DISCRETE 0
+#define ODINN_VJP_CONTINUOUS 1
+
 /* options of the reverse solve of the continuous adjoint; defaults = ContinuousAdjoint()
  * (src/inverse/AdjointTypes.jl:58-67): RDPK3Sp35, reltol = abstol = 1e-8, dtmax = 1/12,
  * linear interpolation of H in time, n_quadrature = 200.  Fields <= 0 take the default. */
@@ -215,6 +223,8 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
                                const odinn_adjoint_opts* adjoint_opts, double* loss, double* dtheta,
                                odinn_solve_stats* stats, odinn_solve_stats* stats_rev);
 int odinn_get_lambda0(odinn_batch* b, int g, double* lam0);
+/* selects ODINN_VJP_DISCRETE (default) or ODINN_VJP_CONTINUOUS for this batch */
+int odinn_set_vjp_method(odinn_batch* b, int method);
 /* TikhonovRegularization(operator = :laplacian) of src/losses/Regularization.jl:92-126 on one field
  * a[nx*ny] (column-major): *loss = sum_mask (lap a)^2 with lap = the reference's staggered Laplacian
  * (:330-352), grad = VJP_lap(2 mask lap a) (:372-382).  mask: nx*ny bytes or NULL (all true).

@@ -19,6 +19,7 @@ POST_NONE, POST_AFFINE, POST_EXPMAX, POST_SCALE = range(4)
  TIMED_SOLVE_STEP_STAGED, TIMED_FUSED_STEP_SKIP) = range(9)
 SCHEME_AUTO, SCHEME_STAGED, SCHEME_FUSED = 0, 1, 2
 LOSS_H, LOSS_V, LOSS_HV = 0, 1, 2
+VJP_DISCRETE, VJP_CONTINUOUS = 0, 1
 
 
 class OdinnError(RuntimeError):
@@ -92,6 +93,7 @@ SIGNATURES = {
     "odinn_loss": (C.c_int, [_vp, _dp]),
     "odinn_loss_grad": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.POINTER(SolverOpts), _dp, _dp,
                                   C.POINTER(SolveStats)]),
+    "odinn_set_vjp_method": (C.c_int, [_vp, C.c_int]),
     "odinn_tikhonov": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double, _dp, C.c_void_p, _dp, _dp]),
     "odinn_loss_grad_continuous": (C.c_int, [_vp, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.POINTER(SolverOpts),
                                              C.POINTER(AdjointOpts), _dp, _dp, C.POINTER(SolveStats),

@@ -34,7 +34,7 @@ from .batch import GlacierBatch, MLPSpec, PhysicalParameters
 __all__ = [
     "Parameters", "SimulationParameters", "SolverParameters", "Hyperparameters", "UDEparameters",
     "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
-    "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DiscreteVJP", "MultiLoss", "TikhonovRegularization",
+    "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DiscreteVJP", "ContinuousVJP", "MultiLoss", "TikhonovRegularization",
     "InitialThicknessRegularization", "RheologyRegularization", "InitialCondition", "evaluate_H0", "evaluate_dH0",
     "sigma_zang", "dsigma_zang", "TrainingResult", "save_inversion_file", "load_inversion_file", "ScalarLogger",
     "callback_diagnosis",
@@ -76,10 +76,15 @@ class DiscreteVJP:
 
 
 @dataclass
+class ContinuousVJP:
+    """src/inverse/VJPTypes.jl:39-50: the continuous-form stencils of adjoint.jl:442-662 (target :A)."""
+
+
+@dataclass
 class DiscreteAdjoint:
     """src/inverse/AdjointTypes.jl:85-91"""
 
-    VJP_method: DiscreteVJP = field(default_factory=DiscreteVJP)
+    VJP_method: object = field(default_factory=DiscreteVJP)  # DiscreteVJP | ContinuousVJP
     MB_VJP: DiscreteVJP = field(default_factory=DiscreteVJP)
 
 
@@ -88,7 +93,7 @@ class ContinuousAdjoint:
     """src/inverse/AdjointTypes.jl:53-67 -- the reference's default `grad` (UDEparameters.jl:63).
     Only VJP_method = DiscreteVJP() and interpolation = :Linear are provided."""
 
-    VJP_method: DiscreteVJP = field(default_factory=DiscreteVJP)
+    VJP_method: object = field(default_factory=DiscreteVJP)  # DiscreteVJP | ContinuousVJP
     solver: str = "RDPK3Sp35"
     reltol: float = 1e-8
     abstol: float = 1e-8
@@ -837,9 +842,10 @@ def SIA2D_b(dH: np.ndarray, H: np.ndarray, simulation: _Simulation, t: float, th
     return None
 
 
-def VJP_lambda_dSIAdH(VJPMode: DiscreteVJP, lam, H, theta, simulation: _Simulation, t, glacier_idx: int = 0):
-    """VJP_λ_∂SIA∂H(::DiscreteVJP, λ, H, θ, simulation, t) -> (λ_∂f∂H, nothing)  (VJPs.jl:2-5)."""
+def VJP_lambda_dSIAdH(VJPMode, lam, H, theta, simulation: _Simulation, t, glacier_idx: int = 0):
+    """VJP_λ_∂SIA∂H(::DiscreteVJP | ::ContinuousVJP, λ, H, θ, simulation, t) -> (λ_∂f∂H, nothing)  (VJPs.jl:2-10)."""
     b = simulation.batch()
+    b.set_vjp_method(L.VJP_CONTINUOUS if isinstance(VJPMode, ContinuousVJP) else L.VJP_DISCRETE)
     if theta is not None and b.P:
         b.set_theta(theta)
     return b.vjp_H(glacier_idx, lam, H, t), None
@@ -879,6 +885,12 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
         loss_grad = b.loss_grad
     else:
         raise TypeError(f"adjoint method {type(grad).__name__} is not provided")
+    if isinstance(grad.VJP_method, ContinuousVJP):
+        b.set_vjp_method(L.VJP_CONTINUOUS)
+    elif isinstance(grad.VJP_method, DiscreteVJP):
+        b.set_vjp_method(L.VJP_DISCRETE)
+    else:
+        raise TypeError(f"VJP method {type(grad.VJP_method).__name__} is not supported yet.")  # gradient.jl:311-314
     theta = np.asarray(theta, dtype=np.float64)
     th_main = theta[:model.n_main]
     dth = np.zeros_like(theta)

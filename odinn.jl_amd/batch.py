@@ -325,6 +325,10 @@ class GlacierBatch:
         self.last_stats_rev = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in sr]
         return float(loss.value), dth
 
+    def set_vjp_method(self, method=L.VJP_DISCRETE):
+        """DiscreteVJP (default) or ContinuousVJP stencil for vjp_H and both adjoints (VJPTypes.jl:29-50)."""
+        L.check(L.lib().odinn_set_vjp_method(self._h, int(method)))
+
     def tikhonov(self, a, dx, dy, mask=None):
         """(loss, grad) of TikhonovRegularization(:laplacian) on one field (Regularization.jl:92-126)."""
         a = np.asfortranarray(a, dtype=np.float64)

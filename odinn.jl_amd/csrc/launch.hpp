@@ -9,9 +9,9 @@ namespace odinn {
   void launch_dhdt_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, const double* U, double* dH, int base); \
   void launch_rk_stage_lm##LM(int stage, int nblk, hipStream_t st, Pools P, LawDev L, const double* src,       \
                               double* dst, double* S2, double* S3, double* E, double abstol, double reltol);   \
-  void launch_vjp_H_lm##LM(int mode, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base);        \
+  void launch_vjp_H_lm##LM(int mode, int vj, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base); \
   void launch_vjp_theta_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base);           \
-  void launch_adj_stage_lm##LM(int stage, int nblk, hipStream_t st, Pools P, LawDev L, AdjStageArgs A);        \
+  void launch_adj_stage_lm##LM(int stage, int vj, int nblk, hipStream_t st, Pools P, LawDev L, AdjStageArgs A); \
   void launch_rk_fused_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,     \
                               double* U1, double* partF, double abstol, double reltol, int skip);
 ODINN_DECL_LM(0)

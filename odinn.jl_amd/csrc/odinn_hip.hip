@@ -152,6 +152,7 @@ struct odinn_batch {
   int nvref_alloc = 0;
   double *d_Vabs = nullptr, *d_Vxr = nullptr, *d_Vyr = nullptr;
   int loss_kind = ODINN_LOSS_H, v_abs = 0, v_scale_loss = 1;
+  int vjp_method = 0;  // 0 DiscreteVJP, 1 ContinuousVJP (H-VJP stencil used by the seams and both adjoints)
   double hv_scaling = 1.0;
   double *d_wv = nullptr, *d_vsc = nullptr;
   int* d_vslot = nullptr;
@@ -378,16 +379,19 @@ void launch_stage(odinn_batch* b, const Pools& P, const LawDev& L, const double*
                                                  launch_rk_stage_lm3, launch_rk_stage_lm4, launch_rk_stage_lm5};
   tab[b->lm()](S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol);
 }
-void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawDev& L, const AdjArgs& A, int base) {
-  static void (*const tab[6])(int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
+// vj < 0: the batch's VJP method (odinn_set_vjp_method)
+void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawDev& L, const AdjArgs& A, int base,
+                  int vj = -1) {
+  static void (*const tab[6])(int, int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
       launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5};
-  tab[b->lm()](mode, nblk, b->stream, P, L, A, base);
+  tab[b->lm()](mode, vj < 0 ? b->vjp_method : vj, nblk, b->stream, P, L, A, base);
 }
-void launch_adj_stage(int lm, int stage, int nblk, hipStream_t st, const Pools& P, const LawDev& L, const AdjStageArgs& A) {
-  static void (*const tab[6])(int, int, hipStream_t, Pools, LawDev, AdjStageArgs) = {
+void launch_adj_stage(int lm, int vj, int stage, int nblk, hipStream_t st, const Pools& P, const LawDev& L,
+                      const AdjStageArgs& A) {
+  static void (*const tab[6])(int, int, int, hipStream_t, Pools, LawDev, AdjStageArgs) = {
       launch_adj_stage_lm0, launch_adj_stage_lm1, launch_adj_stage_lm2, launch_adj_stage_lm3, launch_adj_stage_lm4,
       launch_adj_stage_lm5};
-  tab[lm](stage, nblk, st, P, L, A);
+  tab[lm](stage, vj, nblk, st, P, L, A);
 }
 void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L, const ThArgs& A, int base) {
   static void (*const tab[6])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
@@ -971,6 +975,8 @@ int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H,
   (void)t;
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!H || !lam || !dlam) return fail(ODINN_ERR_ARG, "null field");
+  if (b->vjp_method == 1 && b->law_kind >= ODINN_LAW_NN_Y)
+    return fail(ODINN_ERR_UNSUPPORTED, "ContinuousVJP is provided for target :A (A-type laws) only");
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
   CHK(up_field(b, g, b->d_tmpA, H));
   CHK(up_field(b, g, b->d_lam[0], lam));
@@ -1047,6 +1053,12 @@ int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double
   std::vector<double> dA(b->P);
   h_mlp(b->mlp, b->theta.data(), &b->descs[g].T, dA.data());
   for (int k = 0; k < b->P; ++k) dtheta[k] = dA[k] * Gs;  // cartesian_tensor contraction, target_utils.jl:156-161
+  return ODINN_OK;
+}
+
+int odinn_set_vjp_method(odinn_batch* b, int method) {
+  if (!b || (method != ODINN_VJP_DISCRETE && method != ODINN_VJP_CONTINUOUS)) return fail(ODINN_ERR_ARG, "bad VJP method");
+  b->vjp_method = method;
   return ODINN_OK;
 }
 
@@ -1253,6 +1265,8 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
   if (b->loss_kind != ODINN_LOSS_V && !b->d_Href) return fail(ODINN_ERR_STATE, "no reference thickness data set");
   if (b->loss_kind != ODINN_LOSS_H && !b->d_Vabs) return fail(ODINN_ERR_STATE, "no reference velocity data set");
+  if (b->vjp_method == 1 && b->law_kind >= ODINN_LAW_NN_Y)
+    return fail(ODINN_ERR_UNSUPPORTED, "ContinuousVJP is provided for target :A (A-type laws) only");
   CHK(do_solve(b, n_stops, tstops, n_mb, mb_times, opts, stats));
   const size_t fb = (size_t)b->ntot * sizeof(double);
   HIPCHK(hipMemsetAsync(b->d_lam[0], 0, fb, b->stream));  // lambda_k = 0   (gradient.jl:140)
@@ -1502,7 +1516,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       double* dst = a1;
       for (int stg = 1; stg <= 5; ++stg) {
         SA.src = src; SA.dst = dst;
-        launch_adj_stage(lm, stg, b->ntiles, b->stream, Pl, L, SA);
+        launch_adj_stage(lm, b->vjp_method, stg, b->ntiles, b->stream, Pl, L, SA);
         double* t_ = const_cast<double*>(src);
         src = dst;
         dst = t_;
@@ -1656,7 +1670,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
     case ODINN_TIMED_VJP_H: {
       AdjArgs A{};
       A.H = b->d_U[0]; A.lam = b->d_lam[0]; A.out = b->d_tmpB;
-      launch_vjp_H(b, 0, b->ntiles, P, L, A, 0);
+      launch_vjp_H(b, 0, b->ntiles, P, L, A, 0, 0);
       return ODINN_OK;
     }
     case ODINN_TIMED_VJP_THETA: return theta_vjp_launch(b, b->d_U[0], b->d_lam[0], nullptr, -1, false);

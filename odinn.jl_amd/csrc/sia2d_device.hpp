@@ -630,7 +630,8 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
 }
 
 // Same for a third field kept unclamped and masked to the interior (lambda~).
-template <int NWV = NW, int TYV = TY>
+// MASK = false keeps the boundary-ring values (the continuous-form VJP differentiates lambda itself).
+template <int NWV = NW, int TYV = TY, bool MASK = true>
 __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, const GDev& g, int i0, int j0,
                                               double (*sL)[LDW], double (&own)[TYV / NWV]) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -639,7 +640,7 @@ __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, con
     raw = 0.0;
     if (gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny) {
       raw = Lm[g.off + gi_ + (long long)g.nx * gj_];
-      if (gi_ >= 1 && gi_ <= g.nx - 2 && gj_ >= 1 && gj_ <= g.ny - 2) return raw;
+      if (!MASK || (gi_ >= 1 && gi_ <= g.nx - 2 && gj_ >= 1 && gj_ <= g.ny - 2)) return raw;
     }
     return 0.0;
   };
@@ -1133,11 +1134,13 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
 // contributions.  The closed-form laws reuse the same 35 KB for both (4 blocks / CU); the MLP laws
 // (LM >= 2) are VALU-bound: they keep both side by side (2 blocks / CU) and a rolled node loop, so
 // the inlined network is instantiated once.
-template <int LM>
+// VJ: 0 = DiscreteVJP (adjoint.jl:31-151), 1 = ContinuousVJP (adjoint.jl:442-553; A-type laws only),
+// which needs a third double2 per node ({alpha/4, q/4}).
+template <int LM, int VJ = 0>
 struct VjpHLds {
   static constexpr bool ALIAS = LM <= LM_POW;
   static constexpr int A_D2 = (TY + 2) * LDW + ((TY + 2) * LDW + 1) / 2;  // in double2 units
-  static constexpr int B_D2 = 2 * (TY + 1) * LDN;
+  static constexpr int B_D2 = (VJ ? 3 : 2) * (TY + 1) * LDN;
   static constexpr int SIZE = ALIAS ? (A_D2 > B_D2 ? A_D2 : B_D2) : A_D2 + B_D2;
   static __device__ __forceinline__ double2 (*hs(double2* m))[LDW] { return reinterpret_cast<double2(*)[LDW]>(m); }
   static __device__ __forceinline__ double (*lam(double2* m))[LDW] {
@@ -1145,13 +1148,49 @@ struct VjpHLds {
   }
 };
 
+// One dual node of the CONTINUOUS-form H-VJP (VJP_lambda_dSIA/dH_continuous, adjoint.jl:442-553):
+//   dlam = div(D grad lam) - avg(dD/dH) avg(q) + avg_y(dx(q beta gSx))/dx + avg_x(dy(q beta gSy))/dy
+// on the interior, q = <grad S, grad lam> on the dual grid (:534-538), slopes unclamped, lambda raw.
+// The divergence terms are linear in the node's D, q beta gS: k[c] is what the node adds to corner
+// cell c; the product term needs the corner sums of alpha and q separately (a4 = alpha/4, q4 = q/4).
+template <int LM>
+__device__ __forceinline__ void vjpHc_node(const GDev& g, const LawDev& L, const Pools& P, const double2 (*sHS)[LDW],
+                                           const double (*sL)[LDW], int i0, int j0, int a, int b, double (&k)[4],
+                                           double& a4, double& q4) {
+  const int gi = i0 - 1 + a, gj = j0 - 1 + b;
+  k[0] = k[1] = k[2] = k[3] = 0.0;
+  a4 = 0.0; q4 = 0.0;
+  if (gi < 0 || gi > g.nx - 2 || gj < 0 || gj > g.ny - 2) return;
+  const double2* p = &sHS[b][a];
+  const double* pl = &sL[b][a];
+  const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
+  const double l00 = pl[0], l10 = pl[1], l01 = pl[LDW], l11 = pl[LDW + 1];
+  const double dxl = c10.y - c00.y, dxu = c11.y - c01.y, dyl = c01.y - c00.y, dyr = c11.y - c10.y;
+  const double gx = (dxl + dxu) * g.hinv_dx, gy = (dyl + dyr) * g.hinv_dy;
+  const double Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
+  double An = g.A;
+  if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+  double al, be, sp;
+  const double D = node_D<true, LM>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
+  const double mxl = l10 - l00, mxu = l11 - l01, myl = l01 - l00, myr = l11 - l10;
+  const double q = fma(g.hinv_dx2, fma(dxu, mxu, dxl * mxl), g.hinv_dy2 * fma(dyr, myr, dyl * myl));
+  const double wx = D * g.hinv_dx2, wy = D * g.hinv_dy2;
+  const double px = g.hinv_dx * (q * be * gx), py = g.hinv_dy * (q * be * gy);
+  k[0] = fma(wx, mxl, wy * myl) + px + py;    // cell SW of the node (node = its NE corner)
+  k[1] = fma(-wx, mxl, wy * myr) - px + py;   // cell SE
+  k[2] = fma(wx, mxu, -wy * myl) + px - py;   // cell NW
+  k[3] = fma(-wx, mxu, -wy * myr) - px - py;  // cell NE
+  a4 = 0.25 * al;
+  q4 = 0.25 * q;
+}
+
 // v[m] = (J_H(H)^T lam)[cell m of this thread] from tiles already in LDS (and synchronised).
 // Phase A: every thread evaluates its (up to 5) nodes; phase B: every cell adds the four numbers
 // its corner nodes left for it, masked by H > 0 (adjoint.jl:148).
-template <int LM>
+template <int LM, int VJ = 0>
 __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const Pools& P, double2* smem, int i0,
                                           int j0, const double (&ownH)[RPT], double (&v)[RPT]) {
-  using S = VjpHLds<LM>;
+  using S = VjpHLds<LM, VJ>;
   double2(*sHS)[LDW] = S::hs(smem);
   double(*sL)[LDW] = S::lam(smem);
   double2* cbase = S::ALIAS ? smem : smem + S::A_D2;
@@ -1161,6 +1200,40 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
   // the 65th column and 17th row of nodes: wavefront 0 takes the row, wavefront 1 the column
   const int ea = ty == 0 ? tx : TX, eb = ty == 0 ? TY : tx;
   const bool extra = ty == 0 || (ty == 1 && tx <= TY);
+  if constexpr (VJ == 1) {
+    static_assert(S::ALIAS, "the continuous-form VJP is provided for the closed-form A laws");
+    double2(*sCc)[LDN] = reinterpret_cast<double2(*)[LDN]>(cbase + 2 * (TY + 1) * LDN);  // {alpha/4, q/4}
+    double kk[RPT + 1][4], aa[RPT + 1], qq[RPT + 1];
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m], aa[m], qq[m]);
+    if (extra) vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT], aa[RPT], qq[RPT]);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) {
+      sCa[ty + NW * m][tx] = make_double2(kk[m][0], kk[m][1]);
+      sCb[ty + NW * m][tx] = make_double2(kk[m][2], kk[m][3]);
+      sCc[ty + NW * m][tx] = make_double2(aa[m], qq[m]);
+    }
+    if (extra) {
+      sCa[eb][ea] = make_double2(kk[RPT][0], kk[RPT][1]);
+      sCb[eb][ea] = make_double2(kk[RPT][2], kk[RPT][3]);
+      sCc[eb][ea] = make_double2(aa[RPT], qq[RPT]);
+    }
+    __syncthreads();
+    const int c = tx + 1;
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) {
+      const int r = 1 + ty + NW * m;
+      const int gi = i0 + tx, gj = j0 - 1 + r;
+      v[m] = 0.0;
+      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) {  // inn(dlam) only (adjoint.jl:551-552)
+        const double2 sw = sCc[r - 1][c - 1], se = sCc[r - 1][c], nw = sCc[r][c - 1], ne = sCc[r][c];
+        const double lin = (sCb[r - 1][c - 1].y + sCb[r - 1][c].x) + (sCa[r][c - 1].y + sCa[r][c].x);
+        v[m] = lin - ((sw.x + se.x) + (nw.x + ne.x)) * ((sw.y + se.y) + (nw.y + ne.y));
+      }
+    }
+    return;
+  }
   if constexpr (S::ALIAS) {
     double kk[RPT + 1][4];
 #pragma unroll
@@ -1199,9 +1272,9 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
   }
 }
 
-template <int MODE, int LM>
-__global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
-  __shared__ double2 smem[VjpHLds<LM>::SIZE];
+template <int MODE, int LM, int VJ = 0>
+__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
+  __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const GDev g = P.gd[t4.x];
@@ -1210,13 +1283,13 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_vjp_H(Pools P, 
   if (MODE == 0 && A.snaps) {
     const AdjState a = A.adj[t4.x];
     const double* Ha = A.snaps + (long long)a.seg * A.ntot;
-    load_tile_HS2(Ha, P.B, g, i0, j0, VjpHLds<LM>::hs(smem), ownH, Ha + A.ntot, a.sitp[0]);
+    load_tile_HS2(Ha, P.B, g, i0, j0, VjpHLds<LM, VJ>::hs(smem), ownH, Ha + A.ntot, a.sitp[0]);
   } else {
-    load_tile_HS2(A.H, P.B, g, i0, j0, VjpHLds<LM>::hs(smem), ownH);
+    load_tile_HS2(A.H, P.B, g, i0, j0, VjpHLds<LM, VJ>::hs(smem), ownH);
   }
-  load_tile_lam(A.lam, g, i0, j0, VjpHLds<LM>::lam(smem), ownL);
+  load_tile_lam<NW, TY, VJ == 0>(A.lam, g, i0, j0, VjpHLds<LM, VJ>::lam(smem), ownL);
   __syncthreads();
-  vjpH_tile<LM>(g, L, P, smem, i0, j0, ownH, v);
+  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
   double dt = 1.0, w = 0.0;
@@ -1270,9 +1343,9 @@ struct AdjStageArgs {
   double abstol, reltol;
 };
 
-template <int STAGE, int LM>
-__global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_adj_stage(Pools P, LawDev L, AdjStageArgs A) {
-  __shared__ double2 smem[VjpHLds<LM>::SIZE];
+template <int STAGE, int LM, int VJ = 0>
+__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_stage(Pools P, LawDev L, AdjStageArgs A) {
+  __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x];
   const GState* gs = P.gs + t4.x;
@@ -1286,11 +1359,11 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST ? 4 : 2)) void k_adj_stage(Pools
   double ownH[RPT], ownL[RPT], v[RPT];
   {
     const double* Ha = A.snaps + (long long)a.seg * A.ntot;
-    load_tile_HS2(Ha, P.B, g, i0, j0, VjpHLds<LM>::hs(smem), ownH, Ha + A.ntot, a.sitp[STAGE - 1]);
+    load_tile_HS2(Ha, P.B, g, i0, j0, VjpHLds<LM, VJ>::hs(smem), ownH, Ha + A.ntot, a.sitp[STAGE - 1]);
   }
-  load_tile_lam(X, g, i0, j0, VjpHLds<LM>::lam(smem), ownL);
+  load_tile_lam<NW, TY, VJ == 0>(X, g, i0, j0, VjpHLds<LM, VJ>::lam(smem), ownL);
   __syncthreads();
-  vjpH_tile<LM>(g, L, P, smem, i0, j0, ownH, v);
+  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
   constexpr int s = STAGE - 1;

@@ -599,6 +599,58 @@ def vjp_theta(lam, H, B, dx, dy, ph: Phys, law: Law, theta=None):
     return np.tensordot(g, spatial, axes=([1, 2], [0, 1]))
 
 
+def vjp_H_continuous(lam, H, B, dx, dy, ph: Phys, law: Law, theta=None):
+    """VJP_lambda_dSIA/dH_continuous (adjoint.jl:442-553): the continuous-form adjoint
+    div(D grad lam) - dD/dH <grad S, grad lam> + div(dD/dgradH <grad S, grad lam>) on the interior,
+    with unclamped slopes and no H > 0 mask; 0 on the boundary ring."""
+    Hc = np.maximum(H, 0.0)
+    S = B + Hc
+    dSdx = diff_x(S) / dx
+    dSdy = diff_y(S) / dy
+    gSx = avg_y(dSdx)
+    gSy = avg_x(dSdy)
+    gS = np.sqrt(gSx ** 2 + gSy ** 2)
+    Hbar = avg(Hc)
+    D = diffusivity(law, ph, Hbar, gS, theta)
+    dDdH = avg(d_diffusivity_dH(law, ph, Hbar, gS, theta))  # :499-505
+    beta = d_diffusivity_dgradS(law, ph, Hbar, gS, theta)
+    dDdgx = beta * gSx  # :515-516
+    dDdgy = beta * gSy
+    dlx = diff_x(lam[:, 1:-1]) / dx  # :521-522
+    dly = diff_y(lam[1:-1, :]) / dy
+    Fx = -avg_y(D) * dlx
+    Fy = -avg_x(D) * dly
+    divDgl = -(diff_x(Fx) / dx + diff_y(Fy) / dy)  # :527-531
+    glgS = avg_y(dSdx * diff_x(lam) / dx) + avg_x(dSdy * diff_y(lam) / dy)  # :534-538
+    t2 = dDdH * avg(glgS)  # :540
+    px = glgS * dDdgx
+    py = glgS * dDdgy
+    t3 = avg_y(diff_x(px) / dx) + avg_x(diff_y(py) / dy)  # :543-548
+    out = np.zeros_like(lam)
+    out[1:-1, 1:-1] = divDgl - t2 + t3  # :551-552
+    return out
+
+
+def vjp_theta_continuous(lam, H, B, dx, dy, ph: Phys, law: Law, theta=None):
+    """VJP_lambda_dSIA/dtheta_continuous (adjoint.jl:583-662): sum_ij lam[i,j] * div(avg(dD/dtheta_k) *
+    clamped grad S)[i,j] -- the forward form of the same bilinear expression as the discrete VJP
+    (the two agree to rounding; only the order of summation differs)."""
+    Hc, S, gSx, gSy, gS, Hbar, ex, ey, exc, eyc = _forward_intermediates(H, B, dx, dy, ph)
+    spat = dD_dlaw(law, ph, Hbar, gS)
+
+    def contract(w):  # w = dD/dtheta_k on the dual grid
+        Fx = avg_y(w) * exc
+        Fy = avg_x(w) * eyc
+        return float(np.sum((diff_x(Fx) / dx + diff_y(Fy) / dy) * lam[1:-1, 1:-1]))
+
+    if law.kind == LAW_CONST_A:
+        return np.array([contract(spat)])
+    g = law_grad_theta(law, ph, Hbar, gS, theta)
+    if law.kind == LAW_NN_A_SCALAR:
+        return g.reshape(-1) * contract(spat)
+    return np.array([contract(spat * g[k]) for k in range(g.shape[0])])
+
+
 # ----------------------------------------------------------------------------
 # Mass balance source (callback inversion_utils.jl:498-517; mask/clip logic
 # mirrored at src/inverse/SIA2D/VJPs.jl:129-139).  The climate model (Muninn
@@ -895,8 +947,13 @@ def loss_H(snaps, tstops, H_ref, tH_ref, distance):
     return tot
 
 
-def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=None):
-    """SIA2D_grad_batch! with DiscreteAdjoint + DiscreteVJP (gradient.jl:45-275).
+def _vjp_H_of(vjp):
+    """VJP_lambda_dSIA/dH dispatch on the VJP method (VJPs.jl:2-10)."""
+    return {"discrete": vjp_H, "continuous": vjp_H_continuous}[vjp]
+
+
+def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=None, vjp="discrete"):
+    """SIA2D_grad_batch! with DiscreteAdjoint + DiscreteVJP | ContinuousVJP (gradient.jl:45-275).
 
     Reverse loop (explicit Euler over the snapshots, Jacobian at the END-of-interval
     state, theta-VJP with the already-updated lambda) exactly as :191-253.
@@ -923,7 +980,7 @@ def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=No
             loss_rev += l2sum_loss(snaps[j], Hr, mask, N) * w[j]
         else:
             dl = 0.0
-        g = vjp_H(lam[j], snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # :235-237
+        g = _vjp_H_of(vjp)(lam[j], snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # :235-237
         if j > 0:
             dt = t[j] - t[j - 1]
             lam[j - 1] = lam[j] + dt * g + dl  # :242
@@ -970,7 +1027,7 @@ def linear_itp(ts, fields, t):
 
 
 def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, adj: ContinuousAdjointCfg = None,
-                             theta=None):
+                             theta=None, vjp="discrete"):
     """SIA2D_grad_batch! with ContinuousAdjoint(VJP_method = DiscreteVJP()) and LossH
     (gradient.jl:276-539).  Returns (loss, dL/dtheta, lambda(t0), stats of the reverse solve)."""
     adj = adj or ContinuousAdjointCfg()
@@ -996,7 +1053,7 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
             return u + vjp_mb(cfg.mb, u, H_itp(tt) - inc[tt], gl.B)
         return u
 
-    f_rev = lambda lam, tau: vjp_H(lam, H_itp(-tau), gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # :316-324
+    f_rev = lambda lam, tau: _vjp_H_of(vjp)(lam, H_itp(-tau), gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # :316-324
     nodes, wts = gauss_quadrature(t[0], t[-1], adj.n_quadrature)  # :307-308
     lam1 = effect_loss(t[-1], np.zeros_like(gl.B))  # :441-446 (not covered by the discrete callback)
     lam1 = effect_mb(t[-1], lam1)  # PeriodicCallback(initial_affect = true) :431-432

@@ -107,3 +107,65 @@ def test_continuous_adjoint_rejects_velocity_losses(gpu):
         b.loss_grad_continuous([2010.0, 2010.1])
     assert "LossH" in str(e.value)
     b.close()
+
+
+# ---- ContinuousVJP stencil (adjoint.jl:442-553) ------------------------------------------------
+@pytest.mark.parametrize("shape,C,n", [((96, 80), 0.0, 3.0), ((65, 17), 0.0, 3.0), ((37, 40), 7e-8, 3.0),
+                                       ((130, 50), 0.0, 2.6), ((3, 3), 0.0, 3.0)])
+def test_continuous_vjp_kernel_matches_oracle(gpu, shape, C, n):
+    nx, ny = shape
+    ph = O.Phys(C=C, p=3.0, q=1.0, n=n)
+    H0, B = O.synthetic_icecap(nx, ny, 100.0)
+    H0 = H0 * 0.4
+    rng = np.random.default_rng(7)
+    lam = rng.standard_normal((nx, ny))
+    b = gpu.GlacierBatch([(nx, ny)], [100.0], phys=[gpu.PhysicalParameters(**ph.__dict__)], A=[2e-17])
+    b.set_fields(0, H0, B)
+    b.set_vjp_method(gpu._lib.VJP_CONTINUOUS)
+    law = O.Law(kind=O.LAW_CONST_A, A=2e-17)
+    ref = O.vjp_H_continuous(lam, H0, B, 100.0, 100.0, ph, law)
+    got = b.vjp_H(0, lam, H0)
+    assert rel_l2(got, ref) < (1e-11 if n == 3.0 else 1e-10) or not ref.any()
+    Hn = H0 - 30.0 * rng.uniform(size=H0.shape)  # negative thickness is clamped first (adjoint.jl:466)
+    assert rel_l2(b.vjp_H(0, lam, Hn), O.vjp_H_continuous(lam, Hn, B, 100.0, 100.0, ph, law)) < 1e-10 or nx == 3
+    b.set_vjp_method(gpu._lib.VJP_DISCRETE)
+    assert rel_l2(b.vjp_H(0, lam, H0), O.vjp_H(lam, H0, B, 100.0, 100.0, ph, law)) < 1e-10 or nx == 3
+    b.close()
+
+
+@pytest.mark.parametrize("adjoint", ["discrete", "continuous"])
+def test_gradients_with_continuous_vjp_match_oracle(gpu, adjoint):
+    """DiscreteAdjoint(VJP_method = ContinuousVJP()) and ContinuousAdjoint(VJP_method = ContinuousVJP())
+    (runtests.jl:125,141) against the oracle's loops with the same stencil."""
+    nx, ny = 64, 48
+    ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, False, k=7, step=1.0 / 48.0)
+    law0 = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=om, theta=th0, T=-2.0)
+    b = _batch(gpu, nx, ny, H0, B, gm, th0, ts, ref)
+    b.set_vjp_method(gpu._lib.VJP_CONTINUOUS)
+    if adjoint == "discrete":
+        Lo, go, lam0 = O.loss_and_grad(gl, law0, cfg, ref, ts, vjp="continuous")
+        Lg, gg = b.loss_grad(ts, theta=th0, reltol=1e-8)
+    else:
+        Lo, go, lam0, _ = O.loss_and_grad_continuous(gl, law0, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=16),
+                                                     vjp="continuous")
+        Lg, gg = b.loss_grad_continuous(ts, theta=th0, reltol=1e-8, n_quadrature=16)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-9 and relerr < 1e-5, (ratio, angle, relerr)
+    assert rel_l2(b.lambda0(0), lam0) < 1e-5
+    b.close()
+
+
+def test_continuous_vjp_needs_an_A_type_law(gpu):
+    H0, B = O.synthetic_valley(32, 24, 50.0)
+    ph = O.Phys()
+    b = gpu.GlacierBatch([(32, 24)], [50.0])
+    b.set_fields(0, H0, B)
+    m = O.default_nn(2, light=True, prescale=((-25.0, 0.0), (0.0, 500.0)), post_kind=O.POST_EXPMAX, post_lo=0.0, post_hi=ph.maxA)
+    b.set_law(gpu.LAW_NN_Y, gpu.MLPSpec(m.widths, m.acts, m.prescale, m.post_kind, m.post_lo, m.post_hi),
+              m.init_theta(np.random.default_rng(0)))
+    b.set_vjp_method(gpu._lib.VJP_CONTINUOUS)
+    with pytest.raises(Exception) as e:
+        b.vjp_H(0, np.ones_like(H0), H0)
+    assert "target :A" in str(e.value)
+    b.close()
