@@ -215,11 +215,23 @@ def main():
                 ms.run(2, 1e-6)
                 nst += 2
             tc = time.perf_counter() - tc0
+            # (i) of SURVEY 8(d): the same restatement on ONE host thread (bounded: ~3 s)
+            CO.lib().oc_set_threads(1)
+            st1 = CO.Stepper(H0, B, 100.0, 100.0, O.Phys(), A)
+            st1.step(1e-6)
+            t10 = time.perf_counter()
+            n1 = 0
+            while time.perf_counter() - t10 < 3.0:
+                st1.step(1e-6)
+                n1 += 1
+            t1c = time.perf_counter() - t10
+            CO.lib().oc_set_threads(cores)
             cpu = {
                 "value": 5.0 * n * n * nst * cores / tc,
                 "unit": "cell-steps/s",
                 "cores": cores,
                 "kind": "port",
+                "value_1_thread": 5.0 * n * n * n1 / t1c,
                 "sample": f"{cores} copies of ONE {n}x{n} glacier of the workload, one host thread each "
                           f"(the reference's pmap-over-glaciers pattern), {nst} RDPK3Sp35 steps each, "
                           f"oracle/sia2d_oracle.c, {tc:.1f} s",
