@@ -139,6 +139,8 @@ def main():
     ms_dhdt = b.time_kernel(T.TIMED_DHDT, iters=50, warmup=5)
     ms_vjp = b.time_kernel(T.TIMED_VJP_H, iters=20, warmup=3)
     ms_vjpt = b.time_kernel(T.TIMED_VJP_THETA, iters=20, warmup=3)
+    ms_cfl = b.time_kernel(T.TIMED_EULER_CFL, iters=50, warmup=5)
+    ms_adj = b.time_kernel(T.TIMED_ADJ_STAGE2, iters=20, warmup=3)
     aux = {
         "fused_step_with_ice_free_shortcut_ms": ms_fused_skip,
         "fused_step_with_ice_free_shortcut_cellsteps_per_s": 5.0 * cells * world / (ms_fused_skip * 1e-3),
@@ -152,6 +154,12 @@ def main():
         "dhdt_GBs": B_PER_CELL_DHDT * cells / (ms_dhdt * 1e-3) / 1e9,
         "vjp_H_ms": ms_vjp,
         "vjp_H_GBs": B_PER_CELL_VJPH * cells / (ms_vjp * 1e-3) / 1e9,
+        "euler_cfl_step_ms": ms_cfl,
+        "euler_cfl_step_GBs": 24.0 * cells / (ms_cfl * 1e-3) / 1e9,
+        "euler_cfl_cellsteps_per_s": cells * world / (ms_cfl * 1e-3),
+        "euler_cfl_note": "explicit Euler with CFL-limited dt (scheme 3): ONE cell-step per cell per launch, 24 B per cell-step",
+        "adj_stage2_ms": ms_adj,
+        "adj_stage2_GBs": 88.0 * cells / (ms_adj * 1e-3) / 1e9,
         "vjp_theta_ms": ms_vjpt,
         "vjp_theta_GBs": 24.0 * cells / (ms_vjpt * 1e-3) / 1e9,
     }

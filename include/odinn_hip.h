@@ -105,13 +105,18 @@ typedef struct odinn_solver_opts {
   double dt0;       /* <=0: Hairer-Wanner automatic initial step                            */
   double fixed_dt;  /* >0: non-adaptive RDPK3Sp35 with this step (clipped at tstops)        */
   int64_t maxiters; /* params.solver.maxiters (:567); <=0 -> 1e6                            */
-  int32_t scheme;   /* kernel schedule of one RDPK3Sp35 step (same arithmetic either way):
-                       0 auto, 1 five per-stage kernels (HBM-bound, 264 B/cell/step),
-                       2 one temporally fused kernel (~24 B/cell/step, fp64-VALU-bound).
-                       The environment variable ODINN_SCHEME=1|2 overrides 0.               */
+  int32_t scheme;   /* 0 auto, 1/2: kernel schedule of one RDPK3Sp35 step (same arithmetic either way):
+                       1 five per-stage kernels (HBM-bound, 264 B/cell/step),
+                       2 one temporally fused kernel (~24 B/cell/step, fp64-VALU-bound);
+                       the environment variable ODINN_SCHEME=1|2 overrides 0.
+                       3 ODINN_SCHEME_EULER_CFL: explicit Euler with the CFL-limited step
+                         dt = cfl * min(dx,dy)^2 / (4 max D) (the classical SIA stepping; max D by an
+                         in-kernel wavefront reduction; 24 B per cell-step).  Not a reference scheme:
+                         own definition, restated in oracle/ (solve_euler_cfl).                  */
   int32_t dense;    /* 0 (default): workgroups of the fused step whose whole halo region is ice-free
                        (u == 0) take an exact shortcut (bit-identical result); 1: always run the
                        five stages (what bench.py times for `value`)                              */
+  double cfl;       /* scheme 3 only: CFL safety factor in (0, 1]; <= 0 -> 0.25                  */
 } odinn_solver_opts;
 
 typedef struct odinn_solve_stats {
@@ -124,6 +129,7 @@ typedef struct odinn_solve_stats {
  * ContinuousVJP = discretisation of the continuous adjoint operator (adjoint.jl:442-553; target :A only).
  * VJP_lambda_dSIA/dtheta_continuous (adjoint.jl:583-662) is the forward form of the same bilinear
  * expression as the discrete theta-VJP, so odinn_sia2d_vjp_theta serves both methods. */
+#define ODINN_SCHEME_EULER_CFL 3
 #define ODINN_VJP_DISCRETE 0
 #define ODINN_VJP_CONTINUOUS 1
 
@@ -249,7 +255,9 @@ enum odinn_timed {
                                RK step kernel(s) + controller (error-norm reduce, PID) + post-step */
   ODINN_TIMED_FUSED_STEP = 6,/* the temporally fused RDPK3Sp35 step kernel alone   24 B/cell */
   ODINN_TIMED_SOLVE_STEP_STAGED = 7,/* SOLVE_STEP forced onto the five per-stage kernels       */
-  ODINN_TIMED_FUSED_STEP_SKIP = 8   /* fused step kernel with the ice-free-tile shortcut enabled */
+  ODINN_TIMED_FUSED_STEP_SKIP = 8,  /* fused step kernel with the ice-free-tile shortcut enabled */
+  ODINN_TIMED_EULER_CFL = 9,        /* the CFL Euler step kernel alone (RHS + update + max D)  24 B/cell */
+  ODINN_TIMED_ADJ_STAGE2 = 10       /* one stage of the reverse ODE of the continuous adjoint  ~88 B/cell */
 };
 /* runs `iters` back-to-back launches over ALL glaciers of the batch after `warmup`
  * untimed ones; *ms_total is the elapsed time of the timed launches. */

@@ -258,9 +258,9 @@ class GlacierBatch:
 
     # -- device-resident time loop -----------------------------------------------------
     @staticmethod
-    def _opts(reltol=1e-8, abstol=1e-6, dtmax=0.0, dt0=0.0, fixed_dt=0.0, maxiters=10 ** 6, scheme=0, dense=0):
+    def _opts(reltol=1e-8, abstol=1e-6, dtmax=0.0, dt0=0.0, fixed_dt=0.0, maxiters=10 ** 6, scheme=0, dense=0, cfl=0.0):
         return L.SolverOpts(reltol, abstol, dtmax if np.isfinite(dtmax) else 0.0, dt0, fixed_dt or 0.0, maxiters,
-                            int(scheme), int(dense))
+                            int(scheme), int(dense), float(cfl))
 
     def solve(self, tstops, mb_times=(), **opts) -> List[SolveStats]:
         ts = np.ascontiguousarray(tstops, dtype=np.float64)

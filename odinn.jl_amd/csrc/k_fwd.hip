@@ -9,6 +9,9 @@ namespace odinn {
 void CAT(launch_dhdt_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, const double* U, double* dH, int base) {
   hipLaunchKernelGGL(k_dhdt<ODINN_LM>, dim3(nblk), dim3(NT), 0, st, P, L, U, dH, base);
 }
+void CAT(launch_euler_cfl_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, const double* src, double* dst) {
+  hipLaunchKernelGGL(k_euler_cfl<ODINN_LM>, dim3(nblk), dim3(NT), 0, st, P, L, src, dst);
+}
 void CAT(launch_rk_stage_lm, ODINN_LM)(int stage, int nblk, hipStream_t st, Pools P, LawDev L, const double* src,
                                         double* dst, double* S2, double* S3, double* E, double abstol, double reltol) {
   switch (stage) {

@@ -55,6 +55,9 @@ void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan,
 void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double dtmax, double dt_given) {
   hipLaunchKernelGGL(k_begin, dim3((G + 63) / 64), dim3(64), 0, st, P, G, tstops, dtmax, dt_given);
 }
+void launch_set_dt(int G, hipStream_t st, Pools P, double dt) {
+  hipLaunchKernelGGL(k_set_dt, dim3((G + 63) / 64), dim3(64), 0, st, P, G, dt);
+}
 void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot) {
   hipLaunchKernelGGL(k_adj_begin, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, n_snap, tau0, mb_flag, mb_slot);
 }

@@ -7,6 +7,7 @@ namespace odinn {
 
 #define ODINN_DECL_LM(LM)                                                                                      \
   void launch_dhdt_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, const double* U, double* dH, int base); \
+  void launch_euler_cfl_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, const double* src, double* dst);   \
   void launch_rk_stage_lm##LM(int stage, int nblk, hipStream_t st, Pools P, LawDev L, const double* src,       \
                               double* dst, double* S2, double* S3, double* E, double abstol, double reltol);   \
   void launch_vjp_H_lm##LM(int mode, int vj, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base); \
@@ -51,6 +52,7 @@ void launch_initdt_norms(int nblk, hipStream_t st, Pools P, const double* U, con
                          double abstol, double reltol);
 void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan, double dtmax, double* dt0store);
 void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double dtmax, double dt_given);
+void launch_set_dt(int G, hipStream_t st, Pools P, double dt);
 void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot);
 void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, int all_at_end);
 void launch_tikhonov(hipStream_t st, const double* a, const unsigned char* mask, double* r, double* grad,

@@ -400,6 +400,13 @@ void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L,
   tab[b->lm()](nblk, b->stream, P, L, A, base);
 }
 
+void launch_euler_cfl(odinn_batch* b, const Pools& P, const LawDev& L, const double* src, double* dst) {
+  static void (*const tab[6])(int, hipStream_t, Pools, LawDev, const double*, double*) = {
+      launch_euler_cfl_lm0, launch_euler_cfl_lm1, launch_euler_cfl_lm2, launch_euler_cfl_lm3, launch_euler_cfl_lm4,
+      launch_euler_cfl_lm5};
+  tab[b->lm()](b->ntiles, b->stream, P, L, src, dst);
+}
+
 // one RDPK3Sp35 step for all glaciers: 5 fused stage kernels.  parity p: state in U[p].
 int launch_step(odinn_batch* b, int p, double abstol, double reltol) {
   const Pools P = b->pools(true);
@@ -538,12 +545,15 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   CHK(use_dev(b));
   CHK(refresh_gd(b));
   CHK(refresh_law_field(b));
-  odinn_solver_opts opt{1e-8, 1e-6, 0.0, 0.0, 0.0, 1000000, 0, 0};  // dense = 0: ice-free tiles take the exact shortcut
+  odinn_solver_opts opt{1e-8, 1e-6, 0.0, 0.0, 0.0, 1000000, 0, 0, 0.0};  // dense = 0: ice-free tiles take the exact shortcut
   if (o) opt = *o;
   if (opt.maxiters <= 0) opt.maxiters = 1000000;
   if (opt.abstol <= 0) opt.abstol = 1e-6;
   if (opt.reltol <= 0) opt.reltol = 1e-8;
-  const bool adaptive = !(opt.fixed_dt > 0.0);
+  const bool euler = opt.scheme == ODINN_SCHEME_EULER_CFL;
+  if (euler && !(opt.cfl > 0.0)) opt.cfl = 0.25;
+  if (euler && opt.cfl > 1.0) return fail(ODINN_ERR_ARG, "cfl must be in (0, 1]");
+  const bool adaptive = !(opt.fixed_dt > 0.0) && !euler;
   // stop tables
   b->tstops.assign(tstops, tstops + n_stops);
   b->mb_flag.assign(n_stops, 0);
@@ -589,12 +599,12 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
     launch_initdt_ctrl(b->G, b->stream, P, 1, tspan, opt.dtmax, b->d_dt0);
     nrhs_extra = 2;
   }
-  launch_begin(b->G, b->stream, P, b->d_tstops, opt.dtmax, adaptive ? opt.dt0 : opt.fixed_dt);
+  launch_begin(b->G, b->stream, P, b->d_tstops, opt.dtmax, adaptive ? opt.dt0 : (euler ? 1.0 : opt.fixed_dt));
   int nact = b->G;
   HIPCHK(hipMemcpyAsync(b->d_nactive, &nact, sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipGetLastError());
 
-  const int scheme = pick_scheme(b, opt.scheme);
+  const int scheme = euler ? 3 : pick_scheme(b, opt.scheme);
   CtrlArgs C{};
   C.tstops = b->d_tstops; C.n_stops = n_stops; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
   C.dtmax = opt.dtmax; C.adaptive = adaptive ? 1 : 0; C.fixed_dt = opt.fixed_dt; C.n_active = b->d_nactive;
@@ -602,6 +612,13 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   PostArgs A{};
   A.snaps = b->d_snaps; A.premb = b->d_premb; A.ntot = b->ntot; A.mb0 = b->d_mb0;
   A.Sref = b->any_sref ? b->d_Sref : nullptr;
+  if (euler) {  // priming launch: dt = 0, measures max D(u0) and sets the first step
+    C.cfl = opt.cfl; C.cfl_prime = 1; C.next_cur = 0;
+    launch_set_dt(b->G, b->stream, P, 0.0);
+    launch_euler_cfl(b, P, b->lawdev(), b->d_U[0], b->d_U[1]);
+    launch_controller(b->G, b->stream, P, C);
+    C.cfl_prime = 0;
+  }
   // steps between host polls of the active-glacier counter: at least one step per stop is needed, so
   // the first batch is n_stops-1 steps (short solves that land on a stop every step finish with one
   // poll and no wasted launches); afterwards 16, with parity kept even for the ping-pong buffers
@@ -610,7 +627,10 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   int chunk = std::max(2, std::min(256, (n_stops - 1 + 1) & ~1));
   while (nact > 0) {
     for (int s = 0; s < chunk; ++s) {
-      if (scheme == 2) {
+      if (scheme == 3) {
+        launch_euler_cfl(b, P, b->lawdev(), b->d_U[p], b->d_U[1 - p]);
+        C.next_cur = 1 - p;
+      } else if (scheme == 2) {
         CHK(launch_fused_step(b, opt.abstol, opt.reltol, opt.dense ? 0 : 1));
         C.next_cur = -1;
       } else {
@@ -635,7 +655,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
     if (stats) {
       stats[g].naccept = gs[g].naccept;
       stats[g].nreject = gs[g].nreject;
-      stats[g].nrhs = 5 * (gs[g].naccept + gs[g].nreject) + nrhs_extra;
+      stats[g].nrhs = (euler ? 1 : 5) * (gs[g].naccept + gs[g].nreject) + nrhs_extra + (euler ? 1 : 0);
       stats[g].t_final = gs[g].t;
       stats[g].dt_last = gs[g].dt;
     }
@@ -1629,6 +1649,16 @@ static int timed_prepare(odinn_batch* b) {
   HIPCHK(hipMemcpyAsync(b->d_tstops, ts.data(), 2 * sizeof(double), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemsetAsync(b->d_mb_flag, 0, 2 * sizeof(int), b->stream));
   HIPCHK(hipMemsetAsync(b->d_mb_slot, 0, 2 * sizeof(int), b->stream));
+  // two identical forward snapshots + reverse-solve state for ODINN_TIMED_ADJ_STAGE2
+  if (b->nstops_alloc < 2) {
+    dfree(b->d_snaps);
+    CHK(dalloc(&b->d_snaps, (size_t)2 * b->ntot));
+    b->nstops_alloc = 2;
+  }
+  HIPCHK(hipMemcpyAsync(b->d_snaps, b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_snaps + b->ntot, b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
+  if (!b->d_adj) { CHK(dalloc(&b->d_adj, b->G)); CHK(dalloc(&b->d_qw, b->G)); }
+  launch_adj_begin(b->G, b->stream, P, b->d_adj, 2, 0.0, 0, 0);
   launch_begin(b->G, b->stream, P, b->d_tstops, 0.0, 1e-6);
   HIPCHK(hipStreamSynchronize(b->stream));
   return ODINN_OK;
@@ -1674,6 +1704,14 @@ static int timed_one(odinn_batch* b, int which, int it) {
       return ODINN_OK;
     }
     case ODINN_TIMED_VJP_THETA: return theta_vjp_launch(b, b->d_U[0], b->d_lam[0], nullptr, -1, false);
+    case ODINN_TIMED_EULER_CFL: launch_euler_cfl(b, P, L, b->d_U[0], b->d_U[1]); return ODINN_OK;
+    case ODINN_TIMED_ADJ_STAGE2: {
+      AdjStageArgs SA{};
+      SA.snaps = b->d_snaps; SA.ntot = b->ntot; SA.adj = b->d_adj; SA.S2 = b->d_S2; SA.S3 = b->d_S3; SA.E = b->d_E;
+      SA.abstol = 1e-8; SA.reltol = 1e-8; SA.src = b->d_lam[0]; SA.dst = b->d_lam[1];
+      launch_adj_stage(b->lm(), 0, 2, b->ntiles, b->stream, P, L, SA);
+      return ODINN_OK;
+    }
     default: return fail(ODINN_ERR_ARG, "unknown timed kernel %d", which);
   }
 }

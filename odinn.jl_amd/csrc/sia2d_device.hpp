@@ -168,6 +168,25 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return s;
 }
 
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) s = fmax(s, red[k]);
+  }
+  return s;
+}
+
 // ---- fast fp64 transcendentals for the activations ---------------------------------------
 // ocml's exp/log1p cost ~140 fp64 instructions each (double-double internals); an MLP node
 // evaluation is dominated by them.  softplus/sigmoid only need exp on (-inf, 0] and log1p on
@@ -752,6 +771,47 @@ __global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __
   }
 }
 
+// =====================================================================================
+// K1b: one explicit-Euler step with a CFL-limited step size (the north star's "CFL" mode;
+// read H,B; write H_new = 24 B per cell-step):  u' = u + dt dH/dt(u), and the
+// tile's max D -- wavefront shuffle -> LDS -> one partial per tile, reduced in fixed order by
+// the controller, which sets the NEXT step to dt = cfl * min(dx,dy)^2 / (4 max D).  dt == 0
+// (priming launch) just measures max D(u0).
+// =====================================================================================
+template <int LM>
+__global__ __launch_bounds__(NT) void k_euler_cfl(Pools P, LawDev L, const double* __restrict__ Usrc,
+                                                  double* __restrict__ Udst) {
+  __shared__ double2 sHS[TY + 2][LDW];
+  __shared__ double sD[TY + 1][LDN];
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  if (gs->done) return;
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const double dt = gs->dt;
+  double own[RPT];
+  load_tile_HS2(Usrc, P.B, g, i0, j0, sHS, own);
+  __syncthreads();
+  nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int gi = i0 + tx;
+  double dmax = 0.0;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+    if (gi < g.nx && gj < g.ny) {
+      double k = 0.0;
+      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs<LM>(g, tx + 1, r, sHS, sD);
+      Udst[g.off + gi + (long long)g.nx * gj] = fma(dt, k, own[m]);
+    }
+    dmax = fmax(dmax, sD[r][tx + 1]);  // the node north-east of the cell (0 where it does not exist)
+  }
+  const double tot = block_max(dmax, red);
+  if (threadIdx.x == 0) P.part[4 * (long long)t4.w] = tot;
+}
+
 // The 3S*+ registers tmp/uprev/utilde are pure streams (read once, written once, no halo):
 // they are accessed with the non-temporal policy so that they do not evict the u/B halo rows
 // other tiles are about to re-read from L2 (+10 % on the HBM-bound stage kernels).
@@ -846,6 +906,8 @@ struct CtrlArgs {
   const double* errpart;  // per-tile error partials: errpart[stride * tile]
   int stride;
   int fused;              // partials are indexed by the fused-step tile table
+  double cfl;             // > 0: explicit Euler with dt = cfl*min(dx,dy)^2/(4 max D); the partials are tile maxima
+  int cfl_prime;          // the launch only measured max D(u0): set the first dt, do not advance
   // reverse (continuous-adjoint) solve only; adj == null in the forward solve.  tstops are then
   // tau = -t ascending, the union of the snapshot times and the Gauss-Legendre nodes.
   AdjState* adj;
@@ -881,11 +943,55 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   double s = 0.0;
   {
     const int t0 = C.fused ? g.tile0F : g.tile0, nt = C.fused ? g.ntilesF : g.ntiles;
-    for (int k = threadIdx.x; k < nt; k += 64) s += C.errpart[(long long)C.stride * (t0 + k)];
+    if (C.cfl > 0.0) {
+      for (int k = threadIdx.x; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
+    } else {
+      for (int k = threadIdx.x; k < nt; k += 64) s += C.errpart[(long long)C.stride * (t0 + k)];
+    }
   }
   // fixed-shape tree: lane l holds sum of tiles l, l+64, ... ; then butterfly
-  s = wave_sum(s);
+  s = C.cfl > 0.0 ? wave_max(s) : wave_sum(s);
   if (threadIdx.x != 0) return;
+  if (C.cfl > 0.0) {
+    // explicit Euler, always accepted; the next dt comes from the max diffusivity just measured
+    if (!(s == s) || isinf(s)) gs->nonfinite = 1;
+    double t = gs->t;
+    gs->at_stop = 0;
+    gs->mb_now = 0;
+    gs->EEst = s;
+    if (!C.cfl_prime) {
+      gs->naccept++;
+      gs->accepted = 1;
+      gs->cur = C.next_cur;
+      if (gs->clipped) {
+        t = C.tstops[gs->istop];
+        gs->at_stop = 1;
+        gs->mb_now = C.mb_flag[gs->istop];
+        gs->mb_slot = C.mb_slot[gs->istop];
+        gs->istop++;
+      } else {
+        t += gs->dt;
+      }
+      gs->t = t;
+      if (gs->istop >= C.n_stops) {
+        gs->done = 1;
+        atomicSub(C.n_active, 1);
+        return;
+      }
+    }
+    const double dmin = fmin(g.dx, g.dy);
+    const double rem = C.tstops[gs->istop] - t;
+    double dtn = s > 0.0 ? C.cfl * dmin * dmin / (4.0 * s) : rem;
+    if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
+    if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
+      dtn = rem;
+      gs->clipped = 1;
+    } else {
+      gs->clipped = 0;
+    }
+    gs->dt = dtn;
+    return;
+  }
   const double h = gs->dt;
   double fac = 1.0;
   bool accept = true;
@@ -1783,6 +1889,11 @@ __global__ void k_begin(Pools P, int n, const double* tstops, double dtmax, doub
   gs->naccept = 0; gs->nreject = 0; gs->nonfinite = 0;
 }
 
+
+__global__ void k_set_dt(Pools P, int n, double dt) {
+  const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx < n) P.gs[gidx].dt = dt;
+}
 
 // ---- continuous adjoint: reverse-solve bookkeeping --------------------------------------
 // start of the reverse solve: the glacier sits on stop 0 (tau_0 = -t_{k-1}, the last snapshot), marked

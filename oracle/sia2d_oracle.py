@@ -890,6 +890,47 @@ def solve(
     return snaps, st, cb_inc
 
 
+def max_diffusivity(H, B, dx, dy, ph: Phys, law: Law, theta=None):
+    """max over the dual grid of D(H) (the quantity that bounds an explicit diffusion step)."""
+    Hc, S, gSx, gSy, gS, Hbar, ex, ey, exc, eyc = _forward_intermediates(H, B, dx, dy, ph)
+    return float(np.max(diffusivity(law, ph, Hbar, gS, theta)))
+
+
+def solve_euler_cfl(gl: Glacier, law: Law, tstops, cfl=0.25, dtmax=np.inf, theta=None, callback=None,
+                    callback_times=()):
+    """Explicit Euler with the CFL-limited step dt_n = cfl*min(dx,dy)^2/(4 max D(u_{n-1})) -- the max
+    diffusivity of the PREVIOUS state, u_{-1} := u_0 (the device measures max D in the pass that
+    advances the state) -- clipped to tstops with the same 100-ulp snapping as `solve`.
+    NOT a reference scheme (the reference integrates with OrdinaryDiffEq only): own definition of
+    the north star's "CFL" mode, restated here so that the HIP kernel has something to match."""
+    tstops = [float(t) for t in tstops]
+    cbt = set(float(t) for t in callback_times)
+    f = lambda H: sia2d_rhs(H, gl.B, gl.dx, gl.dy, gl.phys, law, theta)
+    dmin = min(gl.dx, gl.dy)
+    t = tstops[0]
+    u = np.array(gl.H0, F, copy=True)
+    snaps = [u.copy()]
+    nsteps = 0
+    Dmax = max_diffusivity(u, gl.B, gl.dx, gl.dy, gl.phys, law, theta)
+    for ts in tstops[1:]:
+        while t < ts:
+            rem = ts - t
+            h = cfl * dmin * dmin / (4.0 * Dmax) if Dmax > 0.0 else rem
+            h = min(h, dtmax)
+            clipped = h >= rem or abs(rem - h) <= 100.0 * np.finfo(F).eps * abs(t)
+            if clipped:
+                h = rem
+            Dnew = max_diffusivity(u, gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # measured on the state being advanced
+            u = u + h * f(u)
+            Dmax = Dnew
+            t = ts if clipped else t + h
+            nsteps += 1
+        if callback is not None and ts in cbt:
+            u = callback(u, ts)
+        snaps.append(u.copy())
+    return snaps, nsteps
+
+
 # ----------------------------------------------------------------------------
 # Forward simulation of one glacier + loss (batch_loss_iceflow_transient,
 # inversion_utils.jl:383-461) and the discrete adjoint (gradient.jl:129-275)

@@ -31,7 +31,8 @@ def test_struct_layouts_match_the_header(odinn):
     assert ctypes.sizeof(L.GlacierDesc) == 8 + 16 + 72 + 16
     assert ctypes.sizeof(L.MlpDesc) == 4 * (1 + 9 + 8 + 1) + 4 + 32 + 8 + 16
     assert L.MlpDesc.pre_lo.offset == 80 and L.MlpDesc.post_lo.offset == 120
-    assert ctypes.sizeof(L.SolverOpts) == 56 and ctypes.sizeof(L.SolveStats) == 40
+    assert ctypes.sizeof(L.SolverOpts) == 64 and L.SolverOpts.cfl.offset == 56 and ctypes.sizeof(L.SolveStats) == 40
+    assert ctypes.sizeof(L.AdjointOpts) == 40 and L.AdjointOpts.maxiters.offset == 32
 
 
 def test_no_silent_cpu_fallback(odinn):
