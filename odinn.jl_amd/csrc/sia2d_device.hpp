@@ -538,62 +538,8 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
 }
 
 // ---- tile geometry -------------------------------------------------------------------
-// Load the (TX+2)x(TY+2) halo tile of src (clamped at 0) and S = B + max(src,0) into LDS.
+// Load the (TX+2)x(TY+2) halo tile of U into LDS, interleaved: sHS[r][c] = {max(U,0), B + max(U,0)}.
 // Thread (tx, ty) owns interior rows r = 1 + ty + NW*m and keeps their raw values in own[].
-__device__ __forceinline__ void load_tile_HS(const double* __restrict__ U, const double* __restrict__ B, const GDev& g,
-                                             int i0, int j0, double (*sH)[LDW], double (*sS)[LDW],
-                                             double own[RPT]) {
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int gi = i0 + tx;
-  const bool colok = gi < g.nx;
-#pragma unroll
-  for (int m = 0; m < RPT; ++m) {
-    const int r = 1 + ty + NW * m;
-    const int gj = j0 - 1 + r;
-    double h = 0.0, b = 0.0;
-    if (colok && gj < g.ny) {
-      const long long id = g.off + gi + (long long)g.nx * gj;
-      h = U[id];
-      b = B[id];
-    }
-    own[m] = h;
-    const double hc = h > 0.0 ? h : 0.0;
-    sH[r][tx + 1] = hc;
-    sS[r][tx + 1] = b + hc;
-  }
-  // halo rows 0 and TY+1 (waves 0 and 1), halo columns 0 and TX+1 (waves 2 and 3)
-  if (ty < 2) {
-    const int r = ty == 0 ? 0 : TY + 1;
-    const int gj = j0 - 1 + r;
-    double h = 0.0, b = 0.0;
-    if (colok && gj >= 0 && gj < g.ny) {
-      const long long id = g.off + gi + (long long)g.nx * gj;
-      h = U[id];
-      b = B[id];
-    }
-    const double hc = h > 0.0 ? h : 0.0;
-    sH[r][tx + 1] = hc;
-    sS[r][tx + 1] = b + hc;
-  } else {
-    const int l = threadIdx.x - 128;  // 0..127
-    if (l < 2 * (TY + 2)) {
-      const int r = l >> 1, side = l & 1;
-      const int c = side ? TX + 1 : 0;
-      const int gi2 = i0 - 1 + c, gj = j0 - 1 + r;
-      double h = 0.0, b = 0.0;
-      if (gi2 >= 0 && gi2 < g.nx && gj >= 0 && gj < g.ny) {
-        const long long id = g.off + gi2 + (long long)g.nx * gj;
-        h = U[id];
-        b = B[id];
-      }
-      const double hc = h > 0.0 ? h : 0.0;
-      sH[r][c] = hc;
-      sS[r][c] = b + hc;
-    }
-  }
-}
-
-// Interleaved variant for the forward kernels: sHS[r][c] = {max(U,0), B + max(U,0)}.
 template <int NWV = NW, int TYV = TY>
 __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, const double* __restrict__ B, const GDev& g,
                                               int i0, int j0, double2 (*sHS)[LDW], double (&own)[TYV / NWV],
@@ -1174,18 +1120,6 @@ struct AdjArgs {
   const AdjState* adj;
 };
 
-#ifndef ODINN_NTA
-#define ODINN_NTA 256
-#endif
-#ifndef ODINN_TYA
-#define ODINN_TYA 8
-#endif
-constexpr int NTA = ODINN_NTA;   // threads per block of k_vjp_H
-constexpr int NWA = NTA / 64;
-constexpr int TYA = ODINN_TYA;   // k_vjp_H works on 64 x TYA sub-tiles (TY/TYA blocks per table tile): its
-constexpr int NHALF = TY / TYA;  // seven LDS arrays then fit 4 blocks/CU instead of 2
-constexpr int RPTA = TYA / NWA;
-constexpr int NNODEA = (TX + 1) * (TYA + 1);
 // One dual node of k_vjp_H: what node (a,b) of the tile contributes to the VJP of its four corner
 // cells {SW, SE, NW, NE} -- the diffusivity term (adjoint.jl:123-127) AND its share D_node of the
 // clamp/flux term of its four edges (adjoint.jl:130-144, inversion_utils.jl:22-43); the clamped
