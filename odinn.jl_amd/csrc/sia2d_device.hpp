@@ -1402,17 +1402,30 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_
     load_tile_HS2(Ha, P.B, g, i0, j0, VjpHLds<LM, VJ>::hs(smem), ownH, Ha + A.ntot, a.sitp[STAGE - 1]);
   }
   load_tile_lam<NW, TY, VJ == 0>(X, g, i0, j0, VjpHLds<LM, VJ>::lam(smem), ownL);
-  __syncthreads();
-  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int gi = i0 + tx;
-  constexpr int s = STAGE - 1;
-  constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
-  double errsq = 0.0;
   double* __restrict__ Udst = A.dst;
   double* __restrict__ S2 = A.S2;
   double* __restrict__ S3 = A.S3;
   double* __restrict__ E = A.E;
+  // the 3S*+ stream registers are fetched now so that their latency hides behind the stencil work
+  double pup[RPT], ptm[RPT], pe[RPT];
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = j0 + ty + NW * m;
+    pup[m] = ptm[m] = pe[m] = 0.0;
+    if (STAGE > 1 && gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      if (STAGE == 2 || STAGE >= 4) pup[m] = __builtin_nontemporal_load(&S3[id]);
+      if (STAGE != 2) ptm[m] = __builtin_nontemporal_load(&S2[id]);
+      pe[m] = __builtin_nontemporal_load(&E[id]);
+    }
+  }
+  __syncthreads();
+  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
+  constexpr int s = STAGE - 1;
+  constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
+  double errsq = 0.0;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
     const int gj = j0 + ty + NW * m;
@@ -1425,14 +1438,14 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_
         if (gs->accepted) __builtin_nontemporal_store(u, &S3[id]);
         __builtin_nontemporal_store(bh * dtk, &E[id]);
       } else {
-        const double up = (STAGE == 2 || STAGE >= 4) ? __builtin_nontemporal_load(&S3[id]) : 0.0;
-        const double tmp_old = (STAGE == 2) ? up : __builtin_nontemporal_load(&S2[id]);
+        const double up = pup[m];
+        const double tmp_old = (STAGE == 2) ? up : ptm[m];
         const double tmp = fma(dl, u, tmp_old);
         double un = fma(g1, u, g2 * tmp);
         if (STAGE >= 4) un = fma(g3, up, un);
         un = fma(bt, dtk, un);
         Udst[id] = un;
-        const double e = fma(bh, dtk, __builtin_nontemporal_load(&E[id]));
+        const double e = fma(bh, dtk, pe[m]);
         if (STAGE < 5) {
           if (dl != 0.0) __builtin_nontemporal_store(tmp, &S2[id]);
           __builtin_nontemporal_store(e, &E[id]);
