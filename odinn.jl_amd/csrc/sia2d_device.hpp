@@ -37,21 +37,21 @@ constexpr int LDN = TX + 1;    // LDS row stride of node tiles
 constexpr int NNODE = (TX + 1) * (TY + 1);
 constexpr int MAXP = 2048;     // max #theta supported by the in-kernel reductions
 constexpr int MAXL = 8;        // max Dense layers
-// fused-step kernel geometry (sia2d_fused.hpp)
+// fused-step kernel geometry (sia2d_fused.hpp): the halo REGION of a workgroup is exactly one
+// wavefront wide, so a wavefront owns whole region rows (row index wave-uniform, column = lane)
 constexpr int FH = 5;                 // halo = number of stages
 #ifndef ODINN_FOY
-#define ODINN_FOY 32
+#define ODINN_FOY 40                  // 64 x 50 region: 78 KB of LDS, 2 workgroups / CU
 #endif
 #ifndef ODINN_FNT
 #define ODINN_FNT 512
 #endif
-constexpr int FOX = 64, FOY = ODINN_FOY;  // output tile
-constexpr int FRX = FOX + 2 * FH;     // 74
-constexpr int FRY = FOY + 2 * FH;     // 42
+constexpr int FRX = 64;               // region width = one wavefront
+constexpr int FOX = FRX - 2 * FH, FOY = ODINN_FOY;  // 54 x FOY output tile
+constexpr int FRY = FOY + 2 * FH;     // region height
 constexpr int FNT = ODINN_FNT;        // threads per block
 constexpr int FNW = FNT / 64;
-constexpr int FNC = FRX * FRY;        // 3108 region cells
-constexpr int FCPT = (FNC + FNT - 1) / FNT;  // 7 cells per thread
+constexpr int FSLOT = (FRY + FNW - 1) / FNW;  // region rows per wavefront
 constexpr int FLD = FRX + 1;          // LDS row stride (odd)
 
 
@@ -148,6 +148,34 @@ struct Pools {  // pooled device arrays (all glaciers concatenated)
 };
 
 // ---- small helpers ------------------------------------------------------------------
+// One-instruction min/max for the clamp stencils.  fmin/fmax lower to llvm.minnum/maxnum, for which
+// the compiler (IEEE mode) first canonicalises every operand that comes from memory with an extra
+// v_max_f64 x,x,x -- 9 % of the VALU work of the step kernel.  No NaN reaches these sites (a NaN
+// state is caught by the error norm), and for non-NaN operands the results are identical.
+__device__ __forceinline__ double vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max(a, -b) and max(a, 0) with the source modifier / inline constant the compiler would have used
+__device__ __forceinline__ double vmax_neg(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmax0(double a) {
+  double r;
+  asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(a));
+  return r;
+}
+// clamp of a slope between -lom and up: max(min(e, up), -lom)   (inversion_utils.jl:17-20,31-34)
+__device__ __forceinline__ double clampn(double e, double up, double lom) { return vmax_neg(vmin(e, up), lom); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -560,7 +588,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
       b = B[id];
     }
     own[m] = h;
-    const double hc = h > 0.0 ? h : 0.0;
+    const double hc = vmax0(h);
     sHS[r][tx + 1] = make_double2(hc, b + hc);
   }
   if (ty < 2) {
@@ -573,7 +601,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
       if (U2) h = fma(sw, U2[id] - h, h);
       b = B[id];
     }
-    const double hc = h > 0.0 ? h : 0.0;
+    const double hc = vmax0(h);
     sHS[r][tx + 1] = make_double2(hc, b + hc);
   } else if (ty < 4) {
     const int l = threadIdx.x - 128;
@@ -588,7 +616,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
         if (U2) h = fma(sw, U2[id] - h, h);
         b = B[id];
       }
-      const double hc = h > 0.0 ? h : 0.0;
+      const double hc = vmax0(h);
       sHS[r][c] = make_double2(hc, b + hc);
     }
   }
@@ -649,10 +677,10 @@ __device__ __forceinline__ double cell_div(const GDev& g, const double2* p, cons
   const double e0 = ETA1 ? 1.0 : g.eta0;
   const double S0 = c0.y, eH0 = ETA1 ? c0.x : e0 * c0.x;
   const double Dsw = pD[-LDD - 1], Dse = pD[-LDD], Dnw = pD[-1], Dne = pD[0];
-  const double ce = fmax(fmin(ce_.y - S0, ETA1 ? ce_.x : e0 * ce_.x), -eH0);
-  const double cw = fmax(fmin(S0 - cw_.y, eH0), -(ETA1 ? cw_.x : e0 * cw_.x));
-  const double cn = fmax(fmin(cn_.y - S0, ETA1 ? cn_.x : e0 * cn_.x), -eH0);
-  const double cs = fmax(fmin(S0 - cs_.y, eH0), -(ETA1 ? cs_.x : e0 * cs_.x));
+  const double ce = clampn(ce_.y - S0, ETA1 ? ce_.x : e0 * ce_.x, eH0);
+  const double cw = clampn(S0 - cw_.y, eH0, (ETA1 ? cw_.x : e0 * cw_.x));
+  const double cn = clampn(cn_.y - S0, ETA1 ? cn_.x : e0 * cn_.x, eH0);
+  const double cs = clampn(S0 - cs_.y, eH0, (ETA1 ? cs_.x : e0 * cs_.x));
   const double qx = (Dse + Dne) * ce - (Dsw + Dnw) * cw;
   const double qy = (Dnw + Dne) * cn - (Dsw + Dse) * cs;
   return fma(g.hinv_dx2, qx, g.hinv_dy2 * qy);
@@ -679,7 +707,7 @@ __device__ __forceinline__ void nodes_forward(const GDev& g, const LawDev& L, co
   }
 }
 
-__device__ __forceinline__ double clampf(double e, double up, double lo) { return fmax(fmin(e, up), lo); }
+__device__ __forceinline__ double clampf(double e, double up, double lo) { return vmax(vmin(e, up), lo); }
 
 // dH/dt of the cell at halo coordinates (c, r); caller guarantees the cell is interior.
 template <int LM>
@@ -1091,10 +1119,10 @@ __device__ __forceinline__ double node_Da(const GDev& g, const double2* p, const
   Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
   const double e00 = g.eta0 * c00.x, e10 = g.eta0 * c10.x, e01 = g.eta0 * c01.x, e11 = g.eta0 * c11.x;
   double ax = 0.0, ay = 0.0;
-  if (vxl) ax = (l10 - l00) * fmax(fmin(dxl, e10), -e00);
-  if (vxu) ax = fma(l11 - l01, fmax(fmin(dxu, e11), -e01), ax);
-  if (vyl) ay = (l01 - l00) * fmax(fmin(dyl, e01), -e00);
-  if (vyr) ay = fma(l11 - l10, fmax(fmin(dyr, e11), -e10), ay);
+  if (vxl) ax = (l10 - l00) * clampn(dxl, e10, e00);
+  if (vxu) ax = fma(l11 - l01, clampn(dxu, e11, e01), ax);
+  if (vyl) ay = (l01 - l00) * clampn(dyl, e01, e00);
+  if (vyr) ay = fma(l11 - l10, clampn(dyr, e11, e10), ay);
   return -fma(g.hinv_dx2, ax, g.hinv_dy2 * ay);
 }
 
@@ -1141,8 +1169,8 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
   // lambda differences along the four edges (0 on edges that do not exist)
   const double qxl = gj >= 1 ? l10 - l00 : 0.0, qxu = gj + 1 <= g.ny - 2 ? l11 - l01 : 0.0;
   const double qyl = gi >= 1 ? l01 - l00 : 0.0, qyr = gi + 1 <= g.nx - 2 ? l11 - l10 : 0.0;
-  const double ax = fma(qxu, fmax(fmin(dxu, e11), -e01), qxl * fmax(fmin(dxl, e10), -e00));
-  const double ay = fma(qyr, fmax(fmin(dyr, e11), -e10), qyl * fmax(fmin(dyl, e01), -e00));
+  const double ax = fma(qxu, clampn(dxu, e11, e01), qxl * clampn(dxl, e10, e00));
+  const double ay = fma(qyr, clampn(dyr, e11, e10), qyl * clampn(dyl, e01, e00));
   const double Da = -fma(g.hinv_dx2, ax, g.hinv_dy2 * ay);
   double An = g.A;
   if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
