@@ -159,7 +159,7 @@ def main():
         "euler_cfl_cellsteps_per_s": cells * world / (ms_cfl * 1e-3),
         "euler_cfl_note": "explicit Euler with CFL-limited dt (scheme 3): ONE cell-step per cell per launch, 24 B per cell-step",
         "adj_stage2_ms": ms_adj,
-        "adj_stage2_GBs": 88.0 * cells / (ms_adj * 1e-3) / 1e9,
+        "adj_stage2_GBs": 72.0 * cells / (ms_adj * 1e-3) / 1e9,
         "vjp_theta_ms": ms_vjpt,
         "vjp_theta_GBs": 24.0 * cells / (ms_vjpt * 1e-3) / 1e9,
     }
