@@ -148,6 +148,9 @@ struct Pools {  // pooled device arrays (all glaciers concatenated)
 };
 
 // ---- small helpers ------------------------------------------------------------------
+// index of this wavefront in its workgroup, as a SCALAR: rows of a tile are dealt to wavefronts, so
+// row indices, row predicates and the row part of every address then live in SGPRs / SALU
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 // One-instruction min/max for the clamp stencils.  fmin/fmax lower to llvm.minnum/maxnum, for which
 // the compiler (IEEE mode) first canonicalises every operand that comes from memory with an extra
 // v_max_f64 x,x,x -- 9 % of the VALU work of the step kernel.  No NaN reaches these sites (a NaN
@@ -573,7 +576,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
                                               int i0, int j0, double2 (*sHS)[LDW], double (&own)[TYV / NWV],
                                               const double* __restrict__ U2 = nullptr, double sw = 0.0) {
   // U2 != null: the field is U + sw (U2 - U)  (H_itp of the continuous adjoint, gradient.jl:287)
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   const bool colok = gi < g.nx;
 #pragma unroll
@@ -627,7 +630,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
 template <int NWV = NW, int TYV = TY, bool MASK = true>
 __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, const GDev& g, int i0, int j0,
                                               double (*sL)[LDW], double (&own)[TYV / NWV]) {
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   auto ld = [&](int gi_, int gj_, double& raw) -> double {
     raw = 0.0;
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __
   __syncthreads();
   nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
   __syncthreads();
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
@@ -769,7 +772,7 @@ __global__ __launch_bounds__(NT) void k_euler_cfl(Pools P, LawDev L, const doubl
   __syncthreads();
   nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
   __syncthreads();
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   double dmax = 0.0;
 #pragma unroll
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
   __syncthreads();
   nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
   __syncthreads();
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   constexpr int s = STAGE - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
@@ -1079,7 +1082,7 @@ __global__ __launch_bounds__(NT) void k_poststep(Pools P, PostArgs A, double* __
   const GDev g = P.gd[t4.x];
   double* __restrict__ U = gs->cur ? Ub : Ua;
   const int i0 = t4.y * TX, j0 = t4.z * TY;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   const int slot = gs->istop - 1;
 #pragma unroll
@@ -1264,7 +1267,7 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
   double2* cbase = S::ALIAS ? smem : smem + S::A_D2;
   double2(*sCa)[LDN] = reinterpret_cast<double2(*)[LDN]>(cbase);                    // {SW, SE}
   double2(*sCb)[LDN] = reinterpret_cast<double2(*)[LDN]>(cbase + (TY + 1) * LDN);   // {NW, NE}
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   // the 65th column and 17th row of nodes: wavefront 0 takes the row, wavefront 1 the column
   const int ea = ty == 0 ? tx : TX, eb = ty == 0 ? TY : tx;
   const bool extra = ty == 0 || (ty == 1 && tx <= TY);
@@ -1358,7 +1361,7 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_
   load_tile_lam<NW, TY, VJ == 0>(A.lam, g, i0, j0, VjpHLds<LM, VJ>::lam(smem), ownL);
   __syncthreads();
   vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   double dt = 1.0, w = 0.0;
   long long roff = 0;
@@ -1430,7 +1433,7 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_
     load_tile_HS2(Ha, P.B, g, i0, j0, VjpHLds<LM, VJ>::hs(smem), ownH, Ha + A.ntot, a.sitp[STAGE - 1]);
   }
   load_tile_lam<NW, TY, VJ == 0>(X, g, i0, j0, VjpHLds<LM, VJ>::lam(smem), ownL);
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   double* __restrict__ Udst = A.dst;
   double* __restrict__ S2 = A.S2;
@@ -1530,7 +1533,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   load_tile_HS2(A.H, P.B, g, i0, j0, sHS, ownH);
   load_tile_lam(A.lam, g, i0, j0, sL, ownL);
   __syncthreads();
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   double acc = 0.0;
   const long long gstride = (long long)gridDim.x * NT;
   double* gth = A.gscratch ? A.gscratch + ((long long)blockIdx.x * NT + threadIdx.x) : nullptr;
@@ -1631,7 +1634,7 @@ __global__ __launch_bounds__(NT) void k_loss(Pools P, const double* __restrict__
   const int4 t4 = P.tiles[blockIdx.x];
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   const double w = ws[t4.x];
   double s = 0.0;
@@ -1657,7 +1660,7 @@ __global__ __launch_bounds__(NT) void k_mb_vjp(Pools P, const double* __restrict
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
@@ -1685,7 +1688,7 @@ __global__ __launch_bounds__(NT) void k_mb_apply(Pools P, const double* __restri
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
@@ -1772,7 +1775,7 @@ __global__ __launch_bounds__(NT) void k_axpy_g(Pools P, const double* __restrict
   const GDev g = P.gd[t4.x];
   const double a = P.gs[t4.x].dt;
   const int i0 = t4.y * TX, j0 = t4.z * TY;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
@@ -1791,7 +1794,7 @@ __global__ __launch_bounds__(NT) void k_initdt_norms(Pools P, const double* __re
   const int4 t4 = P.tiles[blockIdx.x];
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -1909,7 +1912,7 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
   const AdjState a = A.adj[t4.x];
   double* __restrict__ U = gs->cur ? Ub : Ua;
   const int i0 = t4.y * TX, j0 = t4.z * TY;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
   double w = 0.0;

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta_nn(Pools P, LawDev L, ThArgs A
   load_tile_lam(A.lam, g, i0, j0, sL, ownL);
   if (threadIdx.x == 0) any_active = 0;
   __syncthreads();
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   double wgt[RPT], x0[RPT], x1[RPT];
   bool act = false;
 #pragma unroll

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NT) void k_surface_V(Pools P, const double* __restr
   double own[RPT];
   load_tile_HS2(U, P.B, g, i0, j0, sHS, own);
   __syncthreads();
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
     sQ[b][a] = make_double2(Qx, Qy);
   }
   __syncthreads();
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx, c = tx + 1;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
