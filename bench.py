@@ -84,12 +84,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # ODINN_BENCH_BACKEND=gloo ODINN_BENCH_DEVICE=0: dry run of the N > 1 path on a ONE-GPU box (every rank
+    # on device 0, collectives over gloo); the driver's runs use the defaults: RCCL, one GPU per rank
+    backend = os.environ.get("ODINN_BENCH_BACKEND", "nccl")
+    if "ODINN_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["ODINN_BENCH_DEVICE"])
+    red_dev = f"cuda:{local}" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-        odinn.api._DIST.update(init=True, rank=rank, world=world, local=local, device=f"cuda:{local}")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        odinn.api._DIST.update(init=True, rank=rank, world=world, local=local, device=red_dev)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if odinn.device_count() < 1:
@@ -120,7 +126,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         dist.barrier()
