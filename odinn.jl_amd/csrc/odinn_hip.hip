@@ -764,7 +764,7 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   CHK(dalloc(&b->d_tiles_nat, nat.size()));
   HIPCHK(hipMemcpy(b->d_tiles, swz.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->d_tiles_nat, nat.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
-  {  // tile table of the fused-step kernel (64x32 output tiles), same XCD-banded order
+  {  // tile table of the fused-step kernel (FOX x FOY output tiles), same XCD-banded order
     std::vector<int4> natF;
     for (int g = 0; g < n_glaciers; ++g) {
       GDev& r = b->gd[g];

@@ -7,11 +7,13 @@
 //
 //   * one fused kernel per RHS evaluation / RK stage / VJP: a 64x16-cell tile (+1 halo)
 //     of H and S=B+max(H,0) is staged once through LDS with coalesced 512-B row loads;
-//     every dual-grid quantity (grad S, Hbar, D, and for the adjoint alpha*Da,
-//     beta*gradS*Da) is evaluated ONCE per dual node into LDS -- a node depends only on
-//     its own 2x2 corner cells -- and every primal cell then gathers from its 4 nodes
-//     and its 5-point neighbourhood.  All transposes are written in gather form, so the
-//     adjoint needs no atomics and is bitwise deterministic.
+//     every dual-grid quantity (grad S, Hbar, D) is evaluated ONCE per dual node into LDS
+//     -- a node depends only on its own 2x2 corner cells -- and every primal cell then
+//     gathers from its 4 nodes and its 5-point neighbourhood.  In the H-VJP each node
+//     computes what it contributes to its four corner cells and a cell adds four numbers.
+//     No transpose is a scatter: the adjoint needs no atomics and is bitwise deterministic.
+//   * the default time step is ONE kernel (sia2d_fused.hpp: the five RDPK3Sp35 stages
+//     temporally fused on a 64-wide halo region kept in LDS / registers).
 //   * all glaciers of a batch run in ONE launch: a tile table maps blockIdx -> (glacier,
 //     tile), XCD-swizzled so that the tiles one XCD's L2 sees form a contiguous band.
 //   * the adaptive time loop (RDPK3Sp35 3S*+ registers, embedded error norm, PID step
@@ -90,7 +92,7 @@ constexpr double c_cc[5] = {0.0, 2.300298624518076223899418286314123354e-01,
 // ---- records living in device memory ------------------------------------------------
 struct GDev {  // per-glacier constants
   int nx, ny, ntx, nty, tile0, ntiles;
-  int tile0F, ntilesF;  // range in the fused-step tile table (64x32 output tiles)
+  int tile0F, ntilesF;  // range in the fused-step tile table (FOX x FOY output tiles)
   long long off;   // offset of this glacier in the pooled primal arrays  [doubles]
   long long offd;  // offset in the pooled dual arrays
   double dx, dy, inv_dx, inv_dy, eta0;
@@ -1130,8 +1132,8 @@ __device__ __forceinline__ double node_Da(const GDev& g, const double2* p, const
 }
 
 // =====================================================================================
-// K5: discrete H-VJP (adjoint.jl:99-148) in gather form, optionally fused with the
-// reverse explicit-Euler update of gradient.jl:242:
+// K5: H-VJP (DiscreteVJP adjoint.jl:99-148, or ContinuousVJP :442-553) in node->corner form,
+// optionally fused with the reverse explicit-Euler update of gradient.jl:242:
 //     out = lam + dt * J_H(H)^T lam + w * 2*mask*(H - Href)/N          (MODE 1)
 //     out = J_H(H)^T lam                                               (MODE 0)
 // and the masked L2 loss partial (Losses.jl:133-141) as a by-product in MODE 1.
