@@ -261,7 +261,11 @@ template <class T>
 int dalloc(T** p, size_t n) {
   if (n == 0) n = 1;
   HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  // hipMemset on device memory is asynchronous on the NULL stream, with which the batch's non-blocking
+  // stream does not synchronise: without the wait the zero fill can land AFTER the first
+  // hipMemcpyAsync into the new buffer (seen as an all-zero tstops table, 1 run in ~15)
   HIPCHK(hipMemset(*p, 0, n * sizeof(T)));
+  HIPCHK(hipStreamSynchronize(nullptr));
   return ODINN_OK;
 }
 template <class T>
@@ -936,6 +940,7 @@ int odinn_set_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, c
     if (b->d_Href) {
       HIPCHK(hipMemcpy(nh, b->d_Href, (size_t)b->nref_alloc * b->ntot * sizeof(double), hipMemcpyDeviceToDevice));
       HIPCHK(hipMemcpy(nm, b->d_mask, (size_t)b->nref_alloc * b->ntot, hipMemcpyDeviceToDevice));
+      HIPCHK(hipStreamSynchronize(nullptr));  // D2D copies on the NULL stream do not block the host
     }
     dfree(b->d_Href); dfree(b->d_mask);
     b->d_Href = nh; b->d_mask = nm; b->nref_alloc = n_ref;
@@ -1103,6 +1108,7 @@ int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double*
       HIPCHK(hipMemcpy(na, b->d_Vabs, ob, hipMemcpyDeviceToDevice));
       HIPCHK(hipMemcpy(nx_, b->d_Vxr, ob, hipMemcpyDeviceToDevice));
       HIPCHK(hipMemcpy(ny_, b->d_Vyr, ob, hipMemcpyDeviceToDevice));
+      HIPCHK(hipStreamSynchronize(nullptr));  // D2D copies on the NULL stream do not block the host
     }
     dfree(b->d_Vabs); dfree(b->d_Vxr); dfree(b->d_Vyr);
     b->d_Vabs = na; b->d_Vxr = nx_; b->d_Vyr = ny_; b->nvref_alloc = n_ref;
