@@ -66,8 +66,8 @@ def make_glacier(n, gidx, dx=100.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--glaciers-per-gpu", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
