@@ -1361,17 +1361,36 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_
     load_tile_HS2(A.H, P.B, g, i0, j0, VjpHLds<LM, VJ>::hs(smem), ownH);
   }
   load_tile_lam<NW, TY, VJ == 0>(A.lam, g, i0, j0, VjpHLds<LM, VJ>::lam(smem), ownL);
-  __syncthreads();
-  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
   const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   double dt = 1.0, w = 0.0;
   long long roff = 0;
+  // loss data of this thread's cells (MODE 1 at a data stop), fetched before the stencil phase so
+  // that its latency hides behind it: hd[m] = H - Href where the mask is set, else 0
+  double hd[RPT];
+  bool hm[RPT];
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) { hd[m] = 0.0; hm[m] = false; }
   if (MODE == 1) {
     dt = A.dts[t4.x];
     w = A.ws ? A.ws[t4.x] : 0.0;
-    if (w != 0.0) roff = (long long)A.refslot[t4.x] * A.ntot;
+    if (w != 0.0) {
+      roff = (long long)A.refslot[t4.x] * A.ntot;
+#pragma unroll
+      for (int m = 0; m < RPT; ++m) {
+        const int gj = j0 + ty + NW * m;
+        if (gi < g.nx && gj < g.ny) {
+          const long long id = g.off + gi + (long long)g.nx * gj;
+          if (A.mask[roff + id]) {
+            hm[m] = true;
+            hd[m] = ownH[m] - A.Href[roff + id];
+          }
+        }
+      }
+    }
   }
+  __syncthreads();
+  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
   const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
   double lsum = 0.0;
 #pragma unroll
@@ -1383,10 +1402,9 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_
         A.out[id] = v[m];
       } else {
         double o = fma(dt, v[m], ownL[m]);
-        if (w != 0.0 && A.mask[roff + id]) {
-          const double d = ownH[m] - A.Href[roff + id];
-          o = fma(w * 2.0 * Ninv, d, o);
-          lsum = fma(d, d, lsum);
+        if (hm[m]) {
+          o = fma(w * 2.0 * Ninv, hd[m], o);
+          lsum = fma(hd[m], hd[m], lsum);
         }
         A.out[id] = o;
       }
