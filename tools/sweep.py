@@ -9,7 +9,8 @@ from bench import make_glacier
 T = odinn._lib
 names = {T.TIMED_DHDT: ("dhdt", 24), T.TIMED_RK_STAGE2: ("stage2", 56), T.TIMED_RK_STEP: ("rkstep", 264),
          T.TIMED_SOLVE_STEP_STAGED: ("solvestep_staged", 264), T.TIMED_FUSED_STEP: ("fusedstep", 24),
-         T.TIMED_SOLVE_STEP: ("solvestep", 24), T.TIMED_VJP_H: ("vjpH", 32), T.TIMED_VJP_THETA: ("vjpTh", 24)}
+         T.TIMED_SOLVE_STEP: ("solvestep", 24), T.TIMED_VJP_H: ("vjpH", 32), T.TIMED_VJP_THETA: ("vjpTh", 24),
+         T.TIMED_EULER_CFL: ("eulercfl", 24), T.TIMED_ADJ_STAGE2: ("adjstage2", 72)}
 cfgs = [(1, 128), (1, 256), (1, 512), (1, 1024), (1, 2048), (8, 1024), (64, 128), (16, 512)]
 if len(sys.argv) > 1:
     cfgs = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
