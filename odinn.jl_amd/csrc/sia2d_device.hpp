@@ -1345,6 +1345,28 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
   }
 }
 
+// Barrier (the tiles are complete) + vjpH_tile, or the exact shortcut v = 0 when no own cell of the
+// tile carries ice (DiscreteVJP only: its result is masked by the cell's own H > 0).  Returns whether
+// the stencil ran.
+template <int LM, int VJ>
+__device__ __forceinline__ bool vjpH_tile_or_zero(const GDev& g, const LawDev& L, const Pools& P, double2* smem, int i0,
+                                                  int j0, const double (&ownH)[RPT], double (&v)[RPT]) {
+  if constexpr (VJ == 0) {
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) any = any || ownH[m] > 0.0;
+    if (!__syncthreads_or(any)) {
+#pragma unroll
+      for (int m = 0; m < RPT; ++m) v[m] = 0.0;
+      return false;
+    }
+  } else {
+    __syncthreads();
+  }
+  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
+  return true;
+}
+
 template <int MODE, int LM, int VJ = 0>
 __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
   __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
@@ -1389,8 +1411,9 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_
       }
     }
   }
-  __syncthreads();
-  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
+  // DiscreteVJP: the result is masked by H > 0 of the cell itself (adjoint.jl:148), so a tile whose own
+  // cells are all ice-free yields exactly 0 whatever its nodes would contribute: skip the stencil
+  vjpH_tile_or_zero<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
   const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
   double lsum = 0.0;
 #pragma unroll
@@ -1472,8 +1495,7 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_
       pe[m] = __builtin_nontemporal_load(&E[id]);
     }
   }
-  __syncthreads();
-  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
+  vjpH_tile_or_zero<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
   constexpr int s = STAGE - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
   double errsq = 0.0;
