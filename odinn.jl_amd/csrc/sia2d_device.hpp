@@ -574,10 +574,12 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
 // Load the (TX+2)x(TY+2) halo tile of U into LDS, interleaved: sHS[r][c] = {max(U,0), B + max(U,0)}.
 // Thread (tx, ty) owns interior rows r = 1 + ty + NW*m and keeps their raw values in own[].
 template <int NWV = NW, int TYV = TY>
-__device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, const double* __restrict__ B, const GDev& g,
+__device__ __forceinline__ bool load_tile_HS2(const double* __restrict__ U, const double* __restrict__ B, const GDev& g,
                                               int i0, int j0, double2 (*sHS)[LDW], double (&own)[TYV / NWV],
                                               const double* __restrict__ U2 = nullptr, double sw = 0.0) {
-  // U2 != null: the field is U + sw (U2 - U)  (H_itp of the continuous adjoint, gradient.jl:287)
+  // U2 != null: the field is U + sw (U2 - U)  (H_itp of the continuous adjoint, gradient.jl:287).
+  // Returns whether any value THIS thread loaded (own rows or its share of the halo) carries ice.
+  bool ice = false;
   const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   const bool colok = gi < g.nx;
@@ -594,6 +596,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
     }
     own[m] = h;
     const double hc = vmax0(h);
+    ice = ice || hc > 0.0;
     sHS[r][tx + 1] = make_double2(hc, b + hc);
   }
   if (ty < 2) {
@@ -607,6 +610,7 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
       b = B[id];
     }
     const double hc = vmax0(h);
+    ice = ice || hc > 0.0;
     sHS[r][tx + 1] = make_double2(hc, b + hc);
   } else if (ty < 4) {
     const int l = threadIdx.x - 128;
@@ -622,9 +626,11 @@ __device__ __forceinline__ void load_tile_HS2(const double* __restrict__ U, cons
         b = B[id];
       }
       const double hc = vmax0(h);
+      ice = ice || hc > 0.0;
       sHS[r][c] = make_double2(hc, b + hc);
     }
   }
+  return ice;
 }
 
 // Same for a third field kept unclamped and masked to the interior (lambda~).
@@ -733,10 +739,12 @@ __global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double own[RPT];
-  load_tile_HS2(U, P.B, g, i0, j0, sHS, own);
-  __syncthreads();
-  nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
-  __syncthreads();
+  // no ice on the tile and its halo: every clamped slope and D vanish, dH/dt = 0 exactly -- skip the stencil
+  const bool ice = __syncthreads_or(load_tile_HS2(U, P.B, g, i0, j0, sHS, own));
+  if (ice) {
+    nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
+    __syncthreads();
+  }
   const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
 #pragma unroll
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __
     const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
     if (gi < g.nx && gj < g.ny) {
       double k = 0.0;
-      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs<LM>(g, tx + 1, r, sHS, sD);
+      if (ice && gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs<LM>(g, tx + 1, r, sHS, sD);
       dH[g.off + gi + (long long)g.nx * gj] = k;
     }
   }
@@ -770,10 +778,11 @@ __global__ __launch_bounds__(NT) void k_euler_cfl(Pools P, LawDev L, const doubl
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   const double dt = gs->dt;
   double own[RPT];
-  load_tile_HS2(Usrc, P.B, g, i0, j0, sHS, own);
-  __syncthreads();
-  nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
-  __syncthreads();
+  const bool ice = __syncthreads_or(load_tile_HS2(Usrc, P.B, g, i0, j0, sHS, own));
+  if (ice) {
+    nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
+    __syncthreads();
+  }
   const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   double dmax = 0.0;
@@ -782,10 +791,10 @@ __global__ __launch_bounds__(NT) void k_euler_cfl(Pools P, LawDev L, const doubl
     const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
     if (gi < g.nx && gj < g.ny) {
       double k = 0.0;
-      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs<LM>(g, tx + 1, r, sHS, sD);
+      if (ice && gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs<LM>(g, tx + 1, r, sHS, sD);
       Udst[g.off + gi + (long long)g.nx * gj] = fma(dt, k, own[m]);
     }
-    dmax = fmax(dmax, sD[r][tx + 1]);  // the node north-east of the cell (0 where it does not exist)
+    if (ice) dmax = fmax(dmax, sD[r][tx + 1]);  // the node north-east of the cell (0 where it does not exist)
   }
   const double tot = block_max(dmax, red);
   if (threadIdx.x == 0) P.part[4 * (long long)t4.w] = tot;
@@ -820,10 +829,12 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
   const double* __restrict__ X = Usrc;
   if (STAGE == 1 && !gs->accepted) X = S3;  // rejected step: restart from uprev
   double own[RPT];
-  load_tile_HS2(X, P.B, g, i0, j0, sHS, own);
-  __syncthreads();
-  nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
-  __syncthreads();
+  // no ice on the tile and its halo: every clamped slope and D vanish, dH/dt = 0 exactly -- skip the stencil
+  const bool ice = __syncthreads_or(load_tile_HS2(X, P.B, g, i0, j0, sHS, own));
+  if (ice) {
+    nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
+    __syncthreads();
+  }
   const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   constexpr int s = STAGE - 1;
@@ -835,7 +846,7 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
     if (gi < g.nx && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
       double k = 0.0;
-      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs<LM>(g, tx + 1, r, sHS, sD);
+      if (ice && gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2) k = cell_rhs<LM>(g, tx + 1, r, sHS, sD);
       const double u = own[m];
       const double dtk = dt * k;
       if (STAGE == 1) {
@@ -1572,7 +1583,17 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double ownH[RPT], ownL[RPT];
-  load_tile_HS2(A.H, P.B, g, i0, j0, sHS, ownH);
+  const bool ice = load_tile_HS2(A.H, P.B, g, i0, j0, sHS, ownH);
+  // no ice anywhere on the tile and its halo: every owned node has Hbar = 0, so its weight
+  // spat * Da vanishes identically (A-type and D_hybrid laws: spat ~ Hbar^(n+2); D law: Hbar) -- exact
+  if (!__syncthreads_or(ice)) {
+    if (!nn_node) {
+      if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 2] = 0.0;
+    } else {
+      for (int k = threadIdx.x; k < L.P; k += NT) A.part_theta[(long long)t4.w * L.P + k] = 0.0;
+    }
+    return;
+  }
   load_tile_lam(A.lam, g, i0, j0, sL, ownL);
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = wave_id();
