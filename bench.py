@@ -322,6 +322,7 @@ def main():
                 "traffic": traffic_stage,
                 "ms_per_launch": ms_stage,
                 "algorithmic_bytes_per_launch": B_PER_CELL_STAGE2 * cells,
+                "note": "tiles without ice skip the stencil arithmetic (exactly zero dH/dt); every byte is still moved",
             },
             "cpu_baseline": cpu,
             "aux": aux,
