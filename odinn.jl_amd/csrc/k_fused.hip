@@ -8,8 +8,14 @@
 #define CAT(a, b) CAT_(a, b)
 namespace odinn {
 void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
-                                        double* U1, double* partF, double abstol, double reltol, int skip) {
-  if (skip) hipLaunchKernelGGL((k_rk_fused<ODINN_LM, true>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
-  else hipLaunchKernelGGL((k_rk_fused<ODINN_LM, false>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
+                                        double* U1, double* partF, double abstol, double reltol, int skip, int small) {
+  // small: FOX x FOYS "latency" tiles (tilesF / partF then belong to that table)
+  if (small) {
+    if (skip) hipLaunchKernelGGL((k_rk_fused<ODINN_LM, true, FOYS>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
+    else hipLaunchKernelGGL((k_rk_fused<ODINN_LM, false, FOYS>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
+  } else {
+    if (skip) hipLaunchKernelGGL((k_rk_fused<ODINN_LM, true, FOY>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
+    else hipLaunchKernelGGL((k_rk_fused<ODINN_LM, false, FOY>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
+  }
 }
 }  // namespace odinn

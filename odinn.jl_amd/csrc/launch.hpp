@@ -14,7 +14,7 @@ namespace odinn {
   void launch_vjp_theta_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base);           \
   void launch_adj_stage_lm##LM(int stage, int vj, int nblk, hipStream_t st, Pools P, LawDev L, AdjStageArgs A); \
   void launch_rk_fused_lm##LM(int nblk, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,     \
-                              double* U1, double* partF, double abstol, double reltol, int skip);
+                              double* U1, double* partF, double abstol, double reltol, int skip, int small);
 ODINN_DECL_LM(0)
 ODINN_DECL_LM(1)
 ODINN_DECL_LM(2)

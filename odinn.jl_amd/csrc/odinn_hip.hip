@@ -127,9 +127,17 @@ struct odinn_batch {
   long long ntot = 0, ntotd = 0;
   int ntiles = 0;
   // device pools
-  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr;
-  int ntilesF = 0;
-  double* d_partF = nullptr;
+  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr;
+  int ntilesF = 0, ntilesFs = 0;
+  double *d_partF = nullptr, *d_partFs = nullptr;
+  // the fused step runs on the small "latency" tiles when the throughput tiles cannot fill the 256 CUs
+  // (ODINN_FUSED_TILES=small|large overrides)
+  bool small_tiles() const {
+    const char* e = std::getenv("ODINN_FUSED_TILES");
+    if (e && e[0] == 's') return true;
+    if (e && e[0] == 'l') return false;
+    return ntilesF <= 256;
+  }
   GDev* d_gd = nullptr;
   GState* d_gs = nullptr;
   double *d_B = nullptr, *d_H0 = nullptr, *d_Afield = nullptr, *d_Tfield = nullptr, *d_Gacc = nullptr;
@@ -441,10 +449,14 @@ int pick_scheme(const odinn_batch* b, int requested) {
 int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip) {
   const Pools P = b->pools(true);
   const LawDev L = b->lawdev();
+  const int small = b->small_tiles() ? 1 : 0;
+  const int nblk = small ? b->ntilesFs : b->ntilesF;
+  const int4* tiles = small ? b->d_tilesFs : b->d_tilesF;
+  double* part = small ? b->d_partFs : b->d_partF;
   if (b->lm() == 0)
-    launch_rk_fused_lm0(b->ntilesF, b->stream, P, L, b->d_tilesF, b->d_U[0], b->d_U[1], b->d_partF, abstol, reltol, skip);
+    launch_rk_fused_lm0(nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
   else
-    launch_rk_fused_lm1(b->ntilesF, b->stream, P, L, b->d_tilesF, b->d_U[0], b->d_U[1], b->d_partF, abstol, reltol, skip);
+    launch_rk_fused_lm1(nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -612,7 +624,8 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   CtrlArgs C{};
   C.tstops = b->d_tstops; C.n_stops = n_stops; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
   C.dtmax = opt.dtmax; C.adaptive = adaptive ? 1 : 0; C.fixed_dt = opt.fixed_dt; C.n_active = b->d_nactive;
-  C.errpart = scheme == 2 ? b->d_partF : b->d_part; C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? 1 : 0;
+  C.errpart = scheme == 2 ? (b->small_tiles() ? b->d_partFs : b->d_partF) : b->d_part;
+  C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? (b->small_tiles() ? 2 : 1) : 0;
   PostArgs A{};
   A.snaps = b->d_snaps; A.premb = b->d_premb; A.ntot = b->ntot; A.mb0 = b->d_mb0;
   A.Sref = b->any_sref ? b->d_Sref : nullptr;
@@ -768,12 +781,16 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   CHK(dalloc(&b->d_tiles_nat, nat.size()));
   HIPCHK(hipMemcpy(b->d_tiles, swz.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->d_tiles_nat, nat.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
-  {  // tile table of the fused-step kernel (FOX x FOY output tiles), same XCD-banded order
+  // tile tables of the fused-step kernel, same XCD-banded order: FOX x FOY "throughput" tiles and
+  // FOX x FOYS "latency" tiles (used when the batch has too few throughput tiles to fill the GPU)
+  for (int small = 0; small < 2; ++small) {
+    const int foy = small ? FOYS : FOY;
     std::vector<int4> natF;
     for (int g = 0; g < n_glaciers; ++g) {
       GDev& r = b->gd[g];
-      const int fx = (r.nx + FOX - 1) / FOX, fy = (r.ny + FOY - 1) / FOY;
-      r.tile0F = (int)natF.size(); r.ntilesF = fx * fy;
+      const int fx = (r.nx + FOX - 1) / FOX, fy = (r.ny + foy - 1) / foy;
+      if (small) { r.tile0Fs = (int)natF.size(); r.ntilesFs = fx * fy; }
+      else { r.tile0F = (int)natF.size(); r.ntilesF = fx * fy; }
       for (int ty = 0; ty < fy; ++ty)
         for (int tx = 0; tx < fx; ++tx) natF.push_back(make_int4(g, tx, ty, (int)natF.size()));
     }
@@ -785,10 +802,17 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
         const int t = x * per + r;
         if (t < nF) swzF.push_back(natF[t]);
       }
-    b->ntilesF = nF;
-    CHK(dalloc(&b->d_tilesF, (size_t)nF));
-    CHK(dalloc(&b->d_partF, (size_t)nF));
-    HIPCHK(hipMemcpy(b->d_tilesF, swzF.data(), sizeof(int4) * nF, hipMemcpyHostToDevice));
+    if (small) {
+      b->ntilesFs = nF;
+      CHK(dalloc(&b->d_tilesFs, (size_t)nF));
+      CHK(dalloc(&b->d_partFs, (size_t)nF));
+      HIPCHK(hipMemcpy(b->d_tilesFs, swzF.data(), sizeof(int4) * nF, hipMemcpyHostToDevice));
+    } else {
+      b->ntilesF = nF;
+      CHK(dalloc(&b->d_tilesF, (size_t)nF));
+      CHK(dalloc(&b->d_partF, (size_t)nF));
+      HIPCHK(hipMemcpy(b->d_tilesF, swzF.data(), sizeof(int4) * nF, hipMemcpyHostToDevice));
+    }
   }
   CHK(dalloc(&b->d_gd, n_glaciers));
   CHK(dalloc(&b->d_gs, n_glaciers));
@@ -819,7 +843,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
-  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0);
+  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs);
   dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
   dfree(b->d_rmbs); dfree(b->d_adj);
   dfree(b->d_partsteps);
@@ -1686,7 +1710,8 @@ static int timed_one(odinn_batch* b, int which, int it) {
       CtrlArgs C{};
       C.tstops = b->d_tstops; C.n_stops = 2; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
       C.dtmax = 0.0; C.adaptive = 0; C.fixed_dt = 1e-6; C.n_active = b->d_nactive;
-      C.errpart = scheme == 2 ? b->d_partF : b->d_part; C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? 1 : 0;
+      C.errpart = scheme == 2 ? (b->small_tiles() ? b->d_partFs : b->d_partF) : b->d_part;
+      C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? (b->small_tiles() ? 2 : 1) : 0;
       PostArgs PA;
       PA.snaps = b->d_tmpA; PA.premb = b->d_tmpB; PA.ntot = b->ntot; PA.mb0 = b->d_mb0; PA.Sref = nullptr;
       if (scheme == 2) {

@@ -50,10 +50,10 @@ constexpr int FH = 5;                 // halo = number of stages
 #endif
 constexpr int FRX = 64;               // region width = one wavefront
 constexpr int FOX = FRX - 2 * FH, FOY = ODINN_FOY;  // 54 x FOY output tile
-constexpr int FRY = FOY + 2 * FH;     // region height
+constexpr int FOYS = 8;               // "latency" tile height: used when the batch has too few tiles to fill
+                                      // the GPU -- a workgroup then walks 18 region rows instead of 50
 constexpr int FNT = ODINN_FNT;        // threads per block
 constexpr int FNW = FNT / 64;
-constexpr int FSLOT = (FRY + FNW - 1) / FNW;  // region rows per wavefront
 constexpr int FLD = FRX + 1;          // LDS row stride (odd)
 
 
@@ -93,6 +93,7 @@ constexpr double c_cc[5] = {0.0, 2.300298624518076223899418286314123354e-01,
 struct GDev {  // per-glacier constants
   int nx, ny, ntx, nty, tile0, ntiles;
   int tile0F, ntilesF;  // range in the fused-step tile table (FOX x FOY output tiles)
+  int tile0Fs, ntilesFs; // ... and in the table of FOX x FOYS "latency" tiles
   long long off;   // offset of this glacier in the pooled primal arrays  [doubles]
   long long offd;  // offset in the pooled dual arrays
   double dx, dy, inv_dx, inv_dy, eta0;
@@ -895,7 +896,7 @@ struct CtrlArgs {
   int next_cur;  // ping-pong buffer that holds u_new of this step; -1: flip the glacier's own `cur`
   const double* errpart;  // per-tile error partials: errpart[stride * tile]
   int stride;
-  int fused;              // partials are indexed by the fused-step tile table
+  int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles)
   double cfl;             // > 0: explicit Euler with dt = cfl*min(dx,dy)^2/(4 max D); the partials are tile maxima
   int cfl_prime;          // the launch only measured max D(u0): set the first dt, do not advance
   // reverse (continuous-adjoint) solve only; adj == null in the forward solve.  tstops are then
@@ -932,7 +933,8 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   const GDev g = P.gd[gidx];
   double s = 0.0;
   {
-    const int t0 = C.fused ? g.tile0F : g.tile0, nt = C.fused ? g.ntilesF : g.ntiles;
+    const int t0 = C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
+    const int nt = C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
     if (C.cfl > 0.0) {
       for (int k = threadIdx.x; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
     } else {

@@ -20,11 +20,14 @@
 
 namespace odinn {
 
-template <int S, int LM>
+template <int S, int LM, int FOYV>
 __device__ __forceinline__ void fused_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
                                              int gi, int gj0, int w, int lane, double dt, double2 (*sHS)[FLD],
-                                             double (*sD)[FLD], double (&u)[FSLOT], double (&tmp)[FSLOT],
-                                             const double (&up)[FSLOT], double (&E)[FSLOT], const double (&bb)[FSLOT]) {
+                                             double (*sD)[FLD], double (&u)[(FOYV + 2 * FH + FNW - 1) / FNW], double (&tmp)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                             const double (&up)[(FOYV + 2 * FH + FNW - 1) / FNW], double (&E)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                            const double (&bb)[(FOYV + 2 * FH + FNW - 1) / FNW]) {
+  constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + FNW - 1) / FNW;
+
   // ---- nodes needed by region_S: columns [S-1, 63-S], rows [S-1, FRY-1-S]; node (c, r) = north-east
   //      corner of cell (c, r) ------------------------------------------------------------------
   const bool ncol = lane >= S - 1 && lane <= FRX - 1 - S;
@@ -98,10 +101,11 @@ __device__ __forceinline__ void fused_stage(const GDev& g, const LawDev& L, cons
 #ifndef ODINN_FWPE
 #define ODINN_FWPE 4
 #endif
-template <int LM, bool SKIP>
+template <int LM, bool SKIP, int FOYV>
 __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused(Pools P, LawDev L, const int4* __restrict__ tilesF,
                                                      double* __restrict__ U0, double* __restrict__ U1,
                                                      double* __restrict__ partF, double abstol, double reltol) {
+  constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + FNW - 1) / FNW;
   __shared__ double2 sHS[FRY][FLD];
   __shared__ double sD[FRY][FLD];
   __shared__ double red[FNW];
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused(Pools P, LawDev L,
   double* __restrict__ dst = gs->cur ? U0 : U1;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOY - FH;
+  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOYV - FH;
   const int gi = gi0 + lane;
   const bool inx = gi >= 0 && gi < g.nx;
   double u[FSLOT], tmp[FSLOT], up[FSLOT], E[FSLOT], bb[FSLOT];
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused(Pools P, LawDev L,
     for (int m = 0; m < FSLOT; ++m) nz = nz || (u[m] != 0.0);
     if (!__syncthreads_or(nz)) {
       if (lane >= FH && lane < FH + FOX && inx) {
-        for (int rr = w; rr < FOY; rr += FNW) {
+        for (int rr = w; rr < FOYV; rr += FNW) {
           const int gj = gjo + rr;
           if (gj < g.ny) dst[g.off + gi + (long long)g.nx * gj] = 0.0;
         }
@@ -154,11 +158,11 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused(Pools P, LawDev L,
   } else {
     __syncthreads();
   }
-  fused_stage<1, LM>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
-  fused_stage<2, LM>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
-  fused_stage<3, LM>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
-  fused_stage<4, LM>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
-  fused_stage<5, LM>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  fused_stage<1, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  fused_stage<2, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  fused_stage<3, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  fused_stage<4, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  fused_stage<5, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
   // ---- output tile = region_5 (columns [5, 58], rows [5, FRY-6]): u' straight from the registers,
   //      embedded error partial ------------------------------------------------------------------
   double errsq = 0.0;

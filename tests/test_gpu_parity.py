@@ -456,3 +456,25 @@ def test_ice_free_tile_shortcut_is_bitwise_exact(gpu):
     assert out[0][2:] == out[1][2:]
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert (out[0][1] > 0).sum() > (H0 > 0).sum()  # the cap spread into previously ice-free cells
+
+
+def test_fused_tile_sizes_are_equivalent(gpu, monkeypatch):
+    """The fused step kernel has a throughput tile (54x40) and a latency tile (54x8, picked when the
+    batch cannot fill the GPU): the same expression sequence per cell, compiled twice -- the
+    solutions agree to rounding (the compiler is free to contract a*b + c*d either way per
+    instantiation; the error norm is summed over other tile partials)."""
+    H0, B = O.synthetic_valley(130, 97, 50.0)
+    ts = [2010.0, 2010.25, 2010.5]
+    out = {}
+    for tiles in ("small", "large"):
+        monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
+        b = gpu.GlacierBatch([(130, 97)], [50.0], A=[4e-17])
+        b.set_fields(0, H0, B)
+        st = b.solve(ts, reltol=1e-8)
+        ad = (b.snapshot(0, 2), st[0].naccept, st[0].nreject)
+        b.solve(ts, fixed_dt=0.002)
+        out[tiles] = ad + (b.snapshot(0, 2),)
+        b.close()
+    assert out["small"][1:3] == out["large"][1:3]
+    assert rel_l2(out["small"][0], out["large"][0]) < 1e-12
+    assert np.isfinite(out["large"][3]).all() and rel_l2(out["small"][3], out["large"][3]) < 1e-13
