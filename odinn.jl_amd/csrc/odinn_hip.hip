@@ -1037,8 +1037,9 @@ int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H,
 }
 
 static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
-                            bool accumulate, double* part_deferred = nullptr) {
-  // part_deferred (A-type laws only): the per-tile partials go there and are NOT summed here
+                            bool accumulate, double* part_deferred = nullptr, bool inplace = false) {
+  // part_deferred (A-type laws only): the per-tile partials go there and are NOT summed here;
+  // inplace: they are ADDED onto part_deferred (which the caller zeroed and reduces at the end)
   // g < 0: all glaciers (swizzled table); result of A-type laws lands in d_Gsum / d_Gacc,
   // of Y/U laws in d_dth[g][P]
   const bool nn_node = b->law_kind >= ODINN_LAW_NN_Y;
@@ -1049,6 +1050,7 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
   A.part_theta = nn_node ? b->d_part_theta : nullptr;
   A.gscratch = nn_node ? b->d_gscratch : nullptr;
+  A.accum = (inplace && part_deferred && !nn_node) ? 1 : 0;
   Pools P = b->pools(g < 0);
   if (part_deferred) P.part = part_deferred;
   launch_vjp_theta(b, nblk, P, b->lawdev(), A, base);
@@ -1554,6 +1556,16 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   AdjStageArgs SA{};
   SA.snaps = b->d_snaps; SA.ntot = b->ntot; SA.adj = b->d_adj; SA.S2 = b->d_S2; SA.S3 = b->d_S3; SA.E = b->d_E;
   SA.abstol = ao.abstol; SA.reltol = ao.reltol;
+  const bool acc_inplace = b->law_kind < ODINN_LAW_NN_Y;
+  if (acc_inplace) {
+    const size_t need = 4 * (size_t)b->ntiles;
+    if (need > b->partsteps_cap) {
+      dfree(b->d_partsteps);
+      CHK(dalloc(&b->d_partsteps, need));
+      b->partsteps_cap = need;
+    }
+    HIPCHK(hipMemsetAsync(b->d_partsteps, 0, need * sizeof(double), b->stream));
+  }
   const int CHUNK = 16;
   long long steps = 0;
   int p = 0;
@@ -1574,8 +1586,9 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       C.next_cur = 1 - p;
       launch_controller(G, b->stream, Pl, C);
       launch_adj_poststep(b->ntiles, b->stream, Pl, AP, b->d_lam[0], b->d_lam[1]);
-      // quadrature node reached: dtheta += w * J_theta(H_itp(t))^T lam(t)  (:497-503)
-      CHK(theta_vjp_launch(b, b->d_tmpA, a1, b->d_qw, -1, true));
+      // quadrature node reached: dtheta += w * J_theta(H_itp(t))^T lam(t)  (:497-503); A-type laws add
+      // onto per-tile running sums that are reduced once after the solve
+      CHK(theta_vjp_launch(b, b->d_tmpA, a1, b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace));
       p = 1 - p;
       ++steps;
     }
@@ -1600,6 +1613,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       stats_rev[g].dt_last = gs[g].dt;
     }
   }
+  if (acc_inplace) launch_sum_part_steps(G, b->stream, Pl, b->d_partsteps, 4LL * b->ntiles, 0, 0, 2, b->d_Gsum);
   // lambda(t0) of every glacier -> d_lam[0] (glaciers finish in different ping-pong buffers)
   if (mixed || gs[0].cur != 0) {
     for (int g = 0; g < G; ++g)

@@ -1564,6 +1564,8 @@ struct ThArgs {
   double* Gacc;          // dual pooled accumulator (gridded A) or null
   double* part_theta;    // [ntiles_total][P] for Y/U laws or null
   double* gscratch;      // thread-private gradient scratch [P][grid*NT]
+  int accum;             // A-type laws: add the tile's sum onto its partial slot instead of overwriting it
+                         // (one reduction after a whole reverse solve instead of one per step)
 };
 
 template <int LM>
@@ -1576,7 +1578,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   constexpr bool nn_node = lm_is_nn(LM);
   if (scale == 0.0) {  // this glacier contributes nothing now (e.g. not at a quadrature node)
     if (!nn_node) {
-      if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 2] = 0.0;
+      if (threadIdx.x == 0 && !A.accum) P.part[4 * (long long)t4.w + 2] = 0.0;
     } else {
       for (int k = threadIdx.x; k < L.P; k += NT) A.part_theta[(long long)t4.w * L.P + k] = 0.0;
     }
@@ -1590,7 +1592,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   // spat * Da vanishes identically (A-type and D_hybrid laws: spat ~ Hbar^(n+2); D law: Hbar) -- exact
   if (!__syncthreads_or(ice)) {
     if (!nn_node) {
-      if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 2] = 0.0;
+      if (threadIdx.x == 0 && !A.accum) P.part[4 * (long long)t4.w + 2] = 0.0;
     } else {
       for (int k = threadIdx.x; k < L.P; k += NT) A.part_theta[(long long)t4.w * L.P + k] = 0.0;
     }
@@ -1638,7 +1640,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   }
   if (!nn_node) {
     const double tot = block_sum(acc, red);
-    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 2] = tot;
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 2] = A.accum ? P.part[4 * (long long)t4.w + 2] + tot : tot;
   } else {
     for (int k = 0; k < L.P; ++k) {
       const double tot = block_sum(gth[(long long)k * gstride], red);
