@@ -702,7 +702,7 @@ __device__ __forceinline__ double cell_div(const GDev& g, const double2* p, cons
 template <int LM>
 __device__ __forceinline__ void nodes_forward(const GDev& g, const LawDev& L, const double* __restrict__ Afield, int i0,
                                               int j0, const double2 (*sHS)[LDW], double (*sD)[LDN]) {
-  for (int idx = threadIdx.x; idx < NNODE; idx += NT) {
+  auto node = [&](int idx) {
     const int b = idx / (TX + 1), a = idx - b * (TX + 1);
     const int gi = i0 - 1 + a, gj = j0 - 1 + b;
     double D = 0.0;
@@ -716,10 +716,30 @@ __device__ __forceinline__ void nodes_forward(const GDev& g, const LawDev& L, co
       D = node_D<false, LM>(g, L, Hb, gS2, An, al, be, sp);
     }
     sD[b][a] = D;
+  };
+  if constexpr (lm_is_nn(LM)) {  // one copy of the inlined network, whatever the surrounding control flow
+#pragma unroll 1
+    for (int idx = threadIdx.x; idx < NNODE; idx += NT) node(idx);
+  } else {
+    for (int idx = threadIdx.x; idx < NNODE; idx += NT) node(idx);
   }
 }
 
 __device__ __forceinline__ double clampf(double e, double up, double lo) { return vmax(vmin(e, up), lo); }
+
+// Barrier after the tile loads + "does the tile (with its halo) carry any ice?".  The closed-form laws
+// use the answer for the exact ice-free shortcut; the inlined-MLP laws always answer yes: they skip
+// the network per node where Hbar = 0 anyway, and a conditional stencil made the register allocator
+// keep the whole network live (300 VGPRs instead of 131 for the 2x16 architecture).
+template <int LM>
+__device__ __forceinline__ bool tile_has_ice(bool loaded_ice) {
+  if constexpr (lm_is_nn(LM)) {
+    __syncthreads();
+    return true;
+  } else {
+    return __syncthreads_or(loaded_ice) != 0;
+  }
+}
 
 // dH/dt of the cell at halo coordinates (c, r); caller guarantees the cell is interior.
 template <int LM>
@@ -741,7 +761,7 @@ __global__ __launch_bounds__(NT) void k_dhdt(Pools P, LawDev L, const double* __
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double own[RPT];
   // no ice on the tile and its halo: every clamped slope and D vanish, dH/dt = 0 exactly -- skip the stencil
-  const bool ice = __syncthreads_or(load_tile_HS2(U, P.B, g, i0, j0, sHS, own));
+  const bool ice = tile_has_ice<LM>(load_tile_HS2(U, P.B, g, i0, j0, sHS, own));
   if (ice) {
     nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
     __syncthreads();
@@ -779,7 +799,7 @@ __global__ __launch_bounds__(NT) void k_euler_cfl(Pools P, LawDev L, const doubl
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   const double dt = gs->dt;
   double own[RPT];
-  const bool ice = __syncthreads_or(load_tile_HS2(Usrc, P.B, g, i0, j0, sHS, own));
+  const bool ice = tile_has_ice<LM>(load_tile_HS2(Usrc, P.B, g, i0, j0, sHS, own));
   if (ice) {
     nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
     __syncthreads();
@@ -831,7 +851,7 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
   if (STAGE == 1 && !gs->accepted) X = S3;  // rejected step: restart from uprev
   double own[RPT];
   // no ice on the tile and its halo: every clamped slope and D vanish, dH/dt = 0 exactly -- skip the stencil
-  const bool ice = __syncthreads_or(load_tile_HS2(X, P.B, g, i0, j0, sHS, own));
+  const bool ice = tile_has_ice<LM>(load_tile_HS2(X, P.B, g, i0, j0, sHS, own));
   if (ice) {
     nodes_forward<LM>(g, L, P.Afield, i0, j0, sHS, sD);
     __syncthreads();
@@ -1364,7 +1384,7 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
 template <int LM, int VJ>
 __device__ __forceinline__ bool vjpH_tile_or_zero(const GDev& g, const LawDev& L, const Pools& P, double2* smem, int i0,
                                                   int j0, const double (&ownH)[RPT], double (&v)[RPT]) {
-  if constexpr (VJ == 0) {
+  if constexpr (VJ == 0 && !lm_is_nn(LM)) {  // (a conditional stencil makes the MLP variants spill, see tile_has_ice)
     bool any = false;
 #pragma unroll
     for (int m = 0; m < RPT; ++m) any = any || ownH[m] > 0.0;
