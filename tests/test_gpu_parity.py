@@ -478,3 +478,49 @@ def test_fused_tile_sizes_are_equivalent(gpu, monkeypatch):
     assert out["small"][1:3] == out["large"][1:3]
     assert rel_l2(out["small"][0], out["large"][0]) < 1e-12
     assert np.isfinite(out["large"][3]).all() and rel_l2(out["small"][3], out["large"][3]) < 1e-13
+
+
+def test_randomised_shapes_and_states(gpu):
+    """Seeded sweep over ragged shapes (around the 64x16 tile and the 54x40 / 54x8 fused tiles), rough
+    states with negative thickness, ice-free patches, generic exponents: RHS, both H-VJP stencils and
+    the theta-VJP against the oracle; one RDPK3Sp35 step sequence against the oracle's."""
+    rng = np.random.default_rng(2024)
+    shapes = [(3, 3), (4, 7), (17, 65), (63, 17), (64, 16), (65, 33), (54, 40), (55, 41), (108, 8), (109, 9),
+              (128, 31), (70, 100), (129, 47), (200, 131)]
+    for k, (nx, ny) in enumerate(shapes):
+        n = 3.0 if k % 3 else 2.7
+        C = 0.0 if k % 2 else 5e-8
+        ph = O.Phys(n=n, C=C, p=3.0, q=1.0, eta0=1.0 if k % 4 else 0.8)
+        x = np.linspace(0, 1, nx)[:, None]
+        y = np.linspace(0, 1, ny)[None, :]
+        B = 500.0 + 300.0 * x + 80.0 * np.sin(7 * x + 3 * y) + 5.0 * rng.standard_normal((nx, ny))
+        H = 120.0 * np.exp(-((x - 0.5) ** 2 + (y - 0.4) ** 2) / 0.08) + 15.0 * rng.standard_normal((nx, ny)) - 20.0
+        if k % 3 == 0:
+            H[: nx // 2, :] = 0.0  # an ice-free half (exact-shortcut tiles next to active ones)
+        H, B = np.asfortranarray(H), np.asfortranarray(B)
+        lam = rng.standard_normal((nx, ny))
+        A = 3e-17
+        law = O.Law(kind=O.LAW_CONST_A, A=A)
+        b = gpu.GlacierBatch([(nx, ny)], [37.0], [53.0], phys=[gpu.PhysicalParameters(**ph.__dict__)], A=[A])
+        b.set_fields(0, np.maximum(H, 0.0), B)
+        ref = O.sia2d_rhs(H, B, 37.0, 53.0, ph, law)
+        tol = 1e-11 if n == 3.0 else 1e-10
+        assert rel_l2(b.dhdt(0, H), ref) < tol or not ref.any(), (nx, ny)
+        gv = O.vjp_H(lam, H, B, 37.0, 53.0, ph, law)
+        assert rel_l2(b.vjp_H(0, lam, H), gv) < 10 * tol or not gv.any(), (nx, ny)
+        gt = O.vjp_theta(lam, H, B, 37.0, 53.0, ph, law)
+        assert abs(b.vjp_theta(0, lam, H)[0] - gt[0]) <= 10 * tol * max(abs(gt[0]), 1e-300), (nx, ny)
+        b.set_vjp_method(gpu._lib.VJP_CONTINUOUS)
+        gc = O.vjp_H_continuous(lam, H, B, 37.0, 53.0, ph, law)
+        assert rel_l2(b.vjp_H(0, lam, H), gc) < 10 * tol or not gc.any(), (nx, ny)
+        b.set_vjp_method(gpu._lib.VJP_DISCRETE)
+        if nx >= 17 and ny >= 17:
+            H0 = np.maximum(H, 0.0)
+            f = lambda u: O.sia2d_rhs(u, B, 37.0, 53.0, ph, law)
+            dt = 2e-4
+            snaps, _, _ = O.solve(f, H0, [0.0, 4 * dt], fixed_dt=dt)
+            b.solve([0.0, 4 * dt], fixed_dt=dt)
+            assert rel_l2(b.snapshot(0, 1), snaps[1]) < 1e-11, (nx, ny)
+            b.solve([0.0, 4 * dt], fixed_dt=dt, scheme=1)
+            assert rel_l2(b.snapshot(0, 1), snaps[1]) < 1e-11, (nx, ny)
+        b.close()
