@@ -1,17 +1,9 @@
-# INTEGRATION — binding `libodinn_hip.so` into ODINN.jl
-
-The reference selects its gradient machinery by dispatch on strategy types
-(`params.UDE.grad::AbstractAdjointMethod` and its `.VJP_method::AbstractVJPMethod`,
-`src/inverse/SIA2D/gradient.jl:129,236,245`; `src/inverse/SIA2D/VJPs.jl:2-59`). A maintainer
-would add **one new VJP type and one new adjoint type** whose methods `ccall` the C ABI of
-`include/odinn_hip.h`; nothing else in ODINN changes. The shim below (also kept as a file:
-`julia/OdinnHIP.jl`) is what that file (`src/inverse/HIP/OdinnHIP.jl`, ≈140 lines) looks like. It cannot be executed in the build
-image (no Julia toolchain), so it is documentation of the binding, not tested code.
-
-Julia `Matrix{Float64}` is column-major with dim 1 contiguous — exactly the ABI's layout, so
-arrays are passed without copies or transposes.
-
-```julia
+# OdinnHIP.jl -- the reference-side binding of libodinn_hip.so (see INTEGRATION.md).
+#
+# This is the file a maintainer would add to ODINN.jl (src/inverse/HIP/OdinnHIP.jl): one new VJP type
+# and one new adjoint type whose methods ccall the C ABI of include/odinn_hip.h.  The build image has
+# no Julia toolchain, so this file is NOT executed by the test-suite; the same entry points are
+# exercised from Python (odinn.jl_amd/_lib.py) by tests/ -m gpu.
 module OdinnHIP
 using ODINN, Huginn, Sleipnir
 const lib = "libodinn_hip"            # odinn.jl_amd/csrc/libodinn_hip.so on LD_LIBRARY_PATH
@@ -105,44 +97,3 @@ function SIA2D_grad_batch_HIP!(θ, simulation, adj::HIPAdjoint, grad::ODINN.Cont
     return loss[], [ODINN.Vector2ComponentVector(dθ, θ)]
 end
 end # module
-```
-
-Law/θ plumbing: `odinn_set_law(b, kind, mlp_desc, θ, P, n_H, n_∇S)` takes the Lux chain as an
-`odinn_mlp_desc` (widths, activation codes, ODINN's pre/post-scaling) and θ flattened as
-`ComponentVector2Vector(θ.A)` already is (`[vec(W), b]` per layer). Reference data:
-`odinn_set_reference(b, i, n, tH_ref, H_ref, distance)` with `glacier.thicknessData`.
-
-Other seams of the same kind: `odinn_set_vjp_method(b, ODINN_VJP_CONTINUOUS)` ⇔ `VJP_method = ContinuousVJP()`
-(`VJPTypes.jl:39-50`); `odinn_tikhonov` ⇔ `loss`/`backward_loss(::TikhonovRegularization, a, Δx, Δy, mask, norm)`
-(`Regularization.jl:92-126`); `odinn_surface_V`, `odinn_surface_V_vjp_H/theta` ⇔ `Huginn.V_from_H`,
-`VJP_λ_∂surface_V∂H/∂θ` (`VJPs.jl:61-82`); `odinn_get_lambda0`, `odinn_get_grad_parts`, `odinn_get_grad_field` feed
-`θ.IC` and the per-glacier slots of a `PerGlacierModel` (`gradient.jl:262-271`, `Model.jl:208-224`).
-
-Multi-GPU: where the reference calls `pmap` over worker processes (`gradient.jl:9-10`,
-`src/setup/config.jl:97-139`), start one Julia process per GPU, give each its shard of
-`simulation.glaciers`, and sum `[loss; dθ]` across processes once per iteration (MPI.jl /
-RCCL `ncclAllReduce`, 1+P doubles) instead of `sum(losses)` / `aggregate∇θ`
-(`gradient.jl:14,25`).
-
-## What runs today in this repository
-
-The same entry points are bound from Python by `odinn.jl_amd/_lib.py` (ctypes; one row per
-exported symbol, checked against the header by `tests/test_abi.py`) and used by
-`odinn.jl_amd/api.py`, which mirrors the reference's user-facing names:
-
-```python
-import _odinn_import; odinn = _odinn_import.load()
-p   = odinn.Parameters(simulation=odinn.SimulationParameters(tspan=(2010., 2012.)),
-                       solver=odinn.SolverParameters(reltol=1e-8, step=1/12),
-                       hyper=odinn.Hyperparameters(optimizer=odinn.Adam(1e-2), epochs=50))
-nn  = odinn.NeuralNetwork(p)
-inv = odinn.FunctionalInversion(odinn.Model(odinn.SIA2Dmodel(p, A=odinn.LawA(nn, p)),
-                                            regressors={"A": nn}), glaciers, p)
-odinn.run_b(inv)            # run!(functional_inversion)
-```
-
-Ownership/threading/errors: inputs are never mutated; outputs are caller-allocated; a batch
-is bound to one device and one stream and is not thread-safe (different batches are
-independent); every function returns a status code and `odinn_last_error()` holds the
-message — the reference's `@assert`/`throw` sites map to non-zero codes
-(`ODINN_ERR_MAXITERS` ⇔ solver retcode assert `inversion_utils.jl:569`; `ODINN_ERR_NONFINITE`).
