@@ -49,3 +49,15 @@ def test_product_path_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), f"{f} references the oracle"
+
+
+def test_julia_shim_binds_only_declared_symbols():
+    """julia/OdinnHIP.jl (the reference-side ccall binding, not executable here) and INTEGRATION.md
+    refer only to entry points that include/odinn_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "odinn_hip.h")).read()
+    declared = set(re.findall(r"\b(odinn_[A-Za-z0-9_]+)\s*\(", hdr))
+    for rel in ("julia/OdinnHIP.jl", "INTEGRATION.md"):
+        txt = open(os.path.join(ROOT, rel)).read()
+        used = set(re.findall(r"\(:(odinn_[A-Za-z0-9_]+),\s*lib\)", txt))
+        assert used, rel
+        assert used <= declared, (rel, sorted(used - declared))
