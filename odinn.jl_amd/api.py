@@ -224,8 +224,9 @@ class UDEparameters:
     """src/parameters/UDEparameters.jl:60-80.  grad: DiscreteAdjoint() or ContinuousAdjoint() (the
     reference's default), both with the hand-written DiscreteVJP stencils."""
 
-    grad: object = field(default_factory=DiscreteAdjoint)
-    empirical_loss_function: object = field(default_factory=LossH)  # LossH | LossV | LossHV
+    grad: object = field(default_factory=lambda: ContinuousAdjoint())  # the reference's default (UDEparameters.jl:63)
+    # LossH | LossV | LossHV | MultiLoss; the reference's default is MultiLoss(losses = (LossH(),), λs = (1.0,))
+    empirical_loss_function: object = field(default_factory=lambda: MultiLoss())
     target: str = "A"  # :A | :D_hybrid | :D
     optimization_method: str = "AD+AD"
     initial_condition_filter: str = "identity"  # :identity | :softplus | :Zang1980 (UDEparameters.jl:67)

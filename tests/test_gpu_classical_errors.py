@@ -18,9 +18,11 @@ def _glaciers(odinn, shapes, As):
 
 
 def _params(odinn, k=7, step=1.0 / 96.0, epochs=60):
-    return odinn.Parameters(simulation=odinn.SimulationParameters(tspan=(2010.0, 2010.0 + (k - 1) * step)),
-                            solver=odinn.SolverParameters(reltol=1e-10, step=step),
-                            hyper=odinn.Hyperparameters(optimizer=odinn.LBFGS(), epochs=epochs))
+    p = odinn.Parameters(simulation=odinn.SimulationParameters(tspan=(2010.0, 2010.0 + (k - 1) * step)),
+                         solver=odinn.SolverParameters(reltol=1e-10, step=step),
+                         hyper=odinn.Hyperparameters(optimizer=odinn.LBFGS(), epochs=epochs))
+    p.UDE.grad = odinn.DiscreteAdjoint()  # compared with the oracle's discrete reverse loop
+    return p
 
 
 def test_glacier_wide_inversion_gradient_and_recovery(gpu):

@@ -29,6 +29,7 @@ def _setup(gpu, filt="identity", k=5, step=1.0 / 96.0):
                        solver=gpu.SolverParameters(reltol=1e-10, step=step),
                        hyper=gpu.Hyperparameters(optimizer=gpu.LBFGS(), epochs=25))
     p.UDE.initial_condition_filter = filt
+    p.UDE.grad = gpu.DiscreteAdjoint()  # compared with the oracle's discrete reverse loop
     gl = []
     for kk, (nx, ny) in enumerate([(48, 40), (40, 32)]):
         H0, B = O.synthetic_alpine(nx, ny, hmax=160.0, slope=0.1)

@@ -120,7 +120,7 @@ def test_training_result_file_and_scalar_log(odinn, tmp_path):
     res = odinn.load_inversion_file(str(tmp_path / "_inversion_result.npz"))
     assert np.array_equal(res.θ, th + 2) and len(res.θ_hist) == 3 and len(res.grad_hist) == 3
     assert res.losses == [10.0, 5.0, 10.0 / 3] and np.array_equal(res.grad_hist[2], np.full(5, 1.0))
-    assert res.params["solver"]["reltol"] == p.solver.reltol and res.params["UDE"]["grad"]["__type__"] == "DiscreteAdjoint"
+    assert res.params["solver"]["reltol"] == p.solver.reltol and res.params["UDE"]["grad"]["__type__"] == "ContinuousAdjoint"
     rows = [json.loads(l) for l in open(tmp_path / "run" / "scalars.jsonl")]
     assert [r["tag"] for r in rows[:2]] == ["train/loss", "train/norm_grad"] and rows[0]["step"] == 1
     assert sum(r["tag"] == "train/time_per_iter" for r in rows) == 2  # not on the first call (callback_utils.jl:93)
