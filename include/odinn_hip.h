@@ -222,7 +222,8 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
  * reverse ODE dlam/dtau = J_H(H_itp(-tau))^T lam integrated on the device with adaptive RDPK3Sp35,
  * H interpolated linearly between the forward snapshots (:287), loss and mass-balance terms added
  * at the snapshot times (:331-365, :413-432), dL/dtheta = Gauss-Legendre quadrature of
- * J_theta(H_itp(t))^T lam(t) (:497-503).  LossH only (ODINN_ERR_UNSUPPORTED otherwise).
+ * J_theta(H_itp(t))^T lam(t) (:497-503); with LossV / LossHV also of dl_V/dtheta on reference velocities
+ * interpolated linearly in time (:291-301, :475-503; the data must then span tspan).
  * stats / stats_rev: forward / reverse solve statistics per glacier (may be NULL). */
 int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops,
                                int n_mb, const double* mb_times, const odinn_solver_opts* opts,

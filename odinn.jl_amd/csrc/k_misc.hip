@@ -58,6 +58,13 @@ void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double d
 void launch_set_dt(int G, hipStream_t st, Pools P, double dt) {
   hipLaunchKernelGGL(k_set_dt, dim3((G + 63) / 64), dim3(64), 0, st, P, G, dt);
 }
+void launch_vref_itp(int nblk, hipStream_t st, Pools P, VItpArgs A) {
+  hipLaunchKernelGGL(k_vref_itp, dim3(nblk), dim3(NT), 0, st, P, A);
+}
+void launch_vref_scale(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq,
+                       double* scale_out, double* w_out) {
+  hipLaunchKernelGGL(k_vref_scale, dim3(G), dim3(64), 0, st, P, adj, slotA, G, scale_loss, wq, scale_out, w_out);
+}
 void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot) {
   hipLaunchKernelGGL(k_adj_begin, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, n_snap, tau0, mb_flag, mb_slot);
 }

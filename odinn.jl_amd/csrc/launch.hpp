@@ -53,6 +53,9 @@ void launch_initdt_norms(int nblk, hipStream_t st, Pools P, const double* U, con
 void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan, double dtmax, double* dt0store);
 void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double dtmax, double dt_given);
 void launch_set_dt(int G, hipStream_t st, Pools P, double dt);
+void launch_vref_itp(int nblk, hipStream_t st, Pools P, VItpArgs A);
+void launch_vref_scale(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq,
+                       double* scale_out, double* w_out);
 void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot);
 void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, int all_at_end);
 void launch_tikhonov(hipStream_t st, const double* a, const unsigned char* mask, double* r, double* grad,

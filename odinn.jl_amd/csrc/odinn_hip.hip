@@ -187,6 +187,10 @@ struct odinn_batch {
   int tab_cap = 0;
   double* d_partsteps = nullptr;  // [k][4*ntiles] per-step partials of the discrete reverse loop
   size_t partsteps_cap = 0;
+  // continuous adjoint with a velocity loss
+  int *d_rvA = nullptr, *d_rvB = nullptr, *d_zeroslot = nullptr;
+  double *d_rvs = nullptr, *d_Vq = nullptr, *d_vscq = nullptr, *d_wvq = nullptr;
+  size_t rv_cap = 0;
   // Tikhonov regulariser scratch
   double *d_rega = nullptr, *d_regr = nullptr, *d_regg = nullptr, *d_regp = nullptr;
   unsigned char* d_regm = nullptr;
@@ -847,6 +851,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
   dfree(b->d_rmbs); dfree(b->d_adj);
   dfree(b->d_partsteps);
+  dfree(b->d_rvA); dfree(b->d_rvB); dfree(b->d_zeroslot); dfree(b->d_rvs); dfree(b->d_Vq); dfree(b->d_vscq); dfree(b->d_wvq);
   dfree(b->d_rega); dfree(b->d_regr); dfree(b->d_regg); dfree(b->d_regp); dfree(b->d_regm);
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
@@ -1467,8 +1472,8 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
                                const double* mb_times, const odinn_solver_opts* opts, const odinn_adjoint_opts* aopts,
                                double* loss, double* dtheta, odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
   if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
-  if (b->loss_kind != ODINN_LOSS_H)
-    return fail(ODINN_ERR_UNSUPPORTED, "the continuous adjoint is implemented for LossH only");
+  const bool useV = b->loss_kind != ODINN_LOSS_H;
+  if (useV && b->law_kind >= ODINN_LAW_NN_Y) return fail(ODINN_ERR_STATE, "LossV needs an A-type law (target :A)");
   odinn_adjoint_opts ao{1e-8, 1e-8, 1.0 / 12.0, 200, 0, 1000000};  // AdjointTypes.jl:58-67
   if (aopts) ao = *aopts;
   if (ao.reltol <= 0) ao.reltol = 1e-8;
@@ -1514,6 +1519,40 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   HIPCHK(hipMemcpyAsync(b->d_rmbs, h_mbs.data(), nr * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_tsnap, tstops, k * sizeof(double), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemsetAsync(b->d_qw, 0, sizeof(double) * G, b->stream));
+  // velocity loss: per (reverse stop, glacier) the bracketing reference maps of a quadrature node
+  // (interpolate((tV_ref,), V_ref, Gridded(Linear())), or the single map; gradient.jl:291-301)
+  std::vector<int> h_vA, h_vB;
+  std::vector<double> h_vs;
+  if (useV) {
+    h_vA.assign((size_t)nr * G, -1); h_vB.assign((size_t)nr * G, 0); h_vs.assign((size_t)nr * G, 0.0);
+    for (int i = 0; i < nr; ++i) {
+      if (st[i].snap >= 0) continue;
+      const double tn = -st[i].tau;
+      for (int g = 0; g < G; ++g) {
+        const std::vector<double>& tv = b->t_vref[g];
+        const size_t q = (size_t)i * G + g;
+        if (tv.empty()) continue;
+        if (tv.size() == 1) { h_vA[q] = 0; h_vB[q] = 0; continue; }
+        if (tn < tv.front() || tn > tv.back())
+          return fail(ODINN_ERR_ARG, "glacier %d: the velocity data must span tspan for the continuous adjoint "
+                                     "(linear interpolation in time does not extrapolate)", g);
+        size_t m = 0;
+        while (m + 2 < tv.size() && tn > tv[m + 1]) ++m;
+        h_vA[q] = (int)m; h_vB[q] = (int)m + 1;
+        h_vs[q] = (tn - tv[m]) / (tv[m + 1] - tv[m]);
+      }
+    }
+    const size_t n = (size_t)nr * G;
+    if (n > b->rv_cap) {
+      dfree(b->d_rvA); dfree(b->d_rvB); dfree(b->d_rvs);
+      CHK(dalloc(&b->d_rvA, n)); CHK(dalloc(&b->d_rvB, n)); CHK(dalloc(&b->d_rvs, n));
+      b->rv_cap = n;
+    }
+    if (!b->d_Vq) { CHK(dalloc(&b->d_Vq, 3 * (size_t)b->ntot)); CHK(dalloc(&b->d_vscq, G)); CHK(dalloc(&b->d_wvq, G)); CHK(dalloc(&b->d_zeroslot, G)); }
+    HIPCHK(hipMemcpyAsync(b->d_rvA, h_vA.data(), n * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_rvB, h_vB.data(), n * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_rvs, h_vs.data(), n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  }
   HIPCHK(hipStreamSynchronize(b->stream));  // the staging vectors die with this scope
 
   const Pools Pl = b->pools(true);
@@ -1526,8 +1565,29 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = b->d_tmpA;
   const bool mb_last = b->any_mb && b->mb_flag[k - 1];
   launch_adj_begin(G, b->stream, Pl, b->d_adj, k, h_tau[0], mb_last ? 1 : 0, mb_last ? b->mb_slot[k - 1] : 0);
+  // loss term of a velocity-data snapshot: lam += wV dl_V/dH(H_j)  (backward_loss(::LossV), Losses.jl:338-390)
+  VArgs VS{};
+  if (useV) {
+    VS.Vabs = b->d_Vabs; VS.Vxr = b->d_Vxr; VS.Vyr = b->d_Vyr; VS.wv = b->d_wv; VS.scale = b->d_vsc; VS.refslot = b->d_vslot;
+    VS.ntot = b->ntot; VS.component_abs = b->v_abs; VS.Gacc = nullptr; VS.adj = b->d_adj; VS.G = G;
+    VS.H = b->d_snaps + (size_t)(k - 1) * b->ntot; VS.out = b->d_lam[0];
+    launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, VS, 0);  // at t1 the losses come before the MB VJP
+    VS.H = b->d_tmpA;
+  }
   launch_adj_poststep(b->ntiles, b->stream, Pl, AP, b->d_lam[0], b->d_lam[1]);
   AP.loss_first = 0;
+  // theta-part of the velocity loss at the quadrature nodes (Delta-t = 1; LossHV: x scaling)
+  VItpArgs VI{};
+  VArgs VQ{};
+  if (useV) {
+    VI.Vabs = b->d_Vabs; VI.Vxr = b->d_Vxr; VI.Vyr = b->d_Vyr; VI.ntot = b->ntot; VI.slotA = b->d_rvA; VI.slotB = b->d_rvB;
+    VI.sw = b->d_rvs; VI.G = G; VI.adj = b->d_adj; VI.Vq = b->d_Vq;
+    VQ.H = b->d_tmpA; VQ.out = b->d_tmpB; VQ.Vabs = b->d_Vq; VQ.Vxr = b->d_Vq + b->ntot; VQ.Vyr = b->d_Vq + 2 * b->ntot;
+    VQ.wv = b->d_wvq; VQ.scale = b->d_vscq; VQ.refslot = b->d_zeroslot; VQ.ntot = b->ntot; VQ.component_abs = b->v_abs;
+    VQ.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
+    HIPCHK(hipMemsetAsync(b->d_tmpB, 0, (size_t)b->ntot * sizeof(double), b->stream));
+  }
+  const double wq = b->loss_kind == ODINN_LOSS_HV ? b->hv_scaling : 1.0;
   // ---- initial step (ode_determine_initdt on the reverse problem) ----
   const double tspan = t1 - t0;
   long long nrhs_extra = 0;
@@ -1586,6 +1646,14 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       C.next_cur = 1 - p;
       launch_controller(G, b->stream, Pl, C);
       launch_adj_poststep(b->ntiles, b->stream, Pl, AP, b->d_lam[0], b->d_lam[1]);
+      if (useV) {
+        VS.out = a1;
+        launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, VS, 0);                       // snapshot stops
+        launch_vref_itp(b->ntiles, b->stream, Pl, VI);                                  // quadrature nodes
+        launch_vref_scale(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_vscq, b->d_wvq);
+        launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, VQ, 0);
+        launch_sum_part(G, b->stream, Pl, 3, b->d_Gsum, 1, 0);
+      }
       // quadrature node reached: dtheta += w * J_theta(H_itp(t))^T lam(t)  (:497-503); A-type laws add
       // onto per-tile running sums that are reduced once after the solve
       CHK(theta_vjp_launch(b, b->d_tmpA, a1, b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace));

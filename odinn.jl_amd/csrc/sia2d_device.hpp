@@ -1081,6 +1081,19 @@ struct PostArgs {
   const double* Sref;      // pooled (may be null)
 };
 
+// arguments of k_vref_itp (continuous adjoint with a velocity loss)
+struct VItpArgs {
+  const double* Vabs;   // [n_vref][ntot]
+  const double* Vxr;
+  const double* Vyr;
+  long long ntot;
+  const int* slotA;     // [n_rstop][G]; -1: this glacier has no velocity data
+  const int* slotB;
+  const double* sw;     // interpolation weight inside [slotA, slotB]
+  int G;
+  const AdjState* adj;
+  double* Vq;           // 3 x ntot out: Vabs, Vx, Vy
+};
 // post-step arguments of the reverse (continuous-adjoint) solve, see k_adj_poststep
 struct AdjPostArgs {
   const AdjState* adj;
@@ -2033,7 +2046,7 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
         if (!A.loss_first) l += dl;
         U[id] = l;
       }
-      if (a.qw != 0.0) {
+      if (a.qw != 0.0 || a.snapj >= 0) {  // H_itp at the stop, for the theta-VJP / the velocity loss term
         const double ha = A.snaps[(long long)a.seg_stop * A.ntot + id];
         const double hb = A.snaps[(long long)(a.seg_stop + 1) * A.ntot + id];
         A.Hq[id] = fma(a.s_stop, hb - ha, ha);
@@ -2088,6 +2101,69 @@ __global__ __launch_bounds__(NT) void k_tikhonov_bwd(const double* __restrict__ 
                                                      int ny, double wx, double wy) {
   const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * NW + (threadIdx.x >> 6);
   if (i < nx && j < ny) grad[i + (long long)nx * j] = lap9(r, nx, i, j, wx, wy, true, ny);
+}
+
+
+// ---- continuous adjoint with a velocity loss: the theta-part of the loss at a quadrature node ------
+// (gradient.jl:475-503: backward_loss at t_node with the reference velocities interpolated linearly in
+// time, :291-301).  k_vref_itp writes the interpolated (Vabs, Vx, Vy) of the glaciers that just reached
+// a node and the partial sums for LossV's normalisation (Losses.jl:323-326); k_vref_scale turns them
+// into per-glacier scale and weight for k_surfV_vjp<1>.
+__global__ __launch_bounds__(NT) void k_vref_itp(Pools P, VItpArgs A) {
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  double* pp = P.part + 4 * (long long)t4.w;
+  const bool at_node = gs->at_stop && A.adj[t4.x].qw != 0.0;
+  const long long q = (long long)(gs->istop - 1) * A.G + t4.x;
+  const int sa = at_node ? A.slotA[q] : -1;
+  if (sa < 0) {
+    if (threadIdx.x == 0) { pp[0] = 0.0; pp[1] = 0.0; }
+    return;
+  }
+  const GDev g = P.gd[t4.x];
+  const long long oa = (long long)sa * A.ntot, ob = (long long)A.slotB[q] * A.ntot;
+  const double w = A.sw[q];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  const int tx = threadIdx.x & 63, ty = wave_id();
+  const int gi = i0 + tx;
+  double ss = 0.0, cnt = 0.0;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = j0 + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      auto lerp = [&](const double* f) { const double a = f[oa + id]; return w == 0.0 ? a : fma(w, f[ob + id] - a, a); };
+      const double va = lerp(A.Vabs), vx = lerp(A.Vxr), vy = lerp(A.Vyr);
+      A.Vq[id] = va;
+      A.Vq[A.ntot + id] = vx;
+      A.Vq[2 * A.ntot + id] = vy;
+      if (va > 0.0) { ss = fma(vx, vx, fma(vy, vy, ss)); cnt += 1.0; }
+    }
+  }
+  const double t0 = block_sum(ss, red);
+  const double t1 = block_sum(cnt, red);
+  if (threadIdx.x == 0) { pp[0] = t0; pp[1] = t1; }
+}
+// per glacier: scale = 1/sqrt(mean_{mask} |Vref|^2) (or 1), weight = quadrature weight x wq (0 when not at a node)
+__global__ __launch_bounds__(64) void k_vref_scale(Pools P, const AdjState* adj, const int* slotA, int G, int scale_loss,
+                                                   double wq, double* scale_out, double* w_out) {
+  const int gidx = blockIdx.x;
+  const GDev g = P.gd[gidx];
+  const GState* gs = P.gs + gidx;
+  const bool at_node = gs->at_stop && adj[gidx].qw != 0.0 && slotA[(long long)(gs->istop - 1) * G + gidx] >= 0;
+  double ss = 0.0, cnt = 0.0;
+  if (at_node)
+    for (int k = threadIdx.x; k < g.ntiles; k += 64) {
+      ss += P.part[4 * (long long)(g.tile0 + k)];
+      cnt += P.part[4 * (long long)(g.tile0 + k) + 1];
+    }
+  ss = wave_sum(ss);
+  cnt = wave_sum(cnt);
+  if (threadIdx.x == 0) {
+    scale_out[gidx] = (scale_loss && cnt > 0.0 && ss > 0.0) ? 1.0 / sqrt(ss / cnt) : 1.0;
+    w_out[gidx] = at_node ? adj[gidx].qw * wq : 0.0;
+  }
 }
 
 #endif  // ODINN_MISC_KERNELS

@@ -89,6 +89,10 @@ struct VArgs {
   long long ntot;
   int component_abs;      // 0: :xy, 1: :abs
   double* Gacc;           // gridded-A accumulator or null
+  // continuous adjoint, loss term at a snapshot time: wv / scale / refslot are the full [n_snap][G] tables and
+  // the row is the snapshot the glacier's reverse solve just reached (nothing to do otherwise)
+  const AdjState* adj;
+  int G;
 };
 
 template <int MODE, int LM>
@@ -101,7 +105,17 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
   const GDev g = P.gd[t4.x];
   double wv = 1.0, sc = 1.0;
   long long roff = 0;
-  if (MODE == 1) {
+  if (MODE == 1 && A.adj) {
+    const int j = A.adj[t4.x].snapj;
+    const long long q = (long long)j * A.G + t4.x;
+    wv = (P.gs[t4.x].at_stop && j >= 0) ? A.wv[q] : 0.0;
+    if (wv == 0.0) {
+      if (threadIdx.x == 0) { P.part[4 * (long long)t4.w + 3] = 0.0; P.part[4 * (long long)t4.w + 1] = 0.0; }
+      return;
+    }
+    sc = A.scale[q];
+    roff = (long long)A.refslot[q] * A.ntot;
+  } else if (MODE == 1) {
     wv = A.wv[t4.x];
     if (wv == 0.0) {  // no velocity data at this stop for this glacier
       if (threadIdx.x == 0) { P.part[4 * (long long)t4.w + 3] = 0.0; P.part[4 * (long long)t4.w + 1] = 0.0; }

@@ -1068,25 +1068,47 @@ def linear_itp(ts, fields, t):
 
 
 def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, adj: ContinuousAdjointCfg = None,
-                             theta=None, vjp="discrete"):
-    """SIA2D_grad_batch! with ContinuousAdjoint(VJP_method = DiscreteVJP()) and LossH
-    (gradient.jl:276-539).  Returns (loss, dL/dtheta, lambda(t0), stats of the reverse solve)."""
+                             theta=None, vjp="discrete", V_ref=None, tV_ref=(), vspec=None, loss_kind="H", scaling=1.0):
+    """SIA2D_grad_batch! with ContinuousAdjoint (gradient.jl:276-539) for LossH, LossV or LossHV.
+    Returns (loss, dL/dtheta, lambda(t0), stats of the reverse solve).
+
+    Thickness / velocity terms enter lambda at their data times with the Delta-t weights of the discrete
+    loss (:331-365); the explicit theta-dependence of the velocity loss is integrated by the quadrature
+    with Delta-t = 1 and the reference velocities interpolated linearly in time (:475-503, :291-301) --
+    which needs velocity data spanning tspan (Gridded(Linear()) does not extrapolate) unless there is a
+    single velocity map (constant interpolator)."""
     adj = adj or ContinuousAdjointCfg()
     snaps, st, inc = forward(gl, law, cfg, theta)
     t = [float(x) for x in cfg.tstops]
     k = len(t)
     N = float(gl.B.size)
-    w = loss_weights(t, tH_ref)
+    useH, useV = loss_kind in ("H", "HV"), loss_kind in ("V", "HV")
+    dtH = loss_weights(t, tH_ref) if useH else [0.0] * k
+    dtV = loss_weights(t, tV_ref) if useV else [0.0] * k
+    wH = [d * d if loss_kind == "HV" else d for d in dtH]          # Losses.jl:407,424-431
+    wV = [scaling * d * d if loss_kind == "HV" else d for d in dtV]
+    wq = scaling if loss_kind == "HV" else 1.0                     # quadrature: Delta-t = (1, 1)  (:474)
     tH = [float(x) for x in tH_ref]
+    tV = [float(x) for x in tV_ref]
     mbt = set(float(x) for x in cfg.mb_times) if cfg.mb is not None else set()
     H_itp = lambda tt: linear_itp(t, snaps, tt)  # :287
 
-    def effect_loss(tt, u):  # :331-365; dt weight included, first data time has weight 0
-        if tt in tH:
-            j = t.index(tt)
-            if w[j] != 0.0:
-                Hr = H_ref[tH.index(tt)]
-                return u + l2sum_backward(H_itp(tt), Hr, is_in_glacier(Hr, cfg.loss_distance), N) * w[j]
+    def V_itp(tt):  # :291-301
+        if len(tV) == 1:
+            return V_ref[0]
+        if not (tV[0] <= tt <= tV[-1]):
+            raise ValueError("velocity data must span tspan (Gridded(Linear()) does not extrapolate)")
+        return tuple(linear_itp(tV, [v[c] for v in V_ref], tt) for c in range(3))
+
+    def effect_loss(tt, u):  # :331-365; dt weights included, first data time has weight 0
+        j = t.index(tt)
+        if wH[j] != 0.0:
+            Hr = H_ref[tH.index(tt)]
+            u = u + l2sum_backward(H_itp(tt), Hr, is_in_glacier(Hr, cfg.loss_distance), N) * wH[j]
+        if wV[j] != 0.0:
+            Va, Vxr, Vyr = V_ref[tV.index(tt)]
+            gH, _ = backward_loss_V(vspec, H_itp(tt), gl.B, gl.dx, gl.dy, gl.phys, law, Va, Vxr, Vyr, N, theta)
+            u = u + gH * wV[j]
         return u
 
     def effect_mb(tt, u):  # :413-425
@@ -1107,9 +1129,26 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
     dLdtheta = np.zeros(P)
     at = {tau: i for i, tau in enumerate(stops)}
     for tn, wn in zip(nodes, wts):  # :497-503
-        lam = lam_s[at[-float(tn)]]
-        dLdtheta += wn * vjp_theta(lam, H_itp(float(tn)), gl.B, gl.dx, gl.dy, gl.phys, law, theta)
-    loss = loss_H(snaps, t, H_ref, tH_ref, cfg.loss_distance)
+        tn = float(tn)
+        lam = lam_s[at[-tn]]
+        Hn = H_itp(tn)
+        g = vjp_theta(lam, Hn, gl.B, gl.dx, gl.dy, gl.phys, law, theta)
+        if useV:
+            Va, Vxr, Vyr = V_itp(tn)
+            _, gth = backward_loss_V(vspec, Hn, gl.B, gl.dx, gl.dy, gl.phys, law, Va, Vxr, Vyr, N, theta)
+            g = g + wq * gth
+        dLdtheta += wn * g
+    loss = 0.0
+    if useH:
+        for j in range(k):
+            if wH[j] != 0.0:
+                Hr = H_ref[tH.index(t[j])]
+                loss += l2sum_loss(snaps[j], Hr, is_in_glacier(Hr, cfg.loss_distance), N) * wH[j]
+    if useV:
+        for j in range(k):
+            if wV[j] != 0.0:
+                Va, Vxr, Vyr = V_ref[tV.index(t[j])]
+                loss += loss_V(vspec, snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, Va, Vxr, Vyr, N, theta) * wV[j]
     return loss, dLdtheta, lam_s[-1], st_rev
 
 

@@ -97,15 +97,55 @@ def test_continuous_adjoint_ragged_batch_and_other_laws(gpu):
     b.close()
 
 
-def test_continuous_adjoint_rejects_velocity_losses(gpu):
-    H0, B = O.synthetic_valley(32, 24, 50.0)
-    b = gpu.GlacierBatch([(32, 24)], [50.0])
+@pytest.mark.parametrize("kind,component,scale", [("V", "xy", True), ("V", "abs", False), ("HV", "xy", True)])
+def test_continuous_adjoint_with_velocity_losses(gpu, kind, component, scale):
+    """ContinuousAdjoint with LossV / LossHV (gradient.jl:291-301, 331-365, 475-503): the velocity term
+    enters lambda at the velocity-data snapshots; its explicit theta-dependence is integrated by the
+    quadrature with the reference velocities interpolated linearly in time.  Against the oracle."""
+    from test_gpu_velocity import _velocity_case
+
+    ph = O.Phys()
+    nx, ny = 64, 48
+    H0, B, ts, mlp, th_true, th0, gl, cfg, ref, tV, Vref = _velocity_case(nx, ny, ph)
+    # velocity maps at every snapshot: the interpolant must span tspan
+    law_t = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th_true, T=-3.0)
+    tV = list(ts)
+    Vref = []
+    for j in range(len(ts)):
+        Vx, Vy, V = O.V_from_H(ref[j], B, 50.0, 50.0, ph, law_t)
+        Vref.append((V, Vx, Vy))
+    vspec = O.LossVSpec(component=component, scale_loss=scale)
+    law0 = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th0, T=-3.0)
+    Lo, go, lam0, st = O.loss_and_grad_continuous(gl, law0, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=12),
+                                                  V_ref=Vref, tV_ref=tV, vspec=vspec, loss_kind=kind, scaling=2.5)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-3.0])
     b.set_fields(0, H0, B)
-    b.set_reference(0, [2010.0, 2010.1], [H0, H0], 3)
-    b.set_loss(gpu._lib.LOSS_V)
+    b.set_law(gpu.LAW_NN_A_SCALAR, gpu.MLPSpec(mlp.widths, mlp.acts, None, O.POST_AFFINE, ph.minA, ph.maxA), th0)
+    b.set_reference(0, ts, ref, 3)
+    b.set_velocity_reference(0, tV, [v[0] for v in Vref], [v[1] for v in Vref], [v[2] for v in Vref])
+    b.set_loss({"V": gpu._lib.LOSS_V, "HV": gpu._lib.LOSS_HV}[kind], component, scale, 2.5)
+    Lg, gg = b.loss_grad_continuous(ts, theta=th0, reltol=1e-10, n_quadrature=12)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo), (Lg, Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-9 and relerr < 1e-5, (ratio, angle, relerr)
+    assert rel_l2(b.lambda0(0), lam0) < 1e-5
+    b.close()
+
+
+def test_continuous_adjoint_needs_velocity_data_spanning_tspan(gpu):
+    from test_gpu_velocity import _velocity_case
+
+    ph = O.Phys()
+    H0, B, ts, mlp, th_true, th0, gl, cfg, ref, tV, Vref = _velocity_case(64, 48, ph)
+    b = gpu.GlacierBatch([(64, 48)], [50.0], T=[-3.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_A_SCALAR, gpu.MLPSpec(mlp.widths, mlp.acts, None, O.POST_AFFINE, ph.minA, ph.maxA), th0)
+    b.set_reference(0, ts, ref, 3)
+    b.set_velocity_reference(0, tV, [v[0] for v in Vref], [v[1] for v in Vref], [v[2] for v in Vref])  # tV = ts[2::2]
+    b.set_loss(gpu._lib.LOSS_V, "xy", True, 1.0)
     with pytest.raises(Exception) as e:
-        b.loss_grad_continuous([2010.0, 2010.1])
-    assert "LossH" in str(e.value)
+        b.loss_grad_continuous(ts, theta=th0, n_quadrature=8)
+    assert "span tspan" in str(e.value)
     b.close()
 
 
