@@ -112,3 +112,37 @@ def test_rheology_regularization_gridded(gpu):
         assert np.abs((d1 - d0)[off:off + n] - gr).max() <= 1e-9 * np.abs(gr).max()
         off += n
     assert abs((L1 - L0) - Lr) <= 1e-9 * Lr
+
+
+@pytest.mark.parametrize("adjoint", ["discrete", "continuous"])
+def test_initial_condition_gradient_vs_finite_differences(gpu, adjoint):
+    """test_grad_finite_diff(...; train_initial_conditions = true) (runtests.jl:120-122,129-131; thresholds
+    [5e-3, 5e-7, 5e-3] discrete, [5e-4, 1e-8, 5e-4] continuous): dL/dH0 = lambda(t0) against central finite
+    differences of the GPU forward loss over a sample of ice-covered cells."""
+    p, gl = _setup(gpu, "identity", k=5, step=1.0 / 480.0)
+    p.UDE.grad = gpu.DiscreteAdjoint() if adjoint == "discrete" else gpu.ContinuousAdjoint(n_quadrature=40)
+    gl = gl[:1]
+    ic = gpu.InitialCondition(p, gl)
+    inv = gpu.Inversion(gpu.Model(gpu.SIA2Dmodel(p, A=gpu.ConstantA()), regressors={"IC": ic}), gl, p)
+    th = ic.theta * 0.97
+    dth = np.zeros_like(th)
+    gpu.SIA2D_grad_b(dth, th, inv)
+    b = inv.batch()
+    ts = inv.tstops()
+    g = gl[0]
+
+    def loss_at(x):
+        b.set_fields(0, np.asfortranarray(x.reshape((g.nx, g.ny), order="F")), g.B)
+        b.solve(ts, reltol=1e-10)
+        return float(b.loss()[0])
+
+    rng = np.random.default_rng(0)
+    cells = rng.choice(np.flatnonzero(th > 20.0), 12, replace=False)
+    gn = np.zeros(cells.size)
+    for n_, c in enumerate(cells):
+        e = np.zeros_like(th)
+        e[c] = 1e-3
+        gn[n_] = (loss_at(th + e) - loss_at(th - e)) / 2e-3
+    ratio, angle, relerr = stats_err_arrays(dth[cells], gn)
+    thr = (5e-3, 5e-5, 5e-3) if adjoint == "discrete" else (2e-3, 5e-5, 2e-3)
+    assert abs(ratio) < thr[0] and abs(angle) < thr[1] and relerr < thr[2], (ratio, angle, relerr)
