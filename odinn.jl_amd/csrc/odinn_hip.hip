@@ -200,6 +200,10 @@ struct odinn_batch {
   int *d_rsnap = nullptr, *d_rmbf = nullptr, *d_rmbs = nullptr;
   AdjState* d_adj = nullptr;
   int rev_cap = 0, tsnap_cap = 0;
+  // key of the loss tables currently on the device (upload_loss_tables)
+  const double* tab_key_ptr = nullptr;
+  long long tab_key_ver = -1, refs_version = 0;
+  std::vector<double> tab_key_tstops;
   bool solved = false;
   bool gd_dirty = true;
   std::vector<double> last_loss_g, last_G_g;
@@ -487,6 +491,10 @@ int ensure_tables(odinn_batch* b, int n_stops) {
 // LossH: wH = dtH; LossV: wV = dtV; LossHV: wH = dtH^2, wV = scaling*dtV^2 (Losses.jl:407,424-431
 // multiply by Dt once more on top of the inner losses).
 int upload_loss_tables(odinn_batch* b) {
+  // unchanged stops / reference data / loss selection since the last upload (every iteration of an
+  // inversion): the tables on the device are still valid -- saves six small copies and a sync per solve
+  if (b->tab_key_ptr == b->d_ws && b->d_ws && b->tab_key_ver == b->refs_version && b->tab_key_tstops == b->tstops)
+    return ODINN_OK;
   const int k = (int)b->tstops.size();
   const size_t n = (size_t)k * b->G;
   std::vector<double> dts(n, 0.0), ws(n, 0.0);
@@ -526,6 +534,7 @@ int upload_loss_tables(odinn_batch* b) {
   HIPCHK(hipMemcpyAsync(b->d_vsc, b->vsc_h.data(), n * sizeof(double), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_vslot, b->vslot_h.data(), n * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
+  b->tab_key_ptr = b->d_ws; b->tab_key_ver = b->refs_version; b->tab_key_tstops = b->tstops;
   return ODINN_OK;
 }
 
@@ -959,6 +968,7 @@ int odinn_set_law(odinn_batch* b, int kind, const odinn_mlp_desc* mlp, const dou
 }
 
 int odinn_set_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, const double* H_ref, int distance) {
+  if (b) b->refs_version++;
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (n_ref < 0 || (n_ref > 0 && (!t_ref || !H_ref))) return fail(ODINN_ERR_ARG, "bad reference data");
   if (n_ref > b->nref_alloc) {
@@ -1119,6 +1129,7 @@ int odinn_set_vjp_method(odinn_batch* b, int method) {
 }
 
 int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_loss, double hv_scaling) {
+  if (b) b->refs_version++;
   if (!b) return fail(ODINN_ERR_ARG, "null batch");
   if (kind < ODINN_LOSS_H || kind > ODINN_LOSS_HV) return fail(ODINN_ERR_ARG, "unknown loss kind %d", kind);
   b->loss_kind = kind; b->v_abs = v_component_abs ? 1 : 0; b->v_scale_loss = v_scale_loss ? 1 : 0;
@@ -1128,6 +1139,7 @@ int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_lo
 
 int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, const double* Vabs,
                                  const double* Vx, const double* Vy) {
+  if (b) b->refs_version++;
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (n_ref < 0 || (n_ref > 0 && (!t_ref || !Vabs || !Vx || !Vy))) return fail(ODINN_ERR_ARG, "bad velocity data");
   if (n_ref > b->nvref_alloc) {
