@@ -6,6 +6,7 @@
 #include "sia2d_velocity.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cmath>
 #include <cstdarg>
@@ -571,6 +572,9 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   if (n_stops < 2) return fail(ODINN_ERR_ARG, "need at least 2 tstops");
   for (int j = 1; j < n_stops; ++j)
     if (!(tstops[j] > tstops[j - 1])) return fail(ODINN_ERR_ARG, "tstops must be strictly increasing");
+  static const bool prof = std::getenv("ODINN_PROFILE_HOST") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tp0 = prof ? now() : 0.0, tp1 = 0, tp2 = 0, tp3 = 0, tp4 = 0;
   CHK(use_dev(b));
   CHK(refresh_gd(b));
   CHK(refresh_law_field(b));
@@ -610,6 +614,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   HIPCHK(hipMemcpyAsync(b->d_mb_flag, b->mb_flag.data(), n_stops * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_mb_slot, b->mb_slot.data(), n_stops * sizeof(int), hipMemcpyHostToDevice, b->stream));
   CHK(upload_loss_tables(b));
+  if (prof) { HIPCHK(hipStreamSynchronize(b->stream)); tp1 = now(); }
   // initial state and first snapshot
   const size_t fb = (size_t)b->ntot * sizeof(double);
   HIPCHK(hipMemcpyAsync(b->d_U[0], b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
@@ -629,6 +634,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
     nrhs_extra = 2;
   }
   launch_begin(b->G, b->stream, P, b->d_tstops, opt.dtmax, adaptive ? opt.dt0 : (euler ? 1.0 : opt.fixed_dt));
+  if (prof) { HIPCHK(hipStreamSynchronize(b->stream)); tp2 = now(); }
   int nact = b->G;
   HIPCHK(hipMemcpyAsync(b->d_nactive, &nact, sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipGetLastError());
@@ -655,6 +661,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   long long steps = 0;
   int p = 0;
   int chunk = std::max(2, std::min(256, (n_stops - 1 + 1) & ~1));
+  int polls = 0;
   while (nact > 0) {
     for (int s = 0; s < chunk; ++s) {
       if (scheme == 3) {
@@ -676,10 +683,18 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
     HIPCHK(hipMemcpyAsync(&nact, b->d_nactive, sizeof(int), hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (steps >= opt.maxiters && nact > 0) return fail(ODINN_ERR_MAXITERS, "maxiters (%lld) reached with %d glaciers active", (long long)opt.maxiters, nact);
-    chunk = 16;
+    // after the first batch the solve is usually a few steps from done (a rejection or two): 4, 8, then 16
+    chunk = polls == 0 ? 4 : (polls == 1 ? 8 : 16);
+    ++polls;
   }
+  if (prof) tp3 = now();
   std::vector<GState> gs(b->G);
   HIPCHK(hipMemcpy(gs.data(), b->d_gs, sizeof(GState) * b->G, hipMemcpyDeviceToHost));
+  if (prof) {
+    tp4 = now();
+    std::fprintf(stderr, "[odinn do_solve] setup %.0f us, initdt+begin %.0f us, steps(%lld) %.0f us, state readback %.0f us\n",
+                 tp1 - tp0, tp2 - tp1, steps, tp3 - tp2, tp4 - tp3);
+  }
   for (int g = 0; g < b->G; ++g) {
     if (gs[g].nonfinite) return fail(ODINN_ERR_NONFINITE, "non-finite error estimate in glacier %d", g);
     if (stats) {
