@@ -173,6 +173,62 @@ def main():
         "vjp_theta_GBs": 24.0 * cells / (ms_vjpt * 1e-3) / 1e9,
     }
 
+    # ---- cross-checks: what a plain device copy / triad reaches on this box, and the
+    #      PCIe-inclusive rate of the host-pointer seams (never part of `value`) ------------------
+    try:
+        dev = f"cuda:{local}"
+        nb = 1 << 27  # 1 GiB per fp64 array
+        xa = torch.full((nb,), 1.0, dtype=torch.float64, device=dev)
+        xb = torch.full((nb,), 2.0, dtype=torch.float64, device=dev)
+        xc = torch.empty_like(xa)
+
+        def _ev(fn, iters=10):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters
+
+        ms_copy = _ev(lambda: xc.copy_(xa))
+        ms_triad = _ev(lambda: torch.add(xa, xb, alpha=3.0, out=xc))
+        aux["hbm_copy_GBs_measured"] = 2 * 8.0 * nb / (ms_copy * 1e-3) / 1e9
+        aux["hbm_triad_GBs_measured"] = 3 * 8.0 * nb / (ms_triad * 1e-3) / 1e9
+        aux["hbm_crosscheck_note"] = ("torch device copy (R+W) / triad c = a + 3 b (2R+W) on 1 GiB fp64 arrays: the rate a "
+                                      "trivially streaming kernel reaches on this box, next to the 8 TB/s datasheet peak")
+        aux["rk_stage2_frac_of_measured_triad"] = ach / aux["hbm_triad_GBs_measured"]
+        del xa, xb, xc
+        torch.cuda.empty_cache()
+        # host-pointer seam: H, B (and dH back) cross PCIe on every call
+        Hh = gl[0][0]
+        b.dhdt(0, Hh)
+        tp0 = time.perf_counter()
+        for _ in range(5):
+            b.dhdt(0, Hh)
+        ms_host = (time.perf_counter() - tp0) / 5 * 1e3
+        tp0 = time.perf_counter()
+        for k, (H0, B, A) in enumerate(gl):
+            b.set_fields(k, H0, B)
+        b.sync()
+        ms_h2d = (time.perf_counter() - tp0) * 1e3
+        tp0 = time.perf_counter()
+        for k in range(G):
+            b.H(k)
+        ms_d2h = (time.perf_counter() - tp0) * 1e3
+        ms_job = args.steps * (elapsed / args.steps * 1e3)
+        aux["pcie_dhdt_host_pointers_ms_per_call"] = ms_host
+        aux["pcie_dhdt_host_pointers_cells_per_s"] = n * n / (ms_host * 1e-3)
+        aux["pcie_upload_H0_B_ms"] = ms_h2d
+        aux["pcie_download_H_ms"] = ms_d2h
+        aux["pcie_inclusive_cellsteps_per_s"] = 5.0 * cells * args.steps / ((ms_job + ms_h2d + ms_d2h) * 1e-3)
+        aux["pcie_note"] = (f"inclusive = upload H0,B of all {G} glaciers + {args.steps} resident steps + download H; "
+                            "pageable host memory; reported for reference, never part of `value`")
+    except Exception as e:
+        aux["crosscheck_error"] = str(e)[:200]
+
     # ---- untimed extra: grad-eval/s (forward solve + discrete adjoint + all-reduce) ------
     if not args.no_grad_eval:
       try:
