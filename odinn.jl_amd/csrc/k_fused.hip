@@ -9,7 +9,7 @@
 namespace odinn {
 void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
                                         double* U1, double* partF, double abstol, double reltol, int skip, int small) {
-  // small: FOX x FOYS "latency" tiles (tilesF / partF then belong to that table)
+  // small: 1 = FOX x FOYS "latency" tiles (tilesF / partF then belong to that table)
   if (small) {
     if (skip) hipLaunchKernelGGL((k_rk_fused<ODINN_LM, true, FOYS>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
     else hipLaunchKernelGGL((k_rk_fused<ODINN_LM, false, FOYS>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
@@ -18,4 +18,18 @@ void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev
     else hipLaunchKernelGGL((k_rk_fused<ODINN_LM, false, FOY>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
   }
 }
+#if ODINN_LM == 0
+// strip kernel (integer-power law) on the FOX x FOYT tile table
+void launch_rk_fused_strip(int nblk, int afield, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
+                           double* U1, double* partF, double abstol, double reltol, int skip) {
+#define ODINN_STRIP(SK, AF) \
+  hipLaunchKernelGGL((k_rk_fused_strip<SK, AF>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol)
+  if (afield) {
+    if (skip) ODINN_STRIP(true, true); else ODINN_STRIP(false, true);
+  } else {
+    if (skip) ODINN_STRIP(true, false); else ODINN_STRIP(false, false);
+  }
+#undef ODINN_STRIP
+}
+#endif
 }  // namespace odinn

@@ -128,17 +128,35 @@ struct odinn_batch {
   long long ntot = 0, ntotd = 0;
   int ntiles = 0;
   // device pools
-  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr;
-  int ntilesF = 0, ntilesFs = 0;
-  double *d_partF = nullptr, *d_partFs = nullptr;
+  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr;
+  int ntilesF = 0, ntilesFs = 0, ntilesFt = 0;
+  double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr;
   // the fused step runs on the small "latency" tiles when the throughput tiles cannot fill the 256 CUs
   // (ODINN_FUSED_TILES=small|large overrides)
+  mutable int fused_env = -1;  // ODINN_FUSED_TILES, parsed once: 0 unset, 1 small, 2 large, 3 strip
+  int fused_override() const {
+    if (fused_env < 0) {
+      const char* e = std::getenv("ODINN_FUSED_TILES");
+      fused_env = !e ? 0 : e[0] == 's' ? 1 : e[0] == 'l' ? 2 : e[0] == 't' ? 3 : 0;
+    }
+    return fused_env;
+  }
   bool small_tiles() const {
-    const char* e = std::getenv("ODINN_FUSED_TILES");
-    if (e && e[0] == 's') return true;
-    if (e && e[0] == 'l') return false;
+    const int o = fused_override();
+    if (o) return o == 1;
     return ntilesF <= 256;
   }
+  // which fused-step kernel / tile table: 0 = FOX x FOY row-interleaved, 1 = FOX x FOYS latency tiles,
+  // 2 = FOX x FOYT strip kernel (integer-power law; ODINN_FUSED_TILES=large forces 0)
+  int fused_kind() const {
+    if (small_tiles()) return 1;
+    if (fused_override() == 2) return 0;
+    return lm() == 0 ? 2 : 0;
+  }
+  const int4* fused_tiles() const { const int k = fused_kind(); return k == 2 ? d_tilesFt : k == 1 ? d_tilesFs : d_tilesF; }
+  double* fused_part() const { const int k = fused_kind(); return k == 2 ? d_partFt : k == 1 ? d_partFs : d_partF; }
+  int fused_ntiles() const { const int k = fused_kind(); return k == 2 ? ntilesFt : k == 1 ? ntilesFs : ntilesF; }
+  int fused_ctrl() const { const int k = fused_kind(); return k == 2 ? 3 : k == 1 ? 2 : 1; }
   GDev* d_gd = nullptr;
   GState* d_gs = nullptr;
   double *d_B = nullptr, *d_H0 = nullptr, *d_Afield = nullptr, *d_Tfield = nullptr, *d_Gacc = nullptr;
@@ -458,11 +476,13 @@ int pick_scheme(const odinn_batch* b, int requested) {
 int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip) {
   const Pools P = b->pools(true);
   const LawDev L = b->lawdev();
-  const int small = b->small_tiles() ? 1 : 0;
-  const int nblk = small ? b->ntilesFs : b->ntilesF;
-  const int4* tiles = small ? b->d_tilesFs : b->d_tilesF;
-  double* part = small ? b->d_partFs : b->d_partF;
-  if (b->lm() == 0)
+  const int small = b->fused_kind();
+  const int nblk = b->fused_ntiles();
+  const int4* tiles = b->fused_tiles();
+  double* part = b->fused_part();
+  if (small == 2)
+    launch_rk_fused_strip(nblk, b->gd[0].use_Afield, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip);
+  else if (b->lm() == 0)
     launch_rk_fused_lm0(nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
   else
     launch_rk_fused_lm1(nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
@@ -643,8 +663,8 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   CtrlArgs C{};
   C.tstops = b->d_tstops; C.n_stops = n_stops; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
   C.dtmax = opt.dtmax; C.adaptive = adaptive ? 1 : 0; C.fixed_dt = opt.fixed_dt; C.n_active = b->d_nactive;
-  C.errpart = scheme == 2 ? (b->small_tiles() ? b->d_partFs : b->d_partF) : b->d_part;
-  C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? (b->small_tiles() ? 2 : 1) : 0;
+  C.errpart = scheme == 2 ? b->fused_part() : b->d_part;
+  C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? b->fused_ctrl() : 0;
   PostArgs A{};
   A.snaps = b->d_snaps; A.premb = b->d_premb; A.ntot = b->ntot; A.mb0 = b->d_mb0;
   A.Sref = b->any_sref ? b->d_Sref : nullptr;
@@ -811,13 +831,14 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   HIPCHK(hipMemcpy(b->d_tiles_nat, nat.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
   // tile tables of the fused-step kernel, same XCD-banded order: FOX x FOY "throughput" tiles and
   // FOX x FOYS "latency" tiles (used when the batch has too few throughput tiles to fill the GPU)
-  for (int small = 0; small < 2; ++small) {
-    const int foy = small ? FOYS : FOY;
+  for (int small = 0; small < 3; ++small) {
+    const int foy = small == 2 ? FOYT : small ? FOYS : FOY;
     std::vector<int4> natF;
     for (int g = 0; g < n_glaciers; ++g) {
       GDev& r = b->gd[g];
       const int fx = (r.nx + FOX - 1) / FOX, fy = (r.ny + foy - 1) / foy;
-      if (small) { r.tile0Fs = (int)natF.size(); r.ntilesFs = fx * fy; }
+      if (small == 2) { r.tile0Ft = (int)natF.size(); r.ntilesFt = fx * fy; }
+      else if (small) { r.tile0Fs = (int)natF.size(); r.ntilesFs = fx * fy; }
       else { r.tile0F = (int)natF.size(); r.ntilesF = fx * fy; }
       for (int ty = 0; ty < fy; ++ty)
         for (int tx = 0; tx < fx; ++tx) natF.push_back(make_int4(g, tx, ty, (int)natF.size()));
@@ -830,7 +851,12 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
         const int t = x * per + r;
         if (t < nF) swzF.push_back(natF[t]);
       }
-    if (small) {
+    if (small == 2) {
+      b->ntilesFt = nF;
+      CHK(dalloc(&b->d_tilesFt, (size_t)nF));
+      CHK(dalloc(&b->d_partFt, (size_t)nF));
+      HIPCHK(hipMemcpy(b->d_tilesFt, swzF.data(), sizeof(int4) * nF, hipMemcpyHostToDevice));
+    } else if (small) {
       b->ntilesFs = nF;
       CHK(dalloc(&b->d_tilesFs, (size_t)nF));
       CHK(dalloc(&b->d_partFs, (size_t)nF));
@@ -871,7 +897,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
-  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs);
+  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt);
   dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
   dfree(b->d_rmbs); dfree(b->d_adj);
   dfree(b->d_partsteps);
@@ -1819,8 +1845,8 @@ static int timed_one(odinn_batch* b, int which, int it) {
       CtrlArgs C{};
       C.tstops = b->d_tstops; C.n_stops = 2; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
       C.dtmax = 0.0; C.adaptive = 0; C.fixed_dt = 1e-6; C.n_active = b->d_nactive;
-      C.errpart = scheme == 2 ? (b->small_tiles() ? b->d_partFs : b->d_partF) : b->d_part;
-      C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? (b->small_tiles() ? 2 : 1) : 0;
+      C.errpart = scheme == 2 ? b->fused_part() : b->d_part;
+      C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? b->fused_ctrl() : 0;
       PostArgs PA;
       PA.snaps = b->d_tmpA; PA.premb = b->d_tmpB; PA.ntot = b->ntot; PA.mb0 = b->d_mb0; PA.Sref = nullptr;
       if (scheme == 2) {

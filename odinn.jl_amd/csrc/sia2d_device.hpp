@@ -54,6 +54,9 @@ constexpr int FOYS = 8;               // "latency" tile height: used when the ba
                                       // the GPU -- a workgroup then walks 18 region rows instead of 50
 constexpr int FNT = ODINN_FNT;        // threads per block
 constexpr int FNW = FNT / 64;
+constexpr int TRPT = 7;               // "strip" variant of the fused kernel (integer-power law): a wavefront owns
+constexpr int TRY = TRPT * FNW;       // TRPT CONTIGUOUS region rows, so the y-neighbours of a cell live in the
+constexpr int FOYT = TRY - 2 * FH;    // same thread's registers: 64 x 56 region, 54 x 46 output tile
 constexpr int FLD = FRX + 1;          // LDS row stride (odd)
 
 
@@ -94,6 +97,7 @@ struct GDev {  // per-glacier constants
   int nx, ny, ntx, nty, tile0, ntiles;
   int tile0F, ntilesF;  // range in the fused-step tile table (FOX x FOY output tiles)
   int tile0Fs, ntilesFs; // ... and in the table of FOX x FOYS "latency" tiles
+  int tile0Ft, ntilesFt; // ... and in the table of FOX x FOYT "strip" tiles
   long long off;   // offset of this glacier in the pooled primal arrays  [doubles]
   long long offd;  // offset in the pooled dual arrays
   double dx, dy, inv_dx, inv_dy, eta0;
@@ -674,21 +678,23 @@ __device__ __forceinline__ void load_tile_lam(const double* __restrict__ Lm, con
 // pS/pH point at the node's lower-left cell; LD = row stride of the cell tiles.
 // Cell tiles are stored interleaved as double2 {Hc, S} (16-B aligned) so that every stencil
 // access is ONE full-rate ds_read_b128 instead of two half-rate ds_read2_b64.
-template <int LD>
-__device__ __forceinline__ void node_geom(const GDev& g, const double2* p, double& gx, double& gy, double& Hb) {
-  const double2 c00 = p[0], c10 = p[1], c01 = p[LD], c11 = p[LD + 1];
+__device__ __forceinline__ void node_geom_vals(const GDev& g, double2 c00, double2 c10, double2 c01, double2 c11,
+                                               double& gx, double& gy, double& Hb) {
   gx = ((c10.y - c00.y) + (c11.y - c01.y)) * g.hinv_dx;
   gy = ((c01.y - c00.y) + (c11.y - c10.y)) * g.hinv_dy;
   Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
 }
-// dH/dt of an interior cell: p at the cell, pD at its north-east node; LDD = node row stride.
+template <int LD>
+__device__ __forceinline__ void node_geom(const GDev& g, const double2* p, double& gx, double& gy, double& Hb) {
+  node_geom_vals(g, p[0], p[1], p[LD], p[LD + 1], gx, gy, Hb);
+}
+// dH/dt of an interior cell from its 5-point {Hc, S} values and the D of its four corner nodes.
 // ETA1: eta0 == 1 (the integer-power law mode requires it), so eta0*H is H bit for bit.
-template <int LD, int LDD, bool ETA1 = false>
-__device__ __forceinline__ double cell_div(const GDev& g, const double2* p, const double* pD) {
-  const double2 c0 = p[0], ce_ = p[1], cw_ = p[-1], cn_ = p[LD], cs_ = p[-LD];
+template <bool ETA1>
+__device__ __forceinline__ double cell_div_vals(const GDev& g, double2 c0, double2 ce_, double2 cw_, double2 cn_,
+                                                double2 cs_, double Dsw, double Dse, double Dnw, double Dne) {
   const double e0 = ETA1 ? 1.0 : g.eta0;
   const double S0 = c0.y, eH0 = ETA1 ? c0.x : e0 * c0.x;
-  const double Dsw = pD[-LDD - 1], Dse = pD[-LDD], Dnw = pD[-1], Dne = pD[0];
   const double ce = clampn(ce_.y - S0, ETA1 ? ce_.x : e0 * ce_.x, eH0);
   const double cw = clampn(S0 - cw_.y, eH0, (ETA1 ? cw_.x : e0 * cw_.x));
   const double cn = clampn(cn_.y - S0, ETA1 ? cn_.x : e0 * cn_.x, eH0);
@@ -696,6 +702,11 @@ __device__ __forceinline__ double cell_div(const GDev& g, const double2* p, cons
   const double qx = (Dse + Dne) * ce - (Dsw + Dnw) * cw;
   const double qy = (Dnw + Dne) * cn - (Dsw + Dse) * cs;
   return fma(g.hinv_dx2, qx, g.hinv_dy2 * qy);
+}
+// p at the cell, pD at its north-east node; LDD = node row stride.
+template <int LD, int LDD, bool ETA1 = false>
+__device__ __forceinline__ double cell_div(const GDev& g, const double2* p, const double* pD) {
+  return cell_div_vals<ETA1>(g, p[0], p[1], p[-1], p[LD], p[-LD], pD[-LDD - 1], pD[-LDD], pD[-1], pD[0]);
 }
 
 // D on every dual node of the tile -> sD (0 on nodes outside the glacier's dual grid).
@@ -916,7 +927,7 @@ struct CtrlArgs {
   int next_cur;  // ping-pong buffer that holds u_new of this step; -1: flip the glacier's own `cur`
   const double* errpart;  // per-tile error partials: errpart[stride * tile]
   int stride;
-  int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles)
+  int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles, 3: FOYT tiles)
   double cfl;             // > 0: explicit Euler with dt = cfl*min(dx,dy)^2/(4 max D); the partials are tile maxima
   int cfl_prime;          // the launch only measured max D(u0): set the first dt, do not advance
   // reverse (continuous-adjoint) solve only; adj == null in the forward solve.  tstops are then
@@ -953,8 +964,8 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   const GDev g = P.gd[gidx];
   double s = 0.0;
   {
-    const int t0 = C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
-    const int nt = C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
+    const int t0 = C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
+    const int nt = C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
     if (C.cfl > 0.0) {
       for (int k = threadIdx.x; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
     } else {

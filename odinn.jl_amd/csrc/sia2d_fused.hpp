@@ -98,6 +98,123 @@ __device__ __forceinline__ void fused_stage(const GDev& g, const LawDev& L, cons
   }
 }
 
+#ifndef ODINN_FFAST
+#define ODINN_FFAST 1
+#endif
+// Variant of fused_stage for the integer-power A law (LM_FAST), trimmed for the LDS pipe and the
+// scalar unit, which co-limit the kernel with the fp64 VALU (LDS array busy 53 %, VALU 57 %, waves
+// parked 40 % of their life in s_waitcnt / s_barrier):
+//  * lane predicates are selects, not exec-mask branches; only the wave-uniform row test branches;
+//  * the thread's own cell {Hc, S} is rebuilt from its registers (max(u,0), B + max(u,0) -- bit for bit
+//    what it stored): 2 of 9 ds_read_b128 go;
+//  * the four D reads are single ds_read_b64 (2 LDS cycles each); the compiler would pair them into
+//    ds_read2_b64, which costs 8;
+//  * INNER: the whole halo region lies strictly inside the glacier grid (83 % of the tiles of a 1024^2
+//    glacier), every predicate is true and the selects and compare chains vanish.
+// Lanes outside region_S compute on stale neighbours; what they produce is never read by a lane
+// inside region_{S+1} (a cell of region_{S+1} only touches cells and nodes of region_S), and cells
+// outside the glacier keep u = tmp = utilde = 0 because their k is selected to 0.  Valid cells
+// execute exactly the expression sequence of fused_stage.
+template <int S, int FOYV, bool AF, bool INNER>
+__device__ __forceinline__ void fused_stage_fast(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
+                                                  int gi, int gj0, int w, int lane, double dt, double2 (*sHS)[FLD],
+                                                  double (*sD)[FLD], double (&u)[(FOYV + 2 * FH + FNW - 1) / FNW], double (&tmp)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                                  const double (&up)[(FOYV + 2 * FH + FNW - 1) / FNW], double (&E)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                                  const double (&bb)[(FOYV + 2 * FH + FNW - 1) / FNW]) {
+  constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + FNW - 1) / FNW;
+  const bool nodex = gi >= 0 && gi <= g.nx - 2;
+  // ---- nodes of region_S: rows [S-1, FRY-1-S] ---------------------------------------------------
+#pragma unroll
+  for (int m = 0; m < FSLOT; ++m) {
+    const int r = w + FNW * m;
+    if (r >= S - 1 && r <= FRY - 1 - S) {  // wave-uniform
+      const int gj = gj0 + r;
+      const bool ok = INNER || (nodex && gj >= 0 && gj <= g.ny - 2);
+      const double2* p = &sHS[r][lane];
+      const double hc0 = vmax0(u[m]);
+      double gx, gy, Hb;
+      node_geom_vals(g, make_double2(hc0, bb[m] + hc0), p[1], p[FLD], p[FLD + 1], gx, gy, Hb);
+      const double gS2 = gx * gx + gy * gy;
+      double An = g.A;
+      if (AF) An = Afield[g.offd + (ok ? gi + (long long)(g.nx - 1) * gj : 0LL)];
+      double al, be, sp;
+      const double D = node_D<false, LM_FAST>(g, L, Hb, gS2, An, al, be, sp);
+      sD[r][lane] = ok ? D : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- cells of region_S: rows [S, FRY-1-S] ------------------------------------------------------
+  constexpr int s = S - 1;
+  constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
+  const bool intx = gi >= 1 && gi <= g.nx - 2;
+#pragma unroll
+  for (int m = 0; m < FSLOT; ++m) {
+    const int r = w + FNW * m;
+    if (r >= S && r <= FRY - 1 - S) {
+      const int gj = gj0 + r;
+      const bool interior = INNER || (intx && gj >= 1 && gj <= g.ny - 2);
+      const double2* p = &sHS[r][lane];
+      typedef const volatile __attribute__((address_space(3))) double* lds_vptr;  // volatile: keep three ds_read_b64
+      lds_vptr pD = (lds_vptr)&sD[r][lane];
+      const double hc0 = vmax0(u[m]);
+      const double Dsw = pD[-FLD - 1], Dse = pD[-FLD], Dnw = pD[-1], Dne = pD[0];
+      double k = cell_div_vals<true>(g, make_double2(hc0, bb[m] + hc0), p[1], p[-1], p[FLD], p[-FLD], Dsw, Dse, Dnw, Dne);
+      k = interior ? k : 0.0;
+      const double dtk = dt * k;
+      const double uo = u[m];
+      double un;
+      if (S == 1) {
+        un = fma(bt, dtk, uo);
+        E[m] = bh * dtk;
+      } else {
+        const double t = fma(dl, uo, tmp[m]);
+        un = fma(g1, uo, g2 * t);
+        if (S >= 4) un = fma(g3, up[m], un);
+        un = fma(bt, dtk, un);
+        if (dl != 0.0) tmp[m] = t;
+        E[m] = fma(bh, dtk, E[m]);
+      }
+      u[m] = un;
+    }
+  }
+  __syncthreads();  // every read of sHS of this stage is done
+  if (S < 5) {
+#pragma unroll
+    for (int m = 0; m < FSLOT; ++m) {
+      const int r = w + FNW * m;
+      if (r >= S && r <= FRY - 1 - S) {
+        const double hc = vmax0(u[m]);
+        sHS[r][lane] = make_double2(hc, bb[m] + hc);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int LM, int FOYV, bool AF, bool INNER>
+__device__ __forceinline__ void fused_stages(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
+                                              int gi, int gj0, int w, int lane, double dt, double2 (*sHS)[FLD],
+                                              double (*sD)[FLD], double (&u)[(FOYV + 2 * FH + FNW - 1) / FNW], double (&tmp)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                              const double (&up)[(FOYV + 2 * FH + FNW - 1) / FNW], double (&E)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                              const double (&bb)[(FOYV + 2 * FH + FNW - 1) / FNW]) {
+  if constexpr (LM == LM_FAST && ODINN_FFAST) {
+    fused_stage_fast<1, FOYV, AF, INNER>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+    fused_stage_fast<2, FOYV, AF, INNER>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+    fused_stage_fast<3, FOYV, AF, INNER>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+    fused_stage_fast<4, FOYV, AF, INNER>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+    fused_stage_fast<5, FOYV, AF, INNER>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  } else {
+    fused_stage<1, LM, FOYV>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+    fused_stage<2, LM, FOYV>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+    fused_stage<3, LM, FOYV>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+    fused_stage<4, LM, FOYV>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+    fused_stage<5, LM, FOYV>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  }
+}
+
+#ifndef ODINN_FINNER
+#define ODINN_FINNER 1
+#endif
 #ifndef ODINN_FWPE
 #define ODINN_FWPE 4
 #endif
@@ -158,11 +275,13 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused(Pools P, LawDev L,
   } else {
     __syncthreads();
   }
-  fused_stage<1, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
-  fused_stage<2, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
-  fused_stage<3, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
-  fused_stage<4, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
-  fused_stage<5, LM, FOYV>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  const bool inner = gi0 >= 1 && gi0 + FRX - 1 <= g.nx - 2 && gj0 >= 1 && gj0 + FRY - 1 <= g.ny - 2;  // block-uniform
+  if (LM == LM_FAST && g.use_Afield)
+    fused_stages<LM, FOYV, true, false>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  else if (LM == LM_FAST && ODINN_FINNER && inner)
+    fused_stages<LM, FOYV, false, true>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  else
+    fused_stages<LM, FOYV, false, false>(g, L, P.Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
   // ---- output tile = region_5 (columns [5, 58], rows [5, FRY-6]): u' straight from the registers,
   //      embedded error partial ------------------------------------------------------------------
   double errsq = 0.0;
@@ -190,6 +309,198 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused(Pools P, LawDev L,
 #pragma unroll
     for (int k = 0; k < FNW; ++k) s += red[k];
     partF[t4.w] = s;
+  }
+}
+
+// ================= strip variant (integer-power A law) ==========================================
+// Measured on the row-interleaved kernel above: its time is VALU time + LDS time, not their maximum
+// (removing the seven ds_read_b128 of a node+cell pair drops 190 us to 140 us; barriers and occupancy
+// matter little).  Here wavefront w owns the TRPT contiguous region rows TRPT*w .. TRPT*w+TRPT-1, so
+// of the 5-point / 4-corner neighbourhoods only the x-neighbours come from the LDS: the y-neighbours
+// are the same thread's registers ({Hc, S} rebuilt from u and B, bit for bit what it stored), D of
+// the thread's own nodes stays in registers, D of the column to the west arrives by a DPP wave shift,
+// and only the strip-boundary rows cross wavefronts (one {Hc,S} row each way, one D row).  LDS reads
+// drop from 7 ds_read_b128 + 4 D reads per node+cell pair to 3.4 + 0.14, and sD shrinks to one row per
+// wavefront (62 KB of LDS in all: 2 workgroups / CU with a 46-row output tile instead of 40).
+// The previous-step value u_n needed by stages 4, 5 and the error estimate is re-read from global
+// memory (L2-resident) instead of being held in 14 VGPRs.
+// Every wavefront runs all its rows in every stage; rows and columns outside region_S compute on
+// stale neighbours and nothing inside region_{S+1} ever reads them (see fused_stage_fast).
+// The stage body is one basic block; left alone, the scheduler hoists the LDS loads of all seven rows
+// above the arithmetic and spills ~380 VGPRs.  The "row fence" at the end of each row makes the next
+// row's LDS address depend on this row's results (an empty asm that "rewrites" both), which pins the
+// row order without emitting an instruction.
+__device__ __forceinline__ double dpp_from_west(double x) {  // lane c receives lane c-1's value
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double2 cell_HS(double uu, double b) {
+  const double hc = vmax0(uu);
+  return make_double2(hc, b + hc);
+}
+
+template <int S, bool AF>
+__device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
+                                             const double* __restrict__ src, long long id0, int gi, int gj0, int w, int lane,
+                                             double dt, double2 (*sHS)[FLD], double (&u)[TRPT], double (&tmp)[TRPT],
+                                             double (&E)[TRPT], const double (&bb)[TRPT]) {
+  const int r0 = TRPT * w;
+  const bool nodex = gi >= 0 && gi <= g.nx - 2, intx = gi >= 1 && gi <= g.nx - 2, inx = gi >= 0 && gi < g.nx;
+  constexpr int s = S - 1;
+  constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
+  // D on node (c, r) = north-east corner of cell (c, r), from the {Hc,S} of cells (c,r) (c+1,r) (c,r+1) (c+1,r+1)
+  auto node = [&](int gj, double2 c00, double2 c10, double2 c01, double2 c11) {
+    const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+    double gx, gy, Hb;
+    node_geom_vals(g, c00, c10, c01, c11, gx, gy, Hb);
+    const double gS2 = gx * gx + gy * gy;
+    double An = g.A;
+    if (AF) An = Afield[g.offd + (ok ? gi + (long long)(g.nx - 1) * gj : 0LL)];
+    double al, be, sp;
+    const double Dv = node_D<false, LM_FAST>(g, L, Hb, gS2, An, al, be, sp);
+    return ok ? Dv : 0.0;
+  };
+  // One sweep up the strip: node row r, then cell row r.  The wavefront recomputes the node row below its
+  // strip (r0-1) itself, so no D crosses wavefronts and the stage needs no barrier before its cells.
+  int lx = lane;  // the lane again, but opaque after every row (row fence)
+  const int rs = r0 > 0 ? r0 - 1 : 0;                    // wavefront 0: a garbage row (row 0 is never in region_S)
+  const int rn = r0 + TRPT < TRY ? r0 + TRPT : TRY - 1;  // last wavefront: likewise
+  double2 hs_s = sHS[rs][lane], hs_c = cell_HS(u[0], bb[0]);
+  double2 e_c = sHS[r0][lane + 1];
+  double D_s = node(gj0 + r0 - 1, hs_s, sHS[rs][lane + 1], hs_c, e_c);
+  double Dw_s = dpp_from_west(D_s);
+#pragma unroll
+  for (int m = 0; m < TRPT; ++m) {
+    const int r = r0 + m, gj = gj0 + r;
+    const double2 hs_n = m + 1 < TRPT ? cell_HS(u[m + 1 < TRPT ? m + 1 : m], bb[m + 1 < TRPT ? m + 1 : m]) : sHS[rn][lx];
+    const double2 e_n = sHS[m + 1 < TRPT ? r + 1 : rn][lx + 1];
+    const double2 cw = sHS[r][lx - 1];
+    const double D_c = node(gj, hs_c, e_c, hs_n, e_n);
+    const double Dw_c = dpp_from_west(D_c);
+    const bool interior = intx && gj >= 1 && gj <= g.ny - 2;
+    double k = cell_div_vals<true>(g, hs_c, e_c, cw, hs_n, hs_s, Dw_s, D_s, Dw_c, D_c);
+    k = interior ? k : 0.0;
+    const double dtk = dt * k;
+    const double uo = u[m];
+    double un;
+    if (S == 1) {
+      un = fma(bt, dtk, uo);
+      E[m] = bh * dtk;
+    } else {
+      const double t = fma(dl, uo, tmp[m]);
+      un = fma(g1, uo, g2 * t);
+      if (S >= 4) {
+        const bool have = inx && gj >= 0 && gj < g.ny;
+        const double upv = src[have ? id0 + (long long)g.nx * m : g.off];
+        un = fma(g3, have ? upv : 0.0, un);
+      }
+      un = fma(bt, dtk, un);
+      if (dl != 0.0) tmp[m] = t;
+      E[m] = fma(bh, dtk, E[m]);
+    }
+    u[m] = un;
+    hs_s = hs_c; hs_c = hs_n; e_c = e_n; D_s = D_c; Dw_s = Dw_c;
+    if (S == 1) asm volatile("" : "+v"(lx), "+v"(u[m]), "+v"(E[m]));  // row fence on everything the row produced
+    else asm volatile("" : "+v"(lx), "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]));
+  }
+  __syncthreads();  // every read of sHS of this stage is done
+  if (S < 5) {
+#pragma unroll
+    for (int m = 0; m < TRPT; ++m) sHS[r0 + m][lane] = cell_HS(u[m], bb[m]);
+    __syncthreads();
+  }
+}
+
+template <bool AF>
+__device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
+                                              const double* __restrict__ src, long long id0, int gi, int gj0, int w, int lane,
+                                              double dt, double2 (*sHS)[FLD], double (&u)[TRPT],
+                                              double (&tmp)[TRPT], double (&E)[TRPT], const double (&bb)[TRPT]) {
+  strip_stage<1, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
+  strip_stage<2, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
+  strip_stage<3, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
+  strip_stage<4, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
+  strip_stage<5, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
+}
+
+// AF: A from the dual-grid field.  One stage path per kernel: with two paths in one kernel the register allocator
+// spills (a separate predicate-free kernel for the tiles strictly inside the grid was measured and lost: its
+// second launch costs more than the selects it saves).
+template <bool SKIP, bool AF>
+__global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, LawDev L, const int4* __restrict__ tilesF,
+                                                                    double* __restrict__ U0, double* __restrict__ U1,
+                                                                    double* __restrict__ partF, double abstol, double reltol) {
+  __shared__ double2 sHS[TRY][FLD];
+  __shared__ double red[FNW];
+  const int4 t4 = tilesF[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  if (gs->done) return;
+  const GDev g = P.gd[t4.x];
+  const double dt = gs->dt;
+  const double* __restrict__ src = gs->cur ? U1 : U0;
+  double* __restrict__ dst = gs->cur ? U0 : U1;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOYT - FH;
+  const int gi = gi0 + lane, r0 = TRPT * w;
+  const bool inx = gi >= 0 && gi < g.nx;
+  const long long id0 = g.off + gi + (long long)g.nx * (gj0 + r0);
+  double u[TRPT], tmp[TRPT], E[TRPT], bb[TRPT];
+  bool nz = false;
+#pragma unroll
+  for (int m = 0; m < TRPT; ++m) {
+    const int gj = gj0 + r0 + m;
+    double h = 0.0, b = 0.0;
+    if (inx && gj >= 0 && gj < g.ny) {
+      h = src[id0 + (long long)g.nx * m];
+      b = P.B[id0 + (long long)g.nx * m];
+    }
+    sHS[r0 + m][lane] = cell_HS(h, b);
+    u[m] = h; tmp[m] = h; E[m] = 0.0; bb[m] = b;
+    nz = nz || (h != 0.0);
+  }
+  const bool ocol = lane >= FH && lane < FH + FOX && inx;
+  if (SKIP) {
+    // exact shortcut, see k_rk_fused
+    if (!__syncthreads_or(nz)) {
+      if (ocol) {
+#pragma unroll
+        for (int m = 0; m < TRPT; ++m) {
+          const int r = r0 + m, gj = gj0 + r;
+          if (r >= FH && r <= TRY - 1 - FH && gj < g.ny) dst[id0 + (long long)g.nx * m] = 0.0;
+        }
+      }
+      if (threadIdx.x == 0) partF[t4.w] = 0.0;
+      return;
+    }
+  } else {
+    __syncthreads();
+  }
+  strip_stages<AF>(g, L, P.Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
+  // ---- output rows [FH, TRY-1-FH]: u' from the registers, embedded error partial -----------------------
+  double errsq = 0.0;
+#pragma unroll
+  for (int m = 0; m < TRPT; ++m) {
+    const int r = r0 + m, gj = gj0 + r;
+    if (r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny) {
+      const double upv = src[id0 + (long long)g.nx * m];
+      dst[id0 + (long long)g.nx * m] = u[m];
+      const double err = (u[m] - upv) - E[m];
+      const double sk = abstol + fmax(fabs(upv), fabs(u[m])) * reltol;
+      const double q = err / sk;
+      errsq = fma(q, q, errsq);
+    }
+  }
+  errsq = wave_sum(errsq);
+  if (lane == 0) red[w] = errsq;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < FNW; ++k) sum += red[k];
+    partF[t4.w] = sum;
   }
 }
 
