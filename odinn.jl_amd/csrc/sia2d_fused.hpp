@@ -315,37 +315,47 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused(Pools P, LawDev L,
 // ================= strip variant (integer-power A law) ==========================================
 // Measured on the row-interleaved kernel above: its time is VALU time + LDS time, not their maximum
 // (removing the seven ds_read_b128 of a node+cell pair drops 190 us to 140 us; barriers and occupancy
-// matter little).  Here wavefront w owns the TRPT contiguous region rows TRPT*w .. TRPT*w+TRPT-1, so
-// of the 5-point / 4-corner neighbourhoods only the x-neighbours come from the LDS: the y-neighbours
-// are the same thread's registers ({Hc, S} rebuilt from u and B, bit for bit what it stored), D of
-// the thread's own nodes stays in registers, D of the column to the west arrives by a DPP wave shift,
-// and only the strip-boundary rows cross wavefronts (one {Hc,S} row each way, one D row).  LDS reads
-// drop from 7 ds_read_b128 + 4 D reads per node+cell pair to 3.4 + 0.14, and sD shrinks to one row per
-// wavefront (62 KB of LDS in all: 2 workgroups / CU with a 46-row output tile instead of 40).
-// The previous-step value u_n needed by stages 4, 5 and the error estimate is re-read from global
-// memory (L2-resident) instead of being held in 14 VGPRs.
+// matter little).  Here wavefront w owns the TRPT contiguous region rows TRPT*w .. TRPT*w+TRPT-1 and a
+// thread one column of them, so a cell's neighbourhood is already in the wavefront's registers:
+//  * y-neighbours are the same thread's rows ({Hc, S} rebuilt from u and B, bit for bit);
+//  * x-neighbours are the adjacent lanes' registers, fetched by DPP wave shifts (v_mov_b32_dpp, 4 per
+//    {Hc,S}, 2 per D) -- dearer in VALU slots than an LDS read looks, but an LDS round trip costs a
+//    13-cycle ds_write_b128 plus a ds_read_b128 per neighbour on a pipe shared by four SIMDs;
+//  * only the first and last row of each strip cross wavefronts: 2 ds_write_b128 + 2 ds_read_b128 per
+//    wavefront and stage (was 7 + 49), double-buffered so that a stage needs ONE barrier (was 3);
+//  * D never leaves the registers: the wavefront recomputes the node row below its strip itself.
+// LDS shrinks to 32 KB.  The previous-step value u_n needed by stages 4, 5 and the error estimate is
+// re-read from global memory (L2-resident) instead of being held in 14 VGPRs.
 // Every wavefront runs all its rows in every stage; rows and columns outside region_S compute on
 // stale neighbours and nothing inside region_{S+1} ever reads them (see fused_stage_fast).
-// The stage body is one basic block; left alone, the scheduler hoists the LDS loads of all seven rows
-// above the arithmetic and spills ~380 VGPRs.  The "row fence" at the end of each row makes the next
-// row's LDS address depend on this row's results (an empty asm that "rewrites" both), which pins the
-// row order without emitting an instruction.
-__device__ __forceinline__ double dpp_from_west(double x) {  // lane c receives lane c-1's value
+__device__ __forceinline__ double dpp_shift(double x, const bool from_west) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, false);
+  if (from_west) {  // lane c receives lane c-1's value (wave_shr:1); lane 0 gets 0
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x138, 0xf, 0xf, true);
+  } else {          // lane c receives lane c+1's value (wave_shl:1); lane 63 gets 0
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x130, 0xf, 0xf, true);
+  }
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double dpp_from_west(double x) { return dpp_shift(x, true); }
+__device__ __forceinline__ double2 dpp_from_west(double2 v) { return make_double2(dpp_shift(v.x, true), dpp_shift(v.y, true)); }
+__device__ __forceinline__ double2 dpp_from_east(double2 v) { return make_double2(dpp_shift(v.x, false), dpp_shift(v.y, false)); }
 __device__ __forceinline__ double2 cell_HS(double uu, double b) {
   const double hc = vmax0(uu);
   return make_double2(hc, b + hc);
 }
 
+// sE[buf][w][0 | 1][lane]: {Hc, S} of the first | last row of wavefront w's strip
+typedef double2 (*StripEdges)[FNW][2][FRX];
+
 template <int S, bool AF>
 __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
                                              const double* __restrict__ src, long long id0, int gi, int gj0, int w, int lane,
-                                             double dt, double2 (*sHS)[FLD], double (&u)[TRPT], double (&tmp)[TRPT],
+                                             double dt, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
                                              double (&E)[TRPT], const double (&bb)[TRPT]) {
+  constexpr int rd = (S - 1) & 1, wr = S & 1;  // stage S reads the edge rows from buffer rd, publishes into wr
   const int r0 = TRPT * w;
   const bool nodex = gi >= 0 && gi <= g.nx - 2, intx = gi >= 1 && gi <= g.nx - 2, inx = gi >= 0 && gi < g.nx;
   constexpr int s = S - 1;
@@ -362,21 +372,21 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
     const double Dv = node_D<false, LM_FAST>(g, L, Hb, gS2, An, al, be, sp);
     return ok ? Dv : 0.0;
   };
-  // One sweep up the strip: node row r, then cell row r.  The wavefront recomputes the node row below its
-  // strip (r0-1) itself, so no D crosses wavefronts and the stage needs no barrier before its cells.
-  int lx = lane;  // the lane again, but opaque after every row (row fence)
-  const int rs = r0 > 0 ? r0 - 1 : 0;                    // wavefront 0: a garbage row (row 0 is never in region_S)
-  const int rn = r0 + TRPT < TRY ? r0 + TRPT : TRY - 1;  // last wavefront: likewise
-  double2 hs_s = sHS[rs][lane], hs_c = cell_HS(u[0], bb[0]);
-  double2 e_c = sHS[r0][lane + 1];
-  double D_s = node(gj0 + r0 - 1, hs_s, sHS[rs][lane + 1], hs_c, e_c);
+  // the rows just outside the strip: last row of the wavefront below, first row of the one above (the
+  // outermost wavefronts read their own edge instead: rows 0 and TRY-1 are never in region_S)
+  double2 hs_s = sE[rd][w > 0 ? w - 1 : 0][w > 0 ? 1 : 0][lane];
+  const double2 hs_top = sE[rd][w + 1 < FNW ? w + 1 : w][w + 1 < FNW ? 0 : 1][lane];
+  // One sweep up the strip: node row r, then cell row r; the node row below the strip first.
+  double2 hs_c = cell_HS(u[0], bb[0]);
+  double2 e_c = dpp_from_east(hs_c);
+  double D_s = node(gj0 + r0 - 1, hs_s, dpp_from_east(hs_s), hs_c, e_c);
   double Dw_s = dpp_from_west(D_s);
 #pragma unroll
   for (int m = 0; m < TRPT; ++m) {
-    const int r = r0 + m, gj = gj0 + r;
-    const double2 hs_n = m + 1 < TRPT ? cell_HS(u[m + 1 < TRPT ? m + 1 : m], bb[m + 1 < TRPT ? m + 1 : m]) : sHS[rn][lx];
-    const double2 e_n = sHS[m + 1 < TRPT ? r + 1 : rn][lx + 1];
-    const double2 cw = sHS[r][lx - 1];
+    const int gj = gj0 + r0 + m;
+    const double2 hs_n = m + 1 < TRPT ? cell_HS(u[m + 1 < TRPT ? m + 1 : m], bb[m + 1 < TRPT ? m + 1 : m]) : hs_top;
+    const double2 e_n = dpp_from_east(hs_n);
+    const double2 cw = dpp_from_west(hs_c);
     const double D_c = node(gj, hs_c, e_c, hs_n, e_n);
     const double Dw_c = dpp_from_west(D_c);
     const bool interior = intx && gj >= 1 && gj <= g.ny - 2;
@@ -402,13 +412,17 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
     }
     u[m] = un;
     hs_s = hs_c; hs_c = hs_n; e_c = e_n; D_s = D_c; Dw_s = Dw_c;
-    if (S == 1) asm volatile("" : "+v"(lx), "+v"(u[m]), "+v"(E[m]));  // row fence on everything the row produced
-    else asm volatile("" : "+v"(lx), "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]));
+    // row fence: the stage body is one basic block and, left alone, the scheduler interleaves all seven rows
+    // and spills ~130 VGPRs.  An empty asm that "rewrites" what the row produced and what the next row starts
+    // from pins the row order without emitting an instruction.
+    if (S == 1)
+      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(D_s), "+v"(Dw_s));
+    else
+      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(D_s), "+v"(Dw_s));
   }
-  __syncthreads();  // every read of sHS of this stage is done
   if (S < 5) {
-#pragma unroll
-    for (int m = 0; m < TRPT; ++m) sHS[r0 + m][lane] = cell_HS(u[m], bb[m]);
+    sE[wr][w][0][lane] = cell_HS(u[0], bb[0]);
+    sE[wr][w][1][lane] = cell_HS(u[TRPT - 1], bb[TRPT - 1]);
     __syncthreads();
   }
 }
@@ -416,13 +430,13 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
 template <bool AF>
 __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
                                               const double* __restrict__ src, long long id0, int gi, int gj0, int w, int lane,
-                                              double dt, double2 (*sHS)[FLD], double (&u)[TRPT],
-                                              double (&tmp)[TRPT], double (&E)[TRPT], const double (&bb)[TRPT]) {
-  strip_stage<1, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
-  strip_stage<2, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
-  strip_stage<3, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
-  strip_stage<4, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
-  strip_stage<5, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
+                                              double dt, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
+                                              double (&E)[TRPT], const double (&bb)[TRPT]) {
+  strip_stage<1, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
+  strip_stage<2, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
+  strip_stage<3, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
+  strip_stage<4, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
+  strip_stage<5, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
 }
 
 // AF: A from the dual-grid field.  One stage path per kernel: with two paths in one kernel the register allocator
@@ -432,7 +446,7 @@ template <bool SKIP, bool AF>
 __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, LawDev L, const int4* __restrict__ tilesF,
                                                                     double* __restrict__ U0, double* __restrict__ U1,
                                                                     double* __restrict__ partF, double abstol, double reltol) {
-  __shared__ double2 sHS[TRY][FLD];
+  __shared__ double2 sE[2][FNW][2][FRX];
   __shared__ double red[FNW];
   const int4 t4 = tilesF[blockIdx.x];
   const GState* gs = P.gs + t4.x;
@@ -457,10 +471,11 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
       h = src[id0 + (long long)g.nx * m];
       b = P.B[id0 + (long long)g.nx * m];
     }
-    sHS[r0 + m][lane] = cell_HS(h, b);
     u[m] = h; tmp[m] = h; E[m] = 0.0; bb[m] = b;
     nz = nz || (h != 0.0);
   }
+  sE[0][w][0][lane] = cell_HS(u[0], bb[0]);
+  sE[0][w][1][lane] = cell_HS(u[TRPT - 1], bb[TRPT - 1]);
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   if (SKIP) {
     // exact shortcut, see k_rk_fused
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   } else {
     __syncthreads();
   }
-  strip_stages<AF>(g, L, P.Afield, src, id0, gi, gj0, w, lane, dt, sHS, u, tmp, E, bb);
+  strip_stages<AF>(g, L, P.Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
   // ---- output rows [FH, TRY-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
 #pragma unroll
