@@ -23,7 +23,7 @@ void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev
 void launch_rk_fused_strip(int nblk, int afield, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
                            double* U1, double* partF, double abstol, double reltol, int skip) {
 #define ODINN_STRIP(SK, AF) \
-  hipLaunchKernelGGL((k_rk_fused_strip<SK, AF>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol)
+  hipLaunchKernelGGL((k_rk_fused_strip<SK, AF>), dim3(nblk), dim3(TNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol)
   if (afield) {
     if (skip) ODINN_STRIP(true, true); else ODINN_STRIP(false, true);
   } else {

@@ -54,9 +54,14 @@ constexpr int FOYS = 8;               // "latency" tile height: used when the ba
                                       // the GPU -- a workgroup then walks 18 region rows instead of 50
 constexpr int FNT = ODINN_FNT;        // threads per block
 constexpr int FNW = FNT / 64;
+#ifndef ODINN_TNW
+#define ODINN_TNW 8
+#endif
 constexpr int TRPT = 7;               // "strip" variant of the fused kernel (integer-power law): a wavefront owns
-constexpr int TRY = TRPT * FNW;       // TRPT CONTIGUOUS region rows, so the y-neighbours of a cell live in the
-constexpr int FOYT = TRY - 2 * FH;    // same thread's registers: 64 x 56 region, 54 x 46 output tile
+constexpr int TNW = ODINN_TNW;        // TRPT CONTIGUOUS region rows, so the y-neighbours of a cell live in the
+constexpr int TNT = 64 * TNW;         // same thread's registers: TNW wavefronts, 64 x 56 region, 54 x 46 output tile
+constexpr int TRY = TRPT * TNW;
+constexpr int FOYT = TRY - 2 * FH;
 constexpr int FLD = FRX + 1;          // LDS row stride (odd)
 
 

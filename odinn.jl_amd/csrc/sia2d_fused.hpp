@@ -348,7 +348,7 @@ __device__ __forceinline__ double2 cell_HS(double uu, double b) {
 }
 
 // sE[buf][w][0 | 1][lane]: {Hc, S} of the first | last row of wavefront w's strip
-typedef double2 (*StripEdges)[FNW][2][FRX];
+typedef double2 (*StripEdges)[TNW][2][FRX];
 
 template <int S, bool AF>
 __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
@@ -357,40 +357,54 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
                                              double (&E)[TRPT], const double (&bb)[TRPT]) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;  // stage S reads the edge rows from buffer rd, publishes into wr
   const int r0 = TRPT * w;
-  const bool nodex = gi >= 0 && gi <= g.nx - 2, intx = gi >= 1 && gi <= g.nx - 2, inx = gi >= 0 && gi < g.nx;
+  [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
+  const bool intx = gi >= 1 && gi <= g.nx - 2, inx = gi >= 0 && gi < g.nx;
   constexpr int s = S - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
-  // D on node (c, r) = north-east corner of cell (c, r), from the {Hc,S} of cells (c,r) (c+1,r) (c,r+1) (c+1,r+1)
+  // D on node (c, r) = north-east corner of cell (c, r), from the {Hc,S} of cells (c,r) (c+1,r) (c,r+1) (c+1,r+1).
+  // No select to 0 on nodes outside the glacier's dual grid: such a node only feeds faces of boundary-ring
+  // cells (k is selected to 0 there) and of cells outside the glacier (likewise), see `interior` below.
   auto node = [&](int gj, double2 c00, double2 c10, double2 c01, double2 c11) {
-    const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
     double gx, gy, Hb;
     node_geom_vals(g, c00, c10, c01, c11, gx, gy, Hb);
     const double gS2 = gx * gx + gy * gy;
     double An = g.A;
-    if (AF) An = Afield[g.offd + (ok ? gi + (long long)(g.nx - 1) * gj : 0LL)];
+    if (AF) {
+      const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+      An = Afield[g.offd + (ok ? gi + (long long)(g.nx - 1) * gj : 0LL)];
+    }
     double al, be, sp;
-    const double Dv = node_D<false, LM_FAST>(g, L, Hb, gS2, An, al, be, sp);
-    return ok ? Dv : 0.0;
+    return node_D<false, LM_FAST>(g, L, Hb, gS2, An, al, be, sp);
   };
+  // Flux form of cell_div_vals<true>: the flux through the face between two cells is the same number seen
+  // from either side (same D sum, same clamped slope -- ties included), so a thread computes only its EAST and
+  // NORTH face, takes the west flux from the lane to the west (DPP) and the south flux from its previous row:
+  //   F_e(c,r) = (D(c,r-1) + D(c,r)) clamp(S(c+1,r) - S(c,r);  H(c+1,r), -H(c,r))
+  //   F_n(c,r) = (D(c-1,r) + D(c,r)) clamp(S(c,r+1) - S(c,r);  H(c,r+1), -H(c,r))
+  //   k = (F_e - F_w) / (2 dx^2) + (F_n - F_s) / (2 dy^2)
+  // Two clamps and two products per cell instead of four; rounding differs from cell_div_vals only in
+  // where the compiler contracts a*b - c*d.
+  auto face = [&](double Da, double Db, double2 lo, double2 hi) { return (Da + Db) * clampn(hi.y - lo.y, hi.x, lo.x); };
   // the rows just outside the strip: last row of the wavefront below, first row of the one above (the
   // outermost wavefronts read their own edge instead: rows 0 and TRY-1 are never in region_S)
-  double2 hs_s = sE[rd][w > 0 ? w - 1 : 0][w > 0 ? 1 : 0][lane];
-  const double2 hs_top = sE[rd][w + 1 < FNW ? w + 1 : w][w + 1 < FNW ? 0 : 1][lane];
-  // One sweep up the strip: node row r, then cell row r; the node row below the strip first.
+  const double2 hs_s = sE[rd][w > 0 ? w - 1 : 0][w > 0 ? 1 : 0][lane];
+  const double2 hs_top = sE[rd][w + 1 < TNW ? w + 1 : w][w + 1 < TNW ? 0 : 1][lane];
+  // One sweep up the strip: node row r, then cell row r; the node row and the north faces below the strip first.
   double2 hs_c = cell_HS(u[0], bb[0]);
   double2 e_c = dpp_from_east(hs_c);
   double D_s = node(gj0 + r0 - 1, hs_s, dpp_from_east(hs_s), hs_c, e_c);
-  double Dw_s = dpp_from_west(D_s);
+  double F_s = face(dpp_from_west(D_s), D_s, hs_s, hs_c);
 #pragma unroll
   for (int m = 0; m < TRPT; ++m) {
     const int gj = gj0 + r0 + m;
     const double2 hs_n = m + 1 < TRPT ? cell_HS(u[m + 1 < TRPT ? m + 1 : m], bb[m + 1 < TRPT ? m + 1 : m]) : hs_top;
     const double2 e_n = dpp_from_east(hs_n);
-    const double2 cw = dpp_from_west(hs_c);
     const double D_c = node(gj, hs_c, e_c, hs_n, e_n);
-    const double Dw_c = dpp_from_west(D_c);
+    const double F_e = face(D_s, D_c, hs_c, e_c);
+    const double F_n = face(dpp_from_west(D_c), D_c, hs_c, hs_n);
+    const double F_w = dpp_from_west(F_e);
     const bool interior = intx && gj >= 1 && gj <= g.ny - 2;
-    double k = cell_div_vals<true>(g, hs_c, e_c, cw, hs_n, hs_s, Dw_s, D_s, Dw_c, D_c);
+    double k = fma(g.hinv_dx2, F_e - F_w, g.hinv_dy2 * (F_n - F_s));
     k = interior ? k : 0.0;
     const double dtk = dt * k;
     const double uo = u[m];
@@ -411,14 +425,14 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
       E[m] = fma(bh, dtk, E[m]);
     }
     u[m] = un;
-    hs_s = hs_c; hs_c = hs_n; e_c = e_n; D_s = D_c; Dw_s = Dw_c;
+    hs_c = hs_n; e_c = e_n; D_s = D_c; F_s = F_n;
     // row fence: the stage body is one basic block and, left alone, the scheduler interleaves all seven rows
     // and spills ~130 VGPRs.  An empty asm that "rewrites" what the row produced and what the next row starts
     // from pins the row order without emitting an instruction.
     if (S == 1)
-      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(D_s), "+v"(Dw_s));
+      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(D_s), "+v"(F_s));
     else
-      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(D_s), "+v"(Dw_s));
+      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(D_s), "+v"(F_s));
   }
   if (S < 5) {
     sE[wr][w][0][lane] = cell_HS(u[0], bb[0]);
@@ -443,11 +457,11 @@ __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, con
 // spills (a separate predicate-free kernel for the tiles strictly inside the grid was measured and lost: its
 // second launch costs more than the selects it saves).
 template <bool SKIP, bool AF>
-__global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, LawDev L, const int4* __restrict__ tilesF,
+__global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, LawDev L, const int4* __restrict__ tilesF,
                                                                     double* __restrict__ U0, double* __restrict__ U1,
                                                                     double* __restrict__ partF, double abstol, double reltol) {
-  __shared__ double2 sE[2][FNW][2][FRX];
-  __shared__ double red[FNW];
+  __shared__ double2 sE[2][TNW][2][FRX];
+  __shared__ double red[TNW];
   const int4 t4 = tilesF[blockIdx.x];
   const GState* gs = P.gs + t4.x;
   if (gs->done) return;
@@ -496,11 +510,18 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   strip_stages<AF>(g, L, P.Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
   // ---- output rows [FH, TRY-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
+  double upf[TRPT];
+#pragma unroll
+  for (int m = 0; m < TRPT; ++m) {  // all loads in flight before the first use
+    const int r = r0 + m, gj = gj0 + r;
+    const bool out = r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny;
+    upf[m] = src[out ? id0 + (long long)g.nx * m : g.off];
+  }
 #pragma unroll
   for (int m = 0; m < TRPT; ++m) {
     const int r = r0 + m, gj = gj0 + r;
     if (r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny) {
-      const double upv = src[id0 + (long long)g.nx * m];
+      const double upv = upf[m];
       dst[id0 + (long long)g.nx * m] = u[m];
       const double err = (u[m] - upv) - E[m];
       const double sk = abstol + fmax(fabs(upv), fabs(u[m])) * reltol;
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   if (threadIdx.x == 0) {
     double sum = 0.0;
 #pragma unroll
-    for (int k = 0; k < FNW; ++k) sum += red[k];
+    for (int k = 0; k < TNW; ++k) sum += red[k];
     partF[t4.w] = sum;
   }
 }

@@ -480,9 +480,10 @@ def test_fused_tile_sizes_are_equivalent(gpu, monkeypatch):
         out[tiles] = ad + (b.snapshot(0, 2),)
         b.close()
     # same dt sequence => equal to rounding.  Adaptive runs: the embedded error (u' - u) - utilde cancels ~6 digits,
-    # so an ulp of difference in u' (the strip kernel is separate source, contracted differently) moves the error
-    # norm in its 10th digit and the PID step sizes with it: agreement is bounded by reltol, not by rounding.
-    for other, tol in (("large", 1e-12), ("t", 1e-8)):
+    # so an ulp of difference in u' (the strip kernel is separate source: flux form, contracted differently) moves
+    # the error norm in its 10th digit and the PID step sizes with it: agreement is bounded by the integration
+    # error (~10 reltol), not by rounding.
+    for other, tol in (("large", 1e-12), ("t", 1e-7)):
         assert out["small"][1:3] == out[other][1:3], other
         assert rel_l2(out["small"][0], out[other][0]) < tol, other
         assert np.isfinite(out[other][3]).all() and rel_l2(out["small"][3], out[other][3]) < 1e-13, other
