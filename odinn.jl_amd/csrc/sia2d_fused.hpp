@@ -352,29 +352,33 @@ typedef double2 (*StripEdges)[TNW][2][FRX];
 
 template <int S, bool AF>
 __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
-                                             const double* __restrict__ src, long long id0, int gi, int gj0, int w, int lane,
-                                             double dt, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
+                                             const double* __restrict__ src, long long idc, int gi, int gj0, int w, int lane,
+                                             double dtl, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
                                              double (&E)[TRPT], const double (&bb)[TRPT]) {
+  // idc: linear index of (gi clamped into the grid, row 0); dtl: dt on the lanes with 1 <= gi <= nx-2, else 0
   constexpr int rd = (S - 1) & 1, wr = S & 1;  // stage S reads the edge rows from buffer rd, publishes into wr
   const int r0 = TRPT * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
-  const bool intx = gi >= 1 && gi <= g.nx - 2, inx = gi >= 0 && gi < g.nx;
   constexpr int s = S - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
   // D on node (c, r) = north-east corner of cell (c, r), from the {Hc,S} of cells (c,r) (c+1,r) (c,r+1) (c+1,r+1).
   // No select to 0 on nodes outside the glacier's dual grid: such a node only feeds faces of boundary-ring
-  // cells (k is selected to 0 there) and of cells outside the glacier (likewise), see `interior` below.
+  // cells and of cells outside the glacier, and those never move (see dtk below).
+  // node_geom_vals + node_D<LM_FAST> with the factor 1/4 of Hbar folded into the constant:
+  // A Gam Hbar^5 = (A Gam / 1024) (4 Hbar)^5 bit for bit (powers of two commute with rounding).
+  const double Gq = g.Gam * (1.0 / 1024.0);
   auto node = [&](int gj, double2 c00, double2 c10, double2 c01, double2 c11) {
-    double gx, gy, Hb;
-    node_geom_vals(g, c00, c10, c01, c11, gx, gy, Hb);
+    const double gx = ((c10.y - c00.y) + (c11.y - c01.y)) * g.hinv_dx;
+    const double gy = ((c01.y - c00.y) + (c11.y - c10.y)) * g.hinv_dy;
+    const double H4s = (c00.x + c10.x) + (c01.x + c11.x);  // 4 Hbar
     const double gS2 = gx * gx + gy * gy;
     double An = g.A;
     if (AF) {
       const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
       An = Afield[g.offd + (ok ? gi + (long long)(g.nx - 1) * gj : 0LL)];
     }
-    double al, be, sp;
-    return node_D<false, LM_FAST>(g, L, Hb, gS2, An, al, be, sp);
+    const double H2 = H4s * H4s, H4 = H2 * H2;
+    return (An * Gq) * (H4 * H4s) * gS2;
   };
   // Flux form of cell_div_vals<true>: the flux through the face between two cells is the same number seen
   // from either side (same D sum, same clamped slope -- ties included), so a thread computes only its EAST and
@@ -403,26 +407,27 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
     const double F_e = face(D_s, D_c, hs_c, e_c);
     const double F_n = face(dpp_from_west(D_c), D_c, hs_c, hs_n);
     const double F_w = dpp_from_west(F_e);
-    const bool interior = intx && gj >= 1 && gj <= g.ny - 2;
-    double k = fma(g.hinv_dx2, F_e - F_w, g.hinv_dy2 * (F_n - F_s));
-    k = interior ? k : 0.0;
-    const double dtk = dt * k;
+    const double k = fma(g.hinv_dx2, F_e - F_w, g.hinv_dy2 * (F_n - F_s));
+    // cells that must not move (boundary ring, outside the glacier): dtl is 0 on their lanes and the weights of
+    // dt k are 0 on their rows (wave-uniform, scalar selects) -- fma(0, dt k, x) = x = fma(bt, 0, x) exactly
+    const bool rowint = gj >= 1 && gj <= g.ny - 2;
+    const double btm = rowint ? bt : 0.0, bhm = rowint ? bh : 0.0;
+    const double dtk = dtl * k;
     const double uo = u[m];
     double un;
     if (S == 1) {
-      un = fma(bt, dtk, uo);
-      E[m] = bh * dtk;
+      un = fma(btm, dtk, uo);
+      E[m] = bhm * dtk;
     } else {
       const double t = fma(dl, uo, tmp[m]);
       un = fma(g1, uo, g2 * t);
-      if (S >= 4) {
-        const bool have = inx && gj >= 0 && gj < g.ny;
-        const double upv = src[have ? id0 + (long long)g.nx * m : g.off];
-        un = fma(g3, have ? upv : 0.0, un);
+      if (S >= 4) {  // u_n from global memory; what cells outside the glacier pick up is never read (see node)
+        const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
+        un = fma(g3, src[idc + (long long)g.nx * gjc], un);
       }
-      un = fma(bt, dtk, un);
+      un = fma(btm, dtk, un);
       if (dl != 0.0) tmp[m] = t;
-      E[m] = fma(bh, dtk, E[m]);
+      E[m] = fma(bhm, dtk, E[m]);
     }
     u[m] = un;
     hs_c = hs_n; e_c = e_n; D_s = D_c; F_s = F_n;
@@ -443,14 +448,14 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
 
 template <bool AF>
 __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
-                                              const double* __restrict__ src, long long id0, int gi, int gj0, int w, int lane,
-                                              double dt, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
+                                              const double* __restrict__ src, long long idc, int gi, int gj0, int w, int lane,
+                                              double dtl, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
                                               double (&E)[TRPT], const double (&bb)[TRPT]) {
-  strip_stage<1, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
-  strip_stage<2, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
-  strip_stage<3, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
-  strip_stage<4, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
-  strip_stage<5, AF>(g, L, Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
+  strip_stage<1, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<2, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<3, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<4, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<5, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
 }
 
 // AF: A from the dual-grid field.  One stage path per kernel: with two paths in one kernel the register allocator
@@ -507,7 +512,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   } else {
     __syncthreads();
   }
-  strip_stages<AF>(g, L, P.Afield, src, id0, gi, gj0, w, lane, dt, sE, u, tmp, E, bb);
+  const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
+  strip_stages<AF>(g, L, P.Afield, src, g.off + gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
   // ---- output rows [FH, TRY-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
   double upf[TRPT];
