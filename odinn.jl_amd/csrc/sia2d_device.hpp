@@ -57,7 +57,10 @@ constexpr int FNW = FNT / 64;
 #ifndef ODINN_TNW
 #define ODINN_TNW 8
 #endif
-constexpr int TRPT = 7;               // "strip" variant of the fused kernel (integer-power law): a wavefront owns
+#ifndef ODINN_TRPT
+#define ODINN_TRPT 7
+#endif
+constexpr int TRPT = ODINN_TRPT;               // "strip" variant of the fused kernel (integer-power law): a wavefront owns
 constexpr int TNW = ODINN_TNW;        // TRPT CONTIGUOUS region rows, so the y-neighbours of a cell live in the
 constexpr int TNT = 64 * TNW;         // same thread's registers: TNW wavefronts, 64 x 56 region, 54 x 46 output tile
 constexpr int TRY = TRPT * TNW;

@@ -366,11 +366,13 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   // cells and of cells outside the glacier, and those never move (see dtk below).
   // node_geom_vals + node_D<LM_FAST> with the factor 1/4 of Hbar folded into the constant:
   // A Gam Hbar^5 = (A Gam / 1024) (4 Hbar)^5 bit for bit (powers of two commute with rounding).
+  // The bottom edge of a node's cell quartet is the top edge of the previous row's: its x-difference of S and
+  // its pair sum of Hc are carried up the sweep (dxb, hpb) instead of being recomputed.
   const double Gq = g.Gam * (1.0 / 1024.0);
-  auto node = [&](int gj, double2 c00, double2 c10, double2 c01, double2 c11) {
-    const double gx = ((c10.y - c00.y) + (c11.y - c01.y)) * g.hinv_dx;
-    const double gy = ((c01.y - c00.y) + (c11.y - c10.y)) * g.hinv_dy;
-    const double H4s = (c00.x + c10.x) + (c01.x + c11.x);  // 4 Hbar
+  auto node = [&](int gj, double dxb, double hpb, double dxt, double hpt, double dyw, double dye) {
+    const double gx = (dxb + dxt) * g.hinv_dx;
+    const double gy = (dyw + dye) * g.hinv_dy;
+    const double H4s = hpb + hpt;  // 4 Hbar
     const double gS2 = gx * gx + gy * gy;
     double An = g.A;
     if (AF) {
@@ -388,7 +390,7 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   //   k = (F_e - F_w) / (2 dx^2) + (F_n - F_s) / (2 dy^2)
   // Two clamps and two products per cell instead of four; rounding differs from cell_div_vals only in
   // where the compiler contracts a*b - c*d.
-  auto face = [&](double Da, double Db, double2 lo, double2 hi) { return (Da + Db) * clampn(hi.y - lo.y, hi.x, lo.x); };
+  auto face = [&](double Da, double Db, double slope, double Hhi, double Hlo) { return (Da + Db) * clampn(slope, Hhi, Hlo); };
   // the rows just outside the strip: last row of the wavefront below, first row of the one above (the
   // outermost wavefronts read their own edge instead: rows 0 and TRY-1 are never in region_S)
   const double2 hs_s = sE[rd][w > 0 ? w - 1 : 0][w > 0 ? 1 : 0][lane];
@@ -396,16 +398,23 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   // One sweep up the strip: node row r, then cell row r; the node row and the north faces below the strip first.
   double2 hs_c = cell_HS(u[0], bb[0]);
   double2 e_c = dpp_from_east(hs_c);
-  double D_s = node(gj0 + r0 - 1, hs_s, dpp_from_east(hs_s), hs_c, e_c);
-  double F_s = face(dpp_from_west(D_s), D_s, hs_s, hs_c);
+  double dx_c = e_c.y - hs_c.y, hp_c = hs_c.x + e_c.x;
+  double D_s, F_s;
+  {
+    const double2 e_s = dpp_from_east(hs_s);
+    const double dyw = hs_c.y - hs_s.y;
+    D_s = node(gj0 + r0 - 1, e_s.y - hs_s.y, hs_s.x + e_s.x, dx_c, hp_c, dyw, e_c.y - e_s.y);
+    F_s = face(dpp_from_west(D_s), D_s, dyw, hs_c.x, hs_s.x);
+  }
 #pragma unroll
   for (int m = 0; m < TRPT; ++m) {
     const int gj = gj0 + r0 + m;
     const double2 hs_n = m + 1 < TRPT ? cell_HS(u[m + 1 < TRPT ? m + 1 : m], bb[m + 1 < TRPT ? m + 1 : m]) : hs_top;
     const double2 e_n = dpp_from_east(hs_n);
-    const double D_c = node(gj, hs_c, e_c, hs_n, e_n);
-    const double F_e = face(D_s, D_c, hs_c, e_c);
-    const double F_n = face(dpp_from_west(D_c), D_c, hs_c, hs_n);
+    const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, dyw = hs_n.y - hs_c.y;
+    const double D_c = node(gj, dx_c, hp_c, dx_n, hp_n, dyw, e_n.y - e_c.y);
+    const double F_e = face(D_s, D_c, dx_c, e_c.x, hs_c.x);
+    const double F_n = face(dpp_from_west(D_c), D_c, dyw, hs_n.x, hs_c.x);
     const double F_w = dpp_from_west(F_e);
     const double k = fma(g.hinv_dx2, F_e - F_w, g.hinv_dy2 * (F_n - F_s));
     // cells that must not move (boundary ring, outside the glacier): dtl is 0 on their lanes and the weights of
@@ -430,14 +439,14 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
       E[m] = fma(bhm, dtk, E[m]);
     }
     u[m] = un;
-    hs_c = hs_n; e_c = e_n; D_s = D_c; F_s = F_n;
+    hs_c = hs_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; D_s = D_c; F_s = F_n;
     // row fence: the stage body is one basic block and, left alone, the scheduler interleaves all seven rows
     // and spills ~130 VGPRs.  An empty asm that "rewrites" what the row produced and what the next row starts
     // from pins the row order without emitting an instruction.
     if (S == 1)
-      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(D_s), "+v"(F_s));
+      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(dx_c), "+v"(hp_c), "+v"(D_s), "+v"(F_s));
     else
-      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(D_s), "+v"(F_s));
+      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(dx_c), "+v"(hp_c), "+v"(D_s), "+v"(F_s));
   }
   if (S < 5) {
     sE[wr][w][0][lane] = cell_HS(u[0], bb[0]);
