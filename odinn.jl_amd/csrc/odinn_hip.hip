@@ -131,8 +131,6 @@ struct odinn_batch {
   int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr;
   int ntilesF = 0, ntilesFs = 0, ntilesFt = 0;
   double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr;
-  // the fused step runs on the small "latency" tiles when the throughput tiles cannot fill the 256 CUs
-  // (ODINN_FUSED_TILES=small|large overrides)
   mutable int fused_env = -1;  // ODINN_FUSED_TILES, parsed once: 0 unset, 1 small, 2 large, 3 strip
   int fused_override() const {
     if (fused_env < 0) {
@@ -141,17 +139,17 @@ struct odinn_batch {
     }
     return fused_env;
   }
-  bool small_tiles() const {
-    const int o = fused_override();
-    if (o) return o == 1;
-    return ntilesF <= 256;
-  }
-  // which fused-step kernel / tile table: 0 = FOX x FOY row-interleaved, 1 = FOX x FOYS latency tiles,
-  // 2 = FOX x FOYT strip kernel (integer-power law; ODINN_FUSED_TILES=large forces 0)
+  // which fused-step kernel / tile table: 0 = FOX x FOY row-interleaved kernel, 1 = FOX x FOYS latency tiles of the
+  // same kernel (a workgroup walks 18 region rows instead of 50: batches too small to fill the 256 CUs), 2 = FOX x FOYT
+  // strip kernel (integer-power law).  Measured crossover small <-> strip: ~100 strip tiles (one 512^2 glacier);
+  // ODINN_FUSED_TILES=small|large|t overrides.
   int fused_kind() const {
-    if (small_tiles()) return 1;
-    if (fused_override() == 2) return 0;
-    return lm() == 0 ? 2 : 0;
+    const int o = fused_override();
+    if (o == 1) return 1;
+    if (o == 2) return 0;
+    if (o == 3) return lm() == 0 ? 2 : 0;
+    if (lm() == 0) return ntilesFt >= 96 ? 2 : 1;
+    return ntilesF <= 256 ? 1 : 0;
   }
   const int4* fused_tiles() const { const int k = fused_kind(); return k == 2 ? d_tilesFt : k == 1 ? d_tilesFs : d_tilesF; }
   double* fused_part() const { const int k = fused_kind(); return k == 2 ? d_partFt : k == 1 ? d_partFs : d_partF; }
