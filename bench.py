@@ -9,7 +9,7 @@ it: one RDPK3Sp35 time step (5 RHS + stage updates per cell) + the controller (e
 reduction, PID) + the post-step kernel.  One cell-step = one cell through one fused
 RHS + stage update, so a step is 5 * cells cell-steps.  Two schedules of the same arithmetic
 exist: the default runs the five stages temporally fused in ONE kernel
-(k_rk_fused, ~24 B/cell of HBM traffic per step, fp64-VALU-bound); scheme 1 runs five per-stage
+(k_rk_fused_strip, ~24 B/cell of HBM traffic per step, fp64-VALU-bound); scheme 1 runs five per-stage
 kernels (k_rk_stage, 264 B/cell per step, HBM-bound).  `value` is the default schedule; both
 are timed and reported.
 
@@ -336,7 +336,7 @@ def main():
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
         if pm.get("workload_cells") == cells:
             traffic_stage = pm["k_rk_stage<2,0>"]["hbm_bytes_per_launch"]
-            traffic = pm.get("k_rk_fused<0>", {}).get("hbm_bytes_per_launch")
+            traffic = pm.get("k_rk_fused_strip", {}).get("hbm_bytes_per_launch")
     except Exception:
         pass
     if rank == 0:
@@ -370,7 +370,7 @@ def main():
             # the same arithmetic, where achieved <= peak has its usual meaning, is roofline_per_stage.
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_rk_fused<LM_FAST> (whole RDPK3Sp35 step, 5 stages temporally fused)",
+                "kernel": "k_rk_fused_strip (whole RDPK3Sp35 step, 5 stages temporally fused, integer-power law)",
                 "achieved": ach_fused,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -385,7 +385,7 @@ def main():
                 "hbm_traffic_GBs": (traffic / (ms_fused * 1e-3) / 1e9) if traffic else None,
                 "hbm_traffic_frac_of_peak": (traffic / (ms_fused * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "note": "frac > 1 is the point of temporal fusion: one launch does the work of five HBM-bound stage "
-                        "kernels while reading u,B once and writing u' once; the kernel is fp64-VALU-bound",
+                        "kernels while reading u,B once and writing u' once; the kernel is fp64-VALU-bound (PMC: VALU 84 % busy)",
                 "fp64_TFLOPs": FLOP_PER_CELL_STAGE * 5.0 * cells / (ms_fused * 1e-3) / 1e12,
                 "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS,
                 "fp64_frac": FLOP_PER_CELL_STAGE * 5.0 * cells / (ms_fused * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
