@@ -128,6 +128,8 @@ struct odinn_batch {
   long long ntot = 0, ntotd = 0;
   int ntiles = 0;
   // device pools
+  int* d_est = nullptr;        // per-glacier estimate of the steps still needed (written by the controller)
+  std::vector<int> h_est;
   int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr;
   int ntilesF = 0, ntilesFs = 0, ntilesFt = 0;
   double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr;
@@ -680,6 +682,11 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   int p = 0;
   int chunk = std::max(2, std::min(256, (n_stops - 1 + 1) & ~1));
   int polls = 0;
+  if (!euler) {
+    if (!b->d_est) CHK(dalloc(&b->d_est, (size_t)b->G));
+    C.est_steps = b->d_est;
+    b->h_est.assign(b->G, 0);
+  }
   while (nact > 0) {
     for (int s = 0; s < chunk; ++s) {
       if (scheme == 3) {
@@ -699,10 +706,18 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&nact, b->d_nactive, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    if (C.est_steps) HIPCHK(hipMemcpyAsync(b->h_est.data(), b->d_est, sizeof(int) * b->G, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (steps >= opt.maxiters && nact > 0) return fail(ODINN_ERR_MAXITERS, "maxiters (%lld) reached with %d glaciers active", (long long)opt.maxiters, nact);
-    // after the first batch the solve is usually a few steps from done (a rejection or two): 4, 8, then 16
-    chunk = polls == 0 ? 4 : (polls == 1 ? 8 : 16);
+    if (C.est_steps) {
+      // next poll when the slowest glacier should be done at its current step size (+2 for a rejection or two)
+      int est = 0;
+      for (int g = 0; g < b->G; ++g) est = std::max(est, b->h_est[g]);
+      chunk = std::max(2, std::min(64, (est + 2 + 1) & ~1));
+    } else {
+      chunk = polls == 0 ? 4 : (polls == 1 ? 8 : 16);
+    }
+    if (opt.maxiters - steps < chunk) chunk = (int)std::max<long long>(2, (opt.maxiters - steps + 1) & ~1LL);  // never run far past maxiters
     ++polls;
   }
   if (prof) tp3 = now();
@@ -895,7 +910,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
-  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt);
+  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt); dfree(b->d_est);
   dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
   dfree(b->d_rmbs); dfree(b->d_adj);
   dfree(b->d_partsteps);

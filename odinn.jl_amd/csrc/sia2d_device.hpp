@@ -936,6 +936,7 @@ struct CtrlArgs {
   const double* errpart;  // per-tile error partials: errpart[stride * tile]
   int stride;
   int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles, 3: FOYT tiles)
+  int* est_steps;         // [G] (nullable): estimated steps still needed, for the host's poll spacing
   double cfl;             // > 0: explicit Euler with dt = cfl*min(dx,dy)^2/(4 max D); the partials are tile maxima
   int cfl_prime;          // the launch only measured max D(u0): set the first dt, do not advance
   // reverse (continuous-adjoint) solve only; adj == null in the forward solve.  tstops are then
@@ -1072,6 +1073,7 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   if (gs->istop >= C.n_stops) {
     gs->done = 1;
     atomicSub(C.n_active, 1);
+    if (C.est_steps) C.est_steps[gidx] = 0;
     return;
   }
   double dtn = C.adaptive ? h * fac : C.fixed_dt;
@@ -1085,6 +1087,11 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
     gs->clipped = 0;
   }
   gs->dt = dtn;
+  if (C.est_steps) {  // at the current step size, and at least one step per remaining stop
+    const double e = ceil((C.tstops[C.n_stops - 1] - t) / (C.adaptive ? h * fac : dtn));
+    const int stops_left = C.n_stops - gs->istop;
+    C.est_steps[gidx] = e < (double)stops_left ? stops_left : (e > 1e6 ? 1000000 : (int)e);
+  }
   if (C.adj) adj_stage_weights(C.adj + gidx, C.tsnap, t, dtn, false);
 }
 
