@@ -1692,11 +1692,15 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     }
     HIPCHK(hipMemsetAsync(b->d_partsteps, 0, need * sizeof(double), b->stream));
   }
-  const int CHUNK = 16;
+  // polls as in do_solve: one step per stop at least, then the controller's estimate of what is left
+  if (!b->d_est) CHK(dalloc(&b->d_est, (size_t)G));
+  C.est_steps = b->d_est;
+  b->h_est.assign(G, 0);
+  int chunk = std::max(2, std::min(256, nr & ~1));
   long long steps = 0;
   int p = 0;
   while (nact > 0) {
-    for (int s_ = 0; s_ < CHUNK; ++s_) {
+    for (int s_ = 0; s_ < chunk; ++s_) {
       double* a0 = b->d_lam[p];
       double* a1 = b->d_lam[1 - p];
       // five stages ping-pong lam[p] -> lam[1-p] -> ... ; the step's result lands in lam[1-p]
@@ -1728,10 +1732,15 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&nact, b->d_nactive, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(b->h_est.data(), b->d_est, sizeof(int) * G, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     if (steps >= ao.maxiters && nact > 0)
       return fail(ODINN_ERR_MAXITERS, "maxiters (%lld) reached in the reverse solve with %d glaciers active",
                   (long long)ao.maxiters, nact);
+    int est = 0;
+    for (int g = 0; g < G; ++g) est = std::max(est, b->h_est[g]);
+    chunk = std::max(2, std::min(64, (est + 2 + 1) & ~1));
+    if (ao.maxiters - steps < chunk) chunk = (int)std::max<long long>(2, (ao.maxiters - steps + 1) & ~1LL);
   }
   std::vector<GState> gs(G);
   HIPCHK(hipMemcpy(gs.data(), b->d_gs, sizeof(GState) * G, hipMemcpyDeviceToHost));
