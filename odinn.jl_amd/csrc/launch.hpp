@@ -27,6 +27,9 @@ ODINN_DECL_LM(5)
 void launch_rk_fused_strip(int nblk, int afield, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
                            double* U1, double* partF, double abstol, double reltol, int skip);
 
+// k_adjf.hip, law mode 0 only
+void launch_adj_fused_strip(int nblk, int afield, hipStream_t st, Pools P, AdjFusedArgs A);
+
 // k_vel.hip (A-type law modes 0/1 only)
 struct VArgs;
 void launch_surface_V(int lm, int nblk, hipStream_t st, Pools P, const double* U, double* Vx, double* Vy, int base);

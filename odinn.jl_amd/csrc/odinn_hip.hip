@@ -1106,7 +1106,8 @@ int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H,
 }
 
 static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
-                            bool accumulate, double* part_deferred = nullptr, bool inplace = false) {
+                            bool accumulate, double* part_deferred = nullptr, bool inplace = false,
+                            const double* lam_alt = nullptr) {
   // part_deferred (A-type laws only): the per-tile partials go there and are NOT summed here;
   // inplace: they are ADDED onto part_deferred (which the caller zeroed and reduces at the end)
   // g < 0: all glaciers (swizzled table); result of A-type laws lands in d_Gsum / d_Gacc,
@@ -1115,7 +1116,7 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   const int base = g < 0 ? 0 : b->gd[g].tile0, nblk = g < 0 ? b->ntiles : b->gd[g].ntiles;
   if (nn_node) CHK(ensure_theta_scratch(b, nblk));
   ThArgs A{};
-  A.H = H; A.lam = lam; A.scales = scales;
+  A.H = H; A.lam = lam; A.lam_alt = lam_alt; A.scales = scales;
   A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
   A.part_theta = nn_node ? b->d_part_theta : nullptr;
   A.gscratch = nn_node ? b->d_gscratch : nullptr;
@@ -1692,6 +1693,16 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     }
     HIPCHK(hipMemsetAsync(b->d_partsteps, 0, need * sizeof(double), b->stream));
   }
+  // integer-power law + DiscreteVJP + thickness loss on a batch that fills the GPU: the five stages of a reverse step
+  // run as ONE kernel (sia2d_adj_fused.hpp); ODINN_ADJ_FUSED=0|1 overrides the choice
+  bool fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE && !useV && b->fused_kind() == 2;
+  if (const char* e = std::getenv("ODINN_ADJ_FUSED")) fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE && !useV && e[0] == '1';
+  AdjFusedArgs FA{};
+  if (fused_rev) {
+    FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
+    FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = ao.abstol; FA.reltol = ao.reltol;
+    C.errpart = b->d_partFt; C.stride = 1; C.fused = 3;
+  }
   // polls as in do_solve: one step per stop at least, then the controller's estimate of what is left
   if (!b->d_est) CHK(dalloc(&b->d_est, (size_t)G));
   C.est_steps = b->d_est;
@@ -1703,17 +1714,24 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     for (int s_ = 0; s_ < chunk; ++s_) {
       double* a0 = b->d_lam[p];
       double* a1 = b->d_lam[1 - p];
-      // five stages ping-pong lam[p] -> lam[1-p] -> ... ; the step's result lands in lam[1-p]
-      const double* src = a0;
-      double* dst = a1;
-      for (int stg = 1; stg <= 5; ++stg) {
-        SA.src = src; SA.dst = dst;
-        launch_adj_stage(lm, b->vjp_method, stg, b->ntiles, b->stream, Pl, L, SA);
-        double* t_ = const_cast<double*>(src);
-        src = dst;
-        dst = t_;
+      if (fused_rev) {
+        // the whole step in one kernel: reads lam[cur], writes lam[1 - cur] per glacier; the controller flips cur
+        // on acceptance (a rejected step is simply repeated from the untouched lam[cur])
+        launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, b->stream, Pl, FA);
+        C.next_cur = -1;
+      } else {
+        // five stages ping-pong lam[p] -> lam[1-p] -> ... ; the step's result lands in lam[1-p]
+        const double* src = a0;
+        double* dst = a1;
+        for (int stg = 1; stg <= 5; ++stg) {
+          SA.src = src; SA.dst = dst;
+          launch_adj_stage(lm, b->vjp_method, stg, b->ntiles, b->stream, Pl, L, SA);
+          double* t_ = const_cast<double*>(src);
+          src = dst;
+          dst = t_;
+        }
+        C.next_cur = 1 - p;
       }
-      C.next_cur = 1 - p;
       launch_controller(G, b->stream, Pl, C);
       launch_adj_poststep(b->ntiles, b->stream, Pl, AP, b->d_lam[0], b->d_lam[1]);
       if (useV) {
@@ -1726,7 +1744,11 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       }
       // quadrature node reached: dtheta += w * J_theta(H_itp(t))^T lam(t)  (:497-503); A-type laws add
       // onto per-tile running sums that are reduced once after the solve
-      CHK(theta_vjp_launch(b, b->d_tmpA, a1, b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace));
+      if (fused_rev)
+        CHK(theta_vjp_launch(b, b->d_tmpA, b->d_lam[0], b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace,
+                             b->d_lam[1]));
+      else
+        CHK(theta_vjp_launch(b, b->d_tmpA, a1, b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace));
       p = 1 - p;
       ++steps;
     }

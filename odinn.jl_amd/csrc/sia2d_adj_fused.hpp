@@ -1,0 +1,262 @@
+// sia2d_adj_fused.hpp -- one whole RDPK3Sp35 step of the REVERSE ODE of the continuous adjoint in ONE kernel
+//     dlam/dtau = J_H(H_itp(-tau))^T lam                     (gradient.jl:316-324, adjoint.jl:99-148)
+// for the integer-power A law with the DiscreteVJP stencil: the temporal fusion of k_adj_stage<1..5>, built
+// like k_rk_fused_strip (sia2d_fused.hpp): a wavefront owns TRPT contiguous region rows, a thread one column
+// of them; y-neighbours are the thread's own registers, x-neighbours arrive by DPP wave shifts, only the
+// first and last row of a strip cross wavefronts through a double-buffered LDS exchange (one barrier per
+// stage).  HBM traffic per step: read lam, H_j, H_j+1, B, write lam' = 40 B/cell instead of 5 x 72.
+//
+// Face form of the H-VJP.  k_vjp_H evaluates adjoint.jl:99-148 node by node (vjpH_node: every dual node
+// handles its four edges, so each edge is visited twice).  Here a thread owns, per row, its cell, the EAST and
+// NORTH face of the cell and the node at the cell's north-east corner:
+//   face e(c,r):  dS = S(c+1,r) - S(c,r),  q = lam(c+1,r) - lam(c,r)   (lam masked to the interior, the
+//                 transposed difference of adjoint.jl:100-101),  P = q clamp(dS; H(c+1,r), -H(c,r))
+//   node N(c,r):  Da = -(P_e(c,r) + P_e(c,r+1)) / (2 dx^2) - (P_n(c,r) + P_n(c+1,r)) / (2 dy^2)    (:102-104)
+//                 corner terms  alpha Da / 4 -+ beta gx Da / (2 dx) -+ beta gy Da / (2 dy)         (:123-127)
+//   face e(c,r), second term (:130-144, inversion_utils.jl:22-43):  t = (D(c,r-1) + D(c,r)) q / (2 dx^2);
+//                 +t to the minus cell (c,r) unless dS >= H+ or dS == -H-;  -t to the plus cell (c+1,r) unless
+//                 dS <= -H- or dS == H+   (strict inequalities of the reference; eta0 == 1 in this law mode)
+// and a cell gathers: its own node's SW term, the west lane's SE term and east-face plus part (one DPP of their
+// sum), the NW / NE terms and the north-face plus part of the row below (carried up the sweep).  The result is
+// masked by H > 0 (:147-148).  Per cell the same quantities as vjpH_node with the two visits of an edge
+// merged; rounding differs in where products are summed, nothing else.
+#pragma once
+#include "sia2d_fused.hpp"
+
+namespace odinn {
+
+// {Hc,S} and masked lambda of the first | last row of each wavefront's strip, double-buffered per stage
+typedef double2 (*AdjEdgesHS)[TNW][2][FRX];
+typedef double (*AdjEdgesL)[TNW][2][FRX];
+
+template <int S, bool AF>
+__device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __restrict__ Afield, const double* __restrict__ Ha,
+                                                 const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
+                                                 long long idc, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
+                                                 AdjEdgesL sLm, double (&u)[TRPT], double (&tmp)[TRPT], double (&E)[TRPT],
+                                                 const double* __restrict__ Bp) {
+  constexpr int rd = (S - 1) & 1, wr = S & 1;
+  const int r0 = TRPT * w;
+  [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
+  const bool intx = gi >= 1 && gi <= g.nx - 2, inx = gi >= 0 && gi < g.nx;
+  constexpr int s = S - 1;
+  constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
+  const double Gq = g.Gam * (1.0 / 1024.0);  // A Gam Hbar^k = (A Gam / 1024)(4 Hbar)^k scaled by exact powers of two
+  const double sw = a.sitp[S - 1];
+  long long idf = idc;  // idc again, but opaque after every row fence: keeps each row's global loads in its own row
+  // {Hc, S} of one of the thread's rows at a stage time: H_itp = H_j + sw (H_j+1 - H_j) (load_tile_HS2's formula)
+  // and B re-read from global memory (L2-resident); zeros outside the grid
+  auto hs_itp = [&](int m, double swt) {
+    const int gj = gj0 + r0 + m;
+    const bool have = inx && gj >= 0 && gj < g.ny;
+    const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
+    const long long id = idf + (long long)g.nx * gjc;
+    const double ha = Ha[id], hb = Hb[id], b = Bp[id];
+    const double h = fma(swt, hb - ha, ha);
+    return cell_HS(have ? h : 0.0, have ? b : 0.0);
+  };
+  auto lam_e = [&](int m) {  // lambda masked to the interior cells
+    const int gj = gj0 + r0 + m;
+    return (intx && gj >= 1 && gj <= g.ny - 2) ? u[m] : 0.0;
+  };
+  // the rows just outside the strip (the outermost wavefronts read their own edge: rows 0 and TRY-1 are never in region_S)
+  const int wb = w > 0 ? w - 1 : 0, eb = w > 0 ? 1 : 0, wt = w + 1 < TNW ? w + 1 : w, et = w + 1 < TNW ? 0 : 1;
+  const double2 hs_s = sE[rd][wb][eb][lane], hs_top = sE[rd][wt][et][lane];
+  const double le_s = sLm[rd][wb][eb][lane], le_top = sLm[rd][wt][et][lane];
+  // carried up the sweep (suffix _c: the row being processed)
+  double2 hs_c = hs_itp(0, sw);
+  double le_c = lam_e(0);
+  double2 e_c = dpp_from_east(hs_c);
+  double lee_c = dpp_shift(le_c, false);
+  double dx_c = e_c.y - hs_c.y, hp_c = hs_c.x + e_c.x, qe_c = lee_c - le_c;
+  double Pe_c = qe_c * clampn(dx_c, e_c.x, hs_c.x);
+  double D_s, K01_s, K11w_s, PL_s;
+  double2 hs_next = hs_itp(TRPT > 1 ? 1 : 0, sw);  // {Hc,S} of row m+1, fetched one row ahead of its use
+
+  // node N(c, r) and north face n(c, r) of a row whose own / east-face quantities are the "_lo" arguments and whose
+  // upper neighbours are the "_hi" ones; returns D, the four corner terms and the north face's two second-term parts
+  auto node_face = [&](int gj, double2 hs_lo, double2 e_lo, double le_lo, double dx_lo, double hp_lo, double Pe_lo,
+                       double2 hs_hi, double2 e_hi, double le_hi, double dx_hi, double hp_hi, double Pe_hi, double& D,
+                       double& k00, double& k10, double& k01, double& k11, double& Mn, double& PLn) {
+    const double dyw = hs_hi.y - hs_lo.y, dye = e_hi.y - e_lo.y;
+    const double qn = le_hi - le_lo;
+    const double Pn = qn * clampn(dyw, hs_hi.x, hs_lo.x);
+    const double Pn_e = dpp_shift(Pn, false);
+    const double gx = (dx_lo + dx_hi) * g.hinv_dx, gy = (dyw + dye) * g.hinv_dy;
+    const double Hs = hp_lo + hp_hi;  // 4 Hbar
+    const double gS2 = gx * gx + gy * gy;
+    double An = g.A;
+    if (AF) {
+      const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+      An = Afield[g.offd + (ok ? gi + (long long)(g.nx - 1) * gj : 0LL)];
+    }
+    const double Kq = An * Gq;
+    const double H2 = Hs * Hs, H4 = H2 * H2, H5 = H4 * Hs;
+    D = (Kq * H5) * gS2;
+    const double Da = -fma(g.hinv_dx2, Pe_lo + Pe_hi, g.hinv_dy2 * (Pn + Pn_e));
+    const double ad = (((Kq * 5.0) * H4) * gS2) * Da;  // alpha Da / 4
+    const double bd = ((Kq * 2.0) * H5) * Da;           // beta Da
+    const double bx = g.hinv_dx * (bd * gx), by = g.hinv_dy * (bd * gy);
+    const double am = ad - bx, ap = ad + bx;
+    k00 = am - by; k10 = ap - by; k01 = am + by; k11 = ap + by;
+    // north face, second term
+    const double Dw = dpp_from_west(D);
+    const double tn = ((Dw + D) * g.hinv_dy2) * qn;
+    Mn = (dyw < hs_hi.x && dyw != -hs_lo.x) ? tn : 0.0;
+    PLn = (dyw > -hs_lo.x && dyw != hs_hi.x) ? -tn : 0.0;
+  };
+
+  {  // the node row and the north faces just below the strip
+    const double2 e_s = dpp_from_east(hs_s);
+    const double lee_s = dpp_shift(le_s, false);
+    const double dx_s = e_s.y - hs_s.y, hp_s = hs_s.x + e_s.x;
+    const double Pe_s = (lee_s - le_s) * clampn(dx_s, e_s.x, hs_s.x);
+    double k00, k10, k01, k11, Mn;
+    node_face(gj0 + r0 - 1, hs_s, e_s, le_s, dx_s, hp_s, Pe_s, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, D_s, k00, k10, k01, k11, Mn, PL_s);
+    K01_s = k01;
+    K11w_s = dpp_from_west(k11);
+  }
+#pragma unroll
+  for (int m = 0; m < TRPT; ++m) {
+    const int gj = gj0 + r0 + m;
+    const double2 hs_n = m + 1 < TRPT ? hs_next : hs_top;
+    if (m + 2 < TRPT) hs_next = hs_itp(m + 2 < TRPT ? m + 2 : m, sw);
+    const double le_n = m + 1 < TRPT ? lam_e(m + 1 < TRPT ? m + 1 : m) : le_top;
+    const double2 e_n = dpp_from_east(hs_n);
+    const double lee_n = dpp_shift(le_n, false);
+    const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, qe_n = lee_n - le_n;
+    const double Pe_n = qe_n * clampn(dx_n, e_n.x, hs_n.x);
+    double D_c, k00, k10, k01, k11, Mn, PLn;
+    node_face(gj, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, hs_n, e_n, le_n, dx_n, hp_n, Pe_n, D_c, k00, k10, k01, k11, Mn, PLn);
+    // east face of this row, second term
+    const double te = ((D_s + D_c) * g.hinv_dx2) * qe_c;
+    const double Me = (dx_c < e_c.x && dx_c != -hs_c.x) ? te : 0.0;
+    const double PLe = (dx_c > -hs_c.x && dx_c != e_c.x) ? -te : 0.0;
+    const double W = dpp_from_west(k10 + PLe);  // what the lane to the west holds for this cell
+    double v = ((k00 + W) + (K01_s + K11w_s)) + ((Me + Mn) + PL_s);
+    v = hs_c.x > 0.0 ? v : 0.0;
+    // 3S*+ stage update of lambda (k_adj_stage)
+    const double dtk = dt * v;
+    const double uo = u[m];
+    double un;
+    if (S == 1) {
+      un = fma(bt, dtk, uo);
+      E[m] = bh * dtk;
+    } else {
+      const double t = fma(dl, uo, tmp[m]);
+      un = fma(g1, uo, g2 * t);
+      if (S >= 4) {
+        const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
+        un = fma(g3, src[idf + (long long)g.nx * gjc], un);
+      }
+      un = fma(bt, dtk, un);
+      if (dl != 0.0) tmp[m] = t;
+      E[m] = fma(bh, dtk, E[m]);
+    }
+    u[m] = un;
+    hs_c = hs_n; le_c = le_n; e_c = e_n; lee_c = lee_n; dx_c = dx_n; hp_c = hp_n; qe_c = qe_n; Pe_c = Pe_n;
+    D_s = D_c; K01_s = k01; K11w_s = dpp_from_west(k11); PL_s = PLn;
+    // row fence (see k_rk_fused_strip): pins the row order of this one-basic-block stage body
+    if (S == 1)
+      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y), "+v"(lee_c),
+                   "+v"(D_s), "+v"(K01_s), "+v"(K11w_s), "+v"(PL_s), "+v"(idf));
+    else
+      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y),
+                   "+v"(lee_c), "+v"(D_s), "+v"(K01_s), "+v"(K11w_s), "+v"(PL_s), "+v"(idf));
+  }
+  if (S < 5) {  // publish the strip's edge rows for the next stage: H at ITS time, lambda just updated
+    const double swn = a.sitp[S < 5 ? S : 4];
+    sE[wr][w][0][lane] = hs_itp(0, swn);
+    sE[wr][w][1][lane] = hs_itp(TRPT - 1, swn);
+    sLm[wr][w][0][lane] = lam_e(0);
+    sLm[wr][w][1][lane] = lam_e(TRPT - 1);
+    __syncthreads();
+  }
+}
+
+template <bool AF>
+__global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
+  __shared__ double2 sE[2][TNW][2][FRX];
+  __shared__ double sLm[2][TNW][2][FRX];
+  __shared__ double red[TNW];
+  const int4 t4 = A.tilesF[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  if (gs->done) return;
+  const GDev g = P.gd[t4.x];
+  const AdjState a = A.adj[t4.x];
+  const double dt = gs->dt;
+  const double* __restrict__ src = gs->cur ? A.lam1 : A.lam0;
+  double* __restrict__ dst = gs->cur ? A.lam0 : A.lam1;
+  const double* __restrict__ Ha = A.snaps + (long long)a.seg * A.ntot;
+  const double* __restrict__ Hb = Ha + A.ntot;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOYT - FH;
+  const int gi = gi0 + lane, r0 = TRPT * w;
+  const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
+  const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
+  const long long idc = g.off + gic;
+  const long long id0 = g.off + gi + (long long)g.nx * (gj0 + r0);
+  double u[TRPT], tmp[TRPT], E[TRPT];
+#pragma unroll
+  for (int m = 0; m < TRPT; ++m) {
+    const int gj = gj0 + r0 + m;
+    double l = 0.0;
+    if (inx && gj >= 0 && gj < g.ny) l = src[id0 + (long long)g.nx * m];
+    u[m] = l; tmp[m] = l; E[m] = 0.0;
+  }
+  {  // edge rows for stage 1
+    auto edge = [&](int m, int e) {
+      const int gj = gj0 + r0 + m;
+      double h = 0.0, b = 0.0;
+      if (inx && gj >= 0 && gj < g.ny) {
+        const double ha = Ha[id0 + (long long)g.nx * m];
+        h = fma(a.sitp[0], Hb[id0 + (long long)g.nx * m] - ha, ha);
+        b = P.B[id0 + (long long)g.nx * m];
+      }
+      sE[0][w][e][lane] = cell_HS(h, b);
+      sLm[0][w][e][lane] = (intx && gj >= 1 && gj <= g.ny - 2) ? u[m] : 0.0;
+    };
+    edge(0, 0);
+    edge(TRPT - 1, 1);
+  }
+  __syncthreads();
+  adj_strip_stage<1, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
+  adj_strip_stage<2, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
+  adj_strip_stage<3, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
+  adj_strip_stage<4, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
+  adj_strip_stage<5, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
+  // ---- output rows [FH, TRY-1-FH]: lam' from the registers, embedded error partial -----------------------
+  const bool ocol = lane >= FH && lane < FH + FOX && inx;
+  double errsq = 0.0;
+  double upf[TRPT];
+#pragma unroll
+  for (int m = 0; m < TRPT; ++m) {
+    const int r = r0 + m, gj = gj0 + r;
+    const bool out = r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny;
+    upf[m] = src[out ? id0 + (long long)g.nx * m : g.off];
+  }
+#pragma unroll
+  for (int m = 0; m < TRPT; ++m) {
+    const int r = r0 + m, gj = gj0 + r;
+    if (r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny) {
+      const double upv = upf[m];
+      dst[id0 + (long long)g.nx * m] = u[m];
+      const double err = (u[m] - upv) - E[m];
+      const double sk = A.abstol + fmax(fabs(upv), fabs(u[m])) * A.reltol;
+      const double q = err / sk;
+      errsq = fma(q, q, errsq);
+    }
+  }
+  errsq = wave_sum(errsq);
+  if (lane == 0) red[w] = errsq;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < TNW; ++k) sum += red[k];
+    A.partF[t4.w] = sum;
+  }
+}
+
+}  // namespace odinn

@@ -1529,6 +1529,19 @@ struct AdjStageArgs {
   double abstol, reltol;
 };
 
+// arguments of k_adj_fused_strip (sia2d_adj_fused.hpp): the five stages of a reverse step in one kernel
+struct AdjFusedArgs {
+  const double* snaps;  // forward snapshots [n_snap][ntot]
+  long long ntot;
+  const AdjState* adj;
+  double* lam0;         // lambda ping-pong: the step reads lam[cur] and writes lam[1 - cur]; the controller
+  double* lam1;         // flips cur on acceptance, so a rejected step needs no copy
+  double* partF;        // error partials, FOX x FOYT tile table
+  const int4* tilesF;
+  double abstol, reltol;
+};
+
+
 template <int STAGE, int LM, int VJ = 0>
 __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_stage(Pools P, LawDev L, AdjStageArgs A) {
   __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
@@ -1623,6 +1636,7 @@ struct ThArgs {
   double* Gacc;          // dual pooled accumulator (gridded A) or null
   double* part_theta;    // [ntiles_total][P] for Y/U laws or null
   double* gscratch;      // thread-private gradient scratch [P][grid*NT]
+  const double* lam_alt; // non-null: lambda of glacier g is in lam_alt where gs[g].cur == 1 (fused reverse step: per-glacier ping-pong)
   int accum;             // A-type laws: add the tile's sum onto its partial slot instead of overwriting it
                          // (one reduction after a whole reverse solve instead of one per step)
 };
@@ -1657,7 +1671,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
     }
     return;
   }
-  load_tile_lam(A.lam, g, i0, j0, sL, ownL);
+  load_tile_lam((A.lam_alt && P.gs[t4.x].cur) ? A.lam_alt : A.lam, g, i0, j0, sL, ownL);
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = wave_id();
   double acc = 0.0;

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta_nn(Pools P, LawDev L, ThArgs A
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double ownH[RPT], ownL[RPT];
   load_tile_HS2(A.H, P.B, g, i0, j0, sHS, ownH);
-  load_tile_lam(A.lam, g, i0, j0, sL, ownL);
+  load_tile_lam((A.lam_alt && P.gs[t4.x].cur) ? A.lam_alt : A.lam, g, i0, j0, sL, ownL);
   if (threadIdx.x == 0) any_active = 0;
   __syncthreads();
   const int tx = threadIdx.x & 63, ty = wave_id();
