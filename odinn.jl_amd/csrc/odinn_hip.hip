@@ -1922,6 +1922,14 @@ static int timed_one(odinn_batch* b, int which, int it) {
       launch_adj_stage(b->lm(), 0, 2, b->ntiles, b->stream, P, L, SA);
       return ODINN_OK;
     }
+    case ODINN_TIMED_ADJ_FUSED_STEP: {
+      if (b->lm() != 0) return fail(ODINN_ERR_STATE, "the fused reverse step exists for the integer-power law only");
+      AdjFusedArgs FA{};
+      FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
+      FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = 1e-8; FA.reltol = 1e-8;
+      launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, b->stream, P, FA);
+      return ODINN_OK;
+    }
     default: return fail(ODINN_ERR_ARG, "unknown timed kernel %d", which);
   }
 }

@@ -25,6 +25,15 @@
 
 namespace odinn {
 
+// base[idx] with a block-uniform base and a 32-bit BYTE offset (a glacier has < 2^29 cells), the form the
+// scalar-base addressing mode of global_load / global_store needs: no 64-bit address arithmetic per access
+__device__ __forceinline__ double ldg32(const double* __restrict__ base, unsigned idx) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
+}
+__device__ __forceinline__ void stg32(double* __restrict__ base, unsigned idx, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (idx << 3)) = v;
+}
+
 // {Hc,S} and masked lambda of the first | last row of each wavefront's strip, double-buffered per stage
 typedef double2 (*AdjEdgesHS)[TNW][2][FRX];
 typedef double (*AdjEdgesL)[TNW][2][FRX];
@@ -32,28 +41,29 @@ typedef double (*AdjEdgesL)[TNW][2][FRX];
 template <int S, bool AF>
 __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __restrict__ Afield, const double* __restrict__ Ha,
                                                  const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
-                                                 long long idc, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
+                                                 int gic, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
                                                  AdjEdgesL sLm, double (&u)[TRPT], double (&tmp)[TRPT], double (&E)[TRPT],
                                                  const double* __restrict__ Bp) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;
   const int r0 = TRPT * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
-  const bool intx = gi >= 1 && gi <= g.nx - 2, inx = gi >= 0 && gi < g.nx;
+  const bool intx = gi >= 1 && gi <= g.nx - 2;
   constexpr int s = S - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
   const double Gq = g.Gam * (1.0 / 1024.0);  // A Gam Hbar^k = (A Gam / 1024)(4 Hbar)^k scaled by exact powers of two
   const double sw = a.sitp[S - 1];
-  long long idf = idc;  // idc again, but opaque after every row fence: keeps each row's global loads in its own row
+  // Ha, Hb, src, Bp point at the glacier's first cell (block-uniform: scalar base registers); a cell is addressed by a
+  // 32-bit index.  gif: the clamped column again, but opaque after every row fence -- keeps each row's loads in its row
+  int gif = gic;
   // {Hc, S} of one of the thread's rows at a stage time: H_itp = H_j + sw (H_j+1 - H_j) (load_tile_HS2's formula)
-  // and B re-read from global memory (L2-resident); zeros outside the grid
+  // and B re-read from global memory (L2-resident).  Outside the grid the index is clamped and whatever it picks
+  // up is never used: lambda is masked to the interior, so every term that touches such a cell carries a factor 0.
   auto hs_itp = [&](int m, double swt) {
     const int gj = gj0 + r0 + m;
-    const bool have = inx && gj >= 0 && gj < g.ny;
     const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
-    const long long id = idf + (long long)g.nx * gjc;
-    const double ha = Ha[id], hb = Hb[id], b = Bp[id];
-    const double h = fma(swt, hb - ha, ha);
-    return cell_HS(have ? h : 0.0, have ? b : 0.0);
+    const unsigned id = (unsigned)(gif + g.nx * gjc);  // zero-extended: scalar base + 32-bit offset addressing
+    const double ha = ldg32(Ha, id), hb = ldg32(Hb, id), b = ldg32(Bp, id);
+    return cell_HS(fma(swt, hb - ha, ha), b);
   };
   auto lam_e = [&](int m) {  // lambda masked to the interior cells
     const int gj = gj0 + r0 + m;
@@ -67,10 +77,9 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   double2 hs_c = hs_itp(0, sw);
   double le_c = lam_e(0);
   double2 e_c = dpp_from_east(hs_c);
-  double lee_c = dpp_shift(le_c, false);
-  double dx_c = e_c.y - hs_c.y, hp_c = hs_c.x + e_c.x, qe_c = lee_c - le_c;
+  double dx_c = e_c.y - hs_c.y, hp_c = hs_c.x + e_c.x, qe_c = dpp_shift(le_c, false) - le_c;
   double Pe_c = qe_c * clampn(dx_c, e_c.x, hs_c.x);
-  double D_s, K01_s, K11w_s, PL_s;
+  double D_s, C_s;  // C_s: what the row below holds for this cell (its nodes' NW / NE terms, its north face's plus part)
   double2 hs_next = hs_itp(TRPT > 1 ? 1 : 0, sw);  // {Hc,S} of row m+1, fetched one row ahead of its use
 
   // node N(c, r) and north face n(c, r) of a row whose own / east-face quantities are the "_lo" arguments and whose
@@ -111,10 +120,9 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     const double lee_s = dpp_shift(le_s, false);
     const double dx_s = e_s.y - hs_s.y, hp_s = hs_s.x + e_s.x;
     const double Pe_s = (lee_s - le_s) * clampn(dx_s, e_s.x, hs_s.x);
-    double k00, k10, k01, k11, Mn;
-    node_face(gj0 + r0 - 1, hs_s, e_s, le_s, dx_s, hp_s, Pe_s, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, D_s, k00, k10, k01, k11, Mn, PL_s);
-    K01_s = k01;
-    K11w_s = dpp_from_west(k11);
+    double k00, k10, k01, k11, Mn, PLn;
+    node_face(gj0 + r0 - 1, hs_s, e_s, le_s, dx_s, hp_s, Pe_s, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, D_s, k00, k10, k01, k11, Mn, PLn);
+    C_s = (k01 + dpp_from_west(k11)) + PLn;
   }
 #pragma unroll
   for (int m = 0; m < TRPT; ++m) {
@@ -133,7 +141,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     const double Me = (dx_c < e_c.x && dx_c != -hs_c.x) ? te : 0.0;
     const double PLe = (dx_c > -hs_c.x && dx_c != e_c.x) ? -te : 0.0;
     const double W = dpp_from_west(k10 + PLe);  // what the lane to the west holds for this cell
-    double v = ((k00 + W) + (K01_s + K11w_s)) + ((Me + Mn) + PL_s);
+    double v = ((k00 + W) + C_s) + (Me + Mn);
     v = hs_c.x > 0.0 ? v : 0.0;
     // 3S*+ stage update of lambda (k_adj_stage)
     const double dtk = dt * v;
@@ -147,22 +155,22 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
       un = fma(g1, uo, g2 * t);
       if (S >= 4) {
         const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
-        un = fma(g3, src[idf + (long long)g.nx * gjc], un);
+        un = fma(g3, ldg32(src, (unsigned)(gif + g.nx * gjc)), un);
       }
       un = fma(bt, dtk, un);
       if (dl != 0.0) tmp[m] = t;
       E[m] = fma(bh, dtk, E[m]);
     }
     u[m] = un;
-    hs_c = hs_n; le_c = le_n; e_c = e_n; lee_c = lee_n; dx_c = dx_n; hp_c = hp_n; qe_c = qe_n; Pe_c = Pe_n;
-    D_s = D_c; K01_s = k01; K11w_s = dpp_from_west(k11); PL_s = PLn;
+    hs_c = hs_n; le_c = le_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; qe_c = qe_n; Pe_c = Pe_n;
+    D_s = D_c; C_s = (k01 + dpp_from_west(k11)) + PLn;
     // row fence (see k_rk_fused_strip): pins the row order of this one-basic-block stage body
     if (S == 1)
-      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y), "+v"(lee_c),
-                   "+v"(D_s), "+v"(K01_s), "+v"(K11w_s), "+v"(PL_s), "+v"(idf));
+      asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y), "+v"(qe_c),
+                   "+v"(Pe_c), "+v"(D_s), "+v"(C_s), "+v"(gif));
     else
       asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y),
-                   "+v"(lee_c), "+v"(D_s), "+v"(K01_s), "+v"(K11w_s), "+v"(PL_s), "+v"(idf));
+                   "+v"(qe_c), "+v"(Pe_c), "+v"(D_s), "+v"(C_s), "+v"(gif));
   }
   if (S < 5) {  // publish the strip's edge rows for the next stage: H at ITS time, lambda just updated
     const double swn = a.sitp[S < 5 ? S : 4];
@@ -185,24 +193,25 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
   const GDev g = P.gd[t4.x];
   const AdjState a = A.adj[t4.x];
   const double dt = gs->dt;
-  const double* __restrict__ src = gs->cur ? A.lam1 : A.lam0;
-  double* __restrict__ dst = gs->cur ? A.lam0 : A.lam1;
-  const double* __restrict__ Ha = A.snaps + (long long)a.seg * A.ntot;
+  // everything below is addressed relative to the glacier's first cell (block-uniform bases, 32-bit cell indices)
+  const double* __restrict__ src = (gs->cur ? A.lam1 : A.lam0) + g.off;
+  double* __restrict__ dst = (gs->cur ? A.lam0 : A.lam1) + g.off;
+  const double* __restrict__ Ha = A.snaps + (long long)a.seg * A.ntot + g.off;
   const double* __restrict__ Hb = Ha + A.ntot;
+  const double* __restrict__ Bg = P.B + g.off;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOYT - FH;
   const int gi = gi0 + lane, r0 = TRPT * w;
   const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
   const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
-  const long long idc = g.off + gic;
-  const long long id0 = g.off + gi + (long long)g.nx * (gj0 + r0);
+  const int id0 = gi + g.nx * (gj0 + r0);
   double u[TRPT], tmp[TRPT], E[TRPT];
 #pragma unroll
   for (int m = 0; m < TRPT; ++m) {
     const int gj = gj0 + r0 + m;
     double l = 0.0;
-    if (inx && gj >= 0 && gj < g.ny) l = src[id0 + (long long)g.nx * m];
+    if (inx && gj >= 0 && gj < g.ny) l = ldg32(src, (unsigned)(id0 + g.nx * m));
     u[m] = l; tmp[m] = l; E[m] = 0.0;
   }
   {  // edge rows for stage 1
@@ -210,9 +219,10 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
       const int gj = gj0 + r0 + m;
       double h = 0.0, b = 0.0;
       if (inx && gj >= 0 && gj < g.ny) {
-        const double ha = Ha[id0 + (long long)g.nx * m];
-        h = fma(a.sitp[0], Hb[id0 + (long long)g.nx * m] - ha, ha);
-        b = P.B[id0 + (long long)g.nx * m];
+        const unsigned id = (unsigned)(id0 + g.nx * m);
+        const double ha = ldg32(Ha, id);
+        h = fma(a.sitp[0], ldg32(Hb, id) - ha, ha);
+        b = ldg32(Bg, id);
       }
       sE[0][w][e][lane] = cell_HS(h, b);
       sLm[0][w][e][lane] = (intx && gj >= 1 && gj <= g.ny - 2) ? u[m] : 0.0;
@@ -221,11 +231,11 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
     edge(TRPT - 1, 1);
   }
   __syncthreads();
-  adj_strip_stage<1, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
-  adj_strip_stage<2, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
-  adj_strip_stage<3, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
-  adj_strip_stage<4, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
-  adj_strip_stage<5, AF>(g, P.Afield, Ha, Hb, src, a, idc, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, P.B);
+  adj_strip_stage<1, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<2, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<3, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<4, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<5, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
   // ---- output rows [FH, TRY-1-FH]: lam' from the registers, embedded error partial -----------------------
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   double errsq = 0.0;
@@ -234,14 +244,14 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
   for (int m = 0; m < TRPT; ++m) {
     const int r = r0 + m, gj = gj0 + r;
     const bool out = r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny;
-    upf[m] = src[out ? id0 + (long long)g.nx * m : g.off];
+    upf[m] = ldg32(src, (unsigned)(out ? id0 + g.nx * m : 0));
   }
 #pragma unroll
   for (int m = 0; m < TRPT; ++m) {
     const int r = r0 + m, gj = gj0 + r;
     if (r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny) {
       const double upv = upf[m];
-      dst[id0 + (long long)g.nx * m] = u[m];
+      stg32(dst, (unsigned)(id0 + g.nx * m), u[m]);
       const double err = (u[m] - upv) - E[m];
       const double sk = A.abstol + fmax(fabs(upv), fabs(u[m])) * A.reltol;
       const double q = err / sk;
