@@ -25,15 +25,6 @@
 
 namespace odinn {
 
-// base[idx] with a block-uniform base and a 32-bit BYTE offset (a glacier has < 2^29 cells), the form the
-// scalar-base addressing mode of global_load / global_store needs: no 64-bit address arithmetic per access
-__device__ __forceinline__ double ldg32(const double* __restrict__ base, unsigned idx) {
-  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
-}
-__device__ __forceinline__ void stg32(double* __restrict__ base, unsigned idx, double v) {
-  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (idx << 3)) = v;
-}
-
 // {Hc,S} and masked lambda of the first | last row of each wavefront's strip, double-buffered per stage
 typedef double2 (*AdjEdgesHS)[TNW][2][FRX];
 typedef double (*AdjEdgesL)[TNW][2][FRX];
@@ -97,7 +88,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     double An = g.A;
     if (AF) {
       const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
-      An = Afield[g.offd + (ok ? gi + (long long)(g.nx - 1) * gj : 0LL)];
+      An = ldg32(Afield, (unsigned)(ok ? gif + (g.nx - 1) * gj : 0));  // Afield: the glacier's first dual node (ok: gif == gi)
     }
     const double Kq = An * Gq;
     const double H2 = Hs * Hs, H4 = H2 * H2, H5 = H4 * Hs;
@@ -199,6 +190,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
   const double* __restrict__ Ha = A.snaps + (long long)a.seg * A.ntot + g.off;
   const double* __restrict__ Hb = Ha + A.ntot;
   const double* __restrict__ Bg = P.B + g.off;
+  const double* __restrict__ Afg = AF ? P.Afield + g.offd : nullptr;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOYT - FH;
@@ -231,11 +223,11 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
     edge(TRPT - 1, 1);
   }
   __syncthreads();
-  adj_strip_stage<1, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
-  adj_strip_stage<2, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
-  adj_strip_stage<3, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
-  adj_strip_stage<4, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
-  adj_strip_stage<5, AF>(g, P.Afield, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<1, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<2, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<3, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<4, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<5, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
   // ---- output rows [FH, TRY-1-FH]: lam' from the registers, embedded error partial -----------------------
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   double errsq = 0.0;

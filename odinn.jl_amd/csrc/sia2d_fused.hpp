@@ -328,6 +328,14 @@ __global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused(Pools P, LawDev L,
 // re-read from global memory (L2-resident) instead of being held in 14 VGPRs.
 // Every wavefront runs all its rows in every stage; rows and columns outside region_S compute on
 // stale neighbours and nothing inside region_{S+1} ever reads them (see fused_stage_fast).
+// base[idx] with a block-uniform base and a 32-bit BYTE offset (a glacier has < 2^29 cells), the form the
+// scalar-base addressing mode of global_load / global_store needs: no 64-bit address arithmetic per access
+__device__ __forceinline__ double ldg32(const double* __restrict__ base, unsigned idx) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
+}
+__device__ __forceinline__ void stg32(double* __restrict__ base, unsigned idx, double v) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (idx << 3)) = v;
+}
 __device__ __forceinline__ double dpp_shift(double x, const bool from_west) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   if (from_west) {  // lane c receives lane c-1's value (wave_shr:1); lane 0 gets 0
@@ -352,10 +360,11 @@ typedef double2 (*StripEdges)[TNW][2][FRX];
 
 template <int S, bool AF>
 __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
-                                             const double* __restrict__ src, long long idc, int gi, int gj0, int w, int lane,
+                                             const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                              double dtl, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
                                              double (&E)[TRPT], const double (&bb)[TRPT]) {
-  // idc: linear index of (gi clamped into the grid, row 0); dtl: dt on the lanes with 1 <= gi <= nx-2, else 0
+  // src, Afield: based at the glacier's first cell / dual node (block-uniform), cells addressed by 32-bit indices;
+  // gic: gi clamped into the grid; dtl: dt on the lanes with 1 <= gi <= nx-2, else 0
   constexpr int rd = (S - 1) & 1, wr = S & 1;  // stage S reads the edge rows from buffer rd, publishes into wr
   const int r0 = TRPT * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
@@ -377,7 +386,7 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
     double An = g.A;
     if (AF) {
       const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
-      An = Afield[g.offd + (ok ? gi + (long long)(g.nx - 1) * gj : 0LL)];
+      An = ldg32(Afield, (unsigned)(ok ? gi + (g.nx - 1) * gj : 0));
     }
     const double H2 = H4s * H4s, H4 = H2 * H2;
     return (An * Gq) * (H4 * H4s) * gS2;
@@ -432,7 +441,7 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
       un = fma(g1, uo, g2 * t);
       if (S >= 4) {  // u_n from global memory; what cells outside the glacier pick up is never read (see node)
         const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
-        un = fma(g3, src[idc + (long long)g.nx * gjc], un);
+        un = fma(g3, ldg32(src, (unsigned)(gic + g.nx * gjc)), un);
       }
       un = fma(btm, dtk, un);
       if (dl != 0.0) tmp[m] = t;
@@ -457,14 +466,14 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
 
 template <bool AF>
 __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
-                                              const double* __restrict__ src, long long idc, int gi, int gj0, int w, int lane,
+                                              const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                               double dtl, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
                                               double (&E)[TRPT], const double (&bb)[TRPT]) {
-  strip_stage<1, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<2, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<3, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<4, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<5, AF>(g, L, Afield, src, idc, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<1, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<2, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<3, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<4, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<5, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
 }
 
 // AF: A from the dual-grid field.  One stage path per kernel: with two paths in one kernel the register allocator
@@ -481,14 +490,16 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   if (gs->done) return;
   const GDev g = P.gd[t4.x];
   const double dt = gs->dt;
-  const double* __restrict__ src = gs->cur ? U1 : U0;
-  double* __restrict__ dst = gs->cur ? U0 : U1;
+  // everything below is addressed relative to the glacier's first cell (block-uniform bases, 32-bit cell indices)
+  const double* __restrict__ src = (gs->cur ? U1 : U0) + g.off;
+  double* __restrict__ dst = (gs->cur ? U0 : U1) + g.off;
+  const double* __restrict__ Bg = P.B + g.off;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOYT - FH;
   const int gi = gi0 + lane, r0 = TRPT * w;
   const bool inx = gi >= 0 && gi < g.nx;
-  const long long id0 = g.off + gi + (long long)g.nx * (gj0 + r0);
+  const int id0 = gi + g.nx * (gj0 + r0);
   double u[TRPT], tmp[TRPT], E[TRPT], bb[TRPT];
   bool nz = false;
 #pragma unroll
@@ -496,8 +507,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     const int gj = gj0 + r0 + m;
     double h = 0.0, b = 0.0;
     if (inx && gj >= 0 && gj < g.ny) {
-      h = src[id0 + (long long)g.nx * m];
-      b = P.B[id0 + (long long)g.nx * m];
+      h = ldg32(src, (unsigned)(id0 + g.nx * m));
+      b = ldg32(Bg, (unsigned)(id0 + g.nx * m));
     }
     u[m] = h; tmp[m] = h; E[m] = 0.0; bb[m] = b;
     nz = nz || (h != 0.0);
@@ -512,7 +523,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
 #pragma unroll
         for (int m = 0; m < TRPT; ++m) {
           const int r = r0 + m, gj = gj0 + r;
-          if (r >= FH && r <= TRY - 1 - FH && gj < g.ny) dst[id0 + (long long)g.nx * m] = 0.0;
+          if (r >= FH && r <= TRY - 1 - FH && gj < g.ny) stg32(dst, (unsigned)(id0 + g.nx * m), 0.0);
         }
       }
       if (threadIdx.x == 0) partF[t4.w] = 0.0;
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     __syncthreads();
   }
   const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
-  strip_stages<AF>(g, L, P.Afield, src, g.off + gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
+  strip_stages<AF>(g, L, AF ? P.Afield + g.offd : nullptr, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
   // ---- output rows [FH, TRY-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
   double upf[TRPT];
@@ -530,14 +541,14 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   for (int m = 0; m < TRPT; ++m) {  // all loads in flight before the first use
     const int r = r0 + m, gj = gj0 + r;
     const bool out = r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny;
-    upf[m] = src[out ? id0 + (long long)g.nx * m : g.off];
+    upf[m] = ldg32(src, (unsigned)(out ? id0 + g.nx * m : 0));
   }
 #pragma unroll
   for (int m = 0; m < TRPT; ++m) {
     const int r = r0 + m, gj = gj0 + r;
     if (r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny) {
       const double upv = upf[m];
-      dst[id0 + (long long)g.nx * m] = u[m];
+      stg32(dst, (unsigned)(id0 + g.nx * m), u[m]);
       const double err = (u[m] - upv) - E[m];
       const double sk = abstol + fmax(fabs(upv), fabs(u[m])) * reltol;
       const double q = err / sk;
