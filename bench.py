@@ -149,6 +149,7 @@ def main():
     ms_vjpt = b.time_kernel(T.TIMED_VJP_THETA, iters=20, warmup=3)
     ms_cfl = b.time_kernel(T.TIMED_EULER_CFL, iters=50, warmup=5)
     ms_adj = b.time_kernel(T.TIMED_ADJ_STAGE2, iters=20, warmup=3)
+    ms_adjf = b.time_kernel(T.TIMED_ADJ_FUSED_STEP, iters=20, warmup=3)
     aux = {
         "solve_step_ms_hip_events": ms_step_events,
         "fused_step_with_ice_free_shortcut_ms": ms_fused_skip,
@@ -169,6 +170,10 @@ def main():
         "euler_cfl_note": "explicit Euler with CFL-limited dt (scheme 3): ONE cell-step per cell per launch, 24 B per cell-step",
         "adj_stage2_ms": ms_adj,
         "adj_stage2_GBs": 72.0 * cells / (ms_adj * 1e-3) / 1e9,
+        "adj_fused_step_ms": ms_adjf,
+        "adj_fused_step_note": "k_adj_fused_strip: a whole RDPK3Sp35 step of the reverse ODE of the continuous adjoint in one "
+                               "kernel (R lam,H_j,H_j+1,B  W lam' = 40 B/cell) against 5 x adj_stage2_ms for the staged schedule",
+        "adj_fused_step_speedup_vs_5_stage_kernels": 5.0 * ms_adj / ms_adjf,
         "vjp_theta_ms": ms_vjpt,
         "vjp_theta_GBs": 24.0 * cells / (ms_vjpt * 1e-3) / 1e9,
     }

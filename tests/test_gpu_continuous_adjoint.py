@@ -264,3 +264,50 @@ def test_continuous_adjoint_other_law_modes(gpu, kind, arch):
         ratio, angle, relerr = stats_err_arrays(gg, go)
         assert abs(ratio) < tol and relerr < tol, (ratio, angle, relerr)
     b.close()
+
+
+@pytest.mark.parametrize("case", ["scalar_nn_mb", "gridded_nn", "ragged_batch"])
+def test_fused_reverse_step_matches_the_staged_reverse_solve(gpu, monkeypatch, case):
+    """k_adj_fused_strip (the five stages of a reverse step in one kernel, face form of the H-VJP; what large
+    integer-power-law batches run, forced here with ODINN_ADJ_FUSED=1) against the five k_adj_stage launches
+    (ODINN_ADJ_FUSED=0): same loss, same reverse step counts, gradient and lambda(t0) equal to well below the
+    tolerance of the adaptive reverse solve (1e-8; the two stencil forms round differently, and the embedded error
+    estimate turns an ulp into a 1e-10 relative change of the step sizes)."""
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ODINN_ADJ_FUSED", mode)
+        if case == "ragged_batch":
+            shapes = [(70, 57), (131, 64), (54, 46), (201, 103)]
+            rng = np.random.default_rng(11)
+            b = gpu.GlacierBatch(shapes, [50.0] * 4, A=[3e-17, 5e-17, 2e-17, 4e-17])
+            ts = [2010.0 + j / 12.0 for j in range(5)]
+            for k, (nx, ny) in enumerate(shapes):
+                H0, B = O.synthetic_valley(nx, ny, 50.0)
+                b.set_fields(k, H0, B)
+                b.set_reference(k, ts, [H0 * (1.0 - 0.03 * j) + 0.5 * rng.random((nx, ny)) for j in range(len(ts))], 3)
+            Lg, gg = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=16)
+            lam = [b.lambda0(k) for k in range(4)]
+        else:
+            nx, ny = 96, 80
+            use_mb = case == "scalar_nn_mb"
+            ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, use_mb)
+            if case == "gridded_nn":
+                b = gpu.GlacierBatch([(nx, ny)], [50.0])
+                b.set_fields(0, H0, B)
+                S = B + H0
+                Sd = 0.25 * (S[:-1, :-1] + S[1:, :-1] + S[:-1, 1:] + S[1:, 1:])
+                b.set_T_field(0, np.asfortranarray(-5.0 - 6.5e-3 * (Sd - S.mean())))
+                b.set_law(gpu.LAW_NN_A_GRIDDED, gm, th0)
+                b.set_reference(0, ts, ref, 3)
+            else:
+                b = _batch(gpu, nx, ny, H0, B, gm, th0, ts, ref, mb)
+            Lg, gg = b.loss_grad_continuous(ts, theta=th0, mb_times=ts[1:] if use_mb else (), reltol=1e-8, n_quadrature=16)
+            lam = [b.lambda0(0)]
+        out[mode] = (Lg, np.array(gg, dtype=float).ravel(), lam, [(s.naccept, s.nreject) for s in b.last_stats_rev])
+        b.close()
+    a, f = out["0"], out["1"]
+    assert a[0] == f[0]  # the forward solve is the same code
+    assert a[3] == f[3], (a[3], f[3])
+    assert np.linalg.norm(a[1] - f[1]) <= 2e-9 * np.linalg.norm(a[1]), case
+    for la, lf in zip(a[2], f[2]):
+        assert rel_l2(lf, la) < 2e-9, case
