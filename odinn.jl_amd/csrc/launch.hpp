@@ -28,7 +28,7 @@ void launch_rk_fused_strip(int nblk, int afield, hipStream_t st, Pools P, LawDev
                            double* U1, double* partF, double abstol, double reltol, int skip);
 
 // k_adjf.hip, law mode 0 only
-void launch_adj_fused_strip(int nblk, int afield, hipStream_t st, Pools P, AdjFusedArgs A);
+void launch_adj_fused_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, AdjFusedArgs A);
 
 // k_vel.hip (A-type law modes 0/1 only)
 struct VArgs;

@@ -1697,6 +1697,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   // run as ONE kernel (sia2d_adj_fused.hpp); ODINN_ADJ_FUSED=0|1 overrides the choice
   bool fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE && !useV && b->fused_kind() == 2;
   if (const char* e = std::getenv("ODINN_ADJ_FUSED")) fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE && !useV && e[0] == '1';
+  const int rev_skip = []() { const char* e = std::getenv("ODINN_ADJ_SKIP"); return (e && e[0] == '0') ? 0 : 1; }();
   AdjFusedArgs FA{};
   if (fused_rev) {
     FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
@@ -1717,7 +1718,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       if (fused_rev) {
         // the whole step in one kernel: reads lam[cur], writes lam[1 - cur] per glacier; the controller flips cur
         // on acceptance (a rejected step is simply repeated from the untouched lam[cur])
-        launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, b->stream, Pl, FA);
+        launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, rev_skip, b->stream, Pl, FA);
         C.next_cur = -1;
       } else {
         // five stages ping-pong lam[p] -> lam[1-p] -> ... ; the step's result lands in lam[1-p]
@@ -1927,7 +1928,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
       AdjFusedArgs FA{};
       FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
       FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = 1e-8; FA.reltol = 1e-8;
-      launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, b->stream, P, FA);
+      launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, std::getenv("ODINN_TIMED_ADJ_SKIP") ? 1 : 0, b->stream, P, FA);
       return ODINN_OK;
     }
     default: return fail(ODINN_ERR_ARG, "unknown timed kernel %d", which);

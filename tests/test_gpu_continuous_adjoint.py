@@ -311,3 +311,25 @@ def test_fused_reverse_step_matches_the_staged_reverse_solve(gpu, monkeypatch, c
     assert np.linalg.norm(a[1] - f[1]) <= 2e-9 * np.linalg.norm(a[1]), case
     for la, lf in zip(a[2], f[2]):
         assert rel_l2(lf, la) < 2e-9, case
+
+
+def test_fused_reverse_step_ice_free_shortcut_is_bitwise_exact(gpu, monkeypatch):
+    """Workgroups of k_adj_fused_strip whose halo region has no ice in either bracketing snapshot skip the five
+    stencil stages and run the 3S*+ update with a zero right-hand side: bit-identical to ODINN_ADJ_SKIP=0."""
+    n = 320
+    H0, B = O.synthetic_icecap(n, n, 100.0)
+    H0 = np.asfortranarray(np.where(H0 > 500.0, H0 - 500.0, 0.0))  # small cap: most strip tiles ice-free
+    ts = [0.0, 0.25, 0.5]
+    monkeypatch.setenv("ODINN_ADJ_FUSED", "1")
+    out = []
+    for skip in ("0", "1"):
+        monkeypatch.setenv("ODINN_ADJ_SKIP", skip)
+        b = gpu.GlacierBatch([(n, n)], [100.0], A=[4e-17])
+        b.set_fields(0, H0, B)
+        b.set_reference(0, ts, [H0 * (1.0 - 0.05 * j) for j in range(3)], 3)
+        L, g = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=12)
+        out.append((L, np.array(g, dtype=float).ravel(), b.lambda0(0), b.last_stats_rev[0].naccept, b.last_stats_rev[0].nreject))
+        b.close()
+    assert out[0][0] == out[1][0] and out[0][3:] == out[1][3:]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert np.abs(out[0][2]).max() > 0.0
