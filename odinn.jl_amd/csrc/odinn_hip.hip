@@ -1107,7 +1107,7 @@ int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H,
 
 static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
                             bool accumulate, double* part_deferred = nullptr, bool inplace = false,
-                            const double* lam_alt = nullptr) {
+                            const double* lam_alt = nullptr, const double* snaps = nullptr, const AdjState* adj = nullptr) {
   // part_deferred (A-type laws only): the per-tile partials go there and are NOT summed here;
   // inplace: they are ADDED onto part_deferred (which the caller zeroed and reduces at the end)
   // g < 0: all glaciers (swizzled table); result of A-type laws lands in d_Gsum / d_Gacc,
@@ -1117,6 +1117,7 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   if (nn_node) CHK(ensure_theta_scratch(b, nblk));
   ThArgs A{};
   A.H = H; A.lam = lam; A.lam_alt = lam_alt; A.scales = scales;
+  A.snaps = snaps; A.adj = adj; A.ntot = b->ntot;
   A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
   A.part_theta = nn_node ? b->d_part_theta : nullptr;
   A.gscratch = nn_node ? b->d_gscratch : nullptr;
@@ -1629,7 +1630,10 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   AdjPostArgs AP{};
   AP.adj = b->d_adj; AP.snaps = b->d_snaps; AP.premb = b->d_premb; AP.ntot = b->ntot; AP.mb0 = b->d_mb0;
   AP.Sref = b->any_sref ? b->d_Sref : nullptr; AP.Href = b->d_Href; AP.mask = b->d_mask; AP.ws = b->d_ws;
-  AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = b->d_tmpA;
+  // the theta-VJP of the A-type laws interpolates H at the quadrature node in its tile loader; the per-node MLP laws and
+  // the velocity terms read it from d_tmpA, which the post-step then materialises
+  const bool theta_itp = !useV && b->law_kind < ODINN_LAW_NN_Y;
+  AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = theta_itp ? nullptr : b->d_tmpA;
   const bool mb_last = b->any_mb && b->mb_flag[k - 1];
   launch_adj_begin(G, b->stream, Pl, b->d_adj, k, h_tau[0], mb_last ? 1 : 0, mb_last ? b->mb_slot[k - 1] : 0);
   // loss term of a velocity-data snapshot: lam += wV dl_V/dH(H_j)  (backward_loss(::LossV), Losses.jl:338-390)
@@ -1747,9 +1751,10 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       // onto per-tile running sums that are reduced once after the solve
       if (fused_rev)
         CHK(theta_vjp_launch(b, b->d_tmpA, b->d_lam[0], b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace,
-                             b->d_lam[1]));
+                             b->d_lam[1], theta_itp ? b->d_snaps : nullptr, b->d_adj));
       else
-        CHK(theta_vjp_launch(b, b->d_tmpA, a1, b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace));
+        CHK(theta_vjp_launch(b, b->d_tmpA, a1, b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace, nullptr,
+                             theta_itp ? b->d_snaps : nullptr, b->d_adj));
       p = 1 - p;
       ++steps;
     }

@@ -1637,6 +1637,9 @@ struct ThArgs {
   double* part_theta;    // [ntiles_total][P] for Y/U laws or null
   double* gscratch;      // thread-private gradient scratch [P][grid*NT]
   const double* lam_alt; // non-null: lambda of glacier g is in lam_alt where gs[g].cur == 1 (fused reverse step: per-glacier ping-pong)
+  const double* snaps;   // non-null (continuous adjoint): H = H_itp at the stop each glacier just reached, formed in the tile
+  const AdjState* adj;   //   loader from the two bracketing forward snapshots (seg_stop, s_stop) instead of being read from H
+  long long ntot;
   int accum;             // A-type laws: add the tile's sum onto its partial slot instead of overwriting it
                          // (one reduction after a whole reverse solve instead of one per step)
 };
@@ -1660,7 +1663,14 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double ownH[RPT], ownL[RPT];
-  const bool ice = load_tile_HS2(A.H, P.B, g, i0, j0, sHS, ownH);
+  bool ice;
+  if (A.snaps) {
+    const AdjState a = A.adj[t4.x];
+    const double* Ha = A.snaps + (long long)a.seg_stop * A.ntot;
+    ice = load_tile_HS2(Ha, P.B, g, i0, j0, sHS, ownH, Ha + A.ntot, a.s_stop);
+  } else {
+    ice = load_tile_HS2(A.H, P.B, g, i0, j0, sHS, ownH);
+  }
   // no ice anywhere on the tile and its halo: every owned node has Hbar = 0, so its weight
   // spat * Da vanishes identically (A-type and D_hybrid laws: spat ~ Hbar^(n+2); D law: Hbar) -- exact
   if (!__syncthreads_or(ice)) {
@@ -2086,7 +2096,7 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
         if (!A.loss_first) l += dl;
         U[id] = l;
       }
-      if (a.qw != 0.0 || a.snapj >= 0) {  // H_itp at the stop, for the theta-VJP / the velocity loss term
+      if (A.Hq && (a.qw != 0.0 || a.snapj >= 0)) {  // H_itp at the stop, for the velocity loss term (the theta-VJP forms it itself)
         const double ha = A.snaps[(long long)a.seg_stop * A.ntot + id];
         const double hb = A.snaps[(long long)(a.seg_stop + 1) * A.ntot + id];
         A.Hq[id] = fma(a.s_stop, hb - ha, ha);
