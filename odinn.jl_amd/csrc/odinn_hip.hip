@@ -794,6 +794,10 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   for (int g = 0; g < n_glaciers; ++g)
     if (descs[g].nx < 3 || descs[g].ny < 3 || !(descs[g].dx > 0) || !(descs[g].dy > 0))
       return fail(ODINN_ERR_ARG, "glacier %d: need nx,ny >= 3 and dx,dy > 0", g);
+  for (int g = 0; g < n_glaciers; ++g)  // the strip kernels address a glacier's cells by 32-bit byte offsets
+    if ((long long)descs[g].nx * descs[g].ny >= (1LL << 29))
+      return fail(ODINN_ERR_ARG, "glacier %d: %d x %d cells exceed the 2^29 cells a single glacier may have", g, descs[g].nx,
+                  descs[g].ny);
   odinn_batch* b = new odinn_batch();
   b->device = device;
   b->G = n_glaciers;
