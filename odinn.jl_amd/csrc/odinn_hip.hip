@@ -1701,10 +1701,11 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     }
     HIPCHK(hipMemsetAsync(b->d_partsteps, 0, need * sizeof(double), b->stream));
   }
-  // integer-power law + DiscreteVJP + thickness loss on a batch that fills the GPU: the five stages of a reverse step
-  // run as ONE kernel (sia2d_adj_fused.hpp); ODINN_ADJ_FUSED=0|1 overrides the choice
-  bool fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE && !useV && b->fused_kind() == 2;
-  if (const char* e = std::getenv("ODINN_ADJ_FUSED")) fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE && !useV && e[0] == '1';
+  // integer-power law + DiscreteVJP + thickness loss: the five stages of a reverse step run as ONE kernel
+  // (sia2d_adj_fused.hpp) -- measured faster at every batch size, 4 alpine glaciers included; ODINN_ADJ_FUSED=0
+  // selects the five k_adj_stage launches
+  bool fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE && !useV;
+  if (const char* e = std::getenv("ODINN_ADJ_FUSED")) fused_rev = fused_rev && e[0] != '0';
   const int rev_skip = []() { const char* e = std::getenv("ODINN_ADJ_SKIP"); return (e && e[0] == '0') ? 0 : 1; }();
   AdjFusedArgs FA{};
   if (fused_rev) {
