@@ -569,3 +569,32 @@ def test_randomised_shapes_and_states(gpu):
             b.solve([0.0, 4 * dt], fixed_dt=dt, scheme=1)
             assert rel_l2(b.snapshot(0, 1), snaps[1]) < 1e-11, (nx, ny)
         b.close()
+
+
+def test_strip_kernel_randomised_shapes_fixed_dt(gpu, monkeypatch):
+    """Seeded sweep of ragged shapes around the strip kernel's 54x46 output tile (and far from it), rough states
+    with ice-free patches and negative thickness: three fixed steps of the strip kernel equal the five per-stage
+    kernels to rounding, batched as ONE launch over all glaciers."""
+    monkeypatch.setenv("ODINN_FUSED_TILES", "t")
+    rng = np.random.default_rng(99)
+    shapes = [(3, 3), (5, 60), (53, 45), (54, 46), (55, 47), (107, 93), (109, 91), (64, 56), (65, 57), (200, 17), (17, 200), (163, 139)]
+    fields = []
+    for k, (nx, ny) in enumerate(shapes):
+        x = np.linspace(0, 1, nx)[:, None]
+        y = np.linspace(0, 1, ny)[None, :]
+        B = 400.0 + 250.0 * x + 60.0 * np.sin(5 * x + 4 * y) + 3.0 * rng.standard_normal((nx, ny))
+        H = 150.0 * np.exp(-((x - 0.45) ** 2 + (y - 0.55) ** 2) / 0.06) + 10.0 * rng.standard_normal((nx, ny)) - 15.0
+        if k % 3 == 1:
+            H[:, : ny // 2] = 0.0
+        fields.append((np.asfortranarray(np.maximum(H, 0.0)), np.asfortranarray(B)))
+    res = {}
+    for scheme in (1, 2):
+        b = gpu.GlacierBatch(shapes, [40.0] * len(shapes), [55.0] * len(shapes), A=[3e-17] * len(shapes))
+        for k, (H, B) in enumerate(fields):
+            b.set_fields(k, H, B)
+        b.solve([0.0, 3e-4], fixed_dt=1e-4, scheme=scheme, dense=scheme - 1)
+        res[scheme] = [b.snapshot(k, 1) for k in range(len(shapes))]
+        b.close()
+    for k, shp in enumerate(shapes):
+        assert np.isfinite(res[2][k]).all(), shp
+        assert rel_l2(res[2][k], res[1][k]) < 1e-13, shp
