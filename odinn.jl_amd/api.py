@@ -22,6 +22,7 @@ Everything numerical runs in libodinn_hip.so on the GPU; this module only orches
 from __future__ import annotations
 
 import math
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -40,7 +41,7 @@ __all__ = [
     "callback_diagnosis",
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
-    "shard_glaciers", "init_distributed", "allreduce_loss_grad",
+    "shard_glaciers", "init_distributed", "allreduce_loss_grad", "load_gridded_glacier",
 ]
 
 
@@ -290,6 +291,55 @@ class Glacier2D:
     @property
     def ny(self):
         return self.H0.shape[1]
+
+
+def load_gridded_glacier(path, rgi_id=None, thickness_vars=("consensus_ice_thickness", "distributed_thickness", "thickness"),
+                         topo_vars=("topo_smoothed", "topo"), mask_var="glacier_mask", **glacier_kwargs):
+    """Real-glacier ingestion: a gridded directory file in the layout OGGM writes and Sleipnir reads
+    (`gridded_data.nc`: 1-D coordinates `x`, `y` in metres, 2-D variables on (y, x): surface elevation `topo` /
+    `topo_smoothed`, `glacier_mask`, an ice-thickness estimate) -> `Glacier2D`.
+
+    Own definitions (Sleipnir's glacier initialisation is out of tree): H0 = thickness with NaN -> 0 and 0 outside
+    `glacier_mask`; B = surface - H0; arrays are returned as `[i, j]` = `[x, y]` with x contiguous (this
+    package's layout) and both coordinates increasing; dx, dy = coordinate spacings.  Reads NetCDF-3 (classic /
+    64-bit offset) files through scipy -- the image has no HDF5 stack, so a NetCDF-4 `gridded_data.nc` must be
+    converted first (`nccopy -k classic`) -- and `.npz` files holding the same variable names."""
+    if str(path).endswith(".npz"):
+        with np.load(path) as z:
+            var = {k: np.array(z[k]) for k in z.files}
+    else:
+        from scipy.io import netcdf_file
+
+        with netcdf_file(str(path), "r", mmap=False) as nc:
+            var = {k: np.array(v[:], dtype=float) * getattr(v, "scale_factor", 1.0) + getattr(v, "add_offset", 0.0)
+                   for k, v in nc.variables.items()}
+    x, y = np.asarray(var["x"], float), np.asarray(var["y"], float)
+
+    def pick(names):
+        for n_ in names:
+            if n_ in var:
+                return np.asarray(var[n_], float)
+        raise KeyError(f"none of {names} in {path}")
+
+    thick, topo = pick(thickness_vars), pick(topo_vars)
+    if thick.shape != (y.size, x.size) or topo.shape != thick.shape:
+        raise ValueError(f"expected (y, x) = ({y.size}, {x.size}) fields, got {thick.shape} / {topo.shape}")
+    H = np.nan_to_num(thick, nan=0.0)
+    H = np.maximum(H, 0.0)
+    if mask_var in var:
+        H = np.where(np.asarray(var[mask_var]) > 0, H, 0.0)
+    S = np.nan_to_num(topo, nan=float(np.nanmin(topo)))
+
+    def orient(a):  # (y, x) -> [x, y], both increasing
+        a = a[::-1, :] if y.size > 1 and y[1] < y[0] else a
+        a = a[:, ::-1] if x.size > 1 and x[1] < x[0] else a
+        return np.asfortranarray(a.T)
+
+    H0, S0 = orient(H), orient(S)
+    dx = float(abs(x[1] - x[0])) if x.size > 1 else 1.0
+    dy = float(abs(y[1] - y[0])) if y.size > 1 else dx
+    return Glacier2D(rgi_id or os.path.splitext(os.path.basename(str(path)))[0], H0, np.asfortranarray(S0 - H0), dx, dy,
+                     **glacier_kwargs)
 
 
 def define_callback_steps(tspan, step):

@@ -124,3 +124,42 @@ def test_training_result_file_and_scalar_log(odinn, tmp_path):
     rows = [json.loads(l) for l in open(tmp_path / "run" / "scalars.jsonl")]
     assert [r["tag"] for r in rows[:2]] == ["train/loss", "train/norm_grad"] and rows[0]["step"] == 1
     assert sum(r["tag"] == "train/time_per_iter" for r in rows) == 2  # not on the first call (callback_utils.jl:93)
+
+
+def test_load_gridded_glacier_reads_oggm_style_files(odinn, tmp_path):
+    """Real-glacier ingestion seam: an OGGM-style gridded file (NetCDF-3 through scipy, or .npz):
+    (y, x) variables with y descending are returned as [x, y] with both axes increasing, thickness masked by
+    glacier_mask and NaN -> 0, bed = surface - thickness."""
+    from scipy.io import netcdf_file
+
+    nx, ny, d = 7, 5, 50.0
+    x = 1000.0 + d * np.arange(nx)
+    y = 9000.0 - d * np.arange(ny)  # OGGM: y descending
+    X, Y = np.meshgrid(x, y)  # (ny, nx)
+    topo = 2000.0 + 0.1 * (X - x[0]) + 0.05 * (Y - y[-1])
+    thick = np.where((X - x[3]) ** 2 + (Y - y[2]) ** 2 < (2.2 * d) ** 2, 80.0, np.nan)
+    mask = np.isfinite(thick).astype("i4")
+    mask[2, 3] = 0  # a cell the outline excludes although a thickness is given
+    path = tmp_path / "gridded_data.nc"
+    with netcdf_file(str(path), "w") as nc:
+        nc.createDimension("x", nx)
+        nc.createDimension("y", ny)
+        for name, arr, dims, typ in (("x", x, ("x",), "d"), ("y", y, ("y",), "d"), ("topo_smoothed", topo, ("y", "x"), "d"),
+                                     ("consensus_ice_thickness", thick, ("y", "x"), "d"), ("glacier_mask", mask, ("y", "x"), "i")):
+            v = nc.createVariable(name, typ, dims)
+            v[:] = arr
+    gl = odinn.load_gridded_glacier(path, rgi_id="RGI60-11.00000", A=3e-17)
+    assert gl.rgi_id == "RGI60-11.00000" and (gl.nx, gl.ny) == (nx, ny) and gl.dx == d and gl.dy == d and gl.A == 3e-17
+    assert gl.H0.flags.f_contiguous and gl.B.flags.f_contiguous
+    # [i, j] = [x, y] with y ascending: file row ny-1-j
+    for i in range(nx):
+        for j in range(ny):
+            h = thick[ny - 1 - j, i]
+            h = 0.0 if (not np.isfinite(h) or mask[ny - 1 - j, i] == 0) else h
+            assert gl.H0[i, j] == h
+            assert gl.B[i, j] == topo[ny - 1 - j, i] - h
+    assert gl.H0[3, 2] == 0.0 and (gl.H0 > 0).sum() == mask.sum()
+    assert gl.mask.shape == (nx, ny) and gl.mask[0, 0]
+    np.savez(tmp_path / "g.npz", x=x, y=y, topo=topo, thickness=np.nan_to_num(thick), glacier_mask=mask)
+    g2 = odinn.load_gridded_glacier(tmp_path / "g.npz")
+    assert np.array_equal(g2.H0, gl.H0) and np.array_equal(g2.B, gl.B) and g2.rgi_id == "g"
