@@ -333,3 +333,26 @@ def test_fused_reverse_step_ice_free_shortcut_is_bitwise_exact(gpu, monkeypatch)
     assert out[0][0] == out[1][0] and out[0][3:] == out[1][3:]
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     assert np.abs(out[0][2]).max() > 0.0
+
+
+def test_fused_reverse_step_with_rejected_steps(gpu, monkeypatch):
+    """Loose reverse tolerances and a large dtmax: the loss jumps at the snapshot times make the reverse controller
+    reject steps.  The fused kernel then simply repeats from the untouched lambda[cur] (no saved copy); the staged
+    path restarts from its uprev register.  Same accept / reject counts, gradients equal to rounding."""
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ODINN_ADJ_FUSED", mode)
+        shapes = [(130, 97), (96, 80)]
+        b = gpu.GlacierBatch(shapes, [50.0] * 2, A=[6e-17, 4e-17])
+        ts = [2010.0, 2010.5, 2011.0, 2011.5]
+        for k, (nx, ny) in enumerate(shapes):
+            H0, B = O.synthetic_valley(nx, ny, 50.0)
+            b.set_fields(k, H0, B)
+            b.set_reference(k, ts, [H0 * (1.0 - 0.1 * j) for j in range(len(ts))], 3)
+        L, g = b.loss_grad_continuous(ts, reltol=1e-8, adj_reltol=1e-4, adj_abstol=1e-6, adj_dtmax=0.5, n_quadrature=6)
+        out[mode] = (L, np.array(g, dtype=float).ravel(), [(s.naccept, s.nreject) for s in b.last_stats_rev], b.lambda0(0))
+        b.close()
+    a, f = out["0"], out["1"]
+    assert a[2] == f[2] and sum(r for _, r in a[2]) > 0, (a[2], f[2])
+    assert np.abs(a[1] - f[1]).max() <= 1e-10 * np.abs(a[1]).max()
+    assert rel_l2(f[3], a[3]) < 1e-10
