@@ -24,7 +24,7 @@ ODINN_DECL_LM(5)
 #undef ODINN_DECL_LM
 
 // k_fused.hip, law mode 0 only
-void launch_rk_fused_strip(int nblk, int afield, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
+void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
                            double* U1, double* partF, double abstol, double reltol, int skip);
 
 // k_adjf.hip, law mode 0 only

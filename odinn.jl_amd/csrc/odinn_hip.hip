@@ -130,14 +130,14 @@ struct odinn_batch {
   // device pools
   int* d_est = nullptr;        // per-glacier estimate of the steps still needed (written by the controller)
   std::vector<int> h_est;
-  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr;
-  int ntilesF = 0, ntilesFs = 0, ntilesFt = 0;
-  double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr;
-  mutable int fused_env = -1;  // ODINN_FUSED_TILES, parsed once: 0 unset, 1 small, 2 large, 3 strip
+  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr, *d_tilesFu = nullptr;
+  int ntilesF = 0, ntilesFs = 0, ntilesFt = 0, ntilesFu = 0;
+  double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr, *d_partFu = nullptr;
+  mutable int fused_env = -1;  // ODINN_FUSED_TILES, parsed once: 0 unset, 1 small, 2 large, 3 t (strip, 7 rows), 4 u (strip, 8 rows)
   int fused_override() const {
     if (fused_env < 0) {
       const char* e = std::getenv("ODINN_FUSED_TILES");
-      fused_env = !e ? 0 : e[0] == 's' ? 1 : e[0] == 'l' ? 2 : e[0] == 't' ? 3 : 0;
+      fused_env = !e ? 0 : e[0] == 's' ? 1 : e[0] == 'l' ? 2 : e[0] == 't' ? 3 : e[0] == 'u' ? 4 : 0;
     }
     return fused_env;
   }
@@ -150,13 +150,16 @@ struct odinn_batch {
     if (o == 1) return 1;
     if (o == 2) return 0;
     if (o == 3) return lm() == 0 ? 2 : 0;
-    if (lm() == 0) return ntilesFt >= 96 ? 2 : 1;
+    if (o == 4) return lm() == 0 ? 3 : 0;
+    // 3 = strip kernel with 8 rows per thread (54 x 54 tiles: less halo work, but a longer sweep per workgroup):
+    // pays once the batch more than fills the 512 workgroup slots of the GPU (measured crossover: 400 tiles lose 8 %, 720 win 10 %)
+    if (lm() == 0) return ntilesFu >= 704 ? 3 : (ntilesFt >= 96 ? 2 : 1);
     return ntilesF <= 256 ? 1 : 0;
   }
-  const int4* fused_tiles() const { const int k = fused_kind(); return k == 2 ? d_tilesFt : k == 1 ? d_tilesFs : d_tilesF; }
-  double* fused_part() const { const int k = fused_kind(); return k == 2 ? d_partFt : k == 1 ? d_partFs : d_partF; }
-  int fused_ntiles() const { const int k = fused_kind(); return k == 2 ? ntilesFt : k == 1 ? ntilesFs : ntilesF; }
-  int fused_ctrl() const { const int k = fused_kind(); return k == 2 ? 3 : k == 1 ? 2 : 1; }
+  const int4* fused_tiles() const { const int k = fused_kind(); return k == 3 ? d_tilesFu : k == 2 ? d_tilesFt : k == 1 ? d_tilesFs : d_tilesF; }
+  double* fused_part() const { const int k = fused_kind(); return k == 3 ? d_partFu : k == 2 ? d_partFt : k == 1 ? d_partFs : d_partF; }
+  int fused_ntiles() const { const int k = fused_kind(); return k == 3 ? ntilesFu : k == 2 ? ntilesFt : k == 1 ? ntilesFs : ntilesF; }
+  int fused_ctrl() const { const int k = fused_kind(); return k == 3 ? 4 : k == 2 ? 3 : k == 1 ? 2 : 1; }
   GDev* d_gd = nullptr;
   GState* d_gs = nullptr;
   double *d_B = nullptr, *d_H0 = nullptr, *d_Afield = nullptr, *d_Tfield = nullptr, *d_Gacc = nullptr;
@@ -480,8 +483,9 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip) {
   const int nblk = b->fused_ntiles();
   const int4* tiles = b->fused_tiles();
   double* part = b->fused_part();
-  if (small == 2)
-    launch_rk_fused_strip(nblk, b->gd[0].use_Afield, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip);
+  if (small >= 2)
+    launch_rk_fused_strip(nblk, b->gd[0].use_Afield, small == 3 ? 8 : TRPT, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol,
+                          reltol, skip);
   else if (b->lm() == 0)
     launch_rk_fused_lm0(nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
   else
@@ -848,13 +852,14 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   HIPCHK(hipMemcpy(b->d_tiles_nat, nat.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
   // tile tables of the fused-step kernel, same XCD-banded order: FOX x FOY "throughput" tiles and
   // FOX x FOYS "latency" tiles (used when the batch has too few throughput tiles to fill the GPU)
-  for (int small = 0; small < 3; ++small) {
-    const int foy = small == 2 ? FOYT : small ? FOYS : FOY;
+  for (int small = 0; small < 4; ++small) {
+    const int foy = small == 3 ? FOYT8 : small == 2 ? FOYT : small ? FOYS : FOY;
     std::vector<int4> natF;
     for (int g = 0; g < n_glaciers; ++g) {
       GDev& r = b->gd[g];
       const int fx = (r.nx + FOX - 1) / FOX, fy = (r.ny + foy - 1) / foy;
-      if (small == 2) { r.tile0Ft = (int)natF.size(); r.ntilesFt = fx * fy; }
+      if (small == 3) { r.tile0Fu = (int)natF.size(); r.ntilesFu = fx * fy; }
+      else if (small == 2) { r.tile0Ft = (int)natF.size(); r.ntilesFt = fx * fy; }
       else if (small) { r.tile0Fs = (int)natF.size(); r.ntilesFs = fx * fy; }
       else { r.tile0F = (int)natF.size(); r.ntilesF = fx * fy; }
       for (int ty = 0; ty < fy; ++ty)
@@ -868,7 +873,12 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
         const int t = x * per + r;
         if (t < nF) swzF.push_back(natF[t]);
       }
-    if (small == 2) {
+    if (small == 3) {
+      b->ntilesFu = nF;
+      CHK(dalloc(&b->d_tilesFu, (size_t)nF));
+      CHK(dalloc(&b->d_partFu, (size_t)nF));
+      HIPCHK(hipMemcpy(b->d_tilesFu, swzF.data(), sizeof(int4) * nF, hipMemcpyHostToDevice));
+    } else if (small == 2) {
       b->ntilesFt = nF;
       CHK(dalloc(&b->d_tilesFt, (size_t)nF));
       CHK(dalloc(&b->d_partFt, (size_t)nF));
@@ -914,7 +924,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
-  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt); dfree(b->d_est);
+  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt); dfree(b->d_tilesFu); dfree(b->d_partFu); dfree(b->d_est);
   dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
   dfree(b->d_rmbs); dfree(b->d_adj);
   dfree(b->d_partsteps);

@@ -65,6 +65,7 @@ constexpr int TNW = ODINN_TNW;        // TRPT CONTIGUOUS region rows, so the y-n
 constexpr int TNT = 64 * TNW;         // same thread's registers: TNW wavefronts, 64 x 56 region, 54 x 46 output tile
 constexpr int TRY = TRPT * TNW;
 constexpr int FOYT = TRY - 2 * FH;
+constexpr int FOYT8 = 8 * TNW - 2 * FH;  // forward strip kernel with 8 rows per thread: 54 x 54 output tiles
 constexpr int FLD = FRX + 1;          // LDS row stride (odd)
 
 
@@ -106,6 +107,7 @@ struct GDev {  // per-glacier constants
   int tile0F, ntilesF;  // range in the fused-step tile table (FOX x FOY output tiles)
   int tile0Fs, ntilesFs; // ... and in the table of FOX x FOYS "latency" tiles
   int tile0Ft, ntilesFt; // ... and in the table of FOX x FOYT "strip" tiles
+  int tile0Fu, ntilesFu; // ... and in the table of FOX x FOYT8 strip tiles (forward kernel, 8 rows per thread)
   long long off;   // offset of this glacier in the pooled primal arrays  [doubles]
   long long offd;  // offset in the pooled dual arrays
   double dx, dy, inv_dx, inv_dy, eta0;
@@ -935,7 +937,7 @@ struct CtrlArgs {
   int next_cur;  // ping-pong buffer that holds u_new of this step; -1: flip the glacier's own `cur`
   const double* errpart;  // per-tile error partials: errpart[stride * tile]
   int stride;
-  int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles, 3: FOYT tiles)
+  int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles, 3: FOYT tiles, 4: FOYT8 tiles)
   int* est_steps;         // [G] (nullable): estimated steps still needed, for the host's poll spacing
   double cfl;             // > 0: explicit Euler with dt = cfl*min(dx,dy)^2/(4 max D); the partials are tile maxima
   int cfl_prime;          // the launch only measured max D(u0): set the first dt, do not advance
@@ -973,8 +975,8 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   const GDev g = P.gd[gidx];
   double s = 0.0;
   {
-    const int t0 = C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
-    const int nt = C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
+    const int t0 = C.fused == 4 ? g.tile0Fu : C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
+    const int nt = C.fused == 4 ? g.ntilesFu : C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
     if (C.cfl > 0.0) {
       for (int k = threadIdx.x; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
     } else {

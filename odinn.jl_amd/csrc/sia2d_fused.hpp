@@ -358,15 +358,15 @@ __device__ __forceinline__ double2 cell_HS(double uu, double b) {
 // sE[buf][w][0 | 1][lane]: {Hc, S} of the first | last row of wavefront w's strip
 typedef double2 (*StripEdges)[TNW][2][FRX];
 
-template <int S, bool AF>
+template <int S, bool AF, int NR>
 __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
                                              const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
-                                             double dtl, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
-                                             double (&E)[TRPT], const double (&bb)[TRPT]) {
+                                             double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
+                                             double (&E)[NR], const double (&bb)[NR]) {
   // src, Afield: based at the glacier's first cell / dual node (block-uniform), cells addressed by 32-bit indices;
   // gic: gi clamped into the grid; dtl: dt on the lanes with 1 <= gi <= nx-2, else 0
   constexpr int rd = (S - 1) & 1, wr = S & 1;  // stage S reads the edge rows from buffer rd, publishes into wr
-  const int r0 = TRPT * w;
+  const int r0 = NR * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
   constexpr int s = S - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
@@ -401,7 +401,7 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   // where the compiler contracts a*b - c*d.
   auto face = [&](double Da, double Db, double slope, double Hhi, double Hlo) { return (Da + Db) * clampn(slope, Hhi, Hlo); };
   // the rows just outside the strip: last row of the wavefront below, first row of the one above (the
-  // outermost wavefronts read their own edge instead: rows 0 and TRY-1 are never in region_S)
+  // outermost wavefronts read their own edge instead: rows 0 and (NR * TNW)-1 are never in region_S)
   const double2 hs_s = sE[rd][w > 0 ? w - 1 : 0][w > 0 ? 1 : 0][lane];
   const double2 hs_top = sE[rd][w + 1 < TNW ? w + 1 : w][w + 1 < TNW ? 0 : 1][lane];
   // One sweep up the strip: node row r, then cell row r; the node row and the north faces below the strip first.
@@ -416,9 +416,9 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
     F_s = face(dpp_from_west(D_s), D_s, dyw, hs_c.x, hs_s.x);
   }
 #pragma unroll
-  for (int m = 0; m < TRPT; ++m) {
+  for (int m = 0; m < NR; ++m) {
     const int gj = gj0 + r0 + m;
-    const double2 hs_n = m + 1 < TRPT ? cell_HS(u[m + 1 < TRPT ? m + 1 : m], bb[m + 1 < TRPT ? m + 1 : m]) : hs_top;
+    const double2 hs_n = m + 1 < NR ? cell_HS(u[m + 1 < NR ? m + 1 : m], bb[m + 1 < NR ? m + 1 : m]) : hs_top;
     const double2 e_n = dpp_from_east(hs_n);
     const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, dyw = hs_n.y - hs_c.y;
     const double D_c = node(gj, dx_c, hp_c, dx_n, hp_n, dyw, e_n.y - e_c.y);
@@ -459,27 +459,28 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   }
   if (S < 5) {
     sE[wr][w][0][lane] = cell_HS(u[0], bb[0]);
-    sE[wr][w][1][lane] = cell_HS(u[TRPT - 1], bb[TRPT - 1]);
+    sE[wr][w][1][lane] = cell_HS(u[NR - 1], bb[NR - 1]);
     __syncthreads();
   }
 }
 
-template <bool AF>
+template <bool AF, int NR>
 __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
                                               const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
-                                              double dtl, StripEdges sE, double (&u)[TRPT], double (&tmp)[TRPT],
-                                              double (&E)[TRPT], const double (&bb)[TRPT]) {
-  strip_stage<1, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<2, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<3, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<4, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<5, AF>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+                                              double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
+                                              double (&E)[NR], const double (&bb)[NR]) {
+  strip_stage<1, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<2, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<3, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<4, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<5, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
 }
 
 // AF: A from the dual-grid field.  One stage path per kernel: with two paths in one kernel the register allocator
 // spills (a separate predicate-free kernel for the tiles strictly inside the grid was measured and lost: its
 // second launch costs more than the selects it saves).
-template <bool SKIP, bool AF>
+// NR: rows per thread (7: 54x46 output tiles; 8: 54x54 tiles, less halo work, for batches that fill the GPU twice over)
+template <bool SKIP, bool AF, int NR>
 __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, LawDev L, const int4* __restrict__ tilesF,
                                                                     double* __restrict__ U0, double* __restrict__ U1,
                                                                     double* __restrict__ partF, double abstol, double reltol) {
@@ -496,14 +497,14 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   const double* __restrict__ Bg = P.B + g.off;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOYT - FH;
-  const int gi = gi0 + lane, r0 = TRPT * w;
+  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * (NR * TNW - 2 * FH) - FH;
+  const int gi = gi0 + lane, r0 = NR * w;
   const bool inx = gi >= 0 && gi < g.nx;
   const int id0 = gi + g.nx * (gj0 + r0);
-  double u[TRPT], tmp[TRPT], E[TRPT], bb[TRPT];
+  double u[NR], tmp[NR], E[NR], bb[NR];
   bool nz = false;
 #pragma unroll
-  for (int m = 0; m < TRPT; ++m) {
+  for (int m = 0; m < NR; ++m) {
     const int gj = gj0 + r0 + m;
     double h = 0.0, b = 0.0;
     if (inx && gj >= 0 && gj < g.ny) {
@@ -514,16 +515,16 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     nz = nz || (h != 0.0);
   }
   sE[0][w][0][lane] = cell_HS(u[0], bb[0]);
-  sE[0][w][1][lane] = cell_HS(u[TRPT - 1], bb[TRPT - 1]);
+  sE[0][w][1][lane] = cell_HS(u[NR - 1], bb[NR - 1]);
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   if (SKIP) {
     // exact shortcut, see k_rk_fused
     if (!__syncthreads_or(nz)) {
       if (ocol) {
 #pragma unroll
-        for (int m = 0; m < TRPT; ++m) {
+        for (int m = 0; m < NR; ++m) {
           const int r = r0 + m, gj = gj0 + r;
-          if (r >= FH && r <= TRY - 1 - FH && gj < g.ny) stg32(dst, (unsigned)(id0 + g.nx * m), 0.0);
+          if (r >= FH && r <= (NR * TNW) - 1 - FH && gj < g.ny) stg32(dst, (unsigned)(id0 + g.nx * m), 0.0);
         }
       }
       if (threadIdx.x == 0) partF[t4.w] = 0.0;
@@ -533,20 +534,20 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     __syncthreads();
   }
   const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
-  strip_stages<AF>(g, L, AF ? P.Afield + g.offd : nullptr, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
-  // ---- output rows [FH, TRY-1-FH]: u' from the registers, embedded error partial -----------------------
+  strip_stages<AF, NR>(g, L, AF ? P.Afield + g.offd : nullptr, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
+  // ---- output rows [FH, (NR * TNW)-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
-  double upf[TRPT];
+  double upf[NR];
 #pragma unroll
-  for (int m = 0; m < TRPT; ++m) {  // all loads in flight before the first use
+  for (int m = 0; m < NR; ++m) {  // all loads in flight before the first use
     const int r = r0 + m, gj = gj0 + r;
-    const bool out = r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny;
+    const bool out = r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny;
     upf[m] = ldg32(src, (unsigned)(out ? id0 + g.nx * m : 0));
   }
 #pragma unroll
-  for (int m = 0; m < TRPT; ++m) {
+  for (int m = 0; m < NR; ++m) {
     const int r = r0 + m, gj = gj0 + r;
-    if (r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny) {
+    if (r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny) {
       const double upv = upf[m];
       stg32(dst, (unsigned)(id0 + g.nx * m), u[m]);
       const double err = (u[m] - upv) - E[m];

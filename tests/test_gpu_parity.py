@@ -439,7 +439,7 @@ def test_full_size_properties(gpu):
         b.close()
 
 
-@pytest.mark.parametrize("tiles", ["small", "large", "t"])
+@pytest.mark.parametrize("tiles", ["small", "large", "t", "u"])
 def test_ice_free_tile_shortcut_is_bitwise_exact(gpu, monkeypatch, tiles):
     """The fused step kernels skip workgroups whose whole halo region has u == 0; the result must be
     bit-identical to running all five stages everywhere (opts.dense = 1).  tiles: the 54x8 latency tile,
@@ -470,7 +470,7 @@ def test_fused_tile_sizes_are_equivalent(gpu, monkeypatch):
     H0, B = O.synthetic_valley(130, 97, 50.0)
     ts = [2010.0, 2010.25, 2010.5]
     out = {}
-    for tiles in ("small", "large", "t"):
+    for tiles in ("small", "large", "t", "u"):
         monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
         b = gpu.GlacierBatch([(130, 97)], [50.0], A=[4e-17])
         b.set_fields(0, H0, B)
@@ -483,19 +483,20 @@ def test_fused_tile_sizes_are_equivalent(gpu, monkeypatch):
     # so an ulp of difference in u' (the strip kernel is separate source: flux form, contracted differently) moves
     # the error norm in its 10th digit and the PID step sizes with it: agreement is bounded by the integration
     # error (~10 reltol), not by rounding.
-    for other, tol in (("large", 1e-12), ("t", 1e-7)):
+    for other, tol in (("large", 1e-12), ("t", 1e-7), ("u", 1e-7)):
         assert out["small"][1:3] == out[other][1:3], other
         assert rel_l2(out["small"][0], out[other][0]) < tol, other
         assert np.isfinite(out[other][3]).all() and rel_l2(out["small"][3], out[other][3]) < 1e-13, other
 
 
-@pytest.mark.parametrize("shape", [(130, 97), (54, 46), (55, 47), (301, 211)])
-def test_strip_kernel_matches_the_per_stage_schedule(gpu, monkeypatch, shape):
+@pytest.mark.parametrize("tiles", ["t", "u"])
+@pytest.mark.parametrize("shape", [(130, 97), (54, 46), (55, 47), (54, 54), (55, 55), (301, 211)])
+def test_strip_kernel_matches_the_per_stage_schedule(gpu, monkeypatch, shape, tiles):
     """The strip kernel (scheme 2 with ODINN_FUSED_TILES=t) against the five per-stage kernels (scheme 1) on
     ragged grids around its 54x46 tile, with a constant A and with a gridded A field: equal to rounding under a
     fixed dt, within the solver tolerance under step-size control (see test_fused_tile_sizes_are_equivalent);
-    and against the oracle's integrator."""
-    monkeypatch.setenv("ODINN_FUSED_TILES", "t")
+    and against the oracle's integrator.  tiles: "t" = 7 rows per thread (54x46 tiles), "u" = 8 rows (54x54)."""
+    monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
     nx, ny = shape
     H0, B = O.synthetic_valley(nx, ny, 50.0)
     rng = np.random.default_rng(7)
@@ -574,8 +575,7 @@ def test_randomised_shapes_and_states(gpu):
 def test_strip_kernel_randomised_shapes_fixed_dt(gpu, monkeypatch):
     """Seeded sweep of ragged shapes around the strip kernel's 54x46 output tile (and far from it), rough states
     with ice-free patches and negative thickness: three fixed steps of the strip kernel equal the five per-stage
-    kernels to rounding, batched as ONE launch over all glaciers."""
-    monkeypatch.setenv("ODINN_FUSED_TILES", "t")
+    kernels to rounding, batched as ONE launch over all glaciers (both strip variants)."""
     rng = np.random.default_rng(99)
     shapes = [(3, 3), (5, 60), (53, 45), (54, 46), (55, 47), (107, 93), (109, 91), (64, 56), (65, 57), (200, 17), (17, 200), (163, 139)]
     fields = []
@@ -588,13 +588,15 @@ def test_strip_kernel_randomised_shapes_fixed_dt(gpu, monkeypatch):
             H[:, : ny // 2] = 0.0
         fields.append((np.asfortranarray(np.maximum(H, 0.0)), np.asfortranarray(B)))
     res = {}
-    for scheme in (1, 2):
+    for key, scheme, tiles in (("staged", 1, "t"), ("t", 2, "t"), ("u", 2, "u")):
+        monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
         b = gpu.GlacierBatch(shapes, [40.0] * len(shapes), [55.0] * len(shapes), A=[3e-17] * len(shapes))
         for k, (H, B) in enumerate(fields):
             b.set_fields(k, H, B)
         b.solve([0.0, 3e-4], fixed_dt=1e-4, scheme=scheme, dense=scheme - 1)
-        res[scheme] = [b.snapshot(k, 1) for k in range(len(shapes))]
+        res[key] = [b.snapshot(k, 1) for k in range(len(shapes))]
         b.close()
-    for k, shp in enumerate(shapes):
-        assert np.isfinite(res[2][k]).all(), shp
-        assert rel_l2(res[2][k], res[1][k]) < 1e-13, shp
+    for key in ("t", "u"):
+        for k, shp in enumerate(shapes):
+            assert np.isfinite(res[key][k]).all(), (key, shp)
+            assert rel_l2(res[key][k], res["staged"][k]) < 1e-13, (key, shp)
