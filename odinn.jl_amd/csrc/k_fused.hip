@@ -19,19 +19,24 @@ void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev
   }
 }
 #if ODINN_LM == 0
-// strip kernel (integer-power law) on the FOX x FOYT (rows = 7) or FOX x FOYT8 (rows = 8) tile table
+// strip kernel (integer-power law) on the FOX x FOYT (rows = 7) or FOX x FOYT8 (rows = 8) tile table; sc != null:
+// self-controlled step (no controller / post-step launches, see ScArgs)
 void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
-                           double* U1, double* partF, double abstol, double reltol, int skip) {
-#define ODINN_STRIP(SK, AF, NR) \
-  hipLaunchKernelGGL((k_rk_fused_strip<SK, AF, NR>), dim3(nblk), dim3(TNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol)
+                           double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc) {
+  const ScArgs A = sc ? *sc : ScArgs{};
+#define ODINN_STRIP(SK, AF, NR, SCV) \
+  hipLaunchKernelGGL((k_rk_fused_strip<SK, AF, NR, SCV>), dim3(nblk), dim3(TNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol, A)
+#define ODINN_STRIP_S(SK, AF, NR) \
+  do { if (sc) ODINN_STRIP(SK, AF, NR, true); else ODINN_STRIP(SK, AF, NR, false); } while (0)
 #define ODINN_STRIP_R(SK, AF) \
-  do { if (rows == 8) ODINN_STRIP(SK, AF, 8); else ODINN_STRIP(SK, AF, TRPT); } while (0)
+  do { if (rows == 8) ODINN_STRIP_S(SK, AF, 8); else ODINN_STRIP_S(SK, AF, TRPT); } while (0)
   if (afield) {
     if (skip) ODINN_STRIP_R(true, true); else ODINN_STRIP_R(false, true);
   } else {
     if (skip) ODINN_STRIP_R(true, false); else ODINN_STRIP_R(false, false);
   }
 #undef ODINN_STRIP_R
+#undef ODINN_STRIP_S
 #undef ODINN_STRIP
 }
 #endif

@@ -25,7 +25,7 @@ ODINN_DECL_LM(5)
 
 // k_fused.hip, law mode 0 only
 void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
-                           double* U1, double* partF, double abstol, double reltol, int skip);
+                           double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc = nullptr);
 
 // k_adjf.hip, law mode 0 only
 void launch_adj_fused_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, AdjFusedArgs A);

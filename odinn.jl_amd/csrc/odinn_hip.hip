@@ -133,6 +133,10 @@ struct odinn_batch {
   int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr, *d_tilesFu = nullptr;
   int ntilesF = 0, ntilesFs = 0, ntilesFt = 0, ntilesFu = 0;
   double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr, *d_partFu = nullptr;
+  static int sc_env() {  // ODINN_STEP_SC: -1 unset, 0 off, 1 forced on
+    const char* e = std::getenv("ODINN_STEP_SC");
+    return !e ? -1 : (e[0] == '1' ? 1 : 0);
+  }
   mutable int fused_env = -1;  // ODINN_FUSED_TILES, parsed once: 0 unset, 1 small, 2 large, 3 t (strip, 7 rows), 4 u (strip, 8 rows)
   int fused_override() const {
     if (fused_env < 0) {
@@ -153,7 +157,10 @@ struct odinn_batch {
     if (o == 4) return lm() == 0 ? 3 : 0;
     // 3 = strip kernel with 8 rows per thread (54 x 54 tiles: less halo work, but a longer sweep per workgroup):
     // pays once the batch more than fills the 512 workgroup slots of the GPU (measured crossover: 400 tiles lose 8 %, 720 win 10 %)
-    if (lm() == 0) return ntilesFu >= 704 ? 3 : (ntilesFt >= 96 ? 2 : 1);
+    // below ~100 strip tiles the 54 x 8 latency tiles win as a KERNEL, but the strip kernel can run the self-controlled
+    // step loop (no controller / post-step launches; needs no mass balance), which wins as a STEP (4 alpine glaciers:
+    // 0.64 -> 0.55 ms for 25 steps)
+    if (lm() == 0) return ntilesFu >= 704 ? 3 : ((ntilesFt >= 96 || (!any_mb && sc_env() != 0)) ? 2 : 1);
     return ntilesF <= 256 ? 1 : 0;
   }
   const int4* fused_tiles() const { const int k = fused_kind(); return k == 3 ? d_tilesFu : k == 2 ? d_tilesFt : k == 1 ? d_tilesFs : d_tilesF; }
@@ -162,6 +169,8 @@ struct odinn_batch {
   int fused_ctrl() const { const int k = fused_kind(); return k == 3 ? 4 : k == 2 ? 3 : k == 1 ? 2 : 1; }
   GDev* d_gd = nullptr;
   GState* d_gs = nullptr;
+  GState* d_gs2 = nullptr;   // second state array and second error-partial array of the self-controlled step loop
+  double* d_part2 = nullptr;
   double *d_B = nullptr, *d_H0 = nullptr, *d_Afield = nullptr, *d_Tfield = nullptr, *d_Gacc = nullptr;
   double *d_part = nullptr, *d_U[2] = {nullptr, nullptr}, *d_S2 = nullptr, *d_S3 = nullptr, *d_E = nullptr;
   double *d_lam[2] = {nullptr, nullptr}, *d_tmpA = nullptr, *d_tmpB = nullptr;
@@ -476,21 +485,38 @@ int pick_scheme(const odinn_batch* b, int requested) {
   return s;
 }
 
-int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip) {
+int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, const ScArgs* sc = nullptr,
+                      double* part_override = nullptr) {
   const Pools P = b->pools(true);
   const LawDev L = b->lawdev();
   const int small = b->fused_kind();
   const int nblk = b->fused_ntiles();
   const int4* tiles = b->fused_tiles();
-  double* part = b->fused_part();
+  double* part = part_override ? part_override : b->fused_part();
   if (small >= 2)
     launch_rk_fused_strip(nblk, b->gd[0].use_Afield, small == 3 ? 8 : TRPT, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol,
-                          reltol, skip);
+                          reltol, skip, sc);
   else if (b->lm() == 0)
     launch_rk_fused_lm0(nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
   else
     launch_rk_fused_lm1(nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
   HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+// self-controlled step loop (ScArgs): strip kernel, no mass balance.  Every workgroup repeats the controller's
+// work (~3 us), which pays while the batch fits one round of the GPU's 512 workgroup slots -- launch latency is
+// then most of a step (1 x 512^2: 19.5 -> 16.6 us per step, 4 x 512^2: 27.1 -> 23.8) -- and costs more than the two
+// launches it saves beyond (2 x 1024^2: 39 -> 43 us).  ODINN_STEP_SC=0|1 overrides.
+static bool sc_mode(const odinn_batch* b, int scheme) {
+  if (scheme != 2 || b->fused_kind() < 2 || b->any_mb) return false;
+  if (const char* e = std::getenv("ODINN_STEP_SC")) return e[0] == '1';
+  return b->fused_ntiles() <= 640;
+}
+static int sc_buffers(odinn_batch* b) {
+  if (!b->d_gs2) CHK(dalloc(&b->d_gs2, (size_t)b->G));
+  const size_t need = (size_t)std::max(b->ntilesFt, b->ntilesFu);
+  if (!b->d_part2) CHK(dalloc(&b->d_part2, need));
   return ODINN_OK;
 }
 
@@ -682,6 +708,8 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   // steps between host polls of the active-glacier counter: at least one step per stop is needed, so
   // the first batch is n_stops-1 steps (short solves that land on a stop every step finish with one
   // poll and no wasted launches); afterwards 16, with parity kept even for the ping-pong buffers
+  const bool sc = !euler && sc_mode(b, scheme);
+  if (sc) CHK(sc_buffers(b));
   long long steps = 0;
   int p = 0;
   int chunk = std::max(2, std::min(256, (n_stops - 1 + 1) & ~1));
@@ -696,6 +724,17 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
       if (scheme == 3) {
         launch_euler_cfl(b, P, b->lawdev(), b->d_U[p], b->d_U[1 - p]);
         C.next_cur = 1 - p;
+      } else if (sc) {
+        // launch n reads state / partials [n & 1 ... (n - 1) & 1], writes the other ones; it decides attempt n - 1
+        ScArgs SA{};
+        SA.C = C; SA.C.next_cur = -1;
+        SA.gin = (steps & 1) ? b->d_gs2 : b->d_gs; SA.gout = (steps & 1) ? b->d_gs : b->d_gs2;
+        SA.part_in = (steps & 1) ? b->fused_part() : b->d_part2;
+        SA.snaps = b->d_snaps; SA.ntot = b->ntot;
+        CHK(launch_fused_step(b, opt.abstol, opt.reltol, opt.dense ? 0 : 1, &SA, (steps & 1) ? b->d_part2 : b->fused_part()));
+        p = 1 - p;
+        ++steps;
+        continue;
       } else if (scheme == 2) {
         CHK(launch_fused_step(b, opt.abstol, opt.reltol, opt.dense ? 0 : 1));
         C.next_cur = -1;
@@ -724,6 +763,9 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
     if (opt.maxiters - steps < chunk) chunk = (int)std::max<long long>(2, (opt.maxiters - steps + 1) & ~1LL);  // never run far past maxiters
     ++polls;
   }
+  if (sc && (steps & 1))  // the last launch wrote its state to d_gs2
+    HIPCHK(hipMemcpyAsync(b->d_gs, b->d_gs2, sizeof(GState) * b->G, hipMemcpyDeviceToDevice, b->stream));
+  if (sc) HIPCHK(hipStreamSynchronize(b->stream));
   if (prof) tp3 = now();
   std::vector<GState> gs(b->G);
   HIPCHK(hipMemcpy(gs.data(), b->d_gs, sizeof(GState) * b->G, hipMemcpyDeviceToHost));
@@ -924,7 +966,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
-  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt); dfree(b->d_tilesFu); dfree(b->d_partFu); dfree(b->d_est);
+  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt); dfree(b->d_tilesFu); dfree(b->d_partFu); dfree(b->d_est); dfree(b->d_gs2); dfree(b->d_part2);
   dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
   dfree(b->d_rmbs); dfree(b->d_adj);
   dfree(b->d_partsteps);

@@ -950,6 +950,16 @@ struct CtrlArgs {
   double* qw_out;         // per glacier: weight of the node reached by this step (0 otherwise)
 };
 
+// self-controlled fused step (sia2d_fused.hpp, k_rk_fused_strip<..., SC = true>)
+struct ScArgs {
+  CtrlArgs C;
+  const GState* gin;
+  GState* gout;
+  const double* part_in;  // error partials written by the previous launch (this launch writes partF)
+  double* snaps;          // [n_stops][ntot]
+  long long ntot;
+};
+
 // interpolation weights of H_itp at the five stage times of the step [tau, tau + dt]
 __device__ __forceinline__ void adj_stage_weights(AdjState* a, const double* tsnap, double tau, double dt,
                                                   bool all_at_end) {
@@ -2016,7 +2026,7 @@ __global__ void k_begin(Pools P, int n, const double* tstops, double dtmax, doub
   gs->t = t0; gs->dt = dt; gs->e2 = 1.0; gs->e3 = 1.0; gs->EEst = 0.0;
   gs->accepted = 1; gs->at_stop = 0; gs->mb_now = 0; gs->mb_slot = 0;
   gs->done = 0; gs->istop = 1; gs->clipped = clipped; gs->cur = 0;
-  gs->naccept = 0; gs->nreject = 0; gs->nonfinite = 0;
+  gs->naccept = 0; gs->nreject = 0; gs->nonfinite = 0; gs->pad = 0;
 }
 
 

@@ -476,27 +476,135 @@ __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, con
   strip_stage<5, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
 }
 
+// ---- self-controlled step (SC): no controller / post-step launches ---------------------------------------
+// In the solve loop a step was three dependent launches (step kernel, k_controller, k_poststep); the two small
+// ones cost ~16 % of a step at 8 x 1024^2 and half of it for small batches -- launch latency, not work.  With
+// SC every workgroup of launch n first DECIDES the previous attempt of its glacier itself: wavefront 0 sums the
+// glacier's error partials of launch n-1 (same fixed order as k_controller) and runs the PID controller on the
+// state in gin (`sc_decide`, the forward branch of k_controller verbatim); all workgroups of a glacier compute
+// the same decision from the same numbers, the one that owns tile (0,0) writes the new state to gout (the two
+// state arrays and the two partial arrays alternate between launches, so nobody reads what another workgroup of
+// the same launch writes).  If the decided step reached a stop, each workgroup stores the snapshot of its own
+// output cells from the accepted buffer before stepping on.  Glaciers with a mass balance keep the three-launch
+// path (the MB changes the state at a stop).
+// GState::pad in SC mode: bit 0 = an attempt awaits its decision, bit 1 = a snapshot awaits being stored
+__device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlArgs& C, double errsum, int& est) {
+  const double h = s.dt;
+  double fac = 1.0;
+  bool accept = true;
+  if (C.adaptive) {
+    double EEst = sqrt(errsum / ((double)g.nx * (double)g.ny));
+    if (!(EEst == EEst) || isinf(EEst)) { s.nonfinite = 1; EEst = 1e300; }
+    if (EEst < 2.220446049250313e-16) EEst = 2.220446049250313e-16;
+    s.EEst = EEst;
+    const double e1 = 1.0 / EEst;
+    fac = pow(e1, 0.64 / 3.0) * pow(s.e2, -0.31 / 3.0) * pow(s.e3, 0.04 / 3.0);
+    fac = 1.0 + atan(fac - 1.0);
+    accept = fac >= 0.81;
+    if (accept) { s.e3 = s.e2; s.e2 = e1; }
+  }
+  double t = s.t;
+  s.at_stop = 0;
+  s.mb_now = 0;
+  if (accept) {
+    s.naccept++;
+    s.accepted = 1;
+    s.cur = 1 - s.cur;
+    if (s.clipped) {
+      t = C.tstops[s.istop];
+      s.at_stop = 1;
+      s.istop++;
+    } else {
+      t += h;
+    }
+    s.t = t;
+  } else {
+    s.nreject++;
+    s.accepted = 0;
+  }
+  if (s.istop >= C.n_stops) {
+    s.done = 1;
+    est = 0;
+    return;
+  }
+  double dtn = C.adaptive ? h * fac : C.fixed_dt;
+  if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
+  const double rem = C.tstops[s.istop] - t;
+  if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
+    dtn = rem;
+    s.clipped = 1;
+  } else {
+    s.clipped = 0;
+  }
+  s.dt = dtn;
+  const double e = ceil((C.tstops[C.n_stops - 1] - t) / (C.adaptive ? h * fac : dtn));
+  const int stops_left = C.n_stops - s.istop;
+  est = e < (double)stops_left ? stops_left : (e > 1e6 ? 1000000 : (int)e);
+}
+
 // AF: A from the dual-grid field.  One stage path per kernel: with two paths in one kernel the register allocator
 // spills (a separate predicate-free kernel for the tiles strictly inside the grid was measured and lost: its
 // second launch costs more than the selects it saves).
 // NR: rows per thread (7: 54x46 output tiles; 8: 54x54 tiles, less halo work, for batches that fill the GPU twice over)
-template <bool SKIP, bool AF, int NR>
+template <bool SKIP, bool AF, int NR, bool SC = false>
 __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, LawDev L, const int4* __restrict__ tilesF,
                                                                     double* __restrict__ U0, double* __restrict__ U1,
-                                                                    double* __restrict__ partF, double abstol, double reltol) {
+                                                                    double* __restrict__ partF, double abstol, double reltol,
+                                                                    ScArgs A) {
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double red[TNW];
+  __shared__ GState s_state;
   const int4 t4 = tilesF[blockIdx.x];
-  const GState* gs = P.gs + t4.x;
-  if (gs->done) return;
   const GDev g = P.gd[t4.x];
-  const double dt = gs->dt;
-  // everything below is addressed relative to the glacier's first cell (block-uniform bases, 32-bit cell indices)
-  const double* __restrict__ src = (gs->cur ? U1 : U0) + g.off;
-  double* __restrict__ dst = (gs->cur ? U0 : U1) + g.off;
-  const double* __restrict__ Bg = P.B + g.off;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double dt;
+  int cur, snap_slot = -1;  // snap_slot >= 0: store the snapshot of the stop the decided step reached
+  bool finished;
+  if (SC) {
+    if (w == 0) {
+      GState sn = A.gin[t4.x];
+      int est = -1;
+      bool newly_done = false;
+      if (!sn.done && (sn.pad & 1)) {
+        const int t0 = NR == 8 ? g.tile0Fu : g.tile0Ft, nt = NR == 8 ? g.ntilesFu : g.ntilesFt;
+        double sum = 0.0;
+        for (int k = lane; k < nt; k += 64) sum += A.part_in[t0 + k];
+        sum = wave_sum(sum);
+        if (lane == 0) {
+          sc_decide(sn, g, A.C, sum, est);
+          sn.pad = sn.at_stop ? 2 : 0;
+          newly_done = sn.done != 0;
+        }
+      }
+      if (lane == 0) {
+        s_state = sn;  // what this launch acts on
+        if (t4.y == 0 && t4.z == 0) {  // the glacier's designated workgroup publishes the state for the next launch
+          GState so = sn;
+          so.pad = sn.done ? 0 : 1;  // its snapshot (if any) is stored below, an attempt follows unless done
+          A.gout[t4.x] = so;
+          if (newly_done) atomicSub(A.C.n_active, 1);
+          if (A.C.est_steps && est >= 0) A.C.est_steps[t4.x] = est;
+        }
+      }
+    }
+    __syncthreads();
+    dt = s_state.dt;
+    cur = s_state.cur;
+    finished = s_state.done != 0;
+    if (s_state.pad & 2) snap_slot = s_state.istop - 1;
+    if (finished && snap_slot < 0) return;
+  } else {
+    const GState* gs = P.gs + t4.x;
+    if (gs->done) return;
+    dt = gs->dt;
+    cur = gs->cur;
+    finished = false;
+  }
+  // everything below is addressed relative to the glacier's first cell (block-uniform bases, 32-bit cell indices)
+  const double* __restrict__ src = (cur ? U1 : U0) + g.off;
+  double* __restrict__ dst = (cur ? U0 : U1) + g.off;
+  const double* __restrict__ Bg = P.B + g.off;
   const int gi0 = t4.y * FOX - FH, gj0 = t4.z * (NR * TNW - 2 * FH) - FH;
   const int gi = gi0 + lane, r0 = NR * w;
   const bool inx = gi >= 0 && gi < g.nx;
@@ -513,6 +621,17 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     }
     u[m] = h; tmp[m] = h; E[m] = 0.0; bb[m] = b;
     nz = nz || (h != 0.0);
+  }
+  if (SC && snap_slot >= 0) {  // snapshot of the stop just reached: this workgroup's output cells of the accepted state
+    double* __restrict__ sn = A.snaps + (long long)snap_slot * A.ntot + g.off;
+    if (lane >= FH && lane < FH + FOX && inx) {
+#pragma unroll
+      for (int m = 0; m < NR; ++m) {
+        const int r = r0 + m, gj = gj0 + r;
+        if (r >= FH && r <= (NR * TNW) - 1 - FH && gj < g.ny) stg32(sn, (unsigned)(id0 + g.nx * m), u[m]);
+      }
+    }
+    if (finished) return;
   }
   sE[0][w][0][lane] = cell_HS(u[0], bb[0]);
   sE[0][w][1][lane] = cell_HS(u[NR - 1], bb[NR - 1]);

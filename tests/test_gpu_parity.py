@@ -600,3 +600,33 @@ def test_strip_kernel_randomised_shapes_fixed_dt(gpu, monkeypatch):
         for k, shp in enumerate(shapes):
             assert np.isfinite(res[key][k]).all(), (key, shp)
             assert rel_l2(res[key][k], res["staged"][k]) < 1e-13, (key, shp)
+
+
+def test_self_controlled_step_loop_is_bitwise_the_three_launch_loop(gpu, monkeypatch):
+    """ODINN_STEP_SC=1: every workgroup of the strip kernel decides the previous attempt of its glacier itself (error
+    norm, PID controller, stop handling) and stores the snapshots -- no k_controller / k_poststep launches.  Same
+    kernel arithmetic and the same decisions: snapshots, step counts and final times are bit-identical to the
+    three-launch loop, on a ragged batch with rejections and many stops."""
+    monkeypatch.setenv("ODINN_FUSED_TILES", "t")
+    shapes = [(130, 97), (96, 80), (201, 103), (54, 46)]
+    ts = [2010.0 + 0.05 * j for j in range(9)]
+    out = {}
+    for sc in ("0", "1"):
+        monkeypatch.setenv("ODINN_STEP_SC", sc)
+        b = gpu.GlacierBatch(shapes, [50.0] * 4, A=[8e-17, 4e-17, 6e-17, 2e-17])
+        for k, (nx, ny) in enumerate(shapes):
+            H0, B = O.synthetic_valley(nx, ny, 50.0)
+            b.set_fields(k, H0, B)
+        st = b.solve(ts, reltol=1e-6, dt0=0.004)  # a large first step: rejections
+        out[sc] = ([[b.snapshot(k, j) for j in range(len(ts))] for k in range(4)],
+                   [(s.naccept, s.nreject, s.t_final, s.dt_last) for s in st])
+        st2 = b.solve(ts[:3], fixed_dt=0.0025)
+        out[sc] += ([b.snapshot(k, 2) for k in range(4)], [(s.naccept, s.nreject) for s in st2])
+        b.close()
+    a, f = out["0"], out["1"]
+    assert a[1] == f[1] and a[3] == f[3], (a[1], f[1])
+    assert sum(r for _, r, _, _ in a[1]) > 0
+    for k in range(4):
+        for j in range(len(ts)):
+            assert np.array_equal(a[0][k][j], f[0][k][j]), (k, j)
+        assert np.isfinite(a[2][k]).all() and np.array_equal(a[2][k], f[2][k]), k
