@@ -160,7 +160,8 @@ struct odinn_batch {
     // below ~100 strip tiles the 54 x 8 latency tiles win as a KERNEL, but the strip kernel can run the self-controlled
     // step loop (no controller / post-step launches; needs no mass balance), which wins as a STEP (4 alpine glaciers:
     // 0.64 -> 0.55 ms for 25 steps)
-    if (lm() == 0) return ntilesFu >= 704 ? 3 : ((ntilesFt >= 96 || (!any_mb && sc_env() != 0)) ? 2 : 1);
+    // (the 8-row form of the gridded-A path spills registers: gridded A stays on 7 rows)
+    if (lm() == 0) return (ntilesFu >= 704 && !gd[0].use_Afield) ? 3 : ((ntilesFt >= 96 || (!any_mb && sc_env() != 0)) ? 2 : 1);
     return ntilesF <= 256 ? 1 : 0;
   }
   const int4* fused_tiles() const { const int k = fused_kind(); return k == 3 ? d_tilesFu : k == 2 ? d_tilesFt : k == 1 ? d_tilesFs : d_tilesF; }
@@ -505,13 +506,13 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
 }
 
 // self-controlled step loop (ScArgs): strip kernel, no mass balance.  Every workgroup repeats the controller's
-// work (~3 us), which pays while the batch fits one round of the GPU's 512 workgroup slots -- launch latency is
-// then most of a step (1 x 512^2: 19.5 -> 16.6 us per step, 4 x 512^2: 27.1 -> 23.8) -- and costs more than the two
-// launches it saves beyond (2 x 1024^2: 39 -> 43 us).  ODINN_STEP_SC=0|1 overrides.
+// work (~2 us), which pays while launch latency is a large part of a step (1 x 512^2: 20.0 -> 15.6 us per step,
+// 64 alpine glaciers: 40 -> 35, 2 x 1024^2: 38.8 -> 37.7) and costs slightly more than the two launches it saves on
+// the largest batches (8 x 1024^2: +2 %, 512 alpine glaciers: +3 %).  ODINN_STEP_SC=0|1 overrides.
 static bool sc_mode(const odinn_batch* b, int scheme) {
   if (scheme != 2 || b->fused_kind() < 2 || b->any_mb) return false;
   if (const char* e = std::getenv("ODINN_STEP_SC")) return e[0] == '1';
-  return b->fused_ntiles() <= 640;
+  return b->fused_ntiles() <= 1600;
 }
 static int sc_buffers(odinn_batch* b) {
   if (!b->d_gs2) CHK(dalloc(&b->d_gs2, (size_t)b->G));

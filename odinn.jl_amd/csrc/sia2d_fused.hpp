@@ -488,7 +488,9 @@ __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, con
 // output cells from the accepted buffer before stepping on.  Glaciers with a mass balance keep the three-launch
 // path (the MB changes the state at a stop).
 // GState::pad in SC mode: bit 0 = an attempt awaits its decision, bit 1 = a snapshot awaits being stored
-__device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlArgs& C, double errsum, int& est) {
+// Called by ALL lanes of wavefront 0 with identical arguments: the three pow() of the PID factor run in lanes 0..2 at
+// once (same calls, same product order as k_controller: bit-identical), everything else is computed redundantly.
+__device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlArgs& C, double errsum, int& est, int lane) {
   const double h = s.dt;
   double fac = 1.0;
   bool accept = true;
@@ -498,7 +500,8 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
     if (EEst < 2.220446049250313e-16) EEst = 2.220446049250313e-16;
     s.EEst = EEst;
     const double e1 = 1.0 / EEst;
-    fac = pow(e1, 0.64 / 3.0) * pow(s.e2, -0.31 / 3.0) * pow(s.e3, 0.04 / 3.0);
+    const double pw = pow(lane == 0 ? e1 : (lane == 1 ? s.e2 : s.e3), lane == 0 ? 0.64 / 3.0 : (lane == 1 ? -0.31 / 3.0 : 0.04 / 3.0));
+    fac = __shfl(pw, 0, 64) * __shfl(pw, 1, 64) * __shfl(pw, 2, 64);
     fac = 1.0 + atan(fac - 1.0);
     accept = fac >= 0.81;
     if (accept) { s.e3 = s.e2; s.e2 = e1; }
@@ -558,6 +561,17 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   const GDev g = P.gd[t4.x];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * (NR * TNW - 2 * FH) - FH;
+  const int gi = gi0 + lane, r0 = NR * w;
+  const bool inx = gi >= 0 && gi < g.nx;
+  const int id0 = gi + g.nx * (gj0 + r0);
+  const double* __restrict__ Bg = P.B + g.off;
+  double bb[NR];  // B does not depend on the controller's decision: in SC mode its loads fly while wavefront 0 decides
+#pragma unroll
+  for (int m = 0; m < NR; ++m) {
+    const int gj = gj0 + r0 + m;
+    bb[m] = (inx && gj >= 0 && gj < g.ny) ? ldg32(Bg, (unsigned)(id0 + g.nx * m)) : 0.0;
+  }
   double dt;
   int cur, snap_slot = -1;  // snap_slot >= 0: store the snapshot of the stop the decided step reached
   bool finished;
@@ -570,12 +584,10 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
         const int t0 = NR == 8 ? g.tile0Fu : g.tile0Ft, nt = NR == 8 ? g.ntilesFu : g.ntilesFt;
         double sum = 0.0;
         for (int k = lane; k < nt; k += 64) sum += A.part_in[t0 + k];
-        sum = wave_sum(sum);
-        if (lane == 0) {
-          sc_decide(sn, g, A.C, sum, est);
-          sn.pad = sn.at_stop ? 2 : 0;
-          newly_done = sn.done != 0;
-        }
+        sum = __shfl(wave_sum(sum), 0, 64);
+        sc_decide(sn, g, A.C, sum, est, lane);
+        sn.pad = sn.at_stop ? 2 : 0;
+        newly_done = sn.done != 0;
       }
       if (lane == 0) {
         s_state = sn;  // what this launch acts on
@@ -604,22 +616,14 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   // everything below is addressed relative to the glacier's first cell (block-uniform bases, 32-bit cell indices)
   const double* __restrict__ src = (cur ? U1 : U0) + g.off;
   double* __restrict__ dst = (cur ? U0 : U1) + g.off;
-  const double* __restrict__ Bg = P.B + g.off;
-  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * (NR * TNW - 2 * FH) - FH;
-  const int gi = gi0 + lane, r0 = NR * w;
-  const bool inx = gi >= 0 && gi < g.nx;
-  const int id0 = gi + g.nx * (gj0 + r0);
-  double u[NR], tmp[NR], E[NR], bb[NR];
+  double u[NR], tmp[NR], E[NR];
   bool nz = false;
 #pragma unroll
   for (int m = 0; m < NR; ++m) {
     const int gj = gj0 + r0 + m;
-    double h = 0.0, b = 0.0;
-    if (inx && gj >= 0 && gj < g.ny) {
-      h = ldg32(src, (unsigned)(id0 + g.nx * m));
-      b = ldg32(Bg, (unsigned)(id0 + g.nx * m));
-    }
-    u[m] = h; tmp[m] = h; E[m] = 0.0; bb[m] = b;
+    double h = 0.0;
+    if (inx && gj >= 0 && gj < g.ny) h = ldg32(src, (unsigned)(id0 + g.nx * m));
+    u[m] = h; tmp[m] = h; E[m] = 0.0;
     nz = nz || (h != 0.0);
   }
   if (SC && snap_slot >= 0) {  // snapshot of the stop just reached: this workgroup's output cells of the accepted state
