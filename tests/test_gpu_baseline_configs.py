@@ -140,7 +140,8 @@ def test_config4_batch_of_1024_glaciers(gpu, monkeypatch):
     one.solve([0.0, 0.02], fixed_dt=0.005)
     assert rel_l2(one.snapshot(0, 1), b.snapshot(5, 1)) < 1e-13
     one.close()
-    monkeypatch.setenv("ODINN_FUSED_TILES", "u")  # the kernel the batch of 8 ran on
+    monkeypatch.setenv("ODINN_FUSED_TILES", "u")  # the kernel the batch of 8 ran on ...
+    monkeypatch.setenv("ODINN_STEP_SC", "0")      # ... in the same instantiation (three-launch loop)
     one = gpu.GlacierBatch([(n, n)], [100.0], A=[gl[5][2]])
     one.set_fields(0, gl[5][0], gl[5][1])
     one.solve([0.0, 0.02], fixed_dt=0.005)
