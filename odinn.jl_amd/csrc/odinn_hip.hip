@@ -160,8 +160,7 @@ struct odinn_batch {
     // below ~100 strip tiles the 54 x 8 latency tiles win as a KERNEL, but the strip kernel can run the self-controlled
     // step loop (no controller / post-step launches; needs no mass balance), which wins as a STEP (4 alpine glaciers:
     // 0.64 -> 0.55 ms for 25 steps)
-    // (the 8-row form of the gridded-A path spills registers: gridded A stays on 7 rows)
-    if (lm() == 0) return (ntilesFu >= 704 && !gd[0].use_Afield) ? 3 : ((ntilesFt >= 96 || (!any_mb && sc_env() != 0)) ? 2 : 1);
+    if (lm() == 0) return ntilesFu >= 704 ? 3 : ((ntilesFt >= 96 || (!any_mb && sc_env() != 0)) ? 2 : 1);
     return ntilesF <= 256 ? 1 : 0;
   }
   const int4* fused_tiles() const { const int k = fused_kind(); return k == 3 ? d_tilesFu : k == 2 ? d_tilesFt : k == 1 ? d_tilesFs : d_tilesF; }

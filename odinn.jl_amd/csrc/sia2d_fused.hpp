@@ -359,7 +359,7 @@ __device__ __forceinline__ double2 cell_HS(double uu, double b) {
 typedef double2 (*StripEdges)[TNW][2][FRX];
 
 template <int S, bool AF, int NR>
-__device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
+__device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double (*sA)[TNT],
                                              const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                              double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
                                              double (&E)[NR], const double (&bb)[NR]) {
@@ -378,16 +378,13 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   // The bottom edge of a node's cell quartet is the top edge of the previous row's: its x-difference of S and
   // its pair sum of Hc are carried up the sweep (dxb, hpb) instead of being recomputed.
   const double Gq = g.Gam * (1.0 / 1024.0);
-  auto node = [&](int gj, double dxb, double hpb, double dxt, double hpt, double dyw, double dye) {
+  auto node = [&](int slot, double dxb, double hpb, double dxt, double hpt, double dyw, double dye) {
     const double gx = (dxb + dxt) * g.hinv_dx;
     const double gy = (dyw + dye) * g.hinv_dy;
     const double H4s = hpb + hpt;  // 4 Hbar
     const double gS2 = gx * gx + gy * gy;
     double An = g.A;
-    if (AF) {
-      const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
-      An = ldg32(Afield, (unsigned)(ok ? gi + (g.nx - 1) * gj : 0));
-    }
+    if (AF) An = sA[slot][threadIdx.x];  // the thread's own nodes' A, copied once per launch (see the kernel)
     const double H2 = H4s * H4s, H4 = H2 * H2;
     return (An * Gq) * (H4 * H4s) * gS2;
   };
@@ -412,7 +409,7 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   {
     const double2 e_s = dpp_from_east(hs_s);
     const double dyw = hs_c.y - hs_s.y;
-    D_s = node(gj0 + r0 - 1, e_s.y - hs_s.y, hs_s.x + e_s.x, dx_c, hp_c, dyw, e_c.y - e_s.y);
+    D_s = node(0, e_s.y - hs_s.y, hs_s.x + e_s.x, dx_c, hp_c, dyw, e_c.y - e_s.y);
     F_s = face(dpp_from_west(D_s), D_s, dyw, hs_c.x, hs_s.x);
   }
 #pragma unroll
@@ -421,7 +418,7 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
     const double2 hs_n = m + 1 < NR ? cell_HS(u[m + 1 < NR ? m + 1 : m], bb[m + 1 < NR ? m + 1 : m]) : hs_top;
     const double2 e_n = dpp_from_east(hs_n);
     const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, dyw = hs_n.y - hs_c.y;
-    const double D_c = node(gj, dx_c, hp_c, dx_n, hp_n, dyw, e_n.y - e_c.y);
+    const double D_c = node(m + 1, dx_c, hp_c, dx_n, hp_n, dyw, e_n.y - e_c.y);
     const double F_e = face(D_s, D_c, dx_c, e_c.x, hs_c.x);
     const double F_n = face(dpp_from_west(D_c), D_c, dyw, hs_n.x, hs_c.x);
     const double F_w = dpp_from_west(F_e);
@@ -465,15 +462,15 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
 }
 
 template <bool AF, int NR>
-__device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
+__device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double (*sA)[TNT],
                                               const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                               double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
                                               double (&E)[NR], const double (&bb)[NR]) {
-  strip_stage<1, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<2, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<3, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<4, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<5, AF, NR>(g, L, Afield, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<1, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<2, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<3, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<4, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<5, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
 }
 
 // ---- self-controlled step (SC): no controller / post-step launches ---------------------------------------
@@ -557,6 +554,9 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double red[TNW];
   __shared__ GState s_state;
+  // gridded A: the thread's own nodes (rows r0-1 .. r0+NR-1 of its column) in private LDS slots -- read in each of the
+  // five stages, fetched from global memory once (0 on nodes outside the dual grid: they only feed frozen cells)
+  __shared__ double sA[AF ? NR + 1 : 1][TNT];
   const int4 t4 = tilesF[blockIdx.x];
   const GDev g = P.gd[t4.x];
   const int lane = threadIdx.x & 63;
@@ -657,7 +657,17 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     __syncthreads();
   }
   const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
-  strip_stages<AF, NR>(g, L, AF ? P.Afield + g.offd : nullptr, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
+  if (AF) {
+    const double* __restrict__ Afg = P.Afield + g.offd;
+    const bool nodex = gi >= 0 && gi <= g.nx - 2;
+#pragma unroll
+    for (int m = 0; m <= NR; ++m) {
+      const int gj = gj0 + r0 - 1 + m;
+      const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+      sA[AF ? m : 0][threadIdx.x] = ok ? ldg32(Afg, (unsigned)(gi + (g.nx - 1) * gj)) : 0.0;
+    }
+  }
+  strip_stages<AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
   // ---- output rows [FH, (NR * TNW)-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
   double upf[NR];
