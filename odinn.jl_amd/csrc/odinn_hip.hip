@@ -160,7 +160,7 @@ struct odinn_batch {
     // below ~100 strip tiles the 54 x 8 latency tiles win as a KERNEL, but the strip kernel can run the self-controlled
     // step loop (no controller / post-step launches; needs no mass balance), which wins as a STEP (4 alpine glaciers:
     // 0.64 -> 0.55 ms for 25 steps)
-    if (lm() == 0) return ntilesFu >= 704 ? 3 : ((ntilesFt >= 96 || (!any_mb && sc_env() != 0)) ? 2 : 1);
+    if (lm() == 0) return ntilesFu >= 704 ? 3 : ((ntilesFt >= 96 || sc_env() != 0) ? 2 : 1);
     return ntilesF <= 256 ? 1 : 0;
   }
   const int4* fused_tiles() const { const int k = fused_kind(); return k == 3 ? d_tilesFu : k == 2 ? d_tilesFt : k == 1 ? d_tilesFs : d_tilesF; }
@@ -509,7 +509,7 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
 // 64 alpine glaciers: 40 -> 35, 2 x 1024^2: 38.8 -> 37.7) and costs slightly more than the two launches it saves on
 // the largest batches (8 x 1024^2: +2 %, 512 alpine glaciers: +3 %).  ODINN_STEP_SC=0|1 overrides.
 static bool sc_mode(const odinn_batch* b, int scheme) {
-  if (scheme != 2 || b->fused_kind() < 2 || b->any_mb) return false;
+  if (scheme != 2 || b->fused_kind() < 2 || (b->any_mb && b->gd[0].use_Afield)) return false;  // MB on load: constant-A path
   if (const char* e = std::getenv("ODINN_STEP_SC")) return e[0] == '1';
   return b->fused_ntiles() <= 1600;
 }
@@ -731,6 +731,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
         SA.gin = (steps & 1) ? b->d_gs2 : b->d_gs; SA.gout = (steps & 1) ? b->d_gs : b->d_gs2;
         SA.part_in = (steps & 1) ? b->fused_part() : b->d_part2;
         SA.snaps = b->d_snaps; SA.ntot = b->ntot;
+        SA.premb = b->d_premb; SA.mb0 = b->d_mb0; SA.Sref = b->any_sref ? b->d_Sref : nullptr;
         CHK(launch_fused_step(b, opt.abstol, opt.reltol, opt.dense ? 0 : 1, &SA, (steps & 1) ? b->d_part2 : b->fused_part()));
         p = 1 - p;
         ++steps;

@@ -958,6 +958,9 @@ struct ScArgs {
   const double* part_in;  // error partials written by the previous launch (this launch writes partF)
   double* snaps;          // [n_stops][ntot]
   long long ntot;
+  double* premb;          // mass balance at a stop (applied on load): pre-MB snapshots, pooled MB fields
+  const double* mb0;
+  const double* Sref;     // (nullable)
 };
 
 // interpolation weights of H_itp at the five stage times of the step [tau, tau + dt]

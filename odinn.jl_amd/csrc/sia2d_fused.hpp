@@ -358,8 +358,8 @@ __device__ __forceinline__ double2 cell_HS(double uu, double b) {
 // sE[buf][w][0 | 1][lane]: {Hc, S} of the first | last row of wavefront w's strip
 typedef double2 (*StripEdges)[TNW][2][FRX];
 
-template <int S, bool AF, int NR>
-__device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double (*sA)[TNT],
+template <int S, bool AF, int NR, bool UPL>
+__device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                              const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                              double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
                                              double (&E)[NR], const double (&bb)[NR]) {
@@ -438,7 +438,8 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
       un = fma(g1, uo, g2 * t);
       if (S >= 4) {  // u_n from global memory; what cells outside the glacier pick up is never read (see node)
         const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
-        un = fma(g3, ldg32(src, (unsigned)(gic + g.nx * gjc)), un);
+        // u_n: from the thread's LDS slots where the launch keeps them (UPL), else re-read from global memory
+        un = fma(g3, UPL ? sUp[m][threadIdx.x] : ldg32(src, (unsigned)(gic + g.nx * gjc)), un);
       }
       un = fma(btm, dtk, un);
       if (dl != 0.0) tmp[m] = t;
@@ -461,16 +462,16 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   }
 }
 
-template <bool AF, int NR>
-__device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double (*sA)[TNT],
+template <bool AF, int NR, bool UPL>
+__device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                               const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                               double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
                                               double (&E)[NR], const double (&bb)[NR]) {
-  strip_stage<1, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<2, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<3, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<4, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<5, AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<1, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<2, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<3, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<4, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<5, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
 }
 
 // ---- self-controlled step (SC): no controller / post-step launches ---------------------------------------
@@ -484,7 +485,8 @@ __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, con
 // the same launch writes).  If the decided step reached a stop, each workgroup stores the snapshot of its own
 // output cells from the accepted buffer before stepping on.  Glaciers with a mass balance keep the three-launch
 // path (the MB changes the state at a stop).
-// GState::pad in SC mode: bit 0 = an attempt awaits its decision, bit 1 = a snapshot awaits being stored
+// GState::pad in SC mode: bit 0 = an attempt awaits its decision, bit 1 = a snapshot awaits being stored, bit 2 = the
+// state buffer `cur` still lacks the mass balance of the stop it sits on (applied on load until a step is accepted)
 // Called by ALL lanes of wavefront 0 with identical arguments: the three pow() of the PID factor run in lanes 0..2 at
 // once (same calls, same product order as k_controller: bit-identical), everything else is computed redundantly.
 __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlArgs& C, double errsum, int& est, int lane) {
@@ -513,6 +515,8 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
     if (s.clipped) {
       t = C.tstops[s.istop];
       s.at_stop = 1;
+      s.mb_now = C.mb_flag[s.istop];
+      s.mb_slot = C.mb_slot[s.istop];
       s.istop++;
     } else {
       t += h;
@@ -557,6 +561,10 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   // gridded A: the thread's own nodes (rows r0-1 .. r0+NR-1 of its column) in private LDS slots -- read in each of the
   // five stages, fetched from global memory once (0 on nodes outside the dual grid: they only feed frozen cells)
   __shared__ double sA[AF ? NR + 1 : 1][TNT];
+  // self-controlled launches (constant-A path) keep u_n of the thread's cells in LDS slots as well: it is needed again in
+  // stages 4, 5 and by the error estimate, and after a mass balance applied on load the global copy is not u_n any more
+  constexpr bool UPL = SC && !AF;
+  __shared__ double sUp[UPL ? NR : 1][TNT];
   const int4 t4 = tilesF[blockIdx.x];
   const GDev g = P.gd[t4.x];
   const int lane = threadIdx.x & 63;
@@ -574,7 +582,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   }
   double dt;
   int cur, snap_slot = -1;  // snap_slot >= 0: store the snapshot of the stop the decided step reached
-  bool finished;
+  bool finished, mb_pend = false;
+  int mb_slot = 0;
   if (SC) {
     if (w == 0) {
       GState sn = A.gin[t4.x];
@@ -585,15 +594,21 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
         double sum = 0.0;
         for (int k = lane; k < nt; k += 64) sum += A.part_in[t0 + k];
         sum = __shfl(wave_sum(sum), 0, 64);
+        int mbp = sn.pad & 4;
         sc_decide(sn, g, A.C, sum, est, lane);
-        sn.pad = sn.at_stop ? 2 : 0;
+        if (sn.accepted) mbp = 0;                          // the accepted step replaced the buffer
+        if (sn.at_stop && sn.mb_now && g.has_mb) mbp = 4;  // ... and landed on a stop with a mass balance
+        sn.pad = (sn.at_stop ? 2 : 0) | mbp;
         newly_done = sn.done != 0;
+      } else if (!sn.done) {
+        sn.pad &= 4;
       }
       if (lane == 0) {
         s_state = sn;  // what this launch acts on
         if (t4.y == 0 && t4.z == 0) {  // the glacier's designated workgroup publishes the state for the next launch
           GState so = sn;
-          so.pad = sn.done ? 0 : 1;  // its snapshot (if any) is stored below, an attempt follows unless done
+          // its snapshot (if any) is stored below; an attempt follows unless done; a done glacier's MB is written back below
+          so.pad = sn.done ? 0 : (1 | (sn.pad & 4));
           A.gout[t4.x] = so;
           if (newly_done) atomicSub(A.C.n_active, 1);
           if (A.C.est_steps && est >= 0) A.C.est_steps[t4.x] = est;
@@ -605,6 +620,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     cur = s_state.cur;
     finished = s_state.done != 0;
     if (s_state.pad & 2) snap_slot = s_state.istop - 1;
+    mb_pend = (s_state.pad & 4) != 0;
+    mb_slot = s_state.mb_slot;
     if (finished && snap_slot < 0) return;
   } else {
     const GState* gs = P.gs + t4.x;
@@ -626,13 +643,45 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     u[m] = h; tmp[m] = h; E[m] = 0.0;
     nz = nz || (h != 0.0);
   }
+  if (UPL && mb_pend) {
+    // the buffer sits on a stop whose mass balance has not been applied to it (k_poststep's arithmetic, VJPs.jl:129-139):
+    // apply it to everything loaded; on the first launch after the stop keep the pre-MB state of the own cells
+    const double* __restrict__ mb0 = A.mb0 + g.off;
+    const double* __restrict__ Sr = A.Sref ? A.Sref + g.off : nullptr;
+    double* __restrict__ pm = A.premb + (long long)mb_slot * A.ntot + g.off;
+    nz = false;
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+      const int r = r0 + m, gj = gj0 + r;
+      if (inx && gj >= 0 && gj < g.ny) {
+        const unsigned id = (unsigned)(id0 + g.nx * m);
+        double h = u[m];
+        if (snap_slot >= 0 && r >= FH && r <= (NR * TNW) - 1 - FH && lane >= FH && lane < FH + FOX) stg32(pm, id, h);
+        double dmb;
+        double mb = mb_value(g, ldg32(mb0, id), Sr ? ldg32(Sr, id) : 0.0, h, bb[m], dmb);
+        const bool mask = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
+        if (!mask) mb = 0.0;
+        if (mask && h + mb < 0.0) mb = -h;
+        h += mb;
+        u[m] = h; tmp[m] = h;
+      }
+      nz = nz || (u[m] != 0.0);
+    }
+  }
+  if (UPL) {
+#pragma unroll
+    for (int m = 0; m < NR; ++m) sUp[UPL ? m : 0][threadIdx.x] = u[m];
+  }
   if (SC && snap_slot >= 0) {  // snapshot of the stop just reached: this workgroup's output cells of the accepted state
     double* __restrict__ sn = A.snaps + (long long)snap_slot * A.ntot + g.off;
     if (lane >= FH && lane < FH + FOX && inx) {
 #pragma unroll
       for (int m = 0; m < NR; ++m) {
         const int r = r0 + m, gj = gj0 + r;
-        if (r >= FH && r <= (NR * TNW) - 1 - FH && gj < g.ny) stg32(sn, (unsigned)(id0 + g.nx * m), u[m]);
+        if (r >= FH && r <= (NR * TNW) - 1 - FH && gj < g.ny) {
+          stg32(sn, (unsigned)(id0 + g.nx * m), u[m]);
+          if (finished && mb_pend) stg32(const_cast<double*>(src), (unsigned)(id0 + g.nx * m), u[m]);  // the final state carries its MB
+        }
       }
     }
     if (finished) return;
@@ -667,7 +716,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
       sA[AF ? m : 0][threadIdx.x] = ok ? ldg32(Afg, (unsigned)(gi + (g.nx - 1) * gj)) : 0.0;
     }
   }
-  strip_stages<AF, NR>(g, L, sA, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
+  strip_stages<AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
   // ---- output rows [FH, (NR * TNW)-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
   double upf[NR];
@@ -675,7 +724,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   for (int m = 0; m < NR; ++m) {  // all loads in flight before the first use
     const int r = r0 + m, gj = gj0 + r;
     const bool out = r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny;
-    upf[m] = ldg32(src, (unsigned)(out ? id0 + g.nx * m : 0));
+    upf[m] = UPL ? sUp[UPL ? m : 0][threadIdx.x] : ldg32(src, (unsigned)(out ? id0 + g.nx * m : 0));
   }
 #pragma unroll
   for (int m = 0; m < NR; ++m) {

@@ -606,7 +606,8 @@ def test_self_controlled_step_loop_matches_the_three_launch_loop(gpu, monkeypatc
     """ODINN_STEP_SC=1: every workgroup of the strip kernel decides the previous attempt of its glacier itself (error
     norm, PID controller, stop handling) and stores the snapshots -- no k_controller / k_poststep launches.  Same
     kernel arithmetic and the same decisions as the three-launch loop: same step counts, same snapshots, on a ragged
-    batch with rejections and many stops."""
+    batch with rejections, many stops and a mass balance on half of the glaciers (applied on load by the
+    self-controlled kernel, in place by k_poststep)."""
     monkeypatch.setenv("ODINN_FUSED_TILES", "t")
     shapes = [(130, 97), (96, 80), (201, 103), (54, 46)]
     ts = [2010.0 + 0.05 * j for j in range(9)]
@@ -617,10 +618,13 @@ def test_self_controlled_step_loop_matches_the_three_launch_loop(gpu, monkeypatc
         for k, (nx, ny) in enumerate(shapes):
             H0, B = O.synthetic_valley(nx, ny, 50.0)
             b.set_fields(k, H0, B)
-        st = b.solve(ts, reltol=1e-6, dt0=0.004)  # a large first step: rejections
-        out[sc] = ([[b.snapshot(k, j) for j in range(len(ts))] for k in range(4)],
+            if k % 2 == 0:  # a mass balance with elevation feedback on two of the four glaciers, applied at every stop
+                mb = _mb(H0, B)
+                b.set_mass_balance(k, mb.mb0, mb.dmb_dS, mb.S_ref, mb.mb_max)
+        st = b.solve(ts, mb_times=ts[1:], reltol=1e-6, dt0=0.004)  # a large first step: rejections
+        out[sc] = ([[b.snapshot(k, j) for j in range(len(ts))] + [b.H(k)] for k in range(4)],
                    [(s.naccept, s.nreject, s.t_final, s.dt_last) for s in st])
-        st2 = b.solve(ts[:3], fixed_dt=0.0025)
+        st2 = b.solve(ts[:3], mb_times=ts[1:3], fixed_dt=0.0025)
         out[sc] += ([b.snapshot(k, 2) for k in range(4)], [(s.naccept, s.nreject) for s in st2])
         b.close()
     a, f = out["0"], out["1"]
@@ -629,6 +633,6 @@ def test_self_controlled_step_loop_matches_the_three_launch_loop(gpu, monkeypatc
     # With today's compiler the two kernel instantiations generate the same arithmetic and everything below is
     # bit-identical (np.array_equal holds); the assertions allow what a different FMA contraction could change.
     for k in range(4):
-        for j in range(len(ts)):
+        for j in range(len(ts) + 1):  # every snapshot and the final state (which carries the last mass balance)
             assert rel_l2(f[0][k][j], a[0][k][j]) < 1e-8 or not a[0][k][j].any(), (k, j)
         assert np.isfinite(a[2][k]).all() and rel_l2(f[2][k], a[2][k]) < 1e-13, k
