@@ -483,8 +483,9 @@ __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, con
 // the same decision from the same numbers, the one that owns tile (0,0) writes the new state to gout (the two
 // state arrays and the two partial arrays alternate between launches, so nobody reads what another workgroup of
 // the same launch writes).  If the decided step reached a stop, each workgroup stores the snapshot of its own
-// output cells from the accepted buffer before stepping on.  Glaciers with a mass balance keep the three-launch
-// path (the MB changes the state at a stop).
+// output cells from the accepted buffer before stepping on.  A mass balance at a stop is applied ON LOAD to every
+// launch that reads the flagged buffer (GState::pad bit 2) until a step is accepted; u_n then lives in per-thread
+// LDS slots because the global copy lacks the mass balance.
 // GState::pad in SC mode: bit 0 = an attempt awaits its decision, bit 1 = a snapshot awaits being stored, bit 2 = the
 // state buffer `cur` still lacks the mass balance of the stop it sits on (applied on load until a step is accepted)
 // Called by ALL lanes of wavefront 0 with identical arguments: the three pow() of the PID factor run in lanes 0..2 at
