@@ -562,9 +562,10 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   // gridded A: the thread's own nodes (rows r0-1 .. r0+NR-1 of its column) in private LDS slots -- read in each of the
   // five stages, fetched from global memory once (0 on nodes outside the dual grid: they only feed frozen cells)
   __shared__ double sA[AF ? NR + 1 : 1][TNT];
-  // self-controlled launches (constant-A path) keep u_n of the thread's cells in LDS slots as well: it is needed again in
-  // stages 4, 5 and by the error estimate, and after a mass balance applied on load the global copy is not u_n any more
-  constexpr bool UPL = SC && !AF;
+  // constant-A path: u_n of the thread's cells is kept in private LDS slots -- it is needed again in stages 4, 5 and by the
+  // error estimate (three L2 reads per cell otherwise: -2..3 % per step), and after a mass balance applied on load (SC) the
+  // global copy is not u_n any more.  With a gridded A the slots of A take that LDS.
+  constexpr bool UPL = !AF;
   __shared__ double sUp[UPL ? NR : 1][TNT];
   const int4 t4 = tilesF[blockIdx.x];
   const GDev g = P.gd[t4.x];
