@@ -137,6 +137,14 @@ struct odinn_batch {
     const char* e = std::getenv("ODINN_STEP_SC");
     return !e ? -1 : (e[0] == '1' ? 1 : 0);
   }
+  static int n_cus() {  // compute units of the current device (256 on MI355X)
+    static int n = 0;
+    if (!n) {
+      int dev = 0, v = 0;
+      n = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n;
+  }
   mutable int fused_env = -1;  // ODINN_FUSED_TILES, parsed once: 0 unset, 1 small, 2 large, 3 t (strip, 7 rows), 4 u (strip, 8 rows)
   int fused_override() const {
     if (fused_env < 0) {
@@ -155,12 +163,18 @@ struct odinn_batch {
     if (o == 2) return 0;
     if (o == 3) return lm() == 0 ? 2 : 0;
     if (o == 4) return lm() == 0 ? 3 : 0;
-    // 3 = strip kernel with 8 rows per thread (54 x 54 tiles: less halo work, but a longer sweep per workgroup):
-    // pays once the batch more than fills the 512 workgroup slots of the GPU (measured crossover: 400 tiles lose 8 %, 720 win 10 %)
-    // below ~100 strip tiles the 54 x 8 latency tiles win as a KERNEL, but the strip kernel can run the self-controlled
-    // step loop (no controller / post-step launches; needs no mass balance), which wins as a STEP (4 alpine glaciers:
-    // 0.64 -> 0.55 ms for 25 steps)
-    if (lm() == 0) return ntilesFu >= 704 ? 3 : ((ntilesFt >= 96 || sc_env() != 0) ? 2 : 1);
+    // 2 / 3 = strip kernel with 7 / 8 rows per thread (54 x 46 / 54 x 54 tiles).  The kernel is VALU-bound, so a launch
+    // lasts about (tiles on the busiest CU) x (rows per thread): 8 rows do less halo work per cell but quantise worse.
+    // That model reproduces the measured order on 11 batch shapes (1 x 1024^2: 7 rows win 8 %, 2 x 1024^2: 8 rows win
+    // 10 %, 8 x 512^2: 7 rows win 7 %, ties and everything large: 8 rows win 1..5 %).
+    // Below ~100 strip tiles the 54 x 8 latency tiles win as a KERNEL, but the strip kernel can run the self-controlled
+    // step loop (no controller / post-step launches), which wins as a STEP (4 alpine glaciers: 0.64 -> 0.55 ms for 25
+    // steps)
+    if (lm() == 0) {
+      if (ntilesFt < 96 && sc_env() == 0) return 1;
+      const long cu = n_cus();
+      return 8 * ((ntilesFu + cu - 1) / cu) <= 7 * ((ntilesFt + cu - 1) / cu) ? 3 : 2;
+    }
     return ntilesF <= 256 ? 1 : 0;
   }
   const int4* fused_tiles() const { const int k = fused_kind(); return k == 3 ? d_tilesFu : k == 2 ? d_tilesFt : k == 1 ? d_tilesFs : d_tilesF; }
