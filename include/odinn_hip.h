@@ -259,7 +259,9 @@ enum odinn_timed {
   ODINN_TIMED_FUSED_STEP_SKIP = 8,  /* fused step kernel with the ice-free-tile shortcut enabled */
   ODINN_TIMED_EULER_CFL = 9,        /* the CFL Euler step kernel alone (RHS + update + max D)  24 B/cell */
   ODINN_TIMED_ADJ_STAGE2 = 10,      /* stage 2 of the reverse ODE of the continuous adjoint   72 B/cell */
-  ODINN_TIMED_ADJ_FUSED_STEP = 11   /* a whole reverse RDPK3Sp35 step in one kernel (integer-power law) 40 B/cell */
+  ODINN_TIMED_ADJ_FUSED_STEP = 11,  /* a whole reverse RDPK3Sp35 step in one kernel (integer-power law) 40 B/cell */
+  ODINN_TIMED_LAW_FIELD = 12        /* hoisted LawA: A = NN_theta(T) on the dual grid, once per theta (Laws.jl:339-358);
+                                       NN_A_GRIDDED only                                      16 B/node */
 };
 /* runs `iters` back-to-back launches over ALL glaciers of the batch after `warmup`
  * untimed ones; *ms_total is the elapsed time of the timed launches. */

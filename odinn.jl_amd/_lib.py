@@ -16,7 +16,8 @@ LAW_CONST_A, LAW_NN_A_SCALAR, LAW_NN_A_GRIDDED, LAW_NN_Y, LAW_NN_U = range(5)
 ACT_IDENTITY, ACT_SOFTPLUS, ACT_SIGMOID, ACT_GELU, ACT_TANH, ACT_RELU = range(6)
 POST_NONE, POST_AFFINE, POST_EXPMAX, POST_SCALE = range(4)
 (TIMED_DHDT, TIMED_RK_STEP, TIMED_VJP_H, TIMED_VJP_THETA, TIMED_RK_STAGE2, TIMED_SOLVE_STEP, TIMED_FUSED_STEP,
- TIMED_SOLVE_STEP_STAGED, TIMED_FUSED_STEP_SKIP, TIMED_EULER_CFL, TIMED_ADJ_STAGE2, TIMED_ADJ_FUSED_STEP) = range(12)
+ TIMED_SOLVE_STEP_STAGED, TIMED_FUSED_STEP_SKIP, TIMED_EULER_CFL, TIMED_ADJ_STAGE2, TIMED_ADJ_FUSED_STEP,
+ TIMED_LAW_FIELD) = range(13)
 SCHEME_AUTO, SCHEME_STAGED, SCHEME_FUSED = 0, 1, 2
 LOSS_H, LOSS_V, LOSS_HV = 0, 1, 2
 VJP_DISCRETE, VJP_CONTINUOUS = 0, 1

@@ -2008,6 +2008,9 @@ static int timed_one(odinn_batch* b, int which, int it) {
       launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, std::getenv("ODINN_TIMED_ADJ_SKIP") ? 1 : 0, b->stream, P, FA);
       return ODINN_OK;
     }
+    case ODINN_TIMED_LAW_FIELD:
+      if (b->law_kind != ODINN_LAW_NN_A_GRIDDED) return fail(ODINN_ERR_STATE, "ODINN_TIMED_LAW_FIELD needs the NN_A_GRIDDED law");
+      return refresh_law_field(b);
     default: return fail(ODINN_ERR_ARG, "unknown timed kernel %d", which);
   }
 }

@@ -524,6 +524,21 @@ def test_strip_kernel_matches_the_per_stage_schedule(gpu, monkeypatch, shape, ti
     snaps, st, _ = O.forward(O.Glacier(H0, B, 50.0, 50.0, O.Phys()), law, O.SimConfig(tstops=ts, reltol=1e-8))
     assert rel_l2(b.snapshot(0, 2), snaps[2]) < 1e-6  # adaptive run, own step sequence: the north-star tolerance
     b.close()
+    # the strip kernel DIRECTLY against the oracle's integrator under a fixed dt (same step sequence on both sides):
+    # agreement to rounding, constant A and gridded A
+    ph = O.Phys()
+    for field in (False, True):
+        lawf = O.Law(kind=O.LAW_CONST_A, A=Af if field else 4e-17)
+        f = lambda H: O.sia2d_rhs(H, B, 50.0, 50.0, ph, lawf)
+        ref, sto, _ = O.solve(f, H0, ts[:2], fixed_dt=0.002)
+        b = gpu.GlacierBatch([shape], [50.0], A=[4e-17])
+        b.set_fields(0, H0, B)
+        if field:
+            b.set_A_field(0, Af)
+        stg = b.solve(ts[:2], fixed_dt=0.002, scheme=2)
+        assert stg[0].naccept == sto.naccept
+        assert rel_l2(b.snapshot(0, 1), ref[1]) < 1e-11, (shape, field)
+        b.close()
 
 
 def test_randomised_shapes_and_states(gpu):
@@ -636,3 +651,42 @@ def test_self_controlled_step_loop_matches_the_three_launch_loop(gpu, monkeypatc
         for j in range(len(ts) + 1):  # every snapshot and the final state (which carries the last mass balance)
             assert rel_l2(f[0][k][j], a[0][k][j]) < 1e-8 or not a[0][k][j].any(), (k, j)
         assert np.isfinite(a[2][k]).all() and rel_l2(f[2][k], a[2][k]) < 1e-13, k
+
+
+def test_largest_single_gpu_configuration_64x1024(gpu, monkeypatch):
+    """BASELINE configs[4] resident on ONE GPU (64 x 1024^2, the largest single-GPU configuration): size-independent
+    properties of the fused step on the full batch -- volume conservation per glacier (flux form, no mass balance, the
+    caps stay off the boundary ring) and batch-composition independence (a glacier stepped inside the batch of 64 equals,
+    bit for bit, the same glacier stepped alone with the same kernel form)."""
+    from bench import make_glacier
+
+    monkeypatch.setenv("ODINN_FUSED_TILES", "u")  # the 8-row strip kernel for both batch sizes
+    monkeypatch.setenv("ODINN_STEP_SC", "0")      # and the same three-launch loop
+    n, G = 1024, 64
+    rng = np.random.default_rng(5)
+    base = [make_glacier(n, k) for k in range(4)]
+    # 64 glaciers from 4 distinct fields x 16 scalings of the thickness (cheap to build, all different)
+    scal = [0.5 + 0.03 * (k // 4) for k in range(G)]
+    b = gpu.GlacierBatch([(n, n)] * G, [100.0] * G, A=[base[k % 4][2] for k in range(G)])
+    for k in range(G):
+        b.set_fields(k, base[k % 4][0] * scal[k], base[k % 4][1])
+    ts = [0.0, 0.001]
+    st = b.solve(ts, fixed_dt=0.00025)
+    assert all(s.naccept == 4 for s in st)
+    picks = [0, 37, 63]
+    got = {k: b.snapshot(k, 1) for k in picks}
+    vol_ok = []
+    for k in range(0, G, 7):
+        H1 = b.snapshot(k, 1) if k not in got else got[k]
+        V0 = (base[k % 4][0] * scal[k]).sum()
+        vol_ok.append(abs(H1.sum() - V0) <= 1e-12 * V0)
+        assert np.isfinite(H1).all() and H1.min() >= 0.0
+        assert np.all(H1[0, :] == 0) and np.all(H1[:, -1] == 0)
+    assert all(vol_ok)
+    b.close()
+    for k in picks:
+        b1 = gpu.GlacierBatch([(n, n)], [100.0], A=[base[k % 4][2]])
+        b1.set_fields(0, base[k % 4][0] * scal[k], base[k % 4][1])
+        b1.solve(ts, fixed_dt=0.00025)
+        assert np.array_equal(b1.snapshot(0, 1), got[k]), k
+        b1.close()

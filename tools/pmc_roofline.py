@@ -1,0 +1,52 @@
+"""Turn the counter_collection.csv files of tools/pmc_roofline.sh into profiles/r02/pmc_roofline.json."""
+import csv, sys, glob, collections, statistics, json, os
+
+root = sys.argv[1]
+
+
+def med(tag, pat):
+    """median per counter over the dispatches of the kernels whose name contains `pat`"""
+    agg = collections.defaultdict(list)
+    names = set()
+    for path in glob.glob(os.path.join(root, tag, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(path)):
+            if pat in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                names.add(r["Kernel_Name"].split("(")[0].replace("void ", ""))
+    return {c: statistics.median(v) for c, v in agg.items()}, sorted(names)
+
+
+cells8, cells32 = 8 * 1024 * 1024, 32 * 1024 * 1024
+tiles8 = 8 * 19 * 19  # 54 x 54 output tiles of the 8-row strip kernel on 8 x 1024^2
+out = {"workload_cells": cells8, "source": "tools/pmc_roofline.sh (rocprofv3 --pmc, one counter group per pass, kernel-trace only)",
+       "fetch_correction": "FETCH_SIZE x 2 (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md section HBM); sizes in KiB"}
+for law, key in (("nnA", "fused_step_nn_gridded"), ("const", "fused_step_constA")):
+    f, names = med(f"fused_{law}_f64", "k_rk_fused_strip")
+    bz, _ = med(f"fused_{law}_busy", "k_rk_fused_strip")
+    fe, _ = med(f"fused_{law}_fetch", "k_rk_fused_strip")
+    wr, _ = med(f"fused_{law}_write", "k_rk_fused_strip")
+    if not f:
+        continue
+    add, mul, fma, tr = (f.get("SQ_INSTS_VALU_" + k + "_F64", 0.0) for k in ("ADD", "MUL", "FMA", "TRANS"))
+    flops = 64.0 * (add + mul + 2.0 * fma + tr)
+    executed = tiles8 * 64 * 64 * 5
+    e = {"kernel": names, "wave_insts_add_f64": add, "wave_insts_mul_f64": mul, "wave_insts_fma_f64": fma, "wave_insts_trans_f64": tr,
+         "wave_insts_valu": f.get("SQ_INSTS_VALU"), "waves": f.get("SQ_WAVES"),
+         "flops_executed_per_launch": flops, "executed_cell_stages_per_launch": executed,
+         "flop_per_executed_cell_stage": flops / executed, "useful_cell_stages_per_launch": 5 * cells8,
+         "halo_redundancy": executed / (5.0 * cells8)}
+    if bz:
+        e["valu_busy_frac"] = bz.get("SQ_ACTIVE_INST_VALU", 0) * 4 / max(bz.get("SQ_BUSY_CYCLES", 1), 1)
+        e["sq_raw"] = bz
+    if fe and wr:
+        e["hbm_bytes_per_launch"] = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0
+        e["hbm_bytes_per_cell"] = e["hbm_bytes_per_launch"] / cells8
+    out[key] = e
+for tag, key, pat, bpc in (("dhdt32_nnA", "dhdt_nn_gridded_32", "k_dhdt", 32.0), ("stage32", "rk_stage2_32", "k_rk_stage", 56.0)):
+    fe, names = med(tag + "_fetch", pat)
+    wr, _ = med(tag + "_write", pat)
+    if fe and wr:
+        by = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0
+        out[key] = {"kernel": names, "cells": cells32, "hbm_bytes_per_launch": by, "hbm_bytes_per_cell": by / cells32,
+                    "algorithmic_bytes_per_cell": bpc, "ratio": by / (bpc * cells32)}
+print(json.dumps(out, indent=1))
