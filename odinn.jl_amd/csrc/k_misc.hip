@@ -29,8 +29,18 @@ void launch_mb_apply(int nblk, hipStream_t st, Pools P, const double* H, const d
                      double* Hn, double* MBout, int base) {
   hipLaunchKernelGGL(k_mb_apply, dim3(nblk), dim3(NT), 0, st, P, H, mb0, Sref, Hn, MBout, base);
 }
+template <class AR>
+static bool law_is(const LawDev& L) {
+  if (L.n_layers != AR::NL) return false;
+  for (int l = 0; l <= AR::NL; ++l) if (L.widths[l] != AR::W[l]) return false;
+  for (int l = 0; l < AR::NL; ++l) if (L.acts[l] != AR::A[l]) return false;
+  return true;
+}
 void launch_law_field(hipStream_t st, LawDev L, const double* T, double* Aout, long long n) {
-  hipLaunchKernelGGL(k_law_field, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, L, T, Aout, n);
+  const dim3 grid((unsigned)((n + NT - 1) / NT));
+  if (law_is<Arch16A>(L)) hipLaunchKernelGGL(k_law_field_fixed<Arch16A>, grid, dim3(NT), 0, st, L, T, Aout, n);
+  else if (law_is<ArchDefA>(L)) hipLaunchKernelGGL(k_law_field_fixed<ArchDefA>, grid, dim3(NT), 0, st, L, T, Aout, n);
+  else hipLaunchKernelGGL(k_law_field, grid, dim3(NT), 0, st, L, T, Aout, n);
 }
 void launch_law_field_grad(int nblk, hipStream_t st, LawDev L, const double* T, const double* G, long long n,
                            double* gscratch, double* part_theta) {

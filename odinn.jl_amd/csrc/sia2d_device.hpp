@@ -1881,6 +1881,16 @@ __global__ __launch_bounds__(NT) void k_law_field(LawDev L, const double* __rest
   const long long i = (long long)blockIdx.x * NT + threadIdx.x;
   if (i < n) Aout[i] = mlp_eval_any(L, T[i], 0.0);
 }
+// the same with a compile-time one-input architecture (activations in registers, no run-time width predicates):
+// the default A(T) net 1-3-10-3-1 (ML_utils.jl:31-36) and the "2 layers x 16 units" net of BASELINE configs[2]
+struct ArchDefA { static constexpr int NL = 4, MAXW = 10; static constexpr int W[5] = {1, 3, 10, 3, 1}; static constexpr int A[4] = {1, 1, 1, 2}; };
+struct Arch16A  { static constexpr int NL = 3, MAXW = 16; static constexpr int W[4] = {1, 16, 16, 1};   static constexpr int A[3] = {1, 1, 2}; };
+template <class AR>
+__global__ __launch_bounds__(NT) void k_law_field_fixed(LawDev L, const double* __restrict__ T, double* __restrict__ Aout,
+                                                        long long n) {
+  const long long i = (long long)blockIdx.x * NT + threadIdx.x;
+  if (i < n) Aout[i] = mlp_eval_fixed<AR>(L, T[i], 0.0);
+}
 
 // theta-gradient of the hoisted gridded law: part_theta[block][k] = sum_i G[i]*dA/dtheta_k(T[i])
 __global__ __launch_bounds__(NT) void k_law_field_grad(LawDev L, const double* __restrict__ T,

@@ -368,6 +368,7 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   constexpr int rd = (S - 1) & 1, wr = S & 1;  // stage S reads the edge rows from buffer rd, publishes into wr
   const int r0 = NR * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
+  const double wdx = dtl * g.hinv_dx2, wdy = dtl * g.hinv_dy2;
   constexpr int s = S - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
   // D on node (c, r) = north-east corner of cell (c, r), from the {Hc,S} of cells (c,r) (c+1,r) (c,r+1) (c+1,r+1).
@@ -377,16 +378,16 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   // A Gam Hbar^5 = (A Gam / 1024) (4 Hbar)^5 bit for bit (powers of two commute with rounding).
   // The bottom edge of a node's cell quartet is the top edge of the previous row's: its x-difference of S and
   // its pair sum of Hc are carried up the sweep (dxb, hpb) instead of being recomputed.
-  const double Gq = g.Gam * (1.0 / 1024.0);
+  // |grad S|^2 = (a / 2dx)^2 + (b / 2dy)^2 = (1 / 2dx)^2 (a^2 + (dx/dy)^2 b^2): the factor (1 / 2dx)^2 joins the law
+  // constant (folded into the thread's A slots for a gridded A), one multiplication less per node than scaling a and b
+  const double Gq = g.Gam * (1.0 / 1024.0) * (g.hinv_dx * g.hinv_dx), ryx = (g.hinv_dy * g.hinv_dy) / (g.hinv_dx * g.hinv_dx);
+  const double AGq = g.A * Gq;
   auto node = [&](int slot, double dxb, double hpb, double dxt, double hpt, double dyw, double dye) {
-    const double gx = (dxb + dxt) * g.hinv_dx;
-    const double gy = (dyw + dye) * g.hinv_dy;
+    const double a = dxb + dxt, b = dyw + dye;
     const double H4s = hpb + hpt;  // 4 Hbar
-    const double gS2 = gx * gx + gy * gy;
-    double An = g.A;
-    if (AF) An = sA[slot][threadIdx.x];  // the thread's own nodes' A, copied once per launch (see the kernel)
+    const double gS2 = fma(a, a, (ryx * b) * b);
     const double H2 = H4s * H4s, H4 = H2 * H2;
-    return (An * Gq) * (H4 * H4s) * gS2;
+    return (AF ? sA[slot][threadIdx.x] : AGq) * (H4 * H4s) * gS2;  // sA: A Gam / (1024 (2dx)^2) of the thread's own nodes
   };
   // Flux form of cell_div_vals<true>: the flux through the face between two cells is the same number seen
   // from either side (same D sum, same clamped slope -- ties included), so a thread computes only its EAST and
@@ -422,12 +423,12 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
     const double F_e = face(D_s, D_c, dx_c, e_c.x, hs_c.x);
     const double F_n = face(dpp_from_west(D_c), D_c, dyw, hs_n.x, hs_c.x);
     const double F_w = dpp_from_west(F_e);
-    const double k = fma(g.hinv_dx2, F_e - F_w, g.hinv_dy2 * (F_n - F_s));
-    // cells that must not move (boundary ring, outside the glacier): dtl is 0 on their lanes and the weights of
+    // dt k with dt folded into the two divergence weights (wdx = dt / 2dx^2, wdy = dt / 2dy^2; 0 on frozen lanes)
+    const double dtk = fma(wdx, F_e - F_w, wdy * (F_n - F_s));
+    // cells that must not move (boundary ring, outside the glacier): the weights are 0 on their lanes and the weights of
     // dt k are 0 on their rows (wave-uniform, scalar selects) -- fma(0, dt k, x) = x = fma(bt, 0, x) exactly
     const bool rowint = gj >= 1 && gj <= g.ny - 2;
     const double btm = rowint ? bt : 0.0, bhm = rowint ? bh : 0.0;
-    const double dtk = dtl * k;
     const double uo = u[m];
     double un;
     if (S == 1) {
@@ -582,6 +583,20 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     const int gj = gj0 + r0 + m;
     bb[m] = (inx && gj >= 0 && gj < g.ny) ? ldg32(Bg, (unsigned)(id0 + g.nx * m)) : 0.0;
   }
+  // gridded A: like B it does not depend on the state -- its loads are issued here, ahead of the (dependent) state
+  // loads, and parked in the LDS slots once u is on its way (they used to start after the first barrier: PMC showed
+  // the gridded-A kernel parked 44 % of its wave time against 26 % for constant A)
+  [[maybe_unused]] double aa[AF ? NR + 1 : 1];
+  if (AF) {
+    const double* __restrict__ Afg = P.Afield + g.offd;
+    const bool nodex = gi >= 0 && gi <= g.nx - 2;
+#pragma unroll
+    for (int m = 0; m <= NR; ++m) {
+      const int gj = gj0 + r0 - 1 + m;
+      const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+      aa[AF ? m : 0] = ok ? ldg32(Afg, (unsigned)(gi + (g.nx - 1) * gj)) : 0.0;
+    }
+  }
   double dt;
   int cur, snap_slot = -1;  // snap_slot >= 0: store the snapshot of the stop the decided step reached
   bool finished, mb_pend = false;
@@ -709,14 +724,9 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   }
   const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
   if (AF) {
-    const double* __restrict__ Afg = P.Afield + g.offd;
-    const bool nodex = gi >= 0 && gi <= g.nx - 2;
+    const double Gq = g.Gam * (1.0 / 1024.0) * (g.hinv_dx * g.hinv_dx);  // as in strip_stage
 #pragma unroll
-    for (int m = 0; m <= NR; ++m) {
-      const int gj = gj0 + r0 - 1 + m;
-      const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
-      sA[AF ? m : 0][threadIdx.x] = ok ? ldg32(Afg, (unsigned)(gi + (g.nx - 1) * gj)) : 0.0;
-    }
+    for (int m = 0; m <= NR; ++m) sA[AF ? m : 0][threadIdx.x] = aa[AF ? m : 0] * Gq;
   }
   strip_stages<AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
   // ---- output rows [FH, (NR * TNW)-1-FH]: u' from the registers, embedded error partial -----------------------
