@@ -245,6 +245,30 @@ int odinn_tikhonov(odinn_batch* b, int nx, int ny, double dx, double dy, const d
 int odinn_get_grad_parts(odinn_batch* b, double* loss_per_glacier, double* G_per_glacier);
 int odinn_get_grad_field(odinn_batch* b, int g, double* dLdA_dual);
 
+/* ---- multi-GPU: glaciers shard across ranks (one process per GPU), the only exchange of the path is the sum of
+ * [loss, dtheta...] over ranks -- SIA2D_grad! (src/inverse/SIA2D/gradient.jl:6-31: pmap over glacier batches,
+ * sum(losses), aggregate_grad of Model.jl:208-224).  The communicator is RCCL (ncclAllReduce over xGMI); the caller
+ * distributes the 128-byte unique id of rank 0 by whatever means it has (Julia: Distributed/MPI; Python: torch.distributed
+ * or a file) -- exactly NCCL's bootstrap contract. */
+typedef struct odinn_comm odinn_comm;
+#define ODINN_COMM_ID_BYTES 128
+int odinn_comm_get_unique_id(void* id_out /* ODINN_COMM_ID_BYTES */);
+/* collective over all ranks: binds the calling process's rank to `device` */
+int odinn_comm_init_rank(int device, int nranks, int rank, const void* id, odinn_comm** out);
+int odinn_comm_destroy(odinn_comm* c);
+int odinn_comm_rank(const odinn_comm* c, int* rank, int* nranks);
+/* in-place sum over ranks of n doubles: host buffer (staged through the communicator's device buffer) ... */
+int odinn_comm_allreduce_sum(odinn_comm* c, double* inout, int n);
+/* ... or device buffer, enqueued on `hip_stream` (a hipStream_t; NULL = the communicator's own stream), no host copy */
+int odinn_comm_allreduce_sum_dev(odinn_comm* c, double* inout_dev, int n, void* hip_stream);
+/* SIA2D_grad!: odinn_loss_grad (adjoint = 0, DiscreteAdjoint) or odinn_loss_grad_continuous (adjoint = 1, adjoint_opts
+ * may be NULL) on this rank's batch, then ONE ncclAllReduce(sum, ncclDouble, 1 + P) of [loss, dtheta] on the batch's
+ * stream; every rank returns the global loss and gradient.  comm == NULL: no reduction (single rank). */
+int odinn_batch_loss_grad(odinn_batch* b, odinn_comm* comm, int adjoint, const double* theta, int P, int n_stops,
+                          const double* tstops, int n_mb, const double* mb_times, const odinn_solver_opts* opts,
+                          const odinn_adjoint_opts* adjoint_opts, double* loss, double* dtheta,
+                          odinn_solve_stats* stats, odinn_solve_stats* stats_rev);
+
 /* ---- measurement (HIP events on the batch's own stream, state already in HBM) -------- */
 enum odinn_timed {
   ODINN_TIMED_DHDT = 0,     /* RHS only: read H,B write dH                    24 B/cell     */

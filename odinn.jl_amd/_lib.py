@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODINN_LIB") or os.path.join(_HERE, "csrc", "libodinn_hip.so")  # ODINN_LIB: A/B builds
 
 MAX_LAYERS = 8
+COMM_ID_BYTES = 128
 MAX_WIDTH = 32
 
 LAW_CONST_A, LAW_NN_A_SCALAR, LAW_NN_A_GRIDDED, LAW_NN_Y, LAW_NN_U = range(5)
@@ -104,6 +105,14 @@ SIGNATURES = {
     "odinn_get_lambda0": (C.c_int, [_vp, C.c_int, _dp]),
     "odinn_get_grad_parts": (C.c_int, [_vp, _dp, _dp]),
     "odinn_get_grad_field": (C.c_int, [_vp, C.c_int, _dp]),
+    "odinn_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "odinn_comm_init_rank": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_vp)]),
+    "odinn_comm_destroy": (C.c_int, [_vp]),
+    "odinn_comm_rank": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "odinn_comm_allreduce_sum": (C.c_int, [_vp, _dp, C.c_int]),
+    "odinn_comm_allreduce_sum_dev": (C.c_int, [_vp, C.c_void_p, C.c_int, C.c_void_p]),
+    "odinn_batch_loss_grad": (C.c_int, [_vp, _vp, C.c_int, _dp, C.c_int, C.c_int, _dp, C.c_int, _dp, C.POINTER(SolverOpts),
+                                        C.POINTER(AdjointOpts), _dp, _dp, C.POINTER(SolveStats), C.POINTER(SolveStats)]),
     "odinn_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "odinn_bench_prepare": (C.c_int, [_vp]),
     "odinn_bench_enqueue": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),

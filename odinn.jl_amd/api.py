@@ -586,7 +586,23 @@ def shard_glaciers(cells: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(s) for s in out]
 
 
-_DIST = {"init": False, "rank": 0, "world": 1, "device": None}
+_DIST = {"init": False, "rank": 0, "world": 1, "device": None, "comm": None}
+
+
+def attach_rccl_comm(local: int):
+    """Create the library's own RCCL communicator (odinn_comm_init_rank) for this rank: rank 0 draws the unique id, the
+    already-initialised torch.distributed group carries its 128 bytes to the other ranks (NCCL's bootstrap contract;
+    a Julia host would use Distributed or MPI for the same step).  From then on the all-reduce of [loss, dtheta] runs
+    inside libodinn_hip (ncclAllReduce on device memory), not through torch."""
+    import torch.distributed as dist
+
+    from .batch import Comm
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    _DIST["comm"] = Comm(local, world, rank, box[0])
+    return _DIST["comm"]
 
 
 def init_distributed(backend: Optional[str] = None):
@@ -596,7 +612,10 @@ def init_distributed(backend: Optional[str] = None):
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # ODINN_DEVICE / ODINN_DIST_BACKEND: run several ranks on ONE device with gloo collectives (tests on a 1-GPU box)
+    local = int(os.environ.get("ODINN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if backend is None:
+        backend = os.environ.get("ODINN_DIST_BACKEND")
     if world > 1 and not _DIST["init"]:
         import torch
         import torch.distributed as dist
@@ -608,6 +627,8 @@ def init_distributed(backend: Optional[str] = None):
         if not dist.is_initialized():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
         _DIST.update(init=True, device=(f"cuda:{local}" if backend == "nccl" else "cpu"))
+        if backend == "nccl" and _DIST.get("comm") is None:
+            attach_rccl_comm(local)
     _DIST.update(rank=rank, world=world, local=local)
     return rank, world, local
 
@@ -617,6 +638,9 @@ def allreduce_loss_grad(loss: float, dtheta: np.ndarray):
     (SIA2D_grad!: sum(losses), aggregate∇θ -- gradient.jl:14,25; Model.jl:208-224)."""
     if _DIST["world"] <= 1 or not _DIST["init"]:
         return loss, dtheta
+    if _DIST.get("comm") is not None:  # RCCL through the C ABI (one process per GPU)
+        out = _DIST["comm"].allreduce_sum(np.concatenate([[loss], dtheta]))
+        return float(out[0]), out[1:].copy()
     import torch
     import torch.distributed as dist
 

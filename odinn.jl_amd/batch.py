@@ -85,6 +85,42 @@ class SolveStats:
     dt_last: float
 
 
+class Comm:
+    """RCCL communicator behind the C ABI (odinn_comm_*): one rank per GPU, the single collective of the path is the
+    sum of [loss, dtheta] over ranks (SIA2D_grad!, gradient.jl:6-31)."""
+
+    ID_BYTES = L.COMM_ID_BYTES
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(L.COMM_ID_BYTES)
+        L.check(L.lib().odinn_comm_get_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, device: int, nranks: int, rank: int, uid: bytes):
+        if len(uid) != L.COMM_ID_BYTES:
+            raise ValueError(f"unique id must be {L.COMM_ID_BYTES} bytes")
+        self._h = C.c_void_p()
+        self.nranks, self.rank, self.device = nranks, rank, device
+        L.check(L.lib().odinn_comm_init_rank(device, nranks, rank, C.c_char_p(uid), C.byref(self._h)))
+
+    def allreduce_sum(self, a: np.ndarray) -> np.ndarray:
+        buf = np.ascontiguousarray(a, dtype=np.float64).copy()
+        L.check(L.lib().odinn_comm_allreduce_sum(self._h, _p(buf), buf.size))
+        return buf
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            L.lib().odinn_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GlacierBatch:
     """G glaciers on one device.  ``shapes[g] = (nx, ny)``."""
 
@@ -323,6 +359,27 @@ class GlacierBatch:
         self.tstops = ts
         self.last_stats = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
         self.last_stats_rev = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in sr]
+        return float(loss.value), dth
+
+    def batch_loss_grad(self, comm: Optional["Comm"], tstops, theta=None, mb_times=(), continuous=False, adj_reltol=1e-8,
+                        adj_abstol=1e-8, adj_dtmax=1.0 / 12.0, n_quadrature=200, adj_maxiters=10 ** 6, **opts):
+        """odinn_batch_loss_grad == SIA2D_grad!: this rank's (loss, dtheta) summed over all ranks by ONE RCCL all-reduce
+        inside the library (comm = None: single rank)."""
+        ts = np.ascontiguousarray(tstops, dtype=np.float64)
+        mb = np.ascontiguousarray(mb_times, dtype=np.float64)
+        o = self._opts(**opts)
+        ao = L.AdjointOpts(adj_reltol, adj_abstol, adj_dtmax, int(n_quadrature), 0, int(adj_maxiters))
+        P = 1 if self.law_kind == L.LAW_CONST_A else self.P
+        th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+        loss = C.c_double(0.0)
+        dth = np.zeros(P)
+        st = (L.SolveStats * self.G)()
+        sr = (L.SolveStats * self.G)()
+        L.check(L.lib().odinn_batch_loss_grad(
+            self._h, comm._h if comm is not None else None, 1 if continuous else 0, _p(th) if th is not None else None, P,
+            ts.size, _p(ts), mb.size, _p(mb) if mb.size else None, C.byref(o), C.byref(ao), C.byref(loss), _p(dth), st, sr))
+        self.tstops = ts
+        self.last_stats = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
         return float(loss.value), dth
 
     def set_vjp_method(self, method=L.VJP_DISCRETE):

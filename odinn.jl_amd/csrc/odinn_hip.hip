@@ -5,6 +5,8 @@
 #include "launch.hpp"
 #include "sia2d_velocity.hpp"
 
+#include <rccl/rccl.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -1023,6 +1025,14 @@ int odinn_set_A(odinn_batch* b, int g, double A) {
   CHK(check_g(b, g));
   b->descs[g].A = A;
   b->gd_dirty = true;
+  if (b->has_Afield_const) {
+    // once any glacier of the batch carries a gridded A every kernel reads the field: a scalar A replaces this
+    // glacier's slice of it (it used to be ignored silently)
+    CHK(use_dev(b));
+    const GDev& r = b->gd[g];
+    std::vector<double> a((size_t)(r.nx - 1) * (r.ny - 1), A);
+    CHK(up_field(b, g, b->d_Afield, a.data(), true));
+  }
   return ODINN_OK;
 }
 
@@ -1099,13 +1109,17 @@ int odinn_set_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, c
   if (n_ref > b->nref_alloc) {
     // grow, keeping what other glaciers already uploaded
     double* nh = nullptr; unsigned char* nm = nullptr;
-    CHK(dalloc(&nh, (size_t)n_ref * b->ntot));
-    CHK(dalloc(&nm, (size_t)n_ref * b->ntot));
-    if (b->d_Href) {
-      HIPCHK(hipMemcpy(nh, b->d_Href, (size_t)b->nref_alloc * b->ntot * sizeof(double), hipMemcpyDeviceToDevice));
-      HIPCHK(hipMemcpy(nm, b->d_mask, (size_t)b->nref_alloc * b->ntot, hipMemcpyDeviceToDevice));
-      HIPCHK(hipStreamSynchronize(nullptr));  // D2D copies on the NULL stream do not block the host
-    }
+    auto grow = [&]() -> int {
+      CHK(dalloc(&nh, (size_t)n_ref * b->ntot));
+      CHK(dalloc(&nm, (size_t)n_ref * b->ntot));
+      if (b->d_Href) {
+        HIPCHK(hipMemcpy(nh, b->d_Href, (size_t)b->nref_alloc * b->ntot * sizeof(double), hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(nm, b->d_mask, (size_t)b->nref_alloc * b->ntot, hipMemcpyDeviceToDevice));
+        HIPCHK(hipStreamSynchronize(nullptr));  // D2D copies on the NULL stream do not block the host
+      }
+      return ODINN_OK;
+    };
+    if (const int rc = grow()) { dfree(nh); dfree(nm); return rc; }  // nothing leaks when an allocation or copy fails
     dfree(b->d_Href); dfree(b->d_mask);
     b->d_Href = nh; b->d_mask = nm; b->nref_alloc = n_ref;
   }
@@ -1272,14 +1286,18 @@ int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double*
   if (n_ref > b->nvref_alloc) {
     double *na = nullptr, *nx_ = nullptr, *ny_ = nullptr;
     const size_t nb = (size_t)n_ref * b->ntot;
-    CHK(dalloc(&na, nb)); CHK(dalloc(&nx_, nb)); CHK(dalloc(&ny_, nb));
-    if (b->d_Vabs) {
-      const size_t ob = (size_t)b->nvref_alloc * b->ntot * sizeof(double);
-      HIPCHK(hipMemcpy(na, b->d_Vabs, ob, hipMemcpyDeviceToDevice));
-      HIPCHK(hipMemcpy(nx_, b->d_Vxr, ob, hipMemcpyDeviceToDevice));
-      HIPCHK(hipMemcpy(ny_, b->d_Vyr, ob, hipMemcpyDeviceToDevice));
-      HIPCHK(hipStreamSynchronize(nullptr));  // D2D copies on the NULL stream do not block the host
-    }
+    auto grow = [&]() -> int {
+      CHK(dalloc(&na, nb)); CHK(dalloc(&nx_, nb)); CHK(dalloc(&ny_, nb));
+      if (b->d_Vabs) {
+        const size_t ob = (size_t)b->nvref_alloc * b->ntot * sizeof(double);
+        HIPCHK(hipMemcpy(na, b->d_Vabs, ob, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(nx_, b->d_Vxr, ob, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(ny_, b->d_Vyr, ob, hipMemcpyDeviceToDevice));
+        HIPCHK(hipStreamSynchronize(nullptr));  // D2D copies on the NULL stream do not block the host
+      }
+      return ODINN_OK;
+    };
+    if (const int rc = grow()) { dfree(na); dfree(nx_); dfree(ny_); return rc; }
     dfree(b->d_Vabs); dfree(b->d_Vxr); dfree(b->d_Vyr);
     b->d_Vabs = na; b->d_Vxr = nx_; b->d_Vyr = ny_; b->nvref_alloc = n_ref;
   }
@@ -1919,6 +1937,119 @@ int odinn_get_grad_field(odinn_batch* b, int g, double* dLdA_dual) {
 int odinn_get_lambda0(odinn_batch* b, int g, double* lam0) {
   CHK(check_g(b, g)); CHK(use_dev(b));
   return down_field(b, g, b->d_lam[0], lam0);
+}
+
+// ---- multi-GPU: RCCL communicator behind the C ABI (SIA2D_grad!, gradient.jl:6-31) ----------------------------
+}  // extern "C"
+struct odinn_comm {
+  ncclComm_t comm = nullptr;
+  int device = 0, nranks = 1, rank = 0;
+  hipStream_t stream = nullptr;
+  double* d_buf = nullptr;
+  size_t cap = 0;
+};
+#define NCCLCHK(x)                                                                                         \
+  do {                                                                                                     \
+    ncclResult_t r_ = (x);                                                                                 \
+    if (r_ != ncclSuccess) return fail(ODINN_ERR_HIP, "%s failed: %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); \
+  } while (0)
+static int comm_buf(odinn_comm* c, size_t n) {
+  if (n > c->cap) {
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    c->d_buf = nullptr;
+    HIPCHK(hipMalloc((void**)&c->d_buf, n * sizeof(double)));
+    c->cap = n;
+  }
+  return ODINN_OK;
+}
+extern "C" {
+
+int odinn_comm_get_unique_id(void* id_out) {
+  static_assert(sizeof(ncclUniqueId) == ODINN_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  if (!id_out) return fail(ODINN_ERR_ARG, "null id");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  std::memcpy(id_out, &id, sizeof id);
+  return ODINN_OK;
+}
+
+int odinn_comm_init_rank(int device, int nranks, int rank, const void* id, odinn_comm** out) {
+  if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(ODINN_ERR_ARG, "bad communicator arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ODINN_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(ODINN_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+  odinn_comm* c = new odinn_comm();
+  c->device = device; c->nranks = nranks; c->rank = rank;
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof uid);
+  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, uid, rank);
+  if (r != ncclSuccess) { delete c; return fail(ODINN_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r)); }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { ncclCommDestroy(c->comm); delete c; return fail(ODINN_ERR_HIP, "stream creation failed"); }
+  *out = c;
+  return ODINN_OK;
+}
+
+int odinn_comm_destroy(odinn_comm* c) {
+  if (!c) return ODINN_OK;
+  (void)hipSetDevice(c->device);
+  if (c->comm) ncclCommDestroy(c->comm);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->d_buf) (void)hipFree(c->d_buf);
+  delete c;
+  return ODINN_OK;
+}
+
+int odinn_comm_rank(const odinn_comm* c, int* rank, int* nranks) {
+  if (!c) return fail(ODINN_ERR_ARG, "null communicator");
+  if (rank) *rank = c->rank;
+  if (nranks) *nranks = c->nranks;
+  return ODINN_OK;
+}
+
+int odinn_comm_allreduce_sum_dev(odinn_comm* c, double* inout_dev, int n, void* hip_stream) {
+  if (!c || !inout_dev || n < 0) return fail(ODINN_ERR_ARG, "bad all-reduce arguments");
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  NCCLCHK(ncclAllReduce(inout_dev, inout_dev, (size_t)n, ncclDouble, ncclSum, c->comm, st));
+  return ODINN_OK;
+}
+
+static int comm_allreduce_host(odinn_comm* c, double* inout, int n, hipStream_t st) {
+  CHK(comm_buf(c, (size_t)n));
+  HIPCHK(hipMemcpyAsync(c->d_buf, inout, sizeof(double) * n, hipMemcpyHostToDevice, st));
+  NCCLCHK(ncclAllReduce(c->d_buf, c->d_buf, (size_t)n, ncclDouble, ncclSum, c->comm, st));
+  HIPCHK(hipMemcpyAsync(inout, c->d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return ODINN_OK;
+}
+
+int odinn_comm_allreduce_sum(odinn_comm* c, double* inout, int n) {
+  if (!c || !inout || n < 0) return fail(ODINN_ERR_ARG, "bad all-reduce arguments");
+  HIPCHK(hipSetDevice(c->device));
+  return comm_allreduce_host(c, inout, n, c->stream);
+}
+
+int odinn_batch_loss_grad(odinn_batch* b, odinn_comm* comm, int adjoint, const double* theta, int P, int n_stops,
+                          const double* tstops, int n_mb, const double* mb_times, const odinn_solver_opts* opts,
+                          const odinn_adjoint_opts* adjoint_opts, double* loss, double* dtheta,
+                          odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
+  if (!b || !loss || !dtheta || P < 0) return fail(ODINN_ERR_ARG, "null argument");
+  if (comm && comm->device != b->device) return fail(ODINN_ERR_ARG, "communicator is bound to device %d, batch to device %d", comm->device, b->device);
+  if (adjoint == 0)
+    CHK(odinn_loss_grad(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, loss, dtheta, stats));
+  else if (adjoint == 1)
+    CHK(odinn_loss_grad_continuous(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, adjoint_opts, loss, dtheta, stats, stats_rev));
+  else
+    return fail(ODINN_ERR_ARG, "adjoint must be 0 (DiscreteAdjoint) or 1 (ContinuousAdjoint)");
+  if (!comm || comm->nranks == 1) return ODINN_OK;
+  std::vector<double> buf(1 + (size_t)P);
+  buf[0] = *loss;
+  for (int q = 0; q < P; ++q) buf[1 + q] = dtheta[q];
+  CHK(comm_allreduce_host(comm, buf.data(), 1 + P, b->stream));  // one ncclAllReduce(sum, ncclDouble, 1 + P) on the batch's stream
+  *loss = buf[0];
+  for (int q = 0; q < P; ++q) dtheta[q] = buf[1 + q];
+  return ODINN_OK;
 }
 
 // ---- measurement --------------------------------------------------------------------------

@@ -159,3 +159,20 @@ def test_ice_free_glacier_and_empty_reference(gpu):
     L, g = b.loss_grad(ts, reltol=1e-8)
     assert L == 0.0 and np.all(g == 0.0)
     b.close()
+
+
+def test_scalar_A_after_a_gridded_A_is_not_ignored(gpu):
+    """Once any glacier of a batch carries a gridded A all kernels read the A field; a later odinn_set_A must replace
+    that glacier's slice of the field (it used to be ignored silently)."""
+    H0, B = O.synthetic_alpine(48, 40, hmax=160.0, slope=0.1)
+    b = gpu.GlacierBatch([(48, 40), (48, 40)], [50.0, 50.0], A=[2e-17, 2e-17])
+    for k in range(2):
+        b.set_fields(k, H0, B)
+    b.set_A_field(0, np.full((47, 39), 5e-17, order="F"))
+    b.set_A(1, 3e-17)
+    b.set_A(0, 4e-17)
+    ph = O.Phys()
+    for k, A in ((0, 4e-17), (1, 3e-17)):
+        ref = O.sia2d_rhs(H0, B, 50.0, 50.0, ph, O.Law(kind=O.LAW_CONST_A, A=A))
+        assert rel_l2(b.dhdt(k, H0), ref) < 1e-12
+    b.close()
