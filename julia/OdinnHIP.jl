@@ -2,8 +2,9 @@
 #
 # This is the file a maintainer would add to ODINN.jl (src/inverse/HIP/OdinnHIP.jl): one new VJP type
 # and one new adjoint type whose methods ccall the C ABI of include/odinn_hip.h.  The build image has
-# no Julia toolchain, so this file is NOT executed by the test-suite; the same entry points are
-# exercised from Python (odinn.jl_amd/_lib.py) by tests/ -m gpu.
+# no Julia toolchain, so this file is NOT executed by the test-suite; tests/test_abi.py parses every
+# ccall below and checks its symbol, argument count and pointer/scalar pattern against the header, and
+# the same entry points are exercised from Python (odinn.jl_amd/_lib.py) by tests/ -m gpu.
 module OdinnHIP
 using ODINN, Huginn, Sleipnir
 const lib = "libodinn_hip"            # odinn.jl_amd/csrc/libodinn_hip.so on LD_LIBRARY_PATH
@@ -12,16 +13,32 @@ struct Phys;  rho::Float64; g::Float64; eta0::Float64; n::Float64; p::Float64; q
               C::Float64; minA::Float64; maxA::Float64; end
 struct GlacierDesc; nx::Int32; ny::Int32; dx::Float64; dy::Float64; phys::Phys
                     A::Float64; T::Float64; end
+# odinn_solver_opts / odinn_adjoint_opts / odinn_solve_stats, field for field (include/odinn_hip.h)
+struct SolverOpts; reltol::Float64; abstol::Float64; dtmax::Float64; dt0::Float64; fixed_dt::Float64
+                   maxiters::Int64; scheme::Int32; dense::Int32; cfl::Float64; end
+struct AdjointOpts; reltol::Float64; abstol::Float64; dtmax::Float64; n_quadrature::Int32; reserved::Int32
+                    maxiters::Int64; end
+SolverOpts(solver) = SolverOpts(solver.reltol, 1e-6, 0.0, 0.0, 0.0, Int64(solver.maxiters), Int32(0), Int32(0), 0.0)
+AdjointOpts(grad::ODINN.ContinuousAdjoint, solver) =
+    AdjointOpts(grad.reltol, grad.abstol, grad.dtmax, Int32(grad.n_quadrature), Int32(0), Int64(solver.maxiters))
 
 check(rc) = rc == 0 || error(unsafe_string(ccall((:odinn_last_error, lib), Cstring, ())))
+
+# the scalar long-term air temperature the A / Y laws take as input, obtained the way the reference's own
+# targets obtain it (src/models/target/target_D_hybrid.jl:60, src/laws/laws_utils.jl:85)
+mean_temp(simulation, i) = Huginn.get_input(Huginn.iAvgScalarTemp(), simulation, i, simulation.parameters.simulation.tspan[1])
 
 "One device context per simulation (all glaciers of this process on one GPU)."
 mutable struct Batch; h::Ptr{Cvoid}; end
 function Batch(simulation; device = 0)
     ph = simulation.parameters.physical
-    descs = [GlacierDesc(g.nx, g.ny, g.Δx, g.Δy,
-                 Phys(ph.ρ, ph.g, ph.η₀, g.n, 3.0, 0.0, g.C, ph.minA, ph.maxA), g.A, mean_temp(g))
-             for g in simulation.glaciers]
+    descs = map(enumerate(simulation.glaciers)) do (i, g)
+        # n, p, q, C of the SIA2D cache (the exponents compute_D reads: target_D_hybrid.jl:174-185)
+        c = ODINN.init_cache(simulation.model, simulation, i, simulation.model.trainable_components.θ).iceflow
+        GlacierDesc(g.nx, g.ny, g.Δx, g.Δy,
+            Phys(ph.ρ, ph.g, ph.η₀, c.n.value, c.p.value, c.q.value, c.C.value, ph.minA, ph.maxA),
+            g.A, mean_temp(simulation, i))
+    end
     h = Ref{Ptr{Cvoid}}()
     check(ccall((:odinn_batch_create, lib), Cint, (Cint, Cint, Ptr{GlacierDesc}, Ptr{Ptr{Cvoid}}),
                 device, length(descs), descs, h))
@@ -29,6 +46,11 @@ function Batch(simulation; device = 0)
     for (i, g) in enumerate(simulation.glaciers)
         check(ccall((:odinn_set_fields, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}),
                     b.h, i - 1, g.H₀, g.B))
+        if !isnothing(g.thicknessData)
+            tH = collect(Float64, g.thicknessData.t); Hs = reduce(hcat, vec.(g.thicknessData.H))
+            check(ccall((:odinn_set_reference, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Cint),
+                        b.h, i - 1, length(tH), tH, Hs, simulation.parameters.UDE.empirical_loss_function.loss.distance))
+        end
     end
     finalizer(x -> ccall((:odinn_batch_destroy, lib), Cint, (Ptr{Cvoid},), x.h), b)
 end
@@ -66,34 +88,63 @@ function ODINN.VJP_λ_∂MB∂H(m::HIPVJP, λ, H, simulation, glacier, t)
     return out
 end
 
-# ---- seam 3 (the fast path): the whole per-glacier gradient on the device --------------
-#      a new adjoint type next to DiscreteAdjoint (src/inverse/AdjointTypes.jl:85-91); the
-#      branch `typeof(grad) <: HIPAdjoint` in SIA2D_grad_batch! (gradient.jl:129) becomes:
-struct HIPAdjoint <: ODINN.AbstractAdjointMethod; batch::Batch; VJP_method::HIPVJP; end
-
-function SIA2D_grad_batch_HIP!(θ, simulation, adj::HIPAdjoint, tstops, tstopsMB, solver)
-    opts = Ref((solver.reltol, 1e-6, 0.0, 0.0, 0.0, Int64(solver.maxiters), Int32(0), Int32(0), 0.0))   # odinn_solver_opts
-    loss = Ref(0.0); dθ = zeros(length(θ)); θv = ODINN.ComponentVector2Vector(θ)
-    check(ccall((:odinn_loss_grad, lib), Cint,
-                (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Cvoid},
-                 Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
-                adj.batch.h, θv, length(θv), length(tstops), tstops, length(tstopsMB), tstopsMB, opts,
-                loss, dθ, C_NULL))
-    return loss[], [ODINN.Vector2ComponentVector(dθ, θ)]     # same tuple SIA2D_grad_batch! returns (:554)
+# ---- multi-GPU: one Julia process per GPU; the library owns the RCCL communicator.  Rank 0 draws the 128-byte
+#      unique id, the host distributes it (Distributed.remotecall_fetch / MPI.Bcast!) -- NCCL's bootstrap contract.
+mutable struct Comm; h::Ptr{Cvoid}; end
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:odinn_comm_get_unique_id, lib), Cint, (Ptr{Cvoid},), id))
+    return id
+end
+function Comm(device::Integer, nranks::Integer, rank::Integer, id::Vector{UInt8})
+    h = Ref{Ptr{Cvoid}}()
+    check(ccall((:odinn_comm_init_rank, lib), Cint, (Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}),
+                device, nranks, rank, id, h))
+    finalizer(x -> ccall((:odinn_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.h), Comm(h[]))
 end
 
-# the reference's DEFAULT gradient (ContinuousAdjoint, gradient.jl:276-539) on the device:
-# reverse RDPK3Sp35 solve + Gauss-Legendre quadrature; `grad` supplies reltol/abstol/dtmax/n_quadrature
-function SIA2D_grad_batch_HIP!(θ, simulation, adj::HIPAdjoint, grad::ODINN.ContinuousAdjoint, tstops, tstopsMB, solver)
-    opts  = Ref((solver.reltol, 1e-6, 0.0, 0.0, 0.0, Int64(solver.maxiters), Int32(0), Int32(0), 0.0))  # odinn_solver_opts
-    aopts = Ref((grad.reltol, grad.abstol, grad.dtmax, Int32(grad.n_quadrature), Int32(0),
-                 Int64(solver.maxiters)))                                                    # odinn_adjoint_opts
+# ---- seam 3 (the fast path): the whole gradient on the device ----------------------------
+#      a new adjoint type next to DiscreteAdjoint / ContinuousAdjoint (src/inverse/AdjointTypes.jl:53-91);
+#      SIA2D_grad! (gradient.jl:6-31) gains the method below: this rank's batch of glaciers is solved and
+#      differentiated on its GPU, and ONE ncclAllReduce of [loss, dθ] inside the library replaces
+#      pmap + sum(losses) + aggregate∇θ (gradient.jl:9-25, Model.jl:208-224).
+struct HIPAdjoint{G <: ODINN.AbstractAdjointMethod} <: ODINN.AbstractAdjointMethod
+    batch::Batch; comm::Union{Comm, Nothing}; method::G; VJP_method::HIPVJP
+end
+
+function SIA2D_grad_HIP!(dθ, θ, simulation, adj::HIPAdjoint, tstops, tstopsMB)
+    solver = simulation.parameters.solver
+    opts = Ref(SolverOpts(solver))
+    continuous = adj.method isa ODINN.ContinuousAdjoint
+    aopts = Ref(continuous ? AdjointOpts(adj.method, solver) : AdjointOpts(0.0, 0.0, 0.0, Int32(0), Int32(0), Int64(0)))
+    loss = Ref(0.0); g = zeros(length(θ)); θv = ODINN.ComponentVector2Vector(θ)
+    ts = collect(Float64, tstops); tmb = collect(Float64, tstopsMB)
+    check(ccall((:odinn_batch_loss_grad, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64},
+                 Ptr{SolverOpts}, Ptr{AdjointOpts}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}),
+                adj.batch.h, isnothing(adj.comm) ? C_NULL : adj.comm.h, continuous ? 1 : 0, θv, length(θv),
+                length(ts), ts, length(tmb), tmb, opts, aopts, loss, g, C_NULL, C_NULL))
+    dθ .= ODINN.Vector2ComponentVector(g, θ)
+    return loss[]
+end
+
+# single-rank pieces of the same seam, for callers that keep the reference's own reduction:
+function SIA2D_grad_batch_HIP!(θ, simulation, adj::HIPAdjoint, tstops, tstopsMB)
+    opts = Ref(SolverOpts(simulation.parameters.solver))
     loss = Ref(0.0); dθ = zeros(length(θ)); θv = ODINN.ComponentVector2Vector(θ)
-    check(ccall((:odinn_loss_grad_continuous, lib), Cint,
-                (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid},
-                 Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}),
-                adj.batch.h, θv, length(θv), length(tstops), tstops, length(tstopsMB), tstopsMB, opts, aopts,
-                loss, dθ, C_NULL, C_NULL))
-    return loss[], [ODINN.Vector2ComponentVector(dθ, θ)]
+    ts = collect(Float64, tstops); tmb = collect(Float64, tstopsMB)
+    if adj.method isa ODINN.ContinuousAdjoint   # the reference's DEFAULT gradient (gradient.jl:276-539)
+        aopts = Ref(AdjointOpts(adj.method, simulation.parameters.solver))
+        check(ccall((:odinn_loss_grad_continuous, lib), Cint,
+                    (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{SolverOpts},
+                     Ptr{AdjointOpts}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    adj.batch.h, θv, length(θv), length(ts), ts, length(tmb), tmb, opts, aopts, loss, dθ, C_NULL, C_NULL))
+    else                                        # DiscreteAdjoint (gradient.jl:129-275)
+        check(ccall((:odinn_loss_grad, lib), Cint,
+                    (Ptr{Cvoid}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{SolverOpts},
+                     Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                    adj.batch.h, θv, length(θv), length(ts), ts, length(tmb), tmb, opts, loss, dθ, C_NULL))
+    end
+    return loss[], [ODINN.Vector2ComponentVector(dθ, θ)]     # same tuple SIA2D_grad_batch! returns (gradient.jl:554)
 end
 end # module

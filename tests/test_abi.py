@@ -61,3 +61,79 @@ def test_julia_shim_binds_only_declared_symbols():
         used = set(re.findall(r"\(:(odinn_[A-Za-z0-9_]+),\s*lib\)", txt))
         assert used, rel
         assert used <= declared, (rel, sorted(used - declared))
+
+
+def _split_top(s):
+    """split on commas that are not nested inside (), {} or []"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _header_prototypes():
+    src = open(os.path.join(ROOT, "include", "odinn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"\b(int64_t|int|const char\*)\s+(odinn_[A-Za-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        a = [x for x in _split_top(" ".join(args.split())) if x and x != "void"]
+        protos[name] = (ret, a)
+    return protos
+
+
+def _c_class(arg):
+    """pointer / int / double class of one C parameter"""
+    if "*" in arg:
+        return "ptr"
+    if re.match(r"(const\s+)?double\b", arg):
+        return "double"
+    return "int"
+
+
+def _jl_class(t):
+    t = t.strip()
+    if t.startswith("Ptr{") or t in ("Cstring",):
+        return "ptr"
+    if t in ("Cdouble", "Float64"):
+        return "double"
+    assert t in ("Cint", "Int32", "Int64", "Clonglong"), f"unexpected Julia argument type {t}"
+    return "int"
+
+
+def test_julia_shim_ccalls_match_the_header_prototypes():
+    """Every ccall of julia/OdinnHIP.jl: return type, argument COUNT and the pointer / integer / double class of each
+    argument against the prototype in include/odinn_hip.h (the shim cannot be executed here: no Julia in the image)."""
+    protos = _header_prototypes()
+    assert len(protos) >= 40
+    txt = open(os.path.join(ROOT, "julia", "OdinnHIP.jl")).read()
+    calls = re.findall(r"ccall\(\(:(odinn_[A-Za-z0-9_]+),\s*lib\),\s*([A-Za-z0-9_{}]+),\s*\(([^)]*(?:\{[^}]*\}[^)]*)*)\)", txt, flags=re.S)
+    assert len(calls) >= 12
+    seen = set()
+    for name, ret, types in calls:
+        assert name in protos, name
+        cret, cargs = protos[name]
+        assert {"int": "Cint", "int64_t": "Int64", "const char*": "Cstring"}[cret] == ret, (name, ret)
+        jt = [x for x in _split_top(" ".join(types.split())) if x]
+        assert len(jt) == len(cargs), f"{name}: ccall passes {len(jt)} arguments, the header declares {len(cargs)}"
+        for k, (a, b) in enumerate(zip(jt, cargs)):
+            assert _jl_class(a) == _c_class(b), f"{name}: argument {k} is {a} in the shim, `{b}` in the header"
+        seen.add(name)
+    # the seams a maintainer needs are all bound
+    for need in ("odinn_batch_create", "odinn_sia2d_dhdt", "odinn_sia2d_vjp_H", "odinn_sia2d_vjp_theta", "odinn_loss_grad",
+                 "odinn_loss_grad_continuous", "odinn_batch_loss_grad", "odinn_comm_init_rank", "odinn_comm_get_unique_id"):
+        assert need in seen, need
+    # struct mirrors: same field count as the C structs
+    for jl, cname, n in (("SolverOpts", "odinn_solver_opts", 9), ("AdjointOpts", "odinn_adjoint_opts", 6), ("Phys", "odinn_phys", 9)):
+        m = re.search(r"struct %s;(.*?)end" % jl, txt, flags=re.S)
+        assert m and len(re.findall(r"::", m.group(1))) == n, jl
+    assert "mean_temp(" in txt and re.search(r"^mean_temp\(", txt, flags=re.M), "mean_temp must be defined in the shim"
