@@ -10,6 +10,9 @@ namespace odinn {
 void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
                                         double* U1, double* partF, double abstol, double reltol, int skip, int small) {
   // small: 1 = FOX x FOYS "latency" tiles (tilesF / partF then belong to that table)
+  // inlined-MLP laws: no ice-free shortcut variant (the network is skipped per node where Hbar = 0 anyway, and the
+  // conditional stencil makes the register allocator keep the whole network live: 95-166 spilled VGPRs)
+  if (lm_is_nn(ODINN_LM)) skip = 0;
   if (small) {
     if (skip) hipLaunchKernelGGL((k_rk_fused<ODINN_LM, true, FOYS>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);
     else hipLaunchKernelGGL((k_rk_fused<ODINN_LM, false, FOYS>), dim3(nblk), dim3(FNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol);

@@ -489,6 +489,9 @@ int launch_step(odinn_batch* b, int p, double abstol, double reltol) {
   return ODINN_OK;
 }
 
+#ifndef ODINN_NN_FUSED_MAX_TILES
+#define ODINN_NN_FUSED_MAX_TILES 512  // latency (54 x 8) tiles; measured crossover, see pick_scheme
+#endif
 // scheme actually used: 1 = five per-stage kernels, 2 = one fused kernel per step
 int pick_scheme(const odinn_batch* b, int requested) {
   int s = requested;
@@ -496,8 +499,14 @@ int pick_scheme(const odinn_batch* b, int requested) {
     const char* e = std::getenv("ODINN_SCHEME");
     if (e && (e[0] == '1' || e[0] == '2')) s = e[0] - '0';
   }
+  // inlined-MLP laws (LawY / LawU): the fused step kernel evaluates the network once per dual node and stage inside the
+  // stencil like the per-stage kernels do, but pays ~1.3x redundant evaluations in its halo; it wins where a step is
+  // launch-bound (one launch instead of five), i.e. on batches that do not fill the GPU.  scheme = 2 (or
+  // ODINN_SCHEME=2) forces it at any size.
+  // Measured (2x16 Y law, us per step, per-stage vs fused): 4 alpine glaciers 201 vs 128, 1 x 512^2 216 vs 357,
+  // 64 alpine 600 vs 755, 8 x 1024^2 2797 vs 3614 -- fused while its latency tiles do not fill the GPU
+  if (b->lm() >= 2 && s == 0) s = b->ntilesFs <= ODINN_NN_FUSED_MAX_TILES ? 2 : 1;
   if (s == 0) s = 2;
-  if (b->lm() >= 2) s = 1;  // inlined-MLP laws: MLP-bound, per-stage kernels (no redundant halo MLP work)
   return s;
 }
 
@@ -512,10 +521,11 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
   if (small >= 2)
     launch_rk_fused_strip(nblk, b->gd[0].use_Afield, small == 3 ? 8 : TRPT, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol,
                           reltol, skip, sc);
-  else if (b->lm() == 0)
-    launch_rk_fused_lm0(nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
-  else
-    launch_rk_fused_lm1(nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
+  else {
+    static void (*const tab[6])(int, hipStream_t, Pools, LawDev, const int4*, double*, double*, double*, double, double, int, int) = {
+        launch_rk_fused_lm0, launch_rk_fused_lm1, launch_rk_fused_lm2, launch_rk_fused_lm3, launch_rk_fused_lm4, launch_rk_fused_lm5};
+    tab[b->lm()](nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
+  }
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -2086,12 +2096,8 @@ static int timed_one(odinn_batch* b, int which, int it) {
   const Pools P = b->pools(true);
   const LawDev L = b->lawdev();
   switch (which) {
-    case ODINN_TIMED_FUSED_STEP:
-      if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "no fused step kernel for inlined-MLP laws");
-      return launch_fused_step(b, 1e-6, 1e-8, 0);
-    case ODINN_TIMED_FUSED_STEP_SKIP:
-      if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "no fused step kernel for inlined-MLP laws");
-      return launch_fused_step(b, 1e-6, 1e-8, 1);
+    case ODINN_TIMED_FUSED_STEP: return launch_fused_step(b, 1e-6, 1e-8, 0);
+    case ODINN_TIMED_FUSED_STEP_SKIP: return launch_fused_step(b, 1e-6, 1e-8, 1);
     case ODINN_TIMED_SOLVE_STEP:
     case ODINN_TIMED_SOLVE_STEP_STAGED: {
       const int scheme = which == ODINN_TIMED_SOLVE_STEP_STAGED ? 1 : pick_scheme(b, 0);

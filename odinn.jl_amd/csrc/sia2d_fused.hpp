@@ -191,13 +191,90 @@ __device__ __forceinline__ void fused_stage_fast(const GDev& g, const LawDev& L,
   }
 }
 
+// Inlined-MLP laws (LawY / LawU, Laws.jl:258-265, 114-123): the five stages as a run-time loop with ONE copy of the
+// network in the code (the node loop is not unrolled either) -- the stage bodies above, instantiated five times with the
+// slot loop unrolled, would inline the 2x16 network 35 times.  A node's D = Y(T, Hbar) Gam Hbar^(nH+2) |grad S|^(nS-1)
+// (or Hbar U(Hbar, |grad S|)) is evaluated once per stage from the {Hc, S} tile in LDS exactly as k_rk_stage does;
+// the cell phase is fused_stage's with the RDPK3Sp35 coefficients read from the constant tables.
+template <int LM, int FOYV>
+__device__ __forceinline__ void fused_stages_nn(const GDev& g, const LawDev& L, int gi, int gj0, int w, int lane, double dt,
+                                                 double2 (*sHS)[FLD], double (*sD)[FLD], double (&u)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                                 double (&tmp)[(FOYV + 2 * FH + FNW - 1) / FNW], const double (&up)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                                 double (&E)[(FOYV + 2 * FH + FNW - 1) / FNW], const double (&bb)[(FOYV + 2 * FH + FNW - 1) / FNW]) {
+  constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + FNW - 1) / FNW;
+  const bool nodex = gi >= 0 && gi <= g.nx - 2;
+  const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
+#pragma unroll 1
+  for (int S = 1; S <= 5; ++S) {
+    const bool ncol = lane >= S - 1 && lane <= FRX - 1 - S;
+#pragma unroll 1
+    for (int r = w; r < FRY; r += FNW) {
+      if (r >= S - 1 && r <= FRY - 1 - S) {  // wave-uniform
+        const int gj = gj0 + r;
+        double D = 0.0;
+        if (ncol && nodex && gj >= 0 && gj <= g.ny - 2) {
+          double gx, gy, Hb;
+          node_geom<FLD>(g, &sHS[r][lane], gx, gy, Hb);
+          double al, be, sp;
+          D = node_D<false, LM>(g, L, Hb, gx * gx + gy * gy, 0.0, al, be, sp);
+        }
+        if (ncol) sD[r][lane] = D;
+      }
+    }
+    __syncthreads();
+    const int s = S - 1;
+    const double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
+    const bool ccol = lane >= S && lane <= FRX - 1 - S;
+#pragma unroll
+    for (int m = 0; m < FSLOT; ++m) {
+      const int r = w + FNW * m;
+      if (r >= S && r <= FRY - 1 - S) {
+        const int gj = gj0 + r;
+        if (ccol && inx && gj >= 0 && gj < g.ny) {
+          double k = 0.0;
+          if (intx && gj >= 1 && gj <= g.ny - 2) k = cell_div<FLD, FLD, false>(g, &sHS[r][lane], &sD[r][lane]);
+          const double dtk = dt * k;
+          const double uo = u[m];
+          double un;
+          if (S == 1) {
+            un = fma(bt, dtk, uo);
+            E[m] = bh * dtk;
+          } else {
+            const double t = fma(dl, uo, tmp[m]);
+            un = fma(g1, uo, g2 * t);
+            if (S >= 4) un = fma(g3, up[m], un);
+            un = fma(bt, dtk, un);
+            if (dl != 0.0) tmp[m] = t;
+            E[m] = fma(bh, dtk, E[m]);
+          }
+          u[m] = un;
+        }
+      }
+    }
+    __syncthreads();  // every read of sHS of this stage is done
+    if (S < 5) {
+#pragma unroll
+      for (int m = 0; m < FSLOT; ++m) {
+        const int r = w + FNW * m;
+        if (r >= S && r <= FRY - 1 - S && ccol) {
+          const double hc = vmax0(u[m]);
+          sHS[r][lane] = make_double2(hc, bb[m] + hc);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 template <int LM, int FOYV, bool AF, bool INNER>
 __device__ __forceinline__ void fused_stages(const GDev& g, const LawDev& L, const double* __restrict__ Afield,
                                               int gi, int gj0, int w, int lane, double dt, double2 (*sHS)[FLD],
                                               double (*sD)[FLD], double (&u)[(FOYV + 2 * FH + FNW - 1) / FNW], double (&tmp)[(FOYV + 2 * FH + FNW - 1) / FNW],
                                               const double (&up)[(FOYV + 2 * FH + FNW - 1) / FNW], double (&E)[(FOYV + 2 * FH + FNW - 1) / FNW],
                                               const double (&bb)[(FOYV + 2 * FH + FNW - 1) / FNW]) {
-  if constexpr (LM == LM_FAST && ODINN_FFAST) {
+  if constexpr (lm_is_nn(LM)) {
+    fused_stages_nn<LM, FOYV>(g, L, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
+  } else if constexpr (LM == LM_FAST && ODINN_FFAST) {
     fused_stage_fast<1, FOYV, AF, INNER>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
     fused_stage_fast<2, FOYV, AF, INNER>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
     fused_stage_fast<3, FOYV, AF, INNER>(g, L, Afield, gi, gj0, w, lane, dt, sHS, sD, u, tmp, up, E, bb);
@@ -219,7 +296,7 @@ __device__ __forceinline__ void fused_stages(const GDev& g, const LawDev& L, con
 #define ODINN_FWPE 4
 #endif
 template <int LM, bool SKIP, int FOYV>
-__global__ __launch_bounds__(FNT, ODINN_FWPE) void k_rk_fused(Pools P, LawDev L, const int4* __restrict__ tilesF,
+__global__ __launch_bounds__(FNT, (lm_is_nn(LM) ? 2 : ODINN_FWPE)) void k_rk_fused(Pools P, LawDev L, const int4* __restrict__ tilesF,
                                                      double* __restrict__ U0, double* __restrict__ U1,
                                                      double* __restrict__ partF, double abstol, double reltol) {
   constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + FNW - 1) / FNW;

@@ -690,3 +690,47 @@ def test_largest_single_gpu_configuration_64x1024(gpu, monkeypatch):
         b1.solve(ts, fixed_dt=0.00025)
         assert np.array_equal(b1.snapshot(0, 1), got[k]), k
         b1.close()
+
+
+@pytest.mark.parametrize("tiles", ["small", "large"])
+@pytest.mark.parametrize("case", ["Y_default", "Y_w16", "Y_light", "Y_wide", "U_default"])
+def test_inlined_mlp_fused_step_matches_per_stage_and_oracle(gpu, monkeypatch, case, tiles):
+    """LawY / LawU with the network INLINED in the temporally fused step kernel (k_rk_fused<LM >= 2>: one launch per
+    RDPK3Sp35 step, the MLP evaluated once per dual node and stage inside the stencil) against the five per-stage
+    kernels and against the oracle's integrator: equal to rounding under a fixed dt, within the solver tolerance under
+    step-size control.  Compile-time architectures (LM 3, 4, 5) and the run-time one (LM 2, "wide"); both tile heights."""
+    monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
+    ph = O.Phys()
+    widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "w16": ([2, 16, 16, 1], [1, 1, 2]),
+                    "light": ([2, 3, 1], [1, 2]), "wide": ([2, 5, 8, 20, 30, 10, 1], [3, 3, 1, 1, 1, 2])}[case.split("_")[1]]
+    isY = case.startswith("Y")
+    if isY:
+        om, gm, th = _mlp_pair(gpu, widths, acts, [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+        law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=-5.0)
+        kind = gpu.LAW_NN_Y
+    else:
+        om, gm, th = _mlp_pair(gpu, widths, acts, [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+        law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th)
+        kind = gpu.LAW_NN_U
+    nx, ny = 131, 97  # ragged around the 54 x 40 / 54 x 8 tiles
+    H0, B = O.synthetic_icecap(nx, ny, 100.0)
+    H0 = H0 * 0.4
+    ts = [0.0, 0.02, 0.05] if isY else [0.0, 2e-3, 5e-3]
+    fdt = 0.004 if isY else 4e-4
+    res = {}
+    for scheme in (1, 2):
+        b = gpu.GlacierBatch([(nx, ny)], [100.0], phys=[gpu.PhysicalParameters(**ph.__dict__)])
+        b.set_fields(0, H0, B)
+        b.set_law(kind, gm, th)
+        st = b.solve(ts, reltol=1e-8, scheme=scheme)
+        ad = (b.snapshot(0, 2), st[0].naccept + st[0].nreject)
+        stf = b.solve(ts[:2], fixed_dt=fdt, scheme=scheme)
+        res[scheme] = ad + (b.snapshot(0, 1), stf[0].naccept)
+        b.close()
+    assert np.isfinite(res[2][2]).all() and rel_l2(res[2][2], res[1][2]) < 1e-12, case
+    assert abs(res[1][1] - res[2][1]) <= 1 and rel_l2(res[2][0], res[1][0]) < 1e-6, case
+    f = lambda H: O.sia2d_rhs(H, B, 100.0, 100.0, ph, law)
+    ref, sto, _ = O.solve(f, H0, ts[:2], fixed_dt=fdt)
+    assert sto.naccept == res[2][3]
+    assert rel_l2(res[2][2], ref[1]) < 1e-10, case  # 5 steps of exp/log-laden arithmetic (device softplus: <= 2 ulp)
+    assert np.abs(res[2][2] - H0).max() > 1e-6  # the steps moved the ice
