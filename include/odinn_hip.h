@@ -164,6 +164,15 @@ int odinn_set_T_field(odinn_batch* b, int g, const double* T_dual);   /* NN_A_GR
 int odinn_set_law(odinn_batch* b, int kind, const odinn_mlp_desc* mlp, const double* theta, int P,
                   double n_H, double n_gradS);
 int odinn_set_theta(odinn_batch* b, const double* theta, int P);
+/* spatial evaluation of d law / d theta inside the theta-VJP of the Y law (SIA2D_D_hybrid_target.interpolation,
+ * src/models/target/target_D_hybrid.jl:12-15,121-160): ODINN_GRAD_INTERP_NONE = exact backprop at every dual node
+ * (`:None`), ODINN_GRAD_INTERP_LINEAR = gradients on the <= 2 n_interp_half knots of create_interpolation(Hbar)
+ * (target_utils.jl:245-293), interpolated linearly in Hbar (`:Linear`).  odinn_set_law selects the reference's
+ * default: LINEAR with n_interp_half = 75 for ODINN_LAW_NN_Y, NONE for every other law (:D's default is :None,
+ * target_D_pure.jl:34-39; its :Linear node-grid variant, Laws.jl:153-169, is not provided).  n_interp_half <= 256. */
+#define ODINN_GRAD_INTERP_NONE 0
+#define ODINN_GRAD_INTERP_LINEAR 1
+int odinn_set_grad_interpolation(odinn_batch* b, int kind, int n_interp_half);
 /* thickness data glacier.thicknessData: n_ref fields at times t_ref; the loss mask is
  * is_in_glacier(H_ref, distance) (Losses.jl:266) */
 int odinn_set_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, const double* H_ref,

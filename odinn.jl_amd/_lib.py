@@ -22,6 +22,7 @@ POST_NONE, POST_AFFINE, POST_EXPMAX, POST_SCALE = range(4)
 SCHEME_AUTO, SCHEME_STAGED, SCHEME_FUSED = 0, 1, 2
 LOSS_H, LOSS_V, LOSS_HV = 0, 1, 2
 VJP_DISCRETE, VJP_CONTINUOUS = 0, 1
+GRAD_INTERP_NONE, GRAD_INTERP_LINEAR = 0, 1
 SCHEME_AUTO, SCHEME_STAGED, SCHEME_FUSED, SCHEME_EULER_CFL = 0, 1, 2, 3
 
 
@@ -78,6 +79,7 @@ SIGNATURES = {
     "odinn_set_T_field": (C.c_int, [_vp, C.c_int, _dp]),
     "odinn_set_law": (C.c_int, [_vp, C.c_int, C.POINTER(MlpDesc), _dp, C.c_int, C.c_double, C.c_double]),
     "odinn_set_theta": (C.c_int, [_vp, _dp, C.c_int]),
+    "odinn_set_grad_interpolation": (C.c_int, [_vp, C.c_int, C.c_int]),
     "odinn_set_reference": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int]),
     "odinn_set_mass_balance": (C.c_int, [_vp, C.c_int, _dp, C.c_double, _dp, C.c_double]),
     "odinn_set_velocity_reference": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp]),

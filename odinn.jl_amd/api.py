@@ -41,7 +41,8 @@ __all__ = [
     "callback_diagnosis",
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
-    "shard_glaciers", "init_distributed", "allreduce_loss_grad", "load_gridded_glacier",
+    "shard_glaciers", "init_distributed", "allreduce_loss_grad", "load_gridded_glacier", "attach_rccl_comm",
+    "SIA2D_A_target", "SIA2D_D_hybrid_target", "SIA2D_D_target",
 ]
 
 
@@ -547,10 +548,46 @@ class FieldMB:
     fields: Sequence[np.ndarray]
 
 
-class Model:
-    """Model(iceflow=..., mass_balance=..., regressors=(; A=nn))  (Model.jl:61-127)."""
+@dataclass
+class SIA2D_A_target:
+    """src/models/target/target_A.jl:9"""
 
-    def __init__(self, iceflow: SIA2Dmodel, mass_balance=None, regressors: Optional[Dict[str, NeuralNetwork]] = None):
+
+@dataclass
+class SIA2D_D_hybrid_target:
+    """src/models/target/target_D_hybrid.jl:12-15: how dY/dθ is evaluated over the dual grid in ∂Diffusivity∂θ --
+    :Linear (default) = exact gradients on 2 n_interp_half knots of H̄ (create_interpolation), interpolated linearly;
+    :None = exact backprop at every node."""
+
+    interpolation: str = "Linear"
+    n_interp_half: int = 75
+
+
+@dataclass
+class SIA2D_D_target:
+    """src/models/target/target_D_pure.jl:34-39 (default :None; the :Linear node-grid variant of LawU is not provided)."""
+
+    interpolation: str = "None"
+    n_interp_half: int = 100
+
+
+class Model:
+    """Model(iceflow=..., mass_balance=..., regressors=(; A=nn); target=nothing)  (Model.jl:61-127); the target is
+    inferred from the laws when not given (:102-114)."""
+
+    def __init__(self, iceflow: SIA2Dmodel, mass_balance=None, regressors: Optional[Dict[str, NeuralNetwork]] = None,
+                 target=None):
+        kind = iceflow.law.kind
+        want = SIA2D_D_target if kind == L.LAW_NN_U else SIA2D_D_hybrid_target if kind == L.LAW_NN_Y else SIA2D_A_target
+        if target is None:
+            target = want()
+        elif not isinstance(target, want):
+            raise ValueError(f"The provided laws do not match with the provided target. Make sure that the target is a {want.__name__}.")
+        if isinstance(target, SIA2D_D_target) and target.interpolation != "None":
+            raise NotImplementedError("SIA2D_D_target(interpolation = :Linear) is not provided; use :None (its default)")
+        if getattr(target, "interpolation", "None") not in ("None", "Linear"):
+            raise ValueError("Method to spatially compute gradient with respect to H̄ not specified.")  # target_D_hybrid.jl:161
+        self.target = target
         self.iceflow = iceflow
         self.mass_balance = mass_balance
         self.regressors = regressors or {}
@@ -849,6 +886,10 @@ class _Simulation:
                     b.set_A(k, gl[k].A if gl[k].A is not None else law.value)
         else:
             b.set_law(law.kind, law.mlp, self.model.theta[:self.model.n_main], law.n_H, law.n_gradS)
+            tg = self.model.target
+            if isinstance(tg, SIA2D_D_hybrid_target):
+                b.set_grad_interpolation(L.GRAD_INTERP_LINEAR if tg.interpolation == "Linear" else L.GRAD_INTERP_NONE,
+                                         tg.n_interp_half)
         mb = self.model.mass_balance
         if p.simulation.use_MB and mb is not None:
             for k, g in enumerate(gl):

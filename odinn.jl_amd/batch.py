@@ -195,6 +195,11 @@ class GlacierBatch:
             self.P = th.size
         self.law_kind = kind
 
+    def set_grad_interpolation(self, kind=L.GRAD_INTERP_LINEAR, n_interp_half=75):
+        """`interpolation` / `n_interp_half` of SIA2D_D_hybrid_target (target_D_hybrid.jl:12-15): how d law / d theta is
+        evaluated over the dual grid in the theta-VJP of the Y law.  set_law picks the reference's default."""
+        L.check(L.lib().odinn_set_grad_interpolation(self._h, int(kind), int(n_interp_half)))
+
     def set_theta(self, theta):
         th = np.ascontiguousarray(theta, dtype=np.float64)
         L.check(L.lib().odinn_set_theta(self._h, _p(th), th.size))

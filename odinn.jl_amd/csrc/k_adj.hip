@@ -36,6 +36,12 @@ void CAT(launch_adj_stage_lm, ODINN_LM)(int stage, int vj, int nblk, hipStream_t
   adj_stage_dispatch<0>(stage, nblk, st, P, L, A);
 }
 void CAT(launch_vjp_theta_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base) {
+#if ODINN_LM >= 3
+  if (A.emitH) {  // `:Linear` gradient interpolation: the kernel only emits (Hbar, node weight), no per-node backprop
+    hipLaunchKernelGGL(k_vjp_theta<ODINN_LM>, dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+    return;
+  }
+#endif
 #if ODINN_LM == 3
   hipLaunchKernelGGL(k_vjp_theta_nn<ArchDef>, dim3(nblk), dim3(NT), 0, st, P, L, A, base);
 #elif ODINN_LM == 4

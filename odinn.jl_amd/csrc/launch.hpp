@@ -30,6 +30,13 @@ void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools
 // k_adjf.hip, law mode 0 only
 void launch_adj_fused_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, AdjFusedArgs A);
 
+// k_interp.hip: `:Linear` spatial interpolation of d law / d theta for the Y law (target_D_hybrid.jl:136-160)
+constexpr int INTERP_KMAX = 512;
+size_t interp_sort_temp_bytes(long long nd_max);
+int launch_interp_theta(hipStream_t st, const LawDev& L, double T, int n_half, const double* nodeH, const double* nodeV,
+                        long long nd, double* sH, double* sV, void* tmp, size_t tmp_bytes, double* knots, int* M, double* G,
+                        double* ab, double* dth, int accumulate);
+
 // k_vel.hip (A-type law modes 0/1 only)
 struct VArgs;
 void launch_surface_V(int lm, int nblk, hipStream_t st, Pools P, const double* U, double* Vx, double* Vy, int base);

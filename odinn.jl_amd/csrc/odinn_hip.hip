@@ -221,6 +221,13 @@ struct odinn_batch {
   int P = 0;
   double nH = -1, nS = -1;
   bool has_Afield_const = false;
+  // `:Linear` interpolation of d law / d theta (Y law): knots of Hbar, see k_interp.hip
+  int grad_interp = ODINN_GRAD_INTERP_NONE, n_interp_half = 75;
+  double *d_nodeH = nullptr, *d_nodeV = nullptr, *d_sortH = nullptr, *d_sortV = nullptr, *d_knots = nullptr, *d_knotG = nullptr,
+         *d_knotab = nullptr;
+  int* d_knotM = nullptr;
+  void* d_sorttmp = nullptr;
+  size_t sorttmp_bytes = 0, knotG_cap = 0;
   double *d_part_theta = nullptr, *d_gscratch = nullptr, *d_dth = nullptr;
   size_t part_theta_cap = 0, gscratch_cap = 0, dth_cap = 0;
   // solve bookkeeping
@@ -1001,6 +1008,9 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_rega); dfree(b->d_regr); dfree(b->d_regg); dfree(b->d_regp); dfree(b->d_regm);
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
+  dfree(b->d_nodeH); dfree(b->d_nodeV); dfree(b->d_sortH); dfree(b->d_sortV); dfree(b->d_knots); dfree(b->d_knotG);
+  dfree(b->d_knotab); dfree(b->d_knotM);
+  if (b->d_sorttmp) { (void)hipFree(b->d_sorttmp); b->d_sorttmp = nullptr; }
   dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
   dfree(b->d_Vabs); dfree(b->d_Vxr); dfree(b->d_Vyr); dfree(b->d_wv); dfree(b->d_vsc); dfree(b->d_vslot);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -1089,6 +1099,7 @@ int odinn_set_law(odinn_batch* b, int kind, const odinn_mlp_desc* mlp, const dou
   if (kind < ODINN_LAW_CONST_A || kind > ODINN_LAW_NN_U) return fail(ODINN_ERR_ARG, "unknown law kind %d", kind);
   if (kind == ODINN_LAW_CONST_A) {
     b->law_kind = kind;
+    b->grad_interp = ODINN_GRAD_INTERP_NONE;
     b->P = 0;
     b->mlp.n_layers = 0;
     b->gd_dirty = true;
@@ -1107,6 +1118,10 @@ int odinn_set_law(odinn_batch* b, int kind, const odinn_mlp_desc* mlp, const dou
   b->mlp = *mlp;
   b->P = P;
   b->nH = n_H; b->nS = n_gradS;
+  // the reference's defaults: SIA2D_D_hybrid_target(interpolation = :Linear, n_interp_half = 75) (target_D_hybrid.jl:12-15),
+  // SIA2D_D_target(interpolation = :None) (target_D_pure.jl:34-39); A-type laws have no spatial law gradient
+  b->grad_interp = kind == ODINN_LAW_NN_Y ? ODINN_GRAD_INTERP_LINEAR : ODINN_GRAD_INTERP_NONE;
+  b->n_interp_half = 75;
   dfree(b->d_theta);
   CHK(dalloc(&b->d_theta, (size_t)P));
   return odinn_set_theta(b, theta, P);
@@ -1200,6 +1215,26 @@ int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H,
   return down_field(b, g, b->d_tmpB, dlam);
 }
 
+static int ensure_interp_scratch(odinn_batch* b) {
+  if (!b->d_nodeH) {
+    long long ndmax = 1;
+    for (const GDev& r : b->gd) ndmax = std::max(ndmax, (long long)(r.nx - 1) * (r.ny - 1));
+    CHK(dalloc(&b->d_nodeH, (size_t)b->ntotd)); CHK(dalloc(&b->d_nodeV, (size_t)b->ntotd));
+    CHK(dalloc(&b->d_sortH, (size_t)ndmax)); CHK(dalloc(&b->d_sortV, (size_t)ndmax));
+    CHK(dalloc(&b->d_knots, (size_t)INTERP_KMAX)); CHK(dalloc(&b->d_knotab, (size_t)2 * INTERP_KMAX));
+    CHK(dalloc(&b->d_knotM, (size_t)1));
+    b->sorttmp_bytes = interp_sort_temp_bytes(ndmax);
+    HIPCHK(hipMalloc(&b->d_sorttmp, std::max<size_t>(b->sorttmp_bytes, 16)));
+  }
+  const size_t need = (size_t)std::max(b->P, 1) * INTERP_KMAX;
+  if (need > b->knotG_cap) {
+    dfree(b->d_knotG);
+    CHK(dalloc(&b->d_knotG, need));
+    b->knotG_cap = need;
+  }
+  return ODINN_OK;
+}
+
 static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
                             bool accumulate, double* part_deferred = nullptr, bool inplace = false,
                             const double* lam_alt = nullptr, const double* snaps = nullptr, const AdjState* adj = nullptr) {
@@ -1210,7 +1245,17 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   const bool nn_node = b->law_kind >= ODINN_LAW_NN_Y;
   const int base = g < 0 ? 0 : b->gd[g].tile0, nblk = g < 0 ? b->ntiles : b->gd[g].ntiles;
   if (nn_node) CHK(ensure_theta_scratch(b, nblk));
+  const bool linear = b->law_kind == ODINN_LAW_NN_Y && b->grad_interp == ODINN_GRAD_INTERP_LINEAR;
+  if (linear) {
+    CHK(ensure_interp_scratch(b));
+    const int g0 = g < 0 ? 0 : g, g1 = g < 0 ? b->G : g + 1;
+    const long long lo = b->gd[g0].offd;
+    const long long hi = g1 < b->G ? b->gd[g1].offd : b->ntotd;
+    HIPCHK(hipMemsetAsync(b->d_nodeH + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
+    HIPCHK(hipMemsetAsync(b->d_nodeV + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
+  }
   ThArgs A{};
+  A.emitH = linear ? b->d_nodeH : nullptr; A.emitV = linear ? b->d_nodeV : nullptr;
   A.H = H; A.lam = lam; A.lam_alt = lam_alt; A.scales = scales;
   A.snaps = snaps; A.adj = adj; A.ntot = b->ntot;
   A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
@@ -1221,7 +1266,18 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   if (part_deferred) P.part = part_deferred;
   launch_vjp_theta(b, nblk, P, b->lawdev(), A, base);
   const int ng = g < 0 ? b->G : 1, g0 = g < 0 ? 0 : g;
-  if (part_deferred) {
+  if (linear) {
+    // dtheta_g (+)= sum_knots c_k dY/dtheta(T_g, knot_k): sort the glacier's nodes by Hbar, build its knots, sum per interval
+    const LawDev L = b->lawdev();
+    for (int q = g0; q < g0 + ng; ++q) {
+      const GDev& r = b->gd[q];
+      const long long nd = (long long)(r.nx - 1) * (r.ny - 1);
+      const int rc = launch_interp_theta(b->stream, L, b->descs[q].T, b->n_interp_half, b->d_nodeH + r.offd, b->d_nodeV + r.offd, nd,
+                                         b->d_sortH, b->d_sortV, b->d_sorttmp, b->sorttmp_bytes, b->d_knots, b->d_knotM,
+                                         b->d_knotG, b->d_knotab, b->d_dth + (size_t)q * b->P, accumulate ? 1 : 0);
+      if (rc) return fail(ODINN_ERR_HIP, "gradient interpolation failed (code %d)", rc);
+    }
+  } else if (part_deferred) {
   } else if (nn_node)
     launch_sum_part_theta(b->P, ng, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g0);
   else
@@ -1270,6 +1326,17 @@ int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double
   std::vector<double> dA(b->P);
   h_mlp(b->mlp, b->theta.data(), &b->descs[g].T, dA.data());
   for (int k = 0; k < b->P; ++k) dtheta[k] = dA[k] * Gs;  // cartesian_tensor contraction, target_utils.jl:156-161
+  return ODINN_OK;
+}
+
+int odinn_set_grad_interpolation(odinn_batch* b, int kind, int n_interp_half) {
+  if (!b || (kind != ODINN_GRAD_INTERP_NONE && kind != ODINN_GRAD_INTERP_LINEAR)) return fail(ODINN_ERR_ARG, "bad interpolation kind");
+  if (kind == ODINN_GRAD_INTERP_LINEAR && (n_interp_half < 2 || 2 * n_interp_half > INTERP_KMAX))
+    return fail(ODINN_ERR_ARG, "n_interp_half must be in [2, %d]", INTERP_KMAX / 2);
+  if (kind == ODINN_GRAD_INTERP_LINEAR && b->law_kind != ODINN_LAW_NN_Y)
+    return fail(ODINN_ERR_UNSUPPORTED, "linear interpolation of the law gradient is provided for the Y law (:D_hybrid) only");
+  b->grad_interp = kind;
+  if (kind == ODINN_GRAD_INTERP_LINEAR) b->n_interp_half = n_interp_half;
   return ODINN_OK;
 }
 

@@ -1657,6 +1657,9 @@ struct ThArgs {
   long long ntot;
   int accum;             // A-type laws: add the tile's sum onto its partial slot instead of overwriting it
                          // (one reduction after a whole reverse solve instead of one per step)
+  double* emitH;         // non-null (Y law, `:Linear` gradient interpolation, k_interp.hip): instead of backpropagating
+  double* emitV;         //   per node, write Hbar and the node weight scale * spat * Da to these dual pooled arrays
+                         //   (pre-zeroed by the caller: tiles that leave early contribute zeros)
 };
 
 template <int LM>
@@ -1667,6 +1670,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const double scale = A.scales ? A.scales[t4.x] : 1.0;
   constexpr bool nn_node = lm_is_nn(LM);
+  if (nn_node && A.emitH && (scale == 0.0)) return;
   if (scale == 0.0) {  // this glacier contributes nothing now (e.g. not at a quadrature node)
     if (!nn_node) {
       if (threadIdx.x == 0 && !A.accum) P.part[4 * (long long)t4.w + 2] = 0.0;
@@ -1691,7 +1695,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   if (!__syncthreads_or(ice)) {
     if (!nn_node) {
       if (threadIdx.x == 0 && !A.accum) P.part[4 * (long long)t4.w + 2] = 0.0;
-    } else {
+    } else if (!A.emitH) {
       for (int k = threadIdx.x; k < L.P; k += NT) A.part_theta[(long long)t4.w * L.P + k] = 0.0;
     }
     return;
@@ -1702,7 +1706,8 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   double acc = 0.0;
   const long long gstride = (long long)gridDim.x * NT;
   double* gth = A.gscratch ? A.gscratch + ((long long)blockIdx.x * NT + threadIdx.x) : nullptr;
-  if (nn_node)
+  const bool emit = nn_node && A.emitH != nullptr;
+  if (nn_node && !emit)
     for (int k = 0; k < L.P; ++k) gth[(long long)k * gstride] = 0.0;
   // owned nodes: lower-left cell is an interior-of-tile cell (a = tx+1, b = r)
 #pragma unroll
@@ -1729,6 +1734,10 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
       if (!nn_node) {
         acc += wgt;
         if (A.Gacc) A.Gacc[g.offd + gi + (long long)(g.nx - 1) * gj] += wgt;
+      } else if (emit) {
+        const long long q = g.offd + gi + (long long)(g.nx - 1) * gj;
+        A.emitH[q] = Hb;
+        A.emitV[q] = wgt;
       } else if (!(L.kind == 4 && Hb == 0.0)) {  // target_D_pure.jl:166-168 skips Hbar == 0
         // accumulate wgt * dlaw/dtheta into the thread-private scratch
         const double x0 = (L.kind == 3) ? g.T : Hb, x1 = (L.kind == 3) ? Hb : sqrt(gS2);
@@ -1739,7 +1748,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
   if (!nn_node) {
     const double tot = block_sum(acc, red);
     if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 2] = A.accum ? P.part[4 * (long long)t4.w + 2] + tot : tot;
-  } else {
+  } else if (!emit) {
     for (int k = 0; k < L.P; ++k) {
       const double tot = block_sum(gth[(long long)k * gstride], red);
       if (threadIdx.x == 0) A.part_theta[(long long)t4.w * L.P + k] = tot;

@@ -363,6 +363,17 @@ class Law:
     T: object = -5.0  # temperature input (scalar or dual-grid field)
     n_H: Optional[float] = None  # D_hybrid exponents (target_D_hybrid.jl:180-185)
     n_gradS: Optional[float] = None
+    # spatial evaluation of d law / d theta (SIA2D_D_hybrid_target.interpolation, target_D_hybrid.jl:12-15;
+    # SIA2D_D_target, target_D_pure.jl:34-39): "none" = exact per node, "linear" = gradients on 2 n_interp_half nodes of
+    # Hbar, linearly interpolated.  None = the reference's default for the law: :Linear with n_interp_half = 75 for the Y
+    # law (:D_hybrid), :None for every other law.
+    interpolation: Optional[str] = None
+    n_interp_half: Optional[int] = None
+
+    def interp(self):
+        kind = self.interpolation if self.interpolation is not None else ("linear" if self.kind == LAW_NN_Y else "none")
+        n = self.n_interp_half if self.n_interp_half is not None else (75 if self.kind == LAW_NN_Y else 100)
+        return kind, n
 
 
 @dataclass
@@ -585,6 +596,64 @@ def law_grad_theta(law: Law, ph: Phys, Hbar, gradS, theta=None):
     raise ValueError(law.kind)
 
 
+def create_interpolation(A, n_interp_half, dilation_factor=1.0, minA_unif=None, minA_quantile=None, maxA_unif=None,
+                         maxA_quantile=None):
+    """create_interpolation (src/models/target/target_utils.jl:245-293): the sorted, unique union of n_interp_half
+    uniformly spaced values on [minA_unif, maxA_unif] (default [0, dilation * max A]) and n_interp_half quantiles
+    (probabilities LinRange(0, 1, n + 2)[2:end-1], Statistics.quantile's default definition = type 7) of the entries of A
+    strictly inside (minA_quantile, maxA_quantile) (default (0, max A)).
+    The reference tops the vector up to exactly 2 n_interp_half knots with midpoints of RANDOMLY chosen intervals when
+    the union has duplicates ("in theory, this should never happen", :278-288); that step is not reproducible and is
+    omitted: the vector then simply has fewer knots."""
+    A = np.asarray(A, F).ravel()
+    amax = A.max()
+    lo_u = 0.0 if minA_unif is None else minA_unif
+    lo_q = 0.0 if minA_quantile is None else minA_quantile
+    hi_u = dilation_factor * amax if maxA_unif is None else maxA_unif
+    hi_q = amax if maxA_quantile is None else maxA_quantile
+    if not (lo_u < hi_u and lo_q < hi_q):
+        raise ValueError("There are not enough different values of A to create a proper interpolation.")  # :262
+    n = int(n_interp_half)
+    t = np.arange(n) / (n - 1.0)
+    unif = (1.0 - t) * lo_u + t * hi_u  # LinRange: lerp with t = j / (n - 1)
+    probs = (np.arange(n + 2) / (n + 1.0))[1:-1]
+    inside = np.sort(A[(lo_q < A) & (A < hi_q)])
+    if inside.size == 0:
+        return np.unique(unif)
+    h = (inside.size - 1) * probs  # 0-based position; Statistics._quantile: aleph = (m - 1) p + 1, j = trunc(aleph), gamma
+    j = np.clip(np.floor(h).astype(int), 0, max(inside.size - 2, 0))
+    gam = np.clip(h - j, 0.0, 1.0)
+    a = inside[j]
+    b = inside[np.minimum(j + 1, inside.size - 1)]
+    quant = a + gam * (b - a)
+    return np.unique(np.concatenate([unif, quant]))  # sorted + unique
+
+
+def interp_linear_weights(nodes, x):
+    """Gridded(Linear()) interpolation (Interpolations.jl) of knot values at x in [nodes[0], nodes[-1]]: returns
+    (k, w) with value = (1 - w) v[k] + w v[k + 1]."""
+    x = np.asarray(x, F)
+    k = np.clip(np.searchsorted(nodes, x, side="right") - 1, 0, len(nodes) - 2)
+    w = (x - nodes[k]) / (nodes[k + 1] - nodes[k])
+    return k, w
+
+
+def law_grad_theta_linear(law: Law, ph: Phys, Hbar, gradS, theta=None, n_interp_half=75):
+    """The `interpolation == :Linear` branch of dDiffusivity/dtheta for the Y law (target_D_hybrid.jl:136-160; the same
+    text serves dVelocity/dtheta, :321-345): d law / d theta evaluated exactly on the knots of create_interpolation(Hbar)
+    and interpolated linearly in Hbar at every dual node.  Shape (P, nx-1, ny-1)."""
+    if law.kind != LAW_NN_Y:
+        raise ValueError("linear interpolation of the law gradient is restated for the Y law (:D_hybrid) only")
+    th = law.theta if theta is None else theta
+    nodes = create_interpolation(Hbar, n_interp_half)
+    T = np.full_like(nodes, float(law.T))
+    G = mlp_grad_theta(law.mlp, th, np.stack([T, nodes]))  # (P, M): exact gradients at the knots
+    if nodes.size == 1:
+        return np.broadcast_to(G[:, :1, None], (G.shape[0],) + Hbar.shape).copy()
+    k, w = interp_linear_weights(nodes, Hbar)
+    return (1.0 - w)[None] * G[:, k] + w[None] * G[:, k + 1]
+
+
 def vjp_theta(lam, H, B, dx, dy, ph: Phys, law: Law, theta=None):
     """VJP_lambda_dSIA/dtheta_discrete (adjoint.jl:178-255):
     dtheta_k = sum_ij dD/dtheta_k[i,j] * D_adjoint[i,j]."""
@@ -593,7 +662,11 @@ def vjp_theta(lam, H, B, dx, dy, ph: Phys, law: Law, theta=None):
     spatial = dD_dlaw(law, ph, Hbar, gS) * Da
     if law.kind == LAW_CONST_A:
         return np.array([np.sum(spatial)])  # d/dA (one "parameter": A itself)
-    g = law_grad_theta(law, ph, Hbar, gS, theta)
+    kind, nhalf = law.interp()
+    if kind == "linear" and law.kind == LAW_NN_Y and Hbar.max() > 0.0:
+        g = law_grad_theta_linear(law, ph, Hbar, gS, theta, nhalf)  # the reference's default for :D_hybrid
+    else:
+        g = law_grad_theta(law, ph, Hbar, gS, theta)
     if law.kind == LAW_NN_A_SCALAR:
         return g.reshape(-1) * np.sum(spatial)  # cartesian_tensor (target_utils.jl:156-161)
     return np.tensordot(g, spatial, axes=([1, 2], [0, 1]))

@@ -734,3 +734,51 @@ def test_inlined_mlp_fused_step_matches_per_stage_and_oracle(gpu, monkeypatch, c
     assert sto.naccept == res[2][3]
     assert rel_l2(res[2][2], ref[1]) < 1e-10, case  # 5 steps of exp/log-laden arithmetic (device softplus: <= 2 ulp)
     assert np.abs(res[2][2] - H0).max() > 1e-6  # the steps moved the ice
+
+
+def test_Y_law_theta_gradient_interpolation_modes(gpu):
+    """∂Diffusivity∂θ of the Y law (target_D_hybrid.jl:98-166): the reference's default `interpolation = :Linear`
+    (gradients on the 2 n_interp_half knots of create_interpolation(H̄), interpolated linearly; on the device: sort by
+    H̄, per-interval fixed-order sums, contraction over knots) and `:None` (exact per node), each against the oracle's
+    restatement of the same branch; per-glacier knots in a batch; ice-free glacier; the default is :Linear(75)."""
+    ph = O.Phys()
+    om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+    shapes = [(80, 48), (131, 97), (40, 33)]
+    fields = []
+    for k, (nx, ny) in enumerate(shapes):
+        H0, B = (O.synthetic_icecap(nx, ny, 100.0) if k != 1 else O.synthetic_valley(nx, ny, 100.0))
+        fields.append((H0 * (0.4 if k != 1 else 1.0), B))
+    fields[2] = (np.zeros_like(fields[2][0]), fields[2][1])  # no ice at all
+    Ts = [-5.0, -2.0, -7.0]
+    b = gpu.GlacierBatch(shapes, [100.0] * 3, T=Ts)
+    for k, (H0, B) in enumerate(fields):
+        b.set_fields(k, H0, B)
+    b.set_law(gpu.LAW_NN_Y, gm, th)
+    rng = np.random.default_rng(5)
+    lams = [rng.standard_normal(s) for s in shapes]
+    for mode, n in (("default", 75), ("linear", 20), ("linear", 200), ("none", 0)):
+        if mode == "linear":
+            b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, n)
+        elif mode == "none":
+            b.set_grad_interpolation(gpu._lib.GRAD_INTERP_NONE, 75)
+        for k, (H0, B) in enumerate(fields):
+            law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=Ts[k], interpolation=None if mode == "default" else mode,
+                        n_interp_half=None if mode == "default" else n)
+            ref = O.vjp_theta(lams[k], H0, B, 100.0, 100.0, ph, law)
+            got = b.vjp_theta(k, lams[k], H0)
+            if k == 2:
+                assert np.all(got == 0.0) and np.all(ref == 0.0)
+            else:
+                assert rel_l2(got, ref) < 1e-10, (mode, n, k)
+    # the two branches differ by the interpolation error only
+    b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, 75)
+    gl = b.vjp_theta(0, lams[0], fields[0][0])
+    b.set_grad_interpolation(gpu._lib.GRAD_INTERP_NONE, 75)
+    gn = b.vjp_theta(0, lams[0], fields[0][0])
+    assert 1e-12 < rel_l2(gl, gn) < 5e-3
+    b.close()
+    # A-type and U laws keep the exact branch and reject the linear one
+    b = gpu.GlacierBatch([(40, 33)], [100.0])
+    with pytest.raises(gpu.OdinnError):
+        b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, 75)
+    b.close()
