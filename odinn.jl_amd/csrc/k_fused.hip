@@ -1,4 +1,5 @@
 // k_fused.hip -- temporally fused RDPK3Sp35 step for one law mode (-DODINN_LM=0|1|2)
+#include <cstdlib>
 #include "launch.hpp"
 #include "sia2d_fused.hpp"
 #ifndef ODINN_LM
@@ -27,8 +28,10 @@ void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev
 void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
                            double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc) {
   const ScArgs A = sc ? *sc : ScArgs{};
+  // measurement aid: ODINN_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the occupancy (A/B of waves per SIMD)
+  static const unsigned pad = std::getenv("ODINN_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ODINN_LDS_PAD")) : 0u;
 #define ODINN_STRIP(SK, AF, NR, SCV) \
-  hipLaunchKernelGGL((k_rk_fused_strip<SK, AF, NR, SCV>), dim3(nblk), dim3(TNT), 0, st, P, L, tilesF, U0, U1, partF, abstol, reltol, A)
+  hipLaunchKernelGGL((k_rk_fused_strip<SK, AF, NR, SCV>), dim3(nblk), dim3(TNT), pad, st, P, L, tilesF, U0, U1, partF, abstol, reltol, A)
 #define ODINN_STRIP_S(SK, AF, NR) \
   do { if (sc) ODINN_STRIP(SK, AF, NR, true); else ODINN_STRIP(SK, AF, NR, false); } while (0)
 #define ODINN_STRIP_R(SK, AF) \
