@@ -45,5 +45,15 @@ void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools
 #undef ODINN_STRIP_S
 #undef ODINN_STRIP
 }
+// RHS-only strip kernel on the DOX x DOY tile table
+void launch_dhdt_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, const int4* tilesD, const double* U, double* dH) {
+  if (afield) {
+    if (skip) hipLaunchKernelGGL((k_dhdt_strip<true, true>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, U, dH);
+    else hipLaunchKernelGGL((k_dhdt_strip<true, false>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, U, dH);
+  } else {
+    if (skip) hipLaunchKernelGGL((k_dhdt_strip<false, true>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, U, dH);
+    else hipLaunchKernelGGL((k_dhdt_strip<false, false>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, U, dH);
+  }
+}
 #endif
 }  // namespace odinn

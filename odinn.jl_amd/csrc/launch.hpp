@@ -27,6 +27,9 @@ ODINN_DECL_LM(5)
 void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
                            double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc = nullptr);
 
+void launch_dhdt_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, const int4* tilesD, const double* U, double* dH);
+constexpr int DHDT_OX = 62, DHDT_OY = 62;  // output tile of k_dhdt_strip (sia2d_fused.hpp: DOX, DOY)
+
 // k_adjf.hip, law mode 0 only
 void launch_adj_fused_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, AdjFusedArgs A);
 

@@ -133,6 +133,8 @@ struct odinn_batch {
   int* d_est = nullptr;        // per-glacier estimate of the steps still needed (written by the controller)
   std::vector<int> h_est;
   int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr, *d_tilesFu = nullptr;
+  int4* d_tilesD = nullptr;  // 62 x 62 tiles of the RHS-only strip kernel (all glaciers, XCD-banded)
+  int ntilesD = 0;
   int ntilesF = 0, ntilesFs = 0, ntilesFt = 0, ntilesFu = 0;
   double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr, *d_partFu = nullptr;
   static int sc_env() {  // ODINN_STEP_SC: -1 unset, 0 off, 1 forced on
@@ -436,6 +438,13 @@ int down_field(odinn_batch* b, int g, const double* dpool, double* h, bool dual 
 
 // ---- launches -------------------------------------------------------------------------
 int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */) {
+  // integer-power law, whole batch (or a batch of one glacier): the strip-layout RHS kernel; ODINN_DHDT_STRIP=0 keeps k_dhdt
+  static const bool strip_on = !(std::getenv("ODINN_DHDT_STRIP") && std::getenv("ODINN_DHDT_STRIP")[0] == '0');
+  if (strip_on && b->lm() == 0 && (g < 0 || b->G == 1)) {
+    launch_dhdt_strip(b->ntilesD, b->gd[0].use_Afield, 1, b->stream, b->pools(true), b->d_tilesD, U, dH);
+    HIPCHK(hipGetLastError());
+    return ODINN_OK;
+  }
   const Pools P = b->pools(g < 0);
   const int base = g < 0 ? 0 : b->gd[g].tile0, n = g < 0 ? b->ntiles : b->gd[g].ntiles;
   static void (*const tab[6])(int, hipStream_t, Pools, LawDev, const double*, double*, int) = {
@@ -971,6 +980,26 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
       HIPCHK(hipMemcpy(b->d_tilesF, swzF.data(), sizeof(int4) * nF, hipMemcpyHostToDevice));
     }
   }
+  {  // tile table of k_dhdt_strip
+    std::vector<int4> natD;
+    for (int g = 0; g < n_glaciers; ++g) {
+      const GDev& r = b->gd[g];
+      const int fx = (r.nx + DHDT_OX - 1) / DHDT_OX, fy = (r.ny + DHDT_OY - 1) / DHDT_OY;
+      for (int ty = 0; ty < fy; ++ty)
+        for (int tx = 0; tx < fx; ++tx) natD.push_back(make_int4(g, tx, ty, (int)natD.size()));
+    }
+    const int nD = (int)natD.size(), X = 8, per = (nD + X - 1) / X;
+    std::vector<int4> swzD;
+    swzD.reserve(nD);
+    for (int r = 0; r < per; ++r)
+      for (int x = 0; x < X; ++x) {
+        const int t = x * per + r;
+        if (t < nD) swzD.push_back(natD[t]);
+      }
+    b->ntilesD = nD;
+    CHK(dalloc(&b->d_tilesD, (size_t)nD));
+    HIPCHK(hipMemcpy(b->d_tilesD, swzD.data(), sizeof(int4) * nD, hipMemcpyHostToDevice));
+  }
   CHK(dalloc(&b->d_gd, n_glaciers));
   CHK(dalloc(&b->d_gs, n_glaciers));
   const size_t n = (size_t)b->ntot, nd = (size_t)b->ntotd;
@@ -997,6 +1026,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   if (!b) return ODINN_OK;
   (void)hipSetDevice(b->device);
   (void)hipStreamSynchronize(b->stream);
+  dfree(b->d_tilesD);
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);

@@ -838,4 +838,111 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
   }
 }
 
+// ================= RHS-only strip kernel (integer-power A law) ==================================
+// dH/dt = Huginn.SIA2D! (adjoint.jl:52-97) in the strip layout of k_rk_fused_strip: a wavefront owns DNR contiguous
+// rows of a 64-wide region, a thread one column of them; y-neighbours are the thread's own registers, x-neighbours
+// arrive by DPP, only the first and last row of a strip cross wavefronts (one LDS exchange, one barrier).  One RHS needs
+// a one-cell halo: 62 x 62 outputs per 64 x 64 region (1.07 x redundant work).  Against k_dhdt (64 x 16 LDS tiles,
+// {Hc,S} and D through LDS) the point is memory-level parallelism, not arithmetic: every thread has its 16 (24 with a
+// gridded A) loads in flight before the first use and the workgroup needs 16 KB of LDS instead of 28, so the kernel
+// sits closer to the HBM rate (PMC on k_dhdt past the Infinity Cache: 77 % of the wave time parked, 4.45 TB/s).
+// Same expressions per face and node as strip_stage (flux form); results equal k_dhdt's to rounding.
+constexpr int DNR = 8;                                   // rows per thread
+constexpr int DOX = FRX - 2, DOY = DNR * TNW - 2;        // 62 x 62 output tile
+template <bool AF, bool SKIP>
+__global__ __launch_bounds__(TNT, ODINN_FWPE) void k_dhdt_strip(Pools P, const int4* __restrict__ tilesD,
+                                                                const double* __restrict__ U, double* __restrict__ dH) {
+  __shared__ double2 sE[TNW][2][FRX];
+  const int4 t4 = tilesD[blockIdx.x];
+  const GDev g = P.gd[t4.x];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi0 = t4.y * DOX - 1, gj0 = t4.z * DOY - 1;
+  const int gi = gi0 + lane, r0 = DNR * w;
+  const bool inx = gi >= 0 && gi < g.nx;
+  const int id0 = gi + g.nx * (gj0 + r0);
+  const double* __restrict__ src = U + g.off;
+  const double* __restrict__ Bg = P.B + g.off;
+  double* __restrict__ dst = dH + g.off;
+  double u[DNR], bb[DNR];
+  [[maybe_unused]] double aa[AF ? DNR + 1 : 1];
+#pragma unroll
+  for (int m = 0; m < DNR; ++m) {
+    const int gj = gj0 + r0 + m;
+    const bool ok = inx && gj >= 0 && gj < g.ny;
+    bb[m] = ok ? ldg32(Bg, (unsigned)(id0 + g.nx * m)) : 0.0;
+    u[m] = ok ? ldg32(src, (unsigned)(id0 + g.nx * m)) : 0.0;
+  }
+  const double Gq = g.Gam * (1.0 / 1024.0) * (g.hinv_dx * g.hinv_dx), ryx = (g.hinv_dy * g.hinv_dy) / (g.hinv_dx * g.hinv_dx);
+  if (AF) {  // A on the node rows r0-1 .. r0+DNR-1 of the thread's column (0 outside the dual grid: such nodes only feed masked cells)
+    const double* __restrict__ Afg = P.Afield + g.offd;
+    const bool nodex = gi >= 0 && gi <= g.nx - 2;
+#pragma unroll
+    for (int m = 0; m <= DNR; ++m) {
+      const int gj = gj0 + r0 - 1 + m;
+      const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+      aa[AF ? m : 0] = ok ? ldg32(Afg, (unsigned)(gi + (g.nx - 1) * gj)) : 0.0;
+    }
+  }
+  bool nz = false;
+#pragma unroll
+  for (int m = 0; m < DNR; ++m) nz = nz || (u[m] > 0.0);
+  sE[w][0][lane] = cell_HS(u[0], bb[0]);
+  sE[w][1][lane] = cell_HS(u[DNR - 1], bb[DNR - 1]);
+  const bool ocol = lane >= 1 && lane <= DOX && inx;
+  const bool intx = gi >= 1 && gi <= g.nx - 2;
+  if (SKIP) {
+    // no ice on the whole region: every clamped slope and D vanish, dH/dt = 0 exactly (k_dhdt's shortcut)
+    if (!__syncthreads_or(nz)) {
+      if (ocol) {
+#pragma unroll
+        for (int m = 0; m < DNR; ++m) {
+          const int r = r0 + m, gj = gj0 + r;
+          if (r >= 1 && r <= DOY && gj < g.ny) stg32(dst, (unsigned)(id0 + g.nx * m), 0.0);
+        }
+      }
+      return;
+    }
+  } else {
+    __syncthreads();
+  }
+  const double AGq = g.A * Gq;
+  auto node = [&](int slot, double dxb, double hpb, double dxt, double hpt, double dyw, double dye) {
+    const double a = dxb + dxt, b = dyw + dye;
+    const double H4s = hpb + hpt;  // 4 Hbar
+    const double gS2 = fma(a, a, (ryx * b) * b);
+    const double H2 = H4s * H4s, H4 = H2 * H2;
+    return (AF ? aa[AF ? slot : 0] * Gq : AGq) * (H4 * H4s) * gS2;
+  };
+  auto face = [&](double Da, double Db, double slope, double Hhi, double Hlo) { return (Da + Db) * clampn(slope, Hhi, Hlo); };
+  const double2 hs_s = sE[w > 0 ? w - 1 : 0][w > 0 ? 1 : 0][lane];
+  const double2 hs_top = sE[w + 1 < TNW ? w + 1 : w][w + 1 < TNW ? 0 : 1][lane];
+  double2 hs_c = cell_HS(u[0], bb[0]);
+  double2 e_c = dpp_from_east(hs_c);
+  double dx_c = e_c.y - hs_c.y, hp_c = hs_c.x + e_c.x;
+  double D_s, F_s;
+  {
+    const double2 e_s = dpp_from_east(hs_s);
+    const double dyw = hs_c.y - hs_s.y;
+    D_s = node(0, e_s.y - hs_s.y, hs_s.x + e_s.x, dx_c, hp_c, dyw, e_c.y - e_s.y);
+    F_s = face(dpp_from_west(D_s), D_s, dyw, hs_c.x, hs_s.x);
+  }
+#pragma unroll
+  for (int m = 0; m < DNR; ++m) {
+    const int r = r0 + m, gj = gj0 + r;
+    const double2 hs_n = m + 1 < DNR ? cell_HS(u[m + 1 < DNR ? m + 1 : m], bb[m + 1 < DNR ? m + 1 : m]) : hs_top;
+    const double2 e_n = dpp_from_east(hs_n);
+    const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, dyw = hs_n.y - hs_c.y;
+    const double D_c = node(m + 1, dx_c, hp_c, dx_n, hp_n, dyw, e_n.y - e_c.y);
+    const double F_e = face(D_s, D_c, dx_c, e_c.x, hs_c.x);
+    const double F_n = face(dpp_from_west(D_c), D_c, dyw, hs_n.x, hs_c.x);
+    const double F_w = dpp_from_west(F_e);
+    double k = fma(g.hinv_dx2, F_e - F_w, g.hinv_dy2 * (F_n - F_s));
+    k = (intx && gj >= 1 && gj <= g.ny - 2) ? k : 0.0;  // zero on the boundary ring (adjoint.jl:52-97: dH only on the interior)
+    if (ocol && r >= 1 && r <= DOY && gj < g.ny) stg32(dst, (unsigned)(id0 + g.nx * m), k);
+    hs_c = hs_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; D_s = D_c; F_s = F_n;
+    asm volatile("" : "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(dx_c), "+v"(hp_c), "+v"(D_s), "+v"(F_s));
+  }
+}
+
 }  // namespace odinn
