@@ -55,5 +55,10 @@ void launch_dhdt_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, 
     else hipLaunchKernelGGL((k_dhdt_strip<false, false>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, U, dH);
   }
 }
+// CFL-limited explicit Euler step (scheme 3) in the same layout: dst = u + dt k, partD[tile] = max D
+void launch_euler_cfl_strip(int nblk, int afield, hipStream_t st, Pools P, const int4* tilesD, const double* src, double* dst, double* partD) {
+  if (afield) hipLaunchKernelGGL((k_dhdt_strip<true, true, true>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, src, dst, partD);
+  else hipLaunchKernelGGL((k_dhdt_strip<false, true, true>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, src, dst, partD);
+}
 #endif
 }  // namespace odinn

@@ -28,6 +28,7 @@ void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools
                            double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc = nullptr);
 
 void launch_dhdt_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, const int4* tilesD, const double* U, double* dH);
+void launch_euler_cfl_strip(int nblk, int afield, hipStream_t st, Pools P, const int4* tilesD, const double* src, double* dst, double* partD);
 constexpr int DHDT_OX = 62, DHDT_OY = 62;  // output tile of k_dhdt_strip (sia2d_fused.hpp: DOX, DOY)
 
 // k_adjf.hip, law mode 0 only

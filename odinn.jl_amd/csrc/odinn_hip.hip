@@ -134,6 +134,7 @@ struct odinn_batch {
   std::vector<int> h_est;
   int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr, *d_tilesFu = nullptr;
   int4* d_tilesD = nullptr;  // 62 x 62 tiles of the RHS-only strip kernel (all glaciers, XCD-banded)
+  double* d_partD = nullptr; // per-tile max D of the CFL Euler step in that layout
   int ntilesD = 0;
   int ntilesF = 0, ntilesFs = 0, ntilesFt = 0, ntilesFu = 0;
   double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr, *d_partFu = nullptr;
@@ -483,7 +484,17 @@ void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L,
   tab[b->lm()](nblk, b->stream, P, L, A, base);
 }
 
+// integer-power law: the CFL Euler step runs in the strip layout (k_dhdt_strip<.., EULER>) with its own tile table and
+// per-tile max-D partials; ODINN_DHDT_STRIP=0 keeps the 64 x 16 tile kernel
+static bool euler_strip(const odinn_batch* b) {
+  static const bool on = !(std::getenv("ODINN_DHDT_STRIP") && std::getenv("ODINN_DHDT_STRIP")[0] == '0');
+  return on && b->lm() == 0;
+}
 void launch_euler_cfl(odinn_batch* b, const Pools& P, const LawDev& L, const double* src, double* dst) {
+  if (euler_strip(b)) {
+    launch_euler_cfl_strip(b->ntilesD, b->gd[0].use_Afield, b->stream, P, b->d_tilesD, src, dst, b->d_partD);
+    return;
+  }
   static void (*const tab[6])(int, hipStream_t, Pools, LawDev, const double*, double*) = {
       launch_euler_cfl_lm0, launch_euler_cfl_lm1, launch_euler_cfl_lm2, launch_euler_cfl_lm3, launch_euler_cfl_lm4,
       launch_euler_cfl_lm5};
@@ -737,6 +748,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   C.dtmax = opt.dtmax; C.adaptive = adaptive ? 1 : 0; C.fixed_dt = opt.fixed_dt; C.n_active = b->d_nactive;
   C.errpart = scheme == 2 ? b->fused_part() : b->d_part;
   C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? b->fused_ctrl() : 0;
+  if (euler && euler_strip(b)) { C.errpart = b->d_partD; C.stride = 1; C.fused = 5; }  // max-D partials of the strip-layout Euler step
   PostArgs A{};
   A.snaps = b->d_snaps; A.premb = b->d_premb; A.ntot = b->ntot; A.mb0 = b->d_mb0;
   A.Sref = b->any_sref ? b->d_Sref : nullptr;
@@ -983,8 +995,9 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   {  // tile table of k_dhdt_strip
     std::vector<int4> natD;
     for (int g = 0; g < n_glaciers; ++g) {
-      const GDev& r = b->gd[g];
+      GDev& r = b->gd[g];
       const int fx = (r.nx + DHDT_OX - 1) / DHDT_OX, fy = (r.ny + DHDT_OY - 1) / DHDT_OY;
+      r.tile0D = (int)natD.size(); r.ntilesD = fx * fy;
       for (int ty = 0; ty < fy; ++ty)
         for (int tx = 0; tx < fx; ++tx) natD.push_back(make_int4(g, tx, ty, (int)natD.size()));
     }
@@ -998,6 +1011,7 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
       }
     b->ntilesD = nD;
     CHK(dalloc(&b->d_tilesD, (size_t)nD));
+    CHK(dalloc(&b->d_partD, (size_t)nD));
     HIPCHK(hipMemcpy(b->d_tilesD, swzD.data(), sizeof(int4) * nD, hipMemcpyHostToDevice));
   }
   CHK(dalloc(&b->d_gd, n_glaciers));
@@ -1026,7 +1040,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   if (!b) return ODINN_OK;
   (void)hipSetDevice(b->device);
   (void)hipStreamSynchronize(b->stream);
-  dfree(b->d_tilesD);
+  dfree(b->d_tilesD); dfree(b->d_partD);
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);

@@ -108,6 +108,7 @@ struct GDev {  // per-glacier constants
   int tile0Fs, ntilesFs; // ... and in the table of FOX x FOYS "latency" tiles
   int tile0Ft, ntilesFt; // ... and in the table of FOX x FOYT "strip" tiles
   int tile0Fu, ntilesFu; // ... and in the table of FOX x FOYT8 strip tiles (forward kernel, 8 rows per thread)
+  int tile0D, ntilesD;   // ... and in the table of 62 x 62 tiles of the RHS-only / CFL-Euler strip kernel
   long long off;   // offset of this glacier in the pooled primal arrays  [doubles]
   long long offd;  // offset in the pooled dual arrays
   double dx, dy, inv_dx, inv_dy, eta0;
@@ -988,8 +989,8 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   const GDev g = P.gd[gidx];
   double s = 0.0;
   {
-    const int t0 = C.fused == 4 ? g.tile0Fu : C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
-    const int nt = C.fused == 4 ? g.ntilesFu : C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
+    const int t0 = C.fused == 5 ? g.tile0D : C.fused == 4 ? g.tile0Fu : C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
+    const int nt = C.fused == 5 ? g.ntilesD : C.fused == 4 ? g.ntilesFu : C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
     if (C.cfl > 0.0) {
       for (int k = threadIdx.x; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
     } else {

@@ -849,11 +849,22 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
 // Same expressions per face and node as strip_stage (flux form); results equal k_dhdt's to rounding.
 constexpr int DNR = 8;                                   // rows per thread
 constexpr int DOX = FRX - 2, DOY = DNR * TNW - 2;        // 62 x 62 output tile
-template <bool AF, bool SKIP>
+// EULER: the north star's "CFL mode" (scheme 3, k_euler_cfl's contract): dH holds u' = u + dt k with the glacier's dt
+// from its GState, and partD[tile] = max D over the tile's nodes (wavefront max -> LDS -> one partial per tile, reduced
+// in a fixed order by the controller, which sets the next dt = cfl min(dx,dy)^2 / (4 max D)).
+template <bool AF, bool SKIP, bool EULER = false>
 __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_dhdt_strip(Pools P, const int4* __restrict__ tilesD,
-                                                                const double* __restrict__ U, double* __restrict__ dH) {
+                                                                const double* __restrict__ U, double* __restrict__ dH,
+                                                                double* __restrict__ partD = nullptr) {
   __shared__ double2 sE[TNW][2][FRX];
+  __shared__ double redD[TNW];
   const int4 t4 = tilesD[blockIdx.x];
+  double dt = 0.0;
+  if (EULER) {
+    const GState* gs = P.gs + t4.x;
+    if (gs->done) return;
+    dt = gs->dt;
+  }
   const GDev g = P.gd[t4.x];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -898,9 +909,10 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_dhdt_strip(Pools P, const i
 #pragma unroll
         for (int m = 0; m < DNR; ++m) {
           const int r = r0 + m, gj = gj0 + r;
-          if (r >= 1 && r <= DOY && gj < g.ny) stg32(dst, (unsigned)(id0 + g.nx * m), 0.0);
+          if (r >= 1 && r <= DOY && gj < g.ny) stg32(dst, (unsigned)(id0 + g.nx * m), EULER ? u[m] : 0.0);
         }
       }
+      if (EULER && threadIdx.x == 0) partD[t4.w] = 0.0;
       return;
     }
   } else {
@@ -921,6 +933,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_dhdt_strip(Pools P, const i
   double2 e_c = dpp_from_east(hs_c);
   double dx_c = e_c.y - hs_c.y, hp_c = hs_c.x + e_c.x;
   double D_s, F_s;
+  [[maybe_unused]] double dmax = 0.0;
   {
     const double2 e_s = dpp_from_east(hs_s);
     const double dyw = hs_c.y - hs_s.y;
@@ -939,9 +952,23 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_dhdt_strip(Pools P, const i
     const double F_w = dpp_from_west(F_e);
     double k = fma(g.hinv_dx2, F_e - F_w, g.hinv_dy2 * (F_n - F_s));
     k = (intx && gj >= 1 && gj <= g.ny - 2) ? k : 0.0;  // zero on the boundary ring (adjoint.jl:52-97: dH only on the interior)
-    if (ocol && r >= 1 && r <= DOY && gj < g.ny) stg32(dst, (unsigned)(id0 + g.nx * m), k);
+    const bool outc = ocol && r >= 1 && r <= DOY && gj < g.ny;
+    if (outc) stg32(dst, (unsigned)(id0 + g.nx * m), EULER ? fma(dt, k, u[m]) : k);
+    // the node north-east of an output cell, where it exists (every dual node belongs to exactly one output cell)
+    if (EULER && outc && gi <= g.nx - 2 && gj <= g.ny - 2) dmax = fmax(dmax, D_c);
     hs_c = hs_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; D_s = D_c; F_s = F_n;
     asm volatile("" : "+v"(hs_c.x), "+v"(hs_c.y), "+v"(e_c.x), "+v"(e_c.y), "+v"(dx_c), "+v"(hp_c), "+v"(D_s), "+v"(F_s));
+  }
+  if (EULER) {
+    dmax = wave_max(dmax);
+    if (lane == 0) redD[w] = dmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double mx = 0.0;
+#pragma unroll
+      for (int k = 0; k < TNW; ++k) mx = fmax(mx, redD[k]);
+      partD[t4.w] = mx;
+    }
   }
 }
 
