@@ -33,7 +33,7 @@ void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools
 #define ODINN_STRIP(SK, AF, NR, SCV) \
   hipLaunchKernelGGL((k_rk_fused_strip<SK, AF, NR, SCV>), dim3(nblk), dim3(TNT), pad, st, P, L, tilesF, U0, U1, partF, abstol, reltol, A)
 #define ODINN_STRIP_S(SK, AF, NR) \
-  do { if (sc) ODINN_STRIP(SK, AF, NR, true); else ODINN_STRIP(SK, AF, NR, false); } while (0)
+  do { if (sc && !sc->snap_on_load) ODINN_STRIP(SK, AF, NR, true); else ODINN_STRIP(SK, AF, NR, false); } while (0)
 #define ODINN_STRIP_R(SK, AF) \
   do { if (rows == 8) ODINN_STRIP_S(SK, AF, 8); else ODINN_STRIP_S(SK, AF, TRPT); } while (0)
   if (afield) {

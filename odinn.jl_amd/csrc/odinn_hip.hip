@@ -566,6 +566,14 @@ static bool sc_mode(const odinn_batch* b, int scheme) {
   if (const char* e = std::getenv("ODINN_STEP_SC")) return e[0] == '1';
   return b->fused_ntiles() <= 1600;
 }
+// Large batches (no self-controlled loop) without a mass balance: the strip step kernel stores the snapshot of a stop
+// from the state it loads (ScArgs::snap_on_load), so a step is TWO dependent launches (step kernel, controller) instead of
+// three; the snapshot of the LAST stop (after which no launch loads the state again) is a device copy at the end of the
+// solve.  ODINN_SNAP_ON_LOAD=0 restores the post-step launch.
+static bool snap_on_load_mode(const odinn_batch* b, int scheme, bool sc) {
+  const char* e = std::getenv("ODINN_SNAP_ON_LOAD");  // read per call: tests toggle it
+  return !(e && e[0] == '0') && scheme == 2 && !sc && b->fused_kind() >= 2 && !b->any_mb;
+}
 static int sc_buffers(odinn_batch* b) {
   if (!b->d_gs2) CHK(dalloc(&b->d_gs2, (size_t)b->G));
   const size_t need = (size_t)std::max(b->ntilesFt, b->ntilesFu);
@@ -764,6 +772,9 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   // poll and no wasted launches); afterwards 16, with parity kept even for the ping-pong buffers
   const bool sc = !euler && sc_mode(b, scheme);
   if (sc) CHK(sc_buffers(b));
+  const bool snapload = !euler && snap_on_load_mode(b, scheme, sc);
+  ScArgs SL{};
+  SL.snaps = b->d_snaps; SL.ntot = b->ntot; SL.snap_on_load = 1;
   long long steps = 0;
   int p = 0;
   int chunk = std::max(2, std::min(256, (n_stops - 1 + 1) & ~1));
@@ -791,14 +802,14 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
         ++steps;
         continue;
       } else if (scheme == 2) {
-        CHK(launch_fused_step(b, opt.abstol, opt.reltol, opt.dense ? 0 : 1));
+        CHK(launch_fused_step(b, opt.abstol, opt.reltol, opt.dense ? 0 : 1, snapload ? &SL : nullptr));
         C.next_cur = -1;
       } else {
         CHK(launch_step(b, p, opt.abstol, opt.reltol));
         C.next_cur = 1 - p;
       }
       launch_controller(b->G, b->stream, P, C);
-      launch_poststep(b->ntiles, b->stream, P, A, b->d_U[0], b->d_U[1]);
+      if (!snapload) launch_poststep(b->ntiles, b->stream, P, A, b->d_U[0], b->d_U[1]);
       p = 1 - p;
       ++steps;
     }
@@ -828,6 +839,12 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
     tp4 = now();
     std::fprintf(stderr, "[odinn do_solve] setup %.0f us, initdt+begin %.0f us, steps(%lld) %.0f us, state readback %.0f us\n",
                  tp1 - tp0, tp2 - tp1, steps, tp3 - tp2, tp4 - tp3);
+  }
+  if (snapload) {
+    // the last stop's snapshot of the glacier(s) decided by the very last controller call: one more launch of the step
+    // kernel, in which finished glaciers only store what is pending (no controller behind it)
+    CHK(launch_fused_step(b, opt.abstol, opt.reltol, opt.dense ? 0 : 1, &SL));
+    HIPCHK(hipStreamSynchronize(b->stream));
   }
   for (int g = 0; g < b->G; ++g) {
     if (gs[g].nonfinite) return fail(ODINN_ERR_NONFINITE, "non-finite error estimate in glacier %d", g);
@@ -2219,15 +2236,19 @@ static int timed_one(odinn_batch* b, int which, int it) {
       C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? b->fused_ctrl() : 0;
       PostArgs PA;
       PA.snaps = b->d_tmpA; PA.premb = b->d_tmpB; PA.ntot = b->ntot; PA.mb0 = b->d_mb0; PA.Sref = nullptr;
+      // exactly what do_solve enqueues per step for this batch: with snapshot-on-load there is no post-step launch
+      const bool snapload = snap_on_load_mode(b, scheme, false) && !sc_mode(b, scheme);
+      ScArgs SL{};
+      SL.snaps = b->d_tmpA; SL.ntot = b->ntot; SL.snap_on_load = 1;
       if (scheme == 2) {
-        CHK(launch_fused_step(b, 1e-6, 1e-8, 0));
+        CHK(launch_fused_step(b, 1e-6, 1e-8, 0, snapload ? &SL : nullptr));
         C.next_cur = -1;
       } else {
         CHK(launch_step(b, it & 1, 1e-6, 1e-8));
         C.next_cur = 1 - (it & 1);
       }
       launch_controller(b->G, b->stream, P, C);
-      launch_poststep(b->ntiles, b->stream, P, PA, b->d_U[0], b->d_U[1]);
+      if (!snapload) launch_poststep(b->ntiles, b->stream, P, PA, b->d_U[0], b->d_U[1]);
       return ODINN_OK;
     }
     case ODINN_TIMED_DHDT: return launch_dhdt(b, b->d_U[0], b->d_tmpB, -1);

@@ -962,6 +962,9 @@ struct ScArgs {
   double* premb;          // mass balance at a stop (applied on load): pre-MB snapshots, pooled MB fields
   const double* mb0;
   const double* Sref;     // (nullable)
+  int snap_on_load;       // 1: NOT the self-controlled loop -- the controller kernel decides as usual, but the step kernel
+                          // stores the snapshot of a stop the previous step reached (gs->at_stop) from the state it loads,
+                          // which replaces the post-step launch of batches without a mass balance
 };
 
 // interpolation weights of H_itp at the five stage times of the step [tau, tau + dt]

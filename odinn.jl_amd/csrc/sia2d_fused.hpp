@@ -719,10 +719,15 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     if (finished && snap_slot < 0) return;
   } else {
     const GState* gs = P.gs + t4.x;
-    if (gs->done) return;
+    // snapshot on load (ScArgs::snap_on_load): the step the controller just accepted landed on a stop -- this launch
+    // loads exactly that state, so every workgroup stores its own output cells of it (no post-step launch).  A glacier
+    // that has just finished does only that (the controller clears at_stop of a finished glacier at its next call).
+    const bool snap = A.snap_on_load && gs->at_stop;
+    if (gs->done && !snap) return;
     dt = gs->dt;
     cur = gs->cur;
-    finished = false;
+    finished = gs->done != 0;
+    if (snap) snap_slot = gs->istop - 1;
   }
   // everything below is addressed relative to the glacier's first cell (block-uniform bases, 32-bit cell indices)
   const double* __restrict__ src = (cur ? U1 : U0) + g.off;
@@ -766,7 +771,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
 #pragma unroll
     for (int m = 0; m < NR; ++m) sUp[UPL ? m : 0][threadIdx.x] = u[m];
   }
-  if (SC && snap_slot >= 0) {  // snapshot of the stop just reached: this workgroup's output cells of the accepted state
+  if (snap_slot >= 0) {  // snapshot of the stop just reached: this workgroup's output cells of the accepted state
     double* __restrict__ sn = A.snaps + (long long)snap_slot * A.ntot + g.off;
     if (lane >= FH && lane < FH + FOX && inx) {
 #pragma unroll

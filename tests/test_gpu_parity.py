@@ -782,3 +782,33 @@ def test_Y_law_theta_gradient_interpolation_modes(gpu):
     with pytest.raises(gpu.OdinnError):
         b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, 75)
     b.close()
+
+
+def test_snapshot_on_load_matches_the_post_step_launch(gpu, monkeypatch):
+    """Large batches without a mass balance run TWO launches per step (step kernel, controller): the strip kernel stores
+    the snapshot of a stop from the state it loads, finished glaciers flush theirs in the next launch.  Bit-identical
+    snapshots, step counts and final states to the three-launch loop (ODINN_SNAP_ON_LOAD=0), ragged glaciers that finish
+    at different launches, 7- and 8-row tiles."""
+    monkeypatch.setenv("ODINN_STEP_SC", "0")
+    shapes = [(130, 97), (54, 46), (201, 103), (70, 57)]
+    As = [4e-17, 1e-17, 6e-17, 2e-17]
+    ts = [2010.0 + j / 24.0 for j in range(7)]
+    for tiles in ("t", "u"):
+        monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("ODINN_SNAP_ON_LOAD", mode)
+            b = gpu.GlacierBatch(shapes, [50.0] * 4, A=As)
+            for k, (nx, ny) in enumerate(shapes):
+                b.set_fields(k, *O.synthetic_valley(nx, ny, 50.0))
+            st = b.solve(ts, reltol=1e-8)
+            out[mode] = ([(s.naccept, s.nreject) for s in st], [[b.snapshot(k, j) for j in range(len(ts))] for k in range(4)],
+                         [b.H(k) for k in range(4)])
+            b.close()
+        assert out["1"][0] == out["0"][0]
+        assert len({c for c in out["1"][0]}) > 1  # the glaciers really finish at different launches
+        for k in range(4):
+            for j in range(len(ts)):
+                assert np.array_equal(out["1"][1][k][j], out["0"][1][k][j]), (tiles, k, j)
+            assert np.array_equal(out["1"][2][k], out["0"][2][k])
+            assert np.abs(out["1"][1][k][-1] - out["1"][1][k][0]).max() > 0
