@@ -9,8 +9,9 @@ hoisted into a dual-grid A field once per theta exactly as the reference evaluat
 (src/laws/Laws.jl:339-358).
 
 A "step" is one pass of the hot path over that batch exactly as odinn_solve launches it: one
-RDPK3Sp35 time step (5 RHS + stage updates per cell) + the controller (error-norm reduction, PID)
-+ the post-step kernel.  One cell-step = one cell through one fused RHS + stage update, so a step
+RDPK3Sp35 time step (5 RHS + stage updates per cell) + the controller (error-norm reduction, PID);
+a stop's snapshot is stored by the next step launch from the state it loads (batches with a mass
+balance launch a post-step kernel as well).  One cell-step = one cell through one fused RHS + stage update, so a step
 is 5 * cells cell-steps.  The timed region also contains ONE evaluation of the hoisted law (what a
 solve pays once per theta).  `value` is measured with the exact ice-free-tile shortcut OFF (dense
 work); what odinn_solve runs by default (shortcut on) is in aux.
@@ -512,7 +513,7 @@ def main():
             "config": {
                 "workload": f"{G} synthetic {n}x{n} fp64 ice caps per GPU (BASELINE configs[4] per-GPU share) with the configs[2] law "
                             "A = NN_theta(T) (2 hidden layers x 16 units, gridded T, hoisted once per theta as the reference's LawA); "
-                            "one RDPK3Sp35 step (5 cell-steps per cell) = RK step kernel + controller + post-step; the timed region "
+                            "one RDPK3Sp35 step (5 cell-steps per cell) = RK step kernel + controller, exactly odinn_solve's launch sequence for this batch; the timed region "
                             "includes one evaluation of the hoisted law",
                 "glaciers_per_gpu": G,
                 "grid": [n, n],
