@@ -154,8 +154,18 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         odinn.api._DIST.update(init=True, rank=rank, world=world, local=local, device=red_dev)
+        comm_note = "torch.distributed (" + backend + ")"
         if backend == "nccl":  # the all-reduce of [loss, dtheta] runs inside libodinn_hip (odinn_comm_*, RCCL over xGMI)
-            odinn.api.attach_rccl_comm(local)
+            try:
+                odinn.api.attach_rccl_comm(local)
+                comm_note = "libodinn_hip odinn_comm_* (ncclAllReduce inside the library)"
+            except Exception as e:  # never lose the scaling line to the communicator: torch's RCCL group reduces instead
+                odinn.api._DIST["comm"] = None
+                comm_note = f"torch.distributed (nccl); odinn_comm_init_rank failed: {str(e)[:160]}"
+            ok = torch.tensor([1.0 if odinn.api._DIST.get("comm") is not None else 0.0], device=red_dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks use the same path
+            if float(ok.item()) == 0.0:
+                odinn.api._DIST["comm"] = None
     if odinn.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
 
@@ -202,6 +212,8 @@ def main():
     # ---- the same launches bracketed by HIP events on the library's own stream ----------------------
     ev = lambda which, iters=30, warmup=5: b.time_kernel(which, iters=iters, warmup=warmup)
     aux = {}
+    if world > 1:
+        aux["loss_grad_allreduce"] = comm_note
     ms_step_nn = ev(T.TIMED_SOLVE_STEP, args.steps, args.warmup)
     ms_fused_nn = ev(T.TIMED_FUSED_STEP)
     ms_fused_nn_skip = ev(T.TIMED_FUSED_STEP_SKIP)
