@@ -498,6 +498,33 @@ __device__ __forceinline__ double mlp_eval_lm(const LawDev& L, double x0, double
   else return mlp_eval_any(L, x0, x1);
 }
 
+// ---- powers with a per-glacier (wave-uniform) exponent -----------------------------------------
+// The exponents of the diffusivity (n + 2, n - 1, p - q + 1, ... -- target_A.jl:25-61) are physical constants of a
+// glacier, in practice small integers (n = 3, p = 3, q = 0 or 1).  ocml's pow costs ~280 fp64 instructions; with a
+// uniform small integer exponent the power is a product chain under a scalar branch (<= 6 multiplications,
+// |error| <= a few ulp; 0^0 = 1 as in Julia).  Anything else falls through to pow.
+__device__ __forceinline__ double upow(double x, double e) {
+  const int k = (int)e;
+  if ((double)k == e && k >= 0 && k <= 16) {  // wave-uniform
+    double r = 1.0, b = x;
+    for (int kk = k; kk; kk >>= 1) {
+      if (kk & 1) r *= b;
+      b *= b;
+    }
+    return r;
+  }
+  return pow(x, e);
+}
+// |grad S|^e from |grad S|^2: even exponents need no square root at all
+__device__ __forceinline__ double spow(double gS2, double e) {
+  const int k = (int)e;
+  if ((double)k == e && k >= 0 && k <= 16) {  // wave-uniform
+    const double h = upow(gS2, (double)(k >> 1));
+    return (k & 1) ? h * sqrt(gS2) : h;
+  }
+  return pow(sqrt(gS2), e);
+}
+
 // ---- diffusivity on one dual node ---------------------------------------------------
 // Returns D.  For the adjoint (ADJ) also alpha = dD/dHbar and beta (the reference's
 // "dD/dgradH", i.e. (dD/d|gradS|)/|gradS| for the closed forms) -- target_A.jl:16-62,
@@ -518,50 +545,49 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
       }
       return AG * H5 * gS2;
     }
-    const double gS = sqrt(gS2);
-    const double hn2 = pow(Hb, g.n + 2.0), sn1 = pow(gS, g.n - 1.0);
+    const double hn2 = upow(Hb, g.n + 2.0), sn1 = spow(gS2, g.n - 1.0);
     double D = Anode * g.Gam * hn2 * sn1;
     double hs = 0.0, sp1 = 0.0;
     if (g.Sc != 0.0) {
-      hs = pow(Hb, g.p - g.q + 1.0);
-      sp1 = pow(gS, g.p - 1.0);
+      hs = upow(Hb, g.p - g.q + 1.0);
+      sp1 = spow(gS2, g.p - 1.0);
       D += g.Sc * hs * sp1;
     }
     if (ADJ) {
-      alpha = Anode * g.Gam * (g.n + 2.0) * pow(Hb, g.n + 1.0) * sn1;
-      beta = Anode * g.Gam * (g.n - 1.0) * hn2 * pow(gS, g.n - 3.0);
+      alpha = Anode * g.Gam * (g.n + 2.0) * upow(Hb, g.n + 1.0) * sn1;
+      beta = Anode * g.Gam * (g.n - 1.0) * hn2 * spow(gS2, g.n - 3.0);
       if (g.Sc != 0.0) {
-        alpha += (g.p - g.q + 1.0) * g.Sc * pow(Hb, g.p - g.q) * sp1;
-        beta += g.Sc * (g.p - 1.0) * hs * pow(gS, g.p - 3.0);
+        alpha += (g.p - g.q + 1.0) * g.Sc * upow(Hb, g.p - g.q) * sp1;
+        beta += g.Sc * (g.p - 1.0) * hs * spow(gS2, g.p - 3.0);
       }
       spat = g.Gam * hn2 * sn1;
     }
     return D;
   }
-  const double gS = sqrt(gS2);
   // On ice-free nodes (Hbar == 0) D, alpha, beta and the theta-weight vanish identically
   // (every term carries a positive power of Hbar), so the MLP is not evaluated there.
   const bool ice = Hb > 0.0;
   if (L.kind == 3) {  // Y law, :D_hybrid
     const double Y = ice ? mlp_eval_lm<LM>(L, g.T, Hb) : 0.0;
-    const double geo = g.Gam * pow(Hb, g.nH + 2.0) * pow(gS, g.nS - 1.0);
+    const double sS1 = spow(gS2, g.nS - 1.0);
+    const double geo = g.Gam * upow(Hb, g.nH + 2.0) * sS1;
     double D = Y * geo;
     double hs = 0.0, sp1 = 0.0;
     if (g.Sc != 0.0) {
-      hs = pow(Hb, g.p - g.q + 1.0);
-      sp1 = pow(gS, g.p - 1.0);
+      hs = upow(Hb, g.p - g.q + 1.0);
+      sp1 = spow(gS2, g.p - 1.0);
       D += g.Sc * hs * sp1;
     }
     if (ADJ) {
       const double dH = 1e-4;  // target_D_hybrid.jl:58
       const double Yp = ice ? mlp_eval_lm<LM>(L, g.T, Hb + dH) : 0.0;
       const double slide = g.Sc != 0.0 ? g.Sc * hs * sp1 : 0.0;
-      alpha = (g.nH + 2.0) * Y * g.Gam * pow(Hb, g.nH + 1.0) * pow(gS, g.nS - 1.0) +
+      alpha = (g.nH + 2.0) * Y * g.Gam * upow(Hb, g.nH + 1.0) * sS1 +
               ((slide + Yp * geo) - (slide + Y * geo)) / dH;
-      beta = g.Gam * Y * (g.nS - 1.0) * pow(Hb, g.nH + 2.0) * pow(gS, g.nS - 3.0);
+      beta = g.Gam * Y * (g.nS - 1.0) * upow(Hb, g.nH + 2.0) * spow(gS2, g.nS - 3.0);
       if (g.Sc != 0.0) {
-        alpha += (g.p - g.q + 1.0) * g.Sc * pow(Hb, g.p - g.q) * sp1;
-        beta += g.Sc * (g.p - 1.0) * hs * pow(gS, g.p - 3.0);
+        alpha += (g.p - g.q + 1.0) * g.Sc * upow(Hb, g.p - g.q) * sp1;
+        beta += g.Sc * (g.p - 1.0) * hs * spow(gS2, g.p - 3.0);
       }
       spat = geo;
     }
@@ -572,6 +598,7 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
     if (ADJ) { alpha = 0.0; beta = 0.0; spat = 0.0; }
     return 0.0;
   }
+  const double gS = sqrt(gS2);
   const double U = mlp_eval_lm<LM>(L, Hb, gS);
   if (ADJ) {
     const double dH = 1e-4, dS = 1e-6;  // target_D_pure.jl:109,125
@@ -1728,9 +1755,9 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
         const double H2 = Hb * Hb;
         spat = g.Gam * (H2 * H2 * Hb) * gS2;
       } else if (LM == LM_POW) {
-        spat = g.Gam * pow(Hb, g.n + 2.0) * pow(sqrt(gS2), g.n - 1.0);
+        spat = g.Gam * upow(Hb, g.n + 2.0) * spow(gS2, g.n - 1.0);
       } else if (L.kind == 3) {
-        spat = g.Gam * pow(Hb, g.nH + 2.0) * pow(sqrt(gS2), g.nS - 1.0);
+        spat = g.Gam * upow(Hb, g.nH + 2.0) * spow(gS2, g.nS - 1.0);
       } else {
         spat = Hb > 0.0 ? Hb : 0.0;
       }

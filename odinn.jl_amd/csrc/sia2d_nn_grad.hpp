@@ -142,8 +142,9 @@ __global__ __launch_bounds__(NT) void k_vjp_theta_nn(Pools P, LawDev L, ThArgs A
       double gx, gy, Hb;
       const double Da = node_Da<LDW>(g, &sHS[b][a], &sL[b][a], gj >= 1, gj + 1 <= g.ny - 2, gi >= 1,
                                      gi + 1 <= g.nx - 2, gx, gy, Hb);
-      const double gS = sqrt(gx * gx + gy * gy);
-      const double spat = (L.kind == 3) ? g.Gam * pow(Hb, g.nH + 2.0) * pow(gS, g.nS - 1.0) : Hb;
+      const double gS2 = gx * gx + gy * gy;
+      const double gS = (L.kind == 3) ? 0.0 : sqrt(gS2);  // the U law's second input; the Y law needs |grad S| only through spow
+      const double spat = (L.kind == 3) ? g.Gam * upow(Hb, g.nH + 2.0) * spow(gS2, g.nS - 1.0) : Hb;
       if (Hb > 0.0) {  // ice-free nodes carry zero weight (and target_D_pure.jl:166-168 skips them)
         wgt[m] = scale * spat * Da;
         x0[m] = (L.kind == 3) ? g.T : Hb;

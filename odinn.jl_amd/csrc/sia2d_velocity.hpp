@@ -25,17 +25,16 @@ __device__ __forceinline__ double node_Vup(const GDev& g, double Hb, double gS2,
     spat = Gu * H4 * gS2;
     return AG * H4 * gS2;
   }
-  const double gS = sqrt(gS2);
-  const double hn1 = pow(Hb, g.n + 1.0), sn1 = pow(gS, g.n - 1.0), sn3 = pow(gS, g.n - 3.0);
+  const double hn1 = upow(Hb, g.n + 1.0), sn1 = spow(gS2, g.n - 1.0), sn3 = spow(gS2, g.n - 3.0);
   double D = An * Gu * hn1 * sn1;
-  alpha = An * Gu * (g.n + 1.0) * pow(Hb, g.n) * sn1;
+  alpha = An * Gu * (g.n + 1.0) * upow(Hb, g.n) * sn1;
   beta = An * Gu * (g.n - 1.0) * hn1 * sn3;
   spat = Gu * hn1 * sn1;
   if (g.Sc != 0.0) {  // sliding terms exactly as the reference writes them
     const double k = g.Sc * (g.p - g.q + 2.0);
-    D += k * pow(Hb, g.p - g.q + 1.0) * sn1;
-    alpha += k * pow(Hb, g.p - g.q) * sn1;
-    beta += k * (g.p - 1.0) * pow(Hb, g.p - g.q + 1.0) * sn3;
+    D += k * upow(Hb, g.p - g.q + 1.0) * sn1;
+    alpha += k * upow(Hb, g.p - g.q) * sn1;
+    beta += k * (g.p - 1.0) * upow(Hb, g.p - g.q + 1.0) * sn3;
   }
   return D;
 }
