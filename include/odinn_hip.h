@@ -190,6 +190,14 @@ int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double*
  * scale_loss) :293-390, LossHV(hLoss, vLoss, scaling) :395-440 */
 enum odinn_loss_kind { ODINN_LOSS_H = 0, ODINN_LOSS_V = 1, ODINN_LOSS_HV = 2 };
 int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_loss, double hv_scaling);
+/* LossDhdt, a time-aggregated loss (src/losses/TimeAggregatedLosses.jl:38-113): glacier.dhdtData = (t0, t1, dhdt_ref);
+ * with H0, H1 the predicted thickness at t0, t1 (both must be tstops of the solve), mask = H0 > 1e-2 and
+ * dhdt = mean((H1 - H0)[mask]) / (t1 - t0), the term weight * (dhdt - dhdt_ref)^2 joins the loss of odinn_loss /
+ * odinn_loss_grad / odinn_loss_grad_continuous and +-2 weight (dhdt - dhdt_ref) mask / (N_mask (t1 - t0)) joins lambda at
+ * t1 / t0 (gradient.jl:170-215, :369-449).  `weight` is the MultiLoss lambda of the term relative to the data loss;
+ * weight = 0 (default) switches the term off; t1 <= t0 clears a glacier's data. */
+int odinn_set_dhdt_reference(odinn_batch* b, int g, double t0, double t1, double dhdt_ref);
+int odinn_set_dhdt_loss(odinn_batch* b, double weight);
 
 /* ---- fine-grained seams (host in / host out; parity + drop-in, not the fast path) ---- */
 int odinn_sia2d_dhdt(odinn_batch* b, int g, const double* H, double t, double* dH);

@@ -42,7 +42,7 @@ __all__ = [
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad", "load_gridded_glacier", "attach_rccl_comm",
-    "SIA2D_A_target", "SIA2D_D_hybrid_target", "SIA2D_D_target",
+    "SIA2D_A_target", "SIA2D_D_hybrid_target", "SIA2D_D_target", "LossDhdt", "DhdtData",
 ]
 
 
@@ -172,6 +172,13 @@ class RheologyRegularization:
 
 
 @dataclass
+class LossDhdt:
+    """src/losses/TimeAggregatedLosses.jl:38-113: (mean_{H(t0) > 1e-2}(H(t1) - H(t0)) / (t1 - t0) - dhdt_ref)^2 with
+    glacier.dhdtData = DhdtData((t0, t1), dhdt_ref) -- a time-aggregated loss, evaluated on the device together with its
+    cotangent fields at t0 and t1."""
+
+
+@dataclass
 class MultiLoss:
     """src/losses/MultiLoss.jl:22-35: sum_k lambdas[k] * losses[k].  One data term (LossH | LossV |
     LossHV, evaluated by the device adjoint) plus any number of regularisers."""
@@ -186,14 +193,18 @@ class MultiLoss:
 
 def _split_loss(lf):
     """(data loss, its weight, [(regulariser, weight)]) of a loss specification."""
+    if isinstance(lf, LossDhdt):
+        return LossH(), 1.0, [(lf, 1.0)]  # no thickness data -> the data term is 0
     if not isinstance(lf, MultiLoss):
         return lf, 1.0, []
     data = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if isinstance(l, (LossH, LossV, LossHV))]
     regs = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if not isinstance(l, (LossH, LossV, LossHV))]
+    if len(data) == 0 and any(isinstance(r, LossDhdt) for r, _ in regs):
+        data = [(LossH(), 1.0)]  # LossDhdt alone: a LossH without thickness data contributes nothing
     if len(data) != 1:
         raise ValueError("MultiLoss needs exactly one data term (LossH, LossV or LossHV)")
     for r, _ in regs:
-        if not isinstance(r, (InitialThicknessRegularization, RheologyRegularization)):
+        if not isinstance(r, (InitialThicknessRegularization, RheologyRegularization, LossDhdt)):
             raise TypeError(f"loss term {type(r).__name__} is not provided")
     return data[0][0], float(data[0][1]), regs
 
@@ -255,6 +266,15 @@ class ThicknessData:
 
 
 @dataclass
+class DhdtData:
+    """glacier.dhdtData of LossDhdt: mean surface-elevation change rate `dhdt` between t = (t0, t1)
+    (src/losses/TimeAggregatedLosses.jl:66-68)."""
+
+    t: Tuple[float, float]
+    dhdt: float
+
+
+@dataclass
 class VelocityData:
     """glacier.velocityData: absolute value and components at dates t (nx*ny fields)."""
 
@@ -279,6 +299,7 @@ class Glacier2D:
     T: float = -5.0  # long-term air temperature (iAvgScalarTemp)
     thicknessData: Optional[ThicknessData] = None
     velocityData: Optional[VelocityData] = None
+    dhdtData: Optional[DhdtData] = None
     mask: Optional[np.ndarray] = None  # True OUTSIDE the glacier (Sleipnir builds it from the outline); default H0 <= 0
 
     def __post_init__(self):
@@ -836,6 +857,8 @@ class _Simulation:
                 ts |= set(float(t) for t in g.thicknessData.t)
             if g.velocityData is not None:
                 ts |= set(float(t) for t in g.velocityData.t)
+            if g.dhdtData is not None and any(isinstance(r, LossDhdt) for r, _ in _split_loss(p.UDE.empirical_loss_function)[2]):
+                ts |= set(float(t) for t in g.dhdtData.t)  # discretePostIntegralLossSteps (TimeAggregatedLosses.jl:352-354)
         return sorted(t for t in ts if p.simulation.tspan[0] <= t <= p.simulation.tspan[1])
 
     def mb_times(self):
@@ -872,7 +895,14 @@ class _Simulation:
             if g.velocityData is not None:
                 v = g.velocityData
                 b.set_velocity_reference(k, v.t, v.vabs, v.vx, v.vy)
-        lf, _, _ = _split_loss(p.UDE.empirical_loss_function)
+        lf, w_data, regs_ = _split_loss(p.UDE.empirical_loss_function)
+        for r, w in regs_:
+            if isinstance(r, LossDhdt):  # the device evaluates the term; its weight is relative to the data loss, which
+                for k, g in enumerate(gl):  # SIA2D_grad_b scales by w_data afterwards
+                    if g.dhdtData is None:
+                        raise ValueError("LossDhdt needs glacier.dhdtData")
+                    b.set_dhdt_reference(k, g.dhdtData.t[0], g.dhdtData.t[1], g.dhdtData.dhdt)
+                b.set_dhdt_loss(float(w) / w_data)
         if isinstance(lf, LossHV):
             b.set_loss(L.LOSS_HV, lf.vLoss.component, lf.vLoss.scale_loss, lf.scaling)
         elif isinstance(lf, LossV):
@@ -1039,6 +1069,8 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
     dth *= w_data
     tspan = p.simulation.tspan
     for reg, w in regs:
+        if isinstance(reg, LossDhdt):
+            continue  # evaluated on the device inside loss_grad (odinn_set_dhdt_loss)
         if isinstance(reg, InitialThicknessRegularization):
             if model.IC is None:
                 raise ValueError("Regularization with respect to initial condition requires to set initial "

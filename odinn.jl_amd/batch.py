@@ -234,6 +234,14 @@ class GlacierBatch:
         L.check(L.lib().odinn_set_loss(self._h, int(kind), 1 if component == "abs" else 0, 1 if scale_loss else 0,
                                        float(scaling)))
 
+    def set_dhdt_reference(self, g, t0, t1, dhdt_ref):
+        """glacier.dhdtData of LossDhdt (TimeAggregatedLosses.jl:38-113): mean elevation-change rate between t0 and t1."""
+        L.check(L.lib().odinn_set_dhdt_reference(self._h, int(g), float(t0), float(t1), float(dhdt_ref)))
+
+    def set_dhdt_loss(self, weight=1.0):
+        """weight of the LossDhdt term relative to the data loss (its MultiLoss lambda); 0 switches it off."""
+        L.check(L.lib().odinn_set_dhdt_loss(self._h, float(weight)))
+
     def surface_V(self, g, H):
         H = _f(H, self.shapes[g])
         Vx, Vy = np.empty_like(H), np.empty_like(H)

@@ -36,6 +36,15 @@ static bool law_is(const LawDev& L) {
   for (int l = 0; l < AR::NL; ++l) if (L.acts[l] != AR::A[l]) return false;
   return true;
 }
+void launch_dhdt_sums(int nblk, int G, hipStream_t st, Pools P, const double* snaps, const int* i0s, const int* i1s, long long ntot,
+                      double* part2, const double* dts, const double* refs, double w, double* coef, double* lossacc) {
+  hipLaunchKernelGGL(k_dhdt_sums, dim3(nblk), dim3(NT), 0, st, P, snaps, i0s, i1s, ntot, part2);
+  hipLaunchKernelGGL(k_dhdt_finish, dim3(G), dim3(64), 0, st, P, part2, i0s, dts, refs, w, coef, lossacc);
+}
+void launch_dhdt_cot(int nblk, hipStream_t st, Pools P, double* lam, const double* snaps, const int* i0s, const int* i1s,
+                     const double* coef, int j, long long ntot) {
+  hipLaunchKernelGGL(k_dhdt_cot, dim3(nblk), dim3(NT), 0, st, P, lam, snaps, i0s, i1s, coef, j, ntot);
+}
 void launch_law_field(hipStream_t st, LawDev L, const double* T, double* Aout, long long n) {
   const dim3 grid((unsigned)((n + NT - 1) / NT));
   if (law_is<Arch16A>(L)) hipLaunchKernelGGL(k_law_field_fixed<Arch16A>, grid, dim3(NT), 0, st, L, T, Aout, n);

@@ -60,6 +60,10 @@ void launch_mb_vjp(int nblk, hipStream_t st, Pools P, const double* Hpre, const 
                    const double* lam_in, double* lam_out, int add, int base);
 void launch_mb_apply(int nblk, hipStream_t st, Pools P, const double* H, const double* mb0, const double* Sref,
                      double* Hn, double* MBout, int base);
+void launch_dhdt_sums(int nblk, int G, hipStream_t st, Pools P, const double* snaps, const int* i0s, const int* i1s, long long ntot,
+                      double* part2, const double* dts, const double* refs, double w, double* coef, double* lossacc);
+void launch_dhdt_cot(int nblk, hipStream_t st, Pools P, double* lam, const double* snaps, const int* i0s, const int* i1s,
+                     const double* coef, int j, long long ntot);
 void launch_law_field(hipStream_t st, LawDev L, const double* T, double* Aout, long long n);
 void launch_law_field_grad(int nblk, hipStream_t st, LawDev L, const double* T, const double* G, long long n,
                            double* gscratch, double* part_theta);

@@ -224,6 +224,17 @@ struct odinn_batch {
   int P = 0;
   double nH = -1, nS = -1;
   bool has_Afield_const = false;
+  // LossDhdt (time-aggregated loss): per-glacier data, weight, device tables (stop indices, coefficients, tile partials)
+  std::vector<double> dh_t0, dh_t1, dh_ref;
+  double dhdt_weight = 0.0;
+  int *d_dh_i0 = nullptr, *d_dh_i1 = nullptr;
+  double *d_dh_coef = nullptr, *d_dh_part = nullptr, *d_dh_dt = nullptr, *d_dh_ref = nullptr;
+  std::vector<int> dh_i0_h, dh_i1_h;
+  bool dhdt_on() const {
+    if (!(dhdt_weight != 0.0)) return false;
+    for (size_t g = 0; g < dh_t0.size(); ++g) if (dh_t1[g] > dh_t0[g]) return true;
+    return false;
+  }
   // `:Linear` interpolation of d law / d theta (Y law): knots of Hbar, see k_interp.hip
   int grad_interp = ODINN_GRAD_INTERP_NONE, n_interp_half = 75;
   double *d_nodeH = nullptr, *d_nodeV = nullptr, *d_sortH = nullptr, *d_sortV = nullptr, *d_knots = nullptr, *d_knotG = nullptr,
@@ -860,6 +871,38 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   return ODINN_OK;
 }
 
+// LossDhdt after a forward solve: stop indices of every glacier's (t0, t1), the masked mean thickness change, the
+// loss term (added onto d_lossacc[g]) and the coefficient of its cotangent fields (d_dh_coef[g])
+int dhdt_forward(odinn_batch* b) {
+  if (!b->dhdt_on()) return ODINN_OK;
+  const int k = (int)b->tstops.size();
+  b->dh_i0_h.assign(b->G, -1); b->dh_i1_h.assign(b->G, -1);
+  std::vector<double> dts(b->G, 1.0);
+  for (int g = 0; g < b->G; ++g) {
+    if (!(b->dh_t1[g] > b->dh_t0[g])) continue;
+    for (int j = 0; j < k; ++j) {
+      if (b->tstops[j] == b->dh_t0[g]) b->dh_i0_h[g] = j;
+      if (b->tstops[j] == b->dh_t1[g]) b->dh_i1_h[g] = j;
+    }
+    if (b->dh_i0_h[g] < 0 || b->dh_i1_h[g] < 0)
+      return fail(ODINN_ERR_ARG, "dhdtData times (%g, %g) of glacier %d are not among the tstops", b->dh_t0[g], b->dh_t1[g], g);
+    dts[g] = b->dh_t1[g] - b->dh_t0[g];
+  }
+  if (!b->d_dh_i0) {
+    CHK(dalloc(&b->d_dh_i0, (size_t)b->G)); CHK(dalloc(&b->d_dh_i1, (size_t)b->G)); CHK(dalloc(&b->d_dh_coef, (size_t)b->G));
+    CHK(dalloc(&b->d_dh_dt, (size_t)b->G)); CHK(dalloc(&b->d_dh_ref, (size_t)b->G)); CHK(dalloc(&b->d_dh_part, (size_t)2 * b->ntiles));
+  }
+  HIPCHK(hipMemcpyAsync(b->d_dh_i0, b->dh_i0_h.data(), sizeof(int) * b->G, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_dh_i1, b->dh_i1_h.data(), sizeof(int) * b->G, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_dh_dt, dts.data(), sizeof(double) * b->G, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_dh_ref, b->dh_ref.data(), sizeof(double) * b->G, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));  // the host vectors above are temporaries
+  launch_dhdt_sums(b->ntiles, b->G, b->stream, b->pools(true), b->d_snaps, b->d_dh_i0, b->d_dh_i1, b->ntot, b->d_dh_part,
+                   b->d_dh_dt, b->d_dh_ref, b->dhdt_weight, b->d_dh_coef, b->d_lossacc);
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
 // forward loss over the stored snapshots -> d_lossacc[g]; *const_loss: data-only part of LossV
 int do_loss(odinn_batch* b, double* const_loss) {
   const int k = (int)b->tstops.size();
@@ -878,6 +921,7 @@ int do_loss(odinn_batch* b, double* const_loss) {
       *const_loss += c;
     }
   }
+  CHK(dhdt_forward(b));  // time-aggregated term (inversion_utils.jl:457-460)
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -922,6 +966,7 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   b->descs.assign(descs, descs + n_glaciers);
   b->gd.resize(n_glaciers);
   b->t_ref.resize(n_glaciers);
+  b->dh_t0.assign(n_glaciers, 0.0); b->dh_t1.assign(n_glaciers, 0.0); b->dh_ref.assign(n_glaciers, 0.0);
   b->t_vref.resize(n_glaciers); b->v_scale.resize(n_glaciers); b->v_cxy.resize(n_glaciers); b->v_cabs.resize(n_glaciers);
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
@@ -1058,6 +1103,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   (void)hipSetDevice(b->device);
   (void)hipStreamSynchronize(b->stream);
   dfree(b->d_tilesD); dfree(b->d_partD);
+  dfree(b->d_dh_i0); dfree(b->d_dh_i1); dfree(b->d_dh_coef); dfree(b->d_dh_part); dfree(b->d_dh_dt); dfree(b->d_dh_ref);
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
@@ -1416,6 +1462,18 @@ int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_lo
   return ODINN_OK;
 }
 
+int odinn_set_dhdt_reference(odinn_batch* b, int g, double t0, double t1, double dhdt_ref) {
+  CHK(check_g(b, g));
+  b->dh_t0[g] = t0; b->dh_t1[g] = t1; b->dh_ref[g] = dhdt_ref;
+  return ODINN_OK;
+}
+
+int odinn_set_dhdt_loss(odinn_batch* b, double weight) {
+  if (!b || !(weight >= 0.0)) return fail(ODINN_ERR_ARG, "bad LossDhdt weight");
+  b->dhdt_weight = weight;
+  return ODINN_OK;
+}
+
 int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, const double* Vabs,
                                  const double* Vx, const double* Vy) {
   if (b) b->refs_version++;
@@ -1615,7 +1673,7 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
   if (theta) CHK(odinn_set_theta(b, theta, P));
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
-  if (b->loss_kind != ODINN_LOSS_V && !b->d_Href) return fail(ODINN_ERR_STATE, "no reference thickness data set");
+  if (b->loss_kind != ODINN_LOSS_V && !b->d_Href && !b->dhdt_on()) return fail(ODINN_ERR_STATE, "no reference thickness data set");
   if (b->loss_kind != ODINN_LOSS_H && !b->d_Vabs) return fail(ODINN_ERR_STATE, "no reference velocity data set");
   if (b->vjp_method == 1 && b->law_kind >= ODINN_LAW_NN_Y)
     return fail(ODINN_ERR_UNSUPPORTED, "ContinuousVJP is provided for target :A (A-type laws) only");
@@ -1630,6 +1688,7 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
     CHK(ensure_theta_scratch(b, b->ntiles));
     HIPCHK(hipMemsetAsync(b->d_dth, 0, sizeof(double) * b->G * b->P, b->stream));
   }
+  CHK(dhdt_forward(b));  // LossDhdt: loss term and the coefficients of its cotangent fields (gradient.jl:170-188)
   return ODINN_OK;
 }
 static int grad_finish(odinn_batch* b, int k, int P, double const_loss, double* loss, double* dtheta);
@@ -1671,6 +1730,11 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
     if (defer) Pj.part = b->d_partsteps + (size_t)j * pstride;
     launch_vjp_H(b, 1, b->ntiles, Pj, L, A, 0);  // :235-242
     if (!defer) launch_sum_part(b->G, b->stream, Psw, 1, b->d_lossacc, 1, 0);
+    if (b->dhdt_on()) {  // dl/dH of the time-aggregated loss at this stop (:212-215), before the theta-VJP uses lambda_{j-1}
+      bool any = false;
+      for (int g = 0; g < b->G; ++g) any = any || b->dh_i0_h[g] == j || b->dh_i1_h[g] == j;
+      if (any) launch_dhdt_cot(b->ntiles, b->stream, Psw, lam_new, b->d_snaps, b->d_dh_i0, b->d_dh_i1, b->d_dh_coef, j, b->ntot);
+    }
     if (b->loss_kind != ODINN_LOSS_H) {  // backward_loss(::LossV): dl/dH into lambda_{j-1}, dl/dtheta into dtheta
       double c = 0.0;
       CHK(launch_lossV(b, j, Hj, lam_new, true, &c));
@@ -1861,6 +1925,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   // the velocity terms read it from d_tmpA, which the post-step then materialises
   const bool theta_itp = !useV && b->law_kind < ODINN_LAW_NN_Y;
   AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = theta_itp ? nullptr : b->d_tmpA;
+  if (b->dhdt_on()) { AP.dh_i0 = b->d_dh_i0; AP.dh_i1 = b->d_dh_i1; AP.dh_coef = b->d_dh_coef; }
   const bool mb_last = b->any_mb && b->mb_flag[k - 1];
   launch_adj_begin(G, b->stream, Pl, b->d_adj, k, h_tau[0], mb_last ? 1 : 0, mb_last ? b->mb_slot[k - 1] : 0);
   // loss term of a velocity-data snapshot: lam += wV dl_V/dH(H_j)  (backward_loss(::LossV), Losses.jl:338-390)

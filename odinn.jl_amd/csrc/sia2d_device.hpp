@@ -1181,6 +1181,11 @@ struct AdjPostArgs {
   int G;
   int loss_first;
   double* Hq;
+  // LossDhdt (time-aggregated, TimeAggregatedLosses.jl:82-113): at the snapshot dh_i1[g] (dh_i0[g]) of glacier g the
+  // field +(-) dh_coef[g] [H(t0) > 1e-2] joins lambda after the loss term (CallbackSet order, gradient.jl:437); null: off
+  const int* dh_i0;
+  const int* dh_i1;
+  const double* dh_coef;
 };
 
 __device__ __forceinline__ double mb_value(const GDev& g, double mb0, double sref, double H, double B, double& dmb) {
@@ -1915,6 +1920,73 @@ __global__ __launch_bounds__(NT) void k_mb_apply(Pools P, const double* __restri
   }
 }
 
+// ---- LossDhdt (src/losses/TimeAggregatedLosses.jl:38-113) ------------------------------------------------------
+// forward: per tile  sum_{H0 > 1e-2} (H1 - H0)  and the count, H0 / H1 = snapshots dh_i0[g] / dh_i1[g] of glacier g
+__global__ __launch_bounds__(NT) void k_dhdt_sums(Pools P, const double* __restrict__ snaps, const int* __restrict__ i0s,
+                                                  const int* __restrict__ i1s, long long ntot, double* __restrict__ part2) {
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const int q0 = i0s[t4.x], q1 = i1s[t4.x];
+  double s = 0.0, c = 0.0;
+  if (q0 >= 0) {
+    const GDev g = P.gd[t4.x];
+    const int gi = t4.y * TX + (threadIdx.x & 63), ty = wave_id();
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) {
+      const int gj = t4.z * TY + ty + NW * m;
+      if (gi < g.nx && gj < g.ny) {
+        const long long id = g.off + gi + (long long)g.nx * gj;
+        const double h0 = snaps[(long long)q0 * ntot + id];
+        if (h0 > 1e-2) { s += snaps[(long long)q1 * ntot + id] - h0; c += 1.0; }
+      }
+    }
+  }
+  s = block_sum(s, red);
+  __syncthreads();
+  c = block_sum(c, red);
+  if (threadIdx.x == 0) { part2[2 * (long long)t4.w] = s; part2[2 * (long long)t4.w + 1] = c; }
+}
+// per glacier: dhdt = mean / (t1 - t0), loss += w (dhdt - ref)^2, coef = 2 w (dhdt - ref) / (N (t1 - t0))
+__global__ __launch_bounds__(64) void k_dhdt_finish(Pools P, const double* __restrict__ part2, const int* __restrict__ i0s,
+                                                    const double* __restrict__ dts, const double* __restrict__ refs, double w,
+                                                    double* __restrict__ coef, double* __restrict__ lossacc) {
+  const int gidx = blockIdx.x;
+  const GDev g = P.gd[gidx];
+  if (i0s[gidx] < 0) {
+    if (threadIdx.x == 0) coef[gidx] = 0.0;
+    return;
+  }
+  double s = 0.0, c = 0.0;
+  for (int k = threadIdx.x; k < g.ntiles; k += 64) { s += part2[2 * (long long)(g.tile0 + k)]; c += part2[2 * (long long)(g.tile0 + k) + 1]; }
+  s = wave_sum(s);
+  c = wave_sum(c);
+  if (threadIdx.x == 0) {
+    const double dh = s / c / dts[gidx];  // c == 0 (no ice at t0): NaN, as mean() of an empty set in the reference
+    const double d = dh - refs[gidx];
+    coef[gidx] = 2.0 * w * d / (c * dts[gidx]);
+    lossacc[gidx] += w * d * d;
+  }
+}
+// discrete reverse loop, stop j: lambda_{j-1} += (+ at t1, - at t0) coef [H(t0) > 1e-2]   (gradient.jl:212-215)
+__global__ __launch_bounds__(NT) void k_dhdt_cot(Pools P, double* __restrict__ lam, const double* __restrict__ snaps,
+                                                 const int* __restrict__ i0s, const int* __restrict__ i1s,
+                                                 const double* __restrict__ coef, int j, long long ntot) {
+  const int4 t4 = P.tiles[blockIdx.x];
+  const int q0 = i0s[t4.x], q1 = i1s[t4.x];
+  if (q0 < 0 || (j != q0 && j != q1)) return;
+  const double cf = j == q1 ? coef[t4.x] : -coef[t4.x];
+  const GDev g = P.gd[t4.x];
+  const int gi = t4.y * TX + (threadIdx.x & 63), ty = wave_id();
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = t4.z * TY + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      if (snaps[(long long)q0 * ntot + id] > 1e-2) lam[id] += cf;
+    }
+  }
+}
+
 // A on the dual grid from a gridded temperature: Afield = post(MLP(T))  (hoisted law)
 __global__ __launch_bounds__(NT) void k_law_field(LawDev L, const double* __restrict__ T, double* __restrict__ Aout,
                                                   long long n) {
@@ -2147,7 +2219,13 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
         double dl = 0.0;
         if (w != 0.0 && A.mask[roff + id])
           dl = w * 2.0 * Ninv * (A.snaps[(long long)a.snapj * A.ntot + id] - A.Href[roff + id]);
-        if (A.loss_first) l += dl;
+        double dagg = 0.0;
+        if (A.dh_coef) {
+          const int q0 = A.dh_i0[t4.x], q1 = A.dh_i1[t4.x];
+          if (q0 >= 0 && (a.snapj == q0 || a.snapj == q1) && A.snaps[(long long)q0 * A.ntot + id] > 1e-2)
+            dagg = a.snapj == q1 ? A.dh_coef[t4.x] : -A.dh_coef[t4.x];
+        }
+        if (A.loss_first) l += dl + dagg;
         if (do_mb) {
           const double h = A.premb[(long long)gs->mb_slot * A.ntot + id];
           double dmb;
@@ -2158,7 +2236,7 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
           if (msk && h + mb < 0.0) vv = -l;
           l += vv;
         }
-        if (!A.loss_first) l += dl;
+        if (!A.loss_first) l += dl + dagg;
         U[id] = l;
       }
       if (A.Hq && (a.qw != 0.0 || a.snapj >= 0)) {  // H_itp at the stop, for the velocity loss term (the theta-VJP forms it itself)

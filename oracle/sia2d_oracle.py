@@ -1020,6 +1020,10 @@ class SimConfig:
     mb_times: Sequence[float] = ()  # subset of tstops[1:]
     loss_distance: int = 3
     fixed_dt: Optional[float] = None
+    # LossDhdt (src/losses/TimeAggregatedLosses.jl:38-113): glacier.dhdtData = (t0, t1, dhdt_ref) with t0, t1 among the
+    # stops, and the weight the MultiLoss gives the term (the data loss keeps weight 1)
+    dhdt: Optional[Tuple[float, float, float]] = None
+    dhdt_weight: float = 1.0
 
 
 def forward(gl: Glacier, law: Law, cfg: SimConfig, theta=None):
@@ -1061,6 +1065,24 @@ def loss_H(snaps, tstops, H_ref, tH_ref, distance):
     return tot
 
 
+def dhdt_loss_terms(snaps, tstops, cfg: SimConfig):
+    """LossDhdt, a time-aggregated loss (TimeAggregatedLosses.jl:54-113): with H0, H1 the predictions at dhdtData.t,
+    mask = H0 > 1e-2, dhdt = mean((H1 - H0)[mask]) / (t1 - t0):  loss = (dhdt - dhdt_ref)^2, dL/dH0 = -c mask,
+    dL/dH1 = +c mask with c = 2 (dhdt - dhdt_ref) / (N_mask (t1 - t0)).  Returns (weighted loss, {stop index: field})."""
+    if cfg.dhdt is None:
+        return 0.0, {}
+    t = [float(x) for x in tstops]
+    t0, t1, ref = cfg.dhdt
+    i0, i1 = t.index(float(t0)), t.index(float(t1))
+    H0, H1 = snaps[i0], snaps[i1]
+    mask = H0 > 1e-2
+    nm = int(mask.sum())
+    dh = float(np.mean(H1[mask] - H0[mask])) / (t1 - t0)
+    c = 2.0 * (dh - ref) * mask / (nm * (t1 - t0))
+    w = cfg.dhdt_weight
+    return w * (dh - ref) ** 2, {i0: -w * c, i1: w * c}
+
+
 def _vjp_H_of(vjp):
     """VJP_lambda_dSIA/dH dispatch on the VJP method (VJPs.jl:2-10)."""
     return {"discrete": vjp_H, "continuous": vjp_H_continuous}[vjp]
@@ -1082,6 +1104,7 @@ def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=No
     dLdtheta = np.zeros(P)
     lam = [np.zeros_like(gl.B) for _ in range(k)]
     loss_rev = 0.0
+    l_agg, dl_agg = dhdt_loss_terms(snaps, t, cfg)  # gradient.jl:170-188
     for j in reversed(range(k)):
         tj = t[j]
         if cfg.mb is not None and tj in cfg.mb_times:  # :201-207
@@ -1094,6 +1117,8 @@ def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=No
             loss_rev += l2sum_loss(snaps[j], Hr, mask, N) * w[j]
         else:
             dl = 0.0
+        if j in dl_agg:  # :212-215 (like every dl/dH of the first stop, the j = 0 term is never used: there is no lambda[-1])
+            dl = dl + dl_agg[j]
         g = _vjp_H_of(vjp)(lam[j], snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # :235-237
         if j > 0:
             dt = t[j] - t[j - 1]
@@ -1102,7 +1127,7 @@ def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=No
             dLdtheta += dt * dth  # :249
     loss_fwd = loss_H(snaps, t, H_ref, tH_ref, cfg.loss_distance)
     assert math.isclose(loss_rev, loss_fwd, rel_tol=1e-8, abs_tol=0.0) or loss_fwd == 0.0  # :259
-    return loss_fwd, dLdtheta, lam[0]
+    return loss_fwd + l_agg, dLdtheta, lam[0]  # :254-255
 
 
 # ----------------------------------------------------------------------------
@@ -1189,13 +1214,20 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
             return u + vjp_mb(cfg.mb, u, H_itp(tt) - inc[tt], gl.B)
         return u
 
+    l_agg, dl_agg = dhdt_loss_terms(snaps, t, cfg)  # :369-387
+
+    def effect_agg(tt, u):  # :389-399
+        j = t.index(tt)
+        return u + dl_agg[j] if j in dl_agg else u
+
     f_rev = lambda lam, tau: _vjp_H_of(vjp)(lam, H_itp(-tau), gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # :316-324
     nodes, wts = gauss_quadrature(t[0], t[-1], adj.n_quadrature)  # :307-308
     lam1 = effect_loss(t[-1], np.zeros_like(gl.B))  # :441-446 (not covered by the discrete callback)
+    lam1 = effect_agg(t[-1], lam1)  # :447-449
     lam1 = effect_mb(t[-1], lam1)  # PeriodicCallback(initial_affect = true) :431-432
     snap_tau = [-x for x in reversed(t)]
     stops = sorted(set(snap_tau) | set(-float(x) for x in nodes))  # :457
-    cb = lambda u, tau: effect_loss(-tau, effect_mb(-tau, u))  # CallbackSet order: MB, then loss :437
+    cb = lambda u, tau: effect_agg(-tau, effect_loss(-tau, effect_mb(-tau, u)))  # CallbackSet order: MB, loss, aggregated :437
     lam_s, st_rev, _ = solve(f_rev, lam1, stops, adj.reltol, adj.abstol, adj.dtmax, adj.maxiters,
                              callback=cb, callback_times=snap_tau[1:], time_dependent=True)
     P = 1 if law.kind == LAW_CONST_A else law.mlp.n_params
@@ -1222,7 +1254,7 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
             if wV[j] != 0.0:
                 Va, Vxr, Vyr = V_ref[tV.index(t[j])]
                 loss += loss_V(vspec, snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, Va, Vxr, Vyr, N, theta) * wV[j]
-    return loss, dLdtheta, lam_s[-1], st_rev
+    return loss + l_agg, dLdtheta, lam_s[-1], st_rev
 
 
 # ----------------------------------------------------------------------------
