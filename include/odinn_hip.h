@@ -164,12 +164,17 @@ int odinn_set_T_field(odinn_batch* b, int g, const double* T_dual);   /* NN_A_GR
 int odinn_set_law(odinn_batch* b, int kind, const odinn_mlp_desc* mlp, const double* theta, int P,
                   double n_H, double n_gradS);
 int odinn_set_theta(odinn_batch* b, const double* theta, int P);
-/* spatial evaluation of d law / d theta inside the theta-VJP of the Y law (SIA2D_D_hybrid_target.interpolation,
- * src/models/target/target_D_hybrid.jl:12-15,121-160): ODINN_GRAD_INTERP_NONE = exact backprop at every dual node
- * (`:None`), ODINN_GRAD_INTERP_LINEAR = gradients on the <= 2 n_interp_half knots of create_interpolation(Hbar)
- * (target_utils.jl:245-293), interpolated linearly in Hbar (`:Linear`).  odinn_set_law selects the reference's
- * default: LINEAR with n_interp_half = 75 for ODINN_LAW_NN_Y, NONE for every other law (:D's default is :None,
- * target_D_pure.jl:34-39; its :Linear node-grid variant, Laws.jl:153-169, is not provided).  n_interp_half <= 256. */
+/* spatial evaluation of d law / d theta inside the theta-VJP of the Y and U laws (SIA2D_D_hybrid_target.interpolation,
+ * src/models/target/target_D_hybrid.jl:12-15,121-160; SIA2D_D_target.interpolation, target_D_pure.jl:34-39,163-193):
+ * ODINN_GRAD_INTERP_NONE = exact backprop at every dual node (`:None`); ODINN_GRAD_INTERP_LINEAR (`:Linear`) =
+ *   Y law: gradients on the <= 2 n_interp_half knots of create_interpolation(Hbar) (target_utils.jl:245-293),
+ *          interpolated linearly in Hbar;
+ *   U law: gradients on the fixed (2 n_interp_half)^2 node grid of LawU's p_VJP! (Laws.jl:128-169; both axes
+ *          LinRange(0, 100, 2 n_interp_half), as the law's cache is constructed), interpolated bilinearly in
+ *          (Hbar, |grad S|).  The interpolant does not extrapolate: a dual node with Hbar > 100 makes the call that
+ *          evaluates the theta-VJP fail with ODINN_ERR_ARG ("BoundsError"), as the reference throws.
+ * odinn_set_law selects the reference's default: LINEAR with n_interp_half = 75 for ODINN_LAW_NN_Y, NONE for every
+ * other law.  n_interp_half <= 256; ODINN_ERR_UNSUPPORTED for the A-type laws (no spatial law gradient). */
 #define ODINN_GRAD_INTERP_NONE 0
 #define ODINN_GRAD_INTERP_LINEAR 1
 int odinn_set_grad_interpolation(odinn_batch* b, int kind, int n_interp_half);

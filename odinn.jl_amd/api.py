@@ -586,7 +586,9 @@ class SIA2D_D_hybrid_target:
 
 @dataclass
 class SIA2D_D_target:
-    """src/models/target/target_D_pure.jl:34-39 (default :None; the :Linear node-grid variant of LawU is not provided)."""
+    """src/models/target/target_D_pure.jl:34-39: :None (default) = exact backprop at every node; :Linear = gradients on the
+    fixed (2 n_interp_half)² node grid of LawU's p_VJP! (Laws.jl:128-169, both axes LinRange(0, 100, ·)), interpolated
+    bilinearly in (H̄, |∇S|) -- a node with H̄ > 100 m is outside the interpolant and raises, as in the reference."""
 
     interpolation: str = "None"
     n_interp_half: int = 100
@@ -604,8 +606,6 @@ class Model:
             target = want()
         elif not isinstance(target, want):
             raise ValueError(f"The provided laws do not match with the provided target. Make sure that the target is a {want.__name__}.")
-        if isinstance(target, SIA2D_D_target) and target.interpolation != "None":
-            raise NotImplementedError("SIA2D_D_target(interpolation = :Linear) is not provided; use :None (its default)")
         if getattr(target, "interpolation", "None") not in ("None", "Linear"):
             raise ValueError("Method to spatially compute gradient with respect to H̄ not specified.")  # target_D_hybrid.jl:161
         self.target = target
@@ -917,7 +917,7 @@ class _Simulation:
         else:
             b.set_law(law.kind, law.mlp, self.model.theta[:self.model.n_main], law.n_H, law.n_gradS)
             tg = self.model.target
-            if isinstance(tg, SIA2D_D_hybrid_target):
+            if isinstance(tg, (SIA2D_D_hybrid_target, SIA2D_D_target)):
                 b.set_grad_interpolation(L.GRAD_INTERP_LINEAR if tg.interpolation == "Linear" else L.GRAD_INTERP_NONE,
                                          tg.n_interp_half)
         mb = self.model.mass_balance

@@ -196,8 +196,9 @@ class GlacierBatch:
         self.law_kind = kind
 
     def set_grad_interpolation(self, kind=L.GRAD_INTERP_LINEAR, n_interp_half=75):
-        """`interpolation` / `n_interp_half` of SIA2D_D_hybrid_target (target_D_hybrid.jl:12-15): how d law / d theta is
-        evaluated over the dual grid in the theta-VJP of the Y law.  set_law picks the reference's default."""
+        """`interpolation` / `n_interp_half` of SIA2D_D_hybrid_target (target_D_hybrid.jl:12-15) and SIA2D_D_target
+        (target_D_pure.jl:34-39): how d law / d theta is evaluated over the dual grid in the theta-VJP of the Y law
+        (knots of Hbar) and the U law (fixed node grid, bilinear).  set_law picks the reference's default."""
         L.check(L.lib().odinn_set_grad_interpolation(self._h, int(kind), int(n_interp_half)))
 
     def set_theta(self, theta):

@@ -137,11 +137,135 @@ __global__ __launch_bounds__(64) void k_interp_contract(int P, const int* __rest
   dth[q] = accumulate ? dth[q] + s : s;
 }
 
+// ---- U law (SIA2D_D_target(interpolation = :Linear), target_D_pure.jl:179-193; node gradients: p_VJP!, Laws.jl:153-169) -------
+// The gradient interpolant lives on a FIXED K x K node grid, K = 2 n_interp_half, both axes LinRange(0, 100, K) (the law's
+// cache is built with the Hbar nodes on the slope axis too, Laws.jl:137-142), bilinear in (Hbar, |grad S|).  As in the Y-law
+// path the contraction with the node weights becomes a sum over GRID nodes:  dtheta = sum_ij c_ij dU/dtheta(h_i, s_j),
+// c_ij = sum_nodes v * (tent_i(Hbar) tent_j(|grad S|)).  Deterministic, without atomics: the dual nodes are sorted by the
+// grid cell they fall in (rocPRIM, stable), one workgroup sums the four corner weights of a cell in a fixed order, the
+// grid nodes gather their (up to) four cells, and only grid nodes with c_ij != 0 are differentiated.
+constexpr double UNODE_MAX = 100.0;
+
+__device__ __forceinline__ double unode(int k, int K) {  // LinRange(0.0, 100, K)[k]
+  const double t = (double)k / (double)(K - 1);
+  return (1.0 - t) * 0.0 + t * UNODE_MAX;
+}
+__device__ __forceinline__ int ucell(double x, int K) {  // k with node(k) <= x < node(k+1); the last cell is closed
+  int k = (int)(x * ((double)(K - 1) / UNODE_MAX));
+  k = k < 0 ? 0 : (k > K - 2 ? K - 2 : k);
+  while (k > 0 && unode(k, K) > x) --k;
+  while (k < K - 2 && unode(k + 1, K) <= x) ++k;
+  return k;
+}
+
+// key = cell index of every dual node; a node outside [0, 100]^2 raises the flag (Gridded(Linear()) throws)
+__global__ __launch_bounds__(NT) void k_ucell_keys(const double* __restrict__ H, const double* __restrict__ S, long long nd, int K,
+                                                   unsigned* __restrict__ keys, unsigned* __restrict__ idx, int* __restrict__ err) {
+  const long long q = (long long)blockIdx.x * NT + threadIdx.x;
+  if (q >= nd) return;
+  const double x = H[q], y = S[q];
+  if (!(x >= 0.0 && x <= UNODE_MAX && y >= 0.0 && y <= UNODE_MAX)) {
+    atomicOr(err, 1);
+    keys[q] = 0u; idx[q] = (unsigned)q;
+    return;
+  }
+  keys[q] = (unsigned)(ucell(x, K) * (K - 1) + ucell(y, K));
+  idx[q] = (unsigned)q;
+}
+
+__device__ __forceinline__ long long lower_bound_u(const unsigned* __restrict__ a, long long n, unsigned x) {
+  long long lo = 0, hi = n;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// block c: the dual nodes of grid cell c = iH (K-1) + iS; cell4[4c + {0,1,2,3}] = sum v {(1-wh)(1-ws), wh(1-ws), (1-wh)ws, wh ws}
+__global__ __launch_bounds__(NT) void k_ucell_sums(const unsigned* __restrict__ skeys, const unsigned* __restrict__ sidx, long long nd,
+                                                   const double* __restrict__ H, const double* __restrict__ S,
+                                                   const double* __restrict__ V, int K, double* __restrict__ cell4) {
+  __shared__ double red[NW];
+  const unsigned c = blockIdx.x;
+  const long long lo = lower_bound_u(skeys, nd, c), hi = lower_bound_u(skeys, nd, c + 1u);
+  if (lo == hi) {
+    if (threadIdx.x < 4) cell4[4 * (long long)c + threadIdx.x] = 0.0;
+    return;
+  }
+  const int iH = (int)(c / (unsigned)(K - 1)), iS = (int)(c % (unsigned)(K - 1));
+  const double h0 = unode(iH, K), s0 = unode(iS, K);
+  const double ih = 1.0 / (unode(iH + 1, K) - h0), is = 1.0 / (unode(iS + 1, K) - s0);
+  double a00 = 0.0, a10 = 0.0, a01 = 0.0, a11 = 0.0;
+  for (long long i = lo + threadIdx.x; i < hi; i += NT) {
+    const unsigned q = sidx[i];
+    const double wh = (H[q] - h0) * ih, ws = (S[q] - s0) * is, v = V[q];
+    a00 = fma(v, (1.0 - wh) * (1.0 - ws), a00);
+    a10 = fma(v, wh * (1.0 - ws), a10);
+    a01 = fma(v, (1.0 - wh) * ws, a01);
+    a11 = fma(v, wh * ws, a11);
+  }
+  a00 = block_sum(a00, red); __syncthreads();
+  a10 = block_sum(a10, red); __syncthreads();
+  a01 = block_sum(a01, red); __syncthreads();
+  a11 = block_sum(a11, red);
+  if (threadIdx.x == 0) {
+    cell4[4 * (long long)c + 0] = a00; cell4[4 * (long long)c + 1] = a10;
+    cell4[4 * (long long)c + 2] = a01; cell4[4 * (long long)c + 3] = a11;
+  }
+}
+
+// slot s differentiates the grid nodes s, s + KMAX, ... whose coefficient is not zero: G[q * KMAX + s] = sum c_ij dU/dtheta_q
+__global__ __launch_bounds__(64) void k_unode_grads(LawDev L, int K, const double* __restrict__ cell4, double* __restrict__ G) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= KMAX) return;
+  for (int q = 0; q < L.P; ++q) G[(long long)q * KMAX + s] = 0.0;
+  const int C = K - 1;
+  for (int node = s; node < K * K; node += KMAX) {
+    const int i = node / K, j = node - i * K;
+    double c = 0.0;
+    if (i < C && j < C) c += cell4[4 * ((long long)i * C + j) + 0];
+    if (i > 0 && j < C) c += cell4[4 * ((long long)(i - 1) * C + j) + 1];
+    if (i < C && j > 0) c += cell4[4 * ((long long)i * C + (j - 1)) + 2];
+    if (i > 0 && j > 0) c += cell4[4 * ((long long)(i - 1) * C + (j - 1)) + 3];
+    if (c != 0.0) mlp_grad(L, unode(i, K), unode(j, K), c, G + s, KMAX);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_slot_sum(int P, const double* __restrict__ G, double* __restrict__ dth, int accumulate) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= P) return;
+  double s = 0.0;
+  for (int k = 0; k < KMAX; ++k) s += G[(long long)q * KMAX + k];
+  dth[q] = accumulate ? dth[q] + s : s;
+}
+
 size_t interp_sort_temp_bytes(long long nd_max) {
-  size_t bytes = 0;
+  size_t bytes = 0, bytes_u = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, (const double*)nullptr, (double*)nullptr, (const double*)nullptr,
                                   (double*)nullptr, (size_t)nd_max, 0, 64, nullptr);
-  return bytes;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes_u, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr,
+                                  (unsigned*)nullptr, (size_t)nd_max, 0, 32, nullptr);
+  return bytes > bytes_u ? bytes : bytes_u;
+}
+
+// scratch: sA, sB (nd doubles each: hold the unsorted / sorted {key, index} pairs), tmp, cell4 (4 (K-1)^2), G (P * KMAX),
+// err (int, sticky: set when a node lies outside the interpolant's domain)
+int launch_interp_theta_U(hipStream_t st, const LawDev& L, int n_half, const double* nodeH, const double* nodeS, const double* nodeV,
+                          long long nd, double* sA, double* sB, void* tmp, size_t tmp_bytes, double* cell4, double* G, int* err,
+                          double* dth, int accumulate) {
+  const int K = 2 * n_half;
+  if (K > KMAX || n_half < 2 || nd >= (1ll << 32)) return 1;
+  unsigned* keys = reinterpret_cast<unsigned*>(sA);
+  unsigned* idx = keys + nd;
+  unsigned* skeys = reinterpret_cast<unsigned*>(sB);
+  unsigned* sidx = skeys + nd;
+  hipLaunchKernelGGL(k_ucell_keys, dim3((unsigned)((nd + NT - 1) / NT)), dim3(NT), 0, st, nodeH, nodeS, nd, K, keys, idx, err);
+  if (rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, idx, sidx, (size_t)nd, 0, 32, st) != hipSuccess) return 2;
+  hipLaunchKernelGGL(k_ucell_sums, dim3((unsigned)((K - 1) * (K - 1))), dim3(NT), 0, st, skeys, sidx, nd, nodeH, nodeS, nodeV, K, cell4);
+  hipLaunchKernelGGL(k_unode_grads, dim3(KMAX / 64), dim3(64), 0, st, L, K, cell4, G);
+  hipLaunchKernelGGL(k_slot_sum, dim3((L.P + 63) / 64), dim3(64), 0, st, L.P, G, dth, accumulate);
+  return 0;
 }
 
 // scratch: sH, sV (nd doubles each), tmp (interp_sort_temp_bytes), knots (KMAX), M (int), G (P * KMAX), ab (2 * KMAX)

@@ -41,6 +41,11 @@ int launch_interp_theta(hipStream_t st, const LawDev& L, double T, int n_half, c
                         long long nd, double* sH, double* sV, void* tmp, size_t tmp_bytes, double* knots, int* M, double* G,
                         double* ab, double* dth, int accumulate);
 
+// U law (SIA2D_D_target(interpolation = :Linear), target_D_pure.jl:179-193): bilinear on the fixed node grid of Laws.jl:128-169
+int launch_interp_theta_U(hipStream_t st, const LawDev& L, int n_half, const double* nodeH, const double* nodeS, const double* nodeV,
+                          long long nd, double* sA, double* sB, void* tmp, size_t tmp_bytes, double* cell4, double* G, int* err,
+                          double* dth, int accumulate);
+
 // k_vel.hip (A-type law modes 0/1 only)
 struct VArgs;
 void launch_surface_V(int lm, int nblk, hipStream_t st, Pools P, const double* U, double* Vx, double* Vy, int base);

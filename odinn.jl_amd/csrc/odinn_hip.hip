@@ -237,6 +237,8 @@ struct odinn_batch {
   }
   // `:Linear` interpolation of d law / d theta (Y law): knots of Hbar, see k_interp.hip
   int grad_interp = ODINN_GRAD_INTERP_NONE, n_interp_half = 75;
+  double *d_nodeS = nullptr, *d_ucell = nullptr;  // U law: slope of the dual nodes, corner sums of the node-grid cells
+  int* d_interp_err = nullptr;                    // sticky: a node fell outside the U law's interpolant (it does not extrapolate)
   double *d_nodeH = nullptr, *d_nodeV = nullptr, *d_sortH = nullptr, *d_sortV = nullptr, *d_knots = nullptr, *d_knotG = nullptr,
          *d_knotab = nullptr;
   int* d_knotM = nullptr;
@@ -1115,6 +1117,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_rega); dfree(b->d_regr); dfree(b->d_regg); dfree(b->d_regp); dfree(b->d_regm);
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
+  dfree(b->d_nodeS); dfree(b->d_ucell); if (b->d_interp_err) (void)hipFree(b->d_interp_err);
   dfree(b->d_nodeH); dfree(b->d_nodeV); dfree(b->d_sortH); dfree(b->d_sortV); dfree(b->d_knots); dfree(b->d_knotG);
   dfree(b->d_knotab); dfree(b->d_knotM);
   if (b->d_sorttmp) { (void)hipFree(b->d_sorttmp); b->d_sorttmp = nullptr; }
@@ -1333,6 +1336,12 @@ static int ensure_interp_scratch(odinn_batch* b) {
     b->sorttmp_bytes = interp_sort_temp_bytes(ndmax);
     HIPCHK(hipMalloc(&b->d_sorttmp, std::max<size_t>(b->sorttmp_bytes, 16)));
   }
+  if (b->law_kind == ODINN_LAW_NN_U && !b->d_nodeS) {
+    CHK(dalloc(&b->d_nodeS, (size_t)b->ntotd));
+    CHK(dalloc(&b->d_ucell, (size_t)4 * (INTERP_KMAX - 1) * (INTERP_KMAX - 1)));
+    HIPCHK(hipMalloc(&b->d_interp_err, sizeof(int)));
+    HIPCHK(hipMemsetAsync(b->d_interp_err, 0, sizeof(int), b->stream));
+  }
   const size_t need = (size_t)std::max(b->P, 1) * INTERP_KMAX;
   if (need > b->knotG_cap) {
     dfree(b->d_knotG);
@@ -1340,6 +1349,18 @@ static int ensure_interp_scratch(odinn_batch* b) {
     b->knotG_cap = need;
   }
   return ODINN_OK;
+}
+
+// U law, `:Linear`: Interpolations.Gridded(Linear()) does not extrapolate -- the reference throws a BoundsError when a
+// dual node has Hbar > 100 (or |grad S| > 100); reported once the stream has been synchronised
+static int check_interp_bounds(odinn_batch* b) {
+  if (!b->d_interp_err) return ODINN_OK;
+  int e = 0;
+  HIPCHK(hipMemcpy(&e, b->d_interp_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (!e) return ODINN_OK;
+  HIPCHK(hipMemset(b->d_interp_err, 0, sizeof(int)));
+  return fail(ODINN_ERR_ARG, "BoundsError: a dual node lies outside [0, 100] x [0, 100], the domain of the U law's gradient "
+                             "interpolant (Laws.jl:128-131, interpolation = :Linear)");
 }
 
 static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
@@ -1352,7 +1373,8 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   const bool nn_node = b->law_kind >= ODINN_LAW_NN_Y;
   const int base = g < 0 ? 0 : b->gd[g].tile0, nblk = g < 0 ? b->ntiles : b->gd[g].ntiles;
   if (nn_node) CHK(ensure_theta_scratch(b, nblk));
-  const bool linear = b->law_kind == ODINN_LAW_NN_Y && b->grad_interp == ODINN_GRAD_INTERP_LINEAR;
+  const bool linear = b->law_kind >= ODINN_LAW_NN_Y && b->grad_interp == ODINN_GRAD_INTERP_LINEAR;
+  const bool linU = linear && b->law_kind == ODINN_LAW_NN_U;
   if (linear) {
     CHK(ensure_interp_scratch(b));
     const int g0 = g < 0 ? 0 : g, g1 = g < 0 ? b->G : g + 1;
@@ -1360,9 +1382,10 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
     const long long hi = g1 < b->G ? b->gd[g1].offd : b->ntotd;
     HIPCHK(hipMemsetAsync(b->d_nodeH + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
     HIPCHK(hipMemsetAsync(b->d_nodeV + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
+    if (linU) HIPCHK(hipMemsetAsync(b->d_nodeS + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
   }
   ThArgs A{};
-  A.emitH = linear ? b->d_nodeH : nullptr; A.emitV = linear ? b->d_nodeV : nullptr;
+  A.emitH = linear ? b->d_nodeH : nullptr; A.emitV = linear ? b->d_nodeV : nullptr; A.emitS = linU ? b->d_nodeS : nullptr;
   A.H = H; A.lam = lam; A.lam_alt = lam_alt; A.scales = scales;
   A.snaps = snaps; A.adj = adj; A.ntot = b->ntot;
   A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
@@ -1379,7 +1402,11 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
     for (int q = g0; q < g0 + ng; ++q) {
       const GDev& r = b->gd[q];
       const long long nd = (long long)(r.nx - 1) * (r.ny - 1);
-      const int rc = launch_interp_theta(b->stream, L, b->descs[q].T, b->n_interp_half, b->d_nodeH + r.offd, b->d_nodeV + r.offd, nd,
+      const int rc = linU ? launch_interp_theta_U(b->stream, L, b->n_interp_half, b->d_nodeH + r.offd, b->d_nodeS + r.offd,
+                                                  b->d_nodeV + r.offd, nd, b->d_sortH, b->d_sortV, b->d_sorttmp, b->sorttmp_bytes,
+                                                  b->d_ucell, b->d_knotG, b->d_interp_err, b->d_dth + (size_t)q * b->P,
+                                                  accumulate ? 1 : 0)
+                          : launch_interp_theta(b->stream, L, b->descs[q].T, b->n_interp_half, b->d_nodeH + r.offd, b->d_nodeV + r.offd, nd,
                                          b->d_sortH, b->d_sortV, b->d_sorttmp, b->sorttmp_bytes, b->d_knots, b->d_knotM,
                                          b->d_knotG, b->d_knotab, b->d_dth + (size_t)q * b->P, accumulate ? 1 : 0);
       if (rc) return fail(ODINN_ERR_HIP, "gradient interpolation failed (code %d)", rc);
@@ -1423,7 +1450,7 @@ int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double
   if (b->law_kind >= ODINN_LAW_NN_Y) {
     HIPCHK(hipMemcpyAsync(dtheta, b->d_dth + (size_t)g * b->P, sizeof(double) * b->P, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    return ODINN_OK;
+    return check_interp_bounds(b);
   }
   if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) return gridded_law_grad(b, r.offd, nd, dtheta);
   double Gs = 0.0;
@@ -1440,8 +1467,8 @@ int odinn_set_grad_interpolation(odinn_batch* b, int kind, int n_interp_half) {
   if (!b || (kind != ODINN_GRAD_INTERP_NONE && kind != ODINN_GRAD_INTERP_LINEAR)) return fail(ODINN_ERR_ARG, "bad interpolation kind");
   if (kind == ODINN_GRAD_INTERP_LINEAR && (n_interp_half < 2 || 2 * n_interp_half > INTERP_KMAX))
     return fail(ODINN_ERR_ARG, "n_interp_half must be in [2, %d]", INTERP_KMAX / 2);
-  if (kind == ODINN_GRAD_INTERP_LINEAR && b->law_kind != ODINN_LAW_NN_Y)
-    return fail(ODINN_ERR_UNSUPPORTED, "linear interpolation of the law gradient is provided for the Y law (:D_hybrid) only");
+  if (kind == ODINN_GRAD_INTERP_LINEAR && b->law_kind < ODINN_LAW_NN_Y)
+    return fail(ODINN_ERR_UNSUPPORTED, "the A-type laws have no spatial law gradient to interpolate (Y and U laws only)");
   b->grad_interp = kind;
   if (kind == ODINN_GRAD_INTERP_LINEAR) b->n_interp_half = n_interp_half;
   return ODINN_OK;
@@ -1784,6 +1811,7 @@ static int grad_finish(odinn_batch* b, int k, int P, double const_loss, double* 
   } else {
     std::vector<double> dth((size_t)b->G * b->P);
     HIPCHK(hipMemcpy(dth.data(), b->d_dth, dth.size() * sizeof(double), hipMemcpyDeviceToHost));
+    CHK(check_interp_bounds(b));
     for (int g = 0; g < b->G; ++g)
       for (int q = 0; q < P; ++q) dtheta[q] += dth[(size_t)g * b->P + q];
   }

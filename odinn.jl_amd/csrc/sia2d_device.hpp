@@ -1696,6 +1696,7 @@ struct ThArgs {
   double* emitH;         // non-null (Y law, `:Linear` gradient interpolation, k_interp.hip): instead of backpropagating
   double* emitV;         //   per node, write Hbar and the node weight scale * spat * Da to these dual pooled arrays
                          //   (pre-zeroed by the caller: tiles that leave early contribute zeros)
+  double* emitS;         // U law: |grad S| of the node as well (the second axis of its gradient interpolant)
 };
 
 template <int LM>
@@ -1774,6 +1775,7 @@ __global__ __launch_bounds__(NT) void k_vjp_theta(Pools P, LawDev L, ThArgs A, i
         const long long q = g.offd + gi + (long long)(g.nx - 1) * gj;
         A.emitH[q] = Hb;
         A.emitV[q] = wgt;
+        if (L.kind == 4) A.emitS[q] = sqrt(gS2);
       } else if (!(L.kind == 4 && Hb == 0.0)) {  // target_D_pure.jl:166-168 skips Hbar == 0
         // accumulate wgt * dlaw/dtheta into the thread-private scratch
         const double x0 = (L.kind == 3) ? g.T : Hb, x1 = (L.kind == 3) ? Hb : sqrt(gS2);

@@ -654,6 +654,34 @@ def law_grad_theta_linear(law: Law, ph: Phys, Hbar, gradS, theta=None, n_interp_
     return (1.0 - w)[None] * G[:, k] + w[None] * G[:, k + 1]
 
 
+U_INTERP_NODE_MAX = 100.0  # LinRange(0.0, 100, n_nodes) (Laws.jl:131)
+
+
+def law_grad_theta_bilinear(law: Law, ph: Phys, Hbar, gradS, theta=None, n_interp_half=100):
+    """The `interpolation == :Linear` branch of dU/dtheta for the U law (target_D_pure.jl:179-193): d law / d theta
+    evaluated exactly on a fixed n_nodes x n_nodes grid, n_nodes = 2 n_interp_half (p_VJP!, Laws.jl:153-169), and
+    interpolated bilinearly (Interpolations.Gridded(Linear())) at (Hbar, |grad S|) of every dual node.
+    Both node axes are LinRange(0, 100, n_nodes): the law's cache is constructed with the Hbar nodes in the place of the
+    slope nodes as well (MatrixCacheInterp(zeros(..), H_nodes, H_nodes, grad_itp), Laws.jl:137-142), so the slope axis
+    the reference interpolates on is [0, 100] too and every physical slope lies in its first interval.  A gridded
+    interpolant does not extrapolate: a node with Hbar > 100 raises (BoundsError in the reference).
+    Shape (P, nx-1, ny-1)."""
+    if law.kind != LAW_NN_U:
+        raise ValueError("bilinear interpolation of the law gradient is the U law's (:D) branch")
+    th = law.theta if theta is None else theta
+    K = 2 * int(n_interp_half)
+    t = np.arange(K) / (K - 1.0)
+    nodes = (1.0 - t) * 0.0 + t * U_INTERP_NODE_MAX
+    if Hbar.max() > nodes[-1] or gradS.max() > nodes[-1] or Hbar.min() < 0.0 or gradS.min() < 0.0:
+        raise IndexError("BoundsError: the gradient interpolant of the U law is defined on [0, 100] x [0, 100]")
+    hh, ss = np.meshgrid(nodes, nodes, indexing="ij")
+    G = mlp_grad_theta(law.mlp, th, np.stack([hh, ss]))  # (P, K, K): exact gradients on the node grid
+    kh, wh = interp_linear_weights(nodes, Hbar)
+    ks, ws = interp_linear_weights(nodes, gradS)
+    return ((1.0 - wh) * (1.0 - ws))[None] * G[:, kh, ks] + (wh * (1.0 - ws))[None] * G[:, kh + 1, ks] \
+        + ((1.0 - wh) * ws)[None] * G[:, kh, ks + 1] + (wh * ws)[None] * G[:, kh + 1, ks + 1]
+
+
 def vjp_theta(lam, H, B, dx, dy, ph: Phys, law: Law, theta=None):
     """VJP_lambda_dSIA/dtheta_discrete (adjoint.jl:178-255):
     dtheta_k = sum_ij dD/dtheta_k[i,j] * D_adjoint[i,j]."""
@@ -665,6 +693,8 @@ def vjp_theta(lam, H, B, dx, dy, ph: Phys, law: Law, theta=None):
     kind, nhalf = law.interp()
     if kind == "linear" and law.kind == LAW_NN_Y and Hbar.max() > 0.0:
         g = law_grad_theta_linear(law, ph, Hbar, gS, theta, nhalf)  # the reference's default for :D_hybrid
+    elif kind == "linear" and law.kind == LAW_NN_U:
+        g = law_grad_theta_bilinear(law, ph, Hbar, gS, theta, nhalf)  # SIA2D_D_target(interpolation = :Linear)
     else:
         g = law_grad_theta(law, ph, Hbar, gS, theta)
     if law.kind == LAW_NN_A_SCALAR:

@@ -777,10 +777,76 @@ def test_Y_law_theta_gradient_interpolation_modes(gpu):
     gn = b.vjp_theta(0, lams[0], fields[0][0])
     assert 1e-12 < rel_l2(gl, gn) < 5e-3
     b.close()
-    # A-type and U laws keep the exact branch and reject the linear one
+    # A-type laws have no spatial law gradient: the linear branch is rejected
     b = gpu.GlacierBatch([(40, 33)], [100.0])
     with pytest.raises(gpu.OdinnError):
         b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, 75)
+    b.close()
+
+
+def test_U_law_theta_gradient_bilinear_interpolation(gpu):
+    """SIA2D_D_target(interpolation = :Linear) (target_D_pure.jl:179-193): gradients of the U law on the fixed
+    (2 n_interp_half)^2 node grid of LawU's p_VJP! (Laws.jl:128-169), bilinear in (Hbar, |grad S|).  On the device: dual
+    nodes sorted by grid cell, per-cell corner sums in a fixed order, backprop on the grid nodes that carry weight.
+    Against the oracle's restatement; ragged batch with an ice-free glacier; repeatable to the bit; the default of the law
+    stays :None; a node with Hbar > 100 fails like the reference's BoundsError and the batch stays usable."""
+    ph = O.Phys()
+    om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+    shapes = [(80, 48), (131, 97), (40, 33)]
+    fields = []
+    for k, (nx, ny) in enumerate(shapes):
+        H0, B = (O.synthetic_icecap(nx, ny, 100.0) if k != 1 else O.synthetic_valley(nx, ny, 100.0))
+        fields.append((H0 * (90.0 / H0.max()), B))
+    fields[2] = (np.zeros_like(fields[2][0]), fields[2][1])
+    b = gpu.GlacierBatch(shapes, [100.0] * 3)
+    for k, (H0, B) in enumerate(fields):
+        b.set_fields(k, H0, B)
+    b.set_law(gpu.LAW_NN_U, gm, th)
+    rng = np.random.default_rng(5)
+    lams = [rng.standard_normal(s) for s in shapes]
+    exact = [b.vjp_theta(k, lams[k], fields[k][0]) for k in range(3)]  # the law's default: :None
+    for k in range(2):
+        ref = O.vjp_theta(lams[k], fields[k][0], fields[k][1], 100.0, 100.0, ph, O.Law(kind=O.LAW_NN_U, mlp=om, theta=th))
+        assert rel_l2(exact[k], ref) < 1e-10
+    for n in (100, 10, 256):
+        b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, n)
+        for k, (H0, B) in enumerate(fields):
+            law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, interpolation="linear", n_interp_half=n)
+            ref = O.vjp_theta(lams[k], H0, B, 100.0, 100.0, ph, law)
+            got = b.vjp_theta(k, lams[k], H0)
+            if k == 2:
+                assert np.all(got == 0.0) and np.all(ref == 0.0)
+            else:
+                assert rel_l2(got, ref) < 1e-10, (n, k)
+                assert np.array_equal(got, b.vjp_theta(k, lams[k], H0))
+                assert 1e-12 < rel_l2(got, exact[k]) < 0.5  # interpolation error (the slope axis is [0, 100])
+    # outside the interpolant: error, then the batch keeps working
+    with pytest.raises(gpu.OdinnError, match="BoundsError"):
+        b.vjp_theta(0, lams[0], fields[0][0] * 1.5)
+    got = b.vjp_theta(0, lams[0], fields[0][0])
+    law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, interpolation="linear", n_interp_half=256)
+    assert rel_l2(got, O.vjp_theta(lams[0], fields[0][0], fields[0][1], 100.0, 100.0, ph, law)) < 1e-10
+    b.close()
+    # whole gradients through both adjoints with the :Linear branch on both sides
+    nx, ny = 56, 40
+    H0, B = O.synthetic_alpine(nx, ny, hmax=80.0, slope=0.1)
+    ts = [2010.0 + j / 48.0 for j in range(4)]
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, interpolation="linear", n_interp_half=100)
+    cfg = O.SimConfig(tstops=ts, reltol=1e-8)
+    ref, _, _ = O.forward(gl, law, cfg)
+    ref = [r * (1.0 + 0.02 * j) for j, r in enumerate(ref)]
+    b = gpu.GlacierBatch([(nx, ny)], [50.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_U, gm, th)
+    b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, 100)
+    b.set_reference(0, ts, ref, 3)
+    Lo, go = O.loss_and_grad(gl, law, cfg, ref, ts)[:2]
+    Lg, gg = b.loss_grad(ts, theta=th, reltol=1e-8)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo) and rel_l2(gg, go) < 1e-5
+    Lc, gc = O.loss_and_grad_continuous(gl, law, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=8))[:2]
+    Lg2, gg2 = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+    assert abs(Lg2 - Lc) <= 1e-6 * abs(Lc) and rel_l2(gg2, gc) < 1e-4
     b.close()
 
 

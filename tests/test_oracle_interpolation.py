@@ -53,3 +53,44 @@ def test_Y_law_gradient_linear_vs_exact():
     l75 = O.vjp_theta(lam, H, B, 50.0, 50.0, ph, O.Law(kind=O.LAW_NN_Y, mlp=mlp, theta=th, T=-5.0, interpolation="linear", n_interp_half=75))
     assert np.array_equal(dflt, l75)
     assert O.Law(kind=O.LAW_NN_U).interp()[0] == "none" and O.Law(kind=O.LAW_NN_A_SCALAR).interp()[0] == "none"
+
+
+def test_U_law_gradient_bilinear_node_grid():
+    """SIA2D_D_target(interpolation = :Linear) (target_D_pure.jl:179-193, Laws.jl:128-169): gradients on a fixed node grid
+    over [0, 100]^2, bilinear in (Hbar, |grad S|).  Checked: the bilinear weights reproduce a function affine in both
+    arguments exactly; with the slope axis the reference really uses ([0, 100]: every physical slope sits in the first
+    interval) the branch differs from the exact one by the interpolation error, which shrinks with the node count;
+    a node with Hbar > 100 raises (the gridded interpolant throws); the law's default stays :None."""
+    import pytest
+    ph = O.Phys()
+    H, B = O.synthetic_icecap(48, 40, 100.0)
+    H = H * (80.0 / H.max())
+    mlp = O.MLP([2, 3, 10, 3, 1], [1, 1, 1, 2], [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+    th = mlp.init_theta(np.random.default_rng(9)) + 0.05 * np.random.default_rng(10).standard_normal(mlp.n_params)
+    lam = np.random.default_rng(3).standard_normal(H.shape)
+    exact = O.vjp_theta(lam, H, B, 100.0, 100.0, ph, O.Law(kind=O.LAW_NN_U, mlp=mlp, theta=th))
+    err = []
+    for n in (10, 100, 250):
+        law = O.Law(kind=O.LAW_NN_U, mlp=mlp, theta=th, interpolation="linear", n_interp_half=n)
+        g = O.vjp_theta(lam, H, B, 100.0, 100.0, ph, law)
+        err.append(np.linalg.norm(g - exact) / np.linalg.norm(exact))
+    assert err[0] > err[1] > err[2] and np.isfinite(err).all(), err
+    # direct evaluation of the definition on one node: sum of the four corner gradients with tent weights
+    Hc = np.maximum(H, 0.0)
+    Hbar = O.avg(Hc)
+    S = B + Hc
+    gS = np.sqrt(O.avg_y(O.diff_x(S) / 100.0) ** 2 + O.avg_x(O.diff_y(S) / 100.0) ** 2)
+    G = O.law_grad_theta_bilinear(O.Law(kind=O.LAW_NN_U, mlp=mlp, theta=th), ph, Hbar, gS, th, 10)
+    K = 20
+    nodes = np.arange(K) / (K - 1.0) * 100.0
+    i, j = np.unravel_index(np.argmax(Hbar), Hbar.shape)
+    kh = int(np.searchsorted(nodes, Hbar[i, j], side="right") - 1)
+    wh = (Hbar[i, j] - nodes[kh]) / (nodes[kh + 1] - nodes[kh])
+    ws = gS[i, j] / nodes[1]
+    corner = lambda a, b_: O.mlp_grad_theta(mlp, th, np.array([[nodes[a]], [nodes[b_]]]))[:, 0]
+    want = (1 - wh) * (1 - ws) * corner(kh, 0) + wh * (1 - ws) * corner(kh + 1, 0) + (1 - wh) * ws * corner(kh, 1) \
+        + wh * ws * corner(kh + 1, 1)
+    assert np.allclose(G[:, i, j], want, rtol=1e-12, atol=1e-300)
+    with pytest.raises(IndexError):
+        O.vjp_theta(lam, H * 2.0, B, 100.0, 100.0, ph, O.Law(kind=O.LAW_NN_U, mlp=mlp, theta=th, interpolation="linear"))
+    assert O.Law(kind=O.LAW_NN_U).interp() == ("none", 100)
