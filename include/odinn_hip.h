@@ -203,6 +203,18 @@ int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_lo
  * weight = 0 (default) switches the term off; t1 <= t0 clears a glacier's data. */
 int odinn_set_dhdt_reference(odinn_batch* b, int g, double t0, double t1, double dhdt_ref);
 int odinn_set_dhdt_loss(odinn_batch* b, double weight);
+/* LossAvgV, the other time-aggregated loss (src/losses/TimeAggregatedLosses.jl:115-258): glacier.velocityData holds ONE
+ * sample (date1 = t1, date2 = t2; vabs, vx, vy as nx*ny column-major arrays with V_from_H's pairing).  With
+ * tLoss = t1:step:t2 (last point dropped), dt = diff, T = sum(dt), the predicted velocities V_from_H(H(tLoss_i)) are
+ * averaged with weights dt_i / T and compared with the sample by L2Sum on mask = vabs > 0 (component :xy, or :abs when
+ * component_abs != 0; normalization nx * ny); the term weight * loss joins odinn_loss / odinn_loss_grad /
+ * odinn_loss_grad_continuous, its cotangent dl/dV dt_i / T is pulled back through surface_V at every tLoss_i
+ * (VJP_lambda_dsurface_V/dH joins lambda at that stop, /dtheta joins dtheta; gradient.jl:170-215,274, :369-449,538).
+ * Every tLoss_i must be among the tstops of the solve (ODINN_ERR_ARG otherwise); A-type laws only (target :A), like LossV.
+ * weight = 0 (default) switches the term off; t2 <= t1 clears a glacier's sample. */
+int odinn_set_avgv_reference(odinn_batch* b, int g, double t1, double t2, const double* Vabs, const double* Vx,
+                             const double* Vy);
+int odinn_set_avgv_loss(odinn_batch* b, double weight, double step, int component_abs);
 
 /* ---- fine-grained seams (host in / host out; parity + drop-in, not the fast path) ---- */
 int odinn_sia2d_dhdt(odinn_batch* b, int g, const double* H, double t, double* dH);

@@ -52,7 +52,45 @@ function Batch(simulation; device = 0)
                         b.h, i - 1, length(tH), tH, Hs, simulation.parameters.UDE.empirical_loss_function.loss.distance))
         end
     end
+    set_time_aggregated_losses!(b, simulation)
+    set_grad_interpolation!(b, simulation)
     finalizer(x -> ccall((:odinn_batch_destroy, lib), Cint, (Ptr{Cvoid},), x.h), b)
+end
+
+# time-aggregated terms of a MultiLoss (src/losses/TimeAggregatedLosses.jl): data and weight relative to the data loss
+function set_time_aggregated_losses!(b::Batch, simulation)
+    lf = simulation.parameters.UDE.empirical_loss_function
+    terms = lf isa ODINN.MultiLoss ? collect(zip(lf.losses, lf.λs)) : [(lf, 1.0)]
+    wdata = something(findfirst(t -> t[1] isa Union{ODINN.LossH, ODINN.LossV, ODINN.LossHV}, terms), 0)
+    wdata = wdata == 0 ? 1.0 : terms[wdata][2]
+    for (l, w) in terms
+        if l isa ODINN.LossDhdt
+            for (i, g) in enumerate(simulation.glaciers)
+                check(ccall((:odinn_set_dhdt_reference, lib), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Cdouble),
+                            b.h, i - 1, g.dhdtData.t[1], g.dhdtData.t[2], g.dhdtData.dhdt))
+            end
+            check(ccall((:odinn_set_dhdt_loss, lib), Cint, (Ptr{Cvoid}, Cdouble), b.h, w / wdata))
+        elseif l isa ODINN.LossAvgV
+            for (i, g) in enumerate(simulation.glaciers)
+                v = g.velocityData
+                t1 = Sleipnir.datetime_to_floatyear(only(v.date1)); t2 = Sleipnir.datetime_to_floatyear(only(v.date2))
+                check(ccall((:odinn_set_avgv_reference, lib), Cint,
+                            (Ptr{Cvoid}, Cint, Cdouble, Cdouble, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                            b.h, i - 1, t1, t2, only(v.vabs), only(v.vx), only(v.vy)))
+            end
+            check(ccall((:odinn_set_avgv_loss, lib), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cint),
+                        b.h, w / wdata, l.step, l.component == :abs ? 1 : 0))
+        end
+    end
+end
+
+# `interpolation` / `n_interp_half` of the :D_hybrid and :D targets (target_D_hybrid.jl:12-15, target_D_pure.jl:34-39);
+# called again after odinn_set_law, which resets the mode to the law's default
+function set_grad_interpolation!(b::Batch, simulation)
+    tc = simulation.model.trainable_components
+    (isnothing(tc) || !hasproperty(tc, :target) || !hasproperty(tc.target, :interpolation)) && return
+    check(ccall((:odinn_set_grad_interpolation, lib), Cint, (Ptr{Cvoid}, Cint, Cint),
+                b.h, tc.target.interpolation == :Linear ? 1 : 0, tc.target.n_interp_half))
 end
 
 # ---- seam 1: the ODE right-hand side  (replaces Huginn.SIA2D! in SIA2D_UDE!,

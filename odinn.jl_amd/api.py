@@ -42,7 +42,7 @@ __all__ = [
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad", "load_gridded_glacier", "attach_rccl_comm",
-    "SIA2D_A_target", "SIA2D_D_hybrid_target", "SIA2D_D_target", "LossDhdt", "DhdtData",
+    "SIA2D_A_target", "SIA2D_D_hybrid_target", "SIA2D_D_target", "LossDhdt", "DhdtData", "LossAvgV",
 ]
 
 
@@ -179,6 +179,21 @@ class LossDhdt:
 
 
 @dataclass
+class LossAvgV:
+    """src/losses/TimeAggregatedLosses.jl:115-258: L2Sum between the time-weighted average of the predicted surface
+    velocity over velocityData's single sample [date1, date2] (time grid date1:step:date2) and that sample (component
+    :xy | :abs) -- a time-aggregated loss, evaluated on the device; its cotangent is pulled back through surface_V at
+    every point of the time grid."""
+
+    loss: L2Sum = field(default_factory=L2Sum)
+    component: str = "xy"
+    step: float = 1.0 / 12.0
+
+
+_AGGREGATED = (LossDhdt, LossAvgV)
+
+
+@dataclass
 class MultiLoss:
     """src/losses/MultiLoss.jl:22-35: sum_k lambdas[k] * losses[k].  One data term (LossH | LossV |
     LossHV, evaluated by the device adjoint) plus any number of regularisers."""
@@ -193,18 +208,18 @@ class MultiLoss:
 
 def _split_loss(lf):
     """(data loss, its weight, [(regulariser, weight)]) of a loss specification."""
-    if isinstance(lf, LossDhdt):
+    if isinstance(lf, _AGGREGATED):
         return LossH(), 1.0, [(lf, 1.0)]  # no thickness data -> the data term is 0
     if not isinstance(lf, MultiLoss):
         return lf, 1.0, []
     data = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if isinstance(l, (LossH, LossV, LossHV))]
     regs = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if not isinstance(l, (LossH, LossV, LossHV))]
-    if len(data) == 0 and any(isinstance(r, LossDhdt) for r, _ in regs):
-        data = [(LossH(), 1.0)]  # LossDhdt alone: a LossH without thickness data contributes nothing
+    if len(data) == 0 and any(isinstance(r, _AGGREGATED) for r, _ in regs):
+        data = [(LossH(), 1.0)]  # time-aggregated losses alone: a LossH without thickness data contributes nothing
     if len(data) != 1:
         raise ValueError("MultiLoss needs exactly one data term (LossH, LossV or LossHV)")
     for r, _ in regs:
-        if not isinstance(r, (InitialThicknessRegularization, RheologyRegularization, LossDhdt)):
+        if not isinstance(r, (InitialThicknessRegularization, RheologyRegularization, LossDhdt, LossAvgV)):
             raise TypeError(f"loss term {type(r).__name__} is not provided")
     return data[0][0], float(data[0][1]), regs
 
@@ -276,12 +291,25 @@ class DhdtData:
 
 @dataclass
 class VelocityData:
-    """glacier.velocityData: absolute value and components at dates t (nx*ny fields)."""
+    """glacier.velocityData: absolute value and components at dates t (nx*ny fields).  date1 / date2 (decimal years): the
+    acquisition window of each sample -- LossAvgV reads them (exactly one sample), LossV compares at t."""
 
     t: Sequence[float]
     vabs: Sequence[np.ndarray]
     vx: Sequence[np.ndarray]
     vy: Sequence[np.ndarray]
+    date1: Optional[Sequence[float]] = None
+    date2: Optional[Sequence[float]] = None
+
+
+def _avgv_times(g, loss) -> List[float]:
+    """discretePostIntegralLossSteps(::LossAvgV) (TimeAggregatedLosses.jl:355-363): date1:step:date2 without its last point."""
+    v = g.velocityData
+    if v is None or v.date1 is None or v.date2 is None or len(v.date1) != 1 or len(v.date2) != 1:
+        raise ValueError("With LossAvgV the velocity data should contain exactly one sample.")  # :356
+    t1, t2 = float(v.date1[0]), float(v.date2[0])
+    n = int(math.floor((t2 - t1) / loss.step + 1e-9))
+    return [t1 + i * loss.step for i in range(n)]
 
 
 @dataclass
@@ -857,8 +885,12 @@ class _Simulation:
                 ts |= set(float(t) for t in g.thicknessData.t)
             if g.velocityData is not None:
                 ts |= set(float(t) for t in g.velocityData.t)
-            if g.dhdtData is not None and any(isinstance(r, LossDhdt) for r, _ in _split_loss(p.UDE.empirical_loss_function)[2]):
+            regs_ = _split_loss(p.UDE.empirical_loss_function)[2]
+            if g.dhdtData is not None and any(isinstance(r, LossDhdt) for r, _ in regs_):
                 ts |= set(float(t) for t in g.dhdtData.t)  # discretePostIntegralLossSteps (TimeAggregatedLosses.jl:352-354)
+            for r, _ in regs_:
+                if isinstance(r, LossAvgV):  # :355-363
+                    ts |= set(_avgv_times(g, r))
         return sorted(t for t in ts if p.simulation.tspan[0] <= t <= p.simulation.tspan[1])
 
     def mb_times(self):
@@ -892,11 +924,17 @@ class _Simulation:
             dist_ = (lf.hLoss.loss.distance if isinstance(lf, LossHV) else lf.loss.distance)
             if g.thicknessData is not None:
                 b.set_reference(k, g.thicknessData.t, g.thicknessData.H, dist_)
-            if g.velocityData is not None:
+            if g.velocityData is not None and len(g.velocityData.t) > 0:
                 v = g.velocityData
                 b.set_velocity_reference(k, v.t, v.vabs, v.vx, v.vy)
         lf, w_data, regs_ = _split_loss(p.UDE.empirical_loss_function)
         for r, w in regs_:
+            if isinstance(r, LossAvgV):  # evaluated on the device, weight relative to the data loss
+                for k, g in enumerate(gl):
+                    _avgv_times(g, r)  # validates velocityData
+                    v = g.velocityData
+                    b.set_avgv_reference(k, v.date1[0], v.date2[0], v.vabs[0], v.vx[0], v.vy[0])
+                b.set_avgv_loss(float(w) / w_data, r.step, r.component)
             if isinstance(r, LossDhdt):  # the device evaluates the term; its weight is relative to the data loss, which
                 for k, g in enumerate(gl):  # SIA2D_grad_b scales by w_data afterwards
                     if g.dhdtData is None:
@@ -1069,8 +1107,8 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
     dth *= w_data
     tspan = p.simulation.tspan
     for reg, w in regs:
-        if isinstance(reg, LossDhdt):
-            continue  # evaluated on the device inside loss_grad (odinn_set_dhdt_loss)
+        if isinstance(reg, _AGGREGATED):
+            continue  # evaluated on the device inside loss_grad (odinn_set_dhdt_loss / odinn_set_avgv_loss)
         if isinstance(reg, InitialThicknessRegularization):
             if model.IC is None:
                 raise ValueError("Regularization with respect to initial condition requires to set initial "

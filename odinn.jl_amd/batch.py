@@ -239,6 +239,21 @@ class GlacierBatch:
         """glacier.dhdtData of LossDhdt (TimeAggregatedLosses.jl:38-113): mean elevation-change rate between t0 and t1."""
         L.check(L.lib().odinn_set_dhdt_reference(self._h, int(g), float(t0), float(t1), float(dhdt_ref)))
 
+    def set_avgv_reference(self, g, t1, t2, vabs, vx, vy):
+        """glacier.velocityData of LossAvgV (TimeAggregatedLosses.jl:115-258): ONE sample covering [t1, t2] (date1, date2),
+        nx*ny arrays with V_from_H's pairing; t2 <= t1 clears it."""
+        nx, ny = self.shapes[g]
+        if not t2 > t1:
+            L.check(L.lib().odinn_set_avgv_reference(self._h, int(g), float(t1), float(t2), None, None, None))
+            return
+        va, vx_, vy_ = (np.ascontiguousarray(_f(a, (nx, ny)).ravel(order="F")) for a in (vabs, vx, vy))
+        L.check(L.lib().odinn_set_avgv_reference(self._h, int(g), float(t1), float(t2), _p(va), _p(vx_), _p(vy_)))
+
+    def set_avgv_loss(self, weight=1.0, step=1.0 / 12.0, component="xy"):
+        """weight of the LossAvgV term relative to the data loss (its MultiLoss lambda; 0 switches it off), the spacing of
+        its time grid and the compared component (:xy | :abs)."""
+        L.check(L.lib().odinn_set_avgv_loss(self._h, float(weight), float(step), 1 if component == "abs" else 0))
+
     def set_dhdt_loss(self, weight=1.0):
         """weight of the LossDhdt term relative to the data loss (its MultiLoss lambda); 0 switches it off."""
         L.check(L.lib().odinn_set_dhdt_loss(self._h, float(weight)))

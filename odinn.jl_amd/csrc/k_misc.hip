@@ -61,6 +61,10 @@ void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, doub
 void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd) {
   hipLaunchKernelGGL(k_eval_law, dim3((unsigned)((nd + NT - 1) / NT)), dim3(NT), 0, st, P, L, U, out, gidx);
 }
+void launch_axpy(long long n, hipStream_t st, double a, const double* x, const double* y, double* z) {
+  const long long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_axpy, dim3((unsigned)(nb < 65536 ? (nb < 1 ? 1 : nb) : 65536)), dim3(256), 0, st, n, a, x, y, z);
+}
 void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const double* y, double* z) {
   hipLaunchKernelGGL(k_axpy_g, dim3(nblk), dim3(NT), 0, st, P, x, y, z);
 }

@@ -50,6 +50,9 @@ int launch_interp_theta_U(hipStream_t st, const LawDev& L, int n_half, const dou
 struct VArgs;
 void launch_surface_V(int lm, int nblk, hipStream_t st, Pools P, const double* U, double* Vx, double* Vy, int base);
 void launch_surfV_vjp(int lm, int mode, int nblk, hipStream_t st, Pools P, const VArgs& A, int base);
+void launch_avgv_axpy(int nblk, hipStream_t st, Pools P, const double* Vx, const double* Vy, double* ax, double* ay, const double* w);
+void launch_avgv_cot(int nblk, hipStream_t st, Pools P, double* ax, double* ay, const double* Vabs, const double* Vxr,
+                     const double* Vyr, const unsigned char* on, int component_abs, double weight);
 
 // k_misc.hip
 void launch_controller(int G, hipStream_t st, Pools P, CtrlArgs C);
@@ -75,6 +78,7 @@ void launch_law_field_grad(int nblk, hipStream_t st, LawDev L, const double* T, 
 void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, double* out);
 void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd);
 void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const double* y, double* z);
+void launch_axpy(long long n, hipStream_t st, double a, const double* x, const double* y, double* z);  // z = y + a x
 void launch_initdt_norms(int nblk, hipStream_t st, Pools P, const double* U, const double* F0, const double* F1,
                          double abstol, double reltol);
 void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan, double dtmax, double* dt0store);

@@ -235,6 +235,22 @@ struct odinn_batch {
     for (size_t g = 0; g < dh_t0.size(); ++g) if (dh_t1[g] > dh_t0[g]) return true;
     return false;
   }
+  // LossAvgV (time-aggregated loss): one velocity sample per glacier (pooled), per-stop weights dt_i / T, the time-averaged
+  // velocity / its cotangents (d_avg[0..1]; [2..3]: V of one stop), dL/dH of every tLoss stop (d_aggH[slot])
+  std::vector<double> av_t1, av_t2;
+  double avgv_weight = 0.0, avgv_step = 1.0 / 12.0;
+  int avgv_abs = 0;
+  double *d_aVabs = nullptr, *d_aVx = nullptr, *d_aVy = nullptr, *d_avg = nullptr, *d_wA = nullptr, *d_aggH = nullptr;
+  int* d_agg_slot = nullptr;
+  unsigned char* d_av_on = nullptr;
+  size_t wA_cap = 0, aggH_cap = 0, agg_slot_cap = 0;
+  std::vector<double> wA_h;
+  std::vector<int> agg_slot_h;
+  bool avgv_on() const {
+    if (!(avgv_weight != 0.0) || !d_aVabs) return false;
+    for (size_t g = 0; g < av_t1.size(); ++g) if (av_t2[g] > av_t1[g]) return true;
+    return false;
+  }
   // `:Linear` interpolation of d law / d theta (Y law): knots of Hbar, see k_interp.hip
   int grad_interp = ODINN_GRAD_INTERP_NONE, n_interp_half = 75;
   double *d_nodeS = nullptr, *d_ucell = nullptr;  // U law: slope of the dual nodes, corner sums of the node-grid cells
@@ -905,6 +921,85 @@ int dhdt_forward(odinn_batch* b) {
   return ODINN_OK;
 }
 
+// LossAvgV after a forward solve (TimeAggregatedLosses.jl:146-258): per-glacier tLoss -> stop weights dt_i / T, the time-
+// averaged velocity, its loss (added onto d_lossacc[g]) and, with_grad, everything of its gradient that does not involve
+// lambda: dL/dH of every tLoss stop (d_aggH[agg_slot[j]], added to lambda at stop j by the reverse loops) and dL/dtheta
+// (d_Gsum / d_Gacc, which the reverse loops go on accumulating into)
+int avgv_forward(odinn_batch* b, bool with_grad) {
+  const int k = (int)b->tstops.size();
+  b->agg_slot_h.assign(k, -1);
+  if (!b->avgv_on()) return ODINN_OK;
+  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "LossAvgV needs an A-type law (target :A)");
+  const int G = b->G;
+  b->wA_h.assign((size_t)k * G, 0.0);
+  std::vector<unsigned char> on(G, 0);
+  for (int g = 0; g < G; ++g) {
+    const double t1 = b->av_t1[g], t2 = b->av_t2[g], st = b->avgv_step;
+    if (!(t2 > t1)) continue;
+    const int n = (int)std::floor((t2 - t1) / st + 1e-9);  // tLoss = collect(t1:step:t2) has n + 1 points
+    if (n < 1) return fail(ODINN_ERR_ARG, "LossAvgV: (t1, t2) = (%g, %g) of glacier %d holds no interval of length step = %g", t1, t2, g, st);
+    double T = 0.0;
+    for (int i = 0; i < n; ++i) T += (t1 + (i + 1) * st) - (t1 + i * st);
+    for (int i = 0; i < n; ++i) {
+      const double x = t1 + i * st;
+      int jj = -1;
+      for (int j = 0; j < k; ++j)
+        if (std::fabs(b->tstops[j] - x) <= 1e-9) { jj = j; break; }
+      if (jj < 0) return fail(ODINN_ERR_ARG, "LossAvgV: time %.10g of glacier %d is not among the tstops", x, g);
+      b->wA_h[(size_t)jj * G + g] = ((t1 + (i + 1) * st) - x) / T;
+    }
+    on[g] = 1;
+  }
+  int nslots = 0;
+  for (int j = 0; j < k; ++j) {
+    bool any = false;
+    for (int g = 0; g < G; ++g) any = any || b->wA_h[(size_t)j * G + g] != 0.0;
+    if (any) b->agg_slot_h[j] = nslots++;
+  }
+  if (!b->d_avg) CHK(dalloc(&b->d_avg, (size_t)4 * b->ntot));
+  if (!b->d_av_on) HIPCHK(hipMalloc(&b->d_av_on, (size_t)G));
+  if ((size_t)k * G > b->wA_cap) { dfree(b->d_wA); CHK(dalloc(&b->d_wA, (size_t)k * G)); b->wA_cap = (size_t)k * G; }
+  if ((size_t)k > b->agg_slot_cap) {
+    if (b->d_agg_slot) (void)hipFree(b->d_agg_slot);
+    b->d_agg_slot = nullptr;
+    HIPCHK(hipMalloc(&b->d_agg_slot, sizeof(int) * k));
+    b->agg_slot_cap = (size_t)k;
+  }
+  if (with_grad && (size_t)nslots * b->ntot > b->aggH_cap) {
+    dfree(b->d_aggH);
+    CHK(dalloc(&b->d_aggH, (size_t)nslots * b->ntot));
+    b->aggH_cap = (size_t)nslots * b->ntot;
+  }
+  HIPCHK(hipMemcpyAsync(b->d_wA, b->wA_h.data(), sizeof(double) * k * G, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_agg_slot, b->agg_slot_h.data(), sizeof(int) * k, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_av_on, on.data(), (size_t)G, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));  // `on` is a temporary
+  double *ax = b->d_avg, *ay = b->d_avg + b->ntot, *vx = b->d_avg + 2 * b->ntot, *vy = b->d_avg + 3 * b->ntot;
+  HIPCHK(hipMemsetAsync(ax, 0, (size_t)2 * b->ntot * sizeof(double), b->stream));
+  const Pools P = b->pools(true);
+  for (int j = 0; j < k; ++j) {
+    if (b->agg_slot_h[j] < 0) continue;
+    launch_surface_V(b->lm(), b->ntiles, b->stream, P, b->d_snaps + (size_t)j * b->ntot, vx, vy, 0);
+    launch_avgv_axpy(b->ntiles, b->stream, P, vx, vy, ax, ay, b->d_wA + (size_t)j * G);
+  }
+  launch_avgv_cot(b->ntiles, b->stream, P, ax, ay, b->d_aVabs, b->d_aVx, b->d_aVy, b->d_av_on, b->avgv_abs, b->avgv_weight);
+  launch_sum_part(G, b->stream, P, 1, b->d_lossacc, 1, 0);
+  if (with_grad) {
+    HIPCHK(hipMemsetAsync(b->d_aggH, 0, (size_t)nslots * b->ntot * sizeof(double), b->stream));
+    for (int j = 0; j < k; ++j) {
+      if (b->agg_slot_h[j] < 0) continue;
+      VArgs A{};
+      A.H = b->d_snaps + (size_t)j * b->ntot; A.dVx = ax; A.dVy = ay; A.out = b->d_aggH + (size_t)b->agg_slot_h[j] * b->ntot;
+      A.wv = b->d_wA + (size_t)j * G; A.ntot = b->ntot;
+      A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
+      launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, A, 0);
+      launch_sum_part(G, b->stream, P, 3, b->d_Gsum, 1, 0);
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
 // forward loss over the stored snapshots -> d_lossacc[g]; *const_loss: data-only part of LossV
 int do_loss(odinn_batch* b, double* const_loss) {
   const int k = (int)b->tstops.size();
@@ -923,7 +1018,8 @@ int do_loss(odinn_batch* b, double* const_loss) {
       *const_loss += c;
     }
   }
-  CHK(dhdt_forward(b));  // time-aggregated term (inversion_utils.jl:457-460)
+  CHK(dhdt_forward(b));  // time-aggregated terms (inversion_utils.jl:457-460)
+  CHK(avgv_forward(b, false));
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -969,6 +1065,7 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   b->gd.resize(n_glaciers);
   b->t_ref.resize(n_glaciers);
   b->dh_t0.assign(n_glaciers, 0.0); b->dh_t1.assign(n_glaciers, 0.0); b->dh_ref.assign(n_glaciers, 0.0);
+  b->av_t1.assign(n_glaciers, 0.0); b->av_t2.assign(n_glaciers, 0.0);
   b->t_vref.resize(n_glaciers); b->v_scale.resize(n_glaciers); b->v_cxy.resize(n_glaciers); b->v_cabs.resize(n_glaciers);
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
@@ -1117,6 +1214,9 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_rega); dfree(b->d_regr); dfree(b->d_regg); dfree(b->d_regp); dfree(b->d_regm);
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
+  dfree(b->d_aVabs); dfree(b->d_aVx); dfree(b->d_aVy); dfree(b->d_avg); dfree(b->d_wA); dfree(b->d_aggH);
+  if (b->d_agg_slot) (void)hipFree(b->d_agg_slot);
+  if (b->d_av_on) (void)hipFree(b->d_av_on);
   dfree(b->d_nodeS); dfree(b->d_ucell); if (b->d_interp_err) (void)hipFree(b->d_interp_err);
   dfree(b->d_nodeH); dfree(b->d_nodeV); dfree(b->d_sortH); dfree(b->d_sortV); dfree(b->d_knots); dfree(b->d_knotG);
   dfree(b->d_knotab); dfree(b->d_knotM);
@@ -1501,6 +1601,32 @@ int odinn_set_dhdt_loss(odinn_batch* b, double weight) {
   return ODINN_OK;
 }
 
+int odinn_set_avgv_reference(odinn_batch* b, int g, double t1, double t2, const double* Vabs, const double* Vx,
+                             const double* Vy) {
+  CHK(check_g(b, g)); CHK(use_dev(b));
+  if (!(t2 > t1)) { b->av_t1[g] = 0.0; b->av_t2[g] = 0.0; return ODINN_OK; }
+  if (!Vabs || !Vx || !Vy) return fail(ODINN_ERR_ARG, "null velocity sample");
+  if (!b->d_aVabs) {
+    CHK(dalloc(&b->d_aVabs, (size_t)b->ntot)); CHK(dalloc(&b->d_aVx, (size_t)b->ntot)); CHK(dalloc(&b->d_aVy, (size_t)b->ntot));
+    HIPCHK(hipMemset(b->d_aVabs, 0, (size_t)b->ntot * sizeof(double)));
+    HIPCHK(hipMemset(b->d_aVx, 0, (size_t)b->ntot * sizeof(double)));
+    HIPCHK(hipMemset(b->d_aVy, 0, (size_t)b->ntot * sizeof(double)));
+  }
+  const GDev& r = b->gd[g];
+  const size_t nb = (size_t)r.nx * r.ny * sizeof(double);
+  HIPCHK(hipMemcpy(b->d_aVabs + r.off, Vabs, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_aVx + r.off, Vx, nb, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_aVy + r.off, Vy, nb, hipMemcpyHostToDevice));
+  b->av_t1[g] = t1; b->av_t2[g] = t2;
+  return ODINN_OK;
+}
+
+int odinn_set_avgv_loss(odinn_batch* b, double weight, double step, int component_abs) {
+  if (!b || !(weight >= 0.0) || !(step > 0.0)) return fail(ODINN_ERR_ARG, "bad LossAvgV weight / step");
+  b->avgv_weight = weight; b->avgv_step = step; b->avgv_abs = component_abs ? 1 : 0;
+  return ODINN_OK;
+}
+
 int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double* t_ref, const double* Vabs,
                                  const double* Vx, const double* Vy) {
   if (b) b->refs_version++;
@@ -1700,7 +1826,7 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
   if (theta) CHK(odinn_set_theta(b, theta, P));
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
-  if (b->loss_kind != ODINN_LOSS_V && !b->d_Href && !b->dhdt_on()) return fail(ODINN_ERR_STATE, "no reference thickness data set");
+  if (b->loss_kind != ODINN_LOSS_V && !b->d_Href && !b->dhdt_on() && !b->avgv_on()) return fail(ODINN_ERR_STATE, "no reference thickness data set");
   if (b->loss_kind != ODINN_LOSS_H && !b->d_Vabs) return fail(ODINN_ERR_STATE, "no reference velocity data set");
   if (b->vjp_method == 1 && b->law_kind >= ODINN_LAW_NN_Y)
     return fail(ODINN_ERR_UNSUPPORTED, "ContinuousVJP is provided for target :A (A-type laws) only");
@@ -1716,6 +1842,7 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
     HIPCHK(hipMemsetAsync(b->d_dth, 0, sizeof(double) * b->G * b->P, b->stream));
   }
   CHK(dhdt_forward(b));  // LossDhdt: loss term and the coefficients of its cotangent fields (gradient.jl:170-188)
+  CHK(avgv_forward(b, true));  // LossAvgV: loss term, dL/dH of its stops, dL/dtheta
   return ODINN_OK;
 }
 static int grad_finish(odinn_batch* b, int k, int P, double const_loss, double* loss, double* dtheta);
@@ -1762,6 +1889,8 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
       for (int g = 0; g < b->G; ++g) any = any || b->dh_i0_h[g] == j || b->dh_i1_h[g] == j;
       if (any) launch_dhdt_cot(b->ntiles, b->stream, Psw, lam_new, b->d_snaps, b->d_dh_i0, b->d_dh_i1, b->d_dh_coef, j, b->ntot);
     }
+    if (b->agg_slot_h[j] >= 0)  // LossAvgV: dL/dH of this stop (:212-215)
+      launch_axpy(b->ntot, b->stream, 1.0, b->d_aggH + (size_t)b->agg_slot_h[j] * b->ntot, lam_new, lam_new);
     if (b->loss_kind != ODINN_LOSS_H) {  // backward_loss(::LossV): dl/dH into lambda_{j-1}, dl/dtheta into dtheta
       double c = 0.0;
       CHK(launch_lossV(b, j, Hj, lam_new, true, &c));
@@ -1954,6 +2083,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   const bool theta_itp = !useV && b->law_kind < ODINN_LAW_NN_Y;
   AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = theta_itp ? nullptr : b->d_tmpA;
   if (b->dhdt_on()) { AP.dh_i0 = b->d_dh_i0; AP.dh_i1 = b->d_dh_i1; AP.dh_coef = b->d_dh_coef; }
+  if (b->avgv_on()) { AP.agg_slot = b->d_agg_slot; AP.aggH = b->d_aggH; }
   const bool mb_last = b->any_mb && b->mb_flag[k - 1];
   launch_adj_begin(G, b->stream, Pl, b->d_adj, k, h_tau[0], mb_last ? 1 : 0, mb_last ? b->mb_slot[k - 1] : 0);
   // loss term of a velocity-data snapshot: lam += wV dl_V/dH(H_j)  (backward_loss(::LossV), Losses.jl:338-390)

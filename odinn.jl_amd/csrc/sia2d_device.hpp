@@ -1186,6 +1186,10 @@ struct AdjPostArgs {
   const int* dh_i0;
   const int* dh_i1;
   const double* dh_coef;
+  // LossAvgV (TimeAggregatedLosses.jl:183-258): dL/dH of the stop snapj, precomputed after the forward solve, lives in
+  // aggH[agg_slot[snapj]] (zero for glaciers whose tLoss does not contain the stop); null: off
+  const int* agg_slot;
+  const double* aggH;
 };
 
 __device__ __forceinline__ double mb_value(const GDev& g, double mb0, double sref, double H, double B, double& dmb) {
@@ -2226,6 +2230,10 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
           const int q0 = A.dh_i0[t4.x], q1 = A.dh_i1[t4.x];
           if (q0 >= 0 && (a.snapj == q0 || a.snapj == q1) && A.snaps[(long long)q0 * A.ntot + id] > 1e-2)
             dagg = a.snapj == q1 ? A.dh_coef[t4.x] : -A.dh_coef[t4.x];
+        }
+        if (A.aggH) {
+          const int sl = A.agg_slot[a.snapj];
+          if (sl >= 0) dagg += A.aggH[(long long)sl * A.ntot + id];
         }
         if (A.loss_first) l += dl + dagg;
         if (do_mb) {

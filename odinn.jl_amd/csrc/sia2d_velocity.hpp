@@ -7,6 +7,9 @@
 //   k_surfV_vjp<1>: the same with the cotangent taken from LossV on the fly
 //                   (backward_loss(::LossV), Losses.jl:338-390: L2Sum on :xy or :abs, mask
 //                   V_ref > 0, optional scaling) and accumulated into the adjoint state.
+//   k_surfV_vjp<2>: explicit cotangent arrays scaled per glacier by wv and accumulated -- the per-stop pull-back of
+//                   LossAvgV (TimeAggregatedLosses.jl:240-252), with k_avgv_axpy / k_avgv_cot forming the time-averaged
+//                   velocity, its loss and the cotangent dl/dV (:206-231).
 #pragma once
 #include "sia2d_device.hpp"
 
@@ -114,14 +117,16 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
     }
     sc = A.scale[q];
     roff = (long long)A.refslot[q] * A.ntot;
-  } else if (MODE == 1) {
+  } else if (MODE >= 1) {
     wv = A.wv[t4.x];
     if (wv == 0.0) {  // no velocity data at this stop for this glacier
-      if (threadIdx.x == 0) { P.part[4 * (long long)t4.w + 3] = 0.0; P.part[4 * (long long)t4.w + 1] = 0.0; }
+      if (threadIdx.x == 0) { P.part[4 * (long long)t4.w + 3] = 0.0; if (MODE == 1) P.part[4 * (long long)t4.w + 1] = 0.0; }
       return;
     }
-    sc = A.scale[t4.x];
-    roff = (long long)A.refslot[t4.x] * A.ntot;
+    if (MODE == 1) {
+      sc = A.scale[t4.x];
+      roff = (long long)A.refslot[t4.x] * A.ntot;
+    }
   }
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   double own[RPT];
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
       const long long id = g.off + gi + (long long)g.nx * gj;  // inn1 pairing: node (gi,gj) <-> element [gi,gj]
       const bool owned = (a >= 1 && b >= 1);  // lower-left cell inside the tile interior: reduced here
       double dvx, dvy;
-      if (MODE == 0) {
+      if (MODE != 1) {
         dvx = A.dVx[id];
         dvy = A.dVy[id];
       } else {
@@ -201,5 +206,72 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
     if (MODE == 1) P.part[4 * (long long)t4.w + 1] = lt * Ninv * sc * wv;
   }
 }
+
+// ---- LossAvgV (TimeAggregatedLosses.jl:115-258) ---------------------------------------------------------------------
+#ifdef ODINN_VEL_KERNELS  // non-template kernels: compiled by k_vel.hip only
+// avg += w_g V  for the glaciers whose tLoss contains this stop (w_g = dt_i / T, 0: not this glacier)
+__global__ __launch_bounds__(NT) void k_avgv_axpy(Pools P, const double* __restrict__ Vx, const double* __restrict__ Vy,
+                                                  double* __restrict__ ax, double* __restrict__ ay, const double* __restrict__ w) {
+  const int4 t4 = P.tiles[blockIdx.x];
+  const double wg = w[t4.x];
+  if (wg == 0.0) return;
+  const GDev g = P.gd[t4.x];
+  const int gi = t4.y * TX + (threadIdx.x & 63), ty = wave_id();
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = t4.z * TY + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      ax[id] = fma(Vx[id], wg, ax[id]);
+      ay[id] = fma(Vy[id], wg, ay[id]);
+    }
+  }
+}
+// loss of the averaged velocity against the single reference sample (L2Sum, mask V_ref > 0, normalization nx ny) into the
+// tile partial slot 1, and the averages REPLACED by the cotangents weight * dl/dVx, weight * dl/dVy (:xy or :abs, :224-231)
+__global__ __launch_bounds__(NT) void k_avgv_cot(Pools P, double* __restrict__ ax, double* __restrict__ ay,
+                                                 const double* __restrict__ Vabs, const double* __restrict__ Vxr,
+                                                 const double* __restrict__ Vyr, const unsigned char* __restrict__ on,
+                                                 int component_abs, double weight) {
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  if (!on[t4.x]) {
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = 0.0;
+    return;
+  }
+  const GDev g = P.gd[t4.x];
+  const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
+  const int gi = t4.y * TX + (threadIdx.x & 63), ty = wave_id();
+  double lsum = 0.0;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = t4.z * TY + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double va = Vabs[id];
+      double cx = 0.0, cy = 0.0;
+      if (va > 0.0) {
+        const double vx = ax[id], vy = ay[id];
+        const double ex = vx - Vxr[id], ey = vy - Vyr[id];
+        if (!component_abs) {
+          cx = 2.0 * ex * Ninv * weight;
+          cy = 2.0 * ey * Ninv * weight;
+          lsum = fma(ex, ex, fma(ey, ey, lsum));
+        } else {
+          const double ev = sqrt(vx * vx + vy * vy) - va;
+          const double dv = 2.0 * ev * Ninv;
+          cx = dv * ex / ev * weight;  // as the reference writes it (:229-231)
+          cy = dv * ey / ev * weight;
+          lsum = fma(ev, ev, lsum);
+        }
+      }
+      ax[id] = cx;
+      ay[id] = cy;
+    }
+  }
+  const double lt = block_sum(lsum, red);
+  if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = lt * Ninv * weight;
+}
+#endif  // ODINN_VEL_KERNELS
 
 }  // namespace odinn

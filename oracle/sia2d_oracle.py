@@ -1054,6 +1054,10 @@ class SimConfig:
     # stops, and the weight the MultiLoss gives the term (the data loss keeps weight 1)
     dhdt: Optional[Tuple[float, float, float]] = None
     dhdt_weight: float = 1.0
+    # LossAvgV (TimeAggregatedLosses.jl:115-258): glacier.velocityData with ONE sample (date1 = t1, date2 = t2) and the
+    # MultiLoss weight of the term; every point of t1:step:t2 except the last must be among the stops
+    avgv: Optional["AvgVData"] = None
+    avgv_weight: float = 1.0
 
 
 def forward(gl: Glacier, law: Law, cfg: SimConfig, theta=None):
@@ -1113,6 +1117,90 @@ def dhdt_loss_terms(snaps, tstops, cfg: SimConfig):
     return w * (dh - ref) ** 2, {i0: -w * c, i1: w * c}
 
 
+@dataclass
+class AvgVData:
+    """The single velocity sample LossAvgV compares with (velocityData.date1/date2/vabs/vx/vy, nx*ny arrays with the
+    inn1 pairing of V_from_H) and the fields of the loss type (component, step)."""
+
+    t1: float
+    t2: float
+    Vabs: np.ndarray
+    Vx: np.ndarray
+    Vy: np.ndarray
+    component: str = "xy"
+    step: float = 1.0 / 12.0
+
+
+def avgv_times(a: AvgVData):
+    """tLoss = collect(t1:step:t2), dt = diff(tLoss), tLoss[begin:end-1]  (TimeAggregatedLosses.jl:201-204)."""
+    n = int(math.floor((a.t2 - a.t1) / a.step + 1e-9))
+    tl = [a.t1 + i * a.step for i in range(n + 1)]
+    dt = [tl[i + 1] - tl[i] for i in range(n)]
+    return tl[:-1], dt
+
+
+def _stop_index(t, x):
+    j = int(np.argmin(np.abs(np.asarray(t, F) - x)))
+    if abs(t[j] - x) > 1e-9:
+        raise ValueError(f"time {x} of a time-aggregated loss is not among the stops")  # indFromT
+    return j
+
+
+def avgv_loss_terms(snaps, tstops, cfg: SimConfig, gl, law: Law, theta=None):
+    """LossAvgV (TimeAggregatedLosses.jl:146-258): V_i = V_from_H(H(tLoss_i)), time average with weights dt_i / T,
+    L2Sum against the single reference sample on mask = V_ref > 0 (component :xy or :abs; normalization = prod(N));
+    cotangents dl/dV dt_i / T pulled back through surface_V at every tLoss_i (VJP_lambda_dsurface_V/dH and /dtheta).
+    Returns (weighted loss, {stop index: dL/dH field}, dL/dtheta)."""
+    P = 1 if law.kind == LAW_CONST_A else law.mlp.n_params
+    a = cfg.avgv
+    if a is None:
+        return 0.0, {}, np.zeros(P)
+    t = [float(x) for x in tstops]
+    tl, dt = avgv_times(a)
+    T = sum(dt)
+    idx = [_stop_index(t, x) for x in tl]
+    N = float(gl.B.size)
+    ph = gl.phys
+    avx = np.zeros_like(gl.B)
+    avy = np.zeros_like(gl.B)
+    for i, j in enumerate(idx):
+        Vx, Vy, _ = V_from_H(snaps[j], gl.B, gl.dx, gl.dy, ph, law, theta)
+        avx = avx + (Vx * dt[i]) / T
+        avy = avy + (Vy * dt[i]) / T
+    av = np.sqrt(avx ** 2 + avy ** 2)
+    mask = a.Vabs > 0.0
+    if a.component == "xy":
+        l = l2sum_loss(avx, a.Vx, mask, N) + l2sum_loss(avy, a.Vy, mask, N)
+        dVx = l2sum_backward(avx, a.Vx, mask, N)
+        dVy = l2sum_backward(avy, a.Vy, mask, N)
+    elif a.component == "abs":
+        l = l2sum_loss(av, a.Vabs, mask, N)
+        dV = l2sum_backward(av, a.Vabs, mask, N)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dVx = np.where(mask, dV * (avx - a.Vx) / (av - a.Vabs), 0.0)
+            dVy = np.where(mask, dV * (avy - a.Vy) / (av - a.Vabs), 0.0)
+    else:
+        raise ValueError("Loss type not implemented.")
+    w = cfg.avgv_weight
+    dl, dth = {}, np.zeros(P)
+    for i, j in enumerate(idx):
+        cx, cy = dVx * (dt[i] / T), dVy * (dt[i] / T)
+        dl[j] = w * vjp_surface_V_H(cx, cy, snaps[j], gl.B, gl.dx, gl.dy, ph, law, theta)
+        dth = dth + w * vjp_surface_V_theta(cx, cy, snaps[j], gl.B, gl.dx, gl.dy, ph, law, theta)
+    return w * l, dl, dth
+
+
+def aggregated_loss_terms(snaps, tstops, cfg: SimConfig, gl, law: Law, theta=None):
+    """All time-aggregated terms of the loss (MultiLoss of LossDhdt / LossAvgV; TimeAggregatedLosses.jl:292-345):
+    (loss, {stop index: dL/dH}, dL/dtheta)."""
+    l1, d1 = dhdt_loss_terms(snaps, tstops, cfg)
+    l2, d2, th2 = avgv_loss_terms(snaps, tstops, cfg, gl, law, theta)
+    d = dict(d1)
+    for j, f in d2.items():
+        d[j] = d[j] + f if j in d else f
+    return l1 + l2, d, th2
+
+
 def _vjp_H_of(vjp):
     """VJP_lambda_dSIA/dH dispatch on the VJP method (VJPs.jl:2-10)."""
     return {"discrete": vjp_H, "continuous": vjp_H_continuous}[vjp]
@@ -1134,7 +1222,7 @@ def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=No
     dLdtheta = np.zeros(P)
     lam = [np.zeros_like(gl.B) for _ in range(k)]
     loss_rev = 0.0
-    l_agg, dl_agg = dhdt_loss_terms(snaps, t, cfg)  # gradient.jl:170-188
+    l_agg, dl_agg, dth_agg = aggregated_loss_terms(snaps, t, cfg, gl, law, theta)  # gradient.jl:170-188
     for j in reversed(range(k)):
         tj = t[j]
         if cfg.mb is not None and tj in cfg.mb_times:  # :201-207
@@ -1157,7 +1245,7 @@ def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=No
             dLdtheta += dt * dth  # :249
     loss_fwd = loss_H(snaps, t, H_ref, tH_ref, cfg.loss_distance)
     assert math.isclose(loss_rev, loss_fwd, rel_tol=1e-8, abs_tol=0.0) or loss_fwd == 0.0  # :259
-    return loss_fwd + l_agg, dLdtheta, lam[0]  # :254-255
+    return loss_fwd + l_agg, dLdtheta + dth_agg, lam[0]  # :254-255, :274
 
 
 # ----------------------------------------------------------------------------
@@ -1244,7 +1332,7 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
             return u + vjp_mb(cfg.mb, u, H_itp(tt) - inc[tt], gl.B)
         return u
 
-    l_agg, dl_agg = dhdt_loss_terms(snaps, t, cfg)  # :369-387
+    l_agg, dl_agg, dth_agg = aggregated_loss_terms(snaps, t, cfg, gl, law, theta)  # :369-387
 
     def effect_agg(tt, u):  # :389-399
         j = t.index(tt)
@@ -1284,7 +1372,7 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
             if wV[j] != 0.0:
                 Va, Vxr, Vyr = V_ref[tV.index(t[j])]
                 loss += loss_V(vspec, snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, Va, Vxr, Vyr, N, theta) * wV[j]
-    return loss + l_agg, dLdtheta, lam_s[-1], st_rev
+    return loss + l_agg, dLdtheta + dth_agg, lam_s[-1], st_rev  # :538
 
 
 # ----------------------------------------------------------------------------
