@@ -888,9 +888,12 @@ class _Simulation:
             regs_ = _split_loss(p.UDE.empirical_loss_function)[2]
             if g.dhdtData is not None and any(isinstance(r, LossDhdt) for r, _ in regs_):
                 ts |= set(float(t) for t in g.dhdtData.t)  # discretePostIntegralLossSteps (TimeAggregatedLosses.jl:352-354)
-            for r, _ in regs_:
-                if isinstance(r, LossAvgV):  # :355-363
-                    ts |= set(_avgv_times(g, r))
+        for g in self.glaciers:
+            for r, _ in _split_loss(p.UDE.empirical_loss_function)[2]:
+                if isinstance(r, LossAvgV):  # :355-363; a grid point that is an existing stop up to rounding IS that stop
+                    for x in _avgv_times(g, r):
+                        if not any(abs(x - t) <= 1e-9 for t in ts):
+                            ts.add(x)
         return sorted(t for t in ts if p.simulation.tspan[0] <= t <= p.simulation.tspan[1])
 
     def mb_times(self):

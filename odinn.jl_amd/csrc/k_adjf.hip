@@ -11,4 +11,13 @@ void launch_adj_fused_strip(int nblk, int afield, int skip, hipStream_t st, Pool
     else hipLaunchKernelGGL((k_adj_fused_strip<false, false>), dim3(nblk), dim3(TNT), 0, st, P, A);
   }
 }
+void launch_vjp_H_strip(int mode, int afield, int nblk, hipStream_t st, Pools P, const int4* tilesD, AdjArgs A) {
+  if (afield) {
+    if (mode) hipLaunchKernelGGL((k_vjp_H_strip<true, 1>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, A);
+    else hipLaunchKernelGGL((k_vjp_H_strip<true, 0>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, A);
+  } else {
+    if (mode) hipLaunchKernelGGL((k_vjp_H_strip<false, 1>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, A);
+    else hipLaunchKernelGGL((k_vjp_H_strip<false, 0>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, A);
+  }
+}
 }  // namespace odinn

@@ -497,7 +497,19 @@ void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawD
                   int vj = -1) {
   static void (*const tab[6])(int, int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
       launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5};
-  tab[b->lm()](mode, vj < 0 ? b->vjp_method : vj, nblk, b->stream, P, L, A, base);
+  // integer-power law, DiscreteVJP, all glaciers at once: the strip-layout kernel on the 62 x 62 tile table
+  // (sia2d_adj_fused.hpp: k_vjp_H_strip; ODINN_VJPH_STRIP=0 keeps the 64 x 16 LDS-tile kernel) ...
+  // ... where its 62 x 62 tiles are reasonably full: batches of small glaciers (alpine: 96 x 80 ... 192 x 160 fill them to
+  // 50-67 %) stay on the 64 x 16 tiles (measured: 512 alpine glaciers 53.9 k vs 48.9 k gradients/s); ODINN_VJPH_STRIP=1 forces it
+  const char* se = std::getenv("ODINN_VJPH_STRIP");
+  const bool strip_on = se ? se[0] != '0' : (double)b->ntot >= 0.75 * (double)b->ntilesD * (DHDT_OX * DHDT_OY);
+  const int vje = vj < 0 ? b->vjp_method : vj;
+  if (strip_on && b->lm() == 0 && vje == ODINN_VJP_DISCRETE && !A.snaps && base == 0 && nblk == b->ntiles &&
+      (P.tiles == b->d_tiles || b->G == 1)) {
+    launch_vjp_H_strip(mode, b->gd[0].use_Afield ? 1 : 0, b->ntilesD, b->stream, P, b->d_tilesD, A);
+    return;
+  }
+  tab[b->lm()](mode, vje, nblk, b->stream, P, L, A, base);
 }
 void launch_adj_stage(int lm, int vj, int stage, int nblk, hipStream_t st, const Pools& P, const LawDev& L,
                       const AdjStageArgs& A) {

@@ -314,4 +314,228 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
   }
 }
 
+// ================= H-VJP in the strip layout (integer-power A law, DiscreteVJP) ===================================
+// VJP_lambda_dSIA/dH_discrete (adjoint.jl:99-148) -- k_vjp_H's contract for law mode 0 -- with the face form and the
+// register / DPP layout of adj_strip_stage and the geometry of k_dhdt_strip: a wavefront owns DNR contiguous rows of a
+// 64-wide region (62 x 62 outputs, one-cell halo), every load of the thread (H, B, lambda, the A nodes, the loss data) is
+// in flight before the first use, the first / last row of a strip cross wavefronts through LDS once.
+//   MODE 0: out = J_H^T lam;  MODE 1 (one reverse-Euler step of the DiscreteAdjoint, gradient.jl:235-242):
+//   out = lam + dt_g J_H^T lam + w_g (2 / N) mask (H - Href), loss partial of the tile into its glacier's partial slot.
+// Tiles come from the RHS strip table (tilesD); partials go to the glacier's slots of the regular tile table
+// (tile0 + local index; the slots past ntilesD are zeroed by the glacier's first tile) so that every reduction over
+// P.part keeps working unchanged.
+template <bool AF, int MODE>
+__global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_H_strip(Pools P, const int4* __restrict__ tilesD, AdjArgs A) {
+  __shared__ double2 sE[TNW][2][FRX];
+  __shared__ double sLm[TNW][2][FRX];
+  __shared__ double red[TNW];
+  const int4 t4 = tilesD[blockIdx.x];
+  const GDev g = P.gd[t4.x];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi0 = t4.y * DOX - 1, gj0 = t4.z * DOY - 1;
+  const int gi = gi0 + lane, r0 = DNR * w;
+  const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
+  const bool ocol = lane >= 1 && lane <= DOX && inx;
+  const int id0 = gi + g.nx * (gj0 + r0);
+  const double* __restrict__ Hg = A.H + g.off;
+  const double* __restrict__ Bg = P.B + g.off;
+  const double* __restrict__ Lg = A.lam + g.off;
+  double* __restrict__ dst = A.out + g.off;
+  const long long slot = 4 * (long long)(g.tile0 + (t4.w - g.tile0D)) + 1;
+  // H and lambda of the thread's rows are all in flight before the first use; the bed (and A, and the loss data) of a row
+  // is fetched one row ahead of its use inside the sweep -- with all of them resident the kernel does not fit 128 VGPRs
+  double hh[DNR], ll[DNR];
+#pragma unroll
+  for (int m = 0; m < DNR; ++m) {
+    const int gj = gj0 + r0 + m;
+    const bool ok = inx && gj >= 0 && gj < g.ny;
+    hh[m] = ok ? ldg32(Hg, (unsigned)(id0 + g.nx * m)) : 0.0;
+    ll[m] = ok ? ldg32(Lg, (unsigned)(id0 + g.nx * m)) : 0.0;
+  }
+  int idf = id0;
+  auto bed = [&](int m) {
+    const int gj = gj0 + r0 + m;
+    const bool ok = inx && gj >= 0 && gj < g.ny;
+    return ok ? ldg32(Bg, (unsigned)(idf + g.nx * m)) : 0.0;
+  };
+  const double b_first = bed(0), b_last = bed(DNR - 1);
+  // A of the node row gj0 + r0 - 1 + k of the thread's column (0 outside the dual grid: such nodes only feed masked cells);
+  // fetched one row ahead of its use inside the sweep, like the loss data, to keep the kernel inside 128 VGPRs
+  const double* __restrict__ Afg = AF ? P.Afield + g.offd : nullptr;
+  const bool nodex = gi >= 0 && gi <= g.nx - 2;
+  // idf: the thread's first cell index again, but opaque after every row fence of the sweep -- keeps the loads a row issues
+  // (A of the next node row, loss data and lambda of the next row) inside that row instead of all at the top
+  auto a_node = [&](int k) {
+    const int gj = gj0 + r0 - 1 + k;
+    const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+    return ok ? ldg32(Afg, (unsigned)((idf - id0) + gi + (g.nx - 1) * gj)) : 0.0;
+  };
+  // loss data of the thread's output cells (MODE 1 at a data stop): H - Href where the mask is set
+  double dt = 1.0, wl = 0.0;
+  // (without reference data at this stop the two pointers fall back to H: the loads stay unconditional, their values unused)
+  const unsigned char* __restrict__ Mg = reinterpret_cast<const unsigned char*>(Hg);
+  const double* __restrict__ Rg = Hg;
+  if (MODE == 1) {
+    dt = A.dts[t4.x];
+    wl = A.ws ? A.ws[t4.x] : 0.0;
+    if (wl != 0.0) {
+      const long long roff = (long long)A.refslot[t4.x] * A.ntot + g.off;
+      Mg = A.mask + roff; Rg = A.Href + roff;
+    }
+    // the partial slots of the regular table that the strip tiles of this glacier do not use
+    if (t4.w == g.tile0D)
+      for (int k = g.ntilesD + threadIdx.x; k < g.ntiles; k += TNT) P.part[4 * (long long)(g.tile0 + k) + 1] = 0.0;
+  }
+  auto lam_e = [&](int m) {  // lambda masked to the interior cells (the transposed difference of adjoint.jl:100-101)
+    const int gj = gj0 + r0 + m;
+    return (intx && gj >= 1 && gj <= g.ny - 2) ? ll[m] : 0.0;
+  };
+  bool nz = false;
+#pragma unroll
+  for (int m = 0; m < DNR; ++m) nz = nz || (hh[m] > 0.0);
+  sE[w][0][lane] = cell_HS(hh[0], b_first);
+  sE[w][1][lane] = cell_HS(hh[DNR - 1], b_last);
+  sLm[w][0][lane] = lam_e(0);
+  sLm[w][1][lane] = lam_e(DNR - 1);
+  const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
+  double lsum = 0.0;
+  // no ice on the whole region: the result is masked by the cell's own H > 0 (adjoint.jl:148) -> J^T lam = 0 exactly
+  const bool ice = __syncthreads_or(nz);
+  if (ice) {
+    const double Gq = g.Gam * (1.0 / 1024.0);
+    const int wb = w > 0 ? w - 1 : 0, eb = w > 0 ? 1 : 0, wt = w + 1 < TNW ? w + 1 : w, et = w + 1 < TNW ? 0 : 1;
+    const double2 hs_s = sE[wb][eb][lane], hs_top = sE[wt][et][lane];
+    const double le_s = sLm[wb][eb][lane], le_top = sLm[wt][et][lane];
+    double2 hs_c = cell_HS(hh[0], b_first);
+    double le_c = lam_e(0);
+    double2 e_c = dpp_from_east(hs_c);
+    double dx_c = e_c.y - hs_c.y, hp_c = hs_c.x + e_c.x, qe_c = dpp_shift(le_c, false) - le_c;
+    double Pe_c = qe_c * clampn(dx_c, e_c.x, hs_c.x);
+    double D_s, C_s;
+    double b_nx = bed(DNR > 1 ? 1 : 0);  // bed of row m + 1
+    // of row m, if it is an output cell: H - Href where the mask is set, and lambda of the cell AGAIN (an L2 hit; keeping the
+    // first copy alive until the row's result exists costs 16 VGPRs, i.e. a spill to scratch)
+    auto loss_data = [&](int m, double& d, bool& on, double& lo) {
+      d = 0.0; on = false; lo = 0.0;
+      if (MODE == 1) {
+        const int r = r0 + m, gj = gj0 + r;
+        const bool oc = ocol && r >= 1 && r <= DOY && gj < g.ny;
+        if (oc) {
+          const unsigned id = (unsigned)(idf + g.nx * m);
+          const unsigned char mk = Mg[id];
+          const double hr = ldg32(Rg, id);
+          lo = ldg32(Lg, id);
+          on = wl != 0.0 && mk != 0;
+          d = on ? hh[m] - hr : 0.0;
+        }
+      }
+    };
+    auto node_face = [&](double an, double2 hs_lo, double2 e_lo, double le_lo, double dx_lo, double hp_lo, double Pe_lo,
+                         double2 hs_hi, double2 e_hi, double le_hi, double dx_hi, double hp_hi, double Pe_hi, double& D,
+                         double& k00, double& k10, double& k01, double& k11, double& Mn, double& PLn) {
+      const double dyw = hs_hi.y - hs_lo.y, dye = e_hi.y - e_lo.y;
+      const double qn = le_hi - le_lo;
+      const double Pn = qn * clampn(dyw, hs_hi.x, hs_lo.x);
+      const double Pn_e = dpp_shift(Pn, false);
+      const double gx = (dx_lo + dx_hi) * g.hinv_dx, gy = (dyw + dye) * g.hinv_dy;
+      const double Hs = hp_lo + hp_hi;  // 4 Hbar
+      const double gS2 = gx * gx + gy * gy;
+      const double Kq = (AF ? an : g.A) * Gq;
+      const double H2 = Hs * Hs, H4 = H2 * H2, H5 = H4 * Hs;
+      D = (Kq * H5) * gS2;
+      const double Da = -fma(g.hinv_dx2, Pe_lo + Pe_hi, g.hinv_dy2 * (Pn + Pn_e));
+      const double ad = (((Kq * 5.0) * H4) * gS2) * Da;  // alpha Da / 4
+      const double bd = ((Kq * 2.0) * H5) * Da;           // beta Da
+      const double bx = g.hinv_dx * (bd * gx), by = g.hinv_dy * (bd * gy);
+      const double am = ad - bx, ap = ad + bx;
+      k00 = am - by; k10 = ap - by; k01 = am + by; k11 = ap + by;
+      const double Dw = dpp_from_west(D);
+      const double tn = ((Dw + D) * g.hinv_dy2) * qn;
+      Mn = (dyw < hs_hi.x && dyw != -hs_lo.x) ? tn : 0.0;
+      PLn = (dyw > -hs_lo.x && dyw != hs_hi.x) ? -tn : 0.0;
+    };
+    {  // the node row and the north faces just below the strip
+      const double2 e_s = dpp_from_east(hs_s);
+      const double lee_s = dpp_shift(le_s, false);
+      const double dx_s = e_s.y - hs_s.y, hp_s = hs_s.x + e_s.x;
+      const double Pe_s = (lee_s - le_s) * clampn(dx_s, e_s.x, hs_s.x);
+      double k00, k10, k01, k11, Mn, PLn;
+      node_face(AF ? a_node(0) : 0.0, hs_s, e_s, le_s, dx_s, hp_s, Pe_s, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, D_s, k00, k10, k01, k11, Mn, PLn);
+      C_s = (k01 + dpp_from_west(k11)) + PLn;
+    }
+    double a_nx = AF ? a_node(1) : 0.0, hd_nx, lo_nx;
+    bool hm_nx;
+    loss_data(0, hd_nx, hm_nx, lo_nx);
+#pragma unroll
+    for (int m = 0; m < DNR; ++m) {
+      const int r = r0 + m, gj = gj0 + r;
+      const double a_c = a_nx, hd_c = hd_nx, lo_c = lo_nx;
+      const bool hm_c = hm_nx;
+      if (m + 1 < DNR) {
+        if (AF) a_nx = a_node(m + 2 <= DNR ? m + 2 : m);
+        loss_data(m + 1 < DNR ? m + 1 : m, hd_nx, hm_nx, lo_nx);
+      }
+      const double2 hs_n = m + 1 < DNR ? cell_HS(hh[m + 1 < DNR ? m + 1 : m], b_nx) : hs_top;
+      if (m + 2 < DNR) b_nx = m + 2 == DNR - 1 ? b_last : bed(m + 2 < DNR ? m + 2 : m);
+      const double le_n = m + 1 < DNR ? lam_e(m + 1 < DNR ? m + 1 : m) : le_top;
+      const double2 e_n = dpp_from_east(hs_n);
+      const double lee_n = dpp_shift(le_n, false);
+      const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, qe_n = lee_n - le_n;
+      const double Pe_n = qe_n * clampn(dx_n, e_n.x, hs_n.x);
+      double D_c, k00, k10, k01, k11, Mn, PLn;
+      node_face(a_c, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, hs_n, e_n, le_n, dx_n, hp_n, Pe_n, D_c, k00, k10, k01, k11, Mn, PLn);
+      const double te = ((D_s + D_c) * g.hinv_dx2) * qe_c;
+      const double Me = (dx_c < e_c.x && dx_c != -hs_c.x) ? te : 0.0;
+      const double PLe = (dx_c > -hs_c.x && dx_c != e_c.x) ? -te : 0.0;
+      const double W = dpp_from_west(k10 + PLe);
+      double v = ((k00 + W) + C_s) + (Me + Mn);
+      v = hs_c.x > 0.0 ? v : 0.0;  // dlam .* (H .> 0)  (adjoint.jl:148)
+      if (ocol && r >= 1 && r <= DOY && gj < g.ny) {
+        double o = v;
+        if (MODE == 1) {
+          o = fma(dt, v, lo_c);
+          if (hm_c) {
+            o = fma(wl * 2.0 * Ninv, hd_c, o);
+            lsum = fma(hd_c, hd_c, lsum);
+          }
+        }
+        stg32(dst, (unsigned)(id0 + g.nx * m), o);
+      }
+      hs_c = hs_n; le_c = le_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; qe_c = qe_n; Pe_c = Pe_n;
+      D_s = D_c; C_s = (k01 + dpp_from_west(k11)) + PLn;
+      asm volatile("" : "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y), "+v"(qe_c), "+v"(Pe_c), "+v"(D_s),
+                   "+v"(C_s), "+v"(idf));
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < DNR; ++m) {
+      const int r = r0 + m, gj = gj0 + r;
+      if (ocol && r >= 1 && r <= DOY && gj < g.ny) {
+        double o = 0.0;
+        if (MODE == 1) {
+          o = fma(dt, 0.0, ll[m]);
+          if (wl != 0.0 && Mg[(unsigned)(id0 + g.nx * m)]) {
+            const double hd = hh[m] - ldg32(Rg, (unsigned)(id0 + g.nx * m));
+            o = fma(wl * 2.0 * Ninv, hd, o);
+            lsum = fma(hd, hd, lsum);
+          }
+        }
+        stg32(dst, (unsigned)(id0 + g.nx * m), o);
+      }
+    }
+  }
+  if (MODE == 1) {
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[w] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < TNW; ++k) sum += red[k];
+      P.part[slot] = sum * wl * Ninv;
+    }
+  }
+}
+
 }  // namespace odinn

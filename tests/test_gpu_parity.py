@@ -878,3 +878,52 @@ def test_snapshot_on_load_matches_the_post_step_launch(gpu, monkeypatch):
                 assert np.array_equal(out["1"][1][k][j], out["0"][1][k][j]), (tiles, k, j)
             assert np.array_equal(out["1"][2][k], out["0"][2][k])
             assert np.abs(out["1"][1][k][-1] - out["1"][1][k][0]).max() > 0
+
+
+def test_strip_H_vjp_matches_the_tile_kernel(gpu, monkeypatch):
+    """k_vjp_H_strip (strip / face layout, 62 x 62 tiles, MODE 0 and the reverse-Euler step MODE 1 with the loss term)
+    against k_vjp_H (64 x 16 LDS tiles, node form) on a ragged batch -- an ice-free glacier, a gridded A field and
+    glaciers smaller than one tile included; both against the oracle through the whole discrete adjoint."""
+    ph = O.Phys()
+    shapes = [(130, 97), (54, 46), (201, 103), (70, 57), (33, 40)]
+    ts = [2010.0 + j / 24.0 for j in range(4)]
+    rng = np.random.default_rng(3)
+    fields, refs, Afs = [], [], []
+    for k, (nx, ny) in enumerate(shapes):
+        H0, B = (O.synthetic_valley(nx, ny, 60.0) if k % 2 else O.synthetic_icecap(nx, ny, 60.0))
+        if k == 3:
+            H0 = np.zeros_like(H0)
+        fields.append((H0, B))
+        Afs.append(np.asfortranarray(3e-17 * (1.0 + 0.5 * rng.uniform(size=(nx - 1, ny - 1)))))
+    for afield in (False, True):
+        res = {}
+        for strip in ("1", "0"):
+            monkeypatch.setenv("ODINN_VJPH_STRIP", strip)
+            b = gpu.GlacierBatch(shapes, [60.0] * len(shapes), A=[4e-17] * len(shapes))
+            for k, (H0, B) in enumerate(fields):
+                b.set_fields(k, H0, B)
+                if afield:
+                    b.set_A_field(k, Afs[k])
+            b.solve(ts, reltol=1e-8)
+            if not refs:
+                refs = [[b.snapshot(k, j) * (1.0 + 0.03 * j) for j in range(len(ts))] for k in range(len(shapes))]
+            for k in range(len(shapes)):
+                b.set_reference(k, ts, refs[k], 3)
+            L, g = b.loss_grad(ts, reltol=1e-8)
+            res[strip] = (L, g, [b.lambda0(k) for k in range(len(shapes))])
+            b.close()
+        assert abs(res["1"][0] - res["0"][0]) <= 1e-13 * abs(res["0"][0])
+        assert np.allclose(res["1"][1], res["0"][1], rtol=1e-11, atol=0)
+        for k in range(len(shapes)):
+            assert rel_l2(res["1"][2][k], res["0"][2][k]) < 1e-12 or np.all(res["0"][2][k] == 0), (afield, k)
+    # the strip kernel against the oracle directly (one glacier per batch: the per-glacier entry point runs it too)
+    monkeypatch.setenv("ODINN_VJPH_STRIP", "1")
+    H0, B = fields[0]
+    b = gpu.GlacierBatch([shapes[0]], [60.0], A=[4e-17])
+    b.set_fields(0, H0, B)
+    b.set_A_field(0, Afs[0])
+    lam = rng.standard_normal(H0.shape)
+    H = np.maximum(H0 + rng.standard_normal(H0.shape), 0.0)
+    want = O.vjp_H(lam, H, B, 60.0, 60.0, ph, O.Law(kind=O.LAW_CONST_A, A=Afs[0]))
+    assert rel_l2(b.vjp_H(0, lam, H), want) < 1e-11
+    b.close()
