@@ -20,4 +20,13 @@ void launch_vjp_H_strip(int mode, int afield, int nblk, hipStream_t st, Pools P,
     else hipLaunchKernelGGL((k_vjp_H_strip<false, 0>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, A);
   }
 }
+void launch_vjp_theta_strip(int gacc, int itp, int nblk, hipStream_t st, Pools P, const int4* tilesD, ThArgs A) {
+  if (gacc) {
+    if (itp) hipLaunchKernelGGL((k_vjp_theta_strip<true, true>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, A);
+    else hipLaunchKernelGGL((k_vjp_theta_strip<true, false>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, A);
+  } else {
+    if (itp) hipLaunchKernelGGL((k_vjp_theta_strip<false, true>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, A);
+    else hipLaunchKernelGGL((k_vjp_theta_strip<false, false>), dim3(nblk), dim3(TNT), 0, st, P, tilesD, A);
+  }
+}
 }  // namespace odinn

@@ -34,6 +34,7 @@ constexpr int DHDT_OX = 62, DHDT_OY = 62;  // output tile of k_dhdt_strip (sia2d
 // k_adjf.hip, law mode 0 only
 void launch_adj_fused_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, AdjFusedArgs A);
 void launch_vjp_H_strip(int mode, int afield, int nblk, hipStream_t st, Pools P, const int4* tilesD, AdjArgs A);
+void launch_vjp_theta_strip(int gacc, int itp, int nblk, hipStream_t st, Pools P, const int4* tilesD, ThArgs A);
 
 // k_interp.hip: `:Linear` spatial interpolation of d law / d theta for the Y law (target_D_hybrid.jl:136-160)
 constexpr int INTERP_KMAX = 512;

@@ -522,6 +522,14 @@ void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L,
   static void (*const tab[6])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
       launch_vjp_theta_lm0, launch_vjp_theta_lm1, launch_vjp_theta_lm2, launch_vjp_theta_lm3, launch_vjp_theta_lm4,
       launch_vjp_theta_lm5};
+  // integer-power A-type laws, all glaciers at once: the strip-layout reduction (k_vjp_theta_strip), under the same
+  // tile-fullness rule as k_vjp_H_strip; ODINN_VJPTH_STRIP=0/1 forces the choice
+  const char* se = std::getenv("ODINN_VJPTH_STRIP");
+  const bool strip_on = se ? se[0] != '0' : (double)b->ntot >= 0.75 * (double)b->ntilesD * (DHDT_OX * DHDT_OY);
+  if (strip_on && b->lm() == 0 && !A.emitH && base == 0 && nblk == b->ntiles && (P.tiles == b->d_tiles || b->G == 1)) {
+    launch_vjp_theta_strip(A.Gacc ? 1 : 0, A.snaps ? 1 : 0, b->ntilesD, b->stream, P, b->d_tilesD, A);
+    return;
+  }
   tab[b->lm()](nblk, b->stream, P, L, A, base);
 }
 

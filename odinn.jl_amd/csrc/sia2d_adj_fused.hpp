@@ -538,4 +538,114 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_H_strip(Pools P, const 
   }
 }
 
+// ================= theta-VJP in the strip layout (integer-power A-type laws) ========================================
+// VJP_lambda_dSIA/dtheta_discrete (adjoint.jl:178-255) for the laws whose dD/dtheta factors as (dA/dtheta) x spat(H):
+// the reduction  sum_nodes scale_g spat D_adjoint  -- k_vjp_theta<LM_FAST>'s contract (tile partial in slot 2, optional
+// dual-grid accumulator Gacc, per-glacier scale, in-place accumulation, lambda from the per-glacier ping-pong buffer, H
+// formed from two bracketing snapshots at the stop of the reverse solve) -- with the layout of k_vjp_H_strip.  A thread
+// owns the node at the north-east corner of each of its output cells; D_adjoint of that node comes from the east faces of
+// the row and the row above and the north faces of the cell and its east neighbour (the face form of adj_strip_stage).
+template <bool GACC, bool ITP>
+__global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_theta_strip(Pools P, const int4* __restrict__ tilesD, ThArgs A) {
+  __shared__ double2 sE[TNW][FRX];
+  __shared__ double sLm[TNW][FRX];
+  __shared__ double red[TNW];
+  const int4 t4 = tilesD[blockIdx.x];
+  const GDev g = P.gd[t4.x];
+  const long long slot = 4 * (long long)(g.tile0 + (t4.w - g.tile0D)) + 2;
+  const double scale = A.scales ? A.scales[t4.x] : 1.0;
+  // the partial slots of the regular table that this glacier's strip tiles do not use (in-place accumulation: the caller
+  // zeroed the whole table once)
+  if (!A.accum && t4.w == g.tile0D)
+    for (int k = g.ntilesD + threadIdx.x; k < g.ntiles; k += TNT) P.part[4 * (long long)(g.tile0 + k) + 2] = 0.0;
+  if (scale == 0.0) {  // this glacier contributes nothing now (e.g. not at a quadrature node)
+    if (threadIdx.x == 0 && !A.accum) P.part[slot] = 0.0;
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi0 = t4.y * DOX - 1, gj0 = t4.z * DOY - 1;
+  const int gi = gi0 + lane, r0 = DNR * w;
+  const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
+  const bool ocol = lane >= 1 && lane <= DOX && inx;
+  const int id0 = gi + g.nx * (gj0 + r0);
+  const double* __restrict__ Bg = P.B + g.off;
+  const double* __restrict__ Lg = ((A.lam_alt && P.gs[t4.x].cur) ? A.lam_alt : A.lam) + g.off;
+  const double* __restrict__ Hg = A.H + g.off;
+  [[maybe_unused]] const double* __restrict__ Hb = nullptr;
+  [[maybe_unused]] double sw = 0.0;
+  if (ITP) {
+    const AdjState a = A.adj[t4.x];
+    Hg = A.snaps + (long long)a.seg_stop * A.ntot + g.off;
+    Hb = Hg + A.ntot;
+    sw = a.s_stop;
+  }
+  double2 hs[DNR];
+  double le[DNR];
+  bool nz = false;
+#pragma unroll
+  for (int m = 0; m < DNR; ++m) {
+    const int gj = gj0 + r0 + m;
+    const bool ok = inx && gj >= 0 && gj < g.ny;
+    double h = ok ? ldg32(Hg, (unsigned)(id0 + g.nx * m)) : 0.0;
+    if (ITP) {
+      const double hb = ok ? ldg32(Hb, (unsigned)(id0 + g.nx * m)) : 0.0;
+      h = fma(sw, hb - h, h);  // load_tile_HS2's formula
+    }
+    const double bb = ok ? ldg32(Bg, (unsigned)(id0 + g.nx * m)) : 0.0;
+    const double l = ok ? ldg32(Lg, (unsigned)(id0 + g.nx * m)) : 0.0;
+    hs[m] = cell_HS(h, bb);
+    le[m] = (intx && gj >= 1 && gj <= g.ny - 2) ? l : 0.0;  // lambda masked to the interior
+    nz = nz || h > 0.0;
+  }
+  sE[w][lane] = hs[0];
+  sLm[w][lane] = le[0];
+  // no ice anywhere on the region: every owned node has Hbar = 0, its weight vanishes identically (k_vjp_theta's shortcut)
+  if (!__syncthreads_or(nz)) {
+    if (threadIdx.x == 0 && !A.accum) P.part[slot] = 0.0;
+    return;
+  }
+  const double Gq = g.Gam * (1.0 / 1024.0);
+  const double2 hs_top = sE[w + 1 < TNW ? w + 1 : w][lane];  // (the last wavefront's rows DNR-1 are never output rows)
+  const double le_top = sLm[w + 1 < TNW ? w + 1 : w][lane];
+  double2 hs_c = hs[0];
+  double le_c = le[0];
+  double2 e_c = dpp_from_east(hs_c);
+  double dx_c = e_c.y - hs_c.y, hp_c = hs_c.x + e_c.x;
+  double Pe_c = (dpp_shift(le_c, false) - le_c) * clampn(dx_c, e_c.x, hs_c.x);
+  double acc = 0.0;
+#pragma unroll
+  for (int m = 0; m < DNR; ++m) {
+    const int r = r0 + m, gj = gj0 + r;
+    const double2 hs_n = m + 1 < DNR ? hs[m + 1 < DNR ? m + 1 : m] : hs_top;
+    const double le_n = m + 1 < DNR ? le[m + 1 < DNR ? m + 1 : m] : le_top;
+    const double2 e_n = dpp_from_east(hs_n);
+    const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x;
+    const double Pe_n = (dpp_shift(le_n, false) - le_n) * clampn(dx_n, e_n.x, hs_n.x);
+    const double dyw = hs_n.y - hs_c.y, dye = e_n.y - e_c.y;
+    const double Pn = (le_n - le_c) * clampn(dyw, hs_n.x, hs_c.x);
+    const double Pn_e = dpp_shift(Pn, false);
+    const double gx = (dx_c + dx_n) * g.hinv_dx, gy = (dyw + dye) * g.hinv_dy;
+    const double Hs = hp_c + hp_n;  // 4 Hbar
+    const double gS2 = gx * gx + gy * gy;
+    const double H2 = Hs * Hs, H4 = H2 * H2;
+    const double Da = -fma(g.hinv_dx2, Pe_c + Pe_n, g.hinv_dy2 * (Pn + Pn_e));
+    const double wgt = scale * (((Gq * (H4 * Hs)) * gS2) * Da);
+    if (ocol && r >= 1 && r <= DOY && gi <= g.nx - 2 && gj <= g.ny - 2) {  // gj >= 0 and gi >= 0 hold for output cells
+      acc += wgt;
+      if (GACC) A.Gacc[g.offd + gi + (long long)(g.nx - 1) * gj] += wgt;
+    }
+    hs_c = hs_n; le_c = le_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; Pe_c = Pe_n;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[w] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < TNW; ++k) sum += red[k];
+    P.part[slot] = A.accum ? P.part[slot] + sum : sum;
+  }
+}
+
 }  // namespace odinn

@@ -899,6 +899,7 @@ def test_strip_H_vjp_matches_the_tile_kernel(gpu, monkeypatch):
         res = {}
         for strip in ("1", "0"):
             monkeypatch.setenv("ODINN_VJPH_STRIP", strip)
+            monkeypatch.setenv("ODINN_VJPTH_STRIP", strip)  # k_vjp_theta_strip against k_vjp_theta in the same go
             b = gpu.GlacierBatch(shapes, [60.0] * len(shapes), A=[4e-17] * len(shapes))
             for k, (H0, B) in enumerate(fields):
                 b.set_fields(k, H0, B)
@@ -910,12 +911,21 @@ def test_strip_H_vjp_matches_the_tile_kernel(gpu, monkeypatch):
             for k in range(len(shapes)):
                 b.set_reference(k, ts, refs[k], 3)
             L, g = b.loss_grad(ts, reltol=1e-8)
-            res[strip] = (L, g, [b.lambda0(k) for k in range(len(shapes))])
+            lam0 = [b.lambda0(k) for k in range(len(shapes))]
+            Gf = [b.grad_field(k) for k in range(len(shapes))] if afield else []
+            # the reverse ODE: theta-VJP with H formed from two snapshots at the quadrature nodes, in-place accumulation,
+            # lambda from the per-glacier ping-pong buffer
+            Lc, gc = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=6)
+            res[strip] = (L, g, lam0, Gf, Lc, gc)
             b.close()
         assert abs(res["1"][0] - res["0"][0]) <= 1e-13 * abs(res["0"][0])
         assert np.allclose(res["1"][1], res["0"][1], rtol=1e-11, atol=0)
         for k in range(len(shapes)):
             assert rel_l2(res["1"][2][k], res["0"][2][k]) < 1e-12 or np.all(res["0"][2][k] == 0), (afield, k)
+            if afield and k != 3:
+                assert rel_l2(res["1"][3][k], res["0"][3][k]) < 1e-11, k
+        assert abs(res["1"][4] - res["0"][4]) <= 1e-12 * abs(res["0"][4])
+        assert np.allclose(res["1"][5], res["0"][5], rtol=1e-9, atol=0)
     # the strip kernel against the oracle directly (one glacier per batch: the per-glacier entry point runs it too)
     monkeypatch.setenv("ODINN_VJPH_STRIP", "1")
     H0, B = fields[0]
@@ -926,4 +936,10 @@ def test_strip_H_vjp_matches_the_tile_kernel(gpu, monkeypatch):
     H = np.maximum(H0 + rng.standard_normal(H0.shape), 0.0)
     want = O.vjp_H(lam, H, B, 60.0, 60.0, ph, O.Law(kind=O.LAW_CONST_A, A=Afs[0]))
     assert rel_l2(b.vjp_H(0, lam, H), want) < 1e-11
+    b.close()
+    monkeypatch.setenv("ODINN_VJPTH_STRIP", "1")
+    b = gpu.GlacierBatch([shapes[0]], [60.0], A=[4e-17])
+    b.set_fields(0, H0, B)
+    wth = O.vjp_theta(lam, H, B, 60.0, 60.0, ph, O.Law(kind=O.LAW_CONST_A, A=4e-17))
+    assert abs(b.vjp_theta(0, lam, H)[0] - wth[0]) <= 1e-11 * abs(wth[0])
     b.close()
