@@ -42,7 +42,8 @@ for law, key in (("nnA", "fused_step_nn_gridded"), ("const", "fused_step_constA"
         e["hbm_bytes_per_launch"] = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0
         e["hbm_bytes_per_cell"] = e["hbm_bytes_per_launch"] / cells8
     out[key] = e
-for tag, key, pat, bpc in (("dhdt32_nnA", "dhdt_nn_gridded_32", "k_dhdt", 32.0), ("stage32", "rk_stage2_32", "k_rk_stage", 56.0)):
+for tag, key, pat, bpc in (("dhdt32_nnA", "dhdt_nn_gridded_32", "k_dhdt", 32.0), ("stage32", "rk_stage2_32", "k_rk_stage", 56.0),
+                           ("vjpH32", "vjp_H_32", "k_vjp_H", 32.0), ("vjpth32", "vjp_theta_32", "k_vjp_theta", 24.0)):
     fe, names = med(tag + "_fetch", pat)
     wr, _ = med(tag + "_write", pat)
     if fe and wr:

@@ -17,4 +17,8 @@ run dhdt32_nnA_fetch FETCH_SIZE dhdt 32 nnA
 run dhdt32_nnA_write WRITE_SIZE dhdt 32 nnA
 run stage32_fetch FETCH_SIZE rk_stage2 32 const
 run stage32_write WRITE_SIZE rk_stage2 32 const
+run vjpH32_fetch FETCH_SIZE vjp_H 32 const
+run vjpH32_write WRITE_SIZE vjp_H 32 const
+run vjpth32_fetch FETCH_SIZE vjp_theta 32 const
+run vjpth32_write WRITE_SIZE vjp_theta 32 const
 cd $R && python tools/pmc_roofline.py $O > $R/gpurun_out/pmc_roofline.json && cat $R/gpurun_out/pmc_roofline.json
