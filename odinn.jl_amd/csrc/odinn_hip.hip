@@ -2167,10 +2167,11 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     }
     HIPCHK(hipMemsetAsync(b->d_partsteps, 0, need * sizeof(double), b->stream));
   }
-  // integer-power law + DiscreteVJP + thickness loss: the five stages of a reverse step run as ONE kernel
+  // integer-power law + DiscreteVJP (any loss: the velocity terms are separate launches that follow each glacier's
+  // current lambda buffer): the five stages of a reverse step run as ONE kernel
   // (sia2d_adj_fused.hpp) -- measured faster at every batch size, 4 alpine glaciers included; ODINN_ADJ_FUSED=0
   // selects the five k_adj_stage launches
-  bool fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE && !useV;
+  bool fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE;
   if (const char* e = std::getenv("ODINN_ADJ_FUSED")) fused_rev = fused_rev && e[0] != '0';
   const int rev_skip = []() { const char* e = std::getenv("ODINN_ADJ_SKIP"); return (e && e[0] == '0') ? 0 : 1; }();
   AdjFusedArgs FA{};
@@ -2211,7 +2212,8 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       launch_controller(G, b->stream, Pl, C);
       launch_adj_poststep(b->ntiles, b->stream, Pl, AP, b->d_lam[0], b->d_lam[1]);
       if (useV) {
-        VS.out = a1;
+        if (fused_rev) { VS.out = b->d_lam[0]; VS.out_alt = b->d_lam[1]; }  // per-glacier ping-pong buffers
+        else VS.out = a1;
         launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, VS, 0);                       // snapshot stops
         launch_vref_itp(b->ntiles, b->stream, Pl, VI);                                  // quadrature nodes
         launch_vref_scale(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_vscq, b->d_wvq);

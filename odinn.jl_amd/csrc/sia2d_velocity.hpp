@@ -80,7 +80,9 @@ struct VArgs {
   const double* H;        // state (pooled)
   const double* dVx;      // MODE 0: cotangents (pooled, nx*ny, inn1 pairing)
   const double* dVy;
-  double* out;            // MODE 0: written; MODE 1: accumulated (+=)
+  double* out;            // MODE 0: written; MODE 1 / 2: accumulated (+=)
+  double* out_alt;        // non-null (MODE >= 1): the glaciers whose GState says cur == 1 accumulate here instead (the fused
+                          //   reverse step keeps lambda of every glacier in its own ping-pong buffer)
   // MODE 1: LossV data
   const double* Vabs;     // [slot][ntot]
   const double* Vxr;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
     }
   }
   const int i0 = t4.y * TX, j0 = t4.z * TY;
+  double* __restrict__ outp = (MODE >= 1 && A.out_alt && P.gs[t4.x].cur) ? A.out_alt : A.out;
   double own[RPT];
   load_tile_HS2(A.H, P.B, g, i0, j0, sHS, own);
   __syncthreads();
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
       v = fma(g.inv_dy * 0.5, (qsw.y + qse.y) - (qnw.y + qne.y), v);
       const long long id = g.off + gi + (long long)g.nx * gj;
       if (MODE == 0) A.out[id] = -v;
-      else A.out[id] = fma(-wv, v, A.out[id]);
+      else outp[id] = fma(-wv, v, outp[id]);
     }
   }
   const double gt = block_sum(gsum, red);

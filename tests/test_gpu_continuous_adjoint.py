@@ -266,7 +266,7 @@ def test_continuous_adjoint_other_law_modes(gpu, kind, arch):
     b.close()
 
 
-@pytest.mark.parametrize("case", ["scalar_nn_mb", "gridded_nn", "ragged_batch"])
+@pytest.mark.parametrize("case", ["scalar_nn_mb", "gridded_nn", "ragged_batch", "velocity_hv_batch"])
 def test_fused_reverse_step_matches_the_staged_reverse_solve(gpu, monkeypatch, case):
     """k_adj_fused_strip (the five stages of a reverse step in one kernel, face form of the H-VJP; what large
     integer-power-law batches run, forced here with ODINN_ADJ_FUSED=1) against the five k_adj_stage launches
@@ -287,6 +287,23 @@ def test_fused_reverse_step_matches_the_staged_reverse_solve(gpu, monkeypatch, c
                 b.set_reference(k, ts, [H0 * (1.0 - 0.03 * j) + 0.5 * rng.random((nx, ny)) for j in range(len(ts))], 3)
             Lg, gg = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=16)
             lam = [b.lambda0(k) for k in range(4)]
+        elif case == "velocity_hv_batch":
+            # LossHV on two glaciers that run out of step (per-glacier ping-pong buffers of the fused step): the velocity
+            # term joins lambda at the snapshots through k_surfV_vjp<1>, which follows each glacier's current buffer
+            from test_gpu_velocity import _velocity_case
+            ph = O.Phys()
+            shapes = [(64, 48), (80, 56)]
+            b = gpu.GlacierBatch(shapes, [50.0] * 2, A=[3e-17, 6e-17])
+            for k, (nx, ny) in enumerate(shapes):
+                H0, B, ts, mlp, th_true, th0, gl, cfg, ref, tV, Vref = _velocity_case(nx, ny, ph)
+                law_t = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th_true, T=-3.0)
+                Vs = [O.V_from_H(ref[j], B, 50.0, 50.0, ph, law_t) for j in range(len(ts))]
+                b.set_fields(k, H0, B)
+                b.set_reference(k, ts, ref, 3)
+                b.set_velocity_reference(k, ts, [v[2] for v in Vs], [v[0] for v in Vs], [v[1] for v in Vs])
+            b.set_loss(gpu._lib.LOSS_HV, "xy", True, 2.5)
+            Lg, gg = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=12)
+            lam = [b.lambda0(k) for k in range(2)]
         else:
             nx, ny = 96, 80
             use_mb = case == "scalar_nn_mb"
