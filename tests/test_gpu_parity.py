@@ -925,7 +925,9 @@ def test_strip_H_vjp_matches_the_tile_kernel(gpu, monkeypatch):
             if afield and k != 3:
                 assert rel_l2(res["1"][3][k], res["0"][3][k]) < 1e-11, k
         assert abs(res["1"][4] - res["0"][4]) <= 1e-12 * abs(res["0"][4])
-        assert np.allclose(res["1"][5], res["0"][5], rtol=1e-9, atol=0)
+        # two adaptive reverse solves: the H-VJP behind the initial step size rounds differently in the two layouts, which
+        # can shift the step sequence -- agreement to the integration error (see the fused-vs-staged tests)
+        assert np.linalg.norm(res["1"][5] - res["0"][5]) <= 5e-7 * np.linalg.norm(res["0"][5])
     # the strip kernel against the oracle directly (one glacier per batch: the per-glacier entry point runs it too)
     monkeypatch.setenv("ODINN_VJPH_STRIP", "1")
     H0, B = fields[0]
