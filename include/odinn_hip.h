@@ -215,6 +215,14 @@ int odinn_set_dhdt_loss(odinn_batch* b, double weight);
 int odinn_set_avgv_reference(odinn_batch* b, int g, double t1, double t2, const double* Vabs, const double* Vx,
                              const double* Vy);
 int odinn_set_avgv_loss(odinn_batch* b, double weight, double step, int component_abs);
+/* VelocityRegularization(reg = TikhonovRegularization(), components = :abs, distance) (src/losses/Regularization.jl:64-79,
+ * 192-245; the regulariser of the reference's documented multi-objective example): at every velocity-data time t_m, m >= 2,
+ * of a glacier (the times given to odinn_set_velocity_reference; the maps themselves are not used) the term
+ * weight * (t_m - t_{m-1}) * sum_mask (lap V)^2 with V = |V_from_H(H(t_m))| and mask = is_in_glacier(H(t_m), distance) & V > 0
+ * joins the loss; its dL/dH joins lambda at that stop, its dL/dtheta is summed over the stops (odinn_loss_grad) or integrated
+ * over the quadrature nodes on the interpolated state with Delta-t = 1 (odinn_loss_grad_continuous, gradient.jl:475-503).
+ * `weight` is the MultiLoss lambda of the term relative to the data loss; 0 (default) switches it off.  A-type laws only. */
+int odinn_set_velocity_regularization(odinn_batch* b, double weight, int distance);
 
 /* ---- fine-grained seams (host in / host out; parity + drop-in, not the fast path) ---- */
 int odinn_sia2d_dhdt(odinn_batch* b, int g, const double* H, double t, double* dH);

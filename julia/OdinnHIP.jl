@@ -57,7 +57,8 @@ function Batch(simulation; device = 0)
     finalizer(x -> ccall((:odinn_batch_destroy, lib), Cint, (Ptr{Cvoid},), x.h), b)
 end
 
-# time-aggregated terms of a MultiLoss (src/losses/TimeAggregatedLosses.jl): data and weight relative to the data loss
+# terms of a MultiLoss the library evaluates next to the data loss (src/losses/TimeAggregatedLosses.jl, Regularization.jl:192-245):
+# data and weight relative to the data loss
 function set_time_aggregated_losses!(b::Batch, simulation)
     lf = simulation.parameters.UDE.empirical_loss_function
     terms = lf isa ODINN.MultiLoss ? collect(zip(lf.losses, lf.λs)) : [(lf, 1.0)]
@@ -70,6 +71,8 @@ function set_time_aggregated_losses!(b::Batch, simulation)
                             b.h, i - 1, g.dhdtData.t[1], g.dhdtData.t[2], g.dhdtData.dhdt))
             end
             check(ccall((:odinn_set_dhdt_loss, lib), Cint, (Ptr{Cvoid}, Cdouble), b.h, w / wdata))
+        elseif l isa ODINN.VelocityRegularization   # weighted by the intervals between the velocity-data dates (set_velocity_reference)
+            check(ccall((:odinn_set_velocity_regularization, lib), Cint, (Ptr{Cvoid}, Cdouble, Cint), b.h, w / wdata, l.distance))
         elseif l isa ODINN.LossAvgV
             for (i, g) in enumerate(simulation.glaciers)
                 v = g.velocityData

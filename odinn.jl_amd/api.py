@@ -42,7 +42,7 @@ __all__ = [
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad", "load_gridded_glacier", "attach_rccl_comm",
-    "SIA2D_A_target", "SIA2D_D_hybrid_target", "SIA2D_D_target", "LossDhdt", "DhdtData", "LossAvgV",
+    "SIA2D_A_target", "SIA2D_D_hybrid_target", "SIA2D_D_target", "LossDhdt", "DhdtData", "LossAvgV", "VelocityRegularization",
 ]
 
 
@@ -172,6 +172,21 @@ class RheologyRegularization:
 
 
 @dataclass
+class VelocityRegularization:
+    """src/losses/Regularization.jl:64-79,192-245: Tikhonov penalty on the Laplacian of the predicted surface speed inside
+    the glacier (distance to the margin), at the velocity-data times with their Δt weights -- the regulariser of the
+    reference's documented example MultiLoss((LossH(), VelocityRegularization()), ...).  Evaluated on the device."""
+
+    reg: TikhonovRegularization = field(default_factory=TikhonovRegularization)
+    components: str = "abs"
+    distance: int = 3
+
+    def __post_init__(self):
+        if self.components != "abs":
+            raise ValueError(f"Regularization {self} not implemented.")  # Regularization.jl:214
+
+
+@dataclass
 class LossDhdt:
     """src/losses/TimeAggregatedLosses.jl:38-113: (mean_{H(t0) > 1e-2}(H(t1) - H(t0)) / (t1 - t0) - dhdt_ref)^2 with
     glacier.dhdtData = DhdtData((t0, t1), dhdt_ref) -- a time-aggregated loss, evaluated on the device together with its
@@ -190,7 +205,7 @@ class LossAvgV:
     step: float = 1.0 / 12.0
 
 
-_AGGREGATED = (LossDhdt, LossAvgV)
+_AGGREGATED = (LossDhdt, LossAvgV, VelocityRegularization)  # evaluated on the device next to the data loss
 
 
 @dataclass
@@ -219,7 +234,7 @@ def _split_loss(lf):
     if len(data) != 1:
         raise ValueError("MultiLoss needs exactly one data term (LossH, LossV or LossHV)")
     for r, _ in regs:
-        if not isinstance(r, (InitialThicknessRegularization, RheologyRegularization, LossDhdt, LossAvgV)):
+        if not isinstance(r, (InitialThicknessRegularization, RheologyRegularization, LossDhdt, LossAvgV, VelocityRegularization)):
             raise TypeError(f"loss term {type(r).__name__} is not provided")
     return data[0][0], float(data[0][1]), regs
 
@@ -932,6 +947,11 @@ class _Simulation:
                 b.set_velocity_reference(k, v.t, v.vabs, v.vx, v.vy)
         lf, w_data, regs_ = _split_loss(p.UDE.empirical_loss_function)
         for r, w in regs_:
+            if isinstance(r, VelocityRegularization):
+                if any(g.velocityData is None or len(g.velocityData.t) < 2 for g in gl):
+                    raise ValueError("VelocityRegularization is weighted by the intervals between the velocity-data times: "
+                                     "every glacier needs velocityData with at least two dates")
+                b.set_velocity_regularization(float(w) / w_data, r.distance)
             if isinstance(r, LossAvgV):  # evaluated on the device, weight relative to the data loss
                 for k, g in enumerate(gl):
                     _avgv_times(g, r)  # validates velocityData

@@ -254,6 +254,11 @@ class GlacierBatch:
         its time grid and the compared component (:xy | :abs)."""
         L.check(L.lib().odinn_set_avgv_loss(self._h, float(weight), float(step), 1 if component == "abs" else 0))
 
+    def set_velocity_regularization(self, weight=1.0, distance=3):
+        """VelocityRegularization (Regularization.jl:64-79,192-245): MultiLoss weight relative to the data loss (0: off) and
+        the distance to the margin of its mask; evaluated at the velocity-data times of set_velocity_reference."""
+        L.check(L.lib().odinn_set_velocity_regularization(self._h, float(weight), int(distance)))
+
     def set_dhdt_loss(self, weight=1.0):
         """weight of the LossDhdt term relative to the data loss (its MultiLoss lambda); 0 switches it off."""
         L.check(L.lib().odinn_set_dhdt_loss(self._h, float(weight)))

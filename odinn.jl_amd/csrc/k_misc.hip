@@ -97,6 +97,20 @@ void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double*
 void launch_adj_poststep(int nblk, hipStream_t st, Pools P, AdjPostArgs A, double* Ua, double* Ub) {
   hipLaunchKernelGGL(k_adj_poststep, dim3(nblk), dim3(NT), 0, st, P, A, Ua, Ub);
 }
+void launch_vreg_prep(int nblk, hipStream_t st, Pools P, const double* H, const double* vx, const double* vy, const double* w,
+                      int dist, double* Vabs, unsigned char* mask) {
+  hipLaunchKernelGGL(k_vreg_prep, dim3(nblk), dim3(NT), 0, st, P, H, vx, vy, w, dist, Vabs, mask);
+}
+void launch_vreg_lap(int nblk, hipStream_t st, Pools P, const double* Vabs, const unsigned char* mask, const double* w, double* r) {
+  hipLaunchKernelGGL(k_vreg_lap, dim3(nblk), dim3(NT), 0, st, P, Vabs, mask, w, r);
+}
+void launch_vreg_cot(int nblk, hipStream_t st, Pools P, const double* r, const double* Vabs, const double* w, double* vx, double* vy) {
+  hipLaunchKernelGGL(k_vreg_cot, dim3(nblk), dim3(NT), 0, st, P, r, Vabs, w, vx, vy);
+}
+void launch_lerp(long long n, hipStream_t st, double s, const double* a, const double* b, double* out) {
+  const long long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_lerp, dim3((unsigned)(nb < 65536 ? (nb < 1 ? 1 : nb) : 65536)), dim3(256), 0, st, n, s, a, b, out);
+}
 void launch_tikhonov(hipStream_t st, const double* a, const unsigned char* mask, double* r, double* grad,
                      double* partial, int nx, int ny, double dx, double dy) {
   const dim3 grid((nx + 63) / 64, (ny + NW - 1) / NW);

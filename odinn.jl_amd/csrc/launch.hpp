@@ -81,6 +81,12 @@ void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, doub
 void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd);
 void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const double* y, double* z);
 void launch_axpy(long long n, hipStream_t st, double a, const double* x, const double* y, double* z);  // z = y + a x
+void launch_lerp(long long n, hipStream_t st, double s, const double* a, const double* b, double* out);  // out = a + s (b - a)
+// VelocityRegularization (Regularization.jl:192-245): see k_vreg_* in sia2d_device.hpp
+void launch_vreg_prep(int nblk, hipStream_t st, Pools P, const double* H, const double* vx, const double* vy, const double* w,
+                      int dist, double* Vabs, unsigned char* mask);
+void launch_vreg_lap(int nblk, hipStream_t st, Pools P, const double* Vabs, const unsigned char* mask, const double* w, double* r);
+void launch_vreg_cot(int nblk, hipStream_t st, Pools P, const double* r, const double* Vabs, const double* w, double* vx, double* vy);
 void launch_initdt_norms(int nblk, hipStream_t st, Pools P, const double* U, const double* F0, const double* F1,
                          double abstol, double reltol);
 void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan, double dtmax, double* dt0store);

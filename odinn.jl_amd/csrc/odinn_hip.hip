@@ -244,8 +244,20 @@ struct odinn_batch {
   int* d_agg_slot = nullptr;
   unsigned char* d_av_on = nullptr;
   size_t wA_cap = 0, aggH_cap = 0, agg_slot_cap = 0;
-  std::vector<double> wA_h;
+  std::vector<double> wA_h, wR_h;
   std::vector<int> agg_slot_h;
+  int agg_nslots = 0;
+  // VelocityRegularization: MultiLoss weight (0: off), distance to the margin, per-stop weights, mask scratch, node weights
+  double vreg_weight = 0.0;
+  int vreg_dist = 3;
+  double *d_wR = nullptr, *d_wRq = nullptr;
+  size_t wRq_cap = 0;
+  unsigned char* d_vrm = nullptr;
+  bool vreg_on() const {
+    if (!(vreg_weight != 0.0)) return false;
+    for (const auto& tv : t_vref) if (tv.size() >= 2) return true;
+    return false;
+  }
   bool avgv_on() const {
     if (!(avgv_weight != 0.0) || !d_aVabs) return false;
     for (size_t g = 0; g < av_t1.size(); ++g) if (av_t2[g] > av_t1[g]) return true;
@@ -941,73 +953,100 @@ int dhdt_forward(odinn_batch* b) {
   return ODINN_OK;
 }
 
-// LossAvgV after a forward solve (TimeAggregatedLosses.jl:146-258): per-glacier tLoss -> stop weights dt_i / T, the time-
-// averaged velocity, its loss (added onto d_lossacc[g]) and, with_grad, everything of its gradient that does not involve
-// lambda: dL/dH of every tLoss stop (d_aggH[agg_slot[j]], added to lambda at stop j by the reverse loops) and dL/dtheta
-// (d_Gsum / d_Gacc, which the reverse loops go on accumulating into)
-int avgv_forward(odinn_batch* b, bool with_grad) {
-  const int k = (int)b->tstops.size();
+// Terms of the loss whose gradient does not involve lambda (LossAvgV, VelocityRegularization) are formed right after the
+// forward solve: their dL/dH of stop j lands in d_aggH[agg_slot[j]] and is added to lambda at that stop by the reverse loops,
+// their dL/dtheta goes into d_Gsum / d_Gacc, which the reverse loops go on accumulating into.  agg_tables builds the
+// per-stop per-glacier weight tables of both terms, assigns the slots and clears the fields.
+int agg_tables(odinn_batch* b, bool with_grad) {
+  const int k = (int)b->tstops.size(), G = b->G;
   b->agg_slot_h.assign(k, -1);
-  if (!b->avgv_on()) return ODINN_OK;
-  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "LossAvgV needs an A-type law (target :A)");
-  const int G = b->G;
+  b->agg_nslots = 0;
+  const bool av = b->avgv_on(), vr = b->vreg_on();
+  if (!av && !vr) return ODINN_OK;
+  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "LossAvgV / VelocityRegularization need an A-type law (target :A)");
   b->wA_h.assign((size_t)k * G, 0.0);
+  b->wR_h.assign((size_t)k * G, 0.0);
   std::vector<unsigned char> on(G, 0);
-  for (int g = 0; g < G; ++g) {
-    const double t1 = b->av_t1[g], t2 = b->av_t2[g], st = b->avgv_step;
-    if (!(t2 > t1)) continue;
-    const int n = (int)std::floor((t2 - t1) / st + 1e-9);  // tLoss = collect(t1:step:t2) has n + 1 points
-    if (n < 1) return fail(ODINN_ERR_ARG, "LossAvgV: (t1, t2) = (%g, %g) of glacier %d holds no interval of length step = %g", t1, t2, g, st);
-    double T = 0.0;
-    for (int i = 0; i < n; ++i) T += (t1 + (i + 1) * st) - (t1 + i * st);
-    for (int i = 0; i < n; ++i) {
-      const double x = t1 + i * st;
-      int jj = -1;
-      for (int j = 0; j < k; ++j)
-        if (std::fabs(b->tstops[j] - x) <= 1e-9) { jj = j; break; }
-      if (jj < 0) return fail(ODINN_ERR_ARG, "LossAvgV: time %.10g of glacier %d is not among the tstops", x, g);
-      b->wA_h[(size_t)jj * G + g] = ((t1 + (i + 1) * st) - x) / T;
+  if (av)
+    for (int g = 0; g < G; ++g) {  // LossAvgV: tLoss = collect(t1:step:t2) without its last point, weights dt_i / T
+      const double t1 = b->av_t1[g], t2 = b->av_t2[g], st = b->avgv_step;
+      if (!(t2 > t1)) continue;
+      const int n = (int)std::floor((t2 - t1) / st + 1e-9);
+      if (n < 1) return fail(ODINN_ERR_ARG, "LossAvgV: (t1, t2) = (%g, %g) of glacier %d holds no interval of length step = %g", t1, t2, g, st);
+      double T = 0.0;
+      for (int i = 0; i < n; ++i) T += (t1 + (i + 1) * st) - (t1 + i * st);
+      for (int i = 0; i < n; ++i) {
+        const double x = t1 + i * st;
+        int jj = -1;
+        for (int j = 0; j < k; ++j)
+          if (std::fabs(b->tstops[j] - x) <= 1e-9) { jj = j; break; }
+        if (jj < 0) return fail(ODINN_ERR_ARG, "LossAvgV: time %.10g of glacier %d is not among the tstops", x, g);
+        b->wA_h[(size_t)jj * G + g] = ((t1 + (i + 1) * st) - x) / T;
+      }
+      on[g] = 1;
     }
-    on[g] = 1;
-  }
-  int nslots = 0;
+  if (vr)
+    for (int g = 0; g < G; ++g) {  // VelocityRegularization: Delta-t.V of the velocity-data times (gradient.jl:144-163)
+      const std::vector<double>& tv = b->t_vref[g];
+      for (int j = 0; j < k; ++j)
+        for (size_t m = 1; m < tv.size(); ++m)
+          if (tv[m] == b->tstops[j]) b->wR_h[(size_t)j * G + g] = b->vreg_weight * (tv[m] - tv[m - 1]);
+    }
   for (int j = 0; j < k; ++j) {
     bool any = false;
-    for (int g = 0; g < G; ++g) any = any || b->wA_h[(size_t)j * G + g] != 0.0;
-    if (any) b->agg_slot_h[j] = nslots++;
+    for (int g = 0; g < G; ++g) any = any || b->wA_h[(size_t)j * G + g] != 0.0 || b->wR_h[(size_t)j * G + g] != 0.0;
+    if (any) b->agg_slot_h[j] = b->agg_nslots++;
   }
   if (!b->d_avg) CHK(dalloc(&b->d_avg, (size_t)4 * b->ntot));
   if (!b->d_av_on) HIPCHK(hipMalloc(&b->d_av_on, (size_t)G));
-  if ((size_t)k * G > b->wA_cap) { dfree(b->d_wA); CHK(dalloc(&b->d_wA, (size_t)k * G)); b->wA_cap = (size_t)k * G; }
+  if ((size_t)k * G > b->wA_cap) {
+    dfree(b->d_wA); dfree(b->d_wR);
+    CHK(dalloc(&b->d_wA, (size_t)k * G)); CHK(dalloc(&b->d_wR, (size_t)k * G));
+    b->wA_cap = (size_t)k * G;
+  }
   if ((size_t)k > b->agg_slot_cap) {
     if (b->d_agg_slot) (void)hipFree(b->d_agg_slot);
     b->d_agg_slot = nullptr;
     HIPCHK(hipMalloc(&b->d_agg_slot, sizeof(int) * k));
     b->agg_slot_cap = (size_t)k;
   }
-  if (with_grad && (size_t)nslots * b->ntot > b->aggH_cap) {
+  if (with_grad && (size_t)b->agg_nslots * b->ntot > b->aggH_cap) {
     dfree(b->d_aggH);
-    CHK(dalloc(&b->d_aggH, (size_t)nslots * b->ntot));
-    b->aggH_cap = (size_t)nslots * b->ntot;
+    CHK(dalloc(&b->d_aggH, (size_t)b->agg_nslots * b->ntot));
+    b->aggH_cap = (size_t)b->agg_nslots * b->ntot;
   }
   HIPCHK(hipMemcpyAsync(b->d_wA, b->wA_h.data(), sizeof(double) * k * G, hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_wR, b->wR_h.data(), sizeof(double) * k * G, hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_agg_slot, b->agg_slot_h.data(), sizeof(int) * k, hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_av_on, on.data(), (size_t)G, hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));  // `on` is a temporary
+  if (with_grad && b->agg_nslots > 0)
+    HIPCHK(hipMemsetAsync(b->d_aggH, 0, (size_t)b->agg_nslots * b->ntot * sizeof(double), b->stream));
+  return ODINN_OK;
+}
+
+// LossAvgV (TimeAggregatedLosses.jl:146-258): the time-averaged velocity over the stops of the time grid, its loss (added
+// onto d_lossacc[g]) and, with_grad, the pull-back of dt_i / T dl/dV through surface_V at every stop of the grid
+int avgv_forward(odinn_batch* b, bool with_grad) {
+  if (!b->avgv_on()) return ODINN_OK;
+  const int k = (int)b->tstops.size(), G = b->G;
+  auto stop_on = [&](int j) {
+    for (int g = 0; g < G; ++g) if (b->wA_h[(size_t)j * G + g] != 0.0) return true;
+    return false;
+  };
   double *ax = b->d_avg, *ay = b->d_avg + b->ntot, *vx = b->d_avg + 2 * b->ntot, *vy = b->d_avg + 3 * b->ntot;
   HIPCHK(hipMemsetAsync(ax, 0, (size_t)2 * b->ntot * sizeof(double), b->stream));
   const Pools P = b->pools(true);
   for (int j = 0; j < k; ++j) {
-    if (b->agg_slot_h[j] < 0) continue;
+    if (!stop_on(j)) continue;
     launch_surface_V(b->lm(), b->ntiles, b->stream, P, b->d_snaps + (size_t)j * b->ntot, vx, vy, 0);
     launch_avgv_axpy(b->ntiles, b->stream, P, vx, vy, ax, ay, b->d_wA + (size_t)j * G);
   }
   launch_avgv_cot(b->ntiles, b->stream, P, ax, ay, b->d_aVabs, b->d_aVx, b->d_aVy, b->d_av_on, b->avgv_abs, b->avgv_weight);
   launch_sum_part(G, b->stream, P, 1, b->d_lossacc, 1, 0);
   if (with_grad) {
-    HIPCHK(hipMemsetAsync(b->d_aggH, 0, (size_t)nslots * b->ntot * sizeof(double), b->stream));
     for (int j = 0; j < k; ++j) {
-      if (b->agg_slot_h[j] < 0) continue;
+      if (!stop_on(j)) continue;
       VArgs A{};
       A.H = b->d_snaps + (size_t)j * b->ntot; A.dVx = ax; A.dVy = ay; A.out = b->d_aggH + (size_t)b->agg_slot_h[j] * b->ntot;
       A.wv = b->d_wA + (size_t)j * G; A.ntot = b->ntot;
@@ -1017,6 +1056,62 @@ int avgv_forward(odinn_batch* b, bool with_grad) {
     }
   }
   HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+// VelocityRegularization (Regularization.jl:192-245) at one state H: loss partial onto d_lossacc (w_loss), the pull-back of
+// dReg/dV through surface_V accumulated into `outH` (null: none) and into d_Gsum / d_Gacc (theta: false: not), all scaled
+// per glacier by w[g]
+static int vreg_at(odinn_batch* b, const double* H, const double* w, bool add_loss, double* outH, bool theta) {
+  const Pools P = b->pools(true);
+  double *vx = b->d_avg, *vy = b->d_avg + b->ntot, *va = b->d_avg + 2 * b->ntot, *r = b->d_avg + 3 * b->ntot;
+  launch_surface_V(b->lm(), b->ntiles, b->stream, P, H, vx, vy, 0);
+  launch_vreg_prep(b->ntiles, b->stream, P, H, vx, vy, w, b->vreg_dist, va, b->d_vrm);
+  launch_vreg_lap(b->ntiles, b->stream, P, va, b->d_vrm, w, r);
+  if (add_loss) launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
+  if (outH || theta) {
+    launch_vreg_cot(b->ntiles, b->stream, P, r, va, w, vx, vy);
+    VArgs A{};
+    A.H = H; A.dVx = vx; A.dVy = vy; A.out = outH ? outH : r;  // (r is dead by now: a sink for the unused H-part)
+    A.wv = w; A.ntot = b->ntot;
+    A.Gacc = (theta && b->wants_Gacc()) ? b->d_Gacc : nullptr;
+    launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, A, 0);
+    if (theta) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
+  }
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+// The VelocityRegularization term over a run: loss and dL/dH at the velocity-data stops with the weights Delta-t.V of the
+// discrete loss; dL/dtheta summed over the same stops (DiscreteAdjoint, gradient.jl:252) or -- nq > 0 -- integrated over
+// the Gauss-Legendre nodes on the interpolated state with Delta-t = 1 (ContinuousAdjoint, gradient.jl:475-503)
+int vreg_forward(odinn_batch* b, bool with_grad, bool add_loss, int nq, const double* qt, const double* qw) {
+  if (!b->vreg_on()) return ODINN_OK;
+  const int k = (int)b->tstops.size(), G = b->G;
+  if (!b->d_vrm) HIPCHK(hipMalloc(&b->d_vrm, (size_t)b->ntot));
+  for (int j = 0; j < k; ++j) {
+    bool any = false;
+    for (int g = 0; g < G; ++g) any = any || b->wR_h[(size_t)j * G + g] != 0.0;
+    if (!any) continue;
+    CHK(vreg_at(b, b->d_snaps + (size_t)j * b->ntot, b->d_wR + (size_t)j * G, add_loss,
+                with_grad ? b->d_aggH + (size_t)b->agg_slot_h[j] * b->ntot : nullptr, with_grad && nq == 0));
+  }
+  if (with_grad && nq > 0) {
+    std::vector<double> wq((size_t)nq * G, 0.0);
+    for (int g = 0; g < G; ++g)
+      if (b->t_vref[g].size() >= 2)
+        for (int n = 0; n < nq; ++n) wq[(size_t)n * G + g] = b->vreg_weight * qw[n];
+    if (wq.size() > b->wRq_cap) { dfree(b->d_wRq); CHK(dalloc(&b->d_wRq, wq.size())); b->wRq_cap = wq.size(); }
+    HIPCHK(hipMemcpyAsync(b->d_wRq, wq.data(), sizeof(double) * wq.size(), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));  // wq is a temporary
+    for (int n = 0; n < nq; ++n) {
+      int j = 0;  // segment of the node, interpolate((t,), H, Gridded(Linear())) (gradient.jl:287)
+      while (j + 2 < k && qt[n] >= b->tstops[j + 1]) ++j;
+      const double s_ = (qt[n] - b->tstops[j]) / (b->tstops[j + 1] - b->tstops[j]);
+      launch_lerp(b->ntot, b->stream, s_, b->d_snaps + (size_t)j * b->ntot, b->d_snaps + (size_t)(j + 1) * b->ntot, b->d_tmpA);
+      CHK(vreg_at(b, b->d_tmpA, b->d_wRq + (size_t)n * G, false, nullptr, true));
+    }
+  }
   return ODINN_OK;
 }
 
@@ -1039,7 +1134,9 @@ int do_loss(odinn_batch* b, double* const_loss) {
     }
   }
   CHK(dhdt_forward(b));  // time-aggregated terms (inversion_utils.jl:457-460)
+  CHK(agg_tables(b, false));
   CHK(avgv_forward(b, false));
+  CHK(vreg_forward(b, false, true, 0, nullptr, nullptr));
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -1237,6 +1334,8 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_aVabs); dfree(b->d_aVx); dfree(b->d_aVy); dfree(b->d_avg); dfree(b->d_wA); dfree(b->d_aggH);
   if (b->d_agg_slot) (void)hipFree(b->d_agg_slot);
   if (b->d_av_on) (void)hipFree(b->d_av_on);
+  dfree(b->d_wR); dfree(b->d_wRq);
+  if (b->d_vrm) (void)hipFree(b->d_vrm);
   dfree(b->d_nodeS); dfree(b->d_ucell); if (b->d_interp_err) (void)hipFree(b->d_interp_err);
   dfree(b->d_nodeH); dfree(b->d_nodeV); dfree(b->d_sortH); dfree(b->d_sortV); dfree(b->d_knots); dfree(b->d_knotG);
   dfree(b->d_knotab); dfree(b->d_knotM);
@@ -1641,6 +1740,12 @@ int odinn_set_avgv_reference(odinn_batch* b, int g, double t1, double t2, const 
   return ODINN_OK;
 }
 
+int odinn_set_velocity_regularization(odinn_batch* b, double weight, int distance) {
+  if (!b || !(weight >= 0.0) || distance < 0 || distance > 64) return fail(ODINN_ERR_ARG, "bad VelocityRegularization weight / distance");
+  b->vreg_weight = weight; b->vreg_dist = distance;
+  return ODINN_OK;
+}
+
 int odinn_set_avgv_loss(odinn_batch* b, double weight, double step, int component_abs) {
   if (!b || !(weight >= 0.0) || !(step > 0.0)) return fail(ODINN_ERR_ARG, "bad LossAvgV weight / step");
   b->avgv_weight = weight; b->avgv_step = step; b->avgv_abs = component_abs ? 1 : 0;
@@ -1841,12 +1946,12 @@ int odinn_loss(odinn_batch* b, double* loss_per_glacier) {
 
 // forward solve + zeroed gradient accumulators (common to both adjoints)
 static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
-                        const double* mb_times, const odinn_solver_opts* opts, odinn_solve_stats* stats) {
+                        const double* mb_times, const odinn_solver_opts* opts, odinn_solve_stats* stats, int n_quadrature = 0) {
   CHK(use_dev(b));
   if (theta) CHK(odinn_set_theta(b, theta, P));
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
-  if (b->loss_kind != ODINN_LOSS_V && !b->d_Href && !b->dhdt_on() && !b->avgv_on()) return fail(ODINN_ERR_STATE, "no reference thickness data set");
+  if (b->loss_kind != ODINN_LOSS_V && !b->d_Href && !b->dhdt_on() && !b->avgv_on() && !b->vreg_on()) return fail(ODINN_ERR_STATE, "no reference thickness data set");
   if (b->loss_kind != ODINN_LOSS_H && !b->d_Vabs) return fail(ODINN_ERR_STATE, "no reference velocity data set");
   if (b->vjp_method == 1 && b->law_kind >= ODINN_LAW_NN_Y)
     return fail(ODINN_ERR_UNSUPPORTED, "ContinuousVJP is provided for target :A (A-type laws) only");
@@ -1862,7 +1967,9 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
     HIPCHK(hipMemsetAsync(b->d_dth, 0, sizeof(double) * b->G * b->P, b->stream));
   }
   CHK(dhdt_forward(b));  // LossDhdt: loss term and the coefficients of its cotangent fields (gradient.jl:170-188)
+  CHK(agg_tables(b, true));
   CHK(avgv_forward(b, true));  // LossAvgV: loss term, dL/dH of its stops, dL/dtheta
+  if (n_quadrature == 0) CHK(vreg_forward(b, true, true, 0, nullptr, nullptr));  // (ContinuousAdjoint: once its nodes exist)
   return ODINN_OK;
 }
 static int grad_finish(odinn_batch* b, int k, int P, double const_loss, double* loss, double* dtheta);
@@ -2016,7 +2123,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   if (ao.abstol <= 0) ao.abstol = 1e-8;
   if (ao.n_quadrature <= 0) ao.n_quadrature = 200;
   if (ao.maxiters <= 0) ao.maxiters = 1000000;
-  CHK(grad_prepare(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, stats));
+  CHK(grad_prepare(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, stats, ao.n_quadrature));
   double const_loss = 0.0;
   CHK(do_loss(b, &const_loss));  // forward loss over the snapshots -> d_lossacc
   const int k = n_stops, G = b->G;
@@ -2024,6 +2131,11 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   // ---- reverse stop table: tau = -t ascending over snapshots and quadrature nodes (:457) ----
   std::vector<double> gx, gw;
   gauss_legendre(ao.n_quadrature, gx, gw);
+  if (b->vreg_on()) {  // VelocityRegularization: dL/dH at its stops, dL/dtheta by the quadrature (its loss is in do_loss)
+    std::vector<double> qt(ao.n_quadrature), qwt(ao.n_quadrature);
+    for (int i = 0; i < ao.n_quadrature; ++i) { qt[i] = (t0 + t1) / 2.0 + gx[i] * (t1 - t0) / 2.0; qwt[i] = (t1 - t0) / 2.0 * gw[i]; }
+    CHK(vreg_forward(b, true, false, ao.n_quadrature, qt.data(), qwt.data()));
+  }
   struct Stop { double tau; int snap; double qw; };
   std::vector<Stop> st;
   st.reserve(k + ao.n_quadrature);
@@ -2103,7 +2215,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   const bool theta_itp = !useV && b->law_kind < ODINN_LAW_NN_Y;
   AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = theta_itp ? nullptr : b->d_tmpA;
   if (b->dhdt_on()) { AP.dh_i0 = b->d_dh_i0; AP.dh_i1 = b->d_dh_i1; AP.dh_coef = b->d_dh_coef; }
-  if (b->avgv_on()) { AP.agg_slot = b->d_agg_slot; AP.aggH = b->d_aggH; }
+  if (b->agg_nslots > 0) { AP.agg_slot = b->d_agg_slot; AP.aggH = b->d_aggH; }
   const bool mb_last = b->any_mb && b->mb_flag[k - 1];
   launch_adj_begin(G, b->stream, Pl, b->d_adj, k, h_tau[0], mb_last ? 1 : 0, mb_last ? b->mb_slot[k - 1] : 0);
   // loss term of a velocity-data snapshot: lam += wV dl_V/dH(H_j)  (backward_loss(::LossV), Losses.jl:338-390)

@@ -2307,6 +2307,93 @@ __global__ __launch_bounds__(NT) void k_tikhonov_bwd(const double* __restrict__ 
 }
 
 
+// ---- VelocityRegularization (Regularization.jl:64-79,192-245) on the pooled arrays, all glaciers of a batch at once ----
+// Tikhonov penalty on the Laplacian of the predicted surface speed: w_g sum_mask (lap V)^2, mask = is_in_glacier(H, dist)
+// & (V > 0).  Three passes around the velocity kernels (k_surface_V before, k_surfV_vjp<2> after): prep (V, mask),
+// lap (r = 2 mask lap V, loss partial), cot (dReg/dV = L^T r; dReg/dVx = dReg/dV Vx / V, written over Vx, Vy).
+// w[g] == 0: the glacier has no term at this stop.
+__global__ __launch_bounds__(NT) void k_vreg_prep(Pools P, const double* __restrict__ H, const double* __restrict__ vx,
+                                                  const double* __restrict__ vy, const double* __restrict__ w, int dist,
+                                                  double* __restrict__ Vabs, unsigned char* __restrict__ mask) {
+  const int4 t4 = P.tiles[blockIdx.x];
+  if (w[t4.x] == 0.0) return;
+  const GDev g = P.gd[t4.x];
+  const int gi = t4.y * TX + (threadIdx.x & 63), ty = wave_id();
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = t4.z * TY + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double v = sqrt(vx[id] * vx[id] + vy[id] * vy[id]);
+      // is_in_glacier: ice on the cell and on every cell within Chebyshev distance `dist` (cells outside the grid count as
+      // ice-free) -- the definition the thickness loss uses for its reference mask (odinn_set_reference)
+      bool in = v > 0.0;
+      for (int b = -dist; b <= dist && in; ++b)
+        for (int a = -dist; a <= dist && in; ++a) {
+          const int ii = gi + a, jj = gj + b;
+          in = ii >= 0 && ii < g.nx && jj >= 0 && jj < g.ny && H[g.off + ii + (long long)g.nx * jj] > 0.0;
+        }
+      Vabs[id] = v;
+      mask[id] = in ? 1 : 0;
+    }
+  }
+}
+__global__ __launch_bounds__(NT) void k_vreg_lap(Pools P, const double* __restrict__ Vabs, const unsigned char* __restrict__ mask,
+                                                 const double* __restrict__ w, double* __restrict__ r) {
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const double wg = w[t4.x];
+  if (wg == 0.0) {
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = 0.0;
+    return;
+  }
+  const GDev g = P.gd[t4.x];
+  const double wx = g.inv_dx * g.inv_dx * 0.25, wy = g.inv_dy * g.inv_dy * 0.25;
+  const int gi = t4.y * TX + (threadIdx.x & 63), ty = wave_id();
+  double sq = 0.0;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = t4.z * TY + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      double v = 0.0;
+      if (gi >= 1 && gi <= g.nx - 2 && gj >= 1 && gj <= g.ny - 2 && mask[id]) {
+        const double l = lap9(Vabs + g.off, g.nx, gi, gj, wx, wy, false, g.ny);
+        v = 2.0 * l;
+        sq = fma(l, l, sq);
+      }
+      r[id] = v;
+    }
+  }
+  const double tot = block_sum(sq, red);
+  if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = tot * wg;
+}
+__global__ __launch_bounds__(NT) void k_vreg_cot(Pools P, const double* __restrict__ r, const double* __restrict__ Vabs,
+                                                 const double* __restrict__ w, double* __restrict__ vx, double* __restrict__ vy) {
+  const int4 t4 = P.tiles[blockIdx.x];
+  if (w[t4.x] == 0.0) return;
+  const GDev g = P.gd[t4.x];
+  const double wx = g.inv_dx * g.inv_dx * 0.25, wy = g.inv_dy * g.inv_dy * 0.25;
+  const int gi = t4.y * TX + (threadIdx.x & 63), ty = wave_id();
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = t4.z * TY + ty + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double gV = lap9(r + g.off, g.nx, gi, gj, wx, wy, true, g.ny);  // VJP of the Laplacian (Regularization.jl:372-382)
+      const double v = Vabs[id];
+      const double cx = v > 0.0 ? gV * vx[id] / v : 0.0, cy = v > 0.0 ? gV * vy[id] / v : 0.0;
+      vx[id] = cx;
+      vy[id] = cy;
+    }
+  }
+}
+// out = a + s (b - a) on n entries (the time interpolant of two snapshots, load_tile_HS2's formula)
+__global__ void k_lerp(long long n, double s, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = fma(s, b[i] - a[i], a[i]);
+}
+
 // ---- continuous adjoint with a velocity loss: the theta-part of the loss at a quadrature node ------
 // (gradient.jl:475-503: backward_loss at t_node with the reference velocities interpolated linearly in
 // time, :291-301).  k_vref_itp writes the interpolated (Vabs, Vx, Vy) of the glaciers that just reached

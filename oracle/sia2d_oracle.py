@@ -1058,6 +1058,12 @@ class SimConfig:
     # MultiLoss weight of the term; every point of t1:step:t2 except the last must be among the stops
     avgv: Optional["AvgVData"] = None
     avgv_weight: float = 1.0
+    # VelocityRegularization (src/losses/Regularization.jl:64-79,192-245): Tikhonov penalty on the Laplacian of the predicted
+    # surface speed at the velocity-data times `vreg_times` (weights Delta-t.V = their differences), mask =
+    # is_in_glacier(H_pred, vreg_distance) & (V > 0), MultiLoss weight vreg_weight (0: off)
+    vreg_times: Sequence[float] = ()
+    vreg_distance: int = 3
+    vreg_weight: float = 0.0
 
 
 def forward(gl: Glacier, law: Law, cfg: SimConfig, theta=None):
@@ -1190,15 +1196,64 @@ def avgv_loss_terms(snaps, tstops, cfg: SimConfig, gl, law: Law, theta=None):
     return w * l, dl, dth
 
 
-def aggregated_loss_terms(snaps, tstops, cfg: SimConfig, gl, law: Law, theta=None):
-    """All time-aggregated terms of the loss (MultiLoss of LossDhdt / LossAvgV; TimeAggregatedLosses.jl:292-345):
-    (loss, {stop index: dL/dH}, dL/dtheta)."""
+def vreg_backward(H, gl, law: Law, theta, distance):
+    """VelocityRegularization(reg = TikhonovRegularization(), components = :abs) at one state, Delta-t = 1
+    (Regularization.jl:192-245): loss = sum_mask (lap V)^2 with V = |V_from_H(H)|, mask = is_in_glacier(H, distance) & (V > 0);
+    dReg/dV = VJP_lap(2 mask lap V) (:110-126), dReg/dVx = dReg/dV Vx / V where V > 0, pulled back through surface_V.
+    Returns (loss, dL/dH, dL/dtheta)."""
+    ph = gl.phys
+    Vx, Vy, V = V_from_H(H, gl.B, gl.dx, gl.dy, ph, law, theta)
+    mask = is_in_glacier(H, distance) & (V > 0.0)
+    lap = laplacian(V, gl.dx, gl.dy)
+    c = np.zeros_like(V)
+    c[mask] = 2.0 * lap[mask]
+    dV = vjp_laplacian(c, gl.dx, gl.dy)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dVx = np.where(V > 0.0, dV * Vx / V, 0.0)
+        dVy = np.where(V > 0.0, dV * Vy / V, 0.0)
+    return (float(np.sum(lap[mask] ** 2)), vjp_surface_V_H(dVx, dVy, H, gl.B, gl.dx, gl.dy, ph, law, theta),
+            vjp_surface_V_theta(dVx, dVy, H, gl.B, gl.dx, gl.dy, ph, law, theta))
+
+
+def vreg_loss_terms(snaps, tstops, cfg: SimConfig, gl, law: Law, theta=None, quadrature=None):
+    """The VelocityRegularization term of a MultiLoss over a run: loss and dL/dH at the velocity-data stops with the weights
+    Delta-t.V of the discrete loss (gradient.jl:144-163, :331-365 for the reverse ODE); dL/dtheta summed over the same stops
+    (DiscreteAdjoint, :252) or -- quadrature = (nodes, weights) -- integrated over the Gauss-Legendre nodes on the
+    interpolated state with Delta-t = 1 (ContinuousAdjoint, :475-503).  Returns (loss, {stop: dL/dH}, dL/dtheta)."""
+    P = 1 if law.kind == LAW_CONST_A else law.mlp.n_params
+    if not (cfg.vreg_weight != 0.0) or len(cfg.vreg_times) == 0:
+        return 0.0, {}, np.zeros(P)
+    t = [float(x) for x in tstops]
+    w = loss_weights(t, cfg.vreg_times)
+    lam_w = cfg.vreg_weight
+    l, dl, dth = 0.0, {}, np.zeros(P)
+    for j in range(len(t)):
+        if w[j] == 0.0:
+            continue
+        lj, gH, gth = vreg_backward(snaps[j], gl, law, theta, cfg.vreg_distance)
+        l += lam_w * w[j] * lj
+        dl[j] = lam_w * w[j] * gH
+        if quadrature is None:
+            dth = dth + lam_w * w[j] * gth
+    if quadrature is not None:
+        for tn, wn in zip(*quadrature):
+            _, _, gth = vreg_backward(linear_itp(t, snaps, float(tn)), gl, law, theta, cfg.vreg_distance)
+            dth = dth + lam_w * wn * gth
+    return l, dl, dth
+
+
+def aggregated_loss_terms(snaps, tstops, cfg: SimConfig, gl, law: Law, theta=None, quadrature=None):
+    """Every term of the loss whose gradient does not involve lambda and is therefore formed right after the forward solve:
+    the time-aggregated losses (MultiLoss of LossDhdt / LossAvgV; TimeAggregatedLosses.jl:292-345) and
+    VelocityRegularization.  (loss, {stop index: dL/dH}, dL/dtheta)."""
     l1, d1 = dhdt_loss_terms(snaps, tstops, cfg)
     l2, d2, th2 = avgv_loss_terms(snaps, tstops, cfg, gl, law, theta)
+    l3, d3, th3 = vreg_loss_terms(snaps, tstops, cfg, gl, law, theta, quadrature)
     d = dict(d1)
-    for j, f in d2.items():
-        d[j] = d[j] + f if j in d else f
-    return l1 + l2, d, th2
+    for dd in (d2, d3):
+        for j, f in dd.items():
+            d[j] = d[j] + f if j in d else f
+    return l1 + l2 + l3, d, th2 + th3
 
 
 def _vjp_H_of(vjp):
@@ -1332,14 +1387,14 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
             return u + vjp_mb(cfg.mb, u, H_itp(tt) - inc[tt], gl.B)
         return u
 
-    l_agg, dl_agg, dth_agg = aggregated_loss_terms(snaps, t, cfg, gl, law, theta)  # :369-387
+    nodes, wts = gauss_quadrature(t[0], t[-1], adj.n_quadrature)  # :307-308
+    l_agg, dl_agg, dth_agg = aggregated_loss_terms(snaps, t, cfg, gl, law, theta, (nodes, wts))  # :369-387
 
     def effect_agg(tt, u):  # :389-399
         j = t.index(tt)
         return u + dl_agg[j] if j in dl_agg else u
 
     f_rev = lambda lam, tau: _vjp_H_of(vjp)(lam, H_itp(-tau), gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # :316-324
-    nodes, wts = gauss_quadrature(t[0], t[-1], adj.n_quadrature)  # :307-308
     lam1 = effect_loss(t[-1], np.zeros_like(gl.B))  # :441-446 (not covered by the discrete callback)
     lam1 = effect_agg(t[-1], lam1)  # :447-449
     lam1 = effect_mb(t[-1], lam1)  # PeriodicCallback(initial_affect = true) :431-432
