@@ -195,6 +195,12 @@ int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double*
  * scale_loss) :293-390, LossHV(hLoss, vLoss, scaling) :395-440 */
 enum odinn_loss_kind { ODINN_LOSS_H = 0, ODINN_LOSS_V = 1, ODINN_LOSS_HV = 2 };
 int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_loss, double hv_scaling);
+/* the simple loss inside LossV (and LossHV's velocity part): L2Sum (default) or LogSum(eps) = log^2((a + eps) / (b + eps)) /
+ * normalization (Losses.jl:34-49,207-229; Morlighem et al. 2010).  LogSum asserts non-negative fields in the reference, i.e.
+ * it goes with component :abs; with :xy the gradient entry points fail with ODINN_ERR_ARG. */
+#define ODINN_SIMPLE_L2SUM 0
+#define ODINN_SIMPLE_LOGSUM 1
+int odinn_set_velocity_loss_function(odinn_batch* b, int simple_loss, double eps);
 /* LossDhdt, a time-aggregated loss (src/losses/TimeAggregatedLosses.jl:38-113): glacier.dhdtData = (t0, t1, dhdt_ref);
  * with H0, H1 the predicted thickness at t0, t1 (both must be tstops of the solve), mask = H0 > 1e-2 and
  * dhdt = mean((H1 - H0)[mask]) / (t1 - t0), the term weight * (dhdt - dhdt_ref)^2 joins the loss of odinn_loss /

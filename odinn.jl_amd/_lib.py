@@ -21,6 +21,7 @@ POST_NONE, POST_AFFINE, POST_EXPMAX, POST_SCALE = range(4)
  TIMED_LAW_FIELD) = range(13)
 SCHEME_AUTO, SCHEME_STAGED, SCHEME_FUSED = 0, 1, 2
 LOSS_H, LOSS_V, LOSS_HV = 0, 1, 2
+SIMPLE_L2SUM, SIMPLE_LOGSUM = 0, 1
 VJP_DISCRETE, VJP_CONTINUOUS = 0, 1
 GRAD_INTERP_NONE, GRAD_INTERP_LINEAR = 0, 1
 SCHEME_AUTO, SCHEME_STAGED, SCHEME_FUSED, SCHEME_EULER_CFL = 0, 1, 2, 3
@@ -89,6 +90,7 @@ SIGNATURES = {
     "odinn_set_avgv_reference": (C.c_int, [_vp, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]),
     "odinn_set_avgv_loss": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
     "odinn_set_velocity_regularization": (C.c_int, [_vp, C.c_double, C.c_int]),
+    "odinn_set_velocity_loss_function": (C.c_int, [_vp, C.c_int, C.c_double]),
     "odinn_surface_V": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "odinn_surface_V_vjp_H": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "odinn_surface_V_vjp_theta": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]),

@@ -39,7 +39,7 @@ __all__ = [
     "InitialThicknessRegularization", "RheologyRegularization", "InitialCondition", "evaluate_H0", "evaluate_dH0",
     "sigma_zang", "dsigma_zang", "TrainingResult", "save_inversion_file", "load_inversion_file", "ScalarLogger",
     "callback_diagnosis",
-    "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
+    "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "LogSum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad", "load_gridded_glacier", "attach_rccl_comm",
     "SIA2D_A_target", "SIA2D_D_hybrid_target", "SIA2D_D_target", "LossDhdt", "DhdtData", "LossAvgV", "VelocityRegularization",
@@ -119,19 +119,36 @@ class L2Sum:
 
 
 @dataclass
+class LogSum:
+    """src/losses/Losses.jl:34-49,207-229: log²((a + ϵ) / (b + ϵ)) / normalization (Morlighem et al. 2010); provided as
+    the simple loss of LossV(component = :abs) -- the combination the reference tests (runtests.jl:165-167)."""
+
+    distance: int = 3
+    eps: float = 0.1  # ϵ
+
+
+@dataclass
 class LossH:
     """src/losses/Losses.jl:250-291"""
 
     loss: L2Sum = field(default_factory=L2Sum)
+
+    def __post_init__(self):
+        if isinstance(self.loss, LogSum):
+            raise NotImplementedError("LogSum is provided inside LossV(component = :abs); LossH uses L2Sum")
 
 
 @dataclass
 class LossV:
     """src/losses/Losses.jl:66-81,293-390 (target :A)"""
 
-    loss: L2Sum = field(default_factory=L2Sum)
+    loss: object = field(default_factory=L2Sum)  # L2Sum | LogSum
     component: str = "xy"  # :xy | :abs
     scale_loss: bool = True
+
+    def __post_init__(self):
+        if isinstance(self.loss, LogSum) and self.component != "abs":
+            raise ValueError("LogSum needs non-negative fields (Losses.jl:214): use LossV(loss = LogSum(), component = :abs)")
 
 
 @dataclass
@@ -968,6 +985,9 @@ class _Simulation:
             b.set_loss(L.LOSS_HV, lf.vLoss.component, lf.vLoss.scale_loss, lf.scaling)
         elif isinstance(lf, LossV):
             b.set_loss(L.LOSS_V, lf.component, lf.scale_loss)
+        vl = lf.vLoss if isinstance(lf, LossHV) else lf if isinstance(lf, LossV) else None
+        if vl is not None and isinstance(vl.loss, LogSum):
+            b.set_velocity_loss_function(vl.loss.eps)
         if law.classical is not None:
             self._batch = b
             self._apply_classical(self.model.theta[:self.model.n_main])

@@ -235,6 +235,14 @@ class GlacierBatch:
         L.check(L.lib().odinn_set_loss(self._h, int(kind), 1 if component == "abs" else 0, 1 if scale_loss else 0,
                                        float(scaling)))
 
+    def set_velocity_loss_function(self, logsum_eps=None):
+        """The simple loss inside LossV / LossHV's velocity part: L2Sum (None) or LogSum(eps) (Losses.jl:34-49,207-229;
+        component :abs only -- LogSum asserts non-negative fields)."""
+        if logsum_eps is None:
+            L.check(L.lib().odinn_set_velocity_loss_function(self._h, L.SIMPLE_L2SUM, 0.0))
+        else:
+            L.check(L.lib().odinn_set_velocity_loss_function(self._h, L.SIMPLE_LOGSUM, float(logsum_eps)))
+
     def set_dhdt_reference(self, g, t0, t1, dhdt_ref):
         """glacier.dhdtData of LossDhdt (TimeAggregatedLosses.jl:38-113): mean elevation-change rate between t0 and t1."""
         L.check(L.lib().odinn_set_dhdt_reference(self._h, int(g), float(t0), float(t1), float(dhdt_ref)))

@@ -205,6 +205,17 @@ struct odinn_batch {
   unsigned char* d_mask = nullptr;
   // surface-velocity data and loss selection
   std::vector<std::vector<double>> t_vref;                // per glacier
+  // LossV's simple loss: 0 = L2Sum, > 0 = LogSum(eps) (component :abs only; Losses.jl:34-49,207-229)
+  double v_log_eps = 0.0;
+  std::vector<std::vector<std::vector<double>>> v_edge;  // per glacier per slot: V_ref > 0 on the last row / column
+  // data-only part of LossV on the last row / column of slot m (V_pred = 0 there by construction), divided by nx ny
+  double v_const(int g, int m) const {
+    if (!v_abs) return v_cxy[g][m];
+    if (!(v_log_eps > 0.0)) return v_cabs[g][m];
+    double s_ = 0.0;
+    for (double va : v_edge[g][m]) { const double l = std::log(v_log_eps / (va + v_log_eps)); s_ += l * l; }
+    return s_ / ((double)gd[g].nx * (double)gd[g].ny);
+  }
   std::vector<std::vector<double>> v_scale, v_cxy, v_cabs;  // per glacier per slot: 1/sqrt(mean|Vref|^2),
                                                            // constant loss of the last row/column (:xy, :abs)
   int nvref_alloc = 0;
@@ -721,15 +732,17 @@ int launch_lossV(odinn_batch* b, int j, const double* Hj, double* out, bool with
     if (b->wv_h[q] != 0.0) {
       any = true;
       const int m = b->vslot_h[q];
-      *const_loss += b->wv_h[q] * b->vsc_h[q] * (b->v_abs ? b->v_cabs[g][m] : b->v_cxy[g][m]);
+      *const_loss += b->wv_h[q] * b->vsc_h[q] * b->v_const(g, m);
     }
   }
   if (!any) return ODINN_OK;
   if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "LossV needs an A-type law (target :A)");
+  if (b->v_log_eps > 0.0 && !b->v_abs)
+    return fail(ODINN_ERR_ARG, "LogSum needs non-negative fields (Losses.jl:214): use it with component :abs");
   VArgs A{};
   A.H = Hj; A.out = out; A.Vabs = b->d_Vabs; A.Vxr = b->d_Vxr; A.Vyr = b->d_Vyr;
   A.wv = b->d_wv + (size_t)j * b->G; A.scale = b->d_vsc + (size_t)j * b->G; A.refslot = b->d_vslot + (size_t)j * b->G;
-  A.ntot = b->ntot; A.component_abs = b->v_abs;
+  A.ntot = b->ntot; A.component_abs = b->v_abs; A.log_eps = b->v_abs ? b->v_log_eps : 0.0;
   A.Gacc = (with_grad && b->wants_Gacc()) ? b->d_Gacc : nullptr;
   const Pools P = b->pools(true);
   launch_surfV_vjp(b->lm(), 1, b->ntiles, b->stream, P, A, 0);
@@ -1184,6 +1197,7 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   b->dh_t0.assign(n_glaciers, 0.0); b->dh_t1.assign(n_glaciers, 0.0); b->dh_ref.assign(n_glaciers, 0.0);
   b->av_t1.assign(n_glaciers, 0.0); b->av_t2.assign(n_glaciers, 0.0);
   b->t_vref.resize(n_glaciers); b->v_scale.resize(n_glaciers); b->v_cxy.resize(n_glaciers); b->v_cabs.resize(n_glaciers);
+  b->v_edge.resize(n_glaciers);
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreate(&b->ev0));
@@ -1699,6 +1713,14 @@ int odinn_set_vjp_method(odinn_batch* b, int method) {
   return ODINN_OK;
 }
 
+int odinn_set_velocity_loss_function(odinn_batch* b, int simple_loss, double eps) {
+  if (b) b->refs_version++;
+  if (!b || (simple_loss != ODINN_SIMPLE_L2SUM && simple_loss != ODINN_SIMPLE_LOGSUM)) return fail(ODINN_ERR_ARG, "unknown simple loss");
+  if (simple_loss == ODINN_SIMPLE_LOGSUM && !(eps > 0.0)) return fail(ODINN_ERR_ARG, "LogSum needs eps > 0");
+  b->v_log_eps = simple_loss == ODINN_SIMPLE_LOGSUM ? eps : 0.0;
+  return ODINN_OK;
+}
+
 int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_loss, double hv_scaling) {
   if (b) b->refs_version++;
   if (!b) return fail(ODINN_ERR_ARG, "null batch");
@@ -1779,6 +1801,7 @@ int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double*
   const size_t n = (size_t)r.nx * r.ny;
   b->t_vref[g].assign(t_ref, t_ref + n_ref);
   b->v_scale[g].assign(n_ref, 1.0); b->v_cxy[g].assign(n_ref, 0.0); b->v_cabs[g].assign(n_ref, 0.0);
+  b->v_edge[g].assign(n_ref, std::vector<double>());
   for (int m = 0; m < n_ref; ++m) {
     const double *va = Vabs + m * n, *vx = Vx + m * n, *vy = Vy + m * n;
     double s2 = 0.0, cxy = 0.0, cabs = 0.0;
@@ -1789,7 +1812,7 @@ int odinn_set_velocity_reference(odinn_batch* b, int g, int n_ref, const double*
         if (va[c] > 0.0) {
           s2 += vx[c] * vx[c] + vy[c] * vy[c];
           ++cnt;
-          if (i == r.nx - 1 || j == r.ny - 1) { cxy += vx[c] * vx[c] + vy[c] * vy[c]; cabs += va[c] * va[c]; }
+          if (i == r.nx - 1 || j == r.ny - 1) { cxy += vx[c] * vx[c] + vy[c] * vy[c]; cabs += va[c] * va[c]; b->v_edge[g][m].push_back(va[c]); }
         }
       }
     b->v_scale[g][m] = cnt > 0 ? 1.0 / std::sqrt(s2 / (double)cnt) : 1.0;
@@ -1939,7 +1962,7 @@ int odinn_loss(odinn_batch* b, double* loss_per_glacier) {
     for (int g = 0; g < b->G; ++g) {
       const size_t q = (size_t)j * b->G + g;
       if (b->loss_kind != ODINN_LOSS_H && b->wv_h[q] != 0.0)
-        loss_per_glacier[g] += b->wv_h[q] * b->vsc_h[q] * (b->v_abs ? b->v_cabs[g][b->vslot_h[q]] : b->v_cxy[g][b->vslot_h[q]]);
+        loss_per_glacier[g] += b->wv_h[q] * b->vsc_h[q] * b->v_const(g, b->vslot_h[q]);
     }
   return ODINN_OK;
 }
@@ -2047,7 +2070,7 @@ static int grad_finish(odinn_batch* b, int k, int P, double const_loss, double* 
     for (int j = 1; j < k; ++j) {
       const size_t q = (size_t)j * b->G + g;
       if (b->loss_kind != ODINN_LOSS_H && b->wv_h[q] != 0.0)
-        b->last_loss_g[g] += b->wv_h[q] * b->vsc_h[q] * (b->v_abs ? b->v_cabs[g][b->vslot_h[q]] : b->v_cxy[g][b->vslot_h[q]]);
+        b->last_loss_g[g] += b->wv_h[q] * b->vsc_h[q] * b->v_const(g, b->vslot_h[q]);
     }
   }
   double Ltot = const_loss;
@@ -2222,7 +2245,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   VArgs VS{};
   if (useV) {
     VS.Vabs = b->d_Vabs; VS.Vxr = b->d_Vxr; VS.Vyr = b->d_Vyr; VS.wv = b->d_wv; VS.scale = b->d_vsc; VS.refslot = b->d_vslot;
-    VS.ntot = b->ntot; VS.component_abs = b->v_abs; VS.Gacc = nullptr; VS.adj = b->d_adj; VS.G = G;
+    VS.ntot = b->ntot; VS.component_abs = b->v_abs; VS.log_eps = b->v_abs ? b->v_log_eps : 0.0; VS.Gacc = nullptr; VS.adj = b->d_adj; VS.G = G;
     VS.H = b->d_snaps + (size_t)(k - 1) * b->ntot; VS.out = b->d_lam[0];
     launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, VS, 0);  // at t1 the losses come before the MB VJP
     VS.H = b->d_tmpA;
@@ -2236,7 +2259,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     VI.Vabs = b->d_Vabs; VI.Vxr = b->d_Vxr; VI.Vyr = b->d_Vyr; VI.ntot = b->ntot; VI.slotA = b->d_rvA; VI.slotB = b->d_rvB;
     VI.sw = b->d_rvs; VI.G = G; VI.adj = b->d_adj; VI.Vq = b->d_Vq;
     VQ.H = b->d_tmpA; VQ.out = b->d_tmpB; VQ.Vabs = b->d_Vq; VQ.Vxr = b->d_Vq + b->ntot; VQ.Vyr = b->d_Vq + 2 * b->ntot;
-    VQ.wv = b->d_wvq; VQ.scale = b->d_vscq; VQ.refslot = b->d_zeroslot; VQ.ntot = b->ntot; VQ.component_abs = b->v_abs;
+    VQ.wv = b->d_wvq; VQ.scale = b->d_vscq; VQ.refslot = b->d_zeroslot; VQ.ntot = b->ntot; VQ.component_abs = b->v_abs; VQ.log_eps = b->v_abs ? b->v_log_eps : 0.0;
     VQ.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
     HIPCHK(hipMemsetAsync(b->d_tmpB, 0, (size_t)b->ntot * sizeof(double), b->stream));
   }

@@ -92,6 +92,7 @@ struct VArgs {
   const int* refslot;     // per-glacier slot
   long long ntot;
   int component_abs;      // 0: :xy, 1: :abs
+  double log_eps;         // > 0 (:abs only): LogSum(eps) instead of L2Sum -- log^2((V + eps) / (V_ref + eps)) (Losses.jl:207-229)
   double* Gacc;           // gridded-A accumulator or null
   // continuous adjoint, loss term at a snapshot time: wv / scale / refslot are the full [n_snap][G] tables and
   // the row is the snapshot the glacier's reverse solve just reached (nothing to do otherwise)
@@ -166,10 +167,14 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
             if (owned) lsum = fma(ex, ex, fma(ey, ey, lsum));
           } else {
             const double v = sqrt(vx * vx + vy * vy), ev = v - va;
-            const double dv = 2.0 * ev * Ninv;
+            double dv = 2.0 * ev * Ninv, lq = ev;
+            if (A.log_eps > 0.0) {  // LogSum: l = log^2 q, dl/dV = 2 log q / (V + eps), q = (V + eps) / (V_ref + eps)
+              lq = log((v + A.log_eps) / (va + A.log_eps));
+              dv = 2.0 * lq / (v + A.log_eps) * Ninv;
+            }
             dvx = dv * ex / ev * sc;  // as the reference writes it (Losses.jl:367-368)
             dvy = dv * ey / ev * sc;
-            if (owned) lsum = fma(ev, ev, lsum);
+            if (owned) lsum = fma(lq, lq, lsum);
           }
         }
       }

@@ -835,6 +835,19 @@ def l2sum_backward(a, b, mask, normalization):
     return 2.0 * d / normalization
 
 
+def logsum_loss(a, b, mask, normalization, eps):
+    """LogSum (Losses.jl:207-217): sum log^2((a + eps) / (b + eps)) / normalization on the mask; a, b >= 0 asserted."""
+    assert a.min() >= 0.0 and b.min() >= 0.0
+    return np.sum(np.log((a[mask] + eps) / (b[mask] + eps)) ** 2) / normalization
+
+
+def logsum_backward(a, b, mask, normalization, eps):
+    """Losses.jl:218-229."""
+    d = np.zeros_like(a)
+    d[mask] = np.log((a[mask] + eps) / (b[mask] + eps)) / (a[mask] + eps)
+    return 2.0 * d / normalization
+
+
 # ----------------------------------------------------------------------------
 # Time integration: RDPK3Sp35 (3S*+ low-storage, 5 stages, order 3(2)),
 # Ranocha, Dalcin, Parsani, Ketcheson (2022) "Optimized Runge-Kutta methods with
@@ -1675,6 +1688,7 @@ class LossVSpec:
 
     component: str = "xy"
     scale_loss: bool = True
+    log_eps: Optional[float] = None  # None: L2Sum; eps: LogSum(eps) (component "abs" only, Losses.jl:214)
 
 
 def _lossV_scale(spec: LossVSpec, Vx_ref, Vy_ref, mask):
@@ -1688,7 +1702,10 @@ def loss_V(spec: LossVSpec, H, B, dx, dy, ph, law, Vabs_ref, Vx_ref, Vy_ref, nor
     Vx, Vy, V = V_from_H(H, B, dx, dy, ph, law, theta)
     mask = Vabs_ref > 0.0
     if spec.component == "xy":
+        assert spec.log_eps is None
         l = l2sum_loss(Vx, Vx_ref, mask, normalization) + l2sum_loss(Vy, Vy_ref, mask, normalization)
+    elif spec.log_eps is not None:
+        l = logsum_loss(V, Vabs_ref, mask, normalization, spec.log_eps)
     else:
         l = l2sum_loss(V, Vabs_ref, mask, normalization)
     return l * _lossV_scale(spec, Vx_ref, Vy_ref, mask)
@@ -1702,7 +1719,8 @@ def backward_loss_V(spec: LossVSpec, H, B, dx, dy, ph, law, Vabs_ref, Vx_ref, Vy
         dVx = l2sum_backward(Vx, Vx_ref, mask, normalization)
         dVy = l2sum_backward(Vy, Vy_ref, mask, normalization)
     else:
-        dV = l2sum_backward(V, Vabs_ref, mask, normalization)
+        dV = (l2sum_backward(V, Vabs_ref, mask, normalization) if spec.log_eps is None
+              else logsum_backward(V, Vabs_ref, mask, normalization, spec.log_eps))
         with np.errstate(divide="ignore", invalid="ignore"):
             dVx = np.where(mask, dV * (Vx - Vx_ref) / (V - Vabs_ref), 0.0)
             dVy = np.where(mask, dV * (Vy - Vy_ref) / (V - Vabs_ref), 0.0)

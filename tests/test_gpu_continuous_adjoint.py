@@ -97,7 +97,7 @@ def test_continuous_adjoint_ragged_batch_and_other_laws(gpu):
     b.close()
 
 
-@pytest.mark.parametrize("kind,component,scale", [("V", "xy", True), ("V", "abs", False), ("HV", "xy", True)])
+@pytest.mark.parametrize("kind,component,scale", [("V", "xy", True), ("V", "abs", False), ("HV", "xy", True), ("V", "log", True)])
 def test_continuous_adjoint_with_velocity_losses(gpu, kind, component, scale):
     """ContinuousAdjoint with LossV / LossHV (gradient.jl:291-301, 331-365, 475-503): the velocity term
     enters lambda at the velocity-data snapshots; its explicit theta-dependence is integrated by the
@@ -114,7 +114,9 @@ def test_continuous_adjoint_with_velocity_losses(gpu, kind, component, scale):
     for j in range(len(ts)):
         Vx, Vy, V = O.V_from_H(ref[j], B, 50.0, 50.0, ph, law_t)
         Vref.append((V, Vx, Vy))
-    vspec = O.LossVSpec(component=component, scale_loss=scale)
+    log_eps = 0.1 if component == "log" else None  # LossV(loss = LogSum(), component = :abs), the reference's runtests.jl:165-167
+    component = "abs" if component == "log" else component
+    vspec = O.LossVSpec(component=component, scale_loss=scale, log_eps=log_eps)
     law0 = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th0, T=-3.0)
     Lo, go, lam0, st = O.loss_and_grad_continuous(gl, law0, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=12),
                                                   V_ref=Vref, tV_ref=tV, vspec=vspec, loss_kind=kind, scaling=2.5)
@@ -124,6 +126,7 @@ def test_continuous_adjoint_with_velocity_losses(gpu, kind, component, scale):
     b.set_reference(0, ts, ref, 3)
     b.set_velocity_reference(0, tV, [v[0] for v in Vref], [v[1] for v in Vref], [v[2] for v in Vref])
     b.set_loss({"V": gpu._lib.LOSS_V, "HV": gpu._lib.LOSS_HV}[kind], component, scale, 2.5)
+    b.set_velocity_loss_function(log_eps)
     Lg, gg = b.loss_grad_continuous(ts, theta=th0, reltol=1e-10, n_quadrature=12)
     assert abs(Lg - Lo) <= 1e-6 * abs(Lo), (Lg, Lo)
     ratio, angle, relerr = stats_err_arrays(gg, go)

@@ -95,14 +95,17 @@ def _velocity_case(nx, ny, ph, k=9, step=1.0 / 96.0):
     return H0, B, ts, mlp, th_true, th0, gl, cfg, ref, tV, Vref
 
 
-@pytest.mark.parametrize("kind,component,scale", [("V", "xy", True), ("V", "abs", False), ("HV", "xy", True)])
+@pytest.mark.parametrize("kind,component,scale", [("V", "xy", True), ("V", "abs", False), ("HV", "xy", True),
+                                                  ("V", "log", False), ("HV", "log", True)])
 def test_loss_grad_with_velocity_losses(gpu, kind, component, scale):
     """odinn_loss_grad with LossV / LossHV == the oracle's restatement of gradient.jl:129-275 with
     backward_loss(::LossV) (Losses.jl:338-390) and LossHV (Losses.jl:395-440)."""
     ph = O.Phys()
     nx, ny = 64, 48
     H0, B, ts, mlp, th_true, th0, gl, cfg, ref, tV, Vref = _velocity_case(nx, ny, ph)
-    vspec = O.LossVSpec(component=component, scale_loss=scale)
+    log_eps = 0.1 if component == "log" else None  # LossV(loss = LogSum(), component = :abs) (runtests.jl:165-167)
+    component = "abs" if component == "log" else component
+    vspec = O.LossVSpec(component=component, scale_loss=scale, log_eps=log_eps)
     law0 = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th0, T=-3.0)
     Lo, go, lam0 = O.loss_and_grad_HV(gl, law0, cfg, ref, ts, Vref, tV, vspec, loss_kind=kind, scaling=2.5)
     b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-3.0])
@@ -111,6 +114,7 @@ def test_loss_grad_with_velocity_losses(gpu, kind, component, scale):
     b.set_reference(0, ts, ref, 3)
     b.set_velocity_reference(0, tV, [v[0] for v in Vref], [v[1] for v in Vref], [v[2] for v in Vref])
     b.set_loss({"V": gpu._lib.LOSS_V, "HV": gpu._lib.LOSS_HV}[kind], component, scale, 2.5)
+    b.set_velocity_loss_function(log_eps)
     Lg, gg = b.loss_grad(ts, theta=th0, reltol=1e-10)
     assert abs(Lg - Lo) <= 1e-6 * abs(Lo), (Lg, Lo)
     ratio, angle, relerr = stats_err_arrays(gg, go)
