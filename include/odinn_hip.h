@@ -198,6 +198,10 @@ int odinn_set_loss(odinn_batch* b, int kind, int v_component_abs, int v_scale_lo
 /* the simple loss inside LossV (and LossHV's velocity part): L2Sum (default) or LogSum(eps) = log^2((a + eps) / (b + eps)) /
  * normalization (Losses.jl:34-49,207-229; Morlighem et al. 2010).  LogSum asserts non-negative fields in the reference, i.e.
  * it goes with component :abs; with :xy the gradient entry points fail with ODINN_ERR_ARG. */
+/* target :D (U law): Velocity^ = U / f with f = parameters.simulation.f_surface_velocity_factor (target_D_pure.jl:206-255;
+ * Sleipnir's default is out of tree, the reference's test sets 0.8): the surface-velocity entry points and LossV / LossHV
+ * then differentiate the law by central differences (1e-4 in Hbar, 1e-6 in |grad S|) and backpropagate dU/dtheta per node. */
+int odinn_set_surface_velocity_factor(odinn_batch* b, double f);
 #define ODINN_SIMPLE_L2SUM 0
 #define ODINN_SIMPLE_LOGSUM 1
 int odinn_set_velocity_loss_function(odinn_batch* b, int simple_loss, double eps);

@@ -52,6 +52,8 @@ function Batch(simulation; device = 0)
                         b.h, i - 1, length(tH), tH, Hs, simulation.parameters.UDE.empirical_loss_function.loss.distance))
         end
     end
+    check(ccall((:odinn_set_surface_velocity_factor, lib), Cint, (Ptr{Cvoid}, Cdouble),
+                b.h, simulation.parameters.simulation.f_surface_velocity_factor))   # target :D: Velocityꜛ = U / f
     set_time_aggregated_losses!(b, simulation)
     set_grad_interpolation!(b, simulation)
     finalizer(x -> ccall((:odinn_batch_destroy, lib), Cint, (Ptr{Cvoid},), x.h), b)

@@ -57,6 +57,7 @@ class SimulationParameters:
     multiprocessing: bool = False  # reference: Distributed workers; here: one rank per GPU
     workers: int = 1
     test_mode: bool = False  # light NN (NeuralNetwork.jl:43)
+    f_surface_velocity_factor: float = 1.0  # target :D: Velocityꜛ = U / f (target_D_pure.jl:206-255; 0.8 in test_grad_loss.jl:120)
 
 
 @dataclass
@@ -140,7 +141,7 @@ class LossH:
 
 @dataclass
 class LossV:
-    """src/losses/Losses.jl:66-81,293-390 (target :A)"""
+    """src/losses/Losses.jl:66-81,293-390 (targets :A and :D)"""
 
     loss: object = field(default_factory=L2Sum)  # L2Sum | LogSum
     component: str = "xy"  # :xy | :abs
@@ -998,6 +999,8 @@ class _Simulation:
         else:
             b.set_law(law.kind, law.mlp, self.model.theta[:self.model.n_main], law.n_H, law.n_gradS)
             tg = self.model.target
+            if law.kind == L.LAW_NN_U:
+                b.set_surface_velocity_factor(p.simulation.f_surface_velocity_factor)
             if isinstance(tg, (SIA2D_D_hybrid_target, SIA2D_D_target)):
                 b.set_grad_interpolation(L.GRAD_INTERP_LINEAR if tg.interpolation == "Linear" else L.GRAD_INTERP_NONE,
                                          tg.n_interp_half)

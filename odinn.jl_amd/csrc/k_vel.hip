@@ -3,20 +3,20 @@
 #include "launch.hpp"
 #include "sia2d_velocity.hpp"
 namespace odinn {
-void launch_surface_V(int lm, int nblk, hipStream_t st, Pools P, const double* U, double* Vx, double* Vy, int base) {
-  if (lm == 0) hipLaunchKernelGGL(k_surface_V<0>, dim3(nblk), dim3(NT), 0, st, P, U, Vx, Vy, base);
-  else hipLaunchKernelGGL(k_surface_V<1>, dim3(nblk), dim3(NT), 0, st, P, U, Vx, Vy, base);
+void launch_surface_V(int lm, int nblk, hipStream_t st, Pools P, LawDev L, const double* U, double* Vx, double* Vy, int base,
+                      double finv) {
+  if (lm == 0) hipLaunchKernelGGL(k_surface_V<0>, dim3(nblk), dim3(NT), 0, st, P, L, U, Vx, Vy, base, finv);
+  else if (lm == 1) hipLaunchKernelGGL(k_surface_V<1>, dim3(nblk), dim3(NT), 0, st, P, L, U, Vx, Vy, base, finv);
+  else hipLaunchKernelGGL(k_surface_V<LM_NN>, dim3(nblk), dim3(NT), 0, st, P, L, U, Vx, Vy, base, finv);
 }
-void launch_surfV_vjp(int lm, int mode, int nblk, hipStream_t st, Pools P, const VArgs& A, int base) {
-  if (lm == 0) {
-    if (mode == 0) hipLaunchKernelGGL((k_surfV_vjp<0, 0>), dim3(nblk), dim3(NT), 0, st, P, A, base);
-    else if (mode == 1) hipLaunchKernelGGL((k_surfV_vjp<1, 0>), dim3(nblk), dim3(NT), 0, st, P, A, base);
-    else hipLaunchKernelGGL((k_surfV_vjp<2, 0>), dim3(nblk), dim3(NT), 0, st, P, A, base);
-  } else {
-    if (mode == 0) hipLaunchKernelGGL((k_surfV_vjp<0, 1>), dim3(nblk), dim3(NT), 0, st, P, A, base);
-    else if (mode == 1) hipLaunchKernelGGL((k_surfV_vjp<1, 1>), dim3(nblk), dim3(NT), 0, st, P, A, base);
-    else hipLaunchKernelGGL((k_surfV_vjp<2, 1>), dim3(nblk), dim3(NT), 0, st, P, A, base);
-  }
+// lm >= 2: the U law (target :D) through the run-time MLP evaluation, whatever its architecture
+void launch_surfV_vjp(int lm, int mode, int nblk, hipStream_t st, Pools P, LawDev L, const VArgs& A, int base) {
+#define ODINN_VJP_CASE(M, LMV) hipLaunchKernelGGL((k_surfV_vjp<M, LMV>), dim3(nblk), dim3(NT), 0, st, P, L, A, base)
+  const int l = lm >= 2 ? 2 : lm;
+  if (l == 0) { if (mode == 0) ODINN_VJP_CASE(0, 0); else if (mode == 1) ODINN_VJP_CASE(1, 0); else ODINN_VJP_CASE(2, 0); }
+  else if (l == 1) { if (mode == 0) ODINN_VJP_CASE(0, 1); else if (mode == 1) ODINN_VJP_CASE(1, 1); else ODINN_VJP_CASE(2, 1); }
+  else { if (mode == 0) ODINN_VJP_CASE(0, LM_NN); else if (mode == 1) ODINN_VJP_CASE(1, LM_NN); else ODINN_VJP_CASE(2, LM_NN); }
+#undef ODINN_VJP_CASE
 }
 void launch_avgv_axpy(int nblk, hipStream_t st, Pools P, const double* Vx, const double* Vy, double* ax, double* ay, const double* w) {
   hipLaunchKernelGGL(k_avgv_axpy, dim3(nblk), dim3(NT), 0, st, P, Vx, Vy, ax, ay, w);

@@ -48,10 +48,11 @@ int launch_interp_theta_U(hipStream_t st, const LawDev& L, int n_half, const dou
                           long long nd, double* sA, double* sB, void* tmp, size_t tmp_bytes, double* cell4, double* G, int* err,
                           double* dth, int accumulate);
 
-// k_vel.hip (A-type law modes 0/1 only)
+// k_vel.hip (A-type law modes 0 / 1; lm >= 2: the U law of target :D)
 struct VArgs;
-void launch_surface_V(int lm, int nblk, hipStream_t st, Pools P, const double* U, double* Vx, double* Vy, int base);
-void launch_surfV_vjp(int lm, int mode, int nblk, hipStream_t st, Pools P, const VArgs& A, int base);
+void launch_surface_V(int lm, int nblk, hipStream_t st, Pools P, LawDev L, const double* U, double* Vx, double* Vy, int base,
+                      double finv);
+void launch_surfV_vjp(int lm, int mode, int nblk, hipStream_t st, Pools P, LawDev L, const VArgs& A, int base);
 void launch_avgv_axpy(int nblk, hipStream_t st, Pools P, const double* Vx, const double* Vy, double* ax, double* ay, const double* w);
 void launch_avgv_cot(int nblk, hipStream_t st, Pools P, double* ax, double* ay, const double* Vabs, const double* Vxr,
                      const double* Vyr, const unsigned char* on, int component_abs, double weight);

@@ -205,6 +205,10 @@ struct odinn_batch {
   unsigned char* d_mask = nullptr;
   // surface-velocity data and loss selection
   std::vector<std::vector<double>> t_vref;                // per glacier
+  // f_surface_velocity_factor of the simulation parameters (target :D: Velocity^ = U / f, target_D_pure.jl:206-255)
+  double fV = 1.0;
+  bool vel_law_ok() const { return law_kind < ODINN_LAW_NN_Y || law_kind == ODINN_LAW_NN_U; }
+  bool vel_nn() const { return law_kind == ODINN_LAW_NN_U; }
   // LossV's simple loss: 0 = L2Sum, > 0 = LogSum(eps) (component :abs only; Losses.jl:34-49,207-229)
   double v_log_eps = 0.0;
   std::vector<std::vector<std::vector<double>>> v_edge;  // per glacier per slot: V_ref > 0 on the last row / column
@@ -736,7 +740,7 @@ int launch_lossV(odinn_batch* b, int j, const double* Hj, double* out, bool with
     }
   }
   if (!any) return ODINN_OK;
-  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "LossV needs an A-type law (target :A)");
+  if (!b->vel_law_ok()) return fail(ODINN_ERR_STATE, "LossV needs an A-type law (target :A) or the U law (target :D)");
   if (b->v_log_eps > 0.0 && !b->v_abs)
     return fail(ODINN_ERR_ARG, "LogSum needs non-negative fields (Losses.jl:214): use it with component :abs");
   VArgs A{};
@@ -744,10 +748,16 @@ int launch_lossV(odinn_batch* b, int j, const double* Hj, double* out, bool with
   A.wv = b->d_wv + (size_t)j * b->G; A.scale = b->d_vsc + (size_t)j * b->G; A.refslot = b->d_vslot + (size_t)j * b->G;
   A.ntot = b->ntot; A.component_abs = b->v_abs; A.log_eps = b->v_abs ? b->v_log_eps : 0.0;
   A.Gacc = (with_grad && b->wants_Gacc()) ? b->d_Gacc : nullptr;
+  A.finv = 1.0 / b->fV;
+  if (with_grad && b->vel_nn()) {  // U law: per-node backprop of dU/dtheta, reduced into d_dth like the theta-VJP of the RHS
+    CHK(ensure_theta_scratch(b, b->ntiles));
+    A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
+  }
   const Pools P = b->pools(true);
-  launch_surfV_vjp(b->lm(), 1, b->ntiles, b->stream, P, A, 0);
+  launch_surfV_vjp(b->lm(), 1, b->ntiles, b->stream, P, b->lawdev(), A, 0);
   launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
-  if (with_grad) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
+  if (with_grad && b->vel_nn()) launch_sum_part_theta(b->P, b->G, b->stream, P, b->d_part_theta, b->d_dth, 1, 0);
+  else if (with_grad) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -1052,7 +1062,7 @@ int avgv_forward(odinn_batch* b, bool with_grad) {
   const Pools P = b->pools(true);
   for (int j = 0; j < k; ++j) {
     if (!stop_on(j)) continue;
-    launch_surface_V(b->lm(), b->ntiles, b->stream, P, b->d_snaps + (size_t)j * b->ntot, vx, vy, 0);
+    launch_surface_V(b->lm(), b->ntiles, b->stream, P, b->lawdev(), b->d_snaps + (size_t)j * b->ntot, vx, vy, 0, 1.0);
     launch_avgv_axpy(b->ntiles, b->stream, P, vx, vy, ax, ay, b->d_wA + (size_t)j * G);
   }
   launch_avgv_cot(b->ntiles, b->stream, P, ax, ay, b->d_aVabs, b->d_aVx, b->d_aVy, b->d_av_on, b->avgv_abs, b->avgv_weight);
@@ -1064,7 +1074,7 @@ int avgv_forward(odinn_batch* b, bool with_grad) {
       A.H = b->d_snaps + (size_t)j * b->ntot; A.dVx = ax; A.dVy = ay; A.out = b->d_aggH + (size_t)b->agg_slot_h[j] * b->ntot;
       A.wv = b->d_wA + (size_t)j * G; A.ntot = b->ntot;
       A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
-      launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, A, 0);
+      launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, b->lawdev(), A, 0);
       launch_sum_part(G, b->stream, P, 3, b->d_Gsum, 1, 0);
     }
   }
@@ -1078,7 +1088,7 @@ int avgv_forward(odinn_batch* b, bool with_grad) {
 static int vreg_at(odinn_batch* b, const double* H, const double* w, bool add_loss, double* outH, bool theta) {
   const Pools P = b->pools(true);
   double *vx = b->d_avg, *vy = b->d_avg + b->ntot, *va = b->d_avg + 2 * b->ntot, *r = b->d_avg + 3 * b->ntot;
-  launch_surface_V(b->lm(), b->ntiles, b->stream, P, H, vx, vy, 0);
+  launch_surface_V(b->lm(), b->ntiles, b->stream, P, b->lawdev(), H, vx, vy, 0, 1.0);
   launch_vreg_prep(b->ntiles, b->stream, P, H, vx, vy, w, b->vreg_dist, va, b->d_vrm);
   launch_vreg_lap(b->ntiles, b->stream, P, va, b->d_vrm, w, r);
   if (add_loss) launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
@@ -1088,7 +1098,7 @@ static int vreg_at(odinn_batch* b, const double* H, const double* w, bool add_lo
     A.H = H; A.dVx = vx; A.dVy = vy; A.out = outH ? outH : r;  // (r is dead by now: a sink for the unused H-part)
     A.wv = w; A.ntot = b->ntot;
     A.Gacc = (theta && b->wants_Gacc()) ? b->d_Gacc : nullptr;
-    launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, A, 0);
+    launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, b->lawdev(), A, 0);
     if (theta) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
   }
   HIPCHK(hipGetLastError());
@@ -1713,6 +1723,12 @@ int odinn_set_vjp_method(odinn_batch* b, int method) {
   return ODINN_OK;
 }
 
+int odinn_set_surface_velocity_factor(odinn_batch* b, double f) {
+  if (!b || !(f > 0.0)) return fail(ODINN_ERR_ARG, "f_surface_velocity_factor must be positive");
+  b->fV = f;
+  return ODINN_OK;
+}
+
 int odinn_set_velocity_loss_function(odinn_batch* b, int simple_loss, double eps) {
   if (b) b->refs_version++;
   if (!b || (simple_loss != ODINN_SIMPLE_L2SUM && simple_loss != ODINN_SIMPLE_LOGSUM)) return fail(ODINN_ERR_ARG, "unknown simple loss");
@@ -1829,9 +1845,9 @@ int odinn_surface_V(odinn_batch* b, int g, const double* H, double* Vx, double* 
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!H || !Vx || !Vy) return fail(ODINN_ERR_ARG, "null field");
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
-  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "surface velocity needs an A-type law (target :A)");
+  if (!b->vel_law_ok()) return fail(ODINN_ERR_STATE, "surface velocity needs an A-type law (target :A) or the U law (target :D)");
   CHK(up_field(b, g, b->d_tmpA, H));
-  launch_surface_V(b->lm(), b->gd[g].ntiles, b->stream, b->pools(false), b->d_tmpA, b->d_tmpB, b->d_lam[1], b->gd[g].tile0);
+  launch_surface_V(b->lm(), b->gd[g].ntiles, b->stream, b->pools(false), b->lawdev(), b->d_tmpA, b->d_tmpB, b->d_lam[1], b->gd[g].tile0, 1.0 / b->fV);
   HIPCHK(hipGetLastError());
   CHK(down_field(b, g, b->d_tmpB, Vx));
   return down_field(b, g, b->d_lam[1], Vy);
@@ -1841,7 +1857,7 @@ static int surfV_vjp_common(odinn_batch* b, int g, const double* dVx, const doub
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!H || !dVx || !dVy) return fail(ODINN_ERR_ARG, "null field");
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
-  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "surface velocity needs an A-type law (target :A)");
+  if (!b->vel_law_ok()) return fail(ODINN_ERR_STATE, "surface velocity needs an A-type law (target :A) or the U law (target :D)");
   CHK(up_field(b, g, b->d_tmpA, H));
   CHK(up_field(b, g, b->d_lam[0], dVx));
   CHK(up_field(b, g, b->d_lam[1], dVy));
@@ -1851,9 +1867,15 @@ static int surfV_vjp_common(odinn_batch* b, int g, const double* dVx, const doub
   VArgs A{};
   A.H = b->d_tmpA; A.dVx = b->d_lam[0]; A.dVy = b->d_lam[1]; A.out = b->d_tmpB;
   A.Gacc = b->law_kind == ODINN_LAW_NN_A_GRIDDED ? b->d_Gacc : nullptr;
+  A.finv = 1.0 / b->fV;
+  if (b->vel_nn()) {
+    CHK(ensure_theta_scratch(b, r.ntiles));
+    A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
+  }
   const Pools P = b->pools(false);
-  launch_surfV_vjp(b->lm(), 0, r.ntiles, b->stream, P, A, r.tile0);
-  launch_sum_part(1, b->stream, P, 3, b->d_Gsum, 0, g);
+  launch_surfV_vjp(b->lm(), 0, r.ntiles, b->stream, P, b->lawdev(), A, r.tile0);
+  if (b->vel_nn()) launch_sum_part_theta(b->P, 1, b->stream, P, b->d_part_theta, b->d_dth, 0, g);
+  else launch_sum_part(1, b->stream, P, 3, b->d_Gsum, 0, g);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -1873,6 +1895,11 @@ int odinn_surface_V_vjp_theta(odinn_batch* b, int g, const double* dVx, const do
   CHK(surfV_vjp_common(b, g, dVx, dVy, H));
   const GDev& r = b->gd[g];
   if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) return gridded_law_grad(b, r.offd, (long long)(r.nx - 1) * (r.ny - 1), dtheta);
+  if (b->vel_nn()) {
+    HIPCHK(hipMemcpyAsync(dtheta, b->d_dth + (size_t)g * b->P, sizeof(double) * b->P, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return ODINN_OK;
+  }
   double Gs = 0.0;
   HIPCHK(hipMemcpyAsync(&Gs, b->d_Gsum + g, sizeof(double), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -2139,7 +2166,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
                                double* loss, double* dtheta, odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
   if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
   const bool useV = b->loss_kind != ODINN_LOSS_H;
-  if (useV && b->law_kind >= ODINN_LAW_NN_Y) return fail(ODINN_ERR_STATE, "LossV needs an A-type law (target :A)");
+  if (useV && !b->vel_law_ok()) return fail(ODINN_ERR_STATE, "LossV needs an A-type law (target :A) or the U law (target :D)");
   odinn_adjoint_opts ao{1e-8, 1e-8, 1.0 / 12.0, 200, 0, 1000000};  // AdjointTypes.jl:58-67
   if (aopts) ao = *aopts;
   if (ao.reltol <= 0) ao.reltol = 1e-8;
@@ -2246,8 +2273,9 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   if (useV) {
     VS.Vabs = b->d_Vabs; VS.Vxr = b->d_Vxr; VS.Vyr = b->d_Vyr; VS.wv = b->d_wv; VS.scale = b->d_vsc; VS.refslot = b->d_vslot;
     VS.ntot = b->ntot; VS.component_abs = b->v_abs; VS.log_eps = b->v_abs ? b->v_log_eps : 0.0; VS.Gacc = nullptr; VS.adj = b->d_adj; VS.G = G;
+    VS.finv = 1.0 / b->fV;  // (U law: H-part only here, the theta-part of the loss is integrated at the quadrature nodes)
     VS.H = b->d_snaps + (size_t)(k - 1) * b->ntot; VS.out = b->d_lam[0];
-    launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, VS, 0);  // at t1 the losses come before the MB VJP
+    launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VS, 0);  // at t1 the losses come before the MB VJP
     VS.H = b->d_tmpA;
   }
   launch_adj_poststep(b->ntiles, b->stream, Pl, AP, b->d_lam[0], b->d_lam[1]);
@@ -2261,6 +2289,11 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     VQ.H = b->d_tmpA; VQ.out = b->d_tmpB; VQ.Vabs = b->d_Vq; VQ.Vxr = b->d_Vq + b->ntot; VQ.Vyr = b->d_Vq + 2 * b->ntot;
     VQ.wv = b->d_wvq; VQ.scale = b->d_vscq; VQ.refslot = b->d_zeroslot; VQ.ntot = b->ntot; VQ.component_abs = b->v_abs; VQ.log_eps = b->v_abs ? b->v_log_eps : 0.0;
     VQ.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
+    VQ.finv = 1.0 / b->fV;
+    if (b->vel_nn()) {
+      CHK(ensure_theta_scratch(b, b->ntiles));
+      VQ.gscratch = b->d_gscratch; VQ.part_theta = b->d_part_theta;
+    }
     HIPCHK(hipMemsetAsync(b->d_tmpB, 0, (size_t)b->ntot * sizeof(double), b->stream));
   }
   const double wq = b->loss_kind == ODINN_LOSS_HV ? b->hv_scaling : 1.0;
@@ -2349,11 +2382,12 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       if (useV) {
         if (fused_rev) { VS.out = b->d_lam[0]; VS.out_alt = b->d_lam[1]; }  // per-glacier ping-pong buffers
         else VS.out = a1;
-        launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, VS, 0);                       // snapshot stops
+        launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VS, 0);                       // snapshot stops
         launch_vref_itp(b->ntiles, b->stream, Pl, VI);                                  // quadrature nodes
         launch_vref_scale(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_vscq, b->d_wvq);
-        launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, VQ, 0);
-        launch_sum_part(G, b->stream, Pl, 3, b->d_Gsum, 1, 0);
+        launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VQ, 0);
+        if (b->vel_nn()) launch_sum_part_theta(b->P, G, b->stream, Pl, b->d_part_theta, b->d_dth, 1, 0);
+        else launch_sum_part(G, b->stream, Pl, 3, b->d_Gsum, 1, 0);
       }
       // quadrature node reached: dtheta += w * J_theta(H_itp(t))^T lam(t)  (:497-503); A-type laws add
       // onto per-tile running sums that are reduced once after the solve

@@ -1,4 +1,6 @@
-// sia2d_velocity.hpp -- surface-velocity path for A-type laws:
+// sia2d_velocity.hpp -- surface-velocity path for the A-type laws (target :A, law modes 0 / 1) and the
+// U law (target :D, law mode LM_NN: Velocity^ = U / f with central finite differences for its partials and per-node
+// backprop for d/dtheta, target_D_pure.jl:206-255):
 //   k_surface_V   : (Vx, Vy) = -Velocity^(Hbar, |grad S|) * grad S on the dual grid, stored in
 //                   nx*ny arrays with the reference's inn1 pairing (last row / column 0)
 //                   [Huginn.surface_V / V_from_H, restated from adjoint.jl:268-350]
@@ -42,9 +44,18 @@ __device__ __forceinline__ double node_Vup(const GDev& g, double Hb, double gS2,
   return D;
 }
 
+// target :D (target_D_pure.jl:206-255): Velocity^ = U / f, dVelocity^/dH and /d|grad S| by central differences of the law
+// with steps 1e-4 and 1e-6 (the latter NOT divided by |grad S|, as the reference returns it)
+__device__ __forceinline__ double node_Vup_U(const LawDev& L, double Hb, double gS, double finv, double& alpha, double& beta) {
+  const double dH = 1e-4, dS = 1e-6;
+  alpha = finv * ((mlp_eval_any(L, Hb + dH, gS) - mlp_eval_any(L, Hb - dH, gS)) / (2.0 * dH));
+  beta = finv * ((mlp_eval_any(L, Hb, gS + dS) - mlp_eval_any(L, Hb, gS - dS)) / (2.0 * dS));
+  return mlp_eval_any(L, Hb, gS) * finv;
+}
+
 template <int LM>
-__global__ __launch_bounds__(NT) void k_surface_V(Pools P, const double* __restrict__ U, double* __restrict__ Vx,
-                                                  double* __restrict__ Vy, int tile_base) {
+__global__ __launch_bounds__(NT) void k_surface_V(Pools P, LawDev L, const double* __restrict__ U, double* __restrict__ Vx,
+                                                  double* __restrict__ Vy, int tile_base, double finv) {
   __shared__ double2 sHS[TY + 2][LDW];
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const GDev g = P.gd[t4.x];
@@ -62,10 +73,15 @@ __global__ __launch_bounds__(NT) void k_surface_V(Pools P, const double* __restr
       if (gi <= g.nx - 2 && gj <= g.ny - 2) {  // node whose lower-left cell is (gi, gj)
         double gx, gy, Hb;
         node_geom<LDW>(g, &sHS[r][tx + 1], gx, gy, Hb);
-        double An = g.A;
-        if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
-        double al, be, sp;
-        const double D = node_Vup<LM>(g, Hb, gx * gx + gy * gy, An, al, be, sp);
+        double D;
+        if constexpr (LM == LM_NN) {
+          D = mlp_eval_any(L, Hb, sqrt(gx * gx + gy * gy)) * finv;
+        } else {
+          double An = g.A;
+          if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+          double al, be, sp;
+          D = node_Vup<LM>(g, Hb, gx * gx + gy * gy, An, al, be, sp);
+        }
         vx = -D * gx;
         vy = -D * gy;
       }
@@ -98,10 +114,15 @@ struct VArgs {
   // the row is the snapshot the glacier's reverse solve just reached (nothing to do otherwise)
   const AdjState* adj;
   int G;
+  // U law (target :D): 1 / f_surface_velocity_factor, and the thread-private scratch / per-tile rows of the per-node
+  // backprop of dU/dtheta (null: the theta-part is not wanted)
+  double finv;
+  double* gscratch;
+  double* part_theta;
 };
 
 template <int MODE, int LM>
-__global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_base) {
+__global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, int tile_base) {
   __shared__ double2 sHS[TY + 2][LDW];
   __shared__ double2 sQ[TY + 1][LDN];   // {Qx, Qy}
   __shared__ double sAW[TY + 1][LDN];   // alpha * W
@@ -116,6 +137,8 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
     wv = (P.gs[t4.x].at_stop && j >= 0) ? A.wv[q] : 0.0;
     if (wv == 0.0) {
       if (threadIdx.x == 0) { P.part[4 * (long long)t4.w + 3] = 0.0; P.part[4 * (long long)t4.w + 1] = 0.0; }
+      if (LM == LM_NN && A.part_theta)
+        for (int k = threadIdx.x; k < L.P; k += NT) A.part_theta[(long long)t4.w * L.P + k] = 0.0;
       return;
     }
     sc = A.scale[q];
@@ -124,6 +147,8 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
     wv = A.wv[t4.x];
     if (wv == 0.0) {  // no velocity data at this stop for this glacier
       if (threadIdx.x == 0) { P.part[4 * (long long)t4.w + 3] = 0.0; if (MODE == 1) P.part[4 * (long long)t4.w + 1] = 0.0; }
+      if (LM == LM_NN && A.part_theta)
+        for (int k = threadIdx.x; k < L.P; k += NT) A.part_theta[(long long)t4.w * L.P + k] = 0.0;
       return;
     }
     if (MODE == 1) {
@@ -138,6 +163,10 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
   __syncthreads();
   const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
   double gsum = 0.0, lsum = 0.0;
+  const long long gstride = (long long)gridDim.x * NT;
+  double* gth = (LM == LM_NN && A.gscratch) ? A.gscratch + ((long long)blockIdx.x * NT + threadIdx.x) : nullptr;
+  if (gth)
+    for (int k = 0; k < L.P; ++k) gth[(long long)k * gstride] = 0.0;
   for (int idx = threadIdx.x; idx < NNODE; idx += NT) {
     const int b = idx / (TX + 1), a = idx - b * (TX + 1);
     const int gi = i0 - 1 + a, gj = j0 - 1 + b;
@@ -145,10 +174,16 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
     if (gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
       double gx, gy, Hb;
       node_geom<LDW>(g, &sHS[b][a], gx, gy, Hb);
-      double An = g.A;
-      if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
-      double al, be, sp;
-      const double D = node_Vup<LM>(g, Hb, gx * gx + gy * gy, An, al, be, sp);
+      double al, be, sp = 0.0, D;
+      [[maybe_unused]] double gS = 0.0;
+      if constexpr (LM == LM_NN) {
+        gS = sqrt(gx * gx + gy * gy);
+        D = node_Vup_U(L, Hb, gS, A.finv, al, be);
+      } else {
+        double An = g.A;
+        if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+        D = node_Vup<LM>(g, Hb, gx * gx + gy * gy, An, al, be, sp);
+      }
       const long long id = g.off + gi + (long long)g.nx * gj;  // inn1 pairing: node (gi,gj) <-> element [gi,gj]
       const bool owned = (a >= 1 && b >= 1);  // lower-left cell inside the tile interior: reduced here
       double dvx, dvy;
@@ -183,9 +218,13 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
       Qx = fma(be * gx, W, D * dvx);
       Qy = fma(be * gy, W, D * dvy);
       if (owned) {
-        const double t = sp * W;
-        gsum += t;
-        if (A.Gacc) A.Gacc[g.offd + gi + (long long)(g.nx - 1) * gj] -= wv * t;
+        if constexpr (LM == LM_NN) {  // dVelocity^/dtheta = (Hbar > 0) dU/dtheta / f, exact backprop per node (:None branch)
+          if (gth && Hb > 0.0) mlp_grad(L, Hb, gS, -wv * W * A.finv, gth, gstride);
+        } else {
+          const double t = sp * W;
+          gsum += t;
+          if (A.Gacc) A.Gacc[g.offd + gi + (long long)(g.nx - 1) * gj] -= wv * t;
+        }
       }
     }
     sAW[b][a] = aW;
@@ -212,6 +251,12 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, VArgs A, int tile_bas
   if (threadIdx.x == 0) {
     P.part[4 * (long long)t4.w + 3] = -wv * gt;             // enters dtheta as (dA/dtheta) * sum
     if (MODE == 1) P.part[4 * (long long)t4.w + 1] = lt * Ninv * sc * wv;
+  }
+  if (gth && A.part_theta) {
+    for (int k = 0; k < L.P; ++k) {
+      const double tot = block_sum(gth[(long long)k * gstride], red);
+      if (threadIdx.x == 0) A.part_theta[(long long)t4.w * L.P + k] = tot;
+    }
   }
 }
 

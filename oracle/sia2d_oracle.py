@@ -369,6 +369,9 @@ class Law:
     # law (:D_hybrid), :None for every other law.
     interpolation: Optional[str] = None
     n_interp_half: Optional[int] = None
+    # parameters.simulation.f_surface_velocity_factor (target :D: Velocity^ = U / f, target_D_pure.jl:206-255); kept with the
+    # law here because only the U law reads it
+    fV: float = 1.0
 
     def interp(self):
         kind = self.interpolation if self.interpolation is not None else ("linear" if self.kind == LAW_NN_Y else "none")
@@ -1609,7 +1612,9 @@ def _A_dual(law: Law, ph: Phys, theta=None):
 
 
 def velocity_up(law: Law, ph: Phys, Hbar, gradS, theta=None):
-    """Velocity^ (target_A.jl:94-108), sliding term exactly as written there."""
+    """Velocity^ (target_A.jl:94-108), sliding term exactly as written there; target :D: U / f (target_D_pure.jl:206-217)."""
+    if law.kind == LAW_NN_U:
+        return law_value(law, ph, Hbar, gradS, theta) / law.fV
     A = _A_dual(law, ph, theta)
     D = A * gamma_up_no_A(ph) * _pow(Hbar, ph.n + 1.0) * _pow(gradS, ph.n - 1.0)
     Sc = sliding_S(ph)
@@ -1619,7 +1624,10 @@ def velocity_up(law: Law, ph: Phys, Hbar, gradS, theta=None):
 
 
 def d_velocity_up_dH(law: Law, ph: Phys, Hbar, gradS, theta=None):
-    """dVelocity^/dH (target_A.jl:110-125)."""
+    """dVelocity^/dH (target_A.jl:110-125); target :D: central difference of U with step 1e-4 (target_D_pure.jl:219-231)."""
+    if law.kind == LAW_NN_U:
+        d = 1e-4
+        return (1.0 / law.fV) * (law_value(law, ph, Hbar + d, gradS, theta) - law_value(law, ph, Hbar - d, gradS, theta)) / (2.0 * d)
     A = _A_dual(law, ph, theta)
     out = A * gamma_up_no_A(ph) * (ph.n + 1.0) * _pow(Hbar, ph.n) * _pow(gradS, ph.n - 1.0)
     Sc = sliding_S(ph)
@@ -1629,7 +1637,11 @@ def d_velocity_up_dH(law: Law, ph: Phys, Hbar, gradS, theta=None):
 
 
 def d_velocity_up_dgradS(law: Law, ph: Phys, Hbar, gradS, theta=None):
-    """dVelocity^/dgradH (target_A.jl:127-142)."""
+    """dVelocity^/dgradH (target_A.jl:127-142); target :D: central difference with step 1e-6, not divided by |grad S|
+    (target_D_pure.jl:233-245)."""
+    if law.kind == LAW_NN_U:
+        d = 1e-6
+        return (1.0 / law.fV) * (law_value(law, ph, Hbar, gradS + d, theta) - law_value(law, ph, Hbar, gradS - d, theta)) / (2.0 * d)
     A = _A_dual(law, ph, theta)
     out = A * gamma_up_no_A(ph) * (ph.n - 1.0) * _pow(Hbar, ph.n + 1.0) * _pow(gradS, ph.n - 3.0)
     Sc = sliding_S(ph)
@@ -1673,6 +1685,8 @@ def vjp_surface_V_theta(dVx, dVy, H, B, dx, dy, ph: Phys, law: Law, theta=None):
     """VJP_lambda_dsurface_V/dtheta_discrete (adjoint.jl:352-413)."""
     Hc, S, gSx, gSy, gS, Hbar, *_ = _forward_intermediates(H, B, dx, dy, ph)
     gSdV = gSx * inn1(dVx) + gSy * inn1(dVy)
+    if law.kind == LAW_NN_U:  # dVelocity^/dtheta = dU/dtheta / f with dU/dtheta = (Hbar > 0) x backprop (target_D_pure.jl:139-176,247-255)
+        return -np.tensordot(law_grad_theta(law, ph, Hbar, gS, theta), (Hbar > 0.0) * gSdV / law.fV, axes=([1, 2], [0, 1]))
     spatial = gamma_up_no_A(ph) * _pow(Hbar, ph.n + 1.0) * _pow(gS, ph.n - 1.0) * gSdV
     if law.kind == LAW_CONST_A:
         return -np.array([np.sum(spatial)])

@@ -136,3 +136,88 @@ def test_loss_grad_with_velocity_losses(gpu, kind, component, scale):
     ratio, angle, relerr = stats_err_arrays(gg[idx], gn[idx])
     assert abs(ratio) < 1e-2 and abs(angle) < 1e-7 and relerr < 1e-2, (ratio, angle, relerr)
     b.close()
+
+
+def _u_law(gpu, ph, arch="default"):
+    from test_gpu_parity import _mlp_pair
+    widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "custom": ([2, 5, 10, 5, 1], [3, 3, 3, 1])}[arch]
+    om, gm, th = _mlp_pair(gpu, widths, acts, [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+    return om, gm, th
+
+
+@pytest.mark.parametrize("arch", ["default", "custom"])
+def test_surface_V_with_the_U_law_target_D(gpu, arch):
+    """Target :D (target_D_pure.jl:206-255): Velocity^ = U / f, its partials by central differences of the law (1e-4 in Hbar,
+    1e-6 in |grad S|), dVelocity^/dtheta by per-node backprop; surface_V and both VJPs against the oracle (the H-VJP to the
+    agreement of two finite-difference evaluations in different summation orders)."""
+    ph = O.Phys()
+    om, gm, th = _u_law(gpu, ph, arch)
+    law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, fV=0.8)  # f_surface_velocity_factor of the reference's test (test_grad_loss.jl:120)
+    nx, ny = 70, 53
+    H0, B = O.synthetic_alpine(nx, ny)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_U, gm, th)
+    b.set_surface_velocity_factor(0.8)
+    vx, vy = O.surface_V(H0, B, 50.0, 50.0, ph, law)
+    Vx, Vy = b.surface_V(0, H0)
+    assert rel_l2(Vx[:-1, :-1], vx) < 1e-12 and rel_l2(Vy[:-1, :-1], vy) < 1e-12
+    rng = np.random.default_rng(7)
+    w1, w2 = rng.standard_normal((nx, ny)), rng.standard_normal((nx, ny))
+    assert rel_l2(b.surface_V_vjp_H(0, w1, w2, H0), O.vjp_surface_V_H(w1, w2, H0, B, 50.0, 50.0, ph, law)) < 1e-6
+    assert rel_l2(b.surface_V_vjp_theta(0, w1, w2, H0), O.vjp_surface_V_theta(w1, w2, H0, B, 50.0, 50.0, ph, law)) < 1e-10
+    b.close()
+
+
+@pytest.mark.parametrize("adjoint", ["discrete", "continuous"])
+def test_lossV_with_the_U_law_target_D(gpu, adjoint):
+    """LossV with target :D -- the reference's 'continuous adjoint with discrete VJP (loss V)', runtests.jl:192-194 and
+    :201-203 (custom NN) -- through both adjoints against the oracle, two glaciers with different velocity dates."""
+    ph = O.Phys()
+    om, gm, th = _u_law(gpu, ph)
+    law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, fV=0.8)
+    step = 1.0 / 96.0
+    ts = [2010.0 + j * step for j in range(7)]
+    shapes = [(56, 40), (64, 48)]
+    b = gpu.GlacierBatch(shapes, [50.0] * 2)
+    vspec = O.LossVSpec(component="xy", scale_loss=True)
+    Lo, go = 0.0, 0.0
+    for k, (nx, ny) in enumerate(shapes):
+        H0, B = O.synthetic_alpine(nx, ny, hmax=150.0, slope=0.1)
+        gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+        cfg = O.SimConfig(tstops=ts, reltol=1e-10)
+        ref, _, _ = O.forward(gl, law, cfg)
+        tV = ts if adjoint == "continuous" else ts[1 + k::2]  # the continuous adjoint interpolates the maps over tspan
+        Vref = []
+        for t in tV:
+            Vx, Vy, V = O.V_from_H(ref[ts.index(t)], B, 50.0, 50.0, ph, law)
+            Vref.append((1.1 * V, 1.1 * Vx, 1.1 * Vy))
+        b.set_fields(k, H0, B)
+        b.set_reference(k, ts, ref, 3)
+        b.set_velocity_reference(k, tV, [v[0] for v in Vref], [v[1] for v in Vref], [v[2] for v in Vref])
+        if adjoint == "discrete":
+            l, g, _ = O.loss_and_grad_HV(gl, law, cfg, ref, ts, Vref, tV, vspec, loss_kind="V")
+        else:
+            l, g, _, _ = O.loss_and_grad_continuous(gl, law, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=8),
+                                                    V_ref=Vref, tV_ref=tV, vspec=vspec, loss_kind="V")
+        Lo, go = Lo + l, go + g
+    b.set_law(gpu.LAW_NN_U, gm, th)
+    b.set_surface_velocity_factor(0.8)
+    b.set_loss(gpu._lib.LOSS_V, "xy", True, 1.0)
+    if adjoint == "discrete":
+        Lg, gg = b.loss_grad(ts, theta=th, reltol=1e-10)
+    else:
+        Lg, gg = b.loss_grad_continuous(ts, theta=th, reltol=1e-10, n_quadrature=8)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo), (Lg, Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-8 and relerr < 1e-5, (ratio, angle, relerr)
+    b.close()
+    # the Y law (target :D_hybrid) has no surface-velocity path here
+    b = gpu.GlacierBatch([shapes[0]], [50.0], T=[-5.0])
+    from test_gpu_parity import _mlp_pair
+    om2, gm2, th2 = _mlp_pair(gpu, [2, 3, 1], [1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+    b.set_fields(0, *O.synthetic_alpine(*shapes[0]))
+    b.set_law(gpu.LAW_NN_Y, gm2, th2)
+    with pytest.raises(gpu.OdinnError, match="target :D"):
+        b.surface_V(0, O.synthetic_alpine(*shapes[0])[0])
+    b.close()
