@@ -126,7 +126,7 @@ typedef struct odinn_solve_stats {
 
 /* H-VJP stencil used by odinn_sia2d_vjp_H and inside both adjoints (VJPTypes.jl:29-50):
  * DiscreteVJP = exact transpose of the discretised RHS (adjoint.jl:31-151);
- * ContinuousVJP = discretisation of the continuous adjoint operator (adjoint.jl:442-553; target :A only).
+ * ContinuousVJP = discretisation of the continuous adjoint operator (adjoint.jl:442-553; all targets).
  * VJP_lambda_dSIA/dtheta_continuous (adjoint.jl:583-662) is the forward form of the same bilinear
  * expression as the discrete theta-VJP, so odinn_sia2d_vjp_theta serves both methods. */
 #define ODINN_SCHEME_EULER_CFL 3

@@ -7,15 +7,13 @@
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 namespace odinn {
-// vj: 0 = DiscreteVJP stencil, 1 = ContinuousVJP stencil (closed-form A laws only; the host checks)
+// vj: 0 = DiscreteVJP stencil, 1 = ContinuousVJP stencil
 void CAT(launch_vjp_H_lm, ODINN_LM)(int mode, int vj, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base) {
-#if ODINN_LM <= 1
   if (vj) {
     if (mode == 0) hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM, 1>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
     else hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM, 1>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
     return;
   }
-#endif
   if (mode == 0) hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
   else hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
 }
@@ -30,9 +28,7 @@ static void adj_stage_dispatch(int stage, int nblk, hipStream_t st, Pools P, Law
   }
 }
 void CAT(launch_adj_stage_lm, ODINN_LM)(int stage, int vj, int nblk, hipStream_t st, Pools P, LawDev L, AdjStageArgs A) {
-#if ODINN_LM <= 1
   if (vj) { adj_stage_dispatch<1>(stage, nblk, st, P, L, A); return; }
-#endif
   adj_stage_dispatch<0>(stage, nblk, st, P, L, A);
 }
 void CAT(launch_vjp_theta_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base) {

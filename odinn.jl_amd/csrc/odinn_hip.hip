@@ -1556,8 +1556,6 @@ int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H,
   (void)t;
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!H || !lam || !dlam) return fail(ODINN_ERR_ARG, "null field");
-  if (b->vjp_method == 1 && b->law_kind >= ODINN_LAW_NN_Y)
-    return fail(ODINN_ERR_UNSUPPORTED, "ContinuousVJP is provided for target :A (A-type laws) only");
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
   CHK(up_field(b, g, b->d_tmpA, H));
   CHK(up_field(b, g, b->d_lam[0], lam));
@@ -2003,8 +2001,6 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
   if (b->loss_kind != ODINN_LOSS_V && !b->d_Href && !b->dhdt_on() && !b->avgv_on() && !b->vreg_on()) return fail(ODINN_ERR_STATE, "no reference thickness data set");
   if (b->loss_kind != ODINN_LOSS_H && !b->d_Vabs) return fail(ODINN_ERR_STATE, "no reference velocity data set");
-  if (b->vjp_method == 1 && b->law_kind >= ODINN_LAW_NN_Y)
-    return fail(ODINN_ERR_UNSUPPORTED, "ContinuousVJP is provided for target :A (A-type laws) only");
   CHK(do_solve(b, n_stops, tstops, n_mb, mb_times, opts, stats));
   const size_t fb = (size_t)b->ntot * sizeof(double);
   HIPCHK(hipMemsetAsync(b->d_lam[0], 0, fb, b->stream));  // lambda_k = 0   (gradient.jl:140)

@@ -1334,7 +1334,7 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
 // contributions.  The closed-form laws reuse the same 35 KB for both (4 blocks / CU); the MLP laws
 // (LM >= 2) are VALU-bound: they keep both side by side (2 blocks / CU) and a rolled node loop, so
 // the inlined network is instantiated once.
-// VJ: 0 = DiscreteVJP (adjoint.jl:31-151), 1 = ContinuousVJP (adjoint.jl:442-553; A-type laws only),
+// VJ: 0 = DiscreteVJP (adjoint.jl:31-151), 1 = ContinuousVJP (adjoint.jl:442-553),
 // which needs a third double2 per node ({alpha/4, q/4}).
 template <int LM, int VJ = 0>
 struct VjpHLds {
@@ -1401,23 +1401,36 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
   const int ea = ty == 0 ? tx : TX, eb = ty == 0 ? TY : tx;
   const bool extra = ty == 0 || (ty == 1 && tx <= TY);
   if constexpr (VJ == 1) {
-    static_assert(S::ALIAS, "the continuous-form VJP is provided for the closed-form A laws");
     double2(*sCc)[LDN] = reinterpret_cast<double2(*)[LDN]>(cbase + 2 * (TY + 1) * LDN);  // {alpha/4, q/4}
-    double kk[RPT + 1][4], aa[RPT + 1], qq[RPT + 1];
+    if constexpr (S::ALIAS) {  // closed-form A laws: the node results are staged in registers, their LDS aliases the tiles
+      double kk[RPT + 1][4], aa[RPT + 1], qq[RPT + 1];
 #pragma unroll
-    for (int m = 0; m < RPT; ++m) vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m], aa[m], qq[m]);
-    if (extra) vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT], aa[RPT], qq[RPT]);
-    __syncthreads();
+      for (int m = 0; m < RPT; ++m) vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m], aa[m], qq[m]);
+      if (extra) vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT], aa[RPT], qq[RPT]);
+      __syncthreads();
 #pragma unroll
-    for (int m = 0; m < RPT; ++m) {
-      sCa[ty + NW * m][tx] = make_double2(kk[m][0], kk[m][1]);
-      sCb[ty + NW * m][tx] = make_double2(kk[m][2], kk[m][3]);
-      sCc[ty + NW * m][tx] = make_double2(aa[m], qq[m]);
-    }
-    if (extra) {
-      sCa[eb][ea] = make_double2(kk[RPT][0], kk[RPT][1]);
-      sCb[eb][ea] = make_double2(kk[RPT][2], kk[RPT][3]);
-      sCc[eb][ea] = make_double2(aa[RPT], qq[RPT]);
+      for (int m = 0; m < RPT; ++m) {
+        sCa[ty + NW * m][tx] = make_double2(kk[m][0], kk[m][1]);
+        sCb[ty + NW * m][tx] = make_double2(kk[m][2], kk[m][3]);
+        sCc[ty + NW * m][tx] = make_double2(aa[m], qq[m]);
+      }
+      if (extra) {
+        sCa[eb][ea] = make_double2(kk[RPT][0], kk[RPT][1]);
+        sCb[eb][ea] = make_double2(kk[RPT][2], kk[RPT][3]);
+        sCc[eb][ea] = make_double2(aa[RPT], qq[RPT]);
+      }
+    } else {  // per-node MLP laws (targets :D_hybrid / :D): one node at a time, results in their own LDS
+#pragma unroll 1
+      for (int m = 0; m <= RPT; ++m) {
+        const int a = m < RPT ? tx : ea, b = m < RPT ? ty + NW * m : eb;
+        if (m < RPT || extra) {
+          double k[4], a4, q4;
+          vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, a, b, k, a4, q4);
+          sCa[b][a] = make_double2(k[0], k[1]);
+          sCb[b][a] = make_double2(k[2], k[3]);
+          sCc[b][a] = make_double2(a4, q4);
+        }
+      }
     }
     __syncthreads();
     const int c = tx + 1;

@@ -199,18 +199,44 @@ def test_gradients_with_continuous_vjp_match_oracle(gpu, adjoint):
     b.close()
 
 
-def test_continuous_vjp_needs_an_A_type_law(gpu):
-    H0, B = O.synthetic_valley(32, 24, 50.0)
+@pytest.mark.parametrize("kind,arch", [("Y", "light"), ("Y", "default"), ("Y", "wide"), ("U", "default"), ("U", "light")])
+def test_continuous_vjp_with_the_per_node_mlp_laws(gpu, kind, arch):
+    """ContinuousVJP (adjoint.jl:442-553) with the Y law (target :D_hybrid) and the U law (target :D) -- the reference's
+    'continuous adjoint with continuous VJP' for both targets (runtests.jl:178-180, 189-191): the stencil kernel against the
+    oracle (alpha, beta of these laws are the reference's finite differences, hence 1e-6), and the gradient of the
+    continuous adjoint with that stencil."""
+    from test_gpu_parity import _mlp_pair
+
     ph = O.Phys()
-    b = gpu.GlacierBatch([(32, 24)], [50.0])
+    nx, ny = 56, 40
+    H0, B = O.synthetic_alpine(nx, ny, hmax=150.0, slope=0.1)
+    widths, acts = {"light": ([2, 3, 1], [1, 2]), "default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]),
+                    "wide": ([2, 5, 8, 20, 30, 10, 1], [3, 3, 1, 1, 1, 2])}[arch]
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-5.0])
     b.set_fields(0, H0, B)
-    m = O.default_nn(2, light=True, prescale=((-25.0, 0.0), (0.0, 500.0)), post_kind=O.POST_EXPMAX, post_lo=0.0, post_hi=ph.maxA)
-    b.set_law(gpu.LAW_NN_Y, gpu.MLPSpec(m.widths, m.acts, m.prescale, m.post_kind, m.post_lo, m.post_hi),
-              m.init_theta(np.random.default_rng(0)))
+    if kind == "Y":
+        om, gm, th = _mlp_pair(gpu, widths, acts, [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+        b.set_law(gpu.LAW_NN_Y, gm, th)
+        law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=-5.0)
+    else:
+        om, gm, th = _mlp_pair(gpu, widths, acts, [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+        b.set_law(gpu.LAW_NN_U, gm, th)
+        law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th)
     b.set_vjp_method(gpu._lib.VJP_CONTINUOUS)
-    with pytest.raises(Exception) as e:
-        b.vjp_H(0, np.ones_like(H0), H0)
-    assert "target :A" in str(e.value)
+    lam = np.random.default_rng(7).standard_normal((nx, ny))
+    assert rel_l2(b.vjp_H(0, lam, H0), O.vjp_H_continuous(lam, H0, B, 50.0, 50.0, ph, law)) < 1e-6
+    ts = [2010.0 + j / 48.0 for j in range(4)]
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    cfg = O.SimConfig(tstops=ts, reltol=1e-8)
+    ref, _, _ = O.forward(gl, law, cfg)
+    ref = [r * (1.0 + 0.02 * j) for j, r in enumerate(ref)]
+    b.set_reference(0, ts, ref, 3)
+    Lo, go, lam0, _ = O.loss_and_grad_continuous(gl, law, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=8), vjp="continuous")
+    Lg, gg = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 2e-4 and relerr < 2e-4, (ratio, angle, relerr)
+    assert rel_l2(b.lambda0(0), lam0) < 2e-4
     b.close()
 
 
