@@ -35,7 +35,7 @@ from .batch import GlacierBatch, MLPSpec, PhysicalParameters
 __all__ = [
     "Parameters", "SimulationParameters", "SolverParameters", "Hyperparameters", "UDEparameters",
     "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
-    "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DiscreteVJP", "ContinuousVJP", "MultiLoss", "TikhonovRegularization",
+    "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DummyAdjoint", "DiscreteVJP", "ContinuousVJP", "MultiLoss", "TikhonovRegularization",
     "InitialThicknessRegularization", "RheologyRegularization", "InitialCondition", "evaluate_H0", "evaluate_dH0",
     "sigma_zang", "dsigma_zang", "TrainingResult", "save_inversion_file", "load_inversion_file", "ScalarLogger",
     "callback_diagnosis",
@@ -89,6 +89,18 @@ class DiscreteAdjoint:
 
     VJP_method: object = field(default_factory=DiscreteVJP)  # DiscreteVJP | ContinuousVJP
     MB_VJP: DiscreteVJP = field(default_factory=DiscreteVJP)
+
+
+@dataclass
+class DummyAdjoint:
+    """src/inverse/AdjointTypes.jl:98-107: exercises the training workflow without a sensitivity analysis -- the loss is the
+    real one, the "gradient" is grad_function(θ) or max|θ| · rand(size(θ)) (gradient.jl:540-545; the reference's
+    grad_free_test, runtests.jl:72-73)."""
+
+    grad_function: Optional[Callable] = None
+    VJP_method: object = field(default_factory=DiscreteVJP)
+    MB_VJP: DiscreteVJP = field(default_factory=DiscreteVJP)
+    seed: int = 0  # of the random dummy gradient (reproducible here; `rand` in the reference)
 
 
 @dataclass
@@ -1111,7 +1123,7 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
         def loss_grad(*a, **kw):
             return b.loss_grad_continuous(*a, adj_reltol=grad.reltol, adj_abstol=grad.abstol, adj_dtmax=grad.dtmax,
                                           n_quadrature=grad.n_quadrature, adj_maxiters=p.solver.maxiters, **kw)
-    elif isinstance(grad, DiscreteAdjoint):  # gradient.jl:129
+    elif isinstance(grad, (DiscreteAdjoint, DummyAdjoint)):  # gradient.jl:129; DummyAdjoint: for the loss only
         loss_grad = b.loss_grad
     else:
         raise TypeError(f"adjoint method {type(grad).__name__} is not provided")
@@ -1180,6 +1192,11 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
                 l, gA = b.tikhonov(A, g.dx, g.dy)  # mask = trues(size(H) .- 1)  (:272)
                 loss += w * l
                 dth[offs[gi]:offs[gi + 1]] += w * gA.ravel(order="F") * (hi - lo) * (1.0 - np.tanh(th) ** 2) / 2.0
+    if isinstance(grad, DummyAdjoint):  # gradient.jl:540-545 (the same dummy vector on every rank)
+        if grad.grad_function is not None:
+            dth = np.asarray(grad.grad_function(theta), dtype=np.float64).reshape(theta.shape) / max(_DIST.get("world", 1), 1)
+        else:
+            dth = np.max(np.abs(theta)) * np.random.default_rng(grad.seed).random(theta.shape) / max(_DIST.get("world", 1), 1)
     loss, dth = allreduce_loss_grad(loss, dth)
     if np.linalg.norm(dth) > 1e7:  # gradient.jl:19-24
         import warnings
