@@ -29,12 +29,19 @@ namespace odinn {
 typedef double2 (*AdjEdgesHS)[TNW][2][FRX];
 typedef double (*AdjEdgesL)[TNW][2][FRX];
 
+// ODINN_ADJ_ELDS: the embedded-error accumulator of the thread's rows lives in a thread-private LDS column instead of 2 TRPT
+// VGPRs (it is touched once per row and stage)
+#ifndef ODINN_ADJ_ELDS
+#define ODINN_ADJ_ELDS 1
+#endif
+typedef double (*AdjErr)[FRX];
+
 template <int S, bool AF>
 __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __restrict__ Afield, const double* __restrict__ Ha,
                                                  const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
                                                  int gic, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
                                                  AdjEdgesL sLm, double (&u)[TRPT], double (&tmp)[TRPT], double (&E)[TRPT],
-                                                 const double* __restrict__ Bp) {
+                                                 const double* __restrict__ Bp, AdjErr sEr) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;
   const int r0 = TRPT * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
@@ -140,7 +147,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     double un;
     if (S == 1) {
       un = fma(bt, dtk, uo);
-      E[m] = bh * dtk;
+      if (ODINN_ADJ_ELDS) sEr[r0 + m][lane] = bh * dtk; else E[m] = bh * dtk;
     } else {
       const double t = fma(dl, uo, tmp[m]);
       un = fma(g1, uo, g2 * t);
@@ -150,13 +157,20 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
       }
       un = fma(bt, dtk, un);
       if (dl != 0.0) tmp[m] = t;
-      E[m] = fma(bh, dtk, E[m]);
+      if (ODINN_ADJ_ELDS) sEr[r0 + m][lane] = fma(bh, dtk, sEr[r0 + m][lane]); else E[m] = fma(bh, dtk, E[m]);
     }
     u[m] = un;
     hs_c = hs_n; le_c = le_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; qe_c = qe_n; Pe_c = Pe_n;
     D_s = D_c; C_s = (k01 + dpp_from_west(k11)) + PLn;
     // row fence (see k_rk_fused_strip): pins the row order of this one-basic-block stage body
-    if (S == 1)
+    if (ODINN_ADJ_ELDS) {
+      if (S == 1)
+        asm volatile("" : "+v"(u[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y), "+v"(qe_c),
+                     "+v"(Pe_c), "+v"(D_s), "+v"(C_s), "+v"(gif));
+      else
+        asm volatile("" : "+v"(u[m]), "+v"(tmp[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y),
+                     "+v"(qe_c), "+v"(Pe_c), "+v"(D_s), "+v"(C_s), "+v"(gif));
+    } else if (S == 1)
       asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y), "+v"(qe_c),
                    "+v"(Pe_c), "+v"(D_s), "+v"(C_s), "+v"(gif));
     else
@@ -179,6 +193,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double sLm[2][TNW][2][FRX];
   __shared__ double red[TNW];
+  __shared__ double sEr[ODINN_ADJ_ELDS ? TRY : 1][FRX];
   const int4 t4 = A.tilesF[blockIdx.x];
   const GState* gs = P.gs + t4.x;
   if (gs->done) return;
@@ -276,11 +291,11 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
     edge(TRPT - 1, 1);
   }
   __syncthreads();
-  adj_strip_stage<1, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
-  adj_strip_stage<2, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
-  adj_strip_stage<3, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
-  adj_strip_stage<4, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
-  adj_strip_stage<5, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg);
+  adj_strip_stage<1, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  adj_strip_stage<2, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  adj_strip_stage<3, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  adj_strip_stage<4, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  adj_strip_stage<5, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
   // ---- output rows [FH, TRY-1-FH]: lam' from the registers, embedded error partial -----------------------
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   double errsq = 0.0;
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
     if (r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny) {
       const double upv = upf[m];
       stg32(dst, (unsigned)(id0 + g.nx * m), u[m]);
-      const double err = (u[m] - upv) - E[m];
+      const double err = (u[m] - upv) - (ODINN_ADJ_ELDS ? sEr[r0 + m][lane] : E[m]);
       const double sk = A.abstol + fmax(fabs(upv), fabs(u[m])) * A.reltol;
       const double q = err / sk;
       errsq = fma(q, q, errsq);
