@@ -34,6 +34,12 @@ typedef double (*AdjEdgesL)[TNW][2][FRX];
 #ifndef ODINN_ADJ_ELDS
 #define ODINN_ADJ_ELDS 1
 #endif
+// ODINN_ADJ_PF2: constant-A variants fetch {Hc,S} two rows ahead instead of one (fits 128 VGPRs without scratch once E is in
+// LDS).  Same-box A/B: +2.1 % on the bench's continuous-adjoint gradient (half ice-free domains, shortcut on), but -10 % on
+// the dense all-ice launch (0.260 -> 0.287 ms per 8 x 1024^2): off.
+#ifndef ODINN_ADJ_PF2
+#define ODINN_ADJ_PF2 0
+#endif
 typedef double (*AdjErr)[FRX];
 
 template <int S, bool AF>
@@ -79,6 +85,10 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   double Pe_c = qe_c * clampn(dx_c, e_c.x, hs_c.x);
   double D_s, C_s;  // C_s: what the row below holds for this cell (its nodes' NW / NE terms, its north face's plus part)
   double2 hs_next = hs_itp(TRPT > 1 ? 1 : 0, sw);  // {Hc,S} of row m+1, fetched one row ahead of its use
+  // constant A: registers allow a second row in flight ({Hc,S} of row m+2); with a gridded A they do not (96 B/lane of scratch)
+  constexpr bool PF2 = ODINN_ADJ_PF2 && !AF;
+  [[maybe_unused]] double2 hs_next2;
+  if constexpr (PF2) hs_next2 = hs_itp(TRPT > 2 ? 2 : 0, sw);
 
   // node N(c, r) and north face n(c, r) of a row whose own / east-face quantities are the "_lo" arguments and whose
   // upper neighbours are the "_hi" ones; returns D, the four corner terms and the north face's two second-term parts
@@ -126,7 +136,12 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   for (int m = 0; m < TRPT; ++m) {
     const int gj = gj0 + r0 + m;
     const double2 hs_n = m + 1 < TRPT ? hs_next : hs_top;
-    if (m + 2 < TRPT) hs_next = hs_itp(m + 2 < TRPT ? m + 2 : m, sw);
+    if constexpr (PF2) {
+      hs_next = hs_next2;
+      if (m + 3 < TRPT) hs_next2 = hs_itp(m + 3 < TRPT ? m + 3 : m, sw);
+    } else {
+      if (m + 2 < TRPT) hs_next = hs_itp(m + 2 < TRPT ? m + 2 : m, sw);
+    }
     const double le_n = m + 1 < TRPT ? lam_e(m + 1 < TRPT ? m + 1 : m) : le_top;
     const double2 e_n = dpp_from_east(hs_n);
     const double lee_n = dpp_shift(le_n, false);
