@@ -1,14 +1,18 @@
 // k_adjf.hip -- temporally fused reverse step of the continuous adjoint (integer-power A law, DiscreteVJP)
+#include <cstdlib>
 #include "launch.hpp"
 #include "sia2d_adj_fused.hpp"
 namespace odinn {
 void launch_adj_fused_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, AdjFusedArgs A) {
+  // measurement aid: ODINN_ADJ_LDS_PAD=<bytes> of unused dynamic LDS per workgroup (> 2 KB: one workgroup per CU instead of two,
+  // i.e. half the per-XCD working set against the 4 MB L2 at half the occupancy)
+  static const unsigned pad = std::getenv("ODINN_ADJ_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ODINN_ADJ_LDS_PAD")) : 0u;
   if (afield) {
-    if (skip) hipLaunchKernelGGL((k_adj_fused_strip<true, true>), dim3(nblk), dim3(TNT), 0, st, P, A);
-    else hipLaunchKernelGGL((k_adj_fused_strip<true, false>), dim3(nblk), dim3(TNT), 0, st, P, A);
+    if (skip) hipLaunchKernelGGL((k_adj_fused_strip<true, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+    else hipLaunchKernelGGL((k_adj_fused_strip<true, false>), dim3(nblk), dim3(TNT), pad, st, P, A);
   } else {
-    if (skip) hipLaunchKernelGGL((k_adj_fused_strip<false, true>), dim3(nblk), dim3(TNT), 0, st, P, A);
-    else hipLaunchKernelGGL((k_adj_fused_strip<false, false>), dim3(nblk), dim3(TNT), 0, st, P, A);
+    if (skip) hipLaunchKernelGGL((k_adj_fused_strip<false, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+    else hipLaunchKernelGGL((k_adj_fused_strip<false, false>), dim3(nblk), dim3(TNT), pad, st, P, A);
   }
 }
 void launch_vjp_H_strip(int mode, int afield, int nblk, hipStream_t st, Pools P, const int4* tilesD, AdjArgs A) {

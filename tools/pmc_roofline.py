@@ -50,4 +50,17 @@ for tag, key, pat, bpc in (("dhdt32_nnA", "dhdt_nn_gridded_32", "k_dhdt", 32.0),
         by = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0
         out[key] = {"kernel": names, "cells": cells32, "hbm_bytes_per_launch": by, "hbm_bytes_per_cell": by / cells32,
                     "algorithmic_bytes_per_cell": bpc, "ratio": by / (bpc * cells32)}
+fe, names = med("adjf8_fetch", "k_adj_fused_strip")
+wr, _ = med("adjf8_write", "k_adj_fused_strip")
+bz, _ = med("adjf8_busy", "k_adj_fused_strip")
+if fe and wr:
+    by = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0
+    e = {"kernel": names, "cells": cells8, "hbm_bytes_per_launch": by, "hbm_bytes_per_cell": by / cells8,
+         "algorithmic_bytes_per_cell": 40.0, "ratio": by / (40.0 * cells8),
+         "note": "dense launch on 8 x 1024^2 (320 MiB of lambda, H_j, H_j+1, B, lambda': partly inside the 256 MiB Infinity Cache)"}
+    if bz:
+        e["valu_busy_frac"] = bz.get("SQ_ACTIVE_INST_VALU", 0) * 4 / max(bz.get("SQ_BUSY_CYCLES", 1), 1)
+        e["valu_insts_per_wave"] = bz.get("SQ_INSTS_VALU", 0) / max(bz.get("SQ_WAVES", 1), 1)
+        e["sq_raw"] = bz
+    out["adj_fused_step_8"] = e
 print(json.dumps(out, indent=1))

@@ -21,4 +21,7 @@ run vjpH32_fetch FETCH_SIZE vjp_H 32 const
 run vjpH32_write WRITE_SIZE vjp_H 32 const
 run vjpth32_fetch FETCH_SIZE vjp_theta 32 const
 run vjpth32_write WRITE_SIZE vjp_theta 32 const
+run adjf8_fetch FETCH_SIZE adj_fused_step 8 const
+run adjf8_write WRITE_SIZE adj_fused_step 8 const
+run adjf8_busy "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVES" adj_fused_step 8 const
 cd $R && python tools/pmc_roofline.py $O > $R/gpurun_out/pmc_roofline.json && cat $R/gpurun_out/pmc_roofline.json
