@@ -107,6 +107,9 @@ void launch_vreg_lap(int nblk, hipStream_t st, Pools P, const double* Vabs, cons
 void launch_vreg_cot(int nblk, hipStream_t st, Pools P, const double* r, const double* Vabs, const double* w, double* vx, double* vy) {
   hipLaunchKernelGGL(k_vreg_cot, dim3(nblk), dim3(NT), 0, st, P, r, Vabs, w, vx, vy);
 }
+void launch_seg_pairs(long long ntot, int n_seg, hipStream_t st, const double* snaps, double2* segs) {
+  hipLaunchKernelGGL(k_seg_pairs, dim3(65536), dim3(256), 0, st, ntot, n_seg, snaps, segs);
+}
 void launch_lerp(long long n, hipStream_t st, double s, const double* a, const double* b, double* out) {
   const long long nb = (n + 255) / 256;
   hipLaunchKernelGGL(k_lerp, dim3((unsigned)(nb < 65536 ? (nb < 1 ? 1 : nb) : 65536)), dim3(256), 0, st, n, s, a, b, out);

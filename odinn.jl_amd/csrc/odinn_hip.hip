@@ -259,6 +259,8 @@ struct odinn_batch {
   int* d_agg_slot = nullptr;
   unsigned char* d_av_on = nullptr;
   size_t wA_cap = 0, aggH_cap = 0, agg_slot_cap = 0;
+  double2* d_segs = nullptr;  // {H_j, H_j+1 - H_j} per segment for the fused reverse step
+  size_t segs_cap = 0;
   std::vector<double> wA_h, wR_h;
   std::vector<int> agg_slot_h;
   int agg_nslots = 0;
@@ -1359,6 +1361,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   if (b->d_agg_slot) (void)hipFree(b->d_agg_slot);
   if (b->d_av_on) (void)hipFree(b->d_av_on);
   dfree(b->d_wR); dfree(b->d_wRq);
+  if (b->d_segs) (void)hipFree(b->d_segs);
   if (b->d_vrm) (void)hipFree(b->d_vrm);
   dfree(b->d_nodeS); dfree(b->d_ucell); if (b->d_interp_err) (void)hipFree(b->d_interp_err);
   dfree(b->d_nodeH); dfree(b->d_nodeV); dfree(b->d_sortH); dfree(b->d_sortV); dfree(b->d_knots); dfree(b->d_knotG);
@@ -2343,6 +2346,20 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
     FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = ao.abstol; FA.reltol = ao.reltol;
     C.errpart = b->d_partFt; C.stride = 1; C.fused = 3;
+    // the two bracketing snapshots of every segment interleaved as {H_j, H_j+1 - H_j}: one 16-byte load per cell and
+    // stage instead of two 8-byte ones (ODINN_ADJ_SEGS=0: read the snapshots themselves)
+    const char* es = std::getenv("ODINN_ADJ_SEGS");
+    if (!(es && es[0] == '0')) {
+      const size_t need = (size_t)(k - 1) * b->ntot;
+      if (need > b->segs_cap) {
+        if (b->d_segs) (void)hipFree(b->d_segs);
+        b->d_segs = nullptr; b->segs_cap = 0;
+        HIPCHK(hipMalloc(&b->d_segs, need * sizeof(double2)));
+        b->segs_cap = need;
+      }
+      launch_seg_pairs(b->ntot, k - 1, b->stream, b->d_snaps, b->d_segs);
+      FA.segs = b->d_segs;
+    }
   }
   // polls as in do_solve: one step per stop at least, then the controller's estimate of what is left
   if (!b->d_est) CHK(dalloc(&b->d_est, (size_t)G));
@@ -2625,6 +2642,13 @@ static int timed_prepare(odinn_batch* b) {
   HIPCHK(hipMemcpyAsync(b->d_snaps + b->ntot, b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
   if (!b->d_adj) { CHK(dalloc(&b->d_adj, b->G)); CHK(dalloc(&b->d_qw, b->G)); }
   launch_adj_begin(b->G, b->stream, P, b->d_adj, 2, 0.0, 0, 0);
+  if ((size_t)b->ntot > b->segs_cap) {  // the {H_j, dH} pairs of the one segment, as the reverse solve builds them
+    if (b->d_segs) (void)hipFree(b->d_segs);
+    b->d_segs = nullptr; b->segs_cap = 0;
+    HIPCHK(hipMalloc(&b->d_segs, (size_t)b->ntot * sizeof(double2)));
+    b->segs_cap = (size_t)b->ntot;
+  }
+  launch_seg_pairs(b->ntot, 1, b->stream, b->d_snaps, b->d_segs);
   launch_begin(b->G, b->stream, P, b->d_tstops, 0.0, 1e-6);
   HIPCHK(hipStreamSynchronize(b->stream));
   return ODINN_OK;
@@ -2684,6 +2708,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
       AdjFusedArgs FA{};
       FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
       FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = 1e-8; FA.reltol = 1e-8;
+      { const char* es = std::getenv("ODINN_ADJ_SEGS"); if (!(es && es[0] == '0')) FA.segs = b->d_segs; }
       launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, std::getenv("ODINN_TIMED_ADJ_SKIP") ? 1 : 0, b->stream, P, FA);
       return ODINN_OK;
     }

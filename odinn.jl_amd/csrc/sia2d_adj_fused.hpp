@@ -42,7 +42,7 @@ typedef double (*AdjEdgesL)[TNW][2][FRX];
 #endif
 typedef double (*AdjErr)[FRX];
 
-template <int S, bool AF>
+template <int S, bool AF, bool SG>
 __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __restrict__ Afield, const double* __restrict__ Ha,
                                                  const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
                                                  int gic, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
@@ -66,8 +66,13 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     const int gj = gj0 + r0 + m;
     const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
     const unsigned id = (unsigned)(gif + g.nx * gjc);  // zero-extended: scalar base + 32-bit offset addressing
-    const double ha = ldg32(Ha, id), hb = ldg32(Hb, id), b = ldg32(Bp, id);
-    return cell_HS(fma(swt, hb - ha, ha), b);
+    if constexpr (SG) {  // Ha points at the segment's {H_j, H_j+1 - H_j} pairs
+      const double2 hd = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Ha) + ((size_t)id << 4));
+      return cell_HS(fma(swt, hd.y, hd.x), ldg32(Bp, id));
+    } else {
+      const double ha = ldg32(Ha, id), hb = ldg32(Hb, id), b = ldg32(Bp, id);
+      return cell_HS(fma(swt, hb - ha, ha), b);
+    }
   };
   auto lam_e = [&](int m) {  // lambda masked to the interior cells
     const int gj = gj0 + r0 + m;
@@ -203,7 +208,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
 }
 
 // SKIP: exact ice-free shortcut (see below)
-template <bool AF, bool SKIP>
+template <bool AF, bool SKIP, bool SG = false>
 __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double sLm[2][TNW][2][FRX];
@@ -218,8 +223,17 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
   // everything below is addressed relative to the glacier's first cell (block-uniform bases, 32-bit cell indices)
   const double* __restrict__ src = (gs->cur ? A.lam1 : A.lam0) + g.off;
   double* __restrict__ dst = (gs->cur ? A.lam0 : A.lam1) + g.off;
-  const double* __restrict__ Ha = A.snaps + (long long)a.seg * A.ntot + g.off;
-  const double* __restrict__ Hb = Ha + A.ntot;
+  const double* __restrict__ Ha = SG ? reinterpret_cast<const double*>(A.segs + (long long)a.seg * A.ntot + g.off)
+                                     : A.snaps + (long long)a.seg * A.ntot + g.off;
+  const double* __restrict__ Hb = Ha + A.ntot;  // (unused with SG)
+  auto ld_ab = [&](unsigned id, double& ha, double& hb) {  // the two bracketing snapshots of a cell
+    if constexpr (SG) {
+      const double2 hd = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Ha) + ((size_t)id << 4));
+      ha = hd.x; hb = hd.x + hd.y;
+    } else {
+      ha = ldg32(Ha, id); hb = ldg32(Hb, id);
+    }
+  };
   const double* __restrict__ Bg = P.B + g.off;
   const double* __restrict__ Afg = AF ? P.Afield + g.offd : nullptr;
   const int lane = threadIdx.x & 63;
@@ -240,7 +254,9 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
       const int gj = gj0 + r0 + m;
       const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
       const unsigned id = (unsigned)(gic + g.nx * gjc);
-      ice = ice || ldg32(Ha, id) > 0.0 || ldg32(Hb, id) > 0.0;
+      double ha, hb;
+      ld_ab(id, ha, hb);
+      ice = ice || ha > 0.0 || hb > 0.0;
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) ice = ice || !(a.sitp[k] >= 0.0 && a.sitp[k] <= 1.0);
@@ -295,8 +311,13 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
       double h = 0.0, b = 0.0;
       if (inx && gj >= 0 && gj < g.ny) {
         const unsigned id = (unsigned)(id0 + g.nx * m);
-        const double ha = ldg32(Ha, id);
-        h = fma(a.sitp[0], ldg32(Hb, id) - ha, ha);
+        if constexpr (SG) {
+          const double2 hd = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Ha) + ((size_t)id << 4));
+          h = fma(a.sitp[0], hd.y, hd.x);
+        } else {
+          const double ha = ldg32(Ha, id);
+          h = fma(a.sitp[0], ldg32(Hb, id) - ha, ha);
+        }
         b = ldg32(Bg, id);
       }
       sE[0][w][e][lane] = cell_HS(h, b);
@@ -306,11 +327,11 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
     edge(TRPT - 1, 1);
   }
   __syncthreads();
-  adj_strip_stage<1, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
-  adj_strip_stage<2, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
-  adj_strip_stage<3, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
-  adj_strip_stage<4, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
-  adj_strip_stage<5, AF>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  adj_strip_stage<1, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  adj_strip_stage<2, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  adj_strip_stage<3, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  adj_strip_stage<4, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  adj_strip_stage<5, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
   // ---- output rows [FH, TRY-1-FH]: lam' from the registers, embedded error partial -----------------------
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   double errsq = 0.0;

@@ -1599,6 +1599,8 @@ struct AdjStageArgs {
 
 // arguments of k_adj_fused_strip (sia2d_adj_fused.hpp): the five stages of a reverse step in one kernel
 struct AdjFusedArgs {
+  const double2* segs;  // non-null: {H_j, H_j+1 - H_j} interleaved per segment [n_snap - 1][ntot] (k_seg_pairs): one 16-byte
+                        //   load per cell and stage instead of two 8-byte ones
   const double* snaps;  // forward snapshots [n_snap][ntot]
   long long ntot;
   const AdjState* adj;
@@ -2399,6 +2401,14 @@ __global__ __launch_bounds__(NT) void k_vreg_cot(Pools P, const double* __restri
       vx[id] = cx;
       vy[id] = cy;
     }
+  }
+}
+// segs[j][i] = {H_j[i], H_j+1[i] - H_j[i]} for the n_seg = n_snap - 1 segments of a run (fused reverse step)
+__global__ void k_seg_pairs(long long ntot, int n_seg, const double* __restrict__ snaps, double2* __restrict__ segs) {
+  const long long n = ntot * n_seg;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double a = snaps[i], b = snaps[i + ntot];
+    segs[i] = make_double2(a, b - a);
   }
 }
 // out = a + s (b - a) on n entries (the time interpolant of two snapshots, load_tile_HS2's formula)
