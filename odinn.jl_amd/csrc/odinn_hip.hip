@@ -2349,8 +2349,12 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     // the two bracketing snapshots of every segment interleaved as {H_j, H_j+1 - H_j}: one 16-byte load per cell and
     // stage instead of two 8-byte ones (ODINN_ADJ_SEGS=0: read the snapshots themselves)
     const char* es = std::getenv("ODINN_ADJ_SEGS");
-    if (!(es && es[0] == '0')) {
-      const size_t need = (size_t)(k - 1) * b->ntot;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const size_t need = (size_t)(k - 1) * b->ntot;
+    // (a second copy of the snapshots, twice their size: only while it takes less than half of what is free)
+    const bool fits = need <= b->segs_cap || need * sizeof(double2) <= free_b / 2;
+    if (!(es && es[0] == '0') && fits) {
       if (need > b->segs_cap) {
         if (b->d_segs) (void)hipFree(b->d_segs);
         b->d_segs = nullptr; b->segs_cap = 0;
