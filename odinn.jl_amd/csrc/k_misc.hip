@@ -110,6 +110,9 @@ void launch_vreg_cot(int nblk, hipStream_t st, Pools P, const double* r, const d
 void launch_seg_pairs(long long ntot, int n_seg, hipStream_t st, const double* snaps, double2* segs) {
   hipLaunchKernelGGL(k_seg_pairs, dim3(65536), dim3(256), 0, st, ntot, n_seg, snaps, segs);
 }
+void launch_sum_tilesFt(int G, hipStream_t st, Pools P, const double* part, double* out) {
+  hipLaunchKernelGGL(k_sum_tilesFt, dim3(G), dim3(64), 0, st, P, part, out);
+}
 void launch_lerp(long long n, hipStream_t st, double s, const double* a, const double* b, double* out) {
   const long long nb = (n + 255) / 256;
   hipLaunchKernelGGL(k_lerp, dim3((unsigned)(nb < 65536 ? (nb < 1 ? 1 : nb) : 65536)), dim3(256), 0, st, n, s, a, b, out);

@@ -84,6 +84,7 @@ void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const dou
 void launch_axpy(long long n, hipStream_t st, double a, const double* x, const double* y, double* z);  // z = y + a x
 void launch_lerp(long long n, hipStream_t st, double s, const double* a, const double* b, double* out);  // out = a + s (b - a)
 void launch_seg_pairs(long long ntot, int n_seg, hipStream_t st, const double* snaps, double2* segs);
+void launch_sum_tilesFt(int G, hipStream_t st, Pools P, const double* part, double* out);
 // VelocityRegularization (Regularization.jl:192-245): see k_vreg_* in sia2d_device.hpp
 void launch_vreg_prep(int nblk, hipStream_t st, Pools P, const double* H, const double* vx, const double* vy, const double* w,
                       int dist, double* Vabs, unsigned char* mask);

@@ -259,6 +259,8 @@ struct odinn_batch {
   int* d_agg_slot = nullptr;
   unsigned char* d_av_on = nullptr;
   size_t wA_cap = 0, aggH_cap = 0, agg_slot_cap = 0;
+  double* d_partTh = nullptr;  // fused reverse step: per-tile running sums of the theta-VJP at the quadrature nodes
+  size_t partTh_cap = 0;
   double2* d_segs = nullptr;  // {H_j, H_j+1 - H_j} per segment for the fused reverse step
   size_t segs_cap = 0;
   std::vector<double> wA_h, wR_h;
@@ -1362,6 +1364,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   if (b->d_av_on) (void)hipFree(b->d_av_on);
   dfree(b->d_wR); dfree(b->d_wRq);
   if (b->d_segs) (void)hipFree(b->d_segs);
+  dfree(b->d_partTh);
   if (b->d_vrm) (void)hipFree(b->d_vrm);
   dfree(b->d_nodeS); dfree(b->d_ucell); if (b->d_interp_err) (void)hipFree(b->d_interp_err);
   dfree(b->d_nodeH); dfree(b->d_nodeV); dfree(b->d_sortH); dfree(b->d_sortV); dfree(b->d_knots); dfree(b->d_knotG);
@@ -2364,7 +2367,20 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       launch_seg_pairs(b->ntot, k - 1, b->stream, b->d_snaps, b->d_segs);
       FA.segs = b->d_segs;
     }
+    // A-type laws without a dual-grid accumulator: the theta-VJP of a quadrature node is formed by stage 1 of the step that
+    // follows the node (same lambda, same H_itp) instead of a launch of its own (ODINN_ADJ_THETA_FUSED=0: separate launches)
+    const char* et = std::getenv("ODINN_ADJ_THETA_FUSED");
+    if (acc_inplace && !b->wants_Gacc() && !(et && et[0] == '0')) {
+      if ((size_t)b->ntilesFt > b->partTh_cap) {
+        dfree(b->d_partTh);
+        CHK(dalloc(&b->d_partTh, (size_t)b->ntilesFt));
+        b->partTh_cap = (size_t)b->ntilesFt;
+      }
+      HIPCHK(hipMemsetAsync(b->d_partTh, 0, (size_t)b->ntilesFt * sizeof(double), b->stream));
+      FA.th_part = b->d_partTh;
+    }
   }
+  const bool theta_fused = FA.th_part != nullptr;
   // polls as in do_solve: one step per stop at least, then the controller's estimate of what is left
   if (!b->d_est) CHK(dalloc(&b->d_est, (size_t)G));
   C.est_steps = b->d_est;
@@ -2408,7 +2424,8 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       }
       // quadrature node reached: dtheta += w * J_theta(H_itp(t))^T lam(t)  (:497-503); A-type laws add
       // onto per-tile running sums that are reduced once after the solve
-      if (fused_rev)
+      if (theta_fused) {
+      } else if (fused_rev)
         CHK(theta_vjp_launch(b, b->d_tmpA, b->d_lam[0], b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace,
                              b->d_lam[1], theta_itp ? b->d_snaps : nullptr, b->d_adj));
       else
@@ -2444,6 +2461,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     }
   }
   if (acc_inplace) launch_sum_part_steps(G, b->stream, Pl, b->d_partsteps, 4LL * b->ntiles, 0, 0, 2, b->d_Gsum);
+  if (theta_fused) launch_sum_tilesFt(G, b->stream, Pl, b->d_partTh, b->d_Gsum);
   // lambda(t0) of every glacier -> d_lam[0] (glaciers finish in different ping-pong buffers)
   if (mixed || gs[0].cur != 0) {
     for (int g = 0; g < G; ++g)

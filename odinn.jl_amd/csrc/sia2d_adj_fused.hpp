@@ -47,7 +47,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
                                                  const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
                                                  int gic, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
                                                  AdjEdgesL sLm, double (&u)[TRPT], double (&tmp)[TRPT], double (&E)[TRPT],
-                                                 const double* __restrict__ Bp, AdjErr sEr) {
+                                                 const double* __restrict__ Bp, AdjErr sEr, double* __restrict__ th_red) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;
   const int r0 = TRPT * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
@@ -90,6 +90,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   double Pe_c = qe_c * clampn(dx_c, e_c.x, hs_c.x);
   double D_s, C_s;  // C_s: what the row below holds for this cell (its nodes' NW / NE terms, its north face's plus part)
   double2 hs_next = hs_itp(TRPT > 1 ? 1 : 0, sw);  // {Hc,S} of row m+1, fetched one row ahead of its use
+  [[maybe_unused]] double thacc = 0.0;  // stage 1, th_red != null: the wavefront's share of the theta-VJP (see node_face)
   // constant A: registers allow a second row in flight ({Hc,S} of row m+2); with a gridded A they do not (96 B/lane of scratch)
   constexpr bool PF2 = ODINN_ADJ_PF2 && !AF;
   [[maybe_unused]] double2 hs_next2;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   // upper neighbours are the "_hi" ones; returns D, the four corner terms and the north face's two second-term parts
   auto node_face = [&](int gj, double2 hs_lo, double2 e_lo, double le_lo, double dx_lo, double hp_lo, double Pe_lo,
                        double2 hs_hi, double2 e_hi, double le_hi, double dx_hi, double hp_hi, double Pe_hi, double& D,
-                       double& k00, double& k10, double& k01, double& k11, double& Mn, double& PLn) {
+                       double& k00, double& k10, double& k01, double& k11, double& Mn, double& PLn, double& tw) {
     const double dyw = hs_hi.y - hs_lo.y, dye = e_hi.y - e_lo.y;
     const double qn = le_hi - le_lo;
     const double Pn = qn * clampn(dyw, hs_hi.x, hs_lo.x);
@@ -116,6 +117,10 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     const double H2 = Hs * Hs, H4 = H2 * H2, H5 = H4 * Hs;
     D = (Kq * H5) * gS2;
     const double Da = -fma(g.hinv_dx2, Pe_lo + Pe_hi, g.hinv_dy2 * (Pn + Pn_e));
+    // (stage 1 only) the node's weight in the theta-VJP of the A-type laws, dD/dA x D_adjoint = Gam Hbar^5 |grad S|^2 Da
+    // (adjoint.jl:235-250; k_vjp_theta_strip's expression): stage 1 sits exactly on the state the reverse solve has just
+    // reached, so a quadrature node reached by the previous step gets its theta-VJP here instead of in a launch of its own
+    tw = S == 1 ? ((Gq * H5) * gS2) * Da : 0.0;
     const double ad = (((Kq * 5.0) * H4) * gS2) * Da;  // alpha Da / 4
     const double bd = ((Kq * 2.0) * H5) * Da;           // beta Da
     const double bx = g.hinv_dx * (bd * gx), by = g.hinv_dy * (bd * gy);
@@ -133,8 +138,8 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     const double lee_s = dpp_shift(le_s, false);
     const double dx_s = e_s.y - hs_s.y, hp_s = hs_s.x + e_s.x;
     const double Pe_s = (lee_s - le_s) * clampn(dx_s, e_s.x, hs_s.x);
-    double k00, k10, k01, k11, Mn, PLn;
-    node_face(gj0 + r0 - 1, hs_s, e_s, le_s, dx_s, hp_s, Pe_s, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, D_s, k00, k10, k01, k11, Mn, PLn);
+    double k00, k10, k01, k11, Mn, PLn, tw;
+    node_face(gj0 + r0 - 1, hs_s, e_s, le_s, dx_s, hp_s, Pe_s, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, D_s, k00, k10, k01, k11, Mn, PLn, tw);
     C_s = (k01 + dpp_from_west(k11)) + PLn;
   }
 #pragma unroll
@@ -152,8 +157,12 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     const double lee_n = dpp_shift(le_n, false);
     const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, qe_n = lee_n - le_n;
     const double Pe_n = qe_n * clampn(dx_n, e_n.x, hs_n.x);
-    double D_c, k00, k10, k01, k11, Mn, PLn;
-    node_face(gj, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, hs_n, e_n, le_n, dx_n, hp_n, Pe_n, D_c, k00, k10, k01, k11, Mn, PLn);
+    double D_c, k00, k10, k01, k11, Mn, PLn, tw;
+    node_face(gj, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, hs_n, e_n, le_n, dx_n, hp_n, Pe_n, D_c, k00, k10, k01, k11, Mn, PLn, tw);
+    if (S == 1 && th_red) {  // the node north-east of an OUTPUT cell belongs to this thread (every dual node to exactly one)
+      const bool own = lane >= FH && lane < FH + FOX && r0 + m >= FH && r0 + m <= TRY - 1 - FH && gi <= g.nx - 2 && gj <= g.ny - 2;
+      thacc += own ? tw : 0.0;
+    }
     // east face of this row, second term
     const double te = ((D_s + D_c) * g.hinv_dx2) * qe_c;
     const double Me = (dx_c < e_c.x && dx_c != -hs_c.x) ? te : 0.0;
@@ -196,6 +205,10 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     else
       asm volatile("" : "+v"(u[m]), "+v"(E[m]), "+v"(tmp[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y),
                    "+v"(qe_c), "+v"(Pe_c), "+v"(D_s), "+v"(C_s), "+v"(gif));
+  }
+  if (S == 1 && th_red) {  // reduced across the workgroup behind the barrier that ends the stage
+    thacc = wave_sum(thacc);
+    if (lane == 0) th_red[w] = thacc;
   }
   if (S < 5) {  // publish the strip's edge rows for the next stage: H at ITS time, lambda just updated
     const double swn = a.sitp[S < 5 ? S : 4];
@@ -327,11 +340,21 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
     edge(TRPT - 1, 1);
   }
   __syncthreads();
-  adj_strip_stage<1, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
-  adj_strip_stage<2, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
-  adj_strip_stage<3, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
-  adj_strip_stage<4, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
-  adj_strip_stage<5, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr);
+  __shared__ double th_red[TNW];
+  // theta-VJP of the quadrature node the previous step reached (a.qw: its Gauss-Legendre weight, 0 otherwise; the controller
+  // resets it at every call, so a repeated attempt after a rejection does not count the node twice)
+  double* const thr = (A.th_part && a.qw != 0.0) ? th_red : nullptr;
+  adj_strip_stage<1, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr);
+  if (thr && threadIdx.x == 0) {  // the tile's running sum, reduced per glacier once after the reverse solve
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < TNW; ++k) sum += th_red[k];
+    A.th_part[t4.w] = fma(a.qw, sum, A.th_part[t4.w]);
+  }
+  adj_strip_stage<2, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
+  adj_strip_stage<3, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
+  adj_strip_stage<4, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
+  adj_strip_stage<5, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
   // ---- output rows [FH, TRY-1-FH]: lam' from the registers, embedded error partial -----------------------
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   double errsq = 0.0;

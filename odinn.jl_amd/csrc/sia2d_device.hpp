@@ -1609,6 +1609,8 @@ struct AdjFusedArgs {
   double* partF;        // error partials, FOX x FOYT tile table
   const int4* tilesF;
   double abstol, reltol;
+  double* th_part;      // non-null (A-type laws without a dual-grid accumulator): per-tile running sums of the theta-VJP at
+                        //   the quadrature nodes, formed in stage 1 of the step that follows a node (same tile table)
 };
 
 
@@ -2410,6 +2412,15 @@ __global__ void k_seg_pairs(long long ntot, int n_seg, const double* __restrict_
     const double a = snaps[i], b = snaps[i + ntot];
     segs[i] = make_double2(a, b - a);
   }
+}
+// out[g] += sum of the glacier's entries of a per-tile array on the FOX x FOYT strip-tile table (fixed order)
+__global__ __launch_bounds__(64) void k_sum_tilesFt(Pools P, const double* __restrict__ part, double* __restrict__ out) {
+  const int gidx = blockIdx.x;
+  const GDev g = P.gd[gidx];
+  double s = 0.0;
+  for (int k = threadIdx.x; k < g.ntilesFt; k += 64) s += part[g.tile0Ft + k];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[gidx] += s;
 }
 // out = a + s (b - a) on n entries (the time interpolant of two snapshots, load_tile_HS2's formula)
 __global__ void k_lerp(long long n, double s, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {

@@ -51,8 +51,9 @@ def test_dhdt_loss_and_gradients_match_oracle(gpu, case):
     ratio, angle, relerr = stats_err_arrays(gg, go)
     assert abs(ratio) < 1e-5 and abs(angle) < 1e-9 and relerr < 1e-5, (case, ratio, angle, relerr)
     # lambda(t0) of two adaptive reverse solves (reltol = abstol = 1e-8) through the jumps at t1 and t0: with LossDhdt alone
-    # lambda is O(1e-2) and the absolute tolerance weighs in (observed 4e-5)
-    assert rel_l2(b.lambda0(0), lam0) < (1e-4 if case == "alone" else 1e-5)
+    # lambda is O(1e-2), so the ABSOLUTE tolerance governs: 1e-8 / 1e-2 = 1e-6 relative per step over ~70 steps.  Observed
+    # 4e-5 ... 3e-4 across builds of the reverse kernel that differ only in rounding (the step sequence shifts by a step)
+    assert rel_l2(b.lambda0(0), lam0) < (1e-3 if case == "alone" else 1e-5)
     sr = b.last_stats_rev[0]
     assert abs(sr.naccept - st_o.naccept) <= max(2, st_o.naccept // 10), (sr, st_o)  # 75 vs 70 seen with LossDhdt alone
     # the term really is in there: switching it off changes loss and gradient
