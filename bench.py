@@ -463,6 +463,16 @@ def main():
             aux["nn_inlined_2x16_ms_per_step"] = ms_nn
             aux["nn_inlined_2x16_cellsteps_per_s"] = 5.0 * cells * world / (ms_nn * 1e-3)
             aux["nn_inlined_2x16_note"] = "LawY: Y = NN_theta(T, Hbar) evaluated per dual node inside the stencil (Laws.jl:258-265)"
+            # its own roofline: fp64 vector pipe.  Flops per node evaluation as SURVEY section 7 counts them: 2 x (2*16 + 16*16
+            # + 16) = 608 for the matrix-vector products + 33 activations (32 softplus = exp + log1p, 1 sigmoid) at 25 flop
+            # each (the survey's 20-30) = 1433, + the stencil's own flops per cell-stage
+            fl = 608.0 + 33.0 * 25.0 + FLOP_PER_CELL_STAGE_FALLBACK
+            ach = fl * 5.0 * cells / (ms_nn * 1e-3) / 1e12
+            aux["roofline_nn_inlined"] = {
+                "bound": "fp64-valu", "kernel": "k_rk_stage<LM 4> x 5 or k_rk_fused<LM 4> (2 -> 16 -> 16 -> 1 MLP inlined per dual node and stage)",
+                "flop_per_cell_stage": fl, "flop_definition": "608 (MLP FMAs x 2) + 33 activations x 25 + stencil; the softplus / sigmoid "
+                "of the kernel cost ~50 fp64 instructions each (exp, log1p, division at <= 2 ulp), so the instruction count is ~2x this",
+                "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "ms_per_step": ms_nn}
             b.set_law(odinn.LAW_CONST_A)
         except Exception as e:
             aux["nn_inlined_error"] = str(e)[:200]
