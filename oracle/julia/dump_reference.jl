@@ -13,6 +13,10 @@
 #   dH.f64         Huginn.SIA2D!(dH, H, simulation, t, θ)
 #   vjp_H.f64      VJP_λ_∂SIA∂H(DiscreteVJP(), λ, H, θ, simulation, t)[1]
 #   vjp_theta.f64  VJP_λ_∂SIA∂θ(DiscreteVJP(), λ, H, θ, nothing, simulation, t)   (flattened like θ)
+# and, for the A-type cases (target :A), the surface-velocity seam with the cotangents (∂Vx, ∂Vy) = (λ, reverse(λ, dims = 1)):
+#   Vx.f64, Vy.f64            Huginn.V_from_H(simulation, H, t, θ)
+#   vjp_surfV_H.f64           VJP_λ_∂surface_V∂H(DiscreteVJP(), ∂Vx, ∂Vy, H, θ, simulation, t)[1]
+#   vjp_surfV_theta.f64       VJP_λ_∂surface_V∂θ(DiscreteVJP(), ∂Vx, ∂Vy, H, θ, simulation, t)[1]
 # as raw little-endian Float64, column-major -- the layout of include/odinn_hip.h.
 using ODINN, Huginn, Sleipnir
 
@@ -96,6 +100,19 @@ function run_case(case::String)
     write(joinpath(out, "dH.f64"), vec(dH))
     write(joinpath(out, "vjp_H.f64"), vec(∂H))
     write(joinpath(out, "vjp_theta.f64"), ∂θv)
+    if target == :A   # surface-velocity seam (adjoint.jl:268-413)
+        ∂Vx, ∂Vy = λ, reverse(λ, dims = 1)
+        Vx, Vy, _ = Huginn.V_from_H(simulation, H, t, θ)
+        ∂HV, = ODINN.VJP_λ_∂surface_V∂H(grad.VJP_method, ∂Vx, ∂Vy, H, θ, simulation, t)
+        ∂θV, = ODINN.VJP_λ_∂surface_V∂θ(grad.VJP_method, ∂Vx, ∂Vy, H, θ, simulation, t)
+        ∂θVv = ODINN.ComponentVector2Vector(∂θV)
+        if law == "constA"
+            lo, hi = params.physical.minA, params.physical.maxA
+            ∂θVv = ∂θVv ./ ((hi - lo) / 2 .* (1 .- tanh.(ODINN.ComponentVector2Vector(θ)) .^ 2))
+        end
+        write(joinpath(out, "Vx.f64"), vec(Vx)); write(joinpath(out, "Vy.f64"), vec(Vy))
+        write(joinpath(out, "vjp_surfV_H.f64"), vec(∂HV)); write(joinpath(out, "vjp_surfV_theta.f64"), ∂θVv)
+    end
     println(case, ": ‖dH‖ = ", sqrt(sum(abs2, dH)), "  ‖∂H‖ = ", sqrt(sum(abs2, ∂H)), "  ‖∂θ‖ = ", sqrt(sum(abs2, ∂θv)))
 end
 

@@ -69,6 +69,18 @@ def compute(name):
     )
 
 
+def compute_velocity(name):
+    """Surface-velocity seam of the A-type cases (not stored in the .npz files; used by the reference-dump comparison):
+    (Vx, Vy) = V_from_H(H) and VJP_lambda_dsurface_V/d{H, theta} with the cotangents (dVx, dVy) = (lam, lam reversed)."""
+    H, B, lam, dx, ph, law = case_inputs(name)
+    if law.kind not in (O.LAW_CONST_A, O.LAW_NN_A_SCALAR):
+        return None
+    dVx, dVy = lam, np.asfortranarray(lam[::-1, :])
+    Vx, Vy, _ = O.V_from_H(H, B, dx, dx, ph, law)
+    return dict(Vx=Vx, Vy=Vy, vjp_surfV_H=O.vjp_surface_V_H(dVx, dVy, H, B, dx, dx, ph, law),
+                vjp_surfV_theta=O.vjp_surface_V_theta(dVx, dVy, H, B, dx, dx, ph, law))
+
+
 def solve_case():
     """Short adaptive solve + discrete adjoint on a 48x40 valley (snapshots, loss, gradient)."""
     ph = O.Phys()
