@@ -205,6 +205,9 @@ int odinn_set_surface_velocity_factor(odinn_batch* b, double f);
 #define ODINN_SIMPLE_L2SUM 0
 #define ODINN_SIMPLE_LOGSUM 1
 int odinn_set_velocity_loss_function(odinn_batch* b, int simple_loss, double eps);
+/* the same for LossH (and LossHV's thickness part): L2Sum (default) or LogSum(eps) on the mask is_in_glacier(H_ref, distance);
+ * the reference asserts H_pred >= 0 for LogSum (Losses.jl:214) -- here a negative cell yields the NaN of log. */
+int odinn_set_thickness_loss_function(odinn_batch* b, int simple_loss, double eps);
 /* LossDhdt, a time-aggregated loss (src/losses/TimeAggregatedLosses.jl:38-113): glacier.dhdtData = (t0, t1, dhdt_ref);
  * with H0, H1 the predicted thickness at t0, t1 (both must be tstops of the solve), mask = H0 > 1e-2 and
  * dhdt = mean((H1 - H0)[mask]) / (t1 - t0), the term weight * (dhdt - dhdt_ref)^2 joins the loss of odinn_loss /

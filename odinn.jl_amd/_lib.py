@@ -92,6 +92,7 @@ SIGNATURES = {
     "odinn_set_velocity_regularization": (C.c_int, [_vp, C.c_double, C.c_int]),
     "odinn_set_velocity_loss_function": (C.c_int, [_vp, C.c_int, C.c_double]),
     "odinn_set_surface_velocity_factor": (C.c_int, [_vp, C.c_double]),
+    "odinn_set_thickness_loss_function": (C.c_int, [_vp, C.c_int, C.c_double]),
     "odinn_surface_V": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "odinn_surface_V_vjp_H": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "odinn_surface_V_vjp_theta": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, C.c_int]),

@@ -133,8 +133,8 @@ class L2Sum:
 
 @dataclass
 class LogSum:
-    """src/losses/Losses.jl:34-49,207-229: log²((a + ϵ) / (b + ϵ)) / normalization (Morlighem et al. 2010); provided as
-    the simple loss of LossV(component = :abs) -- the combination the reference tests (runtests.jl:165-167)."""
+    """src/losses/Losses.jl:34-49,207-229: log²((a + ϵ) / (b + ϵ)) / normalization (Morlighem et al. 2010); the simple loss
+    of LossV(component = :abs) -- the combination the reference tests (runtests.jl:165-167) -- or of LossH."""
 
     distance: int = 3
     eps: float = 0.1  # ϵ
@@ -144,11 +144,7 @@ class LogSum:
 class LossH:
     """src/losses/Losses.jl:250-291"""
 
-    loss: L2Sum = field(default_factory=L2Sum)
-
-    def __post_init__(self):
-        if isinstance(self.loss, LogSum):
-            raise NotImplementedError("LogSum is provided inside LossV(component = :abs); LossH uses L2Sum")
+    loss: object = field(default_factory=L2Sum)  # L2Sum | LogSum
 
 
 @dataclass
@@ -998,6 +994,9 @@ class _Simulation:
             b.set_loss(L.LOSS_HV, lf.vLoss.component, lf.vLoss.scale_loss, lf.scaling)
         elif isinstance(lf, LossV):
             b.set_loss(L.LOSS_V, lf.component, lf.scale_loss)
+        hl = lf.hLoss if isinstance(lf, LossHV) else lf if isinstance(lf, LossH) else None
+        if hl is not None and isinstance(hl.loss, LogSum):
+            b.set_thickness_loss_function(hl.loss.eps)
         vl = lf.vLoss if isinstance(lf, LossHV) else lf if isinstance(lf, LossV) else None
         if vl is not None and isinstance(vl.loss, LogSum):
             b.set_velocity_loss_function(vl.loss.eps)

@@ -235,6 +235,13 @@ class GlacierBatch:
         L.check(L.lib().odinn_set_loss(self._h, int(kind), 1 if component == "abs" else 0, 1 if scale_loss else 0,
                                        float(scaling)))
 
+    def set_thickness_loss_function(self, logsum_eps=None):
+        """The simple loss inside LossH / LossHV's thickness part: L2Sum (None) or LogSum(eps) (Losses.jl:34-49,207-229)."""
+        if logsum_eps is None:
+            L.check(L.lib().odinn_set_thickness_loss_function(self._h, L.SIMPLE_L2SUM, 0.0))
+        else:
+            L.check(L.lib().odinn_set_thickness_loss_function(self._h, L.SIMPLE_LOGSUM, float(logsum_eps)))
+
     def set_surface_velocity_factor(self, f):
         """parameters.simulation.f_surface_velocity_factor: Velocity^ = U / f for the U law (target :D)."""
         L.check(L.lib().odinn_set_surface_velocity_factor(self._h, float(f)))

@@ -18,8 +18,8 @@ void launch_sum_part_theta(int Pn, int ng, hipStream_t st, Pools P, const double
   hipLaunchKernelGGL(k_sum_part_theta, dim3(Pn, ng), dim3(64), 0, st, P, part_theta, Pn, out, accumulate, g0);
 }
 void launch_loss(int nblk, hipStream_t st, Pools P, const double* H, const double* Href, const unsigned char* mask,
-                 const double* ws, const int* refslot, long long ntot) {
-  hipLaunchKernelGGL(k_loss, dim3(nblk), dim3(NT), 0, st, P, H, Href, mask, ws, refslot, ntot);
+                 const double* ws, const int* refslot, long long ntot, double log_eps) {
+  hipLaunchKernelGGL(k_loss, dim3(nblk), dim3(NT), 0, st, P, H, Href, mask, ws, refslot, ntot, log_eps);
 }
 void launch_mb_vjp(int nblk, hipStream_t st, Pools P, const double* Hpre, const double* mb0, const double* Sref,
                    const double* lam_in, double* lam_out, int add, int base) {

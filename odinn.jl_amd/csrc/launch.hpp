@@ -66,7 +66,7 @@ void launch_sum_part_steps(int ng, hipStream_t st, Pools P, const double* base, 
 void launch_sum_part_theta(int Pn, int ng, hipStream_t st, Pools P, const double* part_theta, double* out,
                            int accumulate, int g0);
 void launch_loss(int nblk, hipStream_t st, Pools P, const double* H, const double* Href, const unsigned char* mask,
-                 const double* ws, const int* refslot, long long ntot);
+                 const double* ws, const int* refslot, long long ntot, double log_eps);
 void launch_mb_vjp(int nblk, hipStream_t st, Pools P, const double* Hpre, const double* mb0, const double* Sref,
                    const double* lam_in, double* lam_out, int add, int base);
 void launch_mb_apply(int nblk, hipStream_t st, Pools P, const double* H, const double* mb0, const double* Sref,

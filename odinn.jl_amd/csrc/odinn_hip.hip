@@ -209,8 +209,8 @@ struct odinn_batch {
   double fV = 1.0;
   bool vel_law_ok() const { return law_kind < ODINN_LAW_NN_Y || law_kind == ODINN_LAW_NN_U; }
   bool vel_nn() const { return law_kind == ODINN_LAW_NN_U; }
-  // LossV's simple loss: 0 = L2Sum, > 0 = LogSum(eps) (component :abs only; Losses.jl:34-49,207-229)
-  double v_log_eps = 0.0;
+  // LossV's simple loss: 0 = L2Sum, > 0 = LogSum(eps) (component :abs only; Losses.jl:34-49,207-229); h_log_eps: LossH's
+  double v_log_eps = 0.0, h_log_eps = 0.0;
   std::vector<std::vector<std::vector<double>>> v_edge;  // per glacier per slot: V_ref > 0 on the last row / column
   // data-only part of LossV on the last row / column of slot m (V_pred = 0 there by construction), divided by nx ny
   double v_const(int g, int m) const {
@@ -536,6 +536,7 @@ void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawD
   const bool strip_on = se ? se[0] != '0' : (double)b->ntot >= 0.75 * (double)b->ntilesD * (DHDT_OX * DHDT_OY);
   const int vje = vj < 0 ? b->vjp_method : vj;
   if (strip_on && b->lm() == 0 && vje == ODINN_VJP_DISCRETE && !A.snaps && base == 0 && nblk == b->ntiles &&
+      !(mode == 1 && b->h_log_eps > 0.0) &&  // (LossH with LogSum: the tile kernel carries that branch)
       (P.tiles == b->d_tiles || b->G == 1)) {
     launch_vjp_H_strip(mode, b->gd[0].use_Afield ? 1 : 0, b->ntilesD, b->stream, P, b->d_tilesD, A);
     return;
@@ -1151,7 +1152,7 @@ int do_loss(odinn_batch* b, double* const_loss) {
   for (int j = 1; j < k; ++j) {
     if (b->d_Href && b->loss_kind != ODINN_LOSS_V) {
       launch_loss(b->ntiles, b->stream, P, b->d_snaps + (size_t)j * b->ntot, b->d_Href, b->d_mask,
-                  b->d_ws + (size_t)j * b->G, b->d_refslot + (size_t)j * b->G, b->ntot);
+                  b->d_ws + (size_t)j * b->G, b->d_refslot + (size_t)j * b->G, b->ntot, b->h_log_eps);
       launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
     }
     if (b->d_Vabs && b->loss_kind != ODINN_LOSS_H) {
@@ -1733,6 +1734,13 @@ int odinn_set_surface_velocity_factor(odinn_batch* b, double f) {
   return ODINN_OK;
 }
 
+int odinn_set_thickness_loss_function(odinn_batch* b, int simple_loss, double eps) {
+  if (!b || (simple_loss != ODINN_SIMPLE_L2SUM && simple_loss != ODINN_SIMPLE_LOGSUM)) return fail(ODINN_ERR_ARG, "unknown simple loss");
+  if (simple_loss == ODINN_SIMPLE_LOGSUM && !(eps > 0.0)) return fail(ODINN_ERR_ARG, "LogSum needs eps > 0");
+  b->h_log_eps = simple_loss == ODINN_SIMPLE_LOGSUM ? eps : 0.0;
+  return ODINN_OK;
+}
+
 int odinn_set_velocity_loss_function(odinn_batch* b, int simple_loss, double eps) {
   if (b) b->refs_version++;
   if (!b || (simple_loss != ODINN_SIMPLE_L2SUM && simple_loss != ODINN_SIMPLE_LOGSUM)) return fail(ODINN_ERR_ARG, "unknown simple loss");
@@ -2056,7 +2064,7 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
                     b->any_sref ? b->d_Sref : nullptr, lam, lam, 1, 0);
     }
     AdjArgs A{};
-    A.H = Hj; A.lam = lam; A.out = lam_new; A.Href = b->d_Href; A.mask = b->d_mask;
+    A.H = Hj; A.lam = lam; A.out = lam_new; A.Href = b->d_Href; A.mask = b->d_mask; A.h_log_eps = b->h_log_eps;
     A.dts = b->d_dts + (size_t)j * b->G; A.ws = b->d_ws + (size_t)j * b->G;
     A.refslot = b->d_refslot + (size_t)j * b->G; A.ntot = b->ntot;
     Pools Pj = Psw;
@@ -2262,6 +2270,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   AdjPostArgs AP{};
   AP.adj = b->d_adj; AP.snaps = b->d_snaps; AP.premb = b->d_premb; AP.ntot = b->ntot; AP.mb0 = b->d_mb0;
   AP.Sref = b->any_sref ? b->d_Sref : nullptr; AP.Href = b->d_Href; AP.mask = b->d_mask; AP.ws = b->d_ws;
+  AP.h_log_eps = b->h_log_eps;
   // the theta-VJP of the A-type laws interpolates H at the quadrature node in its tile loader; the per-node MLP laws and
   // the velocity terms read it from d_tmpA, which the post-step then materialises
   const bool theta_itp = !useV && b->law_kind < ODINN_LAW_NN_Y;

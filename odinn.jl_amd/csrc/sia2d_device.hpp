@@ -1190,6 +1190,7 @@ struct AdjPostArgs {
   // aggH[agg_slot[snapj]] (zero for glaciers whose tLoss does not contain the stop); null: off
   const int* agg_slot;
   const double* aggH;
+  double h_log_eps;      // LossH's simple loss: 0 = L2Sum, > 0 = LogSum(eps)
 };
 
 __device__ __forceinline__ double mb_value(const GDev& g, double mb0, double sref, double H, double B, double& dmb) {
@@ -1265,7 +1266,21 @@ __device__ __forceinline__ double node_Da(const GDev& g, const double2* p, const
 //     out = J_H(H)^T lam                                               (MODE 0)
 // and the masked L2 loss partial (Losses.jl:133-141) as a by-product in MODE 1.
 // =====================================================================================
+// the simple loss of LossH on one cell (Losses.jl:133-152 L2Sum, :207-229 LogSum(eps)): d = the factor of 2 w / N in dl/dH,
+// q = the cell's share of the loss.  eps == 0: L2Sum.
+__device__ __forceinline__ void simple_loss_terms(double a, double b, double eps, double& d, double& q) {
+  if (eps > 0.0) {
+    const double lg = log((a + eps) / (b + eps));
+    d = lg / (a + eps);
+    q = lg * lg;
+  } else {
+    d = a - b;
+    q = d * d;
+  }
+}
+
 struct AdjArgs {
+  double h_log_eps;    // LossH's simple loss: 0 = L2Sum, > 0 = LogSum(eps)
   const double* H;     // snapshot (pooled)
   const double* lam;   // pooled
   double* out;         // pooled
@@ -1529,10 +1544,10 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_
   long long roff = 0;
   // loss data of this thread's cells (MODE 1 at a data stop), fetched before the stencil phase so
   // that its latency hides behind it: hd[m] = H - Href where the mask is set, else 0
-  double hd[RPT];
+  double hd[RPT], hq[RPT];
   bool hm[RPT];
 #pragma unroll
-  for (int m = 0; m < RPT; ++m) { hd[m] = 0.0; hm[m] = false; }
+  for (int m = 0; m < RPT; ++m) { hd[m] = 0.0; hq[m] = 0.0; hm[m] = false; }
   if (MODE == 1) {
     dt = A.dts[t4.x];
     w = A.ws ? A.ws[t4.x] : 0.0;
@@ -1545,7 +1560,7 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_
           const long long id = g.off + gi + (long long)g.nx * gj;
           if (A.mask[roff + id]) {
             hm[m] = true;
-            hd[m] = ownH[m] - A.Href[roff + id];
+            simple_loss_terms(ownH[m], A.Href[roff + id], A.h_log_eps, hd[m], hq[m]);
           }
         }
       }
@@ -1567,7 +1582,7 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_
         double o = fma(dt, v[m], ownL[m]);
         if (hm[m]) {
           o = fma(w * 2.0 * Ninv, hd[m], o);
-          lsum = fma(hd[m], hd[m], lsum);
+          lsum += hq[m];
         }
         A.out[id] = o;
       }
@@ -1862,7 +1877,7 @@ __global__ __launch_bounds__(64) void k_sum_part_theta(Pools P, const double* pa
 // masked L2 loss partial of one snapshot (forward loss, inversion_utils.jl:425-461)
 __global__ __launch_bounds__(NT) void k_loss(Pools P, const double* __restrict__ H, const double* __restrict__ Href,
                                              const unsigned char* __restrict__ mask, const double* ws,
-                                             const int* refslot, long long ntot) {
+                                             const int* refslot, long long ntot, double log_eps) {
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x];
   const GDev g = P.gd[t4.x];
@@ -1878,7 +1893,11 @@ __global__ __launch_bounds__(NT) void k_loss(Pools P, const double* __restrict__
       const int gj = j0 + ty + NW * m;
       if (gi < g.nx && gj < g.ny) {
         const long long id = g.off + gi + (long long)g.nx * gj;
-        if (mask[roff + id]) { const double d = H[id] - Href[roff + id]; s = fma(d, d, s); }
+        if (mask[roff + id]) {
+          double d, q;
+          simple_loss_terms(H[id], Href[roff + id], log_eps, d, q);
+          s += q;
+        }
       }
     }
   }
@@ -2240,8 +2259,11 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
       if (a.snapj >= 0) {
         double l = U[id];
         double dl = 0.0;
-        if (w != 0.0 && A.mask[roff + id])
-          dl = w * 2.0 * Ninv * (A.snaps[(long long)a.snapj * A.ntot + id] - A.Href[roff + id]);
+        if (w != 0.0 && A.mask[roff + id]) {
+          double d, q;
+          simple_loss_terms(A.snaps[(long long)a.snapj * A.ntot + id], A.Href[roff + id], A.h_log_eps, d, q);
+          dl = w * 2.0 * Ninv * d;
+        }
         double dagg = 0.0;
         if (A.dh_coef) {
           const int q0 = A.dh_i0[t4.x], q1 = A.dh_i1[t4.x];

@@ -851,6 +851,15 @@ def logsum_backward(a, b, mask, normalization, eps):
     return 2.0 * d / normalization
 
 
+def hloss(a, b, mask, normalization, eps=None):
+    """The simple loss inside LossH: L2Sum (eps None) or LogSum(eps)."""
+    return l2sum_loss(a, b, mask, normalization) if eps is None else logsum_loss(a, b, mask, normalization, eps)
+
+
+def hloss_backward(a, b, mask, normalization, eps=None):
+    return l2sum_backward(a, b, mask, normalization) if eps is None else logsum_backward(a, b, mask, normalization, eps)
+
+
 # ----------------------------------------------------------------------------
 # Time integration: RDPK3Sp35 (3S*+ low-storage, 5 stages, order 3(2)),
 # Ranocha, Dalcin, Parsani, Ketcheson (2022) "Optimized Runge-Kutta methods with
@@ -1077,6 +1086,7 @@ class SimConfig:
     # VelocityRegularization (src/losses/Regularization.jl:64-79,192-245): Tikhonov penalty on the Laplacian of the predicted
     # surface speed at the velocity-data times `vreg_times` (weights Delta-t.V = their differences), mask =
     # is_in_glacier(H_pred, vreg_distance) & (V > 0), MultiLoss weight vreg_weight (0: off)
+    h_log_eps: Optional[float] = None  # LossH's simple loss: None = L2Sum, eps = LogSum(eps) (Losses.jl:34-49)
     vreg_times: Sequence[float] = ()
     vreg_distance: int = 3
     vreg_weight: float = 0.0
@@ -1108,7 +1118,7 @@ def loss_weights(tstops, tH_ref):
     return w
 
 
-def loss_H(snaps, tstops, H_ref, tH_ref, distance):
+def loss_H(snaps, tstops, H_ref, tH_ref, distance, log_eps=None):
     """sum_tau w_tau * L2Sum(H_tau, Href_tau)/N  (inversion_utils.jl:425-461, Losses.jl:250-270)."""
     w = loss_weights(tstops, tH_ref)
     tH = list(tH_ref)
@@ -1117,7 +1127,7 @@ def loss_H(snaps, tstops, H_ref, tH_ref, distance):
     for j, t in enumerate(tstops):
         if t in tH and w[j] != 0.0:
             Hr = H_ref[tH.index(t)]
-            tot += l2sum_loss(snaps[j], Hr, is_in_glacier(Hr, distance), N) * w[j]
+            tot += hloss(snaps[j], Hr, is_in_glacier(Hr, distance), N, log_eps) * w[j]
     return tot
 
 
@@ -1302,8 +1312,8 @@ def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=No
         if tj in tH and w[j] != 0.0:
             Hr = H_ref[tH.index(tj)]
             mask = is_in_glacier(Hr, cfg.loss_distance)
-            dl = l2sum_backward(snaps[j], Hr, mask, N) * w[j]
-            loss_rev += l2sum_loss(snaps[j], Hr, mask, N) * w[j]
+            dl = hloss_backward(snaps[j], Hr, mask, N, cfg.h_log_eps) * w[j]
+            loss_rev += hloss(snaps[j], Hr, mask, N, cfg.h_log_eps) * w[j]
         else:
             dl = 0.0
         if j in dl_agg:  # :212-215 (like every dl/dH of the first stop, the j = 0 term is never used: there is no lambda[-1])
@@ -1314,7 +1324,7 @@ def loss_and_grad(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, theta=No
             lam[j - 1] = lam[j] + dt * g + dl  # :242
             dth = vjp_theta(lam[j - 1], snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, theta)  # :245-246
             dLdtheta += dt * dth  # :249
-    loss_fwd = loss_H(snaps, t, H_ref, tH_ref, cfg.loss_distance)
+    loss_fwd = loss_H(snaps, t, H_ref, tH_ref, cfg.loss_distance, cfg.h_log_eps)
     assert math.isclose(loss_rev, loss_fwd, rel_tol=1e-8, abs_tol=0.0) or loss_fwd == 0.0  # :259
     return loss_fwd + l_agg, dLdtheta + dth_agg, lam[0]  # :254-255, :274
 
@@ -1391,7 +1401,7 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
         j = t.index(tt)
         if wH[j] != 0.0:
             Hr = H_ref[tH.index(tt)]
-            u = u + l2sum_backward(H_itp(tt), Hr, is_in_glacier(Hr, cfg.loss_distance), N) * wH[j]
+            u = u + hloss_backward(H_itp(tt), Hr, is_in_glacier(Hr, cfg.loss_distance), N, cfg.h_log_eps) * wH[j]
         if wV[j] != 0.0:
             Va, Vxr, Vyr = V_ref[tV.index(tt)]
             gH, _ = backward_loss_V(vspec, H_itp(tt), gl.B, gl.dx, gl.dy, gl.phys, law, Va, Vxr, Vyr, N, theta)
@@ -1437,7 +1447,7 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
         for j in range(k):
             if wH[j] != 0.0:
                 Hr = H_ref[tH.index(t[j])]
-                loss += l2sum_loss(snaps[j], Hr, is_in_glacier(Hr, cfg.loss_distance), N) * wH[j]
+                loss += hloss(snaps[j], Hr, is_in_glacier(Hr, cfg.loss_distance), N, cfg.h_log_eps) * wH[j]
     if useV:
         for j in range(k):
             if wV[j] != 0.0:
@@ -1772,8 +1782,8 @@ def loss_and_grad_HV(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_ref, V_ref
         if wH[j] != 0.0:
             Hr = H_ref[tH.index(tj)]
             mask = is_in_glacier(Hr, cfg.loss_distance)
-            dl = dl + l2sum_backward(snaps[j], Hr, mask, N) * wH[j]
-            loss_tot += l2sum_loss(snaps[j], Hr, mask, N) * wH[j]
+            dl = dl + hloss_backward(snaps[j], Hr, mask, N, cfg.h_log_eps) * wH[j]
+            loss_tot += hloss(snaps[j], Hr, mask, N, cfg.h_log_eps) * wH[j]
         if wV[j] != 0.0:
             Va, Vxr, Vyr = V_ref[tV.index(tj)]
             gH, gth = backward_loss_V(vspec, snaps[j], gl.B, gl.dx, gl.dy, gl.phys, law, Va, Vxr, Vyr, N, theta)

@@ -945,3 +945,40 @@ def test_strip_H_vjp_matches_the_tile_kernel(gpu, monkeypatch):
     wth = O.vjp_theta(lam, H, B, 60.0, 60.0, ph, O.Law(kind=O.LAW_CONST_A, A=4e-17))
     assert abs(b.vjp_theta(0, lam, H)[0] - wth[0]) <= 1e-11 * abs(wth[0])
     b.close()
+
+
+@pytest.mark.parametrize("adjoint", ["discrete", "continuous"])
+def test_lossH_with_logsum(gpu, adjoint):
+    """LossH(loss = LogSum(eps)) (Losses.jl:34-49,207-229): log^2((H + eps) / (H_ref + eps)) on the reference mask in both
+    adjoints (tile H-VJP kernel MODE 1, k_loss, k_adj_poststep) against the oracle, with a mass balance."""
+    nx, ny = 64, 48
+    ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, True)
+    cfg.h_log_eps = 0.1
+    law0 = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=om, theta=th0, T=-2.0)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-2.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_A_SCALAR, gm, th0)
+    b.set_reference(0, ts, ref, 3)
+    b.set_mass_balance(0, mb.mb0, mb.dmb_dS, mb.S_ref, mb.mb_max)
+    b.set_thickness_loss_function(0.1)
+    if adjoint == "discrete":
+        Lo, go, lam0 = O.loss_and_grad(gl, law0, cfg, ref, ts)
+        Lg, gg = b.loss_grad(ts, theta=th0, mb_times=ts[1:], reltol=1e-8)
+    else:
+        # LogSum puts 1 / (H + eps) into the loss term: lambda is large and sharp on the thin margin cells, and the adaptive
+        # reverse solve resolves it to its tolerance only -- the comparison of lambda(t0) runs at tighter reverse tolerances
+        Lo, go, lam0, _ = O.loss_and_grad_continuous(gl, law0, cfg, ref, ts,
+                                                     O.ContinuousAdjointCfg(n_quadrature=16, reltol=1e-10, abstol=1e-12))
+        Lg, gg = b.loss_grad_continuous(ts, theta=th0, mb_times=ts[1:], reltol=1e-8, n_quadrature=16, adj_reltol=1e-10,
+                                        adj_abstol=1e-12)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-9 and relerr < 1e-5, (ratio, angle, relerr)
+    assert rel_l2(b.lambda0(0), lam0) < (1e-5 if adjoint == "discrete" else 1e-4)
+    b.solve(ts, mb_times=ts[1:], reltol=1e-8)
+    assert abs(b.loss()[0] - Lg) <= 1e-8 * abs(Lg)
+    # it is not the L2 loss
+    b.set_thickness_loss_function(None)
+    L2, _ = b.loss_grad(ts, theta=th0, mb_times=ts[1:], reltol=1e-8)
+    assert abs(L2 - Lg) > 1e-3 * abs(Lg)
+    b.close()
