@@ -66,6 +66,17 @@ function set_time_aggregated_losses!(b::Batch, simulation)
     terms = lf isa ODINN.MultiLoss ? collect(zip(lf.losses, lf.λs)) : [(lf, 1.0)]
     wdata = something(findfirst(t -> t[1] isa Union{ODINN.LossH, ODINN.LossV, ODINN.LossHV}, terms), 0)
     wdata = wdata == 0 ? 1.0 : terms[wdata][2]
+    # the simple loss inside the data terms: L2Sum (default) or LogSum(ϵ) (Losses.jl:34-49)
+    for (l, _) in terms
+        hl = l isa ODINN.LossHV ? l.hLoss : l isa ODINN.LossH ? l : nothing
+        vl = l isa ODINN.LossHV ? l.vLoss : l isa ODINN.LossV ? l : nothing
+        if !isnothing(hl) && hl.loss isa ODINN.LogSum
+            check(ccall((:odinn_set_thickness_loss_function, lib), Cint, (Ptr{Cvoid}, Cint, Cdouble), b.h, 1, hl.loss.ϵ))
+        end
+        if !isnothing(vl) && vl.loss isa ODINN.LogSum
+            check(ccall((:odinn_set_velocity_loss_function, lib), Cint, (Ptr{Cvoid}, Cint, Cdouble), b.h, 1, vl.loss.ϵ))
+        end
+    end
     for (l, w) in terms
         if l isa ODINN.LossDhdt
             for (i, g) in enumerate(simulation.glaciers)
