@@ -1024,121 +1024,157 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
     if (C.cfl > 0.0) {
       for (int k = threadIdx.x; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
     } else {
-      for (int k = threadIdx.x; k < nt; k += 64) s += C.errpart[(long long)C.stride * (t0 + k)];
+      // (the loads of up to eight rounds are issued before the first addition; same order of the additions)
+      for (int k0 = threadIdx.x; k0 < nt; k0 += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = k0 + 64 * q;
+          v[q] = k < nt ? C.errpart[(long long)C.stride * (t0 + k)] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (k0 + 64 * q < nt) s += v[q];
+      }
     }
   }
   // fixed-shape tree: lane l holds sum of tiles l, l+64, ... ; then butterfly
   s = C.cfl > 0.0 ? wave_max(s) : wave_sum(s);
+  // the three powers of the PID factor are evaluated by lanes 0..2 side by side (one pow's latency instead of three on the
+  // single-thread critical path of this kernel; same values, same order of the product)
+  double pw0 = 1.0, pw1 = 1.0, pw2 = 1.0;
+  if (C.adaptive && !(C.cfl > 0.0)) {
+    const double sb = __shfl(s, 0, 64);
+    double EEst = sqrt(sb / ((double)g.nx * (double)g.ny));
+    if (!(EEst == EEst) || isinf(EEst)) EEst = 1e300;
+    if (EEst < 2.220446049250313e-16) EEst = 2.220446049250313e-16;
+    const int l = threadIdx.x;
+    const double base = l == 0 ? 1.0 / EEst : (l == 1 ? gs->e2 : gs->e3);
+    const double ex = l == 0 ? 0.64 / 3.0 : (l == 1 ? -0.31 / 3.0 : 0.04 / 3.0);
+    const double pw = l < 3 ? pow(base, ex) : 1.0;
+    pw0 = __shfl(pw, 0, 64); pw1 = __shfl(pw, 1, 64); pw2 = __shfl(pw, 2, 64);
+  }
   if (threadIdx.x != 0) return;
+  // one thread from here on: the per-glacier state is taken into registers once and written back once (dozens of dependent
+  // global read-modify-writes through `gs->` otherwise: the kernel spent most of its 8 us on them)
+  GState st = *gs;
+  AdjState ad{};
+  if (C.adj) ad = C.adj[gidx];
   if (C.cfl > 0.0) {
     // explicit Euler, always accepted; the next dt comes from the max diffusivity just measured
-    if (!(s == s) || isinf(s)) gs->nonfinite = 1;
-    double t = gs->t;
-    gs->at_stop = 0;
-    gs->mb_now = 0;
-    gs->EEst = s;
+    if (!(s == s) || isinf(s)) st.nonfinite = 1;
+    double t = st.t;
+    st.at_stop = 0;
+    st.mb_now = 0;
+    st.EEst = s;
     if (!C.cfl_prime) {
-      gs->naccept++;
-      gs->accepted = 1;
-      gs->cur = C.next_cur;
-      if (gs->clipped) {
-        t = C.tstops[gs->istop];
-        gs->at_stop = 1;
-        gs->mb_now = C.mb_flag[gs->istop];
-        gs->mb_slot = C.mb_slot[gs->istop];
-        gs->istop++;
+      st.naccept++;
+      st.accepted = 1;
+      st.cur = C.next_cur;
+      if (st.clipped) {
+        t = C.tstops[st.istop];
+        st.at_stop = 1;
+        st.mb_now = C.mb_flag[st.istop];
+        st.mb_slot = C.mb_slot[st.istop];
+        st.istop++;
       } else {
-        t += gs->dt;
+        t += st.dt;
       }
-      gs->t = t;
-      if (gs->istop >= C.n_stops) {
-        gs->done = 1;
+      st.t = t;
+      if (st.istop >= C.n_stops) {
+        st.done = 1;
         atomicSub(C.n_active, 1);
+        *gs = st;
         return;
       }
     }
     const double dmin = fmin(g.dx, g.dy);
-    const double rem = C.tstops[gs->istop] - t;
+    const double rem = C.tstops[st.istop] - t;
     double dtn = s > 0.0 ? C.cfl * dmin * dmin / (4.0 * s) : rem;
     if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
     if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
       dtn = rem;
-      gs->clipped = 1;
+      st.clipped = 1;
     } else {
-      gs->clipped = 0;
+      st.clipped = 0;
     }
-    gs->dt = dtn;
+    st.dt = dtn;
+    *gs = st;
     return;
   }
-  const double h = gs->dt;
+  const double h = st.dt;
   double fac = 1.0;
   bool accept = true;
   if (C.adaptive) {
     double EEst = sqrt(s / ((double)g.nx * (double)g.ny));
-    if (!(EEst == EEst) || isinf(EEst)) { gs->nonfinite = 1; EEst = 1e300; }
+    if (!(EEst == EEst) || isinf(EEst)) { st.nonfinite = 1; EEst = 1e300; }
     if (EEst < 2.220446049250313e-16) EEst = 2.220446049250313e-16;
-    gs->EEst = EEst;
+    st.EEst = EEst;
     const double e1 = 1.0 / EEst;
-    fac = pow(e1, 0.64 / 3.0) * pow(gs->e2, -0.31 / 3.0) * pow(gs->e3, 0.04 / 3.0);
+    fac = pw0 * pw1 * pw2;  // pow(e1, 0.64 / 3) * pow(e2, -0.31 / 3) * pow(e3, 0.04 / 3)
     fac = 1.0 + atan(fac - 1.0);
     accept = fac >= 0.81;
-    if (accept) { gs->e3 = gs->e2; gs->e2 = e1; }
+    if (accept) { st.e3 = st.e2; st.e2 = e1; }
   }
-  double t = gs->t;
-  gs->at_stop = 0;
-  gs->mb_now = 0;
-  if (C.adj) { C.adj[gidx].qw = 0.0; C.adj[gidx].snapj = -1; }
+  double t = st.t;
+  st.at_stop = 0;
+  st.mb_now = 0;
+  if (C.adj) { ad.qw = 0.0; ad.snapj = -1; }
   if (accept) {
-    gs->naccept++;
-    gs->accepted = 1;
-    gs->cur = C.next_cur >= 0 ? C.next_cur : 1 - gs->cur;
-    if (gs->clipped) {
-      t = C.tstops[gs->istop];
-      gs->at_stop = 1;
-      gs->mb_now = C.mb_flag[gs->istop];
-      gs->mb_slot = C.mb_slot[gs->istop];
+    st.naccept++;
+    st.accepted = 1;
+    st.cur = C.next_cur >= 0 ? C.next_cur : 1 - st.cur;
+    if (st.clipped) {
+      t = C.tstops[st.istop];
+      st.at_stop = 1;
+      st.mb_now = C.mb_flag[st.istop];
+      st.mb_slot = C.mb_slot[st.istop];
       if (C.adj) {
-        AdjState* a = C.adj + gidx;
-        a->snapj = C.stop_snap[gs->istop];
-        a->qw = C.stop_qw[gs->istop];
+        AdjState* a = &ad;
+        a->snapj = C.stop_snap[st.istop];
+        a->qw = C.stop_qw[st.istop];
         a->seg_stop = a->seg;
         const double ta = C.tsnap[a->seg];
         a->s_stop = a->snapj >= 0 ? (a->snapj == a->seg ? 0.0 : 1.0) : (-t - ta) / (C.tsnap[a->seg + 1] - ta);
         if (a->snapj >= 1) a->seg = a->snapj - 1;  // the next steps run below snapshot j
       }
-      gs->istop++;
+      st.istop++;
     } else {
       t += h;
     }
-    gs->t = t;
+    st.t = t;
   } else {
-    gs->nreject++;
-    gs->accepted = 0;
+    st.nreject++;
+    st.accepted = 0;
   }
-  if (C.qw_out) C.qw_out[gidx] = C.adj[gidx].qw;
-  if (gs->istop >= C.n_stops) {
-    gs->done = 1;
+  if (C.qw_out) C.qw_out[gidx] = ad.qw;
+  if (st.istop >= C.n_stops) {
+    st.done = 1;
     atomicSub(C.n_active, 1);
     if (C.est_steps) C.est_steps[gidx] = 0;
+    *gs = st;
+    if (C.adj) C.adj[gidx] = ad;
     return;
   }
   double dtn = C.adaptive ? h * fac : C.fixed_dt;
   if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
-  const double rem = C.tstops[gs->istop] - t;
+  const double rem = C.tstops[st.istop] - t;
   // snap to the stop when the step would end within 100 ulp of it
   if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
     dtn = rem;
-    gs->clipped = 1;
+    st.clipped = 1;
   } else {
-    gs->clipped = 0;
+    st.clipped = 0;
   }
-  gs->dt = dtn;
+  st.dt = dtn;
   if (C.est_steps) {  // at the current step size, and at least one step per remaining stop
     const double e = ceil((C.tstops[C.n_stops - 1] - t) / (C.adaptive ? h * fac : dtn));
-    const int stops_left = C.n_stops - gs->istop;
+    const int stops_left = C.n_stops - st.istop;
     C.est_steps[gidx] = e < (double)stops_left ? stops_left : (e > 1e6 ? 1000000 : (int)e);
   }
-  if (C.adj) adj_stage_weights(C.adj + gidx, C.tsnap, t, dtn, false);
+  if (C.adj) adj_stage_weights(&ad, C.tsnap, t, dtn, false);
+  *gs = st;
+  if (C.adj) C.adj[gidx] = ad;
 }
 
 #endif  // ODINN_MISC_KERNELS
