@@ -110,8 +110,8 @@ void launch_vreg_cot(int nblk, hipStream_t st, Pools P, const double* r, const d
 void launch_seg_pairs(long long ntot, int n_seg, hipStream_t st, const double* snaps, double2* segs) {
   hipLaunchKernelGGL(k_seg_pairs, dim3(65536), dim3(256), 0, st, ntot, n_seg, snaps, segs);
 }
-void launch_sum_tilesFt(int G, hipStream_t st, Pools P, const double* part, double* out) {
-  hipLaunchKernelGGL(k_sum_tilesFt, dim3(G), dim3(64), 0, st, P, part, out);
+void launch_sum_tilesFt(int G, int rows, hipStream_t st, Pools P, const double* part, double* out) {
+  hipLaunchKernelGGL(k_sum_tilesFt, dim3(G), dim3(64), 0, st, P, part, out, rows);
 }
 void launch_lerp(long long n, hipStream_t st, double s, const double* a, const double* b, double* out) {
   const long long nb = (n + 255) / 256;

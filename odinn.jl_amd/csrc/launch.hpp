@@ -32,7 +32,7 @@ void launch_euler_cfl_strip(int nblk, int afield, hipStream_t st, Pools P, const
 constexpr int DHDT_OX = 62, DHDT_OY = 62;  // output tile of k_dhdt_strip (sia2d_fused.hpp: DOX, DOY)
 
 // k_adjf.hip, law mode 0 only
-void launch_adj_fused_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, AdjFusedArgs A);
+void launch_adj_fused_strip(int nblk, int afield, int skip, int rows, hipStream_t st, Pools P, AdjFusedArgs A);
 void launch_vjp_H_strip(int mode, int afield, int nblk, hipStream_t st, Pools P, const int4* tilesD, AdjArgs A);
 void launch_vjp_theta_strip(int gacc, int itp, int nblk, hipStream_t st, Pools P, const int4* tilesD, ThArgs A);
 
@@ -84,7 +84,7 @@ void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const dou
 void launch_axpy(long long n, hipStream_t st, double a, const double* x, const double* y, double* z);  // z = y + a x
 void launch_lerp(long long n, hipStream_t st, double s, const double* a, const double* b, double* out);  // out = a + s (b - a)
 void launch_seg_pairs(long long ntot, int n_seg, hipStream_t st, const double* snaps, double2* segs);
-void launch_sum_tilesFt(int G, hipStream_t st, Pools P, const double* part, double* out);
+void launch_sum_tilesFt(int G, int rows, hipStream_t st, Pools P, const double* part, double* out);
 // VelocityRegularization (Regularization.jl:192-245): see k_vreg_* in sia2d_device.hpp
 void launch_vreg_prep(int nblk, hipStream_t st, Pools P, const double* H, const double* vx, const double* vy, const double* w,
                       int dist, double* Vabs, unsigned char* mask);

@@ -132,12 +132,12 @@ struct odinn_batch {
   // device pools
   int* d_est = nullptr;        // per-glacier estimate of the steps still needed (written by the controller)
   std::vector<int> h_est;
-  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr, *d_tilesFu = nullptr;
+  int4 *d_tiles = nullptr, *d_tiles_nat = nullptr, *d_tilesF = nullptr, *d_tilesFs = nullptr, *d_tilesFt = nullptr, *d_tilesFu = nullptr, *d_tilesFv = nullptr;
   int4* d_tilesD = nullptr;  // 62 x 62 tiles of the RHS-only strip kernel (all glaciers, XCD-banded)
   double* d_partD = nullptr; // per-tile max D of the CFL Euler step in that layout
   int ntilesD = 0;
-  int ntilesF = 0, ntilesFs = 0, ntilesFt = 0, ntilesFu = 0;
-  double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr, *d_partFu = nullptr;
+  int ntilesF = 0, ntilesFs = 0, ntilesFt = 0, ntilesFu = 0, ntilesFv = 0;
+  double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr, *d_partFu = nullptr, *d_partFv = nullptr;
   static int sc_env() {  // ODINN_STEP_SC: -1 unset, 0 off, 1 forced on
     const char* e = std::getenv("ODINN_STEP_SC");
     return !e ? -1 : (e[0] == '1' ? 1 : 0);
@@ -1256,13 +1256,14 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
   HIPCHK(hipMemcpy(b->d_tiles_nat, nat.data(), sizeof(int4) * nat.size(), hipMemcpyHostToDevice));
   // tile tables of the fused-step kernel, same XCD-banded order: FOX x FOY "throughput" tiles and
   // FOX x FOYS "latency" tiles (used when the batch has too few throughput tiles to fill the GPU)
-  for (int small = 0; small < 4; ++small) {
-    const int foy = small == 3 ? FOYT8 : small == 2 ? FOYT : small ? FOYS : FOY;
+  for (int small = 0; small < 5; ++small) {
+    const int foy = small == 4 ? FOYT4 : small == 3 ? FOYT8 : small == 2 ? FOYT : small ? FOYS : FOY;
     std::vector<int4> natF;
     for (int g = 0; g < n_glaciers; ++g) {
       GDev& r = b->gd[g];
       const int fx = (r.nx + FOX - 1) / FOX, fy = (r.ny + foy - 1) / foy;
-      if (small == 3) { r.tile0Fu = (int)natF.size(); r.ntilesFu = fx * fy; }
+      if (small == 4) { r.tile0Fv = (int)natF.size(); r.ntilesFv = fx * fy; }
+      else if (small == 3) { r.tile0Fu = (int)natF.size(); r.ntilesFu = fx * fy; }
       else if (small == 2) { r.tile0Ft = (int)natF.size(); r.ntilesFt = fx * fy; }
       else if (small) { r.tile0Fs = (int)natF.size(); r.ntilesFs = fx * fy; }
       else { r.tile0F = (int)natF.size(); r.ntilesF = fx * fy; }
@@ -1277,7 +1278,12 @@ int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* des
         const int t = x * per + r;
         if (t < nF) swzF.push_back(natF[t]);
       }
-    if (small == 3) {
+    if (small == 4) {
+      b->ntilesFv = nF;
+      CHK(dalloc(&b->d_tilesFv, (size_t)nF));
+      CHK(dalloc(&b->d_partFv, (size_t)nF));
+      HIPCHK(hipMemcpy(b->d_tilesFv, swzF.data(), sizeof(int4) * nF, hipMemcpyHostToDevice));
+    } else if (small == 3) {
       b->ntilesFu = nF;
       CHK(dalloc(&b->d_tilesFu, (size_t)nF));
       CHK(dalloc(&b->d_partFu, (size_t)nF));
@@ -1352,7 +1358,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
-  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt); dfree(b->d_tilesFu); dfree(b->d_partFu); dfree(b->d_est); dfree(b->d_gs2); dfree(b->d_part2);
+  dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt); dfree(b->d_tilesFu); dfree(b->d_partFu); dfree(b->d_tilesFv); dfree(b->d_partFv); dfree(b->d_est); dfree(b->d_gs2); dfree(b->d_part2);
   dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_tsnap); dfree(b->d_qw); dfree(b->d_rsnap); dfree(b->d_rmbf);
   dfree(b->d_rmbs); dfree(b->d_adj);
   dfree(b->d_partsteps);
@@ -2354,6 +2360,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   if (const char* e = std::getenv("ODINN_ADJ_FUSED")) fused_rev = fused_rev && e[0] != '0';
   const int rev_skip = []() { const char* e = std::getenv("ODINN_ADJ_SKIP"); return (e && e[0] == '0') ? 0 : 1; }();
   AdjFusedArgs FA{};
+  int adj_rows = TRPT;  // rows per thread of the fused reverse step
   if (fused_rev) {
     FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
     FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = ao.abstol; FA.reltol = ao.reltol;
@@ -2376,16 +2383,32 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       launch_seg_pairs(b->ntot, k - 1, b->stream, b->d_snaps, b->d_segs);
       FA.segs = b->d_segs;
     }
+    // small batches: the 4-rows-per-thread instantiation (54 x 22 output tiles).  A launch lasts about (tiles on the busiest
+    // CU) x (rows per thread) while at most two 7-row workgroups share a CU: 4 rows do more halo work per cell but quantise
+    // finer (measured, continuous gradient, 7 -> 4 rows: 4 / 8 / 12 alpine glaciers 11.8 -> 9.5 / 12.0 -> 9.8 / 12.1 -> 9.9 ms,
+    // 16 / 24: ties within 3 %, 32: 16.3 -> 13.4, 48 / 64: 7 rows win; 1 x 256^2 ... 512^2: 8.2 -> 6.6 ms, 768^2 and up: 7 rows
+    // win -- the model's order every time).  ODINN_ADJ_ROWS=4|7 forces either
+    if (FA.segs) {
+      const char* er = std::getenv("ODINN_ADJ_ROWS");
+      const long cu = b->n_cus();
+      const bool model = b->ntilesFt <= 2 * cu && 4 * ((b->ntilesFv + cu - 1) / cu) < 7 * ((b->ntilesFt + cu - 1) / cu);
+      if (er ? er[0] == '4' : model) {
+        adj_rows = 4;
+        FA.partF = b->d_partFv; FA.tilesF = b->d_tilesFv;
+        C.errpart = b->d_partFv; C.fused = 6;
+      }
+    }
+    const int ntilesR = adj_rows == 4 ? b->ntilesFv : b->ntilesFt;
     // A-type laws without a dual-grid accumulator: the theta-VJP of a quadrature node is formed by stage 1 of the step that
     // follows the node (same lambda, same H_itp) instead of a launch of its own (ODINN_ADJ_THETA_FUSED=0: separate launches)
     const char* et = std::getenv("ODINN_ADJ_THETA_FUSED");
     if (acc_inplace && !b->wants_Gacc() && !(et && et[0] == '0')) {
-      if ((size_t)b->ntilesFt > b->partTh_cap) {
+      if ((size_t)ntilesR > b->partTh_cap) {
         dfree(b->d_partTh);
-        CHK(dalloc(&b->d_partTh, (size_t)b->ntilesFt));
-        b->partTh_cap = (size_t)b->ntilesFt;
+        CHK(dalloc(&b->d_partTh, (size_t)ntilesR));
+        b->partTh_cap = (size_t)ntilesR;
       }
-      HIPCHK(hipMemsetAsync(b->d_partTh, 0, (size_t)b->ntilesFt * sizeof(double), b->stream));
+      HIPCHK(hipMemsetAsync(b->d_partTh, 0, (size_t)ntilesR * sizeof(double), b->stream));
       FA.th_part = b->d_partTh;
     }
   }
@@ -2404,7 +2427,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       if (fused_rev) {
         // the whole step in one kernel: reads lam[cur], writes lam[1 - cur] per glacier; the controller flips cur
         // on acceptance (a rejected step is simply repeated from the untouched lam[cur])
-        launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, rev_skip, b->stream, Pl, FA);
+        launch_adj_fused_strip(adj_rows == 4 ? b->ntilesFv : b->ntilesFt, b->gd[0].use_Afield, rev_skip, adj_rows, b->stream, Pl, FA);
         C.next_cur = -1;
       } else {
         // five stages ping-pong lam[p] -> lam[1-p] -> ... ; the step's result lands in lam[1-p]
@@ -2470,7 +2493,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     }
   }
   if (acc_inplace) launch_sum_part_steps(G, b->stream, Pl, b->d_partsteps, 4LL * b->ntiles, 0, 0, 2, b->d_Gsum);
-  if (theta_fused) launch_sum_tilesFt(G, b->stream, Pl, b->d_partTh, b->d_Gsum);
+  if (theta_fused) launch_sum_tilesFt(G, adj_rows, b->stream, Pl, b->d_partTh, b->d_Gsum);
   // lambda(t0) of every glacier -> d_lam[0] (glaciers finish in different ping-pong buffers)
   if (mixed || gs[0].cur != 0) {
     for (int g = 0; g < G; ++g)
@@ -2740,7 +2763,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
       FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
       FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = 1e-8; FA.reltol = 1e-8;
       { const char* es = std::getenv("ODINN_ADJ_SEGS"); if (!(es && es[0] == '0')) FA.segs = b->d_segs; }
-      launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, std::getenv("ODINN_TIMED_ADJ_SKIP") ? 1 : 0, b->stream, P, FA);
+      launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, std::getenv("ODINN_TIMED_ADJ_SKIP") ? 1 : 0, TRPT, b->stream, P, FA);
       return ODINN_OK;
     }
     case ODINN_TIMED_LAW_FIELD:

@@ -29,7 +29,7 @@ namespace odinn {
 typedef double2 (*AdjEdgesHS)[TNW][2][FRX];
 typedef double (*AdjEdgesL)[TNW][2][FRX];
 
-// ODINN_ADJ_ELDS: the embedded-error accumulator of the thread's rows lives in a thread-private LDS column instead of 2 TRPT
+// ODINN_ADJ_ELDS: the embedded-error accumulator of the thread's rows lives in a thread-private LDS column instead of 2 NR
 // VGPRs (it is touched once per row and stage)
 #ifndef ODINN_ADJ_ELDS
 #define ODINN_ADJ_ELDS 1
@@ -42,14 +42,14 @@ typedef double (*AdjEdgesL)[TNW][2][FRX];
 #endif
 typedef double (*AdjErr)[FRX];
 
-template <int S, bool AF, bool SG>
+template <int S, bool AF, bool SG, int NR>
 __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __restrict__ Afield, const double* __restrict__ Ha,
                                                  const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
                                                  int gic, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
-                                                 AdjEdgesL sLm, double (&u)[TRPT], double (&tmp)[TRPT], double (&E)[TRPT],
+                                                 AdjEdgesL sLm, double (&u)[NR], double (&tmp)[NR], double (&E)[NR],
                                                  const double* __restrict__ Bp, AdjErr sEr, double* __restrict__ th_red) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;
-  const int r0 = TRPT * w;
+  const int r0 = NR * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
   const bool intx = gi >= 1 && gi <= g.nx - 2;
   constexpr int s = S - 1;
@@ -78,7 +78,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     const int gj = gj0 + r0 + m;
     return (intx && gj >= 1 && gj <= g.ny - 2) ? u[m] : 0.0;
   };
-  // the rows just outside the strip (the outermost wavefronts read their own edge: rows 0 and TRY-1 are never in region_S)
+  // the rows just outside the strip (the outermost wavefronts read their own edge: rows 0 and (NR * TNW)-1 are never in region_S)
   const int wb = w > 0 ? w - 1 : 0, eb = w > 0 ? 1 : 0, wt = w + 1 < TNW ? w + 1 : w, et = w + 1 < TNW ? 0 : 1;
   const double2 hs_s = sE[rd][wb][eb][lane], hs_top = sE[rd][wt][et][lane];
   const double le_s = sLm[rd][wb][eb][lane], le_top = sLm[rd][wt][et][lane];
@@ -89,12 +89,12 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   double dx_c = e_c.y - hs_c.y, hp_c = hs_c.x + e_c.x, qe_c = dpp_shift(le_c, false) - le_c;
   double Pe_c = qe_c * clampn(dx_c, e_c.x, hs_c.x);
   double D_s, C_s;  // C_s: what the row below holds for this cell (its nodes' NW / NE terms, its north face's plus part)
-  double2 hs_next = hs_itp(TRPT > 1 ? 1 : 0, sw);  // {Hc,S} of row m+1, fetched one row ahead of its use
+  double2 hs_next = hs_itp(NR > 1 ? 1 : 0, sw);  // {Hc,S} of row m+1, fetched one row ahead of its use
   [[maybe_unused]] double thacc = 0.0;  // stage 1, th_red != null: the wavefront's share of the theta-VJP (see node_face)
   // constant A: registers allow a second row in flight ({Hc,S} of row m+2); with a gridded A they do not (96 B/lane of scratch)
   constexpr bool PF2 = ODINN_ADJ_PF2 && !AF;
   [[maybe_unused]] double2 hs_next2;
-  if constexpr (PF2) hs_next2 = hs_itp(TRPT > 2 ? 2 : 0, sw);
+  if constexpr (PF2) hs_next2 = hs_itp(NR > 2 ? 2 : 0, sw);
 
   // node N(c, r) and north face n(c, r) of a row whose own / east-face quantities are the "_lo" arguments and whose
   // upper neighbours are the "_hi" ones; returns D, the four corner terms and the north face's two second-term parts
@@ -143,16 +143,16 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     C_s = (k01 + dpp_from_west(k11)) + PLn;
   }
 #pragma unroll
-  for (int m = 0; m < TRPT; ++m) {
+  for (int m = 0; m < NR; ++m) {
     const int gj = gj0 + r0 + m;
-    const double2 hs_n = m + 1 < TRPT ? hs_next : hs_top;
+    const double2 hs_n = m + 1 < NR ? hs_next : hs_top;
     if constexpr (PF2) {
       hs_next = hs_next2;
-      if (m + 3 < TRPT) hs_next2 = hs_itp(m + 3 < TRPT ? m + 3 : m, sw);
+      if (m + 3 < NR) hs_next2 = hs_itp(m + 3 < NR ? m + 3 : m, sw);
     } else {
-      if (m + 2 < TRPT) hs_next = hs_itp(m + 2 < TRPT ? m + 2 : m, sw);
+      if (m + 2 < NR) hs_next = hs_itp(m + 2 < NR ? m + 2 : m, sw);
     }
-    const double le_n = m + 1 < TRPT ? lam_e(m + 1 < TRPT ? m + 1 : m) : le_top;
+    const double le_n = m + 1 < NR ? lam_e(m + 1 < NR ? m + 1 : m) : le_top;
     const double2 e_n = dpp_from_east(hs_n);
     const double lee_n = dpp_shift(le_n, false);
     const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, qe_n = lee_n - le_n;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     double D_c, k00, k10, k01, k11, Mn, PLn, tw;
     node_face(gj, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, hs_n, e_n, le_n, dx_n, hp_n, Pe_n, D_c, k00, k10, k01, k11, Mn, PLn, tw);
     if (S == 1 && th_red) {  // the node north-east of an OUTPUT cell belongs to this thread (every dual node to exactly one)
-      const bool own = lane >= FH && lane < FH + FOX && r0 + m >= FH && r0 + m <= TRY - 1 - FH && gi <= g.nx - 2 && gj <= g.ny - 2;
+      const bool own = lane >= FH && lane < FH + FOX && r0 + m >= FH && r0 + m <= (NR * TNW) - 1 - FH && gi <= g.nx - 2 && gj <= g.ny - 2;
       thacc += own ? tw : 0.0;
     }
     // east face of this row, second term
@@ -213,20 +213,20 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   if (S < 5) {  // publish the strip's edge rows for the next stage: H at ITS time, lambda just updated
     const double swn = a.sitp[S < 5 ? S : 4];
     sE[wr][w][0][lane] = hs_itp(0, swn);
-    sE[wr][w][1][lane] = hs_itp(TRPT - 1, swn);
+    sE[wr][w][1][lane] = hs_itp(NR - 1, swn);
     sLm[wr][w][0][lane] = lam_e(0);
-    sLm[wr][w][1][lane] = lam_e(TRPT - 1);
+    sLm[wr][w][1][lane] = lam_e(NR - 1);
     __syncthreads();
   }
 }
 
 // SKIP: exact ice-free shortcut (see below)
-template <bool AF, bool SKIP, bool SG = false>
+template <bool AF, bool SKIP, bool SG = false, int NR = TRPT>
 __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double sLm[2][TNW][2][FRX];
   __shared__ double red[TNW];
-  __shared__ double sEr[ODINN_ADJ_ELDS ? TRY : 1][FRX];
+  __shared__ double sEr[ODINN_ADJ_ELDS ? (NR * TNW) : 1][FRX];
   const int4 t4 = A.tilesF[blockIdx.x];
   const GState* gs = P.gs + t4.x;
   if (gs->done) return;
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
   const double* __restrict__ Afg = AF ? P.Afield + g.offd : nullptr;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * FOYT - FH;
-  const int gi = gi0 + lane, r0 = TRPT * w;
+  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * (NR * TNW - 2 * FH) - FH;
+  const int gi = gi0 + lane, r0 = NR * w;
   const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
   const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
   const int id0 = gi + g.nx * (gj0 + r0);
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
     // lambda with a zero right-hand side -- the arithmetic below, bit-identical to running the stages.
     bool ice = false;
 #pragma unroll
-    for (int m = 0; m < TRPT; ++m) {
+    for (int m = 0; m < NR; ++m) {
       const int gj = gj0 + r0 + m;
       const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
       const unsigned id = (unsigned)(gic + g.nx * gjc);
@@ -277,9 +277,9 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
       const bool ocol = lane >= FH && lane < FH + FOX && inx;
       double errsq = 0.0;
 #pragma unroll
-      for (int m = 0; m < TRPT; ++m) {
+      for (int m = 0; m < NR; ++m) {
         const int r = r0 + m, gj = gj0 + r;
-        if (r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny) {
+        if (r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny) {
           const double up = ldg32(src, (unsigned)(id0 + g.nx * m));
           double un = fma(c_bt[0], 0.0, up), tm = up;  // stage 1 (tmp == u_n)
 #pragma unroll
@@ -310,9 +310,9 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
       return;
     }
   }
-  double u[TRPT], tmp[TRPT], E[TRPT];
+  double u[NR], tmp[NR], E[NR];
 #pragma unroll
-  for (int m = 0; m < TRPT; ++m) {
+  for (int m = 0; m < NR; ++m) {
     const int gj = gj0 + r0 + m;
     double l = 0.0;
     if (inx && gj >= 0 && gj < g.ny) l = ldg32(src, (unsigned)(id0 + g.nx * m));
@@ -337,38 +337,38 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
       sLm[0][w][e][lane] = (intx && gj >= 1 && gj <= g.ny - 2) ? u[m] : 0.0;
     };
     edge(0, 0);
-    edge(TRPT - 1, 1);
+    edge(NR - 1, 1);
   }
   __syncthreads();
   __shared__ double th_red[TNW];
   // theta-VJP of the quadrature node the previous step reached (a.qw: its Gauss-Legendre weight, 0 otherwise; the controller
   // resets it at every call, so a repeated attempt after a rejection does not count the node twice)
   double* const thr = (A.th_part && a.qw != 0.0) ? th_red : nullptr;
-  adj_strip_stage<1, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr);
+  adj_strip_stage<1, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr);
   if (thr && threadIdx.x == 0) {  // the tile's running sum, reduced per glacier once after the reverse solve
     double sum = 0.0;
 #pragma unroll
     for (int k = 0; k < TNW; ++k) sum += th_red[k];
     A.th_part[t4.w] = fma(a.qw, sum, A.th_part[t4.w]);
   }
-  adj_strip_stage<2, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
-  adj_strip_stage<3, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
-  adj_strip_stage<4, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
-  adj_strip_stage<5, AF, SG>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
-  // ---- output rows [FH, TRY-1-FH]: lam' from the registers, embedded error partial -----------------------
+  adj_strip_stage<2, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
+  adj_strip_stage<3, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
+  adj_strip_stage<4, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
+  adj_strip_stage<5, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
+  // ---- output rows [FH, (NR * TNW)-1-FH]: lam' from the registers, embedded error partial -----------------------
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   double errsq = 0.0;
-  double upf[TRPT];
+  double upf[NR];
 #pragma unroll
-  for (int m = 0; m < TRPT; ++m) {
+  for (int m = 0; m < NR; ++m) {
     const int r = r0 + m, gj = gj0 + r;
-    const bool out = r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny;
+    const bool out = r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny;
     upf[m] = ldg32(src, (unsigned)(out ? id0 + g.nx * m : 0));
   }
 #pragma unroll
-  for (int m = 0; m < TRPT; ++m) {
+  for (int m = 0; m < NR; ++m) {
     const int r = r0 + m, gj = gj0 + r;
-    if (r >= FH && r <= TRY - 1 - FH && ocol && gj < g.ny) {
+    if (r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny) {
       const double upv = upf[m];
       stg32(dst, (unsigned)(id0 + g.nx * m), u[m]);
       const double err = (u[m] - upv) - (ODINN_ADJ_ELDS ? sEr[r0 + m][lane] : E[m]);

@@ -65,6 +65,7 @@ constexpr int TNW = ODINN_TNW;        // TRPT CONTIGUOUS region rows, so the y-n
 constexpr int TNT = 64 * TNW;         // same thread's registers: TNW wavefronts, 64 x 56 region, 54 x 46 output tile
 constexpr int TRY = TRPT * TNW;
 constexpr int FOYT = TRY - 2 * FH;
+constexpr int FOYT4 = 4 * TNW - 2 * FH;  // fused reverse step of small batches with 4 rows per thread: 54 x 22 output tiles
 constexpr int FOYT8 = 8 * TNW - 2 * FH;  // forward strip kernel with 8 rows per thread: 54 x 54 output tiles
 constexpr int FLD = FRX + 1;          // LDS row stride (odd)
 
@@ -108,6 +109,7 @@ struct GDev {  // per-glacier constants
   int tile0Fs, ntilesFs; // ... and in the table of FOX x FOYS "latency" tiles
   int tile0Ft, ntilesFt; // ... and in the table of FOX x FOYT "strip" tiles
   int tile0Fu, ntilesFu; // ... and in the table of FOX x FOYT8 strip tiles (forward kernel, 8 rows per thread)
+  int tile0Fv, ntilesFv; // ... and in the table of FOX x FOYT4 strip tiles (fused reverse step of small batches, 4 rows per thread)
   int tile0D, ntilesD;   // ... and in the table of 62 x 62 tiles of the RHS-only / CFL-Euler strip kernel
   long long off;   // offset of this glacier in the pooled primal arrays  [doubles]
   long long offd;  // offset in the pooled dual arrays
@@ -965,7 +967,7 @@ struct CtrlArgs {
   int next_cur;  // ping-pong buffer that holds u_new of this step; -1: flip the glacier's own `cur`
   const double* errpart;  // per-tile error partials: errpart[stride * tile]
   int stride;
-  int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles, 3: FOYT tiles, 4: FOYT8 tiles)
+  int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles, 3: FOYT tiles, 4: FOYT8 tiles, 5: 62 x 62 tiles, 6: FOYT4 tiles)
   int* est_steps;         // [G] (nullable): estimated steps still needed, for the host's poll spacing
   double cfl;             // > 0: explicit Euler with dt = cfl*min(dx,dy)^2/(4 max D); the partials are tile maxima
   int cfl_prime;          // the launch only measured max D(u0): set the first dt, do not advance
@@ -1019,8 +1021,8 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   const GDev g = P.gd[gidx];
   double s = 0.0;
   {
-    const int t0 = C.fused == 5 ? g.tile0D : C.fused == 4 ? g.tile0Fu : C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
-    const int nt = C.fused == 5 ? g.ntilesD : C.fused == 4 ? g.ntilesFu : C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
+    const int t0 = C.fused == 6 ? g.tile0Fv : C.fused == 5 ? g.tile0D : C.fused == 4 ? g.tile0Fu : C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
+    const int nt = C.fused == 6 ? g.ntilesFv : C.fused == 5 ? g.ntilesD : C.fused == 4 ? g.ntilesFu : C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
     if (C.cfl > 0.0) {
       for (int k = threadIdx.x; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
     } else {
@@ -2471,12 +2473,14 @@ __global__ void k_seg_pairs(long long ntot, int n_seg, const double* __restrict_
     segs[i] = make_double2(a, b - a);
   }
 }
-// out[g] += sum of the glacier's entries of a per-tile array on the FOX x FOYT strip-tile table (fixed order)
-__global__ __launch_bounds__(64) void k_sum_tilesFt(Pools P, const double* __restrict__ part, double* __restrict__ out) {
+// out[g] += sum of the glacier's entries of a per-tile array on the FOX x FOYT (rows = 7) or FOX x FOYT4 (rows = 4)
+// strip-tile table (fixed order)
+__global__ __launch_bounds__(64) void k_sum_tilesFt(Pools P, const double* __restrict__ part, double* __restrict__ out, int rows) {
   const int gidx = blockIdx.x;
   const GDev g = P.gd[gidx];
+  const int t0 = rows == 4 ? g.tile0Fv : g.tile0Ft, nt = rows == 4 ? g.ntilesFv : g.ntilesFt;
   double s = 0.0;
-  for (int k = threadIdx.x; k < g.ntilesFt; k += 64) s += part[g.tile0Ft + k];
+  for (int k = threadIdx.x; k < nt; k += 64) s += part[t0 + k];
   s = wave_sum(s);
   if (threadIdx.x == 0) out[gidx] += s;
 }

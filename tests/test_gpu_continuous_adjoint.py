@@ -295,6 +295,57 @@ def test_continuous_adjoint_other_law_modes(gpu, kind, arch):
     b.close()
 
 
+def _reverse_case(gpu, case):
+    """One continuous-adjoint gradient of a named case: (loss, gradient, [lambda(t0)], [(naccept, nreject)])."""
+    if case == "ragged_batch":
+        shapes = [(70, 57), (131, 64), (54, 46), (201, 103)]
+        rng = np.random.default_rng(11)
+        b = gpu.GlacierBatch(shapes, [50.0] * 4, A=[3e-17, 5e-17, 2e-17, 4e-17])
+        ts = [2010.0 + j / 12.0 for j in range(5)]
+        for k, (nx, ny) in enumerate(shapes):
+            H0, B = O.synthetic_valley(nx, ny, 50.0)
+            b.set_fields(k, H0, B)
+            b.set_reference(k, ts, [H0 * (1.0 - 0.03 * j) + 0.5 * rng.random((nx, ny)) for j in range(len(ts))], 3)
+        Lg, gg = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=16)
+        lam = [b.lambda0(k) for k in range(4)]
+    elif case == "velocity_hv_batch":
+        # LossHV on two glaciers that run out of step (per-glacier ping-pong buffers of the fused step): the velocity
+        # term joins lambda at the snapshots through k_surfV_vjp<1>, which follows each glacier's current buffer
+        from test_gpu_velocity import _velocity_case
+        ph = O.Phys()
+        shapes = [(64, 48), (80, 56)]
+        b = gpu.GlacierBatch(shapes, [50.0] * 2, A=[3e-17, 6e-17])
+        for k, (nx, ny) in enumerate(shapes):
+            H0, B, ts, mlp, th_true, th0, gl, cfg, ref, tV, Vref = _velocity_case(nx, ny, ph)
+            law_t = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th_true, T=-3.0)
+            Vs = [O.V_from_H(ref[j], B, 50.0, 50.0, ph, law_t) for j in range(len(ts))]
+            b.set_fields(k, H0, B)
+            b.set_reference(k, ts, ref, 3)
+            b.set_velocity_reference(k, ts, [v[2] for v in Vs], [v[0] for v in Vs], [v[1] for v in Vs])
+        b.set_loss(gpu._lib.LOSS_HV, "xy", True, 2.5)
+        Lg, gg = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=12)
+        lam = [b.lambda0(k) for k in range(2)]
+    else:
+        nx, ny = 96, 80
+        use_mb = case == "scalar_nn_mb"
+        ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, use_mb)
+        if case == "gridded_nn":
+            b = gpu.GlacierBatch([(nx, ny)], [50.0])
+            b.set_fields(0, H0, B)
+            S = B + H0
+            Sd = 0.25 * (S[:-1, :-1] + S[1:, :-1] + S[:-1, 1:] + S[1:, 1:])
+            b.set_T_field(0, np.asfortranarray(-5.0 - 6.5e-3 * (Sd - S.mean())))
+            b.set_law(gpu.LAW_NN_A_GRIDDED, gm, th0)
+            b.set_reference(0, ts, ref, 3)
+        else:
+            b = _batch(gpu, nx, ny, H0, B, gm, th0, ts, ref, mb)
+        Lg, gg = b.loss_grad_continuous(ts, theta=th0, mb_times=ts[1:] if use_mb else (), reltol=1e-8, n_quadrature=16)
+        lam = [b.lambda0(0)]
+    res = (Lg, np.array(gg, dtype=float).ravel(), lam, [(s.naccept, s.nreject) for s in b.last_stats_rev])
+    b.close()
+    return res
+
+
 @pytest.mark.parametrize("case", ["scalar_nn_mb", "gridded_nn", "ragged_batch", "velocity_hv_batch"])
 def test_fused_reverse_step_matches_the_staged_reverse_solve(gpu, monkeypatch, case):
     """k_adj_fused_strip (the five stages of a reverse step in one kernel, face form of the H-VJP; what large
@@ -305,52 +356,7 @@ def test_fused_reverse_step_matches_the_staged_reverse_solve(gpu, monkeypatch, c
     out = {}
     for mode in ("0", "1"):
         monkeypatch.setenv("ODINN_ADJ_FUSED", mode)
-        if case == "ragged_batch":
-            shapes = [(70, 57), (131, 64), (54, 46), (201, 103)]
-            rng = np.random.default_rng(11)
-            b = gpu.GlacierBatch(shapes, [50.0] * 4, A=[3e-17, 5e-17, 2e-17, 4e-17])
-            ts = [2010.0 + j / 12.0 for j in range(5)]
-            for k, (nx, ny) in enumerate(shapes):
-                H0, B = O.synthetic_valley(nx, ny, 50.0)
-                b.set_fields(k, H0, B)
-                b.set_reference(k, ts, [H0 * (1.0 - 0.03 * j) + 0.5 * rng.random((nx, ny)) for j in range(len(ts))], 3)
-            Lg, gg = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=16)
-            lam = [b.lambda0(k) for k in range(4)]
-        elif case == "velocity_hv_batch":
-            # LossHV on two glaciers that run out of step (per-glacier ping-pong buffers of the fused step): the velocity
-            # term joins lambda at the snapshots through k_surfV_vjp<1>, which follows each glacier's current buffer
-            from test_gpu_velocity import _velocity_case
-            ph = O.Phys()
-            shapes = [(64, 48), (80, 56)]
-            b = gpu.GlacierBatch(shapes, [50.0] * 2, A=[3e-17, 6e-17])
-            for k, (nx, ny) in enumerate(shapes):
-                H0, B, ts, mlp, th_true, th0, gl, cfg, ref, tV, Vref = _velocity_case(nx, ny, ph)
-                law_t = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=th_true, T=-3.0)
-                Vs = [O.V_from_H(ref[j], B, 50.0, 50.0, ph, law_t) for j in range(len(ts))]
-                b.set_fields(k, H0, B)
-                b.set_reference(k, ts, ref, 3)
-                b.set_velocity_reference(k, ts, [v[2] for v in Vs], [v[0] for v in Vs], [v[1] for v in Vs])
-            b.set_loss(gpu._lib.LOSS_HV, "xy", True, 2.5)
-            Lg, gg = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=12)
-            lam = [b.lambda0(k) for k in range(2)]
-        else:
-            nx, ny = 96, 80
-            use_mb = case == "scalar_nn_mb"
-            ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, use_mb)
-            if case == "gridded_nn":
-                b = gpu.GlacierBatch([(nx, ny)], [50.0])
-                b.set_fields(0, H0, B)
-                S = B + H0
-                Sd = 0.25 * (S[:-1, :-1] + S[1:, :-1] + S[:-1, 1:] + S[1:, 1:])
-                b.set_T_field(0, np.asfortranarray(-5.0 - 6.5e-3 * (Sd - S.mean())))
-                b.set_law(gpu.LAW_NN_A_GRIDDED, gm, th0)
-                b.set_reference(0, ts, ref, 3)
-            else:
-                b = _batch(gpu, nx, ny, H0, B, gm, th0, ts, ref, mb)
-            Lg, gg = b.loss_grad_continuous(ts, theta=th0, mb_times=ts[1:] if use_mb else (), reltol=1e-8, n_quadrature=16)
-            lam = [b.lambda0(0)]
-        out[mode] = (Lg, np.array(gg, dtype=float).ravel(), lam, [(s.naccept, s.nreject) for s in b.last_stats_rev])
-        b.close()
+        out[mode] = _reverse_case(gpu, case)
     a, f = out["0"], out["1"]
     assert a[0] == f[0]  # the forward solve is the same code
     # accept/reject decisions sit on a threshold: an ulp of difference between the two stencil forms can flip one and
@@ -360,6 +366,26 @@ def test_fused_reverse_step_matches_the_staged_reverse_solve(gpu, monkeypatch, c
         assert abs(na - nf) <= max(2, na // 10) and abs(ra - rf) <= max(2, ra // 2), (a[3], f[3])
     # two adaptive reverse solves at reltol = abstol = 1e-8 whose step sequences may differ by a few steps (above): they
     # agree to the integration error, a few 10 x reltol (observed 1e-16 ... 1.2e-7 over the kernel revisions)
+    assert np.linalg.norm(a[1] - f[1]) <= 5e-7 * np.linalg.norm(a[1]), case
+    for la, lf in zip(a[2], f[2]):
+        assert rel_l2(lf, la) < 5e-7, case
+
+
+@pytest.mark.parametrize("case", ["scalar_nn_mb", "gridded_nn", "ragged_batch", "velocity_hv_batch"])
+def test_fused_reverse_step_rows_per_thread(gpu, monkeypatch, case):
+    """The two instantiations of k_adj_fused_strip -- 7 rows per thread (54 x 46 output tiles) and 4 rows per thread
+    (54 x 22 tiles; what batches too small to fill the GPU run, ODINN_ADJ_ROWS forces either) -- evaluate the same face
+    form cell by cell; only the tiling of the error norm's partial sums differs, so the step sequences agree up to
+    threshold flips and the results to the tolerance of the reverse solve."""
+    monkeypatch.setenv("ODINN_ADJ_FUSED", "1")
+    out = {}
+    for rows in ("7", "4"):
+        monkeypatch.setenv("ODINN_ADJ_ROWS", rows)
+        out[rows] = _reverse_case(gpu, case)
+    a, f = out["7"], out["4"]
+    assert a[0] == f[0]
+    for (na, ra), (nf, rf) in zip(a[3], f[3]):
+        assert abs(na - nf) <= max(2, na // 10) and abs(ra - rf) <= max(2, ra // 2), (a[3], f[3])
     assert np.linalg.norm(a[1] - f[1]) <= 5e-7 * np.linalg.norm(a[1]), case
     for la, lf in zip(a[2], f[2]):
         assert rel_l2(lf, la) < 5e-7, case
