@@ -2279,8 +2279,14 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   AP.h_log_eps = b->h_log_eps;
   // the theta-VJP of the A-type laws interpolates H at the quadrature node in its tile loader; the per-node MLP laws and
   // the velocity terms read it from d_tmpA, which the post-step then materialises
-  const bool theta_itp = !useV && b->law_kind < ODINN_LAW_NN_Y;
-  AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = theta_itp ? nullptr : b->d_tmpA;
+  // closed-form laws without a dual-grid accumulator: the theta-part of a velocity loss takes one pass per quadrature node
+  // (k_surfV_theta_node, which interpolates H itself) instead of the interpolate / scale / pull-back / reduce sequence
+  // (ODINN_VQ_ONEPASS=0 selects that sequence); d_tmpA then is only needed at the snapshot stops
+  bool vq_onepass = useV && lm <= 1 && !b->wants_Gacc() && !b->vel_nn();
+  if (const char* e = std::getenv("ODINN_VQ_ONEPASS")) vq_onepass = vq_onepass && e[0] != '0';
+  const bool theta_itp = (!useV || vq_onepass) && b->law_kind < ODINN_LAW_NN_Y;
+  AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = (theta_itp && !useV) ? nullptr : b->d_tmpA;
+  AP.hq_snap_only = vq_onepass ? 1 : 0;
   if (b->dhdt_on()) { AP.dh_i0 = b->d_dh_i0; AP.dh_i1 = b->d_dh_i1; AP.dh_coef = b->d_dh_coef; }
   if (b->agg_nslots > 0) { AP.agg_slot = b->d_agg_slot; AP.aggH = b->d_aggH; }
   const bool mb_last = b->any_mb && b->mb_flag[k - 1];
@@ -2448,11 +2454,16 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
         if (fused_rev) { VS.out = b->d_lam[0]; VS.out_alt = b->d_lam[1]; }  // per-glacier ping-pong buffers
         else VS.out = a1;
         launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VS, 0);                       // snapshot stops
-        launch_vref_itp(b->ntiles, b->stream, Pl, VI);                                  // quadrature nodes
-        launch_vref_scale(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_vscq, b->d_wvq);
-        launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VQ, 0);
-        if (b->vel_nn()) launch_sum_part_theta(b->P, G, b->stream, Pl, b->d_part_theta, b->d_dth, 1, 0);
-        else launch_sum_part(G, b->stream, Pl, 3, b->d_Gsum, 1, 0);
+        if (vq_onepass) {                                                               // quadrature nodes
+          launch_surfV_theta_node(lm, b->ntiles, b->stream, Pl, VI, b->d_snaps, b->v_abs, b->v_abs ? b->v_log_eps : 0.0);
+          launch_vq_finish(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_Gsum);
+        } else {
+          launch_vref_itp(b->ntiles, b->stream, Pl, VI);
+          launch_vref_scale(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_vscq, b->d_wvq);
+          launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VQ, 0);
+          if (b->vel_nn()) launch_sum_part_theta(b->P, G, b->stream, Pl, b->d_part_theta, b->d_dth, 1, 0);
+          else launch_sum_part(G, b->stream, Pl, 3, b->d_Gsum, 1, 0);
+        }
       }
       // quadrature node reached: dtheta += w * J_theta(H_itp(t))^T lam(t)  (:497-503); A-type laws add
       // onto per-tile running sums that are reduced once after the solve

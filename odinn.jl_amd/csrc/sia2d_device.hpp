@@ -1229,6 +1229,7 @@ struct AdjPostArgs {
   const int* agg_slot;
   const double* aggH;
   double h_log_eps;      // LossH's simple loss: 0 = L2Sum, > 0 = LogSum(eps)
+  int hq_snap_only;      // Hq is wanted at the snapshot stops only (the quadrature nodes' consumer interpolates H itself)
 };
 
 __device__ __forceinline__ double mb_value(const GDev& g, double mb0, double sref, double H, double B, double& dmb) {
@@ -2326,7 +2327,7 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
         if (!A.loss_first) l += dl + dagg;
         U[id] = l;
       }
-      if (A.Hq && (a.qw != 0.0 || a.snapj >= 0)) {  // H_itp at the stop, for the velocity loss term (the theta-VJP forms it itself)
+      if (A.Hq && ((a.qw != 0.0 && !A.hq_snap_only) || a.snapj >= 0)) {  // H_itp at the stop, for the velocity loss term (the theta-VJP forms it itself)
         const double ha = A.snaps[(long long)a.seg_stop * A.ntot + id];
         const double hb = A.snaps[(long long)(a.seg_stop + 1) * A.ntot + id];
         A.Hq[id] = fma(a.s_stop, hb - ha, ha);
@@ -2549,6 +2550,31 @@ __global__ __launch_bounds__(64) void k_vref_scale(Pools P, const AdjState* adj,
   if (threadIdx.x == 0) {
     scale_out[gidx] = (scale_loss && cnt > 0.0 && ss > 0.0) ? 1.0 / sqrt(ss / cnt) : 1.0;
     w_out[gidx] = at_node ? adj[gidx].qw * wq : 0.0;
+  }
+}
+
+// the per-glacier end of k_surfV_theta_node: out[g] += (quadrature weight x wq) x scale x (sum of the tiles' slot 3), with
+// scale = 1/sqrt(mean_{mask} |Vref|^2) (or 1) from slots 0 and 1; fixed summation order
+__global__ __launch_bounds__(64) void k_vq_finish(Pools P, const AdjState* adj, const int* slotA, int G, int scale_loss,
+                                                  double wq, double* out) {
+  const int gidx = blockIdx.x;
+  const GDev g = P.gd[gidx];
+  const GState* gs = P.gs + gidx;
+  const bool at_node = gs->at_stop && adj[gidx].qw != 0.0 && slotA[(long long)(gs->istop - 1) * G + gidx] >= 0;
+  if (!at_node) return;
+  double ss = 0.0, cnt = 0.0, gt = 0.0;
+  for (int k = threadIdx.x; k < g.ntiles; k += 64) {
+    const double* pp = P.part + 4 * (long long)(g.tile0 + k);
+    ss += pp[0];
+    cnt += pp[1];
+    gt += pp[3];
+  }
+  ss = wave_sum(ss);
+  cnt = wave_sum(cnt);
+  gt = wave_sum(gt);
+  if (threadIdx.x == 0) {
+    const double sc = (scale_loss && cnt > 0.0 && ss > 0.0) ? 1.0 / sqrt(ss / cnt) : 1.0;
+    out[gidx] = fma((adj[gidx].qw * wq) * sc, gt, out[gidx]);
   }
 }
 

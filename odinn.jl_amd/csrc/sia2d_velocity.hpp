@@ -260,6 +260,85 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
   }
 }
 
+// ---- continuous adjoint: the theta-part of the velocity loss at a quadrature node in ONE pass ---------------------------
+// (gradient.jl:475-503, backward_loss(::LossV) with the reference velocities interpolated linearly in time, :291-301.)
+// Closed-form laws without a dual-grid accumulator: the weight of a glacier in dL/dtheta is linear in the loss's
+// normalisation 1/sqrt(mean |V_ref|^2) (Losses.jl:323-326), so one pass forms the interpolated reference, the
+// normalisation sums (slots 0, 1: every cell) and the UNSCALED sum of dVelocity^/dA x W over the dual nodes (slot 3);
+// k_vq_finish applies scale and quadrature weight per glacier.  Replaces k_vref_itp + k_vref_scale + k_surfV_vjp<1> +
+// k_sum_part on that path: no interpolated fields (reference velocities, H) written and re-read, no H-cotangent gathered
+// only to be discarded.
+template <int LM>
+__global__ __launch_bounds__(NT) void k_surfV_theta_node(Pools P, VItpArgs I, const double* __restrict__ snaps, int component_abs,
+                                                         double log_eps) {
+  __shared__ double2 sHS[TY + 2][LDW];
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const GState* gs = P.gs + t4.x;
+  double* pp = P.part + 4 * (long long)t4.w;
+  const bool at_node = gs->at_stop && I.adj[t4.x].qw != 0.0;
+  const long long q = (long long)(gs->istop - 1) * I.G + t4.x;
+  const int sa = at_node ? I.slotA[q] : -1;
+  if (sa < 0) {  // not at a node, or no velocity data on this glacier
+    if (threadIdx.x == 0) { pp[0] = 0.0; pp[1] = 0.0; pp[3] = 0.0; }
+    return;
+  }
+  const GDev g = P.gd[t4.x];
+  const long long oa = (long long)sa * I.ntot, ob = (long long)I.slotB[q] * I.ntot;
+  const double w = I.sw[q];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  double own[RPT];
+  {  // H at the node: the interpolant of the two bracketing snapshots (k_adj_poststep's Hq formula, gradient.jl:287)
+    const AdjState a = I.adj[t4.x];
+    const double* Ha = snaps + (long long)a.seg_stop * I.ntot;
+    load_tile_HS2(Ha, P.B, g, i0, j0, sHS, own, Ha + I.ntot, a.s_stop);
+  }
+  __syncthreads();
+  const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
+  const int tx = threadIdx.x & 63, ty = wave_id();
+  const int gi = i0 + tx;
+  double ss = 0.0, cnt = 0.0, gsum = 0.0;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      auto lerp = [&](const double* f) { const double a = f[oa + id]; return w == 0.0 ? a : fma(w, f[ob + id] - a, a); };
+      const double va = lerp(I.Vabs), vxr = lerp(I.Vxr), vyr = lerp(I.Vyr);  // k_vref_itp's formula
+      if (va > 0.0) {  // mask = V_ref > 0 (Losses.jl:361)
+        ss = fma(vxr, vxr, fma(vyr, vyr, ss));
+        cnt += 1.0;
+        if (gi <= g.nx - 2 && gj <= g.ny - 2) {  // the node whose lower-left cell is (gi, gj): inn1 pairing
+          double gx, gy, Hb;
+          node_geom<LDW>(g, &sHS[r][tx + 1], gx, gy, Hb);
+          double An = g.A;
+          if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+          double al, be, sp;
+          const double D = node_Vup<LM>(g, Hb, gx * gx + gy * gy, An, al, be, sp);
+          const double vx = -D * gx, vy = -D * gy;
+          const double ex = vx - vxr, ey = vy - vyr;
+          double dvx, dvy;
+          if (!component_abs) {
+            dvx = 2.0 * ex * Ninv;
+            dvy = 2.0 * ey * Ninv;
+          } else {
+            const double v = sqrt(vx * vx + vy * vy), ev = v - va;
+            double dv = 2.0 * ev * Ninv;
+            if (log_eps > 0.0) dv = 2.0 * log((v + log_eps) / (va + log_eps)) / (v + log_eps) * Ninv;
+            dvx = dv * ex / ev;  // as the reference writes it (Losses.jl:367-368)
+            dvy = dv * ey / ev;
+          }
+          gsum = fma(sp, gx * dvx + gy * dvy, gsum);
+        }
+      }
+    }
+  }
+  const double t0 = block_sum(ss, red);
+  const double t1 = block_sum(cnt, red);
+  const double t3 = block_sum(gsum, red);
+  if (threadIdx.x == 0) { pp[0] = t0; pp[1] = t1; pp[3] = -t3; }
+}
+
 // ---- LossAvgV (TimeAggregatedLosses.jl:115-258) ---------------------------------------------------------------------
 #ifdef ODINN_VEL_KERNELS  // non-template kernels: compiled by k_vel.hip only
 // avg += w_g V  for the glaciers whose tLoss contains this stop (w_g = dt_i / T, 0: not this glacier)

@@ -97,11 +97,15 @@ def test_continuous_adjoint_ragged_batch_and_other_laws(gpu):
     b.close()
 
 
+@pytest.mark.parametrize("onepass", ["1", "0"])
 @pytest.mark.parametrize("kind,component,scale", [("V", "xy", True), ("V", "abs", False), ("HV", "xy", True), ("V", "log", True)])
-def test_continuous_adjoint_with_velocity_losses(gpu, kind, component, scale):
+def test_continuous_adjoint_with_velocity_losses(gpu, monkeypatch, kind, component, scale, onepass):
     """ContinuousAdjoint with LossV / LossHV (gradient.jl:291-301, 331-365, 475-503): the velocity term
     enters lambda at the velocity-data snapshots; its explicit theta-dependence is integrated by the
-    quadrature with the reference velocities interpolated linearly in time.  Against the oracle."""
+    quadrature with the reference velocities interpolated linearly in time.  Against the oracle, through the one-pass
+    node kernel (k_surfV_theta_node, the default for closed-form laws without a dual-grid accumulator) and through the
+    interpolate / scale / pull-back / reduce sequence it replaces (ODINN_VQ_ONEPASS=0)."""
+    monkeypatch.setenv("ODINN_VQ_ONEPASS", onepass)
     from test_gpu_velocity import _velocity_case
 
     ph = O.Phys()
