@@ -1,5 +1,6 @@
 // k_misc.hip -- controller, post-step, reductions, mass balance, hoisted-law kernels
 #define ODINN_MISC_KERNELS 1
+#include <algorithm>
 #include "launch.hpp"
 namespace odinn {
 void launch_controller(int G, hipStream_t st, Pools P, CtrlArgs C) { hipLaunchKernelGGL(k_controller, dim3(G), dim3(64), 0, st, P, C); }
@@ -51,8 +52,20 @@ void launch_law_field(hipStream_t st, LawDev L, const double* T, double* Aout, l
   else if (law_is<ArchDefA>(L)) hipLaunchKernelGGL(k_law_field_fixed<ArchDefA>, grid, dim3(NT), 0, st, L, T, Aout, n);
   else hipLaunchKernelGGL(k_law_field, grid, dim3(NT), 0, st, L, T, Aout, n);
 }
-void launch_law_field_grad(int nblk, hipStream_t st, LawDev L, const double* T, const double* G, long long n,
-                           double* gscratch, double* part_theta) {
+int launch_law_field_grad(hipStream_t st, LawDev L, const double* T, const double* G, long long n, double* part_theta,
+                          int max_rows) {
+  // wave-reduced kernel: 8 workgroups per CU at most, every wavefront strides over the 64-node chunks; returns the rows written
+  const long long nchunk = (n + 63) / 64;
+  int nblk = (int)std::min<long long>((nchunk + NW - 1) / NW, 2048);
+  nblk = std::max(1, std::min(nblk, max_rows));
+  const size_t dyn = (size_t)NW * L.P * sizeof(double) + (size_t)L.P * sizeof(int);
+  if (law_is<Arch16A>(L)) hipLaunchKernelGGL((k_law_field_grad_wave<Arch16A, true>), dim3(nblk), dim3(NT), dyn, st, L, T, G, n, part_theta);
+  else if (law_is<ArchDefA>(L)) hipLaunchKernelGGL((k_law_field_grad_wave<ArchDefA, true>), dim3(nblk), dim3(NT), dyn, st, L, T, G, n, part_theta);
+  else hipLaunchKernelGGL((k_law_field_grad_wave<ArchRT, false>), dim3(nblk), dim3(NT), dyn, st, L, T, G, n, part_theta);
+  return nblk;
+}
+void launch_law_field_grad_scratch(int nblk, hipStream_t st, LawDev L, const double* T, const double* G, long long n,
+                                   double* gscratch, double* part_theta) {
   hipLaunchKernelGGL(k_law_field_grad, dim3(nblk), dim3(NT), 0, st, L, T, G, n, gscratch, part_theta);
 }
 void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, double* out) {

@@ -76,8 +76,9 @@ void launch_dhdt_sums(int nblk, int G, hipStream_t st, Pools P, const double* sn
 void launch_dhdt_cot(int nblk, hipStream_t st, Pools P, double* lam, const double* snaps, const int* i0s, const int* i1s,
                      const double* coef, int j, long long ntot);
 void launch_law_field(hipStream_t st, LawDev L, const double* T, double* Aout, long long n);
-void launch_law_field_grad(int nblk, hipStream_t st, LawDev L, const double* T, const double* G, long long n,
-                           double* gscratch, double* part_theta);
+int launch_law_field_grad(hipStream_t st, LawDev L, const double* T, const double* G, long long n, double* part_theta, int max_rows);
+void launch_law_field_grad_scratch(int nblk, hipStream_t st, LawDev L, const double* T, const double* G, long long n,
+                                   double* gscratch, double* part_theta);
 void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, double* out);
 void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd);
 void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const double* y, double* z);

@@ -456,7 +456,7 @@ int check_g(odinn_batch* b, int g) {
   return ODINN_OK;
 }
 
-int ensure_theta_scratch(odinn_batch* b, int grid_blocks) {
+int ensure_theta_scratch(odinn_batch* b, int grid_blocks, bool thread_scratch = true) {
   const int P = std::max(b->P, 1);
   const size_t need_pt = (size_t)std::max(b->ntiles, grid_blocks) * P;
   if (need_pt > b->part_theta_cap) {
@@ -464,7 +464,7 @@ int ensure_theta_scratch(odinn_batch* b, int grid_blocks) {
     CHK(dalloc(&b->d_part_theta, need_pt));
     b->part_theta_cap = need_pt;
   }
-  const size_t need_gs = (size_t)grid_blocks * NT * P;
+  const size_t need_gs = thread_scratch ? (size_t)grid_blocks * NT * P : 0;
   if (need_gs > b->gscratch_cap) {
     dfree(b->d_gscratch);
     CHK(dalloc(&b->d_gscratch, need_gs));
@@ -1676,10 +1676,19 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
 
 // gridded hoisted law: dtheta = sum_nodes Gacc * dA/dtheta(T)  over dual range [lo, lo+n)
 static int gridded_law_grad(odinn_batch* b, long long lo, long long n, double* dtheta_host) {
-  const int nblk = (int)((n + NT - 1) / NT);
-  CHK(ensure_theta_scratch(b, nblk));
-  launch_law_field_grad(nblk, b->stream, b->lawdev(), b->d_Tfield + lo, b->d_Gacc + lo, n, b->d_gscratch,
-                        b->d_part_theta);
+  int nblk = (int)((n + NT - 1) / NT);
+  // wave-reduced kernel (accumulators in LDS) while they fit; ODINN_LAWGRAD_WAVE=0: per-thread accumulators in global memory
+  const char* ew = std::getenv("ODINN_LAWGRAD_WAVE");
+  const size_t dyn = (size_t)NW * b->P * sizeof(double) + (size_t)b->P * sizeof(int);
+  if (!(ew && ew[0] == '0') && dyn <= 48 * 1024) {
+    const int max_rows = 2048;
+    CHK(ensure_theta_scratch(b, max_rows, false));
+    nblk = launch_law_field_grad(b->stream, b->lawdev(), b->d_Tfield + lo, b->d_Gacc + lo, n, b->d_part_theta, max_rows);
+  } else {
+    CHK(ensure_theta_scratch(b, nblk));
+    launch_law_field_grad_scratch(nblk, b->stream, b->lawdev(), b->d_Tfield + lo, b->d_Gacc + lo, n, b->d_gscratch,
+                                  b->d_part_theta);
+  }
   launch_sum_rows(b->P, b->stream, b->d_part_theta, nblk, b->d_dth);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(dtheta_host, b->d_dth, sizeof(double) * b->P, hipMemcpyDeviceToHost, b->stream));

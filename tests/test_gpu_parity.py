@@ -153,9 +153,21 @@ def test_nn_A_scalar(gpu):
     b.close()
 
 
-def test_nn_A_gridded(gpu):
+@pytest.mark.parametrize("wave", ["1", "0"])
+@pytest.mark.parametrize("arch", ["default", "w16", "runtime", "wide"])
+def test_nn_A_gridded(gpu, monkeypatch, arch, wave):
+    """LawA(nn; scalar = false): A = NN(T) hoisted onto the dual grid; dtheta = sum_nodes Gacc dA/dtheta(T) by the wave-reduced
+    backprop kernel (k_law_field_grad_wave: compile-time 1-3-10-3-1 and 1-16-16-1 nets, run-time architectures) and by the
+    per-thread-accumulator kernel it replaces (ODINN_LAWGRAD_WAVE=0)."""
+    monkeypatch.setenv("ODINN_LAWGRAD_WAVE", wave)
     ph = O.Phys()
-    om, gm, th = _mlp_pair(gpu, [1, 3, 10, 3, 1], [1, 1, 1, 2], None, O.POST_AFFINE, ph.minA, ph.maxA)
+    widths, acts = {
+        "default": ([1, 3, 10, 3, 1], [1, 1, 1, 2]),
+        "w16": ([1, 16, 16, 1], [1, 1, 2]),
+        "runtime": ([1, 5, 7, 1], [3, 4, 2]),
+        "wide": ([1, 20, 30, 1], [1, 1, 2]),
+    }[arch]
+    om, gm, th = _mlp_pair(gpu, widths, acts, None, O.POST_AFFINE, ph.minA, ph.maxA)
     nx, ny = 96, 80
     b, H0, B, _ = _setup(gpu, nx, ny)
     S = B + H0
