@@ -12,6 +12,9 @@
 //      every knot interval is a contiguous range, summed by one workgroup in a fixed order (deterministic, no atomics);
 //   3. k_knots: uniform + quantile knots, sorted, duplicates removed;   4. k_knot_grads: exact backprop at the knots;
 //   5. k_interval_sums: a_k = sum v (1 - w), b_k = sum v w per interval;   6. k_interp_contract: dtheta (+)= sum_k c_k G_k.
+// Default for the Y law: the same steps for ALL glaciers of a call in one sequence of ~20 launches
+// (launch_interp_theta_batch below); the per-glacier sequence remains for the U law and as the A/B reference.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include "launch.hpp"
@@ -40,10 +43,8 @@ __device__ __forceinline__ long long upper_bound_d(const double* __restrict__ a,
 
 // knots[0 .. M): sorted unique union of LinRange(0, max, n) and the type-7 quantiles (probabilities j / (n + 1)) of the
 // sorted values strictly inside (0, max).  M = 0 when the glacier carries no ice.
-__global__ __launch_bounds__(KMAX) void k_knots(const double* __restrict__ sH, long long nd, int n, double* __restrict__ knots,
-                                                int* __restrict__ Mout) {
-  __shared__ double c[KMAX];
-  __shared__ int first[KMAX];
+__device__ __forceinline__ void knots_body(const double* __restrict__ sH, long long nd, int n, double* __restrict__ knots,
+                                           int* __restrict__ Mout, double* c, int* first) {
   const int i = threadIdx.x;
   const double amax = sH[nd - 1];
   if (!(amax > 0.0)) {
@@ -91,6 +92,28 @@ __global__ __launch_bounds__(KMAX) void k_knots(const double* __restrict__ sH, l
   }
 }
 
+__global__ __launch_bounds__(KMAX) void k_knots(const double* __restrict__ sH, long long nd, int n, double* __restrict__ knots,
+                                                int* __restrict__ Mout) {
+  __shared__ double c[KMAX];
+  __shared__ int first[KMAX];
+  knots_body(sH, nd, n, knots, Mout, c, first);
+}
+// the same for the glaciers g0 + blockIdx.x of a batch whose sorted nodes lie at their pooled dual offsets (minus lo)
+// (the pooled dual offsets are padded: a glacier's segment [offd_g, offd_g+1) ends in a few nodes that are never written --
+//  Hbar = 0, weight 0 -- and sort to its front with the ice-free nodes, which neither the knots nor the sums look at)
+__device__ __forceinline__ long long seg_len(const Pools& P, int gidx, int g_last, long long end_all) {
+  return (gidx < g_last ? P.gd[gidx + 1].offd : end_all) - P.gd[gidx].offd;
+}
+__global__ __launch_bounds__(KMAX) void k_knots_b(Pools P, int g0, int g_last, long long lo, long long end_all,
+                                                  const double* __restrict__ sHall, int n, double* __restrict__ knots_all,
+                                                  int* __restrict__ M_all) {
+  __shared__ double c[KMAX];
+  __shared__ int first[KMAX];
+  const int gidx = g0 + blockIdx.x;
+  knots_body(sHall + (P.gd[gidx].offd - lo), seg_len(P, gidx, g_last, end_all), n, knots_all + (size_t)blockIdx.x * KMAX,
+             M_all + blockIdx.x, c, first);
+}
+
 // G[q * KMAX + k] = d Y / d theta_q at (T, knots[k])
 __global__ __launch_bounds__(64) void k_knot_grads(LawDev L, double T, const double* __restrict__ knots, const int* __restrict__ Mp,
                                                    double* __restrict__ G) {
@@ -101,17 +124,19 @@ __global__ __launch_bounds__(64) void k_knot_grads(LawDev L, double T, const dou
 }
 
 // block k: the nodes with knots[k] <= Hbar < knots[k+1] (the last interval takes Hbar == max too)
-__global__ __launch_bounds__(NT) void k_interval_sums(const double* __restrict__ sH, const double* __restrict__ sV, long long nd,
-                                                      const double* __restrict__ knots, const int* __restrict__ Mp,
-                                                      double* __restrict__ ab) {
-  __shared__ double red[NW];
+__device__ __forceinline__ void interval_sums_body(const double* __restrict__ sH, const double* __restrict__ sV, long long nd,
+                                                   const double* __restrict__ knots, const int* __restrict__ Mp,
+                                                   double* __restrict__ ab, double* red) {
   const int k = blockIdx.x, M = *Mp;
   if (k >= M - 1) {
     if (threadIdx.x == 0) { ab[k] = 0.0; ab[KMAX + k] = 0.0; }
     return;
   }
   const double x0 = knots[k], x1 = knots[k + 1], inv = 1.0 / (x1 - x0);
-  const long long lo = lower_bound_d(sH, nd, x0), hi = (k == M - 2) ? nd : lower_bound_d(sH, nd, x1);
+  // (a node with Hbar == 0 carries the weight 0 -- spat has a positive power of Hbar -- and ice-free nodes can be half of
+  //  the domain, all in interval 0: they are skipped)
+  const long long lo = x0 > 0.0 ? lower_bound_d(sH, nd, x0) : upper_bound_d(sH, nd, 0.0);
+  const long long hi = (k == M - 2) ? nd : lower_bound_d(sH, nd, x1);
   double a = 0.0, b = 0.0;
   for (long long i = lo + threadIdx.x; i < hi; i += NT) {
     const double w = (sH[i] - x0) * inv, v = sV[i];
@@ -122,6 +147,89 @@ __global__ __launch_bounds__(NT) void k_interval_sums(const double* __restrict__
   __syncthreads();
   b = block_sum(b, red);
   if (threadIdx.x == 0) { ab[k] = a; ab[KMAX + k] = b; }
+}
+__global__ __launch_bounds__(NT) void k_interval_sums(const double* __restrict__ sH, const double* __restrict__ sV, long long nd,
+                                                      const double* __restrict__ knots, const int* __restrict__ Mp,
+                                                      double* __restrict__ ab) {
+  __shared__ double red[NW];
+  interval_sums_body(sH, sV, nd, knots, Mp, ab, red);
+}
+__global__ __launch_bounds__(NT) void k_interval_sums_b(Pools P, int g0, int g_last, long long lo, long long end_all,
+                                                        const double* __restrict__ sHall, const double* __restrict__ sVall,
+                                                        const double* __restrict__ knots_all, const int* __restrict__ M_all,
+                                                        double* __restrict__ ab_all) {
+  __shared__ double red[NW];
+  const int gidx = g0 + blockIdx.y;
+  const long long off = P.gd[gidx].offd - lo;
+  interval_sums_body(sHall + off, sVall + off, seg_len(P, gidx, g_last, end_all), knots_all + (size_t)blockIdx.y * KMAX,
+                     M_all + blockIdx.y, ab_all + (size_t)blockIdx.y * 2 * KMAX, red);
+}
+
+// ---- the whole batch in one sequence of launches --------------------------------------------------------------------
+// One radix sort of ALL dual nodes of the glaciers [g0, g0 + ng) by Hbar (values: node index), one stable radix sort of
+// the result by glacier (the few bits of the glacier index): every glacier's nodes, sorted by Hbar, at its own pooled
+// offset again.  Then knots and interval sums with one block row per glacier, and the contraction with the knot gradients
+// as ONE wave-reduced backprop per glacier whose lane weights are the knot coefficients c_k (dtheta = sum_k c_k dY/dtheta
+// (T, knot_k) is the gradient of sum_k c_k Y(T, knot_k)): ~20 launches per evaluation whatever the number of glaciers,
+// instead of 23 per glacier.
+__global__ void k_fill_gid(Pools P, int G, long long ntotd, unsigned* __restrict__ gid, unsigned* __restrict__ iota) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < ntotd; i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = G - 1;  // last glacier with offd <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (P.gd[mid].offd <= i) lo = mid; else hi = mid - 1;
+    }
+    gid[i] = (unsigned)lo;
+    iota[i] = (unsigned)i;
+  }
+}
+__global__ void k_gather_gid(const unsigned* __restrict__ gid, const unsigned* __restrict__ idx, long long n,
+                             unsigned* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = gid[idx[i]];
+}
+__global__ void k_gather_HV(const double* __restrict__ H, const double* __restrict__ V, const unsigned* __restrict__ idx, long long n,
+                            double* __restrict__ sH, double* __restrict__ sV) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned j = idx[i];
+    sH[i] = H[j];
+    sV[i] = V[j];
+  }
+}
+// block g: dth[(g0 + g) P + q] (+)= sum_k c_k dY/dtheta_q(T_g, knot_k); dynamic LDS: NW x P accumulators + P ints
+template <class AR, bool FIXED>
+__global__ __launch_bounds__(NT) void k_knot_backprop(Pools P, LawDev L, int g0, const double* __restrict__ knots_all,
+                                                      const int* __restrict__ M_all, const double* __restrict__ ab_all,
+                                                      double* __restrict__ dth, int accumulate) {
+  extern __shared__ double kb_dyn[];
+  __shared__ double stage[NW][WG_SLOTS][WG_LD];
+  double* accs = kb_dyn;
+  int* order = reinterpret_cast<int*>(kb_dyn + (size_t)NW * L.P);
+  const int lane = threadIdx.x & 63, w = wave_id();
+  for (int k = threadIdx.x; k < NW * L.P; k += NT) accs[k] = 0.0;
+  if (threadIdx.x == 0) mlp_grad_order(L, order);
+  __syncthreads();
+  const WaveAcc A{stage[w], order, accs + (size_t)w * L.P};
+  const int M = M_all[blockIdx.x];
+  const double* knots = knots_all + (size_t)blockIdx.x * KMAX;
+  const double* ab = ab_all + (size_t)blockIdx.x * 2 * KMAX;
+  const double T = P.gd[g0 + blockIdx.x].T;
+  for (int c = w; c * 64 < M; c += NW) {
+    const int k = c * 64 + lane;
+    double ck = 0.0, x = 0.0;
+    if (k < M) {
+      ck = (k < M - 1 ? ab[k] : 0.0) + (k > 0 ? ab[KMAX + k - 1] : 0.0);
+      x = knots[k];
+    }
+    mlp_grad_wave<AR, FIXED>(L, T, x, ck, A, lane);
+  }
+  __syncthreads();
+  double* out = dth + (size_t)(g0 + blockIdx.x) * L.P;
+  for (int q = threadIdx.x; q < L.P; q += NT) {
+    double s = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) s += accs[(size_t)ww * L.P + q];
+    out[q] = accumulate ? out[q] + s : s;
+  }
 }
 
 __global__ __launch_bounds__(64) void k_interp_contract(int P, const int* __restrict__ Mp, const double* __restrict__ ab,
@@ -265,6 +373,55 @@ int launch_interp_theta_U(hipStream_t st, const LawDev& L, int n_half, const dou
   hipLaunchKernelGGL(k_ucell_sums, dim3((unsigned)((K - 1) * (K - 1))), dim3(NT), 0, st, skeys, sidx, nd, nodeH, nodeS, nodeV, K, cell4);
   hipLaunchKernelGGL(k_unode_grads, dim3(KMAX / 64), dim3(64), 0, st, L, K, cell4, G);
   hipLaunchKernelGGL(k_slot_sum, dim3((L.P + 63) / 64), dim3(64), 0, st, L.P, G, dth, accumulate);
+  return 0;
+}
+
+template <class AR>
+static bool interp_law_is(const LawDev& L) {
+  if (L.n_layers != AR::NL) return false;
+  for (int l = 0; l <= AR::NL; ++l) if (L.widths[l] != AR::W[l]) return false;
+  for (int l = 0; l < AR::NL; ++l) if (L.acts[l] != AR::A[l]) return false;
+  return true;
+}
+size_t interp_batch_temp_bytes(long long n_max) {
+  size_t b1 = 0, b2 = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, b1, (const double*)nullptr, (double*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr,
+                                  (size_t)n_max, 0, 64, nullptr);
+  (void)rocprim::radix_sort_pairs(nullptr, b2, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr,
+                                  (unsigned*)nullptr, (size_t)n_max, 0, 32, nullptr);
+  return b1 > b2 ? b1 : b2;
+}
+void launch_fill_gid(hipStream_t st, Pools P, int G, long long ntotd, unsigned* gid, unsigned* iota) {
+  hipLaunchKernelGGL(k_fill_gid, dim3(1024), dim3(256), 0, st, P, G, ntotd, gid, iota);
+}
+size_t interp_batch_lds_bytes(int P) { return (size_t)NW * P * sizeof(double) + (size_t)P * sizeof(int); }
+// the glaciers [g0, g0 + ng) whose dual nodes are the pooled range [lo, lo + n): nodeH / nodeV / gid point at the POOL's first
+// node, iota holds 0, 1, 2, ...; scratch (n entries each): sH, sV, iA, iB, kA, kB; knots (ng KMAX), M (ng), ab (ng 2 KMAX)
+int launch_interp_theta_batch(hipStream_t st, Pools P, const LawDev& L, int n_half, int g0, int ng, long long lo, long long n,
+                              const double* nodeH, const double* nodeV, const unsigned* gid, const unsigned* iota, double* sH,
+                              double* sV, unsigned* iA, unsigned* iB, unsigned* kA, unsigned* kB, void* tmp, size_t tmp_bytes,
+                              double* knots, int* M, double* ab, double* dth, int accumulate) {
+  if (2 * n_half > KMAX || n_half < 2 || n >= (1ll << 32)) return 1;
+  const unsigned nb = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+  if (rocprim::radix_sort_pairs(tmp, tmp_bytes, nodeH + lo, sH, iota, iA, (size_t)n, 0, 64, st) != hipSuccess) return 2;
+  const unsigned* order = iA;
+  if (ng > 1) {
+    int bits = 1;
+    while ((1ll << bits) < (long long)(g0 + ng)) ++bits;
+    hipLaunchKernelGGL(k_gather_gid, dim3(nb), dim3(256), 0, st, gid + lo, iA, n, kA);
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, kA, kB, iA, iB, (size_t)n, 0, bits, st) != hipSuccess) return 2;
+    order = iB;
+  }
+  hipLaunchKernelGGL(k_gather_HV, dim3(nb), dim3(256), 0, st, nodeH + lo, nodeV + lo, order, n, sH, sV);
+  hipLaunchKernelGGL(k_knots_b, dim3(ng), dim3(KMAX), 0, st, P, g0, g0 + ng - 1, lo, lo + n, sH, n_half, knots, M);
+  hipLaunchKernelGGL(k_interval_sums_b, dim3(2 * n_half, ng), dim3(NT), 0, st, P, g0, g0 + ng - 1, lo, lo + n, sH, sV, knots, M, ab);
+  const size_t dyn = interp_batch_lds_bytes(L.P);
+  if (interp_law_is<ArchDef>(L))
+    hipLaunchKernelGGL((k_knot_backprop<ArchDef, true>), dim3(ng), dim3(NT), dyn, st, P, L, g0, knots, M, ab, dth, accumulate);
+  else if (interp_law_is<Arch16>(L))
+    hipLaunchKernelGGL((k_knot_backprop<Arch16, true>), dim3(ng), dim3(NT), dyn, st, P, L, g0, knots, M, ab, dth, accumulate);
+  else
+    hipLaunchKernelGGL((k_knot_backprop<ArchRT, false>), dim3(ng), dim3(NT), dyn, st, P, L, g0, knots, M, ab, dth, accumulate);
   return 0;
 }
 

@@ -38,6 +38,13 @@ void launch_vjp_theta_strip(int gacc, int itp, int nblk, hipStream_t st, Pools P
 
 // k_interp.hip: `:Linear` spatial interpolation of d law / d theta for the Y law (target_D_hybrid.jl:136-160)
 constexpr int INTERP_KMAX = 512;
+size_t interp_batch_temp_bytes(long long n_max);
+size_t interp_batch_lds_bytes(int P);
+void launch_fill_gid(hipStream_t st, Pools P, int G, long long ntotd, unsigned* gid, unsigned* iota);
+int launch_interp_theta_batch(hipStream_t st, Pools P, const LawDev& L, int n_half, int g0, int ng, long long lo, long long n,
+                              const double* nodeH, const double* nodeV, const unsigned* gid, const unsigned* iota, double* sH,
+                              double* sV, unsigned* iA, unsigned* iB, unsigned* kA, unsigned* kB, void* tmp, size_t tmp_bytes,
+                              double* knots, int* M, double* ab, double* dth, int accumulate);
 size_t interp_sort_temp_bytes(long long nd_max);
 int launch_interp_theta(hipStream_t st, const LawDev& L, double T, int n_half, const double* nodeH, const double* nodeV,
                         long long nd, double* sH, double* sV, void* tmp, size_t tmp_bytes, double* knots, int* M, double* G,

@@ -290,6 +290,19 @@ struct odinn_batch {
          *d_knotab = nullptr;
   int* d_knotM = nullptr;
   void* d_sorttmp = nullptr;
+  // the per-glacier sort / knots / interval-sums sequences of one evaluation run side by side on interp_lanes streams, each
+  // with its own scratch set (lane l: offset l * <size> into the arrays above)
+  // Y law: the whole batch in one sequence of launches (launch_interp_theta_batch); scratch over the pooled dual nodes
+  unsigned *d_ib_gid = nullptr, *d_ib_iota = nullptr, *d_ib_iA = nullptr, *d_ib_iB = nullptr, *d_ib_kA = nullptr, *d_ib_kB = nullptr;
+  double *d_ib_sH = nullptr, *d_ib_sV = nullptr, *d_ib_knots = nullptr, *d_ib_ab = nullptr;
+  int* d_ib_M = nullptr;
+  void* d_ib_tmp = nullptr;
+  size_t ib_tmp_bytes = 0;
+  static constexpr int INTERP_LANES_MAX = 8;
+  int interp_lanes = 0;
+  long long interp_ndmax = 0;
+  hipStream_t side[INTERP_LANES_MAX] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[INTERP_LANES_MAX] = {};
   size_t sorttmp_bytes = 0, knotG_cap = 0;
   double *d_part_theta = nullptr, *d_gscratch = nullptr, *d_dth = nullptr;
   size_t part_theta_cap = 0, gscratch_cap = 0, dth_cap = 0;
@@ -1377,6 +1390,14 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_nodeH); dfree(b->d_nodeV); dfree(b->d_sortH); dfree(b->d_sortV); dfree(b->d_knots); dfree(b->d_knotG);
   dfree(b->d_knotab); dfree(b->d_knotM);
   if (b->d_sorttmp) { (void)hipFree(b->d_sorttmp); b->d_sorttmp = nullptr; }
+  dfree(b->d_ib_gid); dfree(b->d_ib_iota); dfree(b->d_ib_iA); dfree(b->d_ib_iB); dfree(b->d_ib_kA); dfree(b->d_ib_kB);
+  dfree(b->d_ib_sH); dfree(b->d_ib_sV); dfree(b->d_ib_knots); dfree(b->d_ib_ab); dfree(b->d_ib_M);
+  if (b->d_ib_tmp) { (void)hipFree(b->d_ib_tmp); b->d_ib_tmp = nullptr; }
+  for (int l = 0; l < odinn_batch::INTERP_LANES_MAX; ++l) {
+    if (b->side[l]) (void)hipStreamDestroy(b->side[l]);
+    if (b->ev_join[l]) (void)hipEventDestroy(b->ev_join[l]);
+  }
+  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
   dfree(b->d_Vabs); dfree(b->d_Vxr); dfree(b->d_Vyr); dfree(b->d_wv); dfree(b->d_vsc); dfree(b->d_vslot);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -1583,20 +1604,41 @@ static int ensure_interp_scratch(odinn_batch* b) {
   if (!b->d_nodeH) {
     long long ndmax = 1;
     for (const GDev& r : b->gd) ndmax = std::max(ndmax, (long long)(r.nx - 1) * (r.ny - 1));
+    int lanes = std::min(b->G, (int)odinn_batch::INTERP_LANES_MAX);
+    if (const char* e = std::getenv("ODINN_INTERP_STREAMS")) lanes = std::max(1, std::min(lanes, std::atoi(e)));
+    b->interp_lanes = lanes;
+    b->interp_ndmax = ndmax;
     CHK(dalloc(&b->d_nodeH, (size_t)b->ntotd)); CHK(dalloc(&b->d_nodeV, (size_t)b->ntotd));
-    CHK(dalloc(&b->d_sortH, (size_t)ndmax)); CHK(dalloc(&b->d_sortV, (size_t)ndmax));
-    CHK(dalloc(&b->d_knots, (size_t)INTERP_KMAX)); CHK(dalloc(&b->d_knotab, (size_t)2 * INTERP_KMAX));
-    CHK(dalloc(&b->d_knotM, (size_t)1));
-    b->sorttmp_bytes = interp_sort_temp_bytes(ndmax);
-    HIPCHK(hipMalloc(&b->d_sorttmp, std::max<size_t>(b->sorttmp_bytes, 16)));
+    CHK(dalloc(&b->d_sortH, (size_t)ndmax * lanes)); CHK(dalloc(&b->d_sortV, (size_t)ndmax * lanes));
+    CHK(dalloc(&b->d_knots, (size_t)INTERP_KMAX * lanes)); CHK(dalloc(&b->d_knotab, (size_t)2 * INTERP_KMAX * lanes));
+    CHK(dalloc(&b->d_knotM, (size_t)lanes));
+    b->sorttmp_bytes = (interp_sort_temp_bytes(ndmax) + 255) & ~(size_t)255;
+    HIPCHK(hipMalloc(&b->d_sorttmp, std::max<size_t>(b->sorttmp_bytes, 256) * lanes));
+    if (lanes > 1) {
+      HIPCHK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+      for (int l = 0; l < lanes; ++l) {
+        HIPCHK(hipStreamCreateWithFlags(&b->side[l], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_join[l], hipEventDisableTiming));
+      }
+    }
   }
   if (b->law_kind == ODINN_LAW_NN_U && !b->d_nodeS) {
     CHK(dalloc(&b->d_nodeS, (size_t)b->ntotd));
-    CHK(dalloc(&b->d_ucell, (size_t)4 * (INTERP_KMAX - 1) * (INTERP_KMAX - 1)));
+    CHK(dalloc(&b->d_ucell, (size_t)4 * (INTERP_KMAX - 1) * (INTERP_KMAX - 1) * b->interp_lanes));
     HIPCHK(hipMalloc(&b->d_interp_err, sizeof(int)));
     HIPCHK(hipMemsetAsync(b->d_interp_err, 0, sizeof(int), b->stream));
   }
-  const size_t need = (size_t)std::max(b->P, 1) * INTERP_KMAX;
+  if (b->law_kind == ODINN_LAW_NN_Y && !b->d_ib_gid && b->ntotd < (1ll << 32)) {
+    const size_t N = (size_t)b->ntotd;
+    CHK(dalloc(&b->d_ib_gid, N)); CHK(dalloc(&b->d_ib_iota, N)); CHK(dalloc(&b->d_ib_iA, N)); CHK(dalloc(&b->d_ib_iB, N));
+    CHK(dalloc(&b->d_ib_kA, N)); CHK(dalloc(&b->d_ib_kB, N)); CHK(dalloc(&b->d_ib_sH, N)); CHK(dalloc(&b->d_ib_sV, N));
+    CHK(dalloc(&b->d_ib_knots, (size_t)b->G * INTERP_KMAX)); CHK(dalloc(&b->d_ib_ab, (size_t)b->G * 2 * INTERP_KMAX));
+    CHK(dalloc(&b->d_ib_M, (size_t)b->G));
+    b->ib_tmp_bytes = interp_batch_temp_bytes(b->ntotd);
+    HIPCHK(hipMalloc(&b->d_ib_tmp, std::max<size_t>(b->ib_tmp_bytes, 256)));
+    launch_fill_gid(b->stream, b->pools(true), b->G, b->ntotd, b->d_ib_gid, b->d_ib_iota);
+  }
+  const size_t need = (size_t)std::max(b->P, 1) * INTERP_KMAX * b->interp_lanes;
   if (need > b->knotG_cap) {
     dfree(b->d_knotG);
     CHK(dalloc(&b->d_knotG, need));
@@ -1653,18 +1695,50 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   if (linear) {
     // dtheta_g (+)= sum_knots c_k dY/dtheta(T_g, knot_k): sort the glacier's nodes by Hbar, build its knots, sum per interval
     const LawDev L = b->lawdev();
+    // Y law: all glaciers of the call in one sequence of launches (ODINN_INTERP_BATCH=0: one sequence per glacier)
+    const char* eb = std::getenv("ODINN_INTERP_BATCH");
+    if (!linU && b->d_ib_gid && !(eb && eb[0] == '0') && interp_batch_lds_bytes(b->P) <= 30 * 1024) {
+      const long long lo = b->gd[g0].offd;
+      const long long hi = g0 + ng < b->G ? b->gd[g0 + ng].offd : b->ntotd;
+      const int rc = launch_interp_theta_batch(b->stream, P, L, b->n_interp_half, g0, ng, lo, hi - lo, b->d_nodeH, b->d_nodeV,
+                                               b->d_ib_gid, b->d_ib_iota, b->d_ib_sH, b->d_ib_sV, b->d_ib_iA, b->d_ib_iB, b->d_ib_kA,
+                                               b->d_ib_kB, b->d_ib_tmp, b->ib_tmp_bytes, b->d_ib_knots, b->d_ib_M, b->d_ib_ab,
+                                               b->d_dth, accumulate ? 1 : 0);
+      if (rc) return fail(ODINN_ERR_HIP, "gradient interpolation failed (code %d)", rc);
+      HIPCHK(hipGetLastError());
+      return ODINN_OK;
+    }
+    // glaciers are independent (own nodes, own dtheta slot): their sequences run side by side on the lane streams, forked
+    // from and joined back into the batch's stream by events
+    const int lanes = std::min(ng, b->interp_lanes);
+    if (lanes > 1) {
+      HIPCHK(hipEventRecord(b->ev_fork, b->stream));
+      for (int l = 0; l < lanes; ++l) HIPCHK(hipStreamWaitEvent(b->side[l], b->ev_fork, 0));
+    }
+    const size_t Pk = (size_t)std::max(b->P, 1) * INTERP_KMAX, ucn = (size_t)4 * (INTERP_KMAX - 1) * (INTERP_KMAX - 1);
     for (int q = g0; q < g0 + ng; ++q) {
       const GDev& r = b->gd[q];
       const long long nd = (long long)(r.nx - 1) * (r.ny - 1);
-      const int rc = linU ? launch_interp_theta_U(b->stream, L, b->n_interp_half, b->d_nodeH + r.offd, b->d_nodeS + r.offd,
-                                                  b->d_nodeV + r.offd, nd, b->d_sortH, b->d_sortV, b->d_sorttmp, b->sorttmp_bytes,
-                                                  b->d_ucell, b->d_knotG, b->d_interp_err, b->d_dth + (size_t)q * b->P,
-                                                  accumulate ? 1 : 0)
-                          : launch_interp_theta(b->stream, L, b->descs[q].T, b->n_interp_half, b->d_nodeH + r.offd, b->d_nodeV + r.offd, nd,
-                                         b->d_sortH, b->d_sortV, b->d_sorttmp, b->sorttmp_bytes, b->d_knots, b->d_knotM,
-                                         b->d_knotG, b->d_knotab, b->d_dth + (size_t)q * b->P, accumulate ? 1 : 0);
+      const int l = lanes > 1 ? (q - g0) % lanes : 0;
+      hipStream_t st = lanes > 1 ? b->side[l] : b->stream;
+      double* sH = b->d_sortH + (size_t)l * b->interp_ndmax;
+      double* sV = b->d_sortV + (size_t)l * b->interp_ndmax;
+      void* tmp = static_cast<char*>(b->d_sorttmp) + (size_t)l * std::max<size_t>(b->sorttmp_bytes, 256);
+      const int rc = linU ? launch_interp_theta_U(st, L, b->n_interp_half, b->d_nodeH + r.offd, b->d_nodeS + r.offd,
+                                                  b->d_nodeV + r.offd, nd, sH, sV, tmp, b->sorttmp_bytes,
+                                                  b->d_ucell + (size_t)l * ucn, b->d_knotG + (size_t)l * Pk, b->d_interp_err,
+                                                  b->d_dth + (size_t)q * b->P, accumulate ? 1 : 0)
+                          : launch_interp_theta(st, L, b->descs[q].T, b->n_interp_half, b->d_nodeH + r.offd, b->d_nodeV + r.offd, nd,
+                                                sH, sV, tmp, b->sorttmp_bytes, b->d_knots + (size_t)l * INTERP_KMAX, b->d_knotM + l,
+                                                b->d_knotG + (size_t)l * Pk, b->d_knotab + (size_t)l * 2 * INTERP_KMAX,
+                                                b->d_dth + (size_t)q * b->P, accumulate ? 1 : 0);
       if (rc) return fail(ODINN_ERR_HIP, "gradient interpolation failed (code %d)", rc);
     }
+    if (lanes > 1)
+      for (int l = 0; l < lanes; ++l) {
+        HIPCHK(hipEventRecord(b->ev_join[l], b->side[l]));
+        HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join[l], 0));
+      }
   } else if (part_deferred) {
   } else if (nn_node)
     launch_sum_part_theta(b->P, ng, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g0);
@@ -1680,7 +1754,7 @@ static int gridded_law_grad(odinn_batch* b, long long lo, long long n, double* d
   // wave-reduced kernel (accumulators in LDS) while they fit; ODINN_LAWGRAD_WAVE=0: per-thread accumulators in global memory
   const char* ew = std::getenv("ODINN_LAWGRAD_WAVE");
   const size_t dyn = (size_t)NW * b->P * sizeof(double) + (size_t)b->P * sizeof(int);
-  if (!(ew && ew[0] == '0') && dyn <= 48 * 1024) {
+  if (!(ew && ew[0] == '0') && dyn <= 30 * 1024) {  // + 33 KB of static staging area: within the 64 KB of a workgroup
     const int max_rows = 2048;
     CHK(ensure_theta_scratch(b, max_rows, false));
     nblk = launch_law_field_grad(b->stream, b->lawdev(), b->d_Tfield + lo, b->d_Gacc + lo, n, b->d_part_theta, max_rows);

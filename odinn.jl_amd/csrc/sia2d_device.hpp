@@ -438,6 +438,112 @@ inline __device__ __noinline__ void mlp_grad(const LawDev& L, double x0, double 
   }
 }
 
+// ---- wave-reduced backprop: sum over the 64 lanes of a wavefront of wgt * d out / d theta, accumulated in LDS ----------
+// (users: k_law_field_grad_wave -- the hoisted gridded law -- and the knot contraction of the `:Linear` interpolation)
+constexpr int WG_SLOTS = 16, WG_LD = 65;
+struct WaveAcc {
+  double (*stage)[WG_LD];  // the wavefront's [WG_SLOTS][WG_LD] staging area
+  const int* order;        // parameter index of the n-th contribution of a backward pass (mlp_grad_order)
+  double* acc;             // the wavefront's [P] accumulators
+};
+struct ArchRT { static constexpr int NL = MAXL, MAXW = 32; static constexpr int W[MAXL + 1] = {}; static constexpr int A[MAXL] = {}; };
+// order in which mlp_grad_wave emits its contributions: layers last to first, per output unit the bias, then its weights
+__device__ inline void mlp_grad_order(const LawDev& L, int* order) {
+  int offs[MAXL + 1];
+  offs[0] = 0;
+  for (int l = 0; l < L.n_layers; ++l) offs[l + 1] = offs[l] + L.widths[l + 1] * (L.widths[l] + 1);
+  int n = 0;
+  for (int l = L.n_layers - 1; l >= 0; --l) {
+    const int nin = L.widths[l], nout = L.widths[l + 1];
+    for (int o = 0; o < nout; ++o) {
+      order[n++] = offs[l] + nin * nout + o;
+      for (int i = 0; i < nin; ++i) order[n++] = offs[l] + o + nout * i;
+    }
+  }
+}
+__device__ __forceinline__ void wave_acc_flush(const WaveAcc& A, int base, int nslot, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int kk = lane & 15, q = lane >> 4;
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += A.stage[kk][16 * q + j];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (lane < nslot) A.acc[A.order[base + lane]] += s;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// activation and its derivative from one exponential (softplus / sigmoid: the formulas of act_f and dact_f)
+__device__ __forceinline__ void act_dact(int code, double z, double& a, double& da) {
+  if (code == 1) {
+    const double t = exp_nonpos(-fabs(z));
+    a = log1p_01(t) + fmax(z, 0.0);
+    da = fast_div(z >= 0.0 ? 1.0 : t, 1.0 + t);
+  } else if (code == 2) {
+    a = sigmoid_f(z);
+    da = a * (1.0 - a);
+  } else {
+    a = act_f(code, z);
+    da = dact_f(code, z);
+  }
+}
+// acc[k] += sum over the wavefront's 64 lanes of wgt * d out / d theta_k at the lane's input (mlp_grad's arithmetic per
+// lane).  ALL 64 lanes call it together (a lane without a node passes wgt = 0).  FIXED: compile-time architecture AR,
+// fully unrolled, activations in registers; otherwise the run-time architecture of L (AR = ArchRT).
+template <class AR, bool FIXED>
+__device__ __forceinline__ void mlp_grad_wave(const LawDev& L, double x0, double x1, double wgt, const WaveAcc& A, int lane) {
+  constexpr int MW = AR::MAXW, ML = AR::NL;
+  const int nl = FIXED ? AR::NL : L.n_layers;
+  double hs[ML + 1][MW], ds[ML][MW];
+  const double* __restrict__ th = L.theta;
+  hs[0][0] = L.has_pre ? (x0 - L.pre_lo[0]) * L.pre_inv[0] - 0.5 : x0;
+  if (MW > 1) hs[0][1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
+  int offs[ML + 1];
+  offs[0] = 0;
+#pragma unroll
+  for (int l = 0; l < nl; ++l) {
+    const int nin = FIXED ? AR::W[l] : L.widths[l], nout = FIXED ? AR::W[l + 1] : L.widths[l + 1];
+    const int a = FIXED ? AR::A[l] : L.acts[l];
+    const int off = offs[l];
+#pragma unroll
+    for (int o = 0; o < nout; ++o) {
+      double acc = th[off + nin * nout + o];
+#pragma unroll
+      for (int i = 0; i < nin; ++i) acc = fma(th[off + o + nout * i], hs[l][i], acc);
+      act_dact(a, acc, hs[l + 1][o], ds[l][o]);
+    }
+    offs[l + 1] = off + nout * (nin + 1);
+  }
+  double gv[MW], gn[MW];
+  gv[0] = wgt * dpostscale_f(L, hs[nl][0]);
+  int slot = 0, base = 0;
+#pragma unroll
+  for (int l = nl - 1; l >= 0; --l) {
+    const int nin = FIXED ? AR::W[l] : L.widths[l], nout = FIXED ? AR::W[l + 1] : L.widths[l + 1];
+    const int off = offs[l];
+#pragma unroll
+    for (int i = 0; i < nin; ++i) gn[i] = 0.0;
+#pragma unroll
+    for (int o = 0; o < nout; ++o) {
+      const double dz = gv[o] * ds[l][o];
+#pragma unroll
+      for (int i = -1; i < nin; ++i) {  // i == -1: the bias
+        A.stage[slot][lane] = i < 0 ? dz : dz * hs[l][i < 0 ? 0 : i];
+        if (i >= 0) gn[i] = fma(th[off + o + nout * i], dz, gn[i]);
+        if (++slot == WG_SLOTS) {
+          wave_acc_flush(A, base, WG_SLOTS, lane);
+          base += WG_SLOTS;
+          slot = 0;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < nin; ++i) gv[i] = gn[i];
+  }
+  if (slot) wave_acc_flush(A, base, slot, lane);
+}
+
 // ---- law modes of the stencil kernels ---------------------------------------------------------
 // 0 integer-power A law, 1 generic-pow A law, 2 inlined MLP with run-time architecture,
 // 3..5 inlined MLP with a compile-time architecture (fully unrolled, activations in registers):
@@ -2108,109 +2214,6 @@ __global__ __launch_bounds__(NT) void k_law_field_grad(LawDev L, const double* _
 // parameter's 64 contributions go through an LDS staging area (16 parameters per flush: 16 ds_write + 16 ds_read +
 // 2 cross-row shuffles per lane, bank-conflict free on rows padded to 65) into the wavefront's P accumulators in LDS;
 // chunks whose 64 weights are all zero (no ice: Gacc == 0) are skipped.  Summation order is fixed.
-constexpr int WG_SLOTS = 16, WG_LD = 65;
-struct WaveAcc {
-  double (*stage)[WG_LD];  // the wavefront's [WG_SLOTS][WG_LD] staging area
-  const int* order;        // parameter index of the n-th contribution of a backward pass (mlp_grad_order)
-  double* acc;             // the wavefront's [P] accumulators
-};
-struct ArchRT { static constexpr int NL = MAXL, MAXW = 32; static constexpr int W[MAXL + 1] = {}; static constexpr int A[MAXL] = {}; };
-// order in which mlp_grad_wave emits its contributions: layers last to first, per output unit the bias, then its weights
-__device__ inline void mlp_grad_order(const LawDev& L, int* order) {
-  int offs[MAXL + 1];
-  offs[0] = 0;
-  for (int l = 0; l < L.n_layers; ++l) offs[l + 1] = offs[l] + L.widths[l + 1] * (L.widths[l] + 1);
-  int n = 0;
-  for (int l = L.n_layers - 1; l >= 0; --l) {
-    const int nin = L.widths[l], nout = L.widths[l + 1];
-    for (int o = 0; o < nout; ++o) {
-      order[n++] = offs[l] + nin * nout + o;
-      for (int i = 0; i < nin; ++i) order[n++] = offs[l] + o + nout * i;
-    }
-  }
-}
-__device__ __forceinline__ void wave_acc_flush(const WaveAcc& A, int base, int nslot, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const int kk = lane & 15, q = lane >> 4;
-  double s = 0.0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) s += A.stage[kk][16 * q + j];
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  if (lane < nslot) A.acc[A.order[base + lane]] += s;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-// activation and its derivative from one exponential (softplus / sigmoid: the formulas of act_f and dact_f)
-__device__ __forceinline__ void act_dact(int code, double z, double& a, double& da) {
-  if (code == 1) {
-    const double t = exp_nonpos(-fabs(z));
-    a = log1p_01(t) + fmax(z, 0.0);
-    da = fast_div(z >= 0.0 ? 1.0 : t, 1.0 + t);
-  } else if (code == 2) {
-    a = sigmoid_f(z);
-    da = a * (1.0 - a);
-  } else {
-    a = act_f(code, z);
-    da = dact_f(code, z);
-  }
-}
-// acc[k] += sum over the wavefront's 64 lanes of wgt * d out / d theta_k at the lane's input (mlp_grad's arithmetic per
-// lane).  ALL 64 lanes call it together (a lane without a node passes wgt = 0).  FIXED: compile-time architecture AR,
-// fully unrolled, activations in registers; otherwise the run-time architecture of L (AR = ArchRT).
-template <class AR, bool FIXED>
-__device__ __forceinline__ void mlp_grad_wave(const LawDev& L, double x0, double x1, double wgt, const WaveAcc& A, int lane) {
-  constexpr int MW = AR::MAXW, ML = AR::NL;
-  const int nl = FIXED ? AR::NL : L.n_layers;
-  double hs[ML + 1][MW], ds[ML][MW];
-  const double* __restrict__ th = L.theta;
-  hs[0][0] = L.has_pre ? (x0 - L.pre_lo[0]) * L.pre_inv[0] - 0.5 : x0;
-  if (MW > 1) hs[0][1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
-  int offs[ML + 1];
-  offs[0] = 0;
-#pragma unroll
-  for (int l = 0; l < nl; ++l) {
-    const int nin = FIXED ? AR::W[l] : L.widths[l], nout = FIXED ? AR::W[l + 1] : L.widths[l + 1];
-    const int a = FIXED ? AR::A[l] : L.acts[l];
-    const int off = offs[l];
-#pragma unroll
-    for (int o = 0; o < nout; ++o) {
-      double acc = th[off + nin * nout + o];
-#pragma unroll
-      for (int i = 0; i < nin; ++i) acc = fma(th[off + o + nout * i], hs[l][i], acc);
-      act_dact(a, acc, hs[l + 1][o], ds[l][o]);
-    }
-    offs[l + 1] = off + nout * (nin + 1);
-  }
-  double gv[MW], gn[MW];
-  gv[0] = wgt * dpostscale_f(L, hs[nl][0]);
-  int slot = 0, base = 0;
-#pragma unroll
-  for (int l = nl - 1; l >= 0; --l) {
-    const int nin = FIXED ? AR::W[l] : L.widths[l], nout = FIXED ? AR::W[l + 1] : L.widths[l + 1];
-    const int off = offs[l];
-#pragma unroll
-    for (int i = 0; i < nin; ++i) gn[i] = 0.0;
-#pragma unroll
-    for (int o = 0; o < nout; ++o) {
-      const double dz = gv[o] * ds[l][o];
-#pragma unroll
-      for (int i = -1; i < nin; ++i) {  // i == -1: the bias
-        A.stage[slot][lane] = i < 0 ? dz : dz * hs[l][i < 0 ? 0 : i];
-        if (i >= 0) gn[i] = fma(th[off + o + nout * i], dz, gn[i]);
-        if (++slot == WG_SLOTS) {
-          wave_acc_flush(A, base, WG_SLOTS, lane);
-          base += WG_SLOTS;
-          slot = 0;
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < nin; ++i) gv[i] = gn[i];
-  }
-  if (slot) wave_acc_flush(A, base, slot, lane);
-}
 // part_theta[block][k] = sum over the block's nodes of G[i] * dA/dtheta_k(T[i]); dynamic LDS: NW x P accumulators + P ints
 template <class AR, bool FIXED>
 __global__ __launch_bounds__(NT) void k_law_field_grad_wave(LawDev L, const double* __restrict__ T, const double* __restrict__ G,

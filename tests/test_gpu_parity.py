@@ -796,6 +796,38 @@ def test_Y_law_theta_gradient_interpolation_modes(gpu):
     b.close()
 
 
+@pytest.mark.parametrize("arch", ["default", "w16", "runtime"])
+def test_Y_law_interpolation_batched_and_per_glacier_sequences_agree(gpu, monkeypatch, arch):
+    """The `:Linear` gradient of a whole ragged batch through its three launch schedules: one sequence for all glaciers
+    (one radix sort of every dual node by Hbar + one stable sort by glacier, knots and interval sums with a block row per
+    glacier, the knot contraction as one wave-reduced backprop; the default), one sequence per glacier on side streams,
+    and one per glacier on the batch's stream.  Same knots, same interval sums; only the contraction's rounding differs."""
+    ph = O.Phys()
+    widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "w16": ([2, 16, 16, 1], [1, 1, 2]), "runtime": ([2, 5, 4, 1], [4, 1, 2])}[arch]
+    om, gm, th = _mlp_pair(gpu, widths, acts, [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+    shapes = [(80, 48), (131, 97), (40, 33), (66, 70)]
+    ts = [0.0, 0.5, 1.0]
+    out = []
+    for batch, streams in (("1", "8"), ("0", "8"), ("0", "1")):
+        monkeypatch.setenv("ODINN_INTERP_BATCH", batch)
+        monkeypatch.setenv("ODINN_INTERP_STREAMS", streams)
+        b = gpu.GlacierBatch(shapes, [100.0] * 4, T=[-5.0, -2.0, -7.0, -4.0])
+        for k, (nx, ny) in enumerate(shapes):
+            H0, B = O.synthetic_icecap(nx, ny, 100.0) if k != 1 else O.synthetic_valley(nx, ny, 100.0)
+            H0 = H0 * (0.4 if k != 1 else 1.0) * (0.0 if k == 2 else 1.0)  # glacier 2: no ice at all
+            b.set_fields(k, H0, B)
+            b.set_reference(k, ts, [H0 * (1.0 - 0.05 * j) for j in range(3)], 3)
+        b.set_law(gpu.LAW_NN_Y, gm, th)
+        L, g = b.loss_grad(ts, theta=th, reltol=1e-8)
+        Lc, gc = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+        out.append((L, np.array(g, dtype=float).ravel(), np.array(gc, dtype=float).ravel()))
+        b.close()
+    for o in out[1:]:
+        assert o[0] == out[0][0]
+        assert rel_l2(o[1], out[0][1]) < 1e-12 and rel_l2(o[2], out[0][2]) < 1e-12
+    assert np.linalg.norm(out[0][1]) > 0.0
+
+
 def test_U_law_theta_gradient_bilinear_interpolation(gpu):
     """SIA2D_D_target(interpolation = :Linear) (target_D_pure.jl:179-193): gradients of the U law on the fixed
     (2 n_interp_half)^2 node grid of LawU's p_VJP! (Laws.jl:128-169), bilinear in (Hbar, |grad S|).  On the device: dual
