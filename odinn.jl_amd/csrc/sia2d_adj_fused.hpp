@@ -40,6 +40,11 @@ typedef double (*AdjEdgesL)[TNW][2][FRX];
 #ifndef ODINN_ADJ_PF2
 #define ODINN_ADJ_PF2 0
 #endif
+// ODINN_ADJ_APF: gridded A one node row ahead of its use (like {Hc,S}) instead of inside node_face (8 x 1024^2, gridded
+// law: 282 -> 262 us per reverse step; 0 restores the load at the point of use)
+#ifndef ODINN_ADJ_APF
+#define ODINN_ADJ_APF 1
+#endif
 typedef double (*AdjErr)[FRX];
 
 template <int S, bool AF, bool SG, int NR>
@@ -100,7 +105,8 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   // upper neighbours are the "_hi" ones; returns D, the four corner terms and the north face's two second-term parts
   auto node_face = [&](int gj, double2 hs_lo, double2 e_lo, double le_lo, double dx_lo, double hp_lo, double Pe_lo,
                        double2 hs_hi, double2 e_hi, double le_hi, double dx_hi, double hp_hi, double Pe_hi, double& D,
-                       double& k00, double& k10, double& k01, double& k11, double& Mn, double& PLn, double& tw) {
+                       double& k00, double& k10, double& k01, double& k11, double& Mn, double& PLn, double& tw,
+                       [[maybe_unused]] double An_pf) {
     const double dyw = hs_hi.y - hs_lo.y, dye = e_hi.y - e_lo.y;
     const double qn = le_hi - le_lo;
     const double Pn = qn * clampn(dyw, hs_hi.x, hs_lo.x);
@@ -110,8 +116,12 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     const double gS2 = gx * gx + gy * gy;
     double An = g.A;
     if (AF) {
-      const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
-      An = ldg32(Afield, (unsigned)(ok ? gif + (g.nx - 1) * gj : 0));  // Afield: the glacier's first dual node (ok: gif == gi)
+      if constexpr (ODINN_ADJ_APF) {
+        An = An_pf;
+      } else {
+        const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+        An = ldg32(Afield, (unsigned)(ok ? gif + (g.nx - 1) * gj : 0));  // Afield: the glacier's first dual node (ok: gif == gi)
+      }
     }
     const double Kq = An * Gq;
     const double H2 = Hs * Hs, H4 = H2 * H2, H5 = H4 * Hs;
@@ -133,13 +143,19 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     PLn = (dyw > -hs_lo.x && dyw != hs_hi.x) ? -tn : 0.0;
   };
 
+  [[maybe_unused]] auto ld_A = [&](int gj) {
+    const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+    return ldg32(Afield, (unsigned)(ok ? gif + (g.nx - 1) * gj : 0));
+  };
+  [[maybe_unused]] double A_c = 0.0, A_s = 0.0;
+  if constexpr (AF && ODINN_ADJ_APF) { A_s = ld_A(gj0 + r0 - 1); A_c = ld_A(gj0 + r0); }
   {  // the node row and the north faces just below the strip
     const double2 e_s = dpp_from_east(hs_s);
     const double lee_s = dpp_shift(le_s, false);
     const double dx_s = e_s.y - hs_s.y, hp_s = hs_s.x + e_s.x;
     const double Pe_s = (lee_s - le_s) * clampn(dx_s, e_s.x, hs_s.x);
     double k00, k10, k01, k11, Mn, PLn, tw;
-    node_face(gj0 + r0 - 1, hs_s, e_s, le_s, dx_s, hp_s, Pe_s, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, D_s, k00, k10, k01, k11, Mn, PLn, tw);
+    node_face(gj0 + r0 - 1, hs_s, e_s, le_s, dx_s, hp_s, Pe_s, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, D_s, k00, k10, k01, k11, Mn, PLn, tw, A_s);
     C_s = (k01 + dpp_from_west(k11)) + PLn;
   }
 #pragma unroll
@@ -152,13 +168,15 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     } else {
       if (m + 2 < NR) hs_next = hs_itp(m + 2 < NR ? m + 2 : m, sw);
     }
+    [[maybe_unused]] double A_n = 0.0;
+    if constexpr (AF && ODINN_ADJ_APF) { if (m + 1 < NR) A_n = ld_A(gj + 1); }
     const double le_n = m + 1 < NR ? lam_e(m + 1 < NR ? m + 1 : m) : le_top;
     const double2 e_n = dpp_from_east(hs_n);
     const double lee_n = dpp_shift(le_n, false);
     const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, qe_n = lee_n - le_n;
     const double Pe_n = qe_n * clampn(dx_n, e_n.x, hs_n.x);
     double D_c, k00, k10, k01, k11, Mn, PLn, tw;
-    node_face(gj, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, hs_n, e_n, le_n, dx_n, hp_n, Pe_n, D_c, k00, k10, k01, k11, Mn, PLn, tw);
+    node_face(gj, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, hs_n, e_n, le_n, dx_n, hp_n, Pe_n, D_c, k00, k10, k01, k11, Mn, PLn, tw, A_c);
     if (S == 1 && th_red) {  // the node north-east of an OUTPUT cell belongs to this thread (every dual node to exactly one)
       const bool own = lane >= FH && lane < FH + FOX && r0 + m >= FH && r0 + m <= (NR * TNW) - 1 - FH && gi <= g.nx - 2 && gj <= g.ny - 2;
       thacc += own ? tw : 0.0;
@@ -191,6 +209,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     u[m] = un;
     hs_c = hs_n; le_c = le_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; qe_c = qe_n; Pe_c = Pe_n;
     D_s = D_c; C_s = (k01 + dpp_from_west(k11)) + PLn;
+    if constexpr (AF && ODINN_ADJ_APF) { A_c = A_n; asm volatile("" : "+v"(A_c)); }
     // row fence (see k_rk_fused_strip): pins the row order of this one-basic-block stage body
     if (ODINN_ADJ_ELDS) {
       if (S == 1)
