@@ -1880,7 +1880,7 @@ int odinn_set_avgv_reference(odinn_batch* b, int g, double t1, double t2, const 
 }
 
 int odinn_set_velocity_regularization(odinn_batch* b, double weight, int distance) {
-  if (!b || !(weight >= 0.0) || distance < 0 || distance > 64) return fail(ODINN_ERR_ARG, "bad VelocityRegularization weight / distance");
+  if (!b || !(weight >= 0.0) || distance < 0 || distance > 32) return fail(ODINN_ERR_ARG, "bad VelocityRegularization weight / distance");
   b->vreg_weight = weight; b->vreg_dist = distance;
   return ODINN_OK;
 }

@@ -2537,23 +2537,54 @@ __global__ __launch_bounds__(NT) void k_vreg_prep(Pools P, const double* __restr
   const int4 t4 = P.tiles[blockIdx.x];
   if (w[t4.x] == 0.0) return;
   const GDev g = P.gd[t4.x];
-  const int gi = t4.y * TX + (threadIdx.x & 63), ty = wave_id();
+  const int tx = threadIdx.x & 63;
+  const int gi0 = t4.y * TX, gi = gi0 + tx, ty = wave_id();
+  const double* __restrict__ Hg = H + g.off;
+  // is_in_glacier: ice on the cell and on every cell within Chebyshev distance `dist` (cells outside the grid count as
+  // ice-free) -- the definition the thickness loss uses for its reference mask (odinn_set_reference).  A wavefront owns
+  // RPT consecutive rows; the ice flags of a row are a ballot (plus one load by the first 2 dist lanes for the dist
+  // columns either side of the wavefront's 64), its horizontal erosion is 2 dist shifts and ANDs of that scalar, and
+  // every eroded row is formed once and ANDed into the rows of the wavefront within `dist` of it:
+  // 2 (RPT + 2 dist) loads per wavefront instead of RPT (2 dist + 1)^2 (dist = 3: 261 -> ~70 us at 8 x 1024^2).
+  const int gjw = t4.z * TY + ty * RPT;  // first row of this wavefront
+  unsigned long long inm[RPT];
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) inm[m] = ~0ull;
+  // halo column of this lane: lanes [0, dist) take gi0 - dist + tx, lanes [dist, 2 dist) take gi0 + 64 + (tx - dist)
+  const int hi_col = tx < dist ? gi0 - dist + tx : gi0 + 64 + (tx - dist);
+  const bool hi_ok = tx < 2 * dist && hi_col >= 0 && hi_col < g.nx;
+  for (int rr = -dist; rr < RPT + dist; ++rr) {
+    const int jj = gjw + rr;
+    const bool rowok = jj >= 0 && jj < g.ny;  // wave-uniform
+    unsigned long long E = 0ull;
+    if (rowok) {
+      const bool ice = gi < g.nx && Hg[gi + (long long)g.nx * jj] > 0.0;
+      const bool hice = hi_ok && Hg[hi_col + (long long)g.nx * jj] > 0.0;
+      const unsigned long long M = __builtin_amdgcn_ballot_w64(ice);
+      const unsigned long long Hb = __builtin_amdgcn_ballot_w64(hice);
+      const unsigned long long Lh = Hb & ((1ull << dist) - 1ull);           // bit k: column gi0 - dist + k
+      const unsigned long long Rh = (Hb >> dist) & ((1ull << dist) - 1ull);  // bit k: column gi0 + 64 + k
+      E = M;
+      for (int a = 1; a <= dist; ++a) {
+        // neighbour a to the east of lane t is bit t + a of M, or bit t + a - 64 of Rh; to the west bit t - a, or Lh's top
+        E &= (M >> a) | (Rh << (64 - a));
+        E &= (M << a) | (Lh >> (dist - a));
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) {
+      const int d = rr - m;
+      if (d >= -dist && d <= dist) inm[m] &= E;
+    }
+  }
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
-    const int gj = t4.z * TY + ty + NW * m;
+    const int gj = gjw + m;
     if (gi < g.nx && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
       const double v = sqrt(vx[id] * vx[id] + vy[id] * vy[id]);
-      // is_in_glacier: ice on the cell and on every cell within Chebyshev distance `dist` (cells outside the grid count as
-      // ice-free) -- the definition the thickness loss uses for its reference mask (odinn_set_reference)
-      bool in = v > 0.0;
-      for (int b = -dist; b <= dist && in; ++b)
-        for (int a = -dist; a <= dist && in; ++a) {
-          const int ii = gi + a, jj = gj + b;
-          in = ii >= 0 && ii < g.nx && jj >= 0 && jj < g.ny && H[g.off + ii + (long long)g.nx * jj] > 0.0;
-        }
       Vabs[id] = v;
-      mask[id] = in ? 1 : 0;
+      mask[id] = (((inm[m] >> tx) & 1ull) && v > 0.0) ? 1 : 0;
     }
   }
 }

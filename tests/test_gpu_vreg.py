@@ -66,6 +66,39 @@ def test_vreg_loss_and_gradients_match_oracle(gpu, case):
     b.close()
 
 
+@pytest.mark.parametrize("distance", [0, 1, 3, 5])
+def test_vreg_mask_across_wavefront_and_tile_boundaries(gpu, distance):
+    """is_in_glacier(H, distance) inside k_vreg_prep: row ballots eroded by scalar shifts, the `distance` columns either side of
+    a wavefront's 64 loaded by its first lanes, every eroded row shared by the rows of the wavefront within `distance` of
+    it.  A 150 x 70 glacier (three column tiles, five row tiles) whose margin crosses the tile boundaries, with holes and
+    ice up to the grid edge: loss and dL/dtheta of the term at two stops against the oracle."""
+    ph = O.Phys()
+    nx, ny = 150, 70
+    H0, B = O.synthetic_icecap(nx, ny, 50.0)
+    H0 = H0 * 0.3
+    rng = np.random.default_rng(12)
+    holes = rng.random((nx, ny)) < 0.004          # isolated ice-free cells inside the ice
+    H0 = np.asfortranarray(np.where(holes, 0.0, H0))
+    H0[:, :2] = np.maximum(H0[:, :2], 20.0)       # ice on the first rows: the window leaves the grid
+    H0[60:70, :] = np.maximum(H0[60:70, :], 15.0)  # a band across the wavefront boundary at column 64
+    ts = [2010.0, 2010.0 + 1.0 / 48.0]
+    law = O.Law(kind=O.LAW_CONST_A, A=4e-17)
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    cfg = O.SimConfig(tstops=ts, reltol=1e-8, vreg_times=ts, vreg_distance=distance, vreg_weight=20.0)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], A=[4e-17])
+    b.set_fields(0, H0, B)
+    b.set_velocity_reference(0, ts, *_dummy_v((nx, ny), 2))
+    b.set_velocity_regularization(20.0, distance)
+    b.solve(ts, reltol=1e-8)
+    snaps, _, _ = O.forward(gl, law, cfg)
+    lo, _, gth = O.vreg_loss_terms(snaps, ts, cfg, gl, law)
+    assert lo > 0.0 and abs(b.loss()[0] - lo) <= 1e-9 * abs(lo), distance
+    Lg, gg = b.loss_grad(ts, reltol=1e-8)
+    Lo, go, _ = O.loss_and_grad(gl, law, cfg, [], [])
+    assert abs(Lg - Lo) <= 1e-9 * abs(Lo) and rel_l2(np.ravel(gg), np.ravel(go)) < 1e-6, distance
+    b.close()
+
+
 def test_vreg_ragged_batch_gridded_law(gpu):
     """Three ragged glaciers, hoisted gridded A = NN(T) (theta-part through the dual-grid accumulator), one glacier
     without velocity dates; batch result = sum of the per-glacier oracle results, both adjoints."""
