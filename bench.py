@@ -418,6 +418,16 @@ def main():
                 "ms_per_grad_eval_batch_discrete": tg * 1e3,
                 "ms_per_grad_eval_batch_continuous": tgc * 1e3,
             }
+            # (i') the same with the headline's law: A = NN_theta(T) on the dual grid (2x16 MLP, 321 parameters; dtheta through
+            #      the dual-grid accumulator and the wave-reduced backprop kernel)
+            b.set_law(odinn.LAW_NN_A_GRIDDED, mlpA, thetaA)
+            tgg = timed(lambda: b.loss_grad(ts, theta=thetaA, reltol=1e-8))
+            tggc = timed(lambda: b.loss_grad_continuous(ts, theta=thetaA, reltol=1e-8))
+            grad["bench_workload_gridded_law"] = {
+                "discrete_adjoint": G * world / tgg,
+                "continuous_adjoint": G * world / tggc,
+                "sample": f"as bench_workload, but A = NN_theta(T) gridded with the 2x16 MLP ({len(thetaA)} params) of the headline",
+            }
             b.set_law(odinn.LAW_CONST_A)
             # (ii) BASELINE configs[3]: 4 alpine glaciers (synthetic stand-ins of the README set), and the same set
             #      replicated to fill the GPU (the reference maps one glacier per worker process)

@@ -2491,7 +2491,11 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     // A-type laws without a dual-grid accumulator: the theta-VJP of a quadrature node is formed by stage 1 of the step that
     // follows the node (same lambda, same H_itp) instead of a launch of its own (ODINN_ADJ_THETA_FUSED=0: separate launches)
     const char* et = std::getenv("ODINN_ADJ_THETA_FUSED");
-    if (acc_inplace && !b->wants_Gacc() && !(et && et[0] == '0')) {
+    // (with a dual-grid accumulator -- gridded A -- the same stage also adds the node weights into d_Gacc: needs the
+    //  interleaved snapshot pairs, whose kernel instantiations carry that variant)
+    const bool gacc_fused = b->wants_Gacc() && FA.segs && b->gd[0].use_Afield;
+    if (acc_inplace && (!b->wants_Gacc() || gacc_fused) && !(et && et[0] == '0')) {
+      if (gacc_fused) FA.Gacc = b->d_Gacc;
       if ((size_t)ntilesR > b->partTh_cap) {
         dfree(b->d_partTh);
         CHK(dalloc(&b->d_partTh, (size_t)ntilesR));

@@ -47,12 +47,13 @@ typedef double (*AdjEdgesL)[TNW][2][FRX];
 #endif
 typedef double (*AdjErr)[FRX];
 
-template <int S, bool AF, bool SG, int NR>
+template <int S, bool AF, bool SG, int NR, bool GA = false>
 __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __restrict__ Afield, const double* __restrict__ Ha,
                                                  const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
                                                  int gic, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
                                                  AdjEdgesL sLm, double (&u)[NR], double (&tmp)[NR], double (&E)[NR],
-                                                 const double* __restrict__ Bp, AdjErr sEr, double* __restrict__ th_red) {
+                                                 const double* __restrict__ Bp, AdjErr sEr, double* __restrict__ th_red,
+                                                 [[maybe_unused]] double* __restrict__ Gp = nullptr) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;
   const int r0 = NR * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
@@ -180,6 +181,8 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     if (S == 1 && th_red) {  // the node north-east of an OUTPUT cell belongs to this thread (every dual node to exactly one)
       const bool own = lane >= FH && lane < FH + FOX && r0 + m >= FH && r0 + m <= (NR * TNW) - 1 - FH && gi <= g.nx - 2 && gj <= g.ny - 2;
       thacc += own ? tw : 0.0;
+      // dual-grid accumulator (gridded A): the node's own entry, owned by exactly this thread -- k_vjp_theta_strip<GACC>'s +=
+      if constexpr (GA) { if (own) { const unsigned q = (unsigned)(gif + (g.nx - 1) * gj); Gp[q] = fma(a.qw, tw, Gp[q]); } }
     }
     // east face of this row, second term
     const double te = ((D_s + D_c) * g.hinv_dx2) * qe_c;
@@ -240,7 +243,9 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
 }
 
 // SKIP: exact ice-free shortcut (see below)
-template <bool AF, bool SKIP, bool SG = false, int NR = TRPT>
+// GA (gridded A with a dual-grid accumulator): stage 1 of the step that follows a quadrature node also adds the node
+// weights into A.Gacc (needs A.th_part)
+template <bool AF, bool SKIP, bool SG = false, int NR = TRPT, bool GA = false>
 __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double sLm[2][TNW][2][FRX];
@@ -363,7 +368,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
   // theta-VJP of the quadrature node the previous step reached (a.qw: its Gauss-Legendre weight, 0 otherwise; the controller
   // resets it at every call, so a repeated attempt after a rejection does not count the node twice)
   double* const thr = (A.th_part && a.qw != 0.0) ? th_red : nullptr;
-  adj_strip_stage<1, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr);
+  adj_strip_stage<1, AF, SG, NR, GA>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr,
+                                     GA ? A.Gacc + g.offd : nullptr);
   if (thr && threadIdx.x == 0) {  // the tile's running sum, reduced per glacier once after the reverse solve
     double sum = 0.0;
 #pragma unroll

@@ -1769,8 +1769,9 @@ struct AdjFusedArgs {
   double* partF;        // error partials, FOX x FOYT tile table
   const int4* tilesF;
   double abstol, reltol;
-  double* th_part;      // non-null (A-type laws without a dual-grid accumulator): per-tile running sums of the theta-VJP at
-                        //   the quadrature nodes, formed in stage 1 of the step that follows a node (same tile table)
+  double* th_part;      // non-null (A-type laws): per-tile running sums of the theta-VJP at the quadrature nodes, formed in
+                        //   stage 1 of the step that follows a node (same tile table)
+  double* Gacc;         // non-null (gridded A; needs th_part and segs): the dual-grid accumulator gets the node weights there too
 };
 
 
