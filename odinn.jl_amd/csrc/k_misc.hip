@@ -97,8 +97,9 @@ void launch_set_dt(int G, hipStream_t st, Pools P, double dt) {
 void launch_vref_itp(int nblk, hipStream_t st, Pools P, VItpArgs A) {
   hipLaunchKernelGGL(k_vref_itp, dim3(nblk), dim3(NT), 0, st, P, A);
 }
-void launch_vq_finish(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq, double* out) {
-  hipLaunchKernelGGL(k_vq_finish, dim3(G), dim3(64), 0, st, P, adj, slotA, G, scale_loss, wq, out);
+void launch_vq_finish(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq, double* out,
+                      double* coef) {
+  hipLaunchKernelGGL(k_vq_finish, dim3(G), dim3(64), 0, st, P, adj, slotA, G, scale_loss, wq, out, coef);
 }
 void launch_vref_scale(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq,
                        double* scale_out, double* w_out) {

@@ -18,9 +18,13 @@ void launch_surfV_vjp(int lm, int mode, int nblk, hipStream_t st, Pools P, LawDe
   else { if (mode == 0) ODINN_VJP_CASE(0, LM_NN); else if (mode == 1) ODINN_VJP_CASE(1, LM_NN); else ODINN_VJP_CASE(2, LM_NN); }
 #undef ODINN_VJP_CASE
 }
-void launch_surfV_theta_node(int lm, int nblk, hipStream_t st, Pools P, VItpArgs I, const double* snaps, int component_abs, double log_eps) {
-  if (lm == 0) hipLaunchKernelGGL((k_surfV_theta_node<0>), dim3(nblk), dim3(NT), 0, st, P, I, snaps, component_abs, log_eps);
-  else hipLaunchKernelGGL((k_surfV_theta_node<1>), dim3(nblk), dim3(NT), 0, st, P, I, snaps, component_abs, log_eps);
+void launch_surfV_theta_node(int lm, int nblk, hipStream_t st, Pools P, VItpArgs I, const double* snaps, int component_abs, double log_eps,
+                             double* tnode) {
+  if (lm == 0) hipLaunchKernelGGL((k_surfV_theta_node<0>), dim3(nblk), dim3(NT), 0, st, P, I, snaps, component_abs, log_eps, tnode);
+  else hipLaunchKernelGGL((k_surfV_theta_node<1>), dim3(nblk), dim3(NT), 0, st, P, I, snaps, component_abs, log_eps, tnode);
+}
+void launch_gacc_axpy(int nblk, hipStream_t st, Pools P, const double* coef, const double* tnode, double* Gacc) {
+  hipLaunchKernelGGL(k_gacc_axpy, dim3(nblk), dim3(NT), 0, st, P, coef, tnode, Gacc);
 }
 void launch_avgv_axpy(int nblk, hipStream_t st, Pools P, const double* Vx, const double* Vy, double* ax, double* ay, const double* w) {
   hipLaunchKernelGGL(k_avgv_axpy, dim3(nblk), dim3(NT), 0, st, P, Vx, Vy, ax, ay, w);

@@ -104,8 +104,11 @@ void launch_initdt_ctrl(int G, hipStream_t st, Pools P, int phase, double tspan,
 void launch_begin(int G, hipStream_t st, Pools P, const double* tstops, double dtmax, double dt_given);
 void launch_set_dt(int G, hipStream_t st, Pools P, double dt);
 void launch_vref_itp(int nblk, hipStream_t st, Pools P, VItpArgs A);
-void launch_vq_finish(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq, double* out);
-void launch_surfV_theta_node(int lm, int nblk, hipStream_t st, Pools P, VItpArgs I, const double* snaps, int component_abs, double log_eps);
+void launch_vq_finish(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq, double* out,
+                      double* coef);
+void launch_surfV_theta_node(int lm, int nblk, hipStream_t st, Pools P, VItpArgs I, const double* snaps, int component_abs, double log_eps,
+                             double* tnode);
+void launch_gacc_axpy(int nblk, hipStream_t st, Pools P, const double* coef, const double* tnode, double* Gacc);
 void launch_vref_scale(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq,
                        double* scale_out, double* w_out);
 void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot);

@@ -2362,10 +2362,10 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   AP.h_log_eps = b->h_log_eps;
   // the theta-VJP of the A-type laws interpolates H at the quadrature node in its tile loader; the per-node MLP laws and
   // the velocity terms read it from d_tmpA, which the post-step then materialises
-  // closed-form laws without a dual-grid accumulator: the theta-part of a velocity loss takes one pass per quadrature node
+  // closed-form laws: the theta-part of a velocity loss takes one pass per quadrature node
   // (k_surfV_theta_node, which interpolates H itself) instead of the interpolate / scale / pull-back / reduce sequence
   // (ODINN_VQ_ONEPASS=0 selects that sequence); d_tmpA then is only needed at the snapshot stops
-  bool vq_onepass = useV && lm <= 1 && !b->wants_Gacc() && !b->vel_nn();
+  bool vq_onepass = useV && lm <= 1 && !b->vel_nn();
   if (const char* e = std::getenv("ODINN_VQ_ONEPASS")) vq_onepass = vq_onepass && e[0] != '0';
   const bool theta_itp = (!useV || vq_onepass) && b->law_kind < ODINN_LAW_NN_Y;
   AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = (theta_itp && !useV) ? nullptr : b->d_tmpA;
@@ -2542,8 +2542,12 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
         else VS.out = a1;
         launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VS, 0);                       // snapshot stops
         if (vq_onepass) {                                                               // quadrature nodes
-          launch_surfV_theta_node(lm, b->ntiles, b->stream, Pl, VI, b->d_snaps, b->v_abs, b->v_abs ? b->v_log_eps : 0.0);
-          launch_vq_finish(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_Gsum);
+          // (with a dual-grid accumulator the unscaled node weights go through d_tmpB, idle on this path, and are added
+          //  into d_Gacc once the glacier's scale is known)
+          double* tnode = b->wants_Gacc() ? b->d_tmpB : nullptr;
+          launch_surfV_theta_node(lm, b->ntiles, b->stream, Pl, VI, b->d_snaps, b->v_abs, b->v_abs ? b->v_log_eps : 0.0, tnode);
+          launch_vq_finish(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_Gsum, tnode ? b->d_wvq : nullptr);
+          if (tnode) launch_gacc_axpy(b->ntiles, b->stream, Pl, b->d_wvq, tnode, b->d_Gacc);
         } else {
           launch_vref_itp(b->ntiles, b->stream, Pl, VI);
           launch_vref_scale(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_vscq, b->d_wvq);

@@ -2728,13 +2728,17 @@ __global__ __launch_bounds__(64) void k_vref_scale(Pools P, const AdjState* adj,
 
 // the per-glacier end of k_surfV_theta_node: out[g] += (quadrature weight x wq) x scale x (sum of the tiles' slot 3), with
 // scale = 1/sqrt(mean_{mask} |Vref|^2) (or 1) from slots 0 and 1; fixed summation order
+// coef (non-null): the glacier's coefficient for k_gacc_axpy, -(weight x scale), 0 when it is not at a node
 __global__ __launch_bounds__(64) void k_vq_finish(Pools P, const AdjState* adj, const int* slotA, int G, int scale_loss,
-                                                  double wq, double* out) {
+                                                  double wq, double* out, double* coef) {
   const int gidx = blockIdx.x;
   const GDev g = P.gd[gidx];
   const GState* gs = P.gs + gidx;
   const bool at_node = gs->at_stop && adj[gidx].qw != 0.0 && slotA[(long long)(gs->istop - 1) * G + gidx] >= 0;
-  if (!at_node) return;
+  if (!at_node) {
+    if (coef && threadIdx.x == 0) coef[gidx] = 0.0;
+    return;
+  }
   double ss = 0.0, cnt = 0.0, gt = 0.0;
   for (int k = threadIdx.x; k < g.ntiles; k += 64) {
     const double* pp = P.part + 4 * (long long)(g.tile0 + k);
@@ -2748,6 +2752,7 @@ __global__ __launch_bounds__(64) void k_vq_finish(Pools P, const AdjState* adj, 
   if (threadIdx.x == 0) {
     const double sc = (scale_loss && cnt > 0.0 && ss > 0.0) ? 1.0 / sqrt(ss / cnt) : 1.0;
     out[gidx] = fma((adj[gidx].qw * wq) * sc, gt, out[gidx]);
+    if (coef) coef[gidx] = -((adj[gidx].qw * wq) * sc);
   }
 }
 

@@ -268,9 +268,11 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
 // k_vq_finish applies scale and quadrature weight per glacier.  Replaces k_vref_itp + k_vref_scale + k_surfV_vjp<1> +
 // k_sum_part on that path: no interpolated fields (reference velocities, H) written and re-read, no H-cotangent gathered
 // only to be discarded.
+// tnode (non-null: a dual-grid accumulator is wanted): the unscaled weight of every dual node, which k_gacc_axpy adds into
+// the accumulator once k_vq_finish knows the glacier's coefficient.
 template <int LM>
 __global__ __launch_bounds__(NT) void k_surfV_theta_node(Pools P, VItpArgs I, const double* __restrict__ snaps, int component_abs,
-                                                         double log_eps) {
+                                                         double log_eps, double* __restrict__ tnode) {
   __shared__ double2 sHS[TY + 2][LDW];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x];
@@ -305,10 +307,12 @@ __global__ __launch_bounds__(NT) void k_surfV_theta_node(Pools P, VItpArgs I, co
       const long long id = g.off + gi + (long long)g.nx * gj;
       auto lerp = [&](const double* f) { const double a = f[oa + id]; return w == 0.0 ? a : fma(w, f[ob + id] - a, a); };
       const double va = lerp(I.Vabs), vxr = lerp(I.Vxr), vyr = lerp(I.Vyr);  // k_vref_itp's formula
+      const bool isnode = gi <= g.nx - 2 && gj <= g.ny - 2;
+      double tn = 0.0;
       if (va > 0.0) {  // mask = V_ref > 0 (Losses.jl:361)
         ss = fma(vxr, vxr, fma(vyr, vyr, ss));
         cnt += 1.0;
-        if (gi <= g.nx - 2 && gj <= g.ny - 2) {  // the node whose lower-left cell is (gi, gj): inn1 pairing
+        if (isnode) {  // the node whose lower-left cell is (gi, gj): inn1 pairing
           double gx, gy, Hb;
           node_geom<LDW>(g, &sHS[r][tx + 1], gx, gy, Hb);
           double An = g.A;
@@ -328,9 +332,11 @@ __global__ __launch_bounds__(NT) void k_surfV_theta_node(Pools P, VItpArgs I, co
             dvx = dv * ex / ev;  // as the reference writes it (Losses.jl:367-368)
             dvy = dv * ey / ev;
           }
-          gsum = fma(sp, gx * dvx + gy * dvy, gsum);
+          tn = sp * (gx * dvx + gy * dvy);
+          gsum += tn;
         }
       }
+      if (tnode && isnode) tnode[g.offd + gi + (long long)(g.nx - 1) * gj] = tn;
     }
   }
   const double t0 = block_sum(ss, red);
@@ -338,6 +344,27 @@ __global__ __launch_bounds__(NT) void k_surfV_theta_node(Pools P, VItpArgs I, co
   const double t3 = block_sum(gsum, red);
   if (threadIdx.x == 0) { pp[0] = t0; pp[1] = t1; pp[3] = -t3; }
 }
+
+// Gacc[node] += coef[g] * tnode[node] on the dual nodes of the glaciers with coef[g] != 0 (k_vq_finish: the glacier just
+// reached a quadrature node)
+#ifdef ODINN_VEL_KERNELS
+__global__ __launch_bounds__(NT) void k_gacc_axpy(Pools P, const double* __restrict__ coef, const double* __restrict__ tnode,
+                                                  double* __restrict__ Gacc) {
+  const int4 t4 = P.tiles[blockIdx.x];
+  const double c = coef[t4.x];
+  if (c == 0.0) return;
+  const GDev g = P.gd[t4.x];
+  const int gi = t4.y * TX + (threadIdx.x & 63), ty = wave_id();
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = t4.z * TY + ty + NW * m;
+    if (gi <= g.nx - 2 && gj <= g.ny - 2) {
+      const long long q = g.offd + gi + (long long)(g.nx - 1) * gj;
+      Gacc[q] = fma(c, tnode[q], Gacc[q]);
+    }
+  }
+}
+#endif
 
 // ---- LossAvgV (TimeAggregatedLosses.jl:115-258) ---------------------------------------------------------------------
 #ifdef ODINN_VEL_KERNELS  // non-template kernels: compiled by k_vel.hip only

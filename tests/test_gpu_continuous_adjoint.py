@@ -139,6 +139,43 @@ def test_continuous_adjoint_with_velocity_losses(gpu, monkeypatch, kind, compone
     b.close()
 
 
+@pytest.mark.parametrize("onepass", ["1", "0"])
+def test_continuous_adjoint_velocity_loss_with_the_gridded_law(gpu, monkeypatch, onepass):
+    """LossHV with A = NN(T) on the dual grid: the theta-part of the velocity term at the quadrature nodes goes through the
+    dual-grid accumulator -- one pass (unscaled node weights, scaled into d_Gacc by k_gacc_axpy once k_vq_finish knows the
+    glacier's normalisation) or the interpolate / scale / pull-back sequence (ODINN_VQ_ONEPASS=0).  Against the oracle."""
+    from test_gpu_velocity import _velocity_case
+
+    monkeypatch.setenv("ODINN_VQ_ONEPASS", onepass)
+    ph = O.Phys()
+    nx, ny = 64, 48
+    H0, B, ts, mlp, th_true, th0, gl, cfg, ref, tV, Vref = _velocity_case(nx, ny, ph)
+    S = B + H0
+    T = np.asfortranarray(-3.0 - 6.5e-3 * (O.avg(S) - S.mean()))
+    law_t = O.Law(kind=O.LAW_NN_A_GRIDDED, mlp=mlp, theta=th_true, T=T)
+    Vref = []
+    for j in range(len(ts)):
+        Vx, Vy, V = O.V_from_H(ref[j], B, 50.0, 50.0, ph, law_t)
+        Vref.append((V, Vx, Vy))
+    vspec = O.LossVSpec(component="xy", scale_loss=True)
+    law0 = O.Law(kind=O.LAW_NN_A_GRIDDED, mlp=mlp, theta=th0, T=T)
+    Lo, go, lam0, st = O.loss_and_grad_continuous(gl, law0, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=12),
+                                                  V_ref=Vref, tV_ref=list(ts), vspec=vspec, loss_kind="HV", scaling=2.5)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0])
+    b.set_fields(0, H0, B)
+    b.set_T_field(0, T)
+    b.set_law(gpu.LAW_NN_A_GRIDDED, gpu.MLPSpec(mlp.widths, mlp.acts, None, O.POST_AFFINE, ph.minA, ph.maxA), th0)
+    b.set_reference(0, ts, ref, 3)
+    b.set_velocity_reference(0, ts, [v[0] for v in Vref], [v[1] for v in Vref], [v[2] for v in Vref])
+    b.set_loss(gpu._lib.LOSS_HV, "xy", True, 2.5)
+    Lg, gg = b.loss_grad_continuous(ts, theta=th0, reltol=1e-10, n_quadrature=12)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo), (Lg, Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-9 and relerr < 1e-5, (ratio, angle, relerr)
+    assert rel_l2(b.lambda0(0), lam0) < 1e-5
+    b.close()
+
+
 def test_continuous_adjoint_needs_velocity_data_spanning_tspan(gpu):
     from test_gpu_velocity import _velocity_case
 
