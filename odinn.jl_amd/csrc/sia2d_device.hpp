@@ -2546,7 +2546,7 @@ __global__ __launch_bounds__(NT) void k_vreg_prep(Pools P, const double* __restr
   // RPT consecutive rows; the ice flags of a row are a ballot (plus one load by the first 2 dist lanes for the dist
   // columns either side of the wavefront's 64), its horizontal erosion is 2 dist shifts and ANDs of that scalar, and
   // every eroded row is formed once and ANDed into the rows of the wavefront within `dist` of it:
-  // 2 (RPT + 2 dist) loads per wavefront instead of RPT (2 dist + 1)^2 (dist = 3: 261 -> ~70 us at 8 x 1024^2).
+  // 2 (RPT + 2 dist) loads per wavefront instead of RPT (2 dist + 1)^2 (dist = 3: 261 -> 92 us at 8 x 1024^2).
   const int gjw = t4.z * TY + ty * RPT;  // first row of this wavefront
   unsigned long long inm[RPT];
 #pragma unroll
