@@ -666,7 +666,8 @@ static bool sc_mode(const odinn_batch* b, int scheme) {
 // solve.  ODINN_SNAP_ON_LOAD=0 restores the post-step launch.
 static bool snap_on_load_mode(const odinn_batch* b, int scheme, bool sc) {
   const char* e = std::getenv("ODINN_SNAP_ON_LOAD");  // read per call: tests toggle it
-  return !(e && e[0] == '0') && scheme == 2 && !sc && b->fused_kind() >= 2 && !b->any_mb;
+  // (with a mass balance: the constant-A strip kernels apply it on load -- GState::pad bit 2, kept by the controller)
+  return !(e && e[0] == '0') && scheme == 2 && !sc && b->fused_kind() >= 2 && (!b->any_mb || !b->gd[0].use_Afield);
 }
 static int sc_buffers(odinn_batch* b) {
   if (!b->d_gs2) CHK(dalloc(&b->d_gs2, (size_t)b->G));
@@ -877,6 +878,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   const bool snapload = !euler && snap_on_load_mode(b, scheme, sc);
   ScArgs SL{};
   SL.snaps = b->d_snaps; SL.ntot = b->ntot; SL.snap_on_load = 1;
+  if (b->any_mb) { SL.premb = b->d_premb; SL.mb0 = b->d_mb0; SL.Sref = b->any_sref ? b->d_Sref : nullptr; }
   long long steps = 0;
   int p = 0;
   int chunk = std::max(2, std::min(256, (n_stops - 1 + 1) & ~1));

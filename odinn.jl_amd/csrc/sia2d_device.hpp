@@ -1256,6 +1256,13 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
     st.accepted = 0;
   }
   if (C.qw_out) C.qw_out[gidx] = ad.qw;
+  if (!C.adj) {
+    // forward solve, mass balance applied ON LOAD by the strip step kernel (ScArgs::snap_on_load with a mass balance): bit 2
+    // of `pad` says the buffer `cur` still lacks the mass balance of the stop it sits on -- set when an accepted step lands
+    // on such a stop, cleared by the next accepted step (which replaces the buffer).  Ignored by the post-step schedule.
+    if (accept) st.pad &= ~4;
+    if (accept && st.at_stop && st.mb_now && g.has_mb) st.pad |= 4;
+  }
   if (st.istop >= C.n_stops) {
     st.done = 1;
     atomicSub(C.n_active, 1);

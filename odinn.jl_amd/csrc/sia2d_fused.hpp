@@ -728,6 +728,12 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     cur = gs->cur;
     finished = gs->done != 0;
     if (snap) snap_slot = gs->istop - 1;
+    // ... and with a mass balance (constant-A kernels: u_n in LDS slots) the controller flags the buffer that still lacks the
+    // mass balance of its stop (GState::pad bit 2); it is applied on load below, exactly as in the self-controlled loop
+    if (UPL && A.snap_on_load && A.mb0) {
+      mb_pend = (gs->pad & 4) != 0;
+      mb_slot = gs->mb_slot;
+    }
   }
   // everything below is addressed relative to the glacier's first cell (block-uniform bases, 32-bit cell indices)
   const double* __restrict__ src = (cur ? U1 : U0) + g.off;

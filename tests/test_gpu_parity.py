@@ -639,8 +639,12 @@ def test_self_controlled_step_loop_matches_the_three_launch_loop(gpu, monkeypatc
     shapes = [(130, 97), (96, 80), (201, 103), (54, 46)]
     ts = [2010.0 + 0.05 * j for j in range(9)]
     out = {}
-    for sc in ("0", "1"):
-        monkeypatch.setenv("ODINN_STEP_SC", sc)
+    # "0": the three-launch loop (k_poststep applies the mass balance in place); "2": the two-launch loop of large batches
+    # (step kernel + controller; snapshot and mass balance on load, GState::pad bit 2 kept by the controller); "1": the
+    # self-controlled loop
+    for sc in ("0", "2", "1"):
+        monkeypatch.setenv("ODINN_STEP_SC", "1" if sc == "1" else "0")
+        monkeypatch.setenv("ODINN_SNAP_ON_LOAD", "0" if sc == "0" else "1")
         b = gpu.GlacierBatch(shapes, [50.0] * 4, A=[8e-17, 4e-17, 6e-17, 2e-17])
         for k, (nx, ny) in enumerate(shapes):
             H0, B = O.synthetic_valley(nx, ny, 50.0)
@@ -654,15 +658,17 @@ def test_self_controlled_step_loop_matches_the_three_launch_loop(gpu, monkeypatc
         st2 = b.solve(ts[:3], mb_times=ts[1:3], fixed_dt=0.0025)
         out[sc] += ([b.snapshot(k, 2) for k in range(4)], [(s.naccept, s.nreject) for s in st2])
         b.close()
-    a, f = out["0"], out["1"]
-    assert [x[:2] for x in a[1]] == [x[:2] for x in f[1]] and a[3] == f[3], (a[1], f[1])
+    a = out["0"]
     assert sum(r for _, r, _, _ in a[1]) > 0
-    # With today's compiler the two kernel instantiations generate the same arithmetic and everything below is
-    # bit-identical (np.array_equal holds); the assertions allow what a different FMA contraction could change.
-    for k in range(4):
-        for j in range(len(ts) + 1):  # every snapshot and the final state (which carries the last mass balance)
-            assert rel_l2(f[0][k][j], a[0][k][j]) < 1e-8 or not a[0][k][j].any(), (k, j)
-        assert np.isfinite(a[2][k]).all() and rel_l2(f[2][k], a[2][k]) < 1e-13, k
+    for key in ("2", "1"):
+        f = out[key]
+        assert [x[:2] for x in a[1]] == [x[:2] for x in f[1]] and a[3] == f[3], (key, a[1], f[1])
+        # With today's compiler the kernel instantiations generate the same arithmetic and everything below is
+        # bit-identical (np.array_equal holds); the assertions allow what a different FMA contraction could change.
+        for k in range(4):
+            for j in range(len(ts) + 1):  # every snapshot and the final state (which carries the last mass balance)
+                assert rel_l2(f[0][k][j], a[0][k][j]) < 1e-8 or not a[0][k][j].any(), (key, k, j)
+            assert np.isfinite(a[2][k]).all() and rel_l2(f[2][k], a[2][k]) < 1e-13, (key, k)
 
 
 def test_largest_single_gpu_configuration_64x1024(gpu, monkeypatch):
