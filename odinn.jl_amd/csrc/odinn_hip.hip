@@ -655,10 +655,14 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
 // work (~2 us), which pays while launch latency is a large part of a step (1 x 512^2: 20.0 -> 15.6 us per step,
 // 64 alpine glaciers: 40 -> 35, 2 x 1024^2: 38.8 -> 37.7) and costs slightly more than the two launches it saves on
 // the largest batches (8 x 1024^2: +2 %, 512 alpine glaciers: +3 %).  ODINN_STEP_SC=0|1 overrides.
+// Against the two-launch loop with the faster controller (end of round 2, us per step, two-launch vs self-controlled):
+// 4 alpine 37-43 vs 34, 64 alpine (544 tiles) 50-53 vs 48, 1 x 512^2 19 vs 16, 4 x 512^2 (400) 25 vs 22, 1 x 1024^2 (361)
+// 27 vs 26, 128 alpine (1088) 71-75 vs 72, 2 x 1024^2 (722) 37.5 vs 39.6, 4 x 1024^2 (1444) 50 vs 56: self-controlled
+// up to 640 strip tiles.
 static bool sc_mode(const odinn_batch* b, int scheme) {
   if (scheme != 2 || b->fused_kind() < 2 || (b->any_mb && b->gd[0].use_Afield)) return false;  // MB on load: constant-A path
   if (const char* e = std::getenv("ODINN_STEP_SC")) return e[0] == '1';
-  return b->fused_ntiles() <= 1600;
+  return b->fused_ntiles() <= 640;  // re-measured with the 5.9 us controller and the two-launch loop (tools/sc_probe3.py): see above
 }
 // Large batches (no self-controlled loop) without a mass balance: the strip step kernel stores the snapshot of a stop
 // from the state it loads (ScArgs::snap_on_load), so a step is TWO dependent launches (step kernel, controller) instead of
