@@ -23,6 +23,10 @@ void launch_surfV_theta_node(int lm, int nblk, hipStream_t st, Pools P, VItpArgs
   if (lm == 0) hipLaunchKernelGGL((k_surfV_theta_node<0>), dim3(nblk), dim3(NT), 0, st, P, I, snaps, component_abs, log_eps, tnode);
   else hipLaunchKernelGGL((k_surfV_theta_node<1>), dim3(nblk), dim3(NT), 0, st, P, I, snaps, component_abs, log_eps, tnode);
 }
+void launch_surfV_theta_only(int lm, int nblk, hipStream_t st, Pools P, const VArgs& A) {
+  if (lm == 0) hipLaunchKernelGGL((k_surfV_theta_only<0>), dim3(nblk), dim3(NT), 0, st, P, A);
+  else hipLaunchKernelGGL((k_surfV_theta_only<1>), dim3(nblk), dim3(NT), 0, st, P, A);
+}
 void launch_gacc_axpy(int nblk, hipStream_t st, Pools P, const double* coef, const double* tnode, double* Gacc) {
   hipLaunchKernelGGL(k_gacc_axpy, dim3(nblk), dim3(NT), 0, st, P, coef, tnode, Gacc);
 }

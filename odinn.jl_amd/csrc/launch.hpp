@@ -108,6 +108,7 @@ void launch_vq_finish(int G, hipStream_t st, Pools P, const AdjState* adj, const
                       double* coef);
 void launch_surfV_theta_node(int lm, int nblk, hipStream_t st, Pools P, VItpArgs I, const double* snaps, int component_abs, double log_eps,
                              double* tnode);
+void launch_surfV_theta_only(int lm, int nblk, hipStream_t st, Pools P, const VArgs& A);
 void launch_gacc_axpy(int nblk, hipStream_t st, Pools P, const double* coef, const double* tnode, double* Gacc);
 void launch_vref_scale(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq,
                        double* scale_out, double* w_out);

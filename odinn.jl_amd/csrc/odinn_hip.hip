@@ -1122,7 +1122,9 @@ static int vreg_at(odinn_batch* b, const double* H, const double* w, bool add_lo
     A.H = H; A.dVx = vx; A.dVy = vy; A.out = outH ? outH : r;  // (r is dead by now: a sink for the unused H-part)
     A.wv = w; A.ntot = b->ntot;
     A.Gacc = (theta && b->wants_Gacc()) ? b->d_Gacc : nullptr;
-    launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, b->lawdev(), A, 0);
+    // nobody wants dL/dH (the quadrature nodes of the continuous adjoint), closed-form law: the theta-part alone
+    if (!outH && theta && b->lm() <= 1 && !b->vel_nn()) launch_surfV_theta_only(b->lm(), b->ntiles, b->stream, P, A);
+    else launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, b->lawdev(), A, 0);
     if (theta) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
   }
   HIPCHK(hipGetLastError());

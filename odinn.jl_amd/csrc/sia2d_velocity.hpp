@@ -345,6 +345,48 @@ __global__ __launch_bounds__(NT) void k_surfV_theta_node(Pools P, VItpArgs I, co
   if (threadIdx.x == 0) { pp[0] = t0; pp[1] = t1; pp[3] = -t3; }
 }
 
+// theta-part ONLY of the pull-back of explicit cotangents (k_surfV_vjp<2> without its H-part): closed-form laws, for callers
+// that discard dL/dH (VelocityRegularization at the quadrature nodes of the continuous adjoint).  Slot 3 of the tile
+// partials = -wv sum_nodes dVelocity^/dA x (grad S . dV); the dual-grid accumulator gets the node terms.
+template <int LM>
+__global__ __launch_bounds__(NT) void k_surfV_theta_only(Pools P, VArgs A) {
+  __shared__ double2 sHS[TY + 2][LDW];
+  __shared__ double red[NW];
+  const int4 t4 = P.tiles[blockIdx.x];
+  const double wv = A.wv[t4.x];
+  if (wv == 0.0) {
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 3] = 0.0;
+    return;
+  }
+  const GDev g = P.gd[t4.x];
+  const int i0 = t4.y * TX, j0 = t4.z * TY;
+  double own[RPT];
+  load_tile_HS2(A.H, P.B, g, i0, j0, sHS, own);
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = wave_id();
+  const int gi = i0 + tx;
+  double gsum = 0.0;
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int r = 1 + ty + NW * m, gj = j0 - 1 + r;
+    if (gi <= g.nx - 2 && gj <= g.ny - 2) {  // the node whose lower-left cell is (gi, gj): inn1 pairing
+      double gx, gy, Hb;
+      node_geom<LDW>(g, &sHS[r][tx + 1], gx, gy, Hb);
+      double An = g.A;
+      const long long qd = g.offd + gi + (long long)(g.nx - 1) * gj;
+      if (g.use_Afield) An = P.Afield[qd];
+      double al, be, sp;
+      (void)node_Vup<LM>(g, Hb, gx * gx + gy * gy, An, al, be, sp);
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double t = sp * (gx * A.dVx[id] + gy * A.dVy[id]);
+      gsum += t;
+      if (A.Gacc) A.Gacc[qd] -= wv * t;
+    }
+  }
+  const double gt = block_sum(gsum, red);
+  if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 3] = -wv * gt;
+}
+
 // Gacc[node] += coef[g] * tnode[node] on the dual nodes of the glaciers with coef[g] != 0 (k_vq_finish: the glacier just
 // reached a quadrature node)
 #ifdef ODINN_VEL_KERNELS
