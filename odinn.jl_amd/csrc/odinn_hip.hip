@@ -17,6 +17,17 @@
 #include <string>
 #include <vector>
 
+// The step loops are chains of dependent launches, so launch latency is part of every step.  HIP_FORCE_DEV_KERNARG=1 (kernel
+// arguments in device memory) is the HIP runtime's setting for that on MI300-class parts; it is read when the runtime
+// initialises, so the library asks for it when it is loaded -- without overriding a value the user has set, and without
+// effect if the host application has already initialised HIP.  Measured: 0.122 -> 0.118 ms per step at 8 x 1024^2,
+// 4 alpine glaciers: solve 0.63 -> 0.53 ms, continuous-adjoint gradient 12.3 -> 9.7 ms.
+namespace {
+struct OdinnLoadTimeSettings {
+  OdinnLoadTimeSettings() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+} odinn_load_time_settings;
+}  // namespace
+
 using namespace odinn;
 
 namespace {
