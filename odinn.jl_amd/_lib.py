@@ -8,7 +8,8 @@ import os
 
 # kernel arguments in device memory (the HIP runtime's launch-latency setting for MI300-class parts; takes effect when the
 # runtime has not been initialised yet -- the library's loader sets it too; an explicit value in the environment wins)
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+if not os.environ.get("ODINN_KEEP_HIP_DEFAULTS"):
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODINN_LIB") or os.path.join(_HERE, "csrc", "libodinn_hip.so")  # ODINN_LIB: A/B builds

@@ -20,11 +20,14 @@
 // The step loops are chains of dependent launches, so launch latency is part of every step.  HIP_FORCE_DEV_KERNARG=1 (kernel
 // arguments in device memory) is the HIP runtime's setting for that on MI300-class parts; it is read when the runtime
 // initialises, so the library asks for it when it is loaded -- without overriding a value the user has set, and without
-// effect if the host application has already initialised HIP.  Measured: 0.122 -> 0.118 ms per step at 8 x 1024^2,
-// 4 alpine glaciers: solve 0.63 -> 0.53 ms, continuous-adjoint gradient 12.3 -> 9.7 ms.
+// effect if the host application has already initialised HIP.  On ROCm 7.2 / gfx950 it is the runtime's default already
+// (nothing changes); switched off explicitly it costs 0.118 -> 0.122 ms per step at 8 x 1024^2 and 9.7 -> 12.3 ms on the
+// continuous-adjoint gradient of 4 alpine glaciers.  ODINN_KEEP_HIP_DEFAULTS=1 skips the request.
 namespace {
 struct OdinnLoadTimeSettings {
-  OdinnLoadTimeSettings() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+  OdinnLoadTimeSettings() {
+    if (!std::getenv("ODINN_KEEP_HIP_DEFAULTS")) setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+  }
 } odinn_load_time_settings;
 }  // namespace
 
