@@ -1113,27 +1113,21 @@ __device__ __forceinline__ void adj_stage_weights(AdjState* a, const double* tsn
   }
 }
 
-#ifdef ODINN_MISC_KERNELS
-__global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
-  const int gidx = blockIdx.x;
-  GState* gs = P.gs + gidx;
-  if (gs->done) {
-    if (threadIdx.x == 0) {
-      gs->at_stop = 0;  // its final post-step already ran
-      if (C.qw_out) C.qw_out[gidx] = 0.0;
-    }
-    return;
-  }
-  const GDev g = P.gd[gidx];
+// ---- the step controller, as device functions shared by k_controller and k_adj_ctrl_post -----------------------------------
+// error sum of a glacier's per-tile partials (fixed order: lane l takes tiles l, l + 64, ...; then the butterfly) and the
+// three powers of the PID factor, evaluated by lanes 0..2 side by side (one pow's latency instead of three on the single-
+// thread critical path; same values, same order of the product).  Called by the 64 lanes of one wavefront.
+__device__ __forceinline__ void controller_errsum(const CtrlArgs& C, const GDev& g, double e2, double e3, int lane, double& s_out,
+                                                  double& pw0, double& pw1, double& pw2) {
   double s = 0.0;
   {
     const int t0 = C.fused == 6 ? g.tile0Fv : C.fused == 5 ? g.tile0D : C.fused == 4 ? g.tile0Fu : C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
     const int nt = C.fused == 6 ? g.ntilesFv : C.fused == 5 ? g.ntilesD : C.fused == 4 ? g.ntilesFu : C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
     if (C.cfl > 0.0) {
-      for (int k = threadIdx.x; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
+      for (int k = lane; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
     } else {
       // (the loads of up to eight rounds are issued before the first addition; same order of the additions)
-      for (int k0 = threadIdx.x; k0 < nt; k0 += 64 * 8) {
+      for (int k0 = lane; k0 < nt; k0 += 64 * 8) {
         double v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -1150,18 +1144,116 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
   s = C.cfl > 0.0 ? wave_max(s) : wave_sum(s);
   // the three powers of the PID factor are evaluated by lanes 0..2 side by side (one pow's latency instead of three on the
   // single-thread critical path of this kernel; same values, same order of the product)
-  double pw0 = 1.0, pw1 = 1.0, pw2 = 1.0;
+  pw0 = 1.0; pw1 = 1.0; pw2 = 1.0;
   if (C.adaptive && !(C.cfl > 0.0)) {
     const double sb = __shfl(s, 0, 64);
     double EEst = sqrt(sb / ((double)g.nx * (double)g.ny));
     if (!(EEst == EEst) || isinf(EEst)) EEst = 1e300;
     if (EEst < 2.220446049250313e-16) EEst = 2.220446049250313e-16;
-    const int l = threadIdx.x;
-    const double base = l == 0 ? 1.0 / EEst : (l == 1 ? gs->e2 : gs->e3);
+    const int l = lane;
+    const double base = l == 0 ? 1.0 / EEst : (l == 1 ? e2 : e3);
     const double ex = l == 0 ? 0.64 / 3.0 : (l == 1 ? -0.31 / 3.0 : 0.04 / 3.0);
     const double pw = l < 3 ? pow(base, ex) : 1.0;
     pw0 = __shfl(pw, 0, 64); pw1 = __shfl(pw, 1, 64); pw2 = __shfl(pw, 2, 64);
   }
+  s_out = s;
+}
+// the decision itself (PID controller, accept / reject, stop handling, next step size; the reverse solve's AdjState),
+// on values in registers: one thread.  Returns 1 when the glacier has just finished; est: steps still needed (-1: n/a).
+__device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const GDev& g, const CtrlArgs& C, double s, double pw0,
+                                                 double pw1, double pw2, int& est) {
+  est = -1;
+  const double h = st.dt;
+  double fac = 1.0;
+  bool accept = true;
+  if (C.adaptive) {
+    double EEst = sqrt(s / ((double)g.nx * (double)g.ny));
+    if (!(EEst == EEst) || isinf(EEst)) { st.nonfinite = 1; EEst = 1e300; }
+    if (EEst < 2.220446049250313e-16) EEst = 2.220446049250313e-16;
+    st.EEst = EEst;
+    const double e1 = 1.0 / EEst;
+    fac = pw0 * pw1 * pw2;  // pow(e1, 0.64 / 3) * pow(e2, -0.31 / 3) * pow(e3, 0.04 / 3)
+    fac = 1.0 + atan(fac - 1.0);
+    accept = fac >= 0.81;
+    if (accept) { st.e3 = st.e2; st.e2 = e1; }
+  }
+  double t = st.t;
+  st.at_stop = 0;
+  st.mb_now = 0;
+  if (C.adj) { ad.qw = 0.0; ad.snapj = -1; }
+  if (accept) {
+    st.naccept++;
+    st.accepted = 1;
+    st.cur = C.next_cur >= 0 ? C.next_cur : 1 - st.cur;
+    if (st.clipped) {
+      t = C.tstops[st.istop];
+      st.at_stop = 1;
+      st.mb_now = C.mb_flag[st.istop];
+      st.mb_slot = C.mb_slot[st.istop];
+      if (C.adj) {
+        AdjState* a = &ad;
+        a->snapj = C.stop_snap[st.istop];
+        a->qw = C.stop_qw[st.istop];
+        a->seg_stop = a->seg;
+        const double ta = C.tsnap[a->seg];
+        a->s_stop = a->snapj >= 0 ? (a->snapj == a->seg ? 0.0 : 1.0) : (-t - ta) / (C.tsnap[a->seg + 1] - ta);
+        if (a->snapj >= 1) a->seg = a->snapj - 1;  // the next steps run below snapshot j
+      }
+      st.istop++;
+    } else {
+      t += h;
+    }
+    st.t = t;
+  } else {
+    st.nreject++;
+    st.accepted = 0;
+  }
+  if (!C.adj) {
+    // forward solve, mass balance applied ON LOAD by the strip step kernel (ScArgs::snap_on_load with a mass balance): bit 2
+    // of `pad` says the buffer `cur` still lacks the mass balance of the stop it sits on -- set when an accepted step lands
+    // on such a stop, cleared by the next accepted step (which replaces the buffer).  Ignored by the post-step schedule.
+    if (accept) st.pad &= ~4;
+    if (accept && st.at_stop && st.mb_now && g.has_mb) st.pad |= 4;
+  }
+  if (st.istop >= C.n_stops) {
+    st.done = 1;
+    est = 0;
+    return 1;
+  }
+  double dtn = C.adaptive ? h * fac : C.fixed_dt;
+  if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
+  const double rem = C.tstops[st.istop] - t;
+  // snap to the stop when the step would end within 100 ulp of it
+  if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
+    dtn = rem;
+    st.clipped = 1;
+  } else {
+    st.clipped = 0;
+  }
+  st.dt = dtn;
+  {  // at the current step size, and at least one step per remaining stop
+    const double e = ceil((C.tstops[C.n_stops - 1] - t) / (C.adaptive ? h * fac : dtn));
+    const int stops_left = C.n_stops - st.istop;
+    est = e < (double)stops_left ? stops_left : (e > 1e6 ? 1000000 : (int)e);
+  }
+  if (C.adj) adj_stage_weights(&ad, C.tsnap, t, dtn, false);
+  return 0;
+}
+
+#ifdef ODINN_MISC_KERNELS
+__global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
+  const int gidx = blockIdx.x;
+  GState* gs = P.gs + gidx;
+  if (gs->done) {
+    if (threadIdx.x == 0) {
+      gs->at_stop = 0;  // its final post-step already ran
+      if (C.qw_out) C.qw_out[gidx] = 0.0;
+    }
+    return;
+  }
+  const GDev g = P.gd[gidx];
+  double s, pw0, pw1, pw2;
+  controller_errsum(C, g, gs->e2, gs->e3, (int)threadIdx.x, s, pw0, pw1, pw2);
   if (threadIdx.x != 0) return;
   // one thread from here on: the per-glacier state is taken into registers once and written back once (dozens of dependent
   // global read-modify-writes through `gs->` otherwise: the kernel spent most of its 8 us on them)
@@ -1210,84 +1302,11 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
     *gs = st;
     return;
   }
-  const double h = st.dt;
-  double fac = 1.0;
-  bool accept = true;
-  if (C.adaptive) {
-    double EEst = sqrt(s / ((double)g.nx * (double)g.ny));
-    if (!(EEst == EEst) || isinf(EEst)) { st.nonfinite = 1; EEst = 1e300; }
-    if (EEst < 2.220446049250313e-16) EEst = 2.220446049250313e-16;
-    st.EEst = EEst;
-    const double e1 = 1.0 / EEst;
-    fac = pw0 * pw1 * pw2;  // pow(e1, 0.64 / 3) * pow(e2, -0.31 / 3) * pow(e3, 0.04 / 3)
-    fac = 1.0 + atan(fac - 1.0);
-    accept = fac >= 0.81;
-    if (accept) { st.e3 = st.e2; st.e2 = e1; }
-  }
-  double t = st.t;
-  st.at_stop = 0;
-  st.mb_now = 0;
-  if (C.adj) { ad.qw = 0.0; ad.snapj = -1; }
-  if (accept) {
-    st.naccept++;
-    st.accepted = 1;
-    st.cur = C.next_cur >= 0 ? C.next_cur : 1 - st.cur;
-    if (st.clipped) {
-      t = C.tstops[st.istop];
-      st.at_stop = 1;
-      st.mb_now = C.mb_flag[st.istop];
-      st.mb_slot = C.mb_slot[st.istop];
-      if (C.adj) {
-        AdjState* a = &ad;
-        a->snapj = C.stop_snap[st.istop];
-        a->qw = C.stop_qw[st.istop];
-        a->seg_stop = a->seg;
-        const double ta = C.tsnap[a->seg];
-        a->s_stop = a->snapj >= 0 ? (a->snapj == a->seg ? 0.0 : 1.0) : (-t - ta) / (C.tsnap[a->seg + 1] - ta);
-        if (a->snapj >= 1) a->seg = a->snapj - 1;  // the next steps run below snapshot j
-      }
-      st.istop++;
-    } else {
-      t += h;
-    }
-    st.t = t;
-  } else {
-    st.nreject++;
-    st.accepted = 0;
-  }
+  int est;
+  const int newly_done = controller_decide(st, ad, g, C, s, pw0, pw1, pw2, est);
   if (C.qw_out) C.qw_out[gidx] = ad.qw;
-  if (!C.adj) {
-    // forward solve, mass balance applied ON LOAD by the strip step kernel (ScArgs::snap_on_load with a mass balance): bit 2
-    // of `pad` says the buffer `cur` still lacks the mass balance of the stop it sits on -- set when an accepted step lands
-    // on such a stop, cleared by the next accepted step (which replaces the buffer).  Ignored by the post-step schedule.
-    if (accept) st.pad &= ~4;
-    if (accept && st.at_stop && st.mb_now && g.has_mb) st.pad |= 4;
-  }
-  if (st.istop >= C.n_stops) {
-    st.done = 1;
-    atomicSub(C.n_active, 1);
-    if (C.est_steps) C.est_steps[gidx] = 0;
-    *gs = st;
-    if (C.adj) C.adj[gidx] = ad;
-    return;
-  }
-  double dtn = C.adaptive ? h * fac : C.fixed_dt;
-  if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
-  const double rem = C.tstops[st.istop] - t;
-  // snap to the stop when the step would end within 100 ulp of it
-  if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
-    dtn = rem;
-    st.clipped = 1;
-  } else {
-    st.clipped = 0;
-  }
-  st.dt = dtn;
-  if (C.est_steps) {  // at the current step size, and at least one step per remaining stop
-    const double e = ceil((C.tstops[C.n_stops - 1] - t) / (C.adaptive ? h * fac : dtn));
-    const int stops_left = C.n_stops - st.istop;
-    C.est_steps[gidx] = e < (double)stops_left ? stops_left : (e > 1e6 ? 1000000 : (int)e);
-  }
-  if (C.adj) adj_stage_weights(&ad, C.tsnap, t, dtn, false);
+  if (newly_done) atomicSub(C.n_active, 1);
+  if (C.est_steps && est >= 0) C.est_steps[gidx] = est;
   *gs = st;
   if (C.adj) C.adj[gidx] = ad;
 }
