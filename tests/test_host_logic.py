@@ -163,3 +163,19 @@ def test_load_gridded_glacier_reads_oggm_style_files(odinn, tmp_path):
     np.savez(tmp_path / "g.npz", x=x, y=y, topo=topo, thickness=np.nan_to_num(thick), glacier_mask=mask)
     g2 = odinn.load_gridded_glacier(tmp_path / "g.npz")
     assert np.array_equal(g2.H0, gl.H0) and np.array_equal(g2.B, gl.B) and g2.rgi_id == "g"
+
+
+def test_launch_latency_setting_is_requested_without_overriding_the_user(odinn):
+    """The Python layer asks the HIP runtime for device-memory kernel arguments (HIP_FORCE_DEV_KERNARG=1) before its first
+    HIP call, never overwriting a value the user has set; ODINN_KEEP_HIP_DEFAULTS=1 skips the request (fresh interpreters:
+    the setting is applied at import time)."""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); import _odinn_import; _odinn_import.load(); import os; print(os.environ.get('HIP_FORCE_DEV_KERNARG'))" % root
+    for extra, want in (({}, "1"), ({"HIP_FORCE_DEV_KERNARG": "0"}, "0"), ({"ODINN_KEEP_HIP_DEFAULTS": "1"}, "None")):
+        env = {k: v for k, v in os.environ.items() if k not in ("HIP_FORCE_DEV_KERNARG", "ODINN_KEEP_HIP_DEFAULTS")}
+        env.update(extra)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:]
+        assert out.stdout.strip().splitlines()[-1] == want, (extra, out.stdout)
