@@ -271,7 +271,59 @@ __device__ __forceinline__ double exp_nonpos(double y) {  // y <= 0
   p = fma(p, r, 1.0);
   return ldexp(p, (int)n);
 }
-__device__ __forceinline__ double log1p_01(double t) {  // 0 <= t <= 1
+// log1p on [0, 1] from a 65-entry table {log1p(i/64), 1/(1 + i/64)} (one 16-byte gather, L1-resident) and a degree-8
+// remainder: 1 + t = (1 + t_i)(1 + r), r = (t - t_i)/(1 + t_i), |r| <= 1/128, log1p(t) = L_i + r P(r).  t - t_i is exact
+// (Sterbenz), the truncation r^8/9 < 2e-18 relative even where L_i = 0; <= 2 ulp like the atanh form it replaces (kept
+// below as log1p_01_series, ODINN_LOG1P_TABLE=0) at ~19 instead of ~31 instructions: 32 of the 33 activations of the
+// 2 x 16 net are softplus, each one exp + one log1p.
+// Where it pays is a matter of how many gathers a kernel has in flight: the small default nets (2-3-10-3-1, 1-3-10-3-1: 16
+// softplus per evaluation) gain 18-37 % per solve step (8 x 1024^2, Y law: per-stage 1852 -> 1518 us, fused 2431 -> 1528;
+// 4 alpine glaciers 78 -> 56), the hoisted-law field 0.49 -> 0.38 ms, the U-law reverse stages 18 %; the stencil kernels
+// with the 16-wide net inlined (32 softplus per node, 2 waves per SIMD) become gather-bound and lose 1.8 x (2797 -> 5031
+// us per step).  So: on everywhere except the translation units of the 16-wide compile-time net (ODINN_LM == 4) and
+// of the run-time architectures (ODINN_LM == 2, which may be as wide).
+#ifndef ODINN_LOG1P_TABLE
+#if defined(ODINN_LM) && (ODINN_LM == 2 || ODINN_LM == 4)
+#define ODINN_LOG1P_TABLE 0
+#else
+#define ODINN_LOG1P_TABLE 1
+#endif
+#endif
+__device__ static const double LOG1P_TAB[65][2] __attribute__((aligned(16))) = {
+    {0.0, 1.0}, {0.015504186535965254, 0.9846153846153847},
+    {0.030771658666753687, 0.9696969696969697}, {0.0458095360312942, 0.9552238805970149},
+    {0.06062462181643484, 0.9411764705882353}, {0.07522342123758753, 0.927536231884058},
+    {0.08961215868968714, 0.9142857142857143}, {0.10379679368164356, 0.9014084507042254},
+    {0.11778303565638346, 0.8888888888888888}, {0.13157635778871926, 0.8767123287671232},
+    {0.1451820098444979, 0.8648648648648649}, {0.15860503017663857, 0.8533333333333334},
+    {0.17185025692665923, 0.8421052631578947}, {0.184922338494012, 0.8311688311688312},
+    {0.19782574332991987, 0.8205128205128205}, {0.21056476910734964, 0.810126582278481},
+    {0.22314355131420976, 0.8}, {0.2355660713127669, 0.7901234567901234},
+    {0.24783616390458124, 0.7804878048780488}, {0.25995752443692605, 0.7710843373493976},
+    {0.27193371548364176, 0.7619047619047619}, {0.2837681731306446, 0.7529411764705882},
+    {0.2954642128938359, 0.7441860465116279}, {0.3070250352949119, 0.735632183908046},
+    {0.3184537311185346, 0.7272727272727273}, {0.329753286372468, 0.7191011235955056},
+    {0.3409265869705932, 0.7111111111111111}, {0.3519764231571782, 0.7032967032967034},
+    {0.3629054936893685, 0.6956521739130435}, {0.37371640979358406, 0.6881720430107527},
+    {0.38441169891033206, 0.6808510638297872}, {0.394993808240869, 0.6736842105263158},
+    {0.4054651081081644, 0.6666666666666666}, {0.415827895143711, 0.6597938144329897},
+    {0.42608439531090003, 0.6530612244897959}, {0.43623676677491807, 0.6464646464646465},
+    {0.44628710262841953, 0.64}, {0.45623743348158763, 0.6336633663366337},
+    {0.46608972992459924, 0.6274509803921569}, {0.4758459048699639, 0.6213592233009708},
+    {0.48550781578170077, 0.6153846153846154}, {0.4950772667978515, 0.6095238095238096},
+    {0.5045560107523953, 0.6037735849056604}, {0.5139457511022343, 0.5981308411214953},
+    {0.5232481437645479, 0.5925925925925926}, {0.5324647988694718, 0.5871559633027523},
+    {0.5415972824327444, 0.5818181818181818}, {0.5506471179526623, 0.5765765765765766},
+    {0.5596157879354227, 0.5714285714285714}, {0.5685047353526687, 0.5663716814159292},
+    {0.5773153650348236, 0.5614035087719298}, {0.5860490450035782, 0.5565217391304348},
+    {0.5947071077466928, 0.5517241379310345}, {0.6032908514380843, 0.5470085470085471},
+    {0.6118015411059929, 0.5423728813559322}, {0.6202404097518576, 0.5378151260504201},
+    {0.6286086594223741, 0.5333333333333333}, {0.6369074622370692, 0.5289256198347108},
+    {0.6451379613735847, 0.5245901639344263}, {0.6533012720127457, 0.5203252032520326},
+    {0.661398482245365, 0.5161290322580645}, {0.6694306539426292, 0.512},
+    {0.6773988235918061, 0.5079365079365079}, {0.6853040030989194, 0.5039370078740157},
+    {0.6931471805599453, 0.5}};
+__device__ __forceinline__ double log1p_01_series(double t) {  // 0 <= t <= 1
   const bool big = t > 0.41421356237309503;
   const double num = big ? t - 1.0 : t;
   const double den = big ? t + 3.0 : t + 2.0;
@@ -292,6 +344,24 @@ __device__ __forceinline__ double log1p_01(double t) {  // 0 <= t <= 1
   double r = fma(s_, p, s_);
   r = r + r;
   return big ? r + 0.6931471805599453 : r;
+}
+__device__ __forceinline__ double log1p_01(double t) {  // 0 <= t <= 1
+#if ODINN_LOG1P_TABLE
+  const double k = rint(t * 64.0);
+  const double2 e = *reinterpret_cast<const double2*>(&LOG1P_TAB[(int)k][0]);
+  const double r = (t - k * 0.015625) * e.y;
+  double p = -0.125;
+  p = fma(p, r, 1.0 / 7.0);
+  p = fma(p, r, -1.0 / 6.0);
+  p = fma(p, r, 0.2);
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  p = fma(p, r, 1.0);
+  return fma(r, p, e.x);
+#else
+  return log1p_01_series(t);
+#endif
 }
 __device__ __forceinline__ double softplus_f(double x) { return log1p_01(exp_nonpos(-fabs(x))) + fmax(x, 0.0); }
 __device__ __forceinline__ double sigmoid_f(double x) {
