@@ -179,3 +179,32 @@ def test_launch_latency_setting_is_requested_without_overriding_the_user(odinn):
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-500:]
         assert out.stdout.strip().splitlines()[-1] == want, (extra, out.stdout)
+
+
+def test_log1p_table_recipe_is_within_two_ulp():
+    """The device's table form of log1p on [0, 1] (sia2d_device.hpp: 65 entries {log1p(i/64), 1/(1 + i/64)}, degree-8
+    remainder), restated with plain double arithmetic (no fma: one rounding more per step than the device), against
+    60-digit arithmetic: <= 2 ulp, like the atanh-series form it replaces in most kernels."""
+    import math, random
+    from decimal import Decimal, getcontext
+
+    getcontext().prec = 60
+    tab = [(math.log1p(i / 64.0), 1.0 / (1.0 + i / 64.0)) for i in range(65)]
+
+    def log1p_table(t):
+        k = float(round(t * 64.0))
+        e = tab[int(k)]
+        r = (t - k * 0.015625) * e[1]
+        p = -0.125
+        for c in (1.0 / 7.0, -1.0 / 6.0, 0.2, -0.25, 1.0 / 3.0, -0.5, 1.0):
+            p = p * r + c
+        return r * p + e[0]
+
+    random.seed(7)
+    ts = [1.0, 0.5, 1 / 128, 1 / 64, 3 / 128, 127 / 128, 1e-17, 1e-8] + [random.random() for _ in range(12000)] + \
+         [random.random() * 10 ** random.uniform(-12, 0) for _ in range(8000)]
+    worst = 0.0
+    for t in ts:
+        ref = (Decimal(1) + Decimal(t)).ln() if t > 1e-25 else Decimal(t)
+        worst = max(worst, float(abs(Decimal(log1p_table(t)) - ref) / Decimal(math.ulp(float(ref)))))
+    assert log1p_table(0.0) == 0.0 and worst <= 2.0, worst
