@@ -1,9 +1,9 @@
 // k_fused.hip -- temporally fused RDPK3Sp35 step for one law mode (-DODINN_LM=0|1|2)
 #include <cstdlib>
-// the fused step kernel of the inlined-MLP laws serves the batches that do not fill the GPU (latency, not gather
-// throughput, is what it waits for): the table form of log1p pays here also for the 16-wide and run-time nets
-// (2-16-16-1 Y law, 4 alpine glaciers: 128 -> 112 us per step; 1 x 512^2: 357 -> 253), see sia2d_device.hpp
-#define ODINN_LOG1P_TABLE 1
+// inlined-MLP laws: log1p's table lives in LDS in these kernels (mode 2: filled with the tile; see sia2d_device.hpp)
+#if defined(ODINN_LM) && ODINN_LM >= 2 && !defined(ODINN_LOG1P_TABLE)
+#define ODINN_LOG1P_TABLE 2
+#endif
 #include "launch.hpp"
 #include "sia2d_fused.hpp"
 #ifndef ODINN_LM

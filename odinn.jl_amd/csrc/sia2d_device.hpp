@@ -276,18 +276,16 @@ __device__ __forceinline__ double exp_nonpos(double y) {  // y <= 0
 // (Sterbenz), the truncation r^8/9 < 2e-18 relative even where L_i = 0; <= 2 ulp like the atanh form it replaces (kept
 // below as log1p_01_series, ODINN_LOG1P_TABLE=0) at ~19 instead of ~31 instructions: 32 of the 33 activations of the
 // 2 x 16 net are softplus, each one exp + one log1p.
-// Where it pays is a matter of how many gathers a kernel has in flight: the small default nets (2-3-10-3-1, 1-3-10-3-1: 16
-// softplus per evaluation) gain 18-37 % per solve step (8 x 1024^2, Y law: per-stage 1852 -> 1518 us, fused 2431 -> 1528;
-// 4 alpine glaciers 78 -> 56), the hoisted-law field 0.49 -> 0.38 ms, the U-law reverse stages 18 %; the stencil kernels
-// with the 16-wide net inlined (32 softplus per node, 2 waves per SIMD) become gather-bound and lose 1.8 x (2797 -> 5031
-// us per step).  So: on everywhere except the translation units of the 16-wide compile-time net (ODINN_LM == 4) and
-// of the run-time architectures (ODINN_LM == 2, which may be as wide).
+// Two forms: ODINN_LOG1P_TABLE == 1 reads the table from global memory (L1-resident; the one-node-per-thread kernels: hoisted
+// law field, knot / node-grid gradients, velocity kernels), == 2 from a copy in LDS that the tile loaders fill (the stencil
+// kernels with an inlined network: k_fwd.hip, k_adj.hip, k_fused.hip define it before including this header).  With the
+// global form those stencil kernels are gather-bound for the 16-wide net (32 softplus per node at 2 waves per SIMD:
+// 2797 -> 5031 us per solve step at 8 x 1024^2); with the LDS form every net gains (us per solve step at 8 x 1024^2,
+// series -> LDS table: 2-16-16-1 Y law per-stage 2797 -> 2194, fused 3614 -> 2475; default 2-3-10-3-1 Y law 1852 -> 1244
+// and 2431 -> 1530; U law 1394 -> 1185; 4 alpine glaciers, fused: 128 -> 103, 78 -> 54, 73 -> 56); the hoisted-law field
+// 0.49 -> 0.38 ms.  0 selects the series everywhere.
 #ifndef ODINN_LOG1P_TABLE
-#if defined(ODINN_LM) && (ODINN_LM == 2 || ODINN_LM == 4)
-#define ODINN_LOG1P_TABLE 0
-#else
 #define ODINN_LOG1P_TABLE 1
-#endif
 #endif
 __device__ static const double LOG1P_TAB[65][2] __attribute__((aligned(16))) = {
     {0.0, 1.0}, {0.015504186535965254, 0.9846153846153847},
@@ -323,6 +321,11 @@ __device__ static const double LOG1P_TAB[65][2] __attribute__((aligned(16))) = {
     {0.661398482245365, 0.5161290322580645}, {0.6694306539426292, 0.512},
     {0.6773988235918061, 0.5079365079365079}, {0.6853040030989194, 0.5039370078740157},
     {0.6931471805599453, 0.5}};
+#if ODINN_LOG1P_TABLE == 2
+// mode 2 (the stencil kernels with an inlined network: k_fwd.hip, k_adj.hip, k_fused.hip): the table in LDS, filled by the
+// tile loader -- an L1 gather per activation makes the throughput-bound ones gather-bound, a ds_read_b128 does not
+__shared__ double2 g_log1p_lds[65];
+#endif
 __device__ __forceinline__ double log1p_01_series(double t) {  // 0 <= t <= 1
   const bool big = t > 0.41421356237309503;
   const double num = big ? t - 1.0 : t;
@@ -348,7 +351,11 @@ __device__ __forceinline__ double log1p_01_series(double t) {  // 0 <= t <= 1
 __device__ __forceinline__ double log1p_01(double t) {  // 0 <= t <= 1
 #if ODINN_LOG1P_TABLE
   const double k = rint(t * 64.0);
+#if ODINN_LOG1P_TABLE == 2
+  const double2 e = g_log1p_lds[(int)k];
+#else
   const double2 e = *reinterpret_cast<const double2*>(&LOG1P_TAB[(int)k][0]);
+#endif
   const double r = (t - k * 0.015625) * e.y;
   double p = -0.125;
   p = fma(p, r, 1.0 / 7.0);
@@ -801,6 +808,11 @@ __device__ __forceinline__ bool load_tile_HS2(const double* __restrict__ U, cons
   // U2 != null: the field is U + sw (U2 - U)  (H_itp of the continuous adjoint, gradient.jl:287).
   // Returns whether any value THIS thread loaded (own rows or its share of the halo) carries ice.
   bool ice = false;
+#if ODINN_LOG1P_TABLE == 2
+  // log1p's table into LDS with the tile: every kernel of these units loads its tile through here and has a barrier
+  // between this and its first network evaluation
+  if (threadIdx.x < 65) g_log1p_lds[threadIdx.x] = *reinterpret_cast<const double2*>(&LOG1P_TAB[threadIdx.x][0]);
+#endif
   const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
   const bool colok = gi < g.nx;

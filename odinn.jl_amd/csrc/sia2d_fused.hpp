@@ -316,6 +316,10 @@ __global__ __launch_bounds__(FNT, (lm_is_nn(LM) ? 2 : ODINN_FWPE)) void k_rk_fus
   const int gi = gi0 + lane;
   const bool inx = gi >= 0 && gi < g.nx;
   double u[FSLOT], tmp[FSLOT], up[FSLOT], E[FSLOT], bb[FSLOT];
+#if ODINN_LOG1P_TABLE == 2
+  // inlined-MLP laws: log1p's table into LDS with the tile (a barrier follows before the first network evaluation)
+  if (lm_is_nn(LM) && threadIdx.x < 65) g_log1p_lds[threadIdx.x] = *reinterpret_cast<const double2*>(&LOG1P_TAB[threadIdx.x][0]);
+#endif
 #pragma unroll
   for (int m = 0; m < FSLOT; ++m) {
     const int r = w + FNW * m;
