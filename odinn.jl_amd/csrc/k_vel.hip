@@ -1,5 +1,10 @@
 // k_vel.hip -- surface-velocity kernels (A-type law modes)
 #define ODINN_VEL_KERNELS 1
+// U law (target :D): the surface-velocity kernels evaluate the network five times per dual node; log1p's table lives in LDS
+// here too (mode 2: filled by load_tile_HS2, which every kernel of this unit calls before its first barrier)
+#ifndef ODINN_LOG1P_TABLE
+#define ODINN_LOG1P_TABLE 2
+#endif
 #include "launch.hpp"
 #include "sia2d_velocity.hpp"
 namespace odinn {
