@@ -256,9 +256,22 @@ int odinn_mb_vjp_H(odinn_batch* b, int g, const double* lam, const double* H_pre
 int odinn_eval_law(odinn_batch* b, int g, const double* H, double* out, int n_out);
 
 /* ---- device-resident time loop -------------------------------------------------------- */
+/* Per-glacier stop table.  The reference builds tstops PER GLACIER -- the `step` grid and solver.tstops, which all glaciers
+ * share, plus the glacier's own thickness / velocity data times and the stops of its time-aggregated losses
+ * (src/simulations/inversions/inversion_utils.jl:487-495, src/inverse/SIA2D/gradient.jl:96-107): a glacier's integrator
+ * never lands on another glacier's data times, its result holds its own stops only, and the reverse loops of both adjoints
+ * walk exactly those.  odinn_set_glacier_stops gives glacier g its own table t[0..n-1] (strictly increasing; t[0] and
+ * t[n-1] must equal tstops[0] and tstops[n_stops-1] of the calls that follow: every glacier covers the same tspan); the
+ * `tstops` argument of odinn_solve / odinn_loss_grad* then is the table of the glaciers WITHOUT one.  n = 0 clears.
+ * Snapshot indices (odinn_get_snapshot) and every per-stop quantity of glacier g count ITS stops. */
+int odinn_set_glacier_stops(odinn_batch* b, int g, int n, const double* t);
 /* Integrates every glacier of the batch from tstops[0] to tstops[n_stops-1] with
  * RDPK3Sp35 + PID (adaptive, all control on the device), storing a snapshot at every
- * tstop and applying the mass balance at mb_times (subset of tstops[1:]).
+ * stop of the glacier and applying the mass balance at mb_times, strictly increasing times in (tstops[0], tstops[end]].
+ * A mass-balance time that is not a stop of the glacier makes its integrator land there and apply the mass balance without
+ * adding a snapshot to the result -- PeriodicCallback(mb_action!, step_MB) of inversion_utils.jl:498-517 with
+ * step_MB not a multiple of solver.step.  (odinn_loss_grad rejects such times like the reference's DiscreteAdjoint,
+ * gradient.jl:131; odinn_loss_grad_continuous: ODINN_ERR_UNSUPPORTED.)
  * stats: array of n_glaciers entries (may be NULL). */
 int odinn_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times,
                 const odinn_solver_opts* opts, odinn_solve_stats* stats);

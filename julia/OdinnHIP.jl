@@ -43,20 +43,60 @@ function Batch(simulation; device = 0)
     check(ccall((:odinn_batch_create, lib), Cint, (Cint, Cint, Ptr{GlacierDesc}, Ptr{Ptr{Cvoid}}),
                 device, length(descs), descs, h))
     b = Batch(h[])
+    dl = data_loss(simulation.parameters.UDE.empirical_loss_function)
+    hl = dl isa ODINN.LossHV ? dl.hLoss : dl isa ODINN.LossH ? dl : nothing   # the thickness term (its L2Sum / LogSum carries `distance`)
     for (i, g) in enumerate(simulation.glaciers)
         check(ccall((:odinn_set_fields, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}),
                     b.h, i - 1, g.H₀, g.B))
-        if !isnothing(g.thicknessData)
-            tH = collect(Float64, g.thicknessData.t); Hs = reduce(hcat, vec.(g.thicknessData.H))
+        if !isnothing(g.thicknessData) && !isnothing(hl)   # (no LossH / LossHV in the loss: no thickness data term)
+            tH = collect(Float64, ODINN.tdata(g.thicknessData)); Hs = reduce(hcat, vec.(g.thicknessData.H))
             check(ccall((:odinn_set_reference, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Cint),
-                        b.h, i - 1, length(tH), tH, Hs, simulation.parameters.UDE.empirical_loss_function.loss.distance))
+                        b.h, i - 1, length(tH), tH, Hs, hl.loss.distance))
+        end
+        tV = collect(Float64, ODINN.tdata(g.velocityData, simulation.parameters.simulation.mapping))
+        if length(tV) > 0   # LossV / LossHV data, and the dates VelocityRegularization is weighted by
+            v = g.velocityData
+            check(ccall((:odinn_set_velocity_reference, lib), Cint,
+                        (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                        b.h, i - 1, length(tV), tV, reduce(hcat, vec.(v.vabs)), reduce(hcat, vec.(v.vx)), reduce(hcat, vec.(v.vy))))
         end
     end
+    vl = dl isa ODINN.LossHV ? dl.vLoss : dl isa ODINN.LossV ? dl : nothing
+    check(ccall((:odinn_set_loss, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Cdouble), b.h,
+                dl isa ODINN.LossHV ? 2 : dl isa ODINN.LossV ? 1 : 0,
+                (!isnothing(vl) && vl.component == :abs) ? 1 : 0, (isnothing(vl) || vl.scale_loss) ? 1 : 0,
+                dl isa ODINN.LossHV ? dl.scaling : 1.0))
     check(ccall((:odinn_set_surface_velocity_factor, lib), Cint, (Ptr{Cvoid}, Cdouble),
                 b.h, simulation.parameters.simulation.f_surface_velocity_factor))   # target :D: Velocityꜛ = U / f
-    set_time_aggregated_losses!(b, simulation)
+    set_time_aggregated_losses!(b, simulation)   # (after the velocity dates are known to the library)
     set_grad_interpolation!(b, simulation)
+    set_glacier_stops!(b, simulation)
     finalizer(x -> ccall((:odinn_batch_destroy, lib), Cint, (Ptr{Cvoid},), x.h), b)
+end
+
+# the data term of the empirical loss (LossH / LossV / LossHV, alone or inside a MultiLoss); `nothing` when the loss holds
+# time-aggregated terms and regularisers only (MultiLoss((LossDhdt(),), (1,)): no thickness / velocity data term)
+function data_loss(lf)
+    terms = lf isa ODINN.MultiLoss ? collect(lf.losses) : [lf]
+    k = findfirst(l -> l isa Union{ODINN.LossH, ODINN.LossV, ODINN.LossHV}, terms)
+    return isnothing(k) ? nothing : terms[k]
+end
+
+# The reference builds tstops PER GLACIER: the `step` grid and solver.tstops, shared, plus the glacier's own data times
+# and the stops of its time-aggregated losses (inversion_utils.jl:487-495; gradient.jl:96-107 rebuilds the same table
+# and asserts it equals result.t).  The library keeps one table per glacier: odinn_set_glacier_stops.
+function glacier_tstops(simulation, i)
+    params = simulation.parameters; glacier = simulation.glaciers[i]; lf = params.UDE.empirical_loss_function
+    ts = unique(vcat(Huginn.define_callback_steps(params.simulation.tspan, params.solver.step), params.solver.tstops))
+    return sort(unique(vcat(ts, ODINN.tdata(glacier.thicknessData), ODINN.tdata(glacier.velocityData, params.simulation.mapping),
+                            unique(ODINN.discreteLossSteps(lf, params.simulation.tspan)),
+                            unique(ODINN.discretePostIntegralLossSteps(lf, simulation, i)))))
+end
+function set_glacier_stops!(b::Batch, simulation)
+    for i in eachindex(simulation.glaciers)
+        ts = collect(Float64, glacier_tstops(simulation, i))
+        check(ccall((:odinn_set_glacier_stops, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}), b.h, i - 1, length(ts), ts))
+    end
 end
 
 # terms of a MultiLoss the library evaluates next to the data loss (src/losses/TimeAggregatedLosses.jl, Regularization.jl:192-245):

@@ -108,6 +108,7 @@ SIGNATURES = {
     "odinn_mb_vjp_H": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "odinn_eval_law": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int]),
     "odinn_solve": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.POINTER(SolverOpts), C.POINTER(SolveStats)]),
+    "odinn_set_glacier_stops": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "odinn_get_snapshot": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "odinn_get_H": (C.c_int, [_vp, C.c_int, _dp]),
     "odinn_loss": (C.c_int, [_vp, _dp]),

@@ -917,25 +917,52 @@ class _Simulation:
         self._batch: Optional[GlacierBatch] = None
         self._mine: List[int] = list(range(len(self.glaciers)))
 
-    # tstops exactly as _batch_iceflow_UDE builds them (inversion_utils.jl:487-495)
-    def tstops(self):
+    # tstops exactly as _batch_iceflow_UDE builds them (inversion_utils.jl:487-495) -- PER GLACIER: the `step` grid and
+    # solver.tstops are shared, the thickness / velocity data times and the stops of the time-aggregated losses are the
+    # glacier's own (gradient.jl:96-107 rebuilds the same table for the reverse loop and asserts it equals result.t)
+    def _shared_stops(self):
         p = self.parameters
-        ts = set(define_callback_steps(p.simulation.tspan, p.solver.step)) | set(p.solver.tstops)
-        for g in self.glaciers:
-            if g.thicknessData is not None:
-                ts |= set(float(t) for t in g.thicknessData.t)
-            if g.velocityData is not None:
-                ts |= set(float(t) for t in g.velocityData.t)
-            regs_ = _split_loss(p.UDE.empirical_loss_function)[2]
-            if g.dhdtData is not None and any(isinstance(r, LossDhdt) for r, _ in regs_):
-                ts |= set(float(t) for t in g.dhdtData.t)  # discretePostIntegralLossSteps (TimeAggregatedLosses.jl:352-354)
-        for g in self.glaciers:
-            for r, _ in _split_loss(p.UDE.empirical_loss_function)[2]:
-                if isinstance(r, LossAvgV):  # :355-363; a grid point that is an existing stop up to rounding IS that stop
-                    for x in _avgv_times(g, r):
-                        if not any(abs(x - t) <= 1e-9 for t in ts):
-                            ts.add(x)
+        return set(define_callback_steps(p.simulation.tspan, p.solver.step)) | set(float(t) for t in p.solver.tstops)
+
+    def tstops_glacier(self, i: int):
+        """Stop table of glacier i (index into simulation.glaciers)."""
+        p = self.parameters
+        g = self.glaciers[i]
+        ts = self._shared_stops()
+        if g.thicknessData is not None:
+            ts |= set(float(t) for t in g.thicknessData.t)
+        if g.velocityData is not None:
+            ts |= set(float(t) for t in g.velocityData.t)
+        regs_ = _split_loss(p.UDE.empirical_loss_function)[2]
+        if g.dhdtData is not None and any(isinstance(r, LossDhdt) for r, _ in regs_):
+            ts |= set(float(t) for t in g.dhdtData.t)  # discretePostIntegralLossSteps (TimeAggregatedLosses.jl:352-354)
+        for r, _ in regs_:
+            if isinstance(r, LossAvgV):  # :355-363; a grid point that is an existing stop up to rounding IS that stop
+                for x in _avgv_times(g, r):
+                    if not any(abs(x - t) <= 1e-9 for t in ts):
+                        ts.add(x)
         return sorted(t for t in ts if p.simulation.tspan[0] <= t <= p.simulation.tspan[1])
+
+    def tstops(self):
+        """Union of the glaciers' tables: THE table when all glaciers share their data times; otherwise the table handed to
+        the solver for the glaciers that have no table of their own (see _push_stops)."""
+        ts = set()
+        for i in range(len(self.glaciers)):
+            ts |= set(self.tstops_glacier(i))
+        out = []
+        for t in sorted(ts):  # (grid points of time-aggregated losses computed from different dates agree up to rounding only)
+            if not out or t - out[-1] > 1e-9:
+                out.append(t)
+        return out
+
+    def _push_stops(self):
+        """Hand every glacier of this rank its own stop table (no-op entries for those that only have the shared one)."""
+        b = self.batch()
+        shared = self.tstops()
+        for k, gi in enumerate(self._mine):
+            own = self.tstops_glacier(gi)
+            b.set_glacier_stops(k, None if own == shared else own)
+        return shared
 
     def mb_times(self):
         p = self.parameters
@@ -1140,7 +1167,7 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
     if law.classical is not None:
         # PerGlacierModel: every theta slot has a single owner (Model.jl:214-216); dL/dtheta = dL/dA * dA/dtheta
         simulation._apply_classical(th_main)
-        loss, _ = loss_grad(simulation.tstops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
+        loss, _ = loss_grad(simulation._push_stops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
         lo, hi = law.bounds
         sizes, offs = simulation._slots()
         _, Gg = b.grad_parts()
@@ -1150,10 +1177,10 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
             dLdA = Gg[k] if law.classical == "scalar" else b.grad_field(k).ravel(order="F")
             dth[offs[gi]:offs[gi + 1]] = dLdA * dA
     elif model.n_main:
-        loss, dth[:model.n_main] = loss_grad(simulation.tstops(), theta=th_main, mb_times=simulation.mb_times(),
+        loss, dth[:model.n_main] = loss_grad(simulation._push_stops(), theta=th_main, mb_times=simulation.mb_times(),
                                              **simulation._solver_opts())
     else:  # only the initial condition is trainable
-        loss, _ = loss_grad(simulation.tstops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
+        loss, _ = loss_grad(simulation._push_stops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
     if model.IC is not None:  # dL/dθ.IC = λ(t0) ⊙ ∂H0/∂θ.IC  (gradient.jl:262-271, :507-516)
         offs = simulation._ic_slots()
         for k, gi in enumerate(simulation._mine):
@@ -1208,10 +1235,12 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
 
 def _run_prediction(sim: Prediction):
     b = sim.batch()
-    ts = sim.tstops()
+    ts = sim._push_stops()
     stats = b.solve(ts, mb_times=sim.mb_times(), **sim._solver_opts())
-    sim.results = [Results(sim.glaciers[gi].rgi_id, list(ts), [b.snapshot(k, j) for j in range(len(ts))], stats[k])
-                   for k, gi in enumerate(sim._mine)]
+    sim.results = []
+    for k, gi in enumerate(sim._mine):  # every glacier's result holds ITS stops (Sleipnir.create_results, inversion_utils.jl:533-538)
+        tg = sim.tstops_glacier(gi)
+        sim.results.append(Results(sim.glaciers[gi].rgi_id, list(tg), [b.snapshot(k, j) for j in range(len(tg))], stats[k]))
     return sim.results
 
 

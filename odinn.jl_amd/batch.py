@@ -360,6 +360,12 @@ class GlacierBatch:
         self.tstops = ts
         return [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
 
+    def set_glacier_stops(self, g, t=None):
+        """Glacier g's own stop table (the reference builds tstops per glacier, inversion_utils.jl:487-495); None / empty clears.
+        The `tstops` of solve / loss_grad* then serve the glaciers without one; first and last stop must equal theirs."""
+        ts = np.ascontiguousarray([] if t is None else t, dtype=np.float64)
+        L.check(L.lib().odinn_set_glacier_stops(self._h, g, len(ts), _p(ts) if len(ts) else None))
+
     def snapshot(self, g, istop):
         out = np.empty(self.shapes[g], order="F")
         L.check(L.lib().odinn_get_snapshot(self._h, g, int(istop), _p(out)))

@@ -23,8 +23,8 @@ void launch_loss(int nblk, hipStream_t st, Pools P, const double* H, const doubl
   hipLaunchKernelGGL(k_loss, dim3(nblk), dim3(NT), 0, st, P, H, Href, mask, ws, refslot, ntot, log_eps);
 }
 void launch_mb_vjp(int nblk, hipStream_t st, Pools P, const double* Hpre, const double* mb0, const double* Sref,
-                   const double* lam_in, double* lam_out, int add, int base) {
-  hipLaunchKernelGGL(k_mb_vjp, dim3(nblk), dim3(NT), 0, st, P, Hpre, mb0, Sref, lam_in, lam_out, add, base);
+                   const double* lam_in, double* lam_out, int add, int base, const int* gflag, const int* gslot, long long ntot) {
+  hipLaunchKernelGGL(k_mb_vjp, dim3(nblk), dim3(NT), 0, st, P, Hpre, mb0, Sref, lam_in, lam_out, add, base, gflag, gslot, ntot);
 }
 void launch_mb_apply(int nblk, hipStream_t st, Pools P, const double* H, const double* mb0, const double* Sref,
                      double* Hn, double* MBout, int base) {
@@ -105,8 +105,9 @@ void launch_vref_scale(int G, hipStream_t st, Pools P, const AdjState* adj, cons
                        double* scale_out, double* w_out) {
   hipLaunchKernelGGL(k_vref_scale, dim3(G), dim3(64), 0, st, P, adj, slotA, G, scale_loss, wq, scale_out, w_out);
 }
-void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot) {
-  hipLaunchKernelGGL(k_adj_begin, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, n_snap, tau0, mb_flag, mb_slot);
+void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, const int* n_snaps, double tau0, const int* mb_flags,
+                      const int* mb_slots) {
+  hipLaunchKernelGGL(k_adj_begin, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, n_snaps, tau0, mb_flags, mb_slots);
 }
 void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, int all_at_end) {
   hipLaunchKernelGGL(k_adj_itp, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, tsnap, all_at_end);
@@ -129,6 +130,9 @@ void launch_seg_pairs(long long ntot, int n_seg, hipStream_t st, const double* s
 }
 void launch_sum_tilesFt(int G, int rows, hipStream_t st, Pools P, const double* part, double* out) {
   hipLaunchKernelGGL(k_sum_tilesFt, dim3(G), dim3(64), 0, st, P, part, out, rows);
+}
+void launch_lerp_g(int nblk, hipStream_t st, Pools P, const double* snaps, long long ntot, const int* seg, const double* sw, double* out) {
+  hipLaunchKernelGGL(k_lerp_g, dim3(nblk), dim3(NT), 0, st, P, snaps, ntot, seg, sw, out);
 }
 void launch_lerp(long long n, hipStream_t st, double s, const double* a, const double* b, double* out) {
   const long long nb = (n + 255) / 256;

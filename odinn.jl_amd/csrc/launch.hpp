@@ -75,7 +75,8 @@ void launch_sum_part_theta(int Pn, int ng, hipStream_t st, Pools P, const double
 void launch_loss(int nblk, hipStream_t st, Pools P, const double* H, const double* Href, const unsigned char* mask,
                  const double* ws, const int* refslot, long long ntot, double log_eps);
 void launch_mb_vjp(int nblk, hipStream_t st, Pools P, const double* Hpre, const double* mb0, const double* Sref,
-                   const double* lam_in, double* lam_out, int add, int base);
+                   const double* lam_in, double* lam_out, int add, int base, const int* gflag = nullptr,
+                   const int* gslot = nullptr, long long ntot = 0);
 void launch_mb_apply(int nblk, hipStream_t st, Pools P, const double* H, const double* mb0, const double* Sref,
                      double* Hn, double* MBout, int base);
 void launch_dhdt_sums(int nblk, int G, hipStream_t st, Pools P, const double* snaps, const int* i0s, const int* i1s, long long ntot,
@@ -91,6 +92,7 @@ void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double*
 void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const double* y, double* z);
 void launch_axpy(long long n, hipStream_t st, double a, const double* x, const double* y, double* z);  // z = y + a x
 void launch_lerp(long long n, hipStream_t st, double s, const double* a, const double* b, double* out);  // out = a + s (b - a)
+void launch_lerp_g(int nblk, hipStream_t st, Pools P, const double* snaps, long long ntot, const int* seg, const double* sw, double* out);
 void launch_seg_pairs(long long ntot, int n_seg, hipStream_t st, const double* snaps, double2* segs);
 void launch_sum_tilesFt(int G, int rows, hipStream_t st, Pools P, const double* part, double* out);
 // VelocityRegularization (Regularization.jl:192-245): see k_vreg_* in sia2d_device.hpp
@@ -112,7 +114,8 @@ void launch_surfV_theta_only(int lm, int nblk, hipStream_t st, Pools P, const VA
 void launch_gacc_axpy(int nblk, hipStream_t st, Pools P, const double* coef, const double* tnode, double* Gacc);
 void launch_vref_scale(int G, hipStream_t st, Pools P, const AdjState* adj, const int* slotA, int scale_loss, double wq,
                        double* scale_out, double* w_out);
-void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot);
+void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, const int* n_snaps, double tau0, const int* mb_flags,
+                      const int* mb_slots);
 void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, int all_at_end);
 void launch_tikhonov(hipStream_t st, const double* a, const unsigned char* mask, double* r, double* grad,
                      double* partial, int nx, int ny, double dx, double dy);

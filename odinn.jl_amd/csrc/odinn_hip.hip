@@ -283,7 +283,8 @@ struct odinn_batch {
   // VelocityRegularization: MultiLoss weight (0: off), distance to the margin, per-stop weights, mask scratch, node weights
   double vreg_weight = 0.0;
   int vreg_dist = 3;
-  double *d_wR = nullptr, *d_wRq = nullptr;
+  double *d_wR = nullptr, *d_wRq = nullptr, *d_swq = nullptr;
+  int* d_sgq = nullptr;
   size_t wRq_cap = 0;
   unsigned char* d_vrm = nullptr;
   bool vreg_on() const {
@@ -320,11 +321,26 @@ struct odinn_batch {
   size_t sorttmp_bytes = 0, knotG_cap = 0;
   double *d_part_theta = nullptr, *d_gscratch = nullptr, *d_dth = nullptr;
   size_t part_theta_cap = 0, gscratch_cap = 0, dth_cap = 0;
-  // solve bookkeeping
-  std::vector<double> tstops;
-  std::vector<int> mb_flag, mb_slot;
+  // solve bookkeeping.  Stop tables are PER GLACIER, as the reference builds them (gradient.jl:96-107,
+  // inversion_utils.jl:487-495): ts_g[g] = the result stops of glacier g (own_stops[g] if odinn_set_glacier_stops gave any,
+  // the tstops of the call otherwise); row m of every [kmax][G] table refers to glacier g's OWN m-th result stop, and a
+  // glacier with fewer than kmax stops is idle in the rows it does not have.  The integrator's table (it_*) also holds the
+  // mass-balance times that are not result stops (PeriodicCallback of :498-517: the integrator lands there, the state is
+  // not part of the result); their post-MB states go to hidden snapshot slots behind the kmax result slots.
+  std::vector<double> tstops;                   // the tstops of the last call (common table)
+  std::vector<std::vector<double>> own_stops;   // [G] per-glacier override
+  std::vector<std::vector<double>> ts_g;        // [G] result stops in effect
+  int kmax = 0, imax = 0, nhid = 0, nmb_slots = 0;
+  long long stops_version = 0;
+  std::vector<int> mbf_res, mbs_res;            // [kmax][G]: mass balance applied at result stop m / its pre-MB slot
+  std::vector<double> it_t;                     // [imax][G] integrator stops (padded with the last one)
+  std::vector<int> it_mbf, it_mbs, it_snap, it_n;  // [imax][G] mb flag, pre-MB slot, snapshot slot; [G] number of stops
+  bool ragged = false;                          // some glacier has a table of its own or a hidden stop
+  int K() const { return kmax; }
+  int nres(int g) const { return (int)ts_g[g].size(); }
   double* d_tstops = nullptr;
   int *d_mb_flag = nullptr, *d_mb_slot = nullptr, *d_nactive = nullptr;
+  int *d_snapslot = nullptr, *d_nst = nullptr, *d_mbf_res = nullptr, *d_mbs_res = nullptr;
   double* d_dt0 = nullptr;
   double *d_dts = nullptr, *d_ws = nullptr, *d_lossacc = nullptr, *d_Gsum = nullptr;
   int* d_refslot = nullptr;
@@ -341,13 +357,14 @@ struct odinn_batch {
   size_t reg_cap = 0, regp_cap = 0;
   // reverse (continuous-adjoint) solve tables
   double *d_rtau = nullptr, *d_rqw = nullptr, *d_tsnap = nullptr, *d_qw = nullptr;
-  int *d_rsnap = nullptr, *d_rmbf = nullptr, *d_rmbs = nullptr;
+  int *d_rsnap = nullptr, *d_rmbf = nullptr, *d_rmbs = nullptr, *d_nr = nullptr, *d_ksn = nullptr, *d_lastseg = nullptr;
+  double* d_zerow = nullptr;
   AdjState* d_adj = nullptr;
   int rev_cap = 0, tsnap_cap = 0;
   // key of the loss tables currently on the device (upload_loss_tables)
   const double* tab_key_ptr = nullptr;
   long long tab_key_ver = -1, refs_version = 0;
-  std::vector<double> tab_key_tstops;
+  std::vector<std::vector<double>> tab_key_stops;
   bool solved = false;
   bool gd_dirty = true;
   std::vector<double> last_loss_g, last_G_g;
@@ -696,19 +713,105 @@ static int sc_buffers(odinn_batch* b) {
 
 int ensure_tables(odinn_batch* b, int n_stops) {
   if (n_stops > b->tab_cap) {
-    dfree(b->d_tstops); dfree(b->d_mb_flag); dfree(b->d_mb_slot);
+    dfree(b->d_tstops); dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_snapslot); dfree(b->d_mbf_res); dfree(b->d_mbs_res);
     dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot); dfree(b->d_wv); dfree(b->d_vsc); dfree(b->d_vslot);
     CHK(dalloc(&b->d_wv, (size_t)n_stops * b->G));
     CHK(dalloc(&b->d_vsc, (size_t)n_stops * b->G));
     CHK(dalloc(&b->d_vslot, (size_t)n_stops * b->G));
-    CHK(dalloc(&b->d_tstops, n_stops));
-    CHK(dalloc(&b->d_mb_flag, n_stops));
-    CHK(dalloc(&b->d_mb_slot, n_stops));
+    CHK(dalloc(&b->d_tstops, (size_t)n_stops * b->G));
+    CHK(dalloc(&b->d_mb_flag, (size_t)n_stops * b->G));
+    CHK(dalloc(&b->d_mb_slot, (size_t)n_stops * b->G));
+    CHK(dalloc(&b->d_snapslot, (size_t)n_stops * b->G));
+    CHK(dalloc(&b->d_mbf_res, (size_t)n_stops * b->G));
+    CHK(dalloc(&b->d_mbs_res, (size_t)n_stops * b->G));
+    if (!b->d_nst) CHK(dalloc(&b->d_nst, (size_t)b->G));
     CHK(dalloc(&b->d_dts, (size_t)n_stops * b->G));
     CHK(dalloc(&b->d_ws, (size_t)n_stops * b->G));
     CHK(dalloc(&b->d_refslot, (size_t)n_stops * b->G));
     b->tab_cap = n_stops;
   }
+  return ODINN_OK;
+}
+
+// Per-glacier stop tables of a solve (see odinn_batch::ts_g).  tstops: the table of the call (every glacier without a table
+// of its own); mb_times: the mass-balance times (PeriodicCallback(step_MB), inversion_utils.jl:498-517), in (t0, t1]; they need
+// not be result stops.  Fills the host tables and uploads the integrator's.
+int build_stop_tables(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times) {
+  const int G = b->G;
+  const double t0 = tstops[0], t1 = tstops[n_stops - 1];
+  b->tstops.assign(tstops, tstops + n_stops);
+  b->own_stops.resize(G);
+  b->ts_g.assign(G, std::vector<double>());
+  b->ragged = false;
+  int kmax = 0;
+  for (int g = 0; g < G; ++g) {
+    const std::vector<double>& o = b->own_stops[g];
+    if (o.empty()) {
+      b->ts_g[g] = b->tstops;
+    } else {
+      if (o.front() != t0 || o.back() != t1)
+        return fail(ODINN_ERR_ARG, "the stops of glacier %d span [%.12g, %.12g], the call's tstops [%.12g, %.12g]: every glacier "
+                                   "covers the same tspan", g, o.front(), o.back(), t0, t1);
+      b->ts_g[g] = o;
+      if (o != b->tstops) b->ragged = true;
+    }
+    kmax = std::max(kmax, (int)b->ts_g[g].size());
+  }
+  std::vector<double> mbt;
+  if (b->any_mb)
+    for (int m = 0; m < n_mb; ++m) {
+      if (!(mb_times[m] > t0) || mb_times[m] > t1)
+        return fail(ODINN_ERR_ARG, "mb_times[%d]=%g is not inside (tstops[0], tstops[end]]", m, mb_times[m]);
+      if (m > 0 && !(mb_times[m] > mb_times[m - 1])) return fail(ODINN_ERR_ARG, "mb_times must be strictly increasing");
+      mbt.push_back(mb_times[m]);
+    }
+  struct It { double t; int res, mb, mbs, snap; };
+  std::vector<std::vector<It>> its(G);
+  int imax = 0, nhid = 0, nmbs = 0;
+  for (int g = 0; g < G; ++g) {
+    const std::vector<double>& r = b->ts_g[g];
+    const bool mbg = b->gd[g].has_mb != 0;
+    size_t a = 0, c = 0;
+    int hid = 0, nm = 0;
+    while (a < r.size() || (mbg && c < mbt.size())) {
+      const bool has_r = a < r.size(), has_m = mbg && c < mbt.size();
+      It e{0.0, -1, 0, 0, 0};
+      if (has_r && (!has_m || r[a] <= mbt[c])) {
+        e.t = r[a]; e.res = (int)a;
+        if (has_m && mbt[c] == r[a]) { e.mb = 1; ++c; }
+        ++a;
+      } else {
+        e.t = mbt[c]; e.mb = 1; ++c;
+      }
+      if (e.mb) e.mbs = nm++;
+      e.snap = e.res >= 0 ? e.res : kmax + hid++;
+      its[g].push_back(e);
+    }
+    if (hid) b->ragged = true;
+    imax = std::max(imax, (int)its[g].size()); nhid = std::max(nhid, hid); nmbs = std::max(nmbs, nm);
+  }
+  b->kmax = kmax; b->imax = imax; b->nhid = nhid; b->nmb_slots = nmbs;
+  b->stops_version++;
+  CHK(ensure_tables(b, std::max(imax, kmax)));
+  const size_t ni = (size_t)imax * G, nk = (size_t)kmax * G;
+  b->it_t.assign(ni, t1); b->it_mbf.assign(ni, 0); b->it_mbs.assign(ni, 0); b->it_snap.assign(ni, 0); b->it_n.assign(G, 0);
+  b->mbf_res.assign(nk, 0); b->mbs_res.assign(nk, 0);
+  for (int g = 0; g < G; ++g) {
+    b->it_n[g] = (int)its[g].size();
+    for (size_t i = 0; i < its[g].size(); ++i) {
+      const It& e = its[g][i];
+      const size_t q = i * G + g;
+      b->it_t[q] = e.t; b->it_mbf[q] = e.mb; b->it_mbs[q] = e.mbs; b->it_snap[q] = e.snap;
+      if (e.res >= 0 && e.mb) { b->mbf_res[(size_t)e.res * G + g] = 1; b->mbs_res[(size_t)e.res * G + g] = e.mbs; }
+    }
+  }
+  HIPCHK(hipMemcpyAsync(b->d_tstops, b->it_t.data(), ni * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_mb_flag, b->it_mbf.data(), ni * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_mb_slot, b->it_mbs.data(), ni * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_snapslot, b->it_snap.data(), ni * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_nst, b->it_n.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_mbf_res, b->mbf_res.data(), nk * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_mbs_res, b->mbs_res.data(), nk * sizeof(int), hipMemcpyHostToDevice, b->stream));
   return ODINN_OK;
 }
 
@@ -718,9 +821,9 @@ int ensure_tables(odinn_batch* b, int n_stops) {
 int upload_loss_tables(odinn_batch* b) {
   // unchanged stops / reference data / loss selection since the last upload (every iteration of an
   // inversion): the tables on the device are still valid -- saves six small copies and a sync per solve
-  if (b->tab_key_ptr == b->d_ws && b->d_ws && b->tab_key_ver == b->refs_version && b->tab_key_tstops == b->tstops)
+  if (b->tab_key_ptr == b->d_ws && b->d_ws && b->tab_key_ver == b->refs_version && b->tab_key_stops == b->ts_g)
     return ODINN_OK;
-  const int k = (int)b->tstops.size();
+  const int k = b->K();
   const size_t n = (size_t)k * b->G;
   std::vector<double> dts(n, 0.0), ws(n, 0.0);
   std::vector<int> slot(n, 0);
@@ -729,11 +832,13 @@ int upload_loss_tables(odinn_batch* b) {
   for (int j = 0; j < k; ++j)
     for (int g = 0; g < b->G; ++g) {
       const size_t q = (size_t)j * b->G + g;
-      dts[q] = j > 0 ? b->tstops[j] - b->tstops[j - 1] : 0.0;
+      const std::vector<double>& tsg = b->ts_g[g];
+      if (j >= (int)tsg.size()) continue;  // the glacier has no stop j: dt = 0 marks the row as idle for the reverse kernels
+      dts[q] = j > 0 ? tsg[j] - tsg[j - 1] : 0.0;
       if (useH) {
         const std::vector<double>& tr = b->t_ref[g];
         for (size_t m = 0; m < tr.size(); ++m)
-          if (tr[m] == b->tstops[j]) {
+          if (tr[m] == tsg[j]) {
             slot[q] = (int)m;
             const double d = m >= 1 ? tr[m] - tr[m - 1] : 0.0;
             ws[q] = b->loss_kind == ODINN_LOSS_HV ? d * d : d;
@@ -743,7 +848,7 @@ int upload_loss_tables(odinn_batch* b) {
       if (useV) {
         const std::vector<double>& tv = b->t_vref[g];
         for (size_t m = 0; m < tv.size(); ++m)
-          if (tv[m] == b->tstops[j]) {
+          if (tv[m] == tsg[j]) {
             b->vslot_h[q] = (int)m;
             const double d = m >= 1 ? tv[m] - tv[m - 1] : 0.0;
             b->wv_h[q] = b->loss_kind == ODINN_LOSS_HV ? b->hv_scaling * d * d : d;
@@ -759,7 +864,7 @@ int upload_loss_tables(odinn_batch* b) {
   HIPCHK(hipMemcpyAsync(b->d_vsc, b->vsc_h.data(), n * sizeof(double), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_vslot, b->vslot_h.data(), n * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
-  b->tab_key_ptr = b->d_ws; b->tab_key_ver = b->refs_version; b->tab_key_tstops = b->tstops;
+  b->tab_key_ptr = b->d_ws; b->tab_key_ver = b->refs_version; b->tab_key_stops = b->ts_g;
   return ODINN_OK;
 }
 
@@ -819,32 +924,23 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   if (euler && !(opt.cfl > 0.0)) opt.cfl = 0.25;
   if (euler && opt.cfl > 1.0) return fail(ODINN_ERR_ARG, "cfl must be in (0, 1]");
   const bool adaptive = !(opt.fixed_dt > 0.0) && !euler;
-  // stop tables
-  b->tstops.assign(tstops, tstops + n_stops);
-  b->mb_flag.assign(n_stops, 0);
-  b->mb_slot.assign(n_stops, 0);
-  int nmb = 0;
-  if (b->any_mb)
-    for (int m = 0; m < n_mb; ++m) {
-      bool found = false;
-      for (int j = 1; j < n_stops; ++j)
-        if (tstops[j] == mb_times[m]) { b->mb_flag[j] = 1; b->mb_slot[j] = nmb++; found = true; break; }
-      if (!found) return fail(ODINN_ERR_ARG, "mb_times[%d]=%g is not one of tstops[1:]", m, mb_times[m]);
-    }
-  CHK(ensure_tables(b, n_stops));
-  if (n_stops > b->nstops_alloc) {
+  // stop tables (per glacier)
+  CHK(build_stop_tables(b, n_stops, tstops, n_mb, mb_times));
+  const int nslots = b->kmax + b->nhid, nmb = b->nmb_slots;
+  if (nslots > b->nstops_alloc) {
     dfree(b->d_snaps);
-    CHK(dalloc(&b->d_snaps, (size_t)n_stops * b->ntot));
-    b->nstops_alloc = n_stops;
+    CHK(dalloc(&b->d_snaps, (size_t)nslots * b->ntot));
+    // (rows a glacier does not own are never written by the solve: keep them finite for the kernels that read them under a
+    //  zero weight)
+    HIPCHK(hipMemsetAsync(b->d_snaps, 0, (size_t)nslots * b->ntot * sizeof(double), b->stream));
+    b->nstops_alloc = nslots;
   }
   if (nmb > b->nmb_alloc) {
     dfree(b->d_premb);
     CHK(dalloc(&b->d_premb, (size_t)nmb * b->ntot));
+    HIPCHK(hipMemsetAsync(b->d_premb, 0, (size_t)nmb * b->ntot * sizeof(double), b->stream));
     b->nmb_alloc = nmb;
   }
-  HIPCHK(hipMemcpyAsync(b->d_tstops, tstops, n_stops * sizeof(double), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_mb_flag, b->mb_flag.data(), n_stops * sizeof(int), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_mb_slot, b->mb_slot.data(), n_stops * sizeof(int), hipMemcpyHostToDevice, b->stream));
   CHK(upload_loss_tables(b));
   if (prof) { HIPCHK(hipStreamSynchronize(b->stream)); tp1 = now(); }
   // initial state and first snapshot
@@ -873,7 +969,8 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
 
   const int scheme = euler ? 3 : pick_scheme(b, opt.scheme);
   CtrlArgs C{};
-  C.tstops = b->d_tstops; C.n_stops = n_stops; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
+  C.tstops = b->d_tstops; C.nstops = b->d_nst; C.G = b->G; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
+  C.snap_slot = b->d_snapslot;
   C.dtmax = opt.dtmax; C.adaptive = adaptive ? 1 : 0; C.fixed_dt = opt.fixed_dt; C.n_active = b->d_nactive;
   C.errpart = scheme == 2 ? b->fused_part() : b->d_part;
   C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? b->fused_ctrl() : 0;
@@ -899,7 +996,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
   if (b->any_mb) { SL.premb = b->d_premb; SL.mb0 = b->d_mb0; SL.Sref = b->any_sref ? b->d_Sref : nullptr; }
   long long steps = 0;
   int p = 0;
-  int chunk = std::max(2, std::min(256, (n_stops - 1 + 1) & ~1));
+  int chunk = std::max(2, std::min(256, (b->imax - 1 + 1) & ~1));
   int polls = 0;
   if (!euler) {
     if (!b->d_est) CHK(dalloc(&b->d_est, (size_t)b->G));
@@ -986,14 +1083,14 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
 // loss term (added onto d_lossacc[g]) and the coefficient of its cotangent fields (d_dh_coef[g])
 int dhdt_forward(odinn_batch* b) {
   if (!b->dhdt_on()) return ODINN_OK;
-  const int k = (int)b->tstops.size();
   b->dh_i0_h.assign(b->G, -1); b->dh_i1_h.assign(b->G, -1);
   std::vector<double> dts(b->G, 1.0);
   for (int g = 0; g < b->G; ++g) {
     if (!(b->dh_t1[g] > b->dh_t0[g])) continue;
-    for (int j = 0; j < k; ++j) {
-      if (b->tstops[j] == b->dh_t0[g]) b->dh_i0_h[g] = j;
-      if (b->tstops[j] == b->dh_t1[g]) b->dh_i1_h[g] = j;
+    const std::vector<double>& tsg = b->ts_g[g];
+    for (int j = 0; j < (int)tsg.size(); ++j) {
+      if (tsg[j] == b->dh_t0[g]) b->dh_i0_h[g] = j;
+      if (tsg[j] == b->dh_t1[g]) b->dh_i1_h[g] = j;
     }
     if (b->dh_i0_h[g] < 0 || b->dh_i1_h[g] < 0)
       return fail(ODINN_ERR_ARG, "dhdtData times (%g, %g) of glacier %d are not among the tstops", b->dh_t0[g], b->dh_t1[g], g);
@@ -1019,7 +1116,7 @@ int dhdt_forward(odinn_batch* b) {
 // their dL/dtheta goes into d_Gsum / d_Gacc, which the reverse loops go on accumulating into.  agg_tables builds the
 // per-stop per-glacier weight tables of both terms, assigns the slots and clears the fields.
 int agg_tables(odinn_batch* b, bool with_grad) {
-  const int k = (int)b->tstops.size(), G = b->G;
+  const int k = b->K(), G = b->G;
   b->agg_slot_h.assign(k, -1);
   b->agg_nslots = 0;
   const bool av = b->avgv_on(), vr = b->vreg_on();
@@ -1039,8 +1136,8 @@ int agg_tables(odinn_batch* b, bool with_grad) {
       for (int i = 0; i < n; ++i) {
         const double x = t1 + i * st;
         int jj = -1;
-        for (int j = 0; j < k; ++j)
-          if (std::fabs(b->tstops[j] - x) <= 1e-9) { jj = j; break; }
+        for (int j = 0; j < b->nres(g); ++j)
+          if (std::fabs(b->ts_g[g][j] - x) <= 1e-9) { jj = j; break; }
         if (jj < 0) return fail(ODINN_ERR_ARG, "LossAvgV: time %.10g of glacier %d is not among the tstops", x, g);
         b->wA_h[(size_t)jj * G + g] = ((t1 + (i + 1) * st) - x) / T;
       }
@@ -1049,9 +1146,9 @@ int agg_tables(odinn_batch* b, bool with_grad) {
   if (vr)
     for (int g = 0; g < G; ++g) {  // VelocityRegularization: Delta-t.V of the velocity-data times (gradient.jl:144-163)
       const std::vector<double>& tv = b->t_vref[g];
-      for (int j = 0; j < k; ++j)
+      for (int j = 0; j < b->nres(g); ++j)
         for (size_t m = 1; m < tv.size(); ++m)
-          if (tv[m] == b->tstops[j]) b->wR_h[(size_t)j * G + g] = b->vreg_weight * (tv[m] - tv[m - 1]);
+          if (tv[m] == b->ts_g[g][j]) b->wR_h[(size_t)j * G + g] = b->vreg_weight * (tv[m] - tv[m - 1]);
     }
   for (int j = 0; j < k; ++j) {
     bool any = false;
@@ -1090,7 +1187,7 @@ int agg_tables(odinn_batch* b, bool with_grad) {
 // onto d_lossacc[g]) and, with_grad, the pull-back of dt_i / T dl/dV through surface_V at every stop of the grid
 int avgv_forward(odinn_batch* b, bool with_grad) {
   if (!b->avgv_on()) return ODINN_OK;
-  const int k = (int)b->tstops.size(), G = b->G;
+  const int k = b->K(), G = b->G;
   auto stop_on = [&](int j) {
     for (int g = 0; g < G; ++g) if (b->wA_h[(size_t)j * G + g] != 0.0) return true;
     return false;
@@ -1150,7 +1247,7 @@ static int vreg_at(odinn_batch* b, const double* H, const double* w, bool add_lo
 // the Gauss-Legendre nodes on the interpolated state with Delta-t = 1 (ContinuousAdjoint, gradient.jl:475-503)
 int vreg_forward(odinn_batch* b, bool with_grad, bool add_loss, int nq, const double* qt, const double* qw) {
   if (!b->vreg_on()) return ODINN_OK;
-  const int k = (int)b->tstops.size(), G = b->G;
+  const int k = b->K(), G = b->G;
   if (!b->d_vrm) HIPCHK(hipMalloc(&b->d_vrm, (size_t)b->ntot));
   for (int j = 0; j < k; ++j) {
     bool any = false;
@@ -1164,14 +1261,31 @@ int vreg_forward(odinn_batch* b, bool with_grad, bool add_loss, int nq, const do
     for (int g = 0; g < G; ++g)
       if (b->t_vref[g].size() >= 2)
         for (int n = 0; n < nq; ++n) wq[(size_t)n * G + g] = b->vreg_weight * qw[n];
-    if (wq.size() > b->wRq_cap) { dfree(b->d_wRq); CHK(dalloc(&b->d_wRq, wq.size())); b->wRq_cap = wq.size(); }
+    // segment and weight of every node in every glacier's own snapshots, interpolate((t,), H, Gridded(Linear())) (gradient.jl:287)
+    std::vector<int> sg((size_t)nq * G, -1);
+    std::vector<double> sw((size_t)nq * G, 0.0);
+    for (int g = 0; g < G; ++g) {
+      if (b->t_vref[g].size() < 2) continue;
+      const std::vector<double>& tsg = b->ts_g[g];
+      const int kg = (int)tsg.size();
+      for (int n = 0; n < nq; ++n) {
+        int j = 0;
+        while (j + 2 < kg && qt[n] >= tsg[j + 1]) ++j;
+        sg[(size_t)n * G + g] = j;
+        sw[(size_t)n * G + g] = (qt[n] - tsg[j]) / (tsg[j + 1] - tsg[j]);
+      }
+    }
+    if (wq.size() > b->wRq_cap) {
+      dfree(b->d_wRq); dfree(b->d_swq); dfree(b->d_sgq);
+      CHK(dalloc(&b->d_wRq, wq.size())); CHK(dalloc(&b->d_swq, wq.size())); CHK(dalloc(&b->d_sgq, wq.size()));
+      b->wRq_cap = wq.size();
+    }
     HIPCHK(hipMemcpyAsync(b->d_wRq, wq.data(), sizeof(double) * wq.size(), hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));  // wq is a temporary
+    HIPCHK(hipMemcpyAsync(b->d_swq, sw.data(), sizeof(double) * sw.size(), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_sgq, sg.data(), sizeof(int) * sg.size(), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));  // the staging vectors are temporaries
     for (int n = 0; n < nq; ++n) {
-      int j = 0;  // segment of the node, interpolate((t,), H, Gridded(Linear())) (gradient.jl:287)
-      while (j + 2 < k && qt[n] >= b->tstops[j + 1]) ++j;
-      const double s_ = (qt[n] - b->tstops[j]) / (b->tstops[j + 1] - b->tstops[j]);
-      launch_lerp(b->ntot, b->stream, s_, b->d_snaps + (size_t)j * b->ntot, b->d_snaps + (size_t)(j + 1) * b->ntot, b->d_tmpA);
+      launch_lerp_g(b->ntiles, b->stream, b->pools(true), b->d_snaps, b->ntot, b->d_sgq + (size_t)n * G, b->d_swq + (size_t)n * G, b->d_tmpA);
       CHK(vreg_at(b, b->d_tmpA, b->d_wRq + (size_t)n * G, false, nullptr, true));
     }
   }
@@ -1180,7 +1294,7 @@ int vreg_forward(odinn_batch* b, bool with_grad, bool add_loss, int nq, const do
 
 // forward loss over the stored snapshots -> d_lossacc[g]; *const_loss: data-only part of LossV
 int do_loss(odinn_batch* b, double* const_loss) {
-  const int k = (int)b->tstops.size();
+  const int k = b->K();
   *const_loss = 0.0;
   HIPCHK(hipMemsetAsync(b->d_lossacc, 0, sizeof(double) * b->G, b->stream));
   const Pools P = b->pools(true);
@@ -1401,6 +1515,8 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_rega); dfree(b->d_regr); dfree(b->d_regg); dfree(b->d_regp); dfree(b->d_regm);
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
+  dfree(b->d_snapslot); dfree(b->d_nst); dfree(b->d_mbf_res); dfree(b->d_mbs_res); dfree(b->d_nr); dfree(b->d_ksn); dfree(b->d_lastseg);
+  dfree(b->d_zerow); dfree(b->d_swq); dfree(b->d_sgq);
   dfree(b->d_aVabs); dfree(b->d_aVx); dfree(b->d_aVy); dfree(b->d_avg); dfree(b->d_wA); dfree(b->d_aggH);
   if (b->d_agg_slot) (void)hipFree(b->d_agg_slot);
   if (b->d_av_on) (void)hipFree(b->d_av_on);
@@ -2084,17 +2200,30 @@ int odinn_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, con
   return do_solve(b, n_stops, tstops, n_mb, mb_times, opts, stats);
 }
 
+int odinn_set_glacier_stops(odinn_batch* b, int g, int n, const double* t) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
+  CHK(check_g(b, g));
+  if (n != 0 && (n < 2 || !t)) return fail(ODINN_ERR_ARG, "a glacier needs at least 2 stops (n = 0 clears its table)");
+  for (int j = 1; j < n; ++j)
+    if (!(t[j] > t[j - 1])) return fail(ODINN_ERR_ARG, "the stops of glacier %d must be strictly increasing", g);
+  b->own_stops.resize(b->G);
+  b->own_stops[g].assign(t, t + n);
+  return ODINN_OK;
+}
+
 int odinn_get_snapshot(odinn_batch* b, int g, int istop, double* H_out) {
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!b->solved) return fail(ODINN_ERR_STATE, "no solve has been run");
-  if (istop < 0 || istop >= (int)b->tstops.size()) return fail(ODINN_ERR_ARG, "istop out of range");
+  if (!b->solved || g >= (int)b->ts_g.size()) return fail(ODINN_ERR_STATE, "no solve has been run");
+  // (istop counts the glacier's OWN result stops: the table of odinn_set_glacier_stops, or the tstops of the solve)
+  if (istop < 0 || istop >= b->nres(g)) return fail(ODINN_ERR_ARG, "istop out of range");
   return down_field(b, g, b->d_snaps + (size_t)istop * b->ntot, H_out);
 }
 
 int odinn_get_H(odinn_batch* b, int g, double* H_out) {
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!b->solved) return down_field(b, g, b->d_H0, H_out);
-  return down_field(b, g, b->d_snaps + (size_t)(b->tstops.size() - 1) * b->ntot, H_out);
+  return down_field(b, g, b->d_snaps + (size_t)(b->nres(g) - 1) * b->ntot, H_out);
 }
 
 int odinn_loss(odinn_batch* b, double* loss_per_glacier) {
@@ -2107,7 +2236,7 @@ int odinn_loss(odinn_batch* b, double* loss_per_glacier) {
   HIPCHK(hipMemcpyAsync(loss_per_glacier, b->d_lossacc, sizeof(double) * b->G, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   // data-only part of LossV (cells of the last row / column, where V_pred is 0 by construction)
-  const int k = (int)b->tstops.size();
+  const int k = b->K();
   for (int j = 1; j < k; ++j)
     for (int g = 0; g < b->G; ++g) {
       const size_t q = (size_t)j * b->G + g;
@@ -2151,7 +2280,12 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
   if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
   CHK(grad_prepare(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, stats));
   // ---- reverse loop: gradient.jl:191-253 -------------------------------------------------
-  const int k = n_stops;
+  // Row j of the per-glacier tables = the glacier's own j-th stop (t = result.t of THAT glacier, gradient.jl:71-73): a
+  // glacier with fewer stops than the longest table is idle (dt = 0: lambda = 0 passes through) until its last stop comes up.
+  if (b->nhid > 0)
+    return fail(ODINN_ERR_ARG, "When using the DiscreteAdjoint the tstops of the MB callback must all be included in the "
+                               "tstops from the results (gradient.jl:131)");
+  const int k = b->K();
   const size_t fb = (size_t)b->ntot * sizeof(double);
   const Pools Psw = b->pools(true);
   const LawDev L = b->lawdev();
@@ -2170,9 +2304,12 @@ int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, con
     double* lam = b->d_lam[cur];
     double* lam_new = b->d_lam[1 - cur];
     const double* Hj = b->d_snaps + (size_t)j * b->ntot;
-    if (b->any_mb && b->mb_flag[j]) {  // :201-207
-      launch_mb_vjp(b->ntiles, b->stream, Psw, b->d_premb + (size_t)b->mb_slot[j] * b->ntot, b->d_mb0,
-                    b->any_sref ? b->d_Sref : nullptr, lam, lam, 1, 0);
+    if (b->any_mb) {  // :201-207
+      bool any = false;
+      for (int g = 0; g < b->G; ++g) any = any || b->mbf_res[(size_t)j * b->G + g] != 0;
+      if (any)
+        launch_mb_vjp(b->ntiles, b->stream, Psw, b->d_premb, b->d_mb0, b->any_sref ? b->d_Sref : nullptr, lam, lam, 1, 0,
+                      b->d_mbf_res + (size_t)j * b->G, b->d_mbs_res + (size_t)j * b->G, b->ntot);
     }
     AdjArgs A{};
     A.H = Hj; A.lam = lam; A.out = lam_new; A.Href = b->d_Href; A.mask = b->d_mask; A.h_log_eps = b->h_log_eps;
@@ -2297,46 +2434,69 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   CHK(grad_prepare(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, stats, ao.n_quadrature));
   double const_loss = 0.0;
   CHK(do_loss(b, &const_loss));  // forward loss over the snapshots -> d_lossacc
-  const int k = n_stops, G = b->G;
-  const double t0 = tstops[0], t1 = tstops[k - 1];
-  // ---- reverse stop table: tau = -t ascending over snapshots and quadrature nodes (:457) ----
+  const int k = b->K(), G = b->G;
+  const double t0 = tstops[0], t1 = tstops[n_stops - 1];
+  if (b->nhid > 0)
+    return fail(ODINN_ERR_UNSUPPORTED, "continuous adjoint: mass-balance times that are not result stops are not supported "
+                                       "(the forward solve handles them; make step_MB a multiple of the solver step here)");
+  // ---- reverse stop tables, per glacier: tau = -t ascending over the glacier's own snapshots and the quadrature nodes (:457) ----
   std::vector<double> gx, gw;
   gauss_legendre(ao.n_quadrature, gx, gw);
-  if (b->vreg_on()) {  // VelocityRegularization: dL/dH at its stops, dL/dtheta by the quadrature (its loss is in do_loss)
-    std::vector<double> qt(ao.n_quadrature), qwt(ao.n_quadrature);
-    for (int i = 0; i < ao.n_quadrature; ++i) { qt[i] = (t0 + t1) / 2.0 + gx[i] * (t1 - t0) / 2.0; qwt[i] = (t1 - t0) / 2.0 * gw[i]; }
+  std::vector<double> qt(ao.n_quadrature), qwt(ao.n_quadrature);
+  for (int i = 0; i < ao.n_quadrature; ++i) {  // GaussQuadrature, :560-566
+    qt[i] = (t0 + t1) / 2.0 + gx[i] * (t1 - t0) / 2.0;
+    qwt[i] = (t1 - t0) / 2.0 * gw[i];
+  }
+  if (b->vreg_on())  // VelocityRegularization: dL/dH at its stops, dL/dtheta by the quadrature (its loss is in do_loss)
     CHK(vreg_forward(b, true, false, ao.n_quadrature, qt.data(), qwt.data()));
-  }
   struct Stop { double tau; int snap; double qw; };
-  std::vector<Stop> st;
-  st.reserve(k + ao.n_quadrature);
-  for (int j = 0; j < k; ++j) st.push_back({-tstops[j], j, 0.0});
-  for (int i = 0; i < ao.n_quadrature; ++i)  // GaussQuadrature, :560-566
-    st.push_back({-((t0 + t1) / 2.0 + gx[i] * (t1 - t0) / 2.0), -1, (t1 - t0) / 2.0 * gw[i]});
-  std::stable_sort(st.begin(), st.end(), [](const Stop& a, const Stop& c) { return a.tau < c.tau; });
-  for (size_t i = 1; i < st.size(); ++i)
-    if (!(st[i].tau > st[i - 1].tau)) return fail(ODINN_ERR_ARG, "a quadrature node coincides with a snapshot time");
-  const int nr = (int)st.size();
-  std::vector<double> h_tau(nr), h_qw(nr);
-  std::vector<int> h_snap(nr), h_mbf(nr, 0), h_mbs(nr, 0);
-  for (int i = 0; i < nr; ++i) {
-    h_tau[i] = st[i].tau; h_qw[i] = st[i].qw; h_snap[i] = st[i].snap;
-    if (st[i].snap >= 1 && b->any_mb && b->mb_flag[st[i].snap]) { h_mbf[i] = 1; h_mbs[i] = b->mb_slot[st[i].snap]; }
+  std::vector<std::vector<Stop>> stg(G);
+  int nr = 0;
+  for (int g = 0; g < G; ++g) {
+    std::vector<Stop>& st = stg[g];
+    const std::vector<double>& tsg = b->ts_g[g];
+    st.reserve(tsg.size() + ao.n_quadrature);
+    for (int j = 0; j < (int)tsg.size(); ++j) st.push_back({-tsg[j], j, 0.0});
+    for (int i = 0; i < ao.n_quadrature; ++i) st.push_back({-qt[i], -1, qwt[i]});
+    std::stable_sort(st.begin(), st.end(), [](const Stop& a, const Stop& c) { return a.tau < c.tau; });
+    for (size_t i = 1; i < st.size(); ++i)
+      if (!(st[i].tau > st[i - 1].tau)) return fail(ODINN_ERR_ARG, "a quadrature node coincides with a snapshot time");
+    nr = std::max(nr, (int)st.size());
   }
-  if (nr > b->rev_cap) {
+  const size_t nrG = (size_t)nr * G;
+  std::vector<double> h_tau(nrG, -t0), h_qw(nrG, 0.0), h_tsnap((size_t)k * G, t1);
+  std::vector<int> h_snap(nrG, -1), h_mbf(nrG, 0), h_mbs(nrG, 0), h_nr(G), h_ksn(G);
+  for (int g = 0; g < G; ++g) {
+    const std::vector<Stop>& st = stg[g];
+    h_nr[g] = (int)st.size(); h_ksn[g] = b->nres(g);
+    for (int j = 0; j < b->nres(g); ++j) h_tsnap[(size_t)j * G + g] = b->ts_g[g][j];
+    for (int i = 0; i < (int)st.size(); ++i) {
+      const size_t q = (size_t)i * G + g;
+      h_tau[q] = st[i].tau; h_qw[q] = st[i].qw; h_snap[q] = st[i].snap;
+      if (st[i].snap >= 1 && b->any_mb && b->mbf_res[(size_t)st[i].snap * G + g]) { h_mbf[q] = 1; h_mbs[q] = b->mbs_res[(size_t)st[i].snap * G + g]; }
+    }
+  }
+  if ((int)nrG > b->rev_cap) {
     dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_rsnap); dfree(b->d_rmbf); dfree(b->d_rmbs);
-    CHK(dalloc(&b->d_rtau, nr)); CHK(dalloc(&b->d_rqw, nr)); CHK(dalloc(&b->d_rsnap, nr));
-    CHK(dalloc(&b->d_rmbf, nr)); CHK(dalloc(&b->d_rmbs, nr));
-    b->rev_cap = nr;
+    CHK(dalloc(&b->d_rtau, nrG)); CHK(dalloc(&b->d_rqw, nrG)); CHK(dalloc(&b->d_rsnap, nrG));
+    CHK(dalloc(&b->d_rmbf, nrG)); CHK(dalloc(&b->d_rmbs, nrG));
+    b->rev_cap = (int)nrG;
   }
-  if (k > b->tsnap_cap) { dfree(b->d_tsnap); CHK(dalloc(&b->d_tsnap, k)); b->tsnap_cap = k; }
+  if (k * G > b->tsnap_cap) { dfree(b->d_tsnap); CHK(dalloc(&b->d_tsnap, (size_t)k * G)); b->tsnap_cap = k * G; }
   if (!b->d_adj) { CHK(dalloc(&b->d_adj, G)); CHK(dalloc(&b->d_qw, G)); }
-  HIPCHK(hipMemcpyAsync(b->d_rtau, h_tau.data(), nr * sizeof(double), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_rqw, h_qw.data(), nr * sizeof(double), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_rsnap, h_snap.data(), nr * sizeof(int), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_rmbf, h_mbf.data(), nr * sizeof(int), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_rmbs, h_mbs.data(), nr * sizeof(int), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemcpyAsync(b->d_tsnap, tstops, k * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  if (!b->d_nr) { CHK(dalloc(&b->d_nr, (size_t)G)); CHK(dalloc(&b->d_ksn, (size_t)G)); CHK(dalloc(&b->d_lastseg, (size_t)G)); CHK(dalloc(&b->d_zerow, (size_t)G)); }
+  HIPCHK(hipMemcpyAsync(b->d_rtau, h_tau.data(), nrG * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rqw, h_qw.data(), nrG * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rsnap, h_snap.data(), nrG * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rmbf, h_mbf.data(), nrG * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rmbs, h_mbs.data(), nrG * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_tsnap, h_tsnap.data(), (size_t)k * G * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_nr, h_nr.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_ksn, h_ksn.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  std::vector<int> h_lastseg(G);
+  for (int g = 0; g < G; ++g) h_lastseg[g] = b->nres(g) - 1;
+  HIPCHK(hipMemcpyAsync(b->d_lastseg, h_lastseg.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemsetAsync(b->d_zerow, 0, (size_t)G * sizeof(double), b->stream));
   HIPCHK(hipMemsetAsync(b->d_qw, 0, sizeof(double) * G, b->stream));
   // velocity loss: per (reverse stop, glacier) the bracketing reference maps of a quadrature node
   // (interpolate((tV_ref,), V_ref, Gridded(Linear())), or the single map; gradient.jl:291-301)
@@ -2344,10 +2504,10 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   std::vector<double> h_vs;
   if (useV) {
     h_vA.assign((size_t)nr * G, -1); h_vB.assign((size_t)nr * G, 0); h_vs.assign((size_t)nr * G, 0.0);
-    for (int i = 0; i < nr; ++i) {
-      if (st[i].snap >= 0) continue;
-      const double tn = -st[i].tau;
-      for (int g = 0; g < G; ++g) {
+    for (int g = 0; g < G; ++g)
+      for (int i = 0; i < (int)stg[g].size(); ++i) {
+        if (stg[g][i].snap >= 0) continue;
+        const double tn = -stg[g][i].tau;
         const std::vector<double>& tv = b->t_vref[g];
         const size_t q = (size_t)i * G + g;
         if (tv.empty()) continue;
@@ -2360,7 +2520,6 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
         h_vA[q] = (int)m; h_vB[q] = (int)m + 1;
         h_vs[q] = (tn - tv[m]) / (tv[m + 1] - tv[m]);
       }
-    }
     const size_t n = (size_t)nr * G;
     if (n > b->rv_cap) {
       dfree(b->d_rvA); dfree(b->d_rvB); dfree(b->d_rvs);
@@ -2394,15 +2553,17 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   AP.hq_snap_only = vq_onepass ? 1 : 0;
   if (b->dhdt_on()) { AP.dh_i0 = b->d_dh_i0; AP.dh_i1 = b->d_dh_i1; AP.dh_coef = b->d_dh_coef; }
   if (b->agg_nslots > 0) { AP.agg_slot = b->d_agg_slot; AP.aggH = b->d_aggH; }
-  const bool mb_last = b->any_mb && b->mb_flag[k - 1];
-  launch_adj_begin(G, b->stream, Pl, b->d_adj, k, h_tau[0], mb_last ? 1 : 0, mb_last ? b->mb_slot[k - 1] : 0);
+  // (row 0 of the reverse tables is every glacier's last snapshot, tau_0 = -t1, with its mass-balance flag / slot)
+  launch_adj_begin(G, b->stream, Pl, b->d_adj, b->d_ksn, -t1, b->d_rmbf, b->d_rmbs);
+  // H(t1) of every glacier (its own last result slot) gathered into d_E, free until the second RHS of the initial-step heuristic
+  launch_lerp_g(b->ntiles, b->stream, Pl, b->d_snaps, b->ntot, b->d_lastseg, b->d_zerow, b->d_E);
   // loss term of a velocity-data snapshot: lam += wV dl_V/dH(H_j)  (backward_loss(::LossV), Losses.jl:338-390)
   VArgs VS{};
   if (useV) {
     VS.Vabs = b->d_Vabs; VS.Vxr = b->d_Vxr; VS.Vyr = b->d_Vyr; VS.wv = b->d_wv; VS.scale = b->d_vsc; VS.refslot = b->d_vslot;
     VS.ntot = b->ntot; VS.component_abs = b->v_abs; VS.log_eps = b->v_abs ? b->v_log_eps : 0.0; VS.Gacc = nullptr; VS.adj = b->d_adj; VS.G = G;
     VS.finv = 1.0 / b->fV;  // (U law: H-part only here, the theta-part of the loss is integrated at the quadrature nodes)
-    VS.H = b->d_snaps + (size_t)(k - 1) * b->ntot; VS.out = b->d_lam[0];
+    VS.H = b->d_E; VS.out = b->d_lam[0];
     launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VS, 0);  // at t1 the losses come before the MB VJP
     VS.H = b->d_tmpA;
   }
@@ -2430,7 +2591,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   long long nrhs_extra = 0;
   {
     AdjArgs A{};
-    A.H = b->d_snaps + (size_t)(k - 1) * b->ntot; A.lam = b->d_lam[0]; A.out = b->d_S2; A.ntot = b->ntot;
+    A.H = b->d_E; A.lam = b->d_lam[0]; A.out = b->d_S2; A.ntot = b->ntot;
     launch_vjp_H(b, 0, b->ntiles, Pl, L, A, 0);  // f0
     launch_initdt_norms(b->ntiles, b->stream, Pl, b->d_lam[0], b->d_S2, nullptr, ao.abstol, ao.reltol);
     launch_initdt_ctrl(G, b->stream, Pl, 0, tspan, ao.dtmax, b->d_dt0);
@@ -2447,7 +2608,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   int nact = G;
   HIPCHK(hipMemcpyAsync(b->d_nactive, &nact, sizeof(int), hipMemcpyHostToDevice, b->stream));
   CtrlArgs C{};
-  C.tstops = b->d_rtau; C.n_stops = nr; C.mb_flag = b->d_rmbf; C.mb_slot = b->d_rmbs; C.dtmax = ao.dtmax;
+  C.tstops = b->d_rtau; C.nstops = b->d_nr; C.G = G; C.mb_flag = b->d_rmbf; C.mb_slot = b->d_rmbs; C.dtmax = ao.dtmax;
   C.adaptive = 1; C.fixed_dt = 0.0; C.n_active = b->d_nactive; C.errpart = b->d_part; C.stride = 4; C.fused = 0;
   C.adj = b->d_adj; C.tsnap = b->d_tsnap; C.stop_snap = b->d_rsnap; C.stop_qw = b->d_rqw; C.qw_out = b->d_qw;
   AdjStageArgs SA{};
@@ -2805,11 +2966,14 @@ static int timed_prepare(odinn_batch* b) {
   HIPCHK(hipMemcpyAsync(b->d_U[0], b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_S3, b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_lam[0], b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
-  std::vector<double> ts = {0.0, 1e30};
-  CHK(ensure_tables(b, 2));
-  HIPCHK(hipMemcpyAsync(b->d_tstops, ts.data(), 2 * sizeof(double), hipMemcpyHostToDevice, b->stream));
-  HIPCHK(hipMemsetAsync(b->d_mb_flag, 0, 2 * sizeof(int), b->stream));
-  HIPCHK(hipMemsetAsync(b->d_mb_slot, 0, 2 * sizeof(int), b->stream));
+  const double ts[2] = {0.0, 1e30};
+  {
+    std::vector<std::vector<double>> keep;  // the synthetic two-stop table overrides the glaciers' own tables here
+    keep.swap(b->own_stops);
+    const int rc = build_stop_tables(b, 2, ts, 0, nullptr);
+    b->own_stops.swap(keep);
+    CHK(rc);
+  }
   // two identical forward snapshots + reverse-solve state for ODINN_TIMED_ADJ_STAGE2
   if (b->nstops_alloc < 2) {
     dfree(b->d_snaps);
@@ -2819,7 +2983,13 @@ static int timed_prepare(odinn_batch* b) {
   HIPCHK(hipMemcpyAsync(b->d_snaps, b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_snaps + b->ntot, b->d_H0, fb, hipMemcpyDeviceToDevice, b->stream));
   if (!b->d_adj) { CHK(dalloc(&b->d_adj, b->G)); CHK(dalloc(&b->d_qw, b->G)); }
-  launch_adj_begin(b->G, b->stream, P, b->d_adj, 2, 0.0, 0, 0);
+  if (!b->d_nr) { CHK(dalloc(&b->d_nr, (size_t)b->G)); CHK(dalloc(&b->d_ksn, (size_t)b->G)); CHK(dalloc(&b->d_lastseg, (size_t)b->G)); CHK(dalloc(&b->d_zerow, (size_t)b->G)); }
+  {
+    std::vector<int> two(b->G, 2);
+    HIPCHK(hipMemcpyAsync(b->d_ksn, two.data(), (size_t)b->G * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  }
+  launch_adj_begin(b->G, b->stream, P, b->d_adj, b->d_ksn, 0.0, b->d_mb_flag, b->d_mb_slot);
   if ((size_t)b->ntot > b->segs_cap) {  // the {H_j, dH} pairs of the one segment, as the reverse solve builds them
     if (b->d_segs) (void)hipFree(b->d_segs);
     b->d_segs = nullptr; b->segs_cap = 0;
@@ -2842,7 +3012,8 @@ static int timed_one(odinn_batch* b, int which, int it) {
     case ODINN_TIMED_SOLVE_STEP_STAGED: {
       const int scheme = which == ODINN_TIMED_SOLVE_STEP_STAGED ? 1 : pick_scheme(b, 0);
       CtrlArgs C{};
-      C.tstops = b->d_tstops; C.n_stops = 2; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
+      C.tstops = b->d_tstops; C.nstops = b->d_nst; C.G = b->G; C.mb_flag = b->d_mb_flag; C.mb_slot = b->d_mb_slot;
+      C.snap_slot = b->d_snapslot;
       C.dtmax = 0.0; C.adaptive = 0; C.fixed_dt = 1e-6; C.n_active = b->d_nactive;
       C.errpart = scheme == 2 ? b->fused_part() : b->d_part;
       C.stride = scheme == 2 ? 1 : 4; C.fused = scheme == 2 ? b->fused_ctrl() : 0;

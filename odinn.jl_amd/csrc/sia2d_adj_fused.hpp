@@ -493,6 +493,9 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_H_strip(Pools P, const 
   bool nz = false;
 #pragma unroll
   for (int m = 0; m < DNR; ++m) nz = nz || (hh[m] > 0.0);
+  // dt = 0: the glacier has no stop in this row of the per-glacier stop tables (see k_vjp_H) -- the ice-free branch below
+  // then passes lambda through (wl = 0 there as well) whatever the unused snapshot slot holds
+  if (MODE == 1 && dt == 0.0) nz = false;
   sE[w][0][lane] = cell_HS(hh[0], b_first);
   sE[w][1][lane] = cell_HS(hh[DNR - 1], b_last);
   sLm[w][0][lane] = lam_e(0);

@@ -137,6 +137,8 @@ struct GState {  // per-glacier integrator state (written by the controller kern
   long long naccept, nreject;
   int nonfinite;
   int pad;
+  int snap_slot;  // snapshot slot of the stop just reached (forward solve: CtrlArgs::snap_slot of that stop)
+  int pad2;
 };
 
 struct AdjState {  // per-glacier state of the reverse (continuous-adjoint) solve, written by the controller
@@ -1143,11 +1145,18 @@ __global__ __launch_bounds__(NT) void k_rk_stage(Pools P, LawDev L, const double
 // controller: one block (64 threads) per glacier.  Sums the error partials in a fixed
 // order, applies the PID controller (beta = 0.64,-0.31,0.04; limiter 1+atan(x-1);
 // accept iff factor >= 0.81), advances t / tstops, and proposes the next dt.
+// Stop tables are PER GLACIER (the reference builds tstops per glacier: gradient.jl:96-107, inversion_utils.jl:487-495):
+// entry i of glacier g lives at [i * G + g]; glacier g has nstops[g] entries (t_0 ... t_end, strictly increasing).
 struct CtrlArgs {
-  const double* tstops;
-  int n_stops;
-  const int* mb_flag;  // per stop: 1 if the mass balance is applied there
-  const int* mb_slot;  // per stop: index of the pre-MB snapshot
+  const double* tstops;   // [imax][G]
+  const int* nstops;      // [G]
+  int G;
+  const int* mb_flag;     // [imax][G]: 1 if the mass balance is applied at that stop
+  const int* mb_slot;     // [imax][G]: index of the pre-MB snapshot
+  const int* snap_slot;   // [imax][G] forward solve: slot of the stop's snapshot (result stops: the glacier's own result
+                          // index; stops that exist only for the mass balance: hidden slots behind them); null: i
+  __device__ __forceinline__ double tstop(int i, int g) const { return tstops[(long long)i * G + g]; }
+  __device__ __forceinline__ int at(const int* tab, int i, int g) const { return tab[(long long)i * G + g]; }
   double dtmax;
   int adaptive;
   double fixed_dt;
@@ -1162,9 +1171,9 @@ struct CtrlArgs {
   // reverse (continuous-adjoint) solve only; adj == null in the forward solve.  tstops are then
   // tau = -t ascending, the union of the snapshot times and the Gauss-Legendre nodes.
   AdjState* adj;
-  const double* tsnap;    // forward snapshot times t_0 < ... < t_{k-1}
-  const int* stop_snap;   // per stop: forward snapshot index, -1 for a quadrature node
-  const double* stop_qw;  // per stop: quadrature weight, 0 for a snapshot time
+  const double* tsnap;    // [kmax][G] forward snapshot times t_0 < ... < t_{k_g - 1} of every glacier
+  const int* stop_snap;   // [imax][G] per stop: forward snapshot index, -1 for a quadrature node
+  const double* stop_qw;  // [imax][G] per stop: quadrature weight, 0 for a snapshot time
   double* qw_out;         // per glacier: weight of the node reached by this step (0 otherwise)
 };
 
@@ -1185,9 +1194,9 @@ struct ScArgs {
 };
 
 // interpolation weights of H_itp at the five stage times of the step [tau, tau + dt]
-__device__ __forceinline__ void adj_stage_weights(AdjState* a, const double* tsnap, double tau, double dt,
+__device__ __forceinline__ void adj_stage_weights(AdjState* a, const double* tsnap, int G, int gidx, double tau, double dt,
                                                   bool all_at_end) {
-  const double ta = tsnap[a->seg], inv = 1.0 / (tsnap[a->seg + 1] - ta);
+  const double ta = tsnap[(long long)a->seg * G + gidx], inv = 1.0 / (tsnap[(long long)(a->seg + 1) * G + gidx] - ta);
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const double t = -(tau + (all_at_end ? 1.0 : c_cc[i]) * dt);
@@ -1242,8 +1251,9 @@ __device__ __forceinline__ void controller_errsum(const CtrlArgs& C, const GDev&
 }
 // the decision itself (PID controller, accept / reject, stop handling, next step size; the reverse solve's AdjState),
 // on values in registers: one thread.  Returns 1 when the glacier has just finished; est: steps still needed (-1: n/a).
-__device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const GDev& g, const CtrlArgs& C, double s, double pw0,
-                                                 double pw1, double pw2, int& est) {
+__device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const GDev& g, const CtrlArgs& C, int gidx, double s,
+                                                 double pw0, double pw1, double pw2, int& est) {
+  const int n_stops = C.nstops[gidx];
   est = -1;
   const double h = st.dt;
   double fac = 1.0;
@@ -1268,17 +1278,18 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
     st.accepted = 1;
     st.cur = C.next_cur >= 0 ? C.next_cur : 1 - st.cur;
     if (st.clipped) {
-      t = C.tstops[st.istop];
+      t = C.tstop(st.istop, gidx);
       st.at_stop = 1;
-      st.mb_now = C.mb_flag[st.istop];
-      st.mb_slot = C.mb_slot[st.istop];
+      st.mb_now = C.at(C.mb_flag, st.istop, gidx);
+      st.mb_slot = C.at(C.mb_slot, st.istop, gidx);
+      st.snap_slot = C.snap_slot ? C.at(C.snap_slot, st.istop, gidx) : st.istop;
       if (C.adj) {
         AdjState* a = &ad;
-        a->snapj = C.stop_snap[st.istop];
-        a->qw = C.stop_qw[st.istop];
+        a->snapj = C.at(C.stop_snap, st.istop, gidx);
+        a->qw = C.stop_qw[(long long)st.istop * C.G + gidx];
         a->seg_stop = a->seg;
-        const double ta = C.tsnap[a->seg];
-        a->s_stop = a->snapj >= 0 ? (a->snapj == a->seg ? 0.0 : 1.0) : (-t - ta) / (C.tsnap[a->seg + 1] - ta);
+        const double ta = C.tsnap[(long long)a->seg * C.G + gidx];
+        a->s_stop = a->snapj >= 0 ? (a->snapj == a->seg ? 0.0 : 1.0) : (-t - ta) / (C.tsnap[(long long)(a->seg + 1) * C.G + gidx] - ta);
         if (a->snapj >= 1) a->seg = a->snapj - 1;  // the next steps run below snapshot j
       }
       st.istop++;
@@ -1297,14 +1308,14 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
     if (accept) st.pad &= ~4;
     if (accept && st.at_stop && st.mb_now && g.has_mb) st.pad |= 4;
   }
-  if (st.istop >= C.n_stops) {
+  if (st.istop >= n_stops) {
     st.done = 1;
     est = 0;
     return 1;
   }
   double dtn = C.adaptive ? h * fac : C.fixed_dt;
   if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
-  const double rem = C.tstops[st.istop] - t;
+  const double rem = C.tstop(st.istop, gidx) - t;
   // snap to the stop when the step would end within 100 ulp of it
   if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
     dtn = rem;
@@ -1314,11 +1325,11 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
   }
   st.dt = dtn;
   {  // at the current step size, and at least one step per remaining stop
-    const double e = ceil((C.tstops[C.n_stops - 1] - t) / (C.adaptive ? h * fac : dtn));
-    const int stops_left = C.n_stops - st.istop;
+    const double e = ceil((C.tstop(n_stops - 1, gidx) - t) / (C.adaptive ? h * fac : dtn));
+    const int stops_left = n_stops - st.istop;
     est = e < (double)stops_left ? stops_left : (e > 1e6 ? 1000000 : (int)e);
   }
-  if (C.adj) adj_stage_weights(&ad, C.tsnap, t, dtn, false);
+  if (C.adj) adj_stage_weights(&ad, C.tsnap, C.G, gidx, t, dtn, false);
   return 0;
 }
 
@@ -1354,16 +1365,17 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
       st.accepted = 1;
       st.cur = C.next_cur;
       if (st.clipped) {
-        t = C.tstops[st.istop];
+        t = C.tstop(st.istop, gidx);
         st.at_stop = 1;
-        st.mb_now = C.mb_flag[st.istop];
-        st.mb_slot = C.mb_slot[st.istop];
+        st.mb_now = C.at(C.mb_flag, st.istop, gidx);
+        st.mb_slot = C.at(C.mb_slot, st.istop, gidx);
+        st.snap_slot = C.snap_slot ? C.at(C.snap_slot, st.istop, gidx) : st.istop;
         st.istop++;
       } else {
         t += st.dt;
       }
       st.t = t;
-      if (st.istop >= C.n_stops) {
+      if (st.istop >= C.nstops[gidx]) {
         st.done = 1;
         atomicSub(C.n_active, 1);
         *gs = st;
@@ -1371,7 +1383,7 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
       }
     }
     const double dmin = fmin(g.dx, g.dy);
-    const double rem = C.tstops[st.istop] - t;
+    const double rem = C.tstop(st.istop, gidx) - t;
     double dtn = s > 0.0 ? C.cfl * dmin * dmin / (4.0 * s) : rem;
     if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
     if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
@@ -1385,7 +1397,7 @@ __global__ __launch_bounds__(64) void k_controller(Pools P, CtrlArgs C) {
     return;
   }
   int est;
-  const int newly_done = controller_decide(st, ad, g, C, s, pw0, pw1, pw2, est);
+  const int newly_done = controller_decide(st, ad, g, C, gidx, s, pw0, pw1, pw2, est);
   if (C.qw_out) C.qw_out[gidx] = ad.qw;
   if (newly_done) atomicSub(C.n_active, 1);
   if (C.est_steps && est >= 0) C.est_steps[gidx] = est;
@@ -1467,7 +1479,7 @@ __global__ __launch_bounds__(NT) void k_poststep(Pools P, PostArgs A, double* __
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   const int tx = threadIdx.x & 63, ty = wave_id();
   const int gi = i0 + tx;
-  const int slot = gs->istop - 1;
+  const int slot = gs->snap_slot;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
     const int gj = j0 + ty + NW * m;
@@ -1782,6 +1794,21 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
+  if (MODE == 1 && A.dts[t4.x] == 0.0) {
+    // reverse-Euler loop, row m of the per-glacier stop tables: this glacier has no stop m (fewer stops of its own than the
+    // longest table of the batch: dt = 0 only there, own stops are strictly increasing) -- lambda passes through untouched
+    const int gi_ = i0 + (threadIdx.x & 63);
+#pragma unroll
+    for (int m = 0; m < RPT; ++m) {
+      const int gj = j0 + wave_id() + NW * m;
+      if (gi_ < g.nx && gj < g.ny) {
+        const long long id = g.off + gi_ + (long long)g.nx * gj;
+        A.out[id] = A.lam[id];
+      }
+    }
+    if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = 0.0;
+    return;
+  }
   double ownH[RPT], ownL[RPT], v[RPT];
   if (MODE == 0 && A.snaps) {
     const AdjState a = A.adj[t4.x];
@@ -2159,11 +2186,17 @@ __global__ __launch_bounds__(NT) void k_loss(Pools P, const double* __restrict__
   if (threadIdx.x == 0) P.part[4 * (long long)t4.w + 1] = tot * w / ((double)g.nx * (double)g.ny);
 }
 
-// lam += VJP_MB(lam, H_pre)   (VJPs.jl:107-151), in place; flag per glacier
+// lam += VJP_MB(lam, H_pre)   (VJPs.jl:107-151), in place; flag per glacier.  gflag / gslot (nullable): per-glacier tables of
+// the discrete reverse loop -- glacier g takes part iff gflag[g], and its pre-MB state is Hpre + gslot[g] * ntot
 __global__ __launch_bounds__(NT) void k_mb_vjp(Pools P, const double* __restrict__ Hpre, const double* __restrict__ mb0,
                                                const double* __restrict__ Sref, const double* __restrict__ lam_in,
-                                               double* __restrict__ lam_out, int add, int tile_base) {
+                                               double* __restrict__ lam_out, int add, int tile_base,
+                                               const int* __restrict__ gflag, const int* __restrict__ gslot, long long ntot) {
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
+  if (gflag) {
+    if (!gflag[t4.x]) return;  // (in place, add = 1: nothing to do)
+    Hpre += (long long)gslot[t4.x] * ntot;
+  }
   const GDev g = P.gd[t4.x];
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   const int tx = threadIdx.x & 63, ty = wave_id();
@@ -2469,20 +2502,20 @@ __global__ __launch_bounds__(64) void k_initdt_ctrl(Pools P, int phase, double t
 
 // start of a solve: reset the integrator state; dt is already in gs->dt (given or from
 // k_initdt_ctrl) and is clipped to the first stop here.
-__global__ void k_begin(Pools P, int n, const double* tstops, double dtmax, double dt_given) {
+__global__ void k_begin(Pools P, int n, const double* tstops /* [imax][n] */, double dtmax, double dt_given) {
   const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
   if (gidx >= n) return;
   GState* gs = P.gs + gidx;
-  const double t0 = tstops[0];
+  const double t0 = tstops[gidx];
   double dt = dt_given > 0.0 ? dt_given : gs->dt;
   if (dtmax > 0.0 && dt > dtmax) dt = dtmax;
-  const double rem = tstops[1] - t0;
+  const double rem = tstops[n + gidx] - t0;
   int clipped = 0;
   if (dt >= rem || fabs(rem - dt) <= 100.0 * 2.220446049250313e-16 * fabs(t0)) { dt = rem; clipped = 1; }
   gs->t = t0; gs->dt = dt; gs->e2 = 1.0; gs->e3 = 1.0; gs->EEst = 0.0;
   gs->accepted = 1; gs->at_stop = 0; gs->mb_now = 0; gs->mb_slot = 0;
   gs->done = 0; gs->istop = 1; gs->clipped = clipped; gs->cur = 0;
-  gs->naccept = 0; gs->nreject = 0; gs->nonfinite = 0; gs->pad = 0;
+  gs->naccept = 0; gs->nreject = 0; gs->nonfinite = 0; gs->pad = 0; gs->snap_slot = 0; gs->pad2 = 0;
 }
 
 
@@ -2496,11 +2529,13 @@ __global__ void k_set_dt(Pools P, int n, double dt) {
 // as "just reached" so that the post-step kernel adds the loss term of t_{k-1} and then the
 // mass-balance VJP (gradient.jl:441-446 and PeriodicCallback(initial_affect = true) :431-432).
 // seg starts in the last snapshot interval; k_begin later resets the integrator state proper.
-__global__ void k_adj_begin(Pools P, int n, AdjState* adj, int n_snap, double tau0, int mb_flag, int mb_slot) {
+__global__ void k_adj_begin(Pools P, int n, AdjState* adj, const int* n_snaps /* [n] */, double tau0, const int* mb_flags,
+                            const int* mb_slots /* stop 0 of the reverse tables: [n] */) {
   const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
   if (gidx >= n) return;
   GState* gs = P.gs + gidx;
   AdjState* a = adj + gidx;
+  const int n_snap = n_snaps[gidx], mb_flag = mb_flags[gidx], mb_slot = mb_slots[gidx];
   a->seg = n_snap - 2; a->seg_stop = n_snap - 2; a->snapj = n_snap - 1; a->pad = 0;
   a->qw = 0.0; a->s_stop = 1.0;
   for (int i = 0; i < 5; ++i) a->sitp[i] = 1.0;
@@ -2513,7 +2548,7 @@ __global__ void k_adj_itp(Pools P, int n, AdjState* adj, const double* tsnap, in
   const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
   if (gidx >= n) return;
   const GState* gs = P.gs + gidx;
-  adj_stage_weights(adj + gidx, tsnap, gs->t, gs->dt, all_at_end != 0);
+  adj_stage_weights(adj + gidx, tsnap, n, gidx, gs->t, gs->dt, all_at_end != 0);
 }
 
 // post-step of the reverse solve (pointwise, no-op for glaciers not at a stop):
@@ -2767,6 +2802,28 @@ __global__ __launch_bounds__(64) void k_sum_tilesFt(Pools P, const double* __res
   if (threadIdx.x == 0) out[gidx] += s;
 }
 // out = a + s (b - a) on n entries (the time interpolant of two snapshots, load_tile_HS2's formula)
+// out = H_seg + s (H_seg+1 - H_seg) with the segment and the weight PER GLACIER (every glacier interpolates between its own
+// result snapshots, interpolate((t,), H, Gridded(Linear())), gradient.jl:287); seg < 0: the glacier is skipped
+__global__ __launch_bounds__(NT) void k_lerp_g(Pools P, const double* __restrict__ snaps, long long ntot, const int* __restrict__ seg,
+                                               const double* __restrict__ sw, double* __restrict__ out) {
+  const int4 t4 = P.tiles[blockIdx.x];
+  const int sg = seg[t4.x];
+  if (sg < 0) return;
+  const GDev g = P.gd[t4.x];
+  const double s = sw[t4.x];
+  const double* __restrict__ a = snaps + (long long)sg * ntot;
+  const double* __restrict__ b = a + ntot;
+  const int gi = t4.y * TX + (threadIdx.x & 63);
+#pragma unroll
+  for (int m = 0; m < RPT; ++m) {
+    const int gj = t4.z * TY + wave_id() + NW * m;
+    if (gi < g.nx && gj < g.ny) {
+      const long long id = g.off + gi + (long long)g.nx * gj;
+      const double ha = a[id];
+      out[id] = s != 0.0 ? fma(s, b[id] - ha, ha) : ha;  // (s = 0: the slot above may not exist)
+    }
+  }
+}
 __global__ void k_lerp(long long n, double s, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     out[i] = fma(s, b[i] - a[i], a[i]);

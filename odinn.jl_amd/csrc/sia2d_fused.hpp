@@ -572,8 +572,9 @@ __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, con
 // state buffer `cur` still lacks the mass balance of the stop it sits on (applied on load until a step is accepted)
 // Called by ALL lanes of wavefront 0 with identical arguments: the three pow() of the PID factor run in lanes 0..2 at
 // once (same calls, same product order as k_controller: bit-identical), everything else is computed redundantly.
-__device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlArgs& C, double errsum, int& est, int lane) {
+__device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlArgs& C, int gidx, double errsum, int& est, int lane) {
   const double h = s.dt;
+  const int n_stops = C.nstops[gidx];
   double fac = 1.0;
   bool accept = true;
   if (C.adaptive) {
@@ -596,10 +597,11 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
     s.accepted = 1;
     s.cur = 1 - s.cur;
     if (s.clipped) {
-      t = C.tstops[s.istop];
+      t = C.tstop(s.istop, gidx);
       s.at_stop = 1;
-      s.mb_now = C.mb_flag[s.istop];
-      s.mb_slot = C.mb_slot[s.istop];
+      s.mb_now = C.at(C.mb_flag, s.istop, gidx);
+      s.mb_slot = C.at(C.mb_slot, s.istop, gidx);
+      s.snap_slot = C.snap_slot ? C.at(C.snap_slot, s.istop, gidx) : s.istop;
       s.istop++;
     } else {
       t += h;
@@ -609,14 +611,14 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
     s.nreject++;
     s.accepted = 0;
   }
-  if (s.istop >= C.n_stops) {
+  if (s.istop >= n_stops) {
     s.done = 1;
     est = 0;
     return;
   }
   double dtn = C.adaptive ? h * fac : C.fixed_dt;
   if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
-  const double rem = C.tstops[s.istop] - t;
+  const double rem = C.tstop(s.istop, gidx) - t;
   if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
     dtn = rem;
     s.clipped = 1;
@@ -624,8 +626,8 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
     s.clipped = 0;
   }
   s.dt = dtn;
-  const double e = ceil((C.tstops[C.n_stops - 1] - t) / (C.adaptive ? h * fac : dtn));
-  const int stops_left = C.n_stops - s.istop;
+  const double e = ceil((C.tstop(n_stops - 1, gidx) - t) / (C.adaptive ? h * fac : dtn));
+  const int stops_left = n_stops - s.istop;
   est = e < (double)stops_left ? stops_left : (e > 1e6 ? 1000000 : (int)e);
 }
 
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
         for (int k = lane; k < nt; k += 64) sum += A.part_in[t0 + k];
         sum = __shfl(wave_sum(sum), 0, 64);
         int mbp = sn.pad & 4;
-        sc_decide(sn, g, A.C, sum, est, lane);
+        sc_decide(sn, g, A.C, t4.x, sum, est, lane);
         if (sn.accepted) mbp = 0;                          // the accepted step replaced the buffer
         if (sn.at_stop && sn.mb_now && g.has_mb) mbp = 4;  // ... and landed on a stop with a mass balance
         sn.pad = (sn.at_stop ? 2 : 0) | mbp;
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     dt = s_state.dt;
     cur = s_state.cur;
     finished = s_state.done != 0;
-    if (s_state.pad & 2) snap_slot = s_state.istop - 1;
+    if (s_state.pad & 2) snap_slot = s_state.snap_slot;
     mb_pend = (s_state.pad & 4) != 0;
     mb_slot = s_state.mb_slot;
     if (finished && snap_slot < 0) return;
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     dt = gs->dt;
     cur = gs->cur;
     finished = gs->done != 0;
-    if (snap) snap_slot = gs->istop - 1;
+    if (snap) snap_slot = gs->snap_slot;
     // ... and with a mass balance (constant-A kernels: u_n in LDS slots) the controller flags the buffer that still lacks the
     // mass balance of its stop (GState::pad bit 2); it is applied on load below, exactly as in the self-controlled loop
     if (UPL && A.snap_on_load && A.mb0) {

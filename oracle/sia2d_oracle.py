@@ -965,9 +965,16 @@ def solve(
     ``solve(prob, RDPK3Sp35(); callback, reltol, maxiters, tstops)``) with the
     mass-balance PeriodicCallback of :498-517 passed as ``callback(u, t) -> u`` at
     ``callback_times``.  Returns (snapshots, stats, cb_increments).
+
+    A callback time that is not a tstop is an integrator stop all the same -- PeriodicCallback adds its own tstops
+    (step_MB not a multiple of solver.step) -- but the state there is not part of the result (Sleipnir.create_results
+    evaluates the solution at `tstops`, inversion_utils.jl:533-538).
     """
     tstops = [float(t) for t in tstops]
     cbt = set(float(t) for t in callback_times)
+    saved = set(tstops)
+    if callback is not None:
+        tstops = sorted(saved | set(t for t in cbt if tstops[0] < t <= tstops[-1]))
     t = tstops[0]
     u = np.array(u0, F, copy=True)
     snaps = [u.copy()]
@@ -1014,7 +1021,8 @@ def solve(
             unew = callback(u, ts)
             cb_inc[ts] = unew - u
             u = unew
-        snaps.append(u.copy())
+        if ts in saved:
+            snaps.append(u.copy())
     return snaps, st, cb_inc
 
 

@@ -202,7 +202,8 @@ def test_multiloss_with_lossavgv_through_the_api(gpu):
     Lo, go = 0.0, np.zeros(2)
     for kk, g in enumerate(gl):
         A = lo + (hi - lo) * (np.tanh(th[kk]) + 1) / 2
-        cfg = O.SimConfig(tstops=inv.tstops(), reltol=1e-10, avgv=samples[kk], avgv_weight=0.7 / 1.5)
+        # (every glacier has its OWN stop table: the shared grid, its data times, the grid of its velocity window)
+        cfg = O.SimConfig(tstops=inv.tstops_glacier(kk), reltol=1e-10, avgv=samples[kk], avgv_weight=0.7 / 1.5)
         l1, g1, _ = O.loss_and_grad(O.Glacier(g.H0, g.B, 50.0, 50.0, ph), O.Law(kind=O.LAW_CONST_A, A=A), cfg, g.thicknessData.H, tH)
         Lo += 1.5 * l1
         go[kk] = 1.5 * g1[0] * (hi - lo) / 2 * (1 - np.tanh(th[kk]) ** 2)

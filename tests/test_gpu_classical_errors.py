@@ -129,8 +129,14 @@ def test_abi_error_behaviour(gpu):
     with pytest.raises(gpu.OdinnError, match="expects 2 MLP inputs"):
         b.set_law(gpu.LAW_NN_Y, mlp, np.zeros(mlp.n_params))
     b.set_mass_balance(0, np.zeros((32, 24)))
-    with pytest.raises(gpu.OdinnError, match="not one of tstops"):
-        b.solve([0.0, 0.1], mb_times=[0.05])
+    with pytest.raises(gpu.OdinnError, match="not inside"):
+        b.solve([0.0, 0.1], mb_times=[0.2])  # (a time inside tspan that is not a tstop is a stop of the integrator only)
+    with pytest.raises(gpu.OdinnError, match="strictly increasing"):
+        b.solve([0.0, 0.1], mb_times=[0.05, 0.05])
+    with pytest.raises(gpu.OdinnError, match="same tspan"):
+        b.set_glacier_stops(0, [0.0, 0.05])
+        b.solve([0.0, 0.1])
+    b.set_glacier_stops(0, None)
     with pytest.raises(gpu.OdinnError, match="maxiters"):
         b.solve([0.0, 50.0], maxiters=3, dt0=1e-9)
     with pytest.raises(ValueError):
