@@ -43,11 +43,10 @@ import os
 
 # Kernel arguments in device memory: the HIP runtime's launch-latency setting for MI300-class parts (read when the
 # runtime initialises, so before torch / the library make their first HIP call).  Already the default of ROCm 7.2 on
-# gfx950 (no difference measured with or without this line); pinned here because the step loop is a chain of dependent
-# launches and an explicit 0 costs 3 % per step at 8 x 1024^2 and 27 % on the 4-glacier gradients.  A value set in the
-# environment wins; ODINN_KEEP_HIP_DEFAULTS=1 skips the request.
-if not os.environ.get("ODINN_KEEP_HIP_DEFAULTS"):
-    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# gfx950 (no difference measured with or without this line); pinned here, for THIS process only, because the step loop is
+# a chain of dependent launches and an explicit 0 costs 3 % per step at 8 x 1024^2 and 27 % on the 4-glacier gradients.
+# A value set in the environment wins.  (The library and its Python layer do not touch the process environment.)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 import socket
 import sys
 import time

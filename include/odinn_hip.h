@@ -213,7 +213,9 @@ int odinn_set_thickness_loss_function(odinn_batch* b, int simple_loss, double ep
  * dhdt = mean((H1 - H0)[mask]) / (t1 - t0), the term weight * (dhdt - dhdt_ref)^2 joins the loss of odinn_loss /
  * odinn_loss_grad / odinn_loss_grad_continuous and +-2 weight (dhdt - dhdt_ref) mask / (N_mask (t1 - t0)) joins lambda at
  * t1 / t0 (gradient.jl:170-215, :369-449).  `weight` is the MultiLoss lambda of the term relative to the data loss;
- * weight = 0 (default) switches the term off; t1 <= t0 clears a glacier's data. */
+ * weight = 0 (default) switches the term off; t1 <= t0 clears a glacier's data.  A glacier without data does not contribute
+ * to the term; a non-zero weight with NO glacier carrying the data makes the loss / gradient entry points fail with
+ * ODINN_ERR_STATE (the same rule holds for LossAvgV and VelocityRegularization below). */
 int odinn_set_dhdt_reference(odinn_batch* b, int g, double t0, double t1, double dhdt_ref);
 int odinn_set_dhdt_loss(odinn_batch* b, double weight);
 /* LossAvgV, the other time-aggregated loss (src/losses/TimeAggregatedLosses.jl:115-258): glacier.velocityData holds ONE

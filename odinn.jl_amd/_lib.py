@@ -6,10 +6,9 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-# kernel arguments in device memory (the HIP runtime's launch-latency setting for MI300-class parts; takes effect when the
-# runtime has not been initialised yet -- the library's loader sets it too; an explicit value in the environment wins)
-if not os.environ.get("ODINN_KEEP_HIP_DEFAULTS"):
-    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# (HIP_FORCE_DEV_KERNARG -- kernel arguments in device memory, the runtime's launch-latency setting and its default on
+#  ROCm 7.2 / gfx950 -- is process-wide: this layer does not touch the environment.  bench.py and the tests request it for
+#  their own process; ODINN_REQUEST_DEV_KERNARG=1 makes the library's loader request it.)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ODINN_LIB") or os.path.join(_HERE, "csrc", "libodinn_hip.so")  # ODINN_LIB: A/B builds

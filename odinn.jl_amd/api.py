@@ -247,16 +247,21 @@ class MultiLoss:
             raise ValueError("You need to provide an hyperparameter for each loss term defined.")  # MultiLoss.jl:29
 
 
+class _NoDataTerm(LossH):
+    """Marker: the loss holds time-aggregated terms / regularisers only (MultiLoss((LossDhdt(),), (1,)) has no thickness
+    term even when the glacier carries thicknessData): no reference is uploaded, so the device adds no LossH."""
+
+
 def _split_loss(lf):
     """(data loss, its weight, [(regulariser, weight)]) of a loss specification."""
     if isinstance(lf, _AGGREGATED):
-        return LossH(), 1.0, [(lf, 1.0)]  # no thickness data -> the data term is 0
+        return _NoDataTerm(), 1.0, [(lf, 1.0)]
     if not isinstance(lf, MultiLoss):
         return lf, 1.0, []
     data = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if isinstance(l, (LossH, LossV, LossHV))]
     regs = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if not isinstance(l, (LossH, LossV, LossHV))]
     if len(data) == 0 and any(isinstance(r, _AGGREGATED) for r, _ in regs):
-        data = [(LossH(), 1.0)]  # time-aggregated losses alone: a LossH without thickness data contributes nothing
+        data = [(_NoDataTerm(), 1.0)]  # time-aggregated losses alone: no data term
     if len(data) != 1:
         raise ValueError("MultiLoss needs exactly one data term (LossH, LossV or LossHV)")
     for r, _ in regs:
@@ -993,7 +998,7 @@ class _Simulation:
             b.set_fields(k, g.H0, g.B)
             lf, _, _ = _split_loss(p.UDE.empirical_loss_function)
             dist_ = (lf.hLoss.loss.distance if isinstance(lf, LossHV) else lf.loss.distance)
-            if g.thicknessData is not None:
+            if g.thicknessData is not None and not isinstance(lf, (_NoDataTerm, LossV)):  # (only LossH / LossHV read it)
                 b.set_reference(k, g.thicknessData.t, g.thicknessData.H, dist_)
             if g.velocityData is not None and len(g.velocityData.t) > 0:
                 v = g.velocityData

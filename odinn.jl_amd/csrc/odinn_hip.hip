@@ -5,6 +5,7 @@
 #include "launch.hpp"
 #include "sia2d_velocity.hpp"
 
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -18,15 +19,17 @@
 #include <vector>
 
 // The step loops are chains of dependent launches, so launch latency is part of every step.  HIP_FORCE_DEV_KERNARG=1 (kernel
-// arguments in device memory) is the HIP runtime's setting for that on MI300-class parts; it is read when the runtime
-// initialises, so the library asks for it when it is loaded -- without overriding a value the user has set, and without
-// effect if the host application has already initialised HIP.  On ROCm 7.2 / gfx950 it is the runtime's default already
-// (nothing changes); switched off explicitly it costs 0.118 -> 0.122 ms per step at 8 x 1024^2 and 9.7 -> 12.3 ms on the
-// continuous-adjoint gradient of 4 alpine glaciers.  ODINN_KEEP_HIP_DEFAULTS=1 skips the request.
+// arguments in device memory) is the HIP runtime's setting for that on MI300-class parts.  It is a PROCESS-wide runtime
+// setting (it changes HIP for every other user of the runtime in the process), so the library does not touch it unless
+// asked to: ODINN_REQUEST_DEV_KERNARG=1 makes the loader request it (never over a value the user has set, and without effect
+// once the host application has initialised HIP).  On ROCm 7.2 / gfx950 it is the runtime's default already; switched off
+// explicitly it costs 0.118 -> 0.122 ms per step at 8 x 1024^2 and 9.7 -> 12.3 ms on the continuous-adjoint gradient of 4
+// alpine glaciers.
 namespace {
 struct OdinnLoadTimeSettings {
   OdinnLoadTimeSettings() {
-    if (!std::getenv("ODINN_KEEP_HIP_DEFAULTS")) setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+    const char* e = std::getenv("ODINN_REQUEST_DEV_KERNARG");
+    if (e && e[0] == '1') setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
   }
 } odinn_load_time_settings;
 }  // namespace
@@ -1292,8 +1295,22 @@ int vreg_forward(odinn_batch* b, bool with_grad, bool add_loss, int nq, const do
   return ODINN_OK;
 }
 
+// A MultiLoss term with a non-zero weight whose data no glacier carries would silently drop out of the loss: refuse instead
+// (glaciers WITHOUT the data of a term that others carry simply do not contribute to it -- the per-glacier opt-out)
+int check_loss_terms(odinn_batch* b) {
+  if (b->dhdt_weight != 0.0 && !b->dhdt_on())
+    return fail(ODINN_ERR_STATE, "LossDhdt has weight %g but no glacier carries dhdtData (odinn_set_dhdt_reference)", b->dhdt_weight);
+  if (b->avgv_weight != 0.0 && !b->avgv_on())
+    return fail(ODINN_ERR_STATE, "LossAvgV has weight %g but no glacier carries a velocity sample (odinn_set_avgv_reference)", b->avgv_weight);
+  if (b->vreg_weight != 0.0 && !b->vreg_on())
+    return fail(ODINN_ERR_STATE, "VelocityRegularization has weight %g but no glacier carries two velocity-data dates "
+                                 "(odinn_set_velocity_reference)", b->vreg_weight);
+  return ODINN_OK;
+}
+
 // forward loss over the stored snapshots -> d_lossacc[g]; *const_loss: data-only part of LossV
 int do_loss(odinn_batch* b, double* const_loss) {
+  CHK(check_loss_terms(b));
   const int k = b->K();
   *const_loss = 0.0;
   HIPCHK(hipMemsetAsync(b->d_lossacc, 0, sizeof(double) * b->G, b->stream));
@@ -1914,6 +1931,7 @@ int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double
   if (!H || !lam || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
+  CHK(check_loss_terms(b));
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
   CHK(up_field(b, g, b->d_tmpA, H));
   CHK(up_field(b, g, b->d_lam[0], lam));
@@ -2131,6 +2149,7 @@ int odinn_surface_V_vjp_theta(odinn_batch* b, int g, const double* dVx, const do
   CHK(check_g(b, g));
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
+  CHK(check_loss_terms(b));
   CHK(surfV_vjp_common(b, g, dVx, dVy, H));
   const GDev& r = b->gd[g];
   if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) return gridded_law_grad(b, r.offd, (long long)(r.nx - 1) * (r.ny - 1), dtheta);
@@ -2253,6 +2272,7 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
   if (theta) CHK(odinn_set_theta(b, theta, P));
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
+  CHK(check_loss_terms(b));
   if (b->loss_kind != ODINN_LOSS_V && !b->d_Href && !b->dhdt_on() && !b->avgv_on() && !b->vreg_on()) return fail(ODINN_ERR_STATE, "no reference thickness data set");
   if (b->loss_kind != ODINN_LOSS_H && !b->d_Vabs) return fail(ODINN_ERR_STATE, "no reference velocity data set");
   CHK(do_solve(b, n_stops, tstops, n_mb, mb_times, opts, stats));
@@ -2852,10 +2872,54 @@ struct odinn_comm {
   double* d_buf = nullptr;
   size_t cap = 0;
 };
+// RCCL is resolved on the first odinn_comm_* call (dlopen), not at link time: single-GPU users load libodinn_hip.so
+// without an RCCL installation.  Search order: $ODINN_RCCL_LIB, the dynamic loader's path (librccl.so.1, librccl.so),
+// $ROCM_PATH/lib, /opt/rocm/lib.  <rccl/rccl.h> is used for its types and constants only.
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+static RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.handle ? &api : nullptr;
+  tried = true;
+  std::vector<std::string> cand;
+  if (const char* e = std::getenv("ODINN_RCCL_LIB")) cand.push_back(e);
+  cand.push_back("librccl.so.1"); cand.push_back("librccl.so");
+  if (const char* r = std::getenv("ROCM_PATH")) { cand.push_back(std::string(r) + "/lib/librccl.so.1"); cand.push_back(std::string(r) + "/lib/librccl.so"); }
+  cand.push_back("/opt/rocm/lib/librccl.so.1"); cand.push_back("/opt/rocm/lib/librccl.so");
+  for (const std::string& c : cand) {
+    api.handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (api.handle) break;
+    api.err = dlerror() ? dlerror() : "";
+  }
+  if (!api.handle) return nullptr;
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+  api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
+    dlclose(api.handle);
+    api.handle = nullptr;
+    api.err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclGetErrorString";
+    return nullptr;
+  }
+  return &api;
+}
+#define RCCL_OR_FAIL(R)                                                                                                  \
+  RcclApi* R = rccl();                                                                                                   \
+  if (!R) return fail(ODINN_ERR_UNSUPPORTED, "RCCL (librccl.so) could not be loaded: the odinn_comm_* entry points need it (set ODINN_RCCL_LIB or ROCM_PATH)")
 #define NCCLCHK(x)                                                                                         \
   do {                                                                                                     \
     ncclResult_t r_ = (x);                                                                                 \
-    if (r_ != ncclSuccess) return fail(ODINN_ERR_HIP, "%s failed: %s (%s:%d)", #x, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    if (r_ != ncclSuccess) return fail(ODINN_ERR_HIP, "%s failed: %s (%s:%d)", #x, rccl()->GetErrorString(r_), __FILE__, __LINE__); \
   } while (0)
 static int comm_buf(odinn_comm* c, size_t n) {
   if (n > c->cap) {
@@ -2872,7 +2936,8 @@ int odinn_comm_get_unique_id(void* id_out) {
   static_assert(sizeof(ncclUniqueId) == ODINN_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
   if (!id_out) return fail(ODINN_ERR_ARG, "null id");
   ncclUniqueId id;
-  NCCLCHK(ncclGetUniqueId(&id));
+  RCCL_OR_FAIL(R);
+  NCCLCHK(R->GetUniqueId(&id));
   std::memcpy(id_out, &id, sizeof id);
   return ODINN_OK;
 }
@@ -2882,14 +2947,15 @@ int odinn_comm_init_rank(int device, int nranks, int rank, const void* id, odinn
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(ODINN_ERR_NO_DEVICE, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(ODINN_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+  RCCL_OR_FAIL(R);
   HIPCHK(hipSetDevice(device));
   odinn_comm* c = new odinn_comm();
   c->device = device; c->nranks = nranks; c->rank = rank;
   ncclUniqueId uid;
   std::memcpy(&uid, id, sizeof uid);
-  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, uid, rank);
-  if (r != ncclSuccess) { delete c; return fail(ODINN_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r)); }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { ncclCommDestroy(c->comm); delete c; return fail(ODINN_ERR_HIP, "stream creation failed"); }
+  ncclResult_t r = R->CommInitRank(&c->comm, nranks, uid, rank);
+  if (r != ncclSuccess) { delete c; return fail(ODINN_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString(r)); }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { R->CommDestroy(c->comm); delete c; return fail(ODINN_ERR_HIP, "stream creation failed"); }
   *out = c;
   return ODINN_OK;
 }
@@ -2897,7 +2963,7 @@ int odinn_comm_init_rank(int device, int nranks, int rank, const void* id, odinn
 int odinn_comm_destroy(odinn_comm* c) {
   if (!c) return ODINN_OK;
   (void)hipSetDevice(c->device);
-  if (c->comm) ncclCommDestroy(c->comm);
+  if (c->comm && rccl()) rccl()->CommDestroy(c->comm);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->d_buf) (void)hipFree(c->d_buf);
   delete c;
@@ -2915,14 +2981,14 @@ int odinn_comm_allreduce_sum_dev(odinn_comm* c, double* inout_dev, int n, void* 
   if (!c || !inout_dev || n < 0) return fail(ODINN_ERR_ARG, "bad all-reduce arguments");
   HIPCHK(hipSetDevice(c->device));
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
-  NCCLCHK(ncclAllReduce(inout_dev, inout_dev, (size_t)n, ncclDouble, ncclSum, c->comm, st));
+  NCCLCHK(rccl()->AllReduce(inout_dev, inout_dev, (size_t)n, ncclDouble, ncclSum, c->comm, st));
   return ODINN_OK;
 }
 
 static int comm_allreduce_host(odinn_comm* c, double* inout, int n, hipStream_t st) {
   CHK(comm_buf(c, (size_t)n));
   HIPCHK(hipMemcpyAsync(c->d_buf, inout, sizeof(double) * n, hipMemcpyHostToDevice, st));
-  NCCLCHK(ncclAllReduce(c->d_buf, c->d_buf, (size_t)n, ncclDouble, ncclSum, c->comm, st));
+  NCCLCHK(rccl()->AllReduce(c->d_buf, c->d_buf, (size_t)n, ncclDouble, ncclSum, c->comm, st));
   HIPCHK(hipMemcpyAsync(inout, c->d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   return ODINN_OK;
@@ -2940,19 +3006,31 @@ int odinn_batch_loss_grad(odinn_batch* b, odinn_comm* comm, int adjoint, const d
                           odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
   if (!b || !loss || !dtheta || P < 0) return fail(ODINN_ERR_ARG, "null argument");
   if (comm && comm->device != b->device) return fail(ODINN_ERR_ARG, "communicator is bound to device %d, batch to device %d", comm->device, b->device);
-  if (adjoint == 0)
-    CHK(odinn_loss_grad(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, loss, dtheta, stats));
-  else if (adjoint == 1)
-    CHK(odinn_loss_grad_continuous(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, adjoint_opts, loss, dtheta, stats, stats_rev));
-  else
-    return fail(ODINN_ERR_ARG, "adjoint must be 0 (DiscreteAdjoint) or 1 (ContinuousAdjoint)");
-  if (!comm || comm->nranks == 1) return ODINN_OK;
-  std::vector<double> buf(1 + (size_t)P);
-  buf[0] = *loss;
-  for (int q = 0; q < P; ++q) buf[1 + q] = dtheta[q];
-  CHK(comm_allreduce_host(comm, buf.data(), 1 + P, b->stream));  // one ncclAllReduce(sum, ncclDouble, 1 + P) on the batch's stream
-  *loss = buf[0];
-  for (int q = 0; q < P; ++q) dtheta[q] = buf[1 + q];
+  if (adjoint != 0 && adjoint != 1) return fail(ODINN_ERR_ARG, "adjoint must be 0 (DiscreteAdjoint) or 1 (ContinuousAdjoint)");
+  // This rank's part.  A failure here is rank-local and data-dependent (maxiters, a BoundsError of the U law's interpolant,
+  // a stop table that does not hold a loss term's times, ...): the rank must still take part in the collective, or every
+  // other rank blocks in ncclAllReduce forever.  So the buffer carries a status slot, [n_failed, loss, dtheta...]: a failed
+  // rank contributes {1, 0, 0...}, and after the reduction EVERY rank returns an error if n_failed > 0.
+  const int rc = adjoint == 0
+                     ? odinn_loss_grad(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, loss, dtheta, stats)
+                     : odinn_loss_grad_continuous(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, adjoint_opts, loss, dtheta, stats, stats_rev);
+  if (!comm || comm->nranks == 1) return rc;
+  const std::string local_err = rc != ODINN_OK ? g_err : std::string();
+  std::vector<double> buf(2 + (size_t)P, 0.0);
+  buf[0] = rc != ODINN_OK ? 1.0 : 0.0;
+  if (rc == ODINN_OK) {
+    buf[1] = *loss;
+    for (int q = 0; q < P; ++q) buf[2 + q] = dtheta[q];
+  }
+  // one ncclAllReduce(sum, ncclDouble, 2 + P) on the batch's stream (H2D, reduce, D2H enqueued back to back, one sync)
+  const int rc2 = comm_allreduce_host(comm, buf.data(), 2 + P, b->stream);
+  if (rc != ODINN_OK) return fail(rc, "%s", local_err.c_str());
+  if (rc2 != ODINN_OK) return rc2;
+  if (buf[0] > 0.0)
+    return fail(ODINN_ERR_STATE, "odinn_batch_loss_grad: %d of %d ranks failed in their local gradient evaluation (this rank did "
+                                 "not); loss and gradient are not valid", (int)buf[0], comm->nranks);
+  *loss = buf[1];
+  for (int q = 0; q < P; ++q) dtheta[q] = buf[2 + q];
   return ODINN_OK;
 }
 

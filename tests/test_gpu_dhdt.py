@@ -114,3 +114,31 @@ def test_multiloss_with_lossdhdt_through_the_api(gpu):
         go[kk] = 1.5 * g1[0] * (hi - lo) / 2 * (1 - np.tanh(th[kk]) ** 2)
     assert abs(L - Lo) <= 1e-6 * abs(Lo)
     assert np.allclose(dth, go, rtol=1e-5)
+
+
+def test_lossdhdt_alone_ignores_the_thickness_data(gpu):
+    """MultiLoss((LossDhdt(),), (1,)) on glaciers that DO carry thicknessData: the loss has the dhdt term only (no LossH is
+    slipped in), while the thickness-data times still are stops of the solve (inversion_utils.jl:487-495)."""
+    k, step = 5, 1.0 / 96.0
+    p = gpu.Parameters(simulation=gpu.SimulationParameters(tspan=(2010.0, 2010.0 + (k - 1) * step)),
+                       solver=gpu.SolverParameters(reltol=1e-10, step=2 * step))
+    p.UDE.grad = gpu.DiscreteAdjoint()
+    p.UDE.empirical_loss_function = gpu.MultiLoss(losses=(gpu.LossDhdt(),), lambdas=(0.7,))
+    ts = [2010.0 + j * step for j in range(k)]
+    H0, B = O.synthetic_alpine(48, 40, hmax=160.0, slope=0.1)
+    g = gpu.Glacier2D("SYN-0", H0, B, 50.0, 50.0, A=3e-17)
+    g.thicknessData = gpu.ThicknessData(ts, [H0 * (1.0 - 0.05 * j) for j in range(k)])  # far from the prediction: a LossH would show
+    g.dhdtData = gpu.DhdtData((ts[1], ts[3]), -1.0)
+    reg = gpu.GlacierWideInv(p, [g], "A")
+    inv = gpu.Inversion(gpu.Model(gpu.SIA2Dmodel(p, A=gpu.LawA(p, scalar=True)), regressors={"A": reg}), [g], p)
+    assert inv.tstops() == ts
+    th = reg.theta.copy()
+    dth = np.zeros_like(th)
+    L = gpu.SIA2D_grad_b(dth, th, inv)
+    ph = O.Phys()
+    lo, hi = ph.minA, ph.maxA
+    A = lo + (hi - lo) * (np.tanh(th[0]) + 1) / 2
+    cfg = O.SimConfig(tstops=ts, reltol=1e-10, dhdt=(ts[1], ts[3], -1.0), dhdt_weight=1.0)
+    l1, g1, _ = O.loss_and_grad(O.Glacier(H0, B, 50.0, 50.0, ph), O.Law(kind=O.LAW_CONST_A, A=A), cfg, [], [])
+    assert abs(L - 0.7 * l1) <= 1e-6 * abs(0.7 * l1)
+    assert np.allclose(dth, 0.7 * g1[0] * (hi - lo) / 2 * (1 - np.tanh(th[0]) ** 2), rtol=1e-5)

@@ -165,20 +165,35 @@ def test_load_gridded_glacier_reads_oggm_style_files(odinn, tmp_path):
     assert np.array_equal(g2.H0, gl.H0) and np.array_equal(g2.B, gl.B) and g2.rgi_id == "g"
 
 
-def test_launch_latency_setting_is_requested_without_overriding_the_user(odinn):
-    """The Python layer asks the HIP runtime for device-memory kernel arguments (HIP_FORCE_DEV_KERNARG=1) before its first
-    HIP call, never overwriting a value the user has set; ODINN_KEEP_HIP_DEFAULTS=1 skips the request (fresh interpreters:
-    the setting is applied at import time)."""
+def test_importing_the_package_leaves_the_hip_environment_alone(odinn):
+    """HIP_FORCE_DEV_KERNARG is a process-wide runtime setting: neither the Python layer nor the library's loader sets it
+    unless asked to (ODINN_REQUEST_DEV_KERNARG=1, and then never over a value the user has set).  Fresh interpreters."""
     import os, subprocess, sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import sys; sys.path.insert(0, %r); import _odinn_import; _odinn_import.load(); import os; print(os.environ.get('HIP_FORCE_DEV_KERNARG'))" % root
-    for extra, want in (({}, "1"), ({"HIP_FORCE_DEV_KERNARG": "0"}, "0"), ({"ODINN_KEEP_HIP_DEFAULTS": "1"}, "None")):
-        env = {k: v for k, v in os.environ.items() if k not in ("HIP_FORCE_DEV_KERNARG", "ODINN_KEEP_HIP_DEFAULTS")}
+    code = ("import sys; sys.path.insert(0, %r); import _odinn_import; p = _odinn_import.load(); p._lib.lib(); import os, ctypes; "
+            "g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p; v = g(b'HIP_FORCE_DEV_KERNARG'); "  # (the C environment: the loader's setenv does not show in os.environ)
+            "print(os.environ.get('HIP_FORCE_DEV_KERNARG') if v is None else v.decode())" % root)
+    for extra, want in (({}, "None"), ({"HIP_FORCE_DEV_KERNARG": "0"}, "0"), ({"ODINN_REQUEST_DEV_KERNARG": "1"}, "1"),
+                        ({"ODINN_REQUEST_DEV_KERNARG": "1", "HIP_FORCE_DEV_KERNARG": "0"}, "0")):
+        env = {k: v for k, v in os.environ.items() if k not in ("HIP_FORCE_DEV_KERNARG", "ODINN_REQUEST_DEV_KERNARG")}
         env.update(extra)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-500:]
         assert out.stdout.strip().splitlines()[-1] == want, (extra, out.stdout)
+
+
+def test_library_does_not_link_rccl():
+    """RCCL is resolved lazily by the odinn_comm_* entry points (dlopen): single-GPU users can load the library on a machine
+    without it."""
+    import os, subprocess
+
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "odinn.jl_amd", "csrc", "libodinn_hip.so")
+    out = subprocess.run(["readelf", "-d", so], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("readelf not available")
+    needed = [l for l in out.stdout.splitlines() if "NEEDED" in l]
+    assert needed and not any("rccl" in l or "nccl" in l for l in needed), needed
 
 
 def test_log1p_table_recipe_is_within_two_ulp():
