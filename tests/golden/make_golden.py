@@ -97,6 +97,54 @@ def solve_case():
                 naccept=st.naccept)
 
 
+SOLVE_NQ = 24  # Gauss-Legendre nodes of the continuous-adjoint part of the whole-path dump
+PIECES_NHALF = 75
+
+
+def solve_case_continuous():
+    """The same case through the continuous adjoint (ContinuousAdjoint(n_quadrature = SOLVE_NQ), reltol = abstol = 1e-8)."""
+    c = solve_case()
+    ph = O.Phys()
+    mlp = O.default_nn(1, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
+    gl = O.Glacier(c["H0"], c["B"], 50.0, 50.0, ph)
+    cfg = O.SimConfig(tstops=list(c["ts"]), reltol=1e-8)
+    L, g, lam0, st = O.loss_and_grad_continuous(gl, O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=c["th0"], T=-2.0), cfg,
+                                                list(c["ref"]), list(c["ts"]), O.ContinuousAdjointCfg(n_quadrature=SOLVE_NQ))
+    return dict(loss=L, grad=g, lam0=lam0, naccept=st.naccept, nreject=st.nreject)
+
+
+def solve_case_forward():
+    """Forward solve of the case at theta0 (what run!(Prediction) / simulate_iceflow_UDE! produce): snapshots and step counts."""
+    c = solve_case()
+    ph = O.Phys()
+    mlp = O.default_nn(1, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
+    gl = O.Glacier(c["H0"], c["B"], 50.0, 50.0, ph)
+    snaps, st, _ = O.forward(gl, O.Law(kind=O.LAW_NN_A_SCALAR, mlp=mlp, theta=c["th0"], T=-2.0), O.SimConfig(tstops=list(c["ts"]), reltol=1e-8))
+    return dict(snaps=np.stack(snaps), naccept=st.naccept, nreject=st.nreject)
+
+
+def pieces_inputs():
+    """Inputs of the out-of-tree pieces (see oracle/julia/export_inputs.py::export_mask_cases)."""
+    H_a, B_a = O.synthetic_valley(64, 48, 50.0)
+    rng = np.random.default_rng(1234)
+    H_b = np.asfortranarray(np.abs(rng.standard_normal((33, 29))) * 40.0 + 1.0)
+    H_b[:, :4] = 0.0       # an ice-free strip; elsewhere the ice touches the border of the domain
+    H_b[10:14, 12:16] = 0.0  # a hole
+    H_b[25, 20] = 0.0        # a single ice-free cell
+    MB = np.asfortranarray(1.5 * np.random.default_rng(77).standard_normal(H_a.shape))
+    Hmb = np.asfortranarray(np.where(H_a > 0, H_a * np.random.default_rng(78).random(H_a.shape) * 0.2, 0.0))  # thin ice: the clip acts
+    return dict(H_a=H_a, H_b=H_b, MB=MB, Hmb=Hmb)
+
+
+def pieces_outputs():
+    p = pieces_inputs()
+    Hbar = O.avg(np.maximum(p["H_a"], 0.0))
+    mb = O.MassBalance(mb0=p["MB"], dmb_dS=0.0, S_ref=None, mb_max=np.inf)
+    Hn, inc = O.mb_apply(mb, p["Hmb"], np.zeros_like(p["Hmb"]))
+    return dict(mask_a=O.is_in_glacier(p["H_a"], 3).astype(np.float64), mask_b=O.is_in_glacier(p["H_b"], 3).astype(np.float64),
+                knots=np.asarray(O.create_interpolation(Hbar, PIECES_NHALF)), H_after_mb=Hn, mb_applied=inc)
+
+
 if __name__ == "__main__":
     for c in CASES:
         np.savez_compressed(os.path.join(HERE, f"rhs_{c}.npz"), **compute(c))
