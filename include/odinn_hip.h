@@ -145,6 +145,31 @@ typedef struct odinn_adjoint_opts {
   int64_t maxiters; /* params.solver.maxiters (gradient.jl:468) */
 } odinn_adjoint_opts;
 
+/* Kernel schedule of a batch: which of the library's equivalent kernel forms run (same arithmetic, results agree to rounding --
+ * see DESIGN.md "Different compilations of the same per-cell expression sequence").  Every field: -1 = automatic (the library's
+ * measured rule, the default), otherwise the forced choice.  The environment variable named with each field, if set,
+ * overrides the field (measurement / A-B aid).  `scheme` and `dense` of odinn_solver_opts stay per solve. */
+typedef struct odinn_schedule {
+  int32_t step_sc;         /* ODINN_STEP_SC: 1 = self-controlled step loop (no controller / post-step launches), 0 = off          */
+  int32_t fused_tiles;     /* ODINN_FUSED_TILES (s|l|t|u): fused step kernel -- 1 54x8 latency tiles, 2 54x40 tiles, 3 strip kernel
+                              with 7 rows per thread, 4 strip kernel with 8 rows per thread                                        */
+  int32_t dhdt_strip;      /* ODINN_DHDT_STRIP: 0 = keep the 64x16-tile RHS / CFL-Euler kernels instead of the strip layout        */
+  int32_t vjph_strip;      /* ODINN_VJPH_STRIP: H-VJP in the strip layout (1) or on 64x16 LDS tiles (0)                            */
+  int32_t vjpth_strip;     /* ODINN_VJPTH_STRIP: the same for the theta-VJP reduction                                              */
+  int32_t snap_on_load;    /* ODINN_SNAP_ON_LOAD: 0 = post-step launch per step instead of the snapshot-on-load two-launch loop    */
+  int32_t interp_streams;  /* ODINN_INTERP_STREAMS: side streams of the per-glacier `:Linear` interpolation sequences (1 ... 8)     */
+  int32_t interp_batch;    /* ODINN_INTERP_BATCH: 0 = one interpolation sequence per glacier instead of one per call (Y law)      */
+  int32_t lawgrad_wave;    /* ODINN_LAWGRAD_WAVE: 0 = per-thread accumulators for the gridded law's theta-gradient                */
+  int32_t vq_onepass;      /* ODINN_VQ_ONEPASS: 0 = interpolate / scale / pull-back / reduce sequence at the quadrature nodes of a
+                              velocity loss instead of the one-pass node kernel                                                    */
+  int32_t adj_fused;       /* ODINN_ADJ_FUSED: 0 = five k_adj_stage launches per reverse step instead of the fused reverse step   */
+  int32_t adj_skip;        /* ODINN_ADJ_SKIP: 0 = no ice-free shortcut in the fused reverse step                                   */
+  int32_t adj_segs;        /* ODINN_ADJ_SEGS: 0 = read the two snapshots instead of the interleaved {H_j, H_j+1 - H_j} pairs       */
+  int32_t adj_rows;        /* ODINN_ADJ_ROWS: 4 | 7 rows per thread of the fused reverse step                                      */
+  int32_t adj_theta_fused; /* ODINN_ADJ_THETA_FUSED: 0 = theta-VJP of a quadrature node in launches of its own                     */
+  int32_t reserved[5];     /* zero                                                                                                 */
+} odinn_schedule;
+
 typedef struct odinn_batch odinn_batch;
 
 const char* odinn_last_error(void);
@@ -156,6 +181,9 @@ int odinn_device_name(int dev, char* buf, int buflen);
 int odinn_batch_create(int device, int n_glaciers, const odinn_glacier_desc* descs, odinn_batch** out);
 int odinn_batch_destroy(odinn_batch* b);
 int odinn_batch_sync(odinn_batch* b);
+/* sc == NULL: everything automatic.  odinn_get_schedule returns what is in effect (environment overrides applied). */
+int odinn_set_schedule(odinn_batch* b, const odinn_schedule* sc);
+int odinn_get_schedule(odinn_batch* b, odinn_schedule* out);
 int odinn_set_fields(odinn_batch* b, int g, const double* H0, const double* B);
 int odinn_set_A(odinn_batch* b, int g, double A);
 int odinn_set_A_field(odinn_batch* b, int g, const double* A_dual);   /* CONST_A, gridded  */

@@ -18,6 +18,11 @@ struct SolverOpts; reltol::Float64; abstol::Float64; dtmax::Float64; dt0::Float6
                    maxiters::Int64; scheme::Int32; dense::Int32; cfl::Float64; end
 struct AdjointOpts; reltol::Float64; abstol::Float64; dtmax::Float64; n_quadrature::Int32; reserved::Int32
                     maxiters::Int64; end
+# odinn_schedule: which of the library's equivalent kernel forms run (-1 = automatic); set_schedule!(batch; adj_fused = 0, ...)
+struct Schedule; step_sc::Int32; fused_tiles::Int32; dhdt_strip::Int32; vjph_strip::Int32; vjpth_strip::Int32
+                 snap_on_load::Int32; interp_streams::Int32; interp_batch::Int32; lawgrad_wave::Int32; vq_onepass::Int32
+                 adj_fused::Int32; adj_skip::Int32; adj_segs::Int32; adj_rows::Int32; adj_theta_fused::Int32
+                 reserved::NTuple{5, Int32}; end
 SolverOpts(solver) = SolverOpts(solver.reltol, 1e-6, 0.0, 0.0, 0.0, Int64(solver.maxiters), Int32(0), Int32(0), 0.0)
 AdjointOpts(grad::ODINN.ContinuousAdjoint, solver) =
     AdjointOpts(grad.reltol, grad.abstol, grad.dtmax, Int32(grad.n_quadrature), Int32(0), Int64(solver.maxiters))
@@ -97,6 +102,14 @@ function set_glacier_stops!(b::Batch, simulation)
         ts = collect(Float64, glacier_tstops(simulation, i))
         check(ccall((:odinn_set_glacier_stops, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}), b.h, i - 1, length(ts), ts))
     end
+end
+
+function set_schedule!(b; kw...)
+    f = fieldnames(Schedule)[1:15]
+    unknown = setdiff(keys(kw), f)
+    isempty(unknown) || error("unknown schedule field(s): $(unknown)")
+    sc = Ref(Schedule((Int32(get(kw, k, -1)) for k in f)..., ntuple(_ -> Int32(0), 5)))
+    check(ccall((:odinn_set_schedule, lib), Cint, (Ptr{Cvoid}, Ptr{Schedule}), b.h, sc))
 end
 
 # terms of a MultiLoss the library evaluates next to the data loss (src/losses/TimeAggregatedLosses.jl, Regularization.jl:192-245):

@@ -360,6 +360,17 @@ class GlacierBatch:
         self.tstops = ts
         return [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
 
+    def set_schedule(self, **fields):
+        """odinn_set_schedule: force kernel forms (fields of odinn_schedule, -1 / omitted = automatic); no argument: all automatic."""
+        sc = L.Schedule(**fields)
+        L.check(L.lib().odinn_set_schedule(self._h, C.byref(sc)))
+
+    def get_schedule(self):
+        """The schedule in effect (environment overrides applied) as a dict."""
+        sc = L.Schedule()
+        L.check(L.lib().odinn_get_schedule(self._h, C.byref(sc)))
+        return {k: getattr(sc, k) for k in L.SCHEDULE_FIELDS}
+
     def set_glacier_stops(self, g, t=None):
         """Glacier g's own stop table (the reference builds tstops per glacier, inversion_utils.jl:487-495); None / empty clears.
         The `tstops` of solve / loss_grad* then serve the glaciers without one; first and last stop must equal theirs."""

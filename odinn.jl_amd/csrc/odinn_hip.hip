@@ -137,7 +137,16 @@ int mlp_nparams(const odinn_mlp_desc& m) {
 
 }  // namespace
 
+// Kernel-schedule switch: the environment variable (a measurement / A-B override) if it is set, else the batch's
+// odinn_schedule field, else -1 = the library's own measured rule.  Flags are '0' / '1' (any other digit string: atoi).
+static int sched_val(int field, const char* env) {
+  if (const char* e = std::getenv(env))
+    if (e[0] >= '0' && e[0] <= '9') return std::atoi(e);
+  return field;
+}
+
 struct odinn_batch {
+  odinn_schedule sched = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -155,9 +164,9 @@ struct odinn_batch {
   int ntilesD = 0;
   int ntilesF = 0, ntilesFs = 0, ntilesFt = 0, ntilesFu = 0, ntilesFv = 0;
   double *d_partF = nullptr, *d_partFs = nullptr, *d_partFt = nullptr, *d_partFu = nullptr, *d_partFv = nullptr;
-  static int sc_env() {  // ODINN_STEP_SC: -1 unset, 0 off, 1 forced on
-    const char* e = std::getenv("ODINN_STEP_SC");
-    return !e ? -1 : (e[0] == '1' ? 1 : 0);
+  int sc_env() const {  // odinn_schedule::step_sc / ODINN_STEP_SC: -1 automatic, 0 off, 1 forced on
+    const int v = sched_val(sched.step_sc, "ODINN_STEP_SC");
+    return v < 0 ? -1 : (v == 1 ? 1 : 0);
   }
   static int n_cus() {  // compute units of the current device (256 on MI355X)
     static int n = 0;
@@ -167,13 +176,14 @@ struct odinn_batch {
     }
     return n;
   }
-  mutable int fused_env = -1;  // ODINN_FUSED_TILES, parsed once: 0 unset, 1 small, 2 large, 3 t (strip, 7 rows), 4 u (strip, 8 rows)
+  // odinn_schedule::fused_tiles / ODINN_FUSED_TILES (s | l | t | u, or the digit): 0 automatic, 1 small, 2 large,
+  // 3 strip with 7 rows per thread, 4 strip with 8 rows per thread
   int fused_override() const {
-    if (fused_env < 0) {
-      const char* e = std::getenv("ODINN_FUSED_TILES");
-      fused_env = !e ? 0 : e[0] == 's' ? 1 : e[0] == 'l' ? 2 : e[0] == 't' ? 3 : e[0] == 'u' ? 4 : 0;
+    if (const char* e = std::getenv("ODINN_FUSED_TILES")) {
+      const int v = e[0] == 's' ? 1 : e[0] == 'l' ? 2 : e[0] == 't' ? 3 : e[0] == 'u' ? 4 : (e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 0;
+      if (v) return v;
     }
-    return fused_env;
+    return sched.fused_tiles >= 1 && sched.fused_tiles <= 4 ? sched.fused_tiles : 0;
   }
   // which fused-step kernel / tile table: 0 = FOX x FOY row-interleaved kernel, 1 = FOX x FOYS latency tiles of the
   // same kernel (a workgroup walks 18 region rows instead of 50: batches too small to fill the 256 CUs), 2 = FOX x FOYT
@@ -547,7 +557,7 @@ int down_field(odinn_batch* b, int g, const double* dpool, double* h, bool dual 
 // ---- launches -------------------------------------------------------------------------
 int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */) {
   // integer-power law, whole batch (or a batch of one glacier): the strip-layout RHS kernel; ODINN_DHDT_STRIP=0 keeps k_dhdt
-  static const bool strip_on = !(std::getenv("ODINN_DHDT_STRIP") && std::getenv("ODINN_DHDT_STRIP")[0] == '0');
+  const bool strip_on = sched_val(b->sched.dhdt_strip, "ODINN_DHDT_STRIP") != 0;
   if (strip_on && b->lm() == 0 && (g < 0 || b->G == 1)) {
     launch_dhdt_strip(b->ntilesD, b->gd[0].use_Afield, 1, b->stream, b->pools(true), b->d_tilesD, U, dH);
     HIPCHK(hipGetLastError());
@@ -579,8 +589,8 @@ void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawD
   // (sia2d_adj_fused.hpp: k_vjp_H_strip; ODINN_VJPH_STRIP=0 keeps the 64 x 16 LDS-tile kernel) ...
   // ... where its 62 x 62 tiles are reasonably full: batches of small glaciers (alpine: 96 x 80 ... 192 x 160 fill them to
   // 50-67 %) stay on the 64 x 16 tiles (measured: 512 alpine glaciers 53.9 k vs 48.9 k gradients/s); ODINN_VJPH_STRIP=1 forces it
-  const char* se = std::getenv("ODINN_VJPH_STRIP");
-  const bool strip_on = se ? se[0] != '0' : (double)b->ntot >= 0.75 * (double)b->ntilesD * (DHDT_OX * DHDT_OY);
+  const int se = sched_val(b->sched.vjph_strip, "ODINN_VJPH_STRIP");
+  const bool strip_on = se >= 0 ? se != 0 : (double)b->ntot >= 0.75 * (double)b->ntilesD * (DHDT_OX * DHDT_OY);
   const int vje = vj < 0 ? b->vjp_method : vj;
   if (strip_on && b->lm() == 0 && vje == ODINN_VJP_DISCRETE && !A.snaps && base == 0 && nblk == b->ntiles &&
       !(mode == 1 && b->h_log_eps > 0.0) &&  // (LossH with LogSum: the tile kernel carries that branch)
@@ -603,8 +613,8 @@ void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L,
       launch_vjp_theta_lm5};
   // integer-power A-type laws, all glaciers at once: the strip-layout reduction (k_vjp_theta_strip), under the same
   // tile-fullness rule as k_vjp_H_strip; ODINN_VJPTH_STRIP=0/1 forces the choice
-  const char* se = std::getenv("ODINN_VJPTH_STRIP");
-  const bool strip_on = se ? se[0] != '0' : (double)b->ntot >= 0.75 * (double)b->ntilesD * (DHDT_OX * DHDT_OY);
+  const int se = sched_val(b->sched.vjpth_strip, "ODINN_VJPTH_STRIP");
+  const bool strip_on = se >= 0 ? se != 0 : (double)b->ntot >= 0.75 * (double)b->ntilesD * (DHDT_OX * DHDT_OY);
   if (strip_on && b->lm() == 0 && !A.emitH && base == 0 && nblk == b->ntiles && (P.tiles == b->d_tiles || b->G == 1)) {
     launch_vjp_theta_strip(A.Gacc ? 1 : 0, A.snaps ? 1 : 0, b->ntilesD, b->stream, P, b->d_tilesD, A);
     return;
@@ -615,8 +625,7 @@ void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L,
 // integer-power law: the CFL Euler step runs in the strip layout (k_dhdt_strip<.., EULER>) with its own tile table and
 // per-tile max-D partials; ODINN_DHDT_STRIP=0 keeps the 64 x 16 tile kernel
 static bool euler_strip(const odinn_batch* b) {
-  static const bool on = !(std::getenv("ODINN_DHDT_STRIP") && std::getenv("ODINN_DHDT_STRIP")[0] == '0');
-  return on && b->lm() == 0;
+  return sched_val(b->sched.dhdt_strip, "ODINN_DHDT_STRIP") != 0 && b->lm() == 0;
 }
 void launch_euler_cfl(odinn_batch* b, const Pools& P, const LawDev& L, const double* src, double* dst) {
   if (euler_strip(b)) {
@@ -695,7 +704,7 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
 // up to 640 strip tiles.
 static bool sc_mode(const odinn_batch* b, int scheme) {
   if (scheme != 2 || b->fused_kind() < 2 || (b->any_mb && b->gd[0].use_Afield)) return false;  // MB on load: constant-A path
-  if (const char* e = std::getenv("ODINN_STEP_SC")) return e[0] == '1';
+  if (b->sc_env() >= 0) return b->sc_env() == 1;
   return b->fused_ntiles() <= 640;  // re-measured with the 5.9 us controller and the two-launch loop (tools/sc_probe3.py): see above
 }
 // Large batches (no self-controlled loop) without a mass balance: the strip step kernel stores the snapshot of a stop
@@ -703,9 +712,9 @@ static bool sc_mode(const odinn_batch* b, int scheme) {
 // three; the snapshot of the LAST stop (after which no launch loads the state again) is a device copy at the end of the
 // solve.  ODINN_SNAP_ON_LOAD=0 restores the post-step launch.
 static bool snap_on_load_mode(const odinn_batch* b, int scheme, bool sc) {
-  const char* e = std::getenv("ODINN_SNAP_ON_LOAD");  // read per call: tests toggle it
+  const int e = sched_val(b->sched.snap_on_load, "ODINN_SNAP_ON_LOAD");  // read per call: tests toggle it
   // (with a mass balance: the constant-A strip kernels apply it on load -- GState::pad bit 2, kept by the controller)
-  return !(e && e[0] == '0') && scheme == 2 && !sc && b->fused_kind() >= 2 && (!b->any_mb || !b->gd[0].use_Afield);
+  return e != 0 && scheme == 2 && !sc && b->fused_kind() >= 2 && (!b->any_mb || !b->gd[0].use_Afield);
 }
 static int sc_buffers(odinn_batch* b) {
   if (!b->d_gs2) CHK(dalloc(&b->d_gs2, (size_t)b->G));
@@ -1760,7 +1769,7 @@ static int ensure_interp_scratch(odinn_batch* b) {
     long long ndmax = 1;
     for (const GDev& r : b->gd) ndmax = std::max(ndmax, (long long)(r.nx - 1) * (r.ny - 1));
     int lanes = std::min(b->G, (int)odinn_batch::INTERP_LANES_MAX);
-    if (const char* e = std::getenv("ODINN_INTERP_STREAMS")) lanes = std::max(1, std::min(lanes, std::atoi(e)));
+    if (const int e = sched_val(b->sched.interp_streams, "ODINN_INTERP_STREAMS"); e >= 1) lanes = std::max(1, std::min(lanes, e));
     b->interp_lanes = lanes;
     b->interp_ndmax = ndmax;
     CHK(dalloc(&b->d_nodeH, (size_t)b->ntotd)); CHK(dalloc(&b->d_nodeV, (size_t)b->ntotd));
@@ -1851,8 +1860,8 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
     // dtheta_g (+)= sum_knots c_k dY/dtheta(T_g, knot_k): sort the glacier's nodes by Hbar, build its knots, sum per interval
     const LawDev L = b->lawdev();
     // Y law: all glaciers of the call in one sequence of launches (ODINN_INTERP_BATCH=0: one sequence per glacier)
-    const char* eb = std::getenv("ODINN_INTERP_BATCH");
-    if (!linU && b->d_ib_gid && !(eb && eb[0] == '0') && interp_batch_lds_bytes(b->P) <= 30 * 1024) {
+    const int eb = sched_val(b->sched.interp_batch, "ODINN_INTERP_BATCH");
+    if (!linU && b->d_ib_gid && eb != 0 && interp_batch_lds_bytes(b->P) <= 30 * 1024) {
       const long long lo = b->gd[g0].offd;
       const long long hi = g0 + ng < b->G ? b->gd[g0 + ng].offd : b->ntotd;
       const int rc = launch_interp_theta_batch(b->stream, P, L, b->n_interp_half, g0, ng, lo, hi - lo, b->d_nodeH, b->d_nodeV,
@@ -1907,9 +1916,9 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
 static int gridded_law_grad(odinn_batch* b, long long lo, long long n, double* dtheta_host) {
   int nblk = (int)((n + NT - 1) / NT);
   // wave-reduced kernel (accumulators in LDS) while they fit; ODINN_LAWGRAD_WAVE=0: per-thread accumulators in global memory
-  const char* ew = std::getenv("ODINN_LAWGRAD_WAVE");
+  const int ew = sched_val(b->sched.lawgrad_wave, "ODINN_LAWGRAD_WAVE");
   const size_t dyn = (size_t)NW * b->P * sizeof(double) + (size_t)b->P * sizeof(int);
-  if (!(ew && ew[0] == '0') && dyn <= 30 * 1024) {  // + 33 KB of static staging area: within the 64 KB of a workgroup
+  if (ew != 0 && dyn <= 30 * 1024) {  // + 33 KB of static staging area: within the 64 KB of a workgroup
     const int max_rows = 2048;
     CHK(ensure_theta_scratch(b, max_rows, false));
     nblk = launch_law_field_grad(b->stream, b->lawdev(), b->d_Tfield + lo, b->d_Gacc + lo, n, b->d_part_theta, max_rows);
@@ -2227,6 +2236,38 @@ int odinn_set_glacier_stops(odinn_batch* b, int g, int n, const double* t) {
     if (!(t[j] > t[j - 1])) return fail(ODINN_ERR_ARG, "the stops of glacier %d must be strictly increasing", g);
   b->own_stops.resize(b->G);
   b->own_stops[g].assign(t, t + n);
+  return ODINN_OK;
+}
+
+int odinn_set_schedule(odinn_batch* b, const odinn_schedule* sc) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
+  const odinn_schedule automatic = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
+  b->sched = sc ? *sc : automatic;
+  if (b->sched.adj_rows >= 0 && b->sched.adj_rows != 4 && b->sched.adj_rows != 7)
+    return fail(ODINN_ERR_ARG, "odinn_schedule.adj_rows must be -1, 4 or 7");
+  if (b->sched.fused_tiles > 4) return fail(ODINN_ERR_ARG, "odinn_schedule.fused_tiles must be -1 ... 4");
+  return ODINN_OK;
+}
+
+int odinn_get_schedule(odinn_batch* b, odinn_schedule* out) {
+  if (!b || !out) return fail(ODINN_ERR_ARG, "null argument");
+  *out = b->sched;
+  // what is in effect: an environment override wins over the field
+  out->step_sc = sched_val(b->sched.step_sc, "ODINN_STEP_SC");
+  out->fused_tiles = b->fused_override() ? b->fused_override() : -1;
+  out->dhdt_strip = sched_val(b->sched.dhdt_strip, "ODINN_DHDT_STRIP");
+  out->vjph_strip = sched_val(b->sched.vjph_strip, "ODINN_VJPH_STRIP");
+  out->vjpth_strip = sched_val(b->sched.vjpth_strip, "ODINN_VJPTH_STRIP");
+  out->snap_on_load = sched_val(b->sched.snap_on_load, "ODINN_SNAP_ON_LOAD");
+  out->interp_streams = sched_val(b->sched.interp_streams, "ODINN_INTERP_STREAMS");
+  out->interp_batch = sched_val(b->sched.interp_batch, "ODINN_INTERP_BATCH");
+  out->lawgrad_wave = sched_val(b->sched.lawgrad_wave, "ODINN_LAWGRAD_WAVE");
+  out->vq_onepass = sched_val(b->sched.vq_onepass, "ODINN_VQ_ONEPASS");
+  out->adj_fused = sched_val(b->sched.adj_fused, "ODINN_ADJ_FUSED");
+  out->adj_skip = sched_val(b->sched.adj_skip, "ODINN_ADJ_SKIP");
+  out->adj_segs = sched_val(b->sched.adj_segs, "ODINN_ADJ_SEGS");
+  out->adj_rows = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS");
+  out->adj_theta_fused = sched_val(b->sched.adj_theta_fused, "ODINN_ADJ_THETA_FUSED");
   return ODINN_OK;
 }
 
@@ -2567,7 +2608,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   // (k_surfV_theta_node, which interpolates H itself) instead of the interpolate / scale / pull-back / reduce sequence
   // (ODINN_VQ_ONEPASS=0 selects that sequence); d_tmpA then is only needed at the snapshot stops
   bool vq_onepass = useV && lm <= 1 && !b->vel_nn();
-  if (const char* e = std::getenv("ODINN_VQ_ONEPASS")) vq_onepass = vq_onepass && e[0] != '0';
+  vq_onepass = vq_onepass && sched_val(b->sched.vq_onepass, "ODINN_VQ_ONEPASS") != 0;
   const bool theta_itp = (!useV || vq_onepass) && b->law_kind < ODINN_LAW_NN_Y;
   AP.refslot = b->d_refslot; AP.G = G; AP.loss_first = 1; AP.Hq = (theta_itp && !useV) ? nullptr : b->d_tmpA;
   AP.hq_snap_only = vq_onepass ? 1 : 0;
@@ -2649,8 +2690,8 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   // (sia2d_adj_fused.hpp) -- measured faster at every batch size, 4 alpine glaciers included; ODINN_ADJ_FUSED=0
   // selects the five k_adj_stage launches
   bool fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE;
-  if (const char* e = std::getenv("ODINN_ADJ_FUSED")) fused_rev = fused_rev && e[0] != '0';
-  const int rev_skip = []() { const char* e = std::getenv("ODINN_ADJ_SKIP"); return (e && e[0] == '0') ? 0 : 1; }();
+  fused_rev = fused_rev && sched_val(b->sched.adj_fused, "ODINN_ADJ_FUSED") != 0;
+  const int rev_skip = sched_val(b->sched.adj_skip, "ODINN_ADJ_SKIP") == 0 ? 0 : 1;
   AdjFusedArgs FA{};
   int adj_rows = TRPT;  // rows per thread of the fused reverse step
   if (fused_rev) {
@@ -2659,13 +2700,13 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     C.errpart = b->d_partFt; C.stride = 1; C.fused = 3;
     // the two bracketing snapshots of every segment interleaved as {H_j, H_j+1 - H_j}: one 16-byte load per cell and
     // stage instead of two 8-byte ones (ODINN_ADJ_SEGS=0: read the snapshots themselves)
-    const char* es = std::getenv("ODINN_ADJ_SEGS");
+    const int es = sched_val(b->sched.adj_segs, "ODINN_ADJ_SEGS");
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const size_t need = (size_t)(k - 1) * b->ntot;
     // (a second copy of the snapshots, twice their size: only while it takes less than half of what is free)
     const bool fits = need <= b->segs_cap || need * sizeof(double2) <= free_b / 2;
-    if (!(es && es[0] == '0') && fits) {
+    if (es != 0 && fits) {
       if (need > b->segs_cap) {
         if (b->d_segs) (void)hipFree(b->d_segs);
         b->d_segs = nullptr; b->segs_cap = 0;
@@ -2681,10 +2722,10 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     // 16 / 24: ties within 3 %, 32: 16.3 -> 13.4, 48 / 64: 7 rows win; 1 x 256^2 ... 512^2: 8.2 -> 6.6 ms, 768^2 and up: 7 rows
     // win -- the model's order every time).  ODINN_ADJ_ROWS=4|7 forces either
     if (FA.segs) {
-      const char* er = std::getenv("ODINN_ADJ_ROWS");
+      const int er = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS");
       const long cu = b->n_cus();
       const bool model = b->ntilesFt <= 2 * cu && 4 * ((b->ntilesFv + cu - 1) / cu) < 7 * ((b->ntilesFt + cu - 1) / cu);
-      if (er ? er[0] == '4' : model) {
+      if (er == 4 || er == 7 ? er == 4 : model) {
         adj_rows = 4;
         FA.partF = b->d_partFv; FA.tilesF = b->d_tilesFv;
         C.errpart = b->d_partFv; C.fused = 6;
@@ -2693,11 +2734,11 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     const int ntilesR = adj_rows == 4 ? b->ntilesFv : b->ntilesFt;
     // A-type laws without a dual-grid accumulator: the theta-VJP of a quadrature node is formed by stage 1 of the step that
     // follows the node (same lambda, same H_itp) instead of a launch of its own (ODINN_ADJ_THETA_FUSED=0: separate launches)
-    const char* et = std::getenv("ODINN_ADJ_THETA_FUSED");
+    const int et = sched_val(b->sched.adj_theta_fused, "ODINN_ADJ_THETA_FUSED");
     // (with a dual-grid accumulator -- gridded A -- the same stage also adds the node weights into d_Gacc: needs the
     //  interleaved snapshot pairs, whose kernel instantiations carry that variant)
     const bool gacc_fused = b->wants_Gacc() && FA.segs && b->gd[0].use_Afield;
-    if (acc_inplace && (!b->wants_Gacc() || gacc_fused) && !(et && et[0] == '0')) {
+    if (acc_inplace && (!b->wants_Gacc() || gacc_fused) && et != 0) {
       if (gacc_fused) FA.Gacc = b->d_Gacc;
       if ((size_t)ntilesR > b->partTh_cap) {
         dfree(b->d_partTh);
@@ -3135,7 +3176,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
       AdjFusedArgs FA{};
       FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
       FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = 1e-8; FA.reltol = 1e-8;
-      { const char* es = std::getenv("ODINN_ADJ_SEGS"); if (!(es && es[0] == '0')) FA.segs = b->d_segs; }
+      if (sched_val(b->sched.adj_segs, "ODINN_ADJ_SEGS") != 0) FA.segs = b->d_segs;
       launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, std::getenv("ODINN_TIMED_ADJ_SKIP") ? 1 : 0, TRPT, b->stream, P, FA);
       return ODINN_OK;
     }

@@ -33,6 +33,11 @@ def test_struct_layouts_match_the_header(odinn):
     assert L.MlpDesc.pre_lo.offset == 80 and L.MlpDesc.post_lo.offset == 120
     assert ctypes.sizeof(L.SolverOpts) == 64 and L.SolverOpts.cfl.offset == 56 and ctypes.sizeof(L.SolveStats) == 40
     assert ctypes.sizeof(L.AdjointOpts) == 40 and L.AdjointOpts.maxiters.offset == 32
+    assert ctypes.sizeof(L.Schedule) == 80 and L.Schedule.adj_theta_fused.offset == 56
+    hdr = open(os.path.join(ROOT, "include", "odinn_hip.h")).read()
+    body = re.search(r"typedef struct odinn_schedule \{(.*?)\} odinn_schedule;", hdr, flags=re.S).group(1)
+    fields = re.findall(r"int32_t\s+([a-z_]+)\s*;", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert tuple(fields) == L.SCHEDULE_FIELDS, "odinn_schedule fields out of sync with the ctypes mirror"
 
 
 def test_no_silent_cpu_fallback(odinn):
@@ -133,7 +138,8 @@ def test_julia_shim_ccalls_match_the_header_prototypes():
                  "odinn_loss_grad_continuous", "odinn_batch_loss_grad", "odinn_comm_init_rank", "odinn_comm_get_unique_id"):
         assert need in seen, need
     # struct mirrors: same field count as the C structs
-    for jl, cname, n in (("SolverOpts", "odinn_solver_opts", 9), ("AdjointOpts", "odinn_adjoint_opts", 6), ("Phys", "odinn_phys", 9)):
+    for jl, cname, n in (("SolverOpts", "odinn_solver_opts", 9), ("AdjointOpts", "odinn_adjoint_opts", 6), ("Phys", "odinn_phys", 9),
+                         ("Schedule", "odinn_schedule", 16)):
         m = re.search(r"struct %s;(.*?)end" % jl, txt, flags=re.S)
         assert m and len(re.findall(r"::", m.group(1))) == n, jl
     assert "mean_temp(" in txt and re.search(r"^mean_temp\(", txt, flags=re.M), "mean_temp must be defined in the shim"
