@@ -30,12 +30,15 @@ void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev
 // strip kernel (integer-power law) on the FOX x FOYT (rows = 7) or FOX x FOYT8 (rows = 8) tile table; sc != null:
 // self-controlled step (no controller / post-step launches, see ScArgs)
 void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
-                           double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc) {
+                           double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc, int sq) {
   const ScArgs A = sc ? *sc : ScArgs{};
   // measurement aid: ODINN_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the occupancy (A/B of waves per SIMD)
   static const unsigned pad = std::getenv("ODINN_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ODINN_LDS_PAD")) : 0u;
+  // sq: dx == dy on every glacier of the batch (one multiplication less per node, bit-identical)
+#define ODINN_STRIP_Q(SK, AF, NR, SCV, SQV) \
+  hipLaunchKernelGGL((k_rk_fused_strip<SK, AF, NR, SCV, SQV>), dim3(nblk), dim3(TNT), pad, st, P, L, tilesF, U0, U1, partF, abstol, reltol, A)
 #define ODINN_STRIP(SK, AF, NR, SCV) \
-  hipLaunchKernelGGL((k_rk_fused_strip<SK, AF, NR, SCV>), dim3(nblk), dim3(TNT), pad, st, P, L, tilesF, U0, U1, partF, abstol, reltol, A)
+  do { if (sq) ODINN_STRIP_Q(SK, AF, NR, SCV, true); else ODINN_STRIP_Q(SK, AF, NR, SCV, false); } while (0)
 #define ODINN_STRIP_S(SK, AF, NR) \
   do { if (sc && !sc->snap_on_load) ODINN_STRIP(SK, AF, NR, true); else ODINN_STRIP(SK, AF, NR, false); } while (0)
 #define ODINN_STRIP_R(SK, AF) \
@@ -48,6 +51,7 @@ void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools
 #undef ODINN_STRIP_R
 #undef ODINN_STRIP_S
 #undef ODINN_STRIP
+#undef ODINN_STRIP_Q
 }
 // RHS-only strip kernel on the DOX x DOY tile table
 void launch_dhdt_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, const int4* tilesD, const double* U, double* dH) {

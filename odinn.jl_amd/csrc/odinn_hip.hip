@@ -682,10 +682,12 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
   const int nblk = b->fused_ntiles();
   const int4* tiles = b->fused_tiles();
   double* part = part_override ? part_override : b->fused_part();
-  if (small >= 2)
+  if (small >= 2) {
+    bool sq = true;  // square cells everywhere: the kernel instantiation without the dx / dy ratio (bit-identical, 2.5 % fewer VALU instructions)
+    for (const GDev& r : b->gd) sq = sq && r.dx == r.dy;
     launch_rk_fused_strip(nblk, b->gd[0].use_Afield, small == 3 ? 8 : TRPT, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol,
-                          reltol, skip, sc);
-  else {
+                          reltol, skip, sc, sq ? 1 : 0);
+  } else {
     static void (*const tab[6])(int, hipStream_t, Pools, LawDev, const int4*, double*, double*, double*, double, double, int, int) = {
         launch_rk_fused_lm0, launch_rk_fused_lm1, launch_rk_fused_lm2, launch_rk_fused_lm3, launch_rk_fused_lm4, launch_rk_fused_lm5};
     tab[b->lm()](nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);

@@ -439,7 +439,7 @@ __device__ __forceinline__ double2 cell_HS(double uu, double b) {
 // sE[buf][w][0 | 1][lane]: {Hc, S} of the first | last row of wavefront w's strip
 typedef double2 (*StripEdges)[TNW][2][FRX];
 
-template <int S, bool AF, int NR, bool UPL>
+template <int S, bool AF, int NR, bool UPL, bool SQ>
 __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                              const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                              double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
@@ -466,7 +466,9 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   auto node = [&](int slot, double dxb, double hpb, double dxt, double hpt, double dyw, double dye) {
     const double a = dxb + dxt, b = dyw + dye;
     const double H4s = hpb + hpt;  // 4 Hbar
-    const double gS2 = fma(a, a, (ryx * b) * b);
+    // SQ (dx == dy on every glacier of the launch): ryx == 1.0 exactly, and (1.0 * b) * b == b * b bit for bit -- one
+    // multiplication less per node (2.5 % of the kernel's VALU instructions)
+    const double gS2 = SQ ? fma(a, a, b * b) : fma(a, a, (ryx * b) * b);
     const double H2 = H4s * H4s, H4 = H2 * H2;
     return (AF ? sA[slot][threadIdx.x] : AGq) * (H4 * H4s) * gS2;  // sA: A Gam / (1024 (2dx)^2) of the thread's own nodes
   };
@@ -544,16 +546,16 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   }
 }
 
-template <bool AF, int NR, bool UPL>
+template <bool AF, int NR, bool UPL, bool SQ>
 __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                               const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                               double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
                                               double (&E)[NR], const double (&bb)[NR]) {
-  strip_stage<1, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<2, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<3, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<4, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<5, AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<1, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<2, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<3, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<4, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+  strip_stage<5, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
 }
 
 // ---- self-controlled step (SC): no controller / post-step launches ---------------------------------------
@@ -635,7 +637,7 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
 // spills (a separate predicate-free kernel for the tiles strictly inside the grid was measured and lost: its
 // second launch costs more than the selects it saves).
 // NR: rows per thread (7: 54x46 output tiles; 8: 54x54 tiles, less halo work, for batches that fill the GPU twice over)
-template <bool SKIP, bool AF, int NR, bool SC = false>
+template <bool SKIP, bool AF, int NR, bool SC = false, bool SQ = false>
 __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, LawDev L, const int4* __restrict__ tilesF,
                                                                     double* __restrict__ U0, double* __restrict__ U1,
                                                                     double* __restrict__ partF, double abstol, double reltol,
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
 #pragma unroll
     for (int m = 0; m <= NR; ++m) sA[AF ? m : 0][threadIdx.x] = aa[AF ? m : 0] * Gq;
   }
-  strip_stages<AF, NR, UPL>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
+  strip_stages<AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
   // ---- output rows [FH, (NR * TNW)-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
   double upf[NR];

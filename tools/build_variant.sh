@@ -13,5 +13,5 @@ hipcc $F -c k_adjf.hip -o $out/k_adjf.o &
 wait
 objs=""
 for o in k_misc k_vel k_interp k_fwd0 k_fwd1 k_fwd2 k_fwd3 k_fwd4 k_fwd5 k_adj0 k_adj1 k_adj2 k_adj3 k_adj4 k_adj5 k_fused2 k_fused3 k_fused4 k_fused5; do objs="$objs $o.o"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libodinn_$name.so $out/odinn_hip.o $out/k_fused0.o $out/k_fused1.o $out/k_adjf.o $objs -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libodinn_$name.so $out/odinn_hip.o $out/k_fused0.o $out/k_fused1.o $out/k_adjf.o $objs -ldl
 echo built variants/libodinn_$name.so
