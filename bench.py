@@ -28,7 +28,7 @@ Prints ONE JSON line (rank 0):
   roofline            dominant kernel of the timed region, k_rk_fused_strip<gridded A, 8 rows>: a whole
                       RDPK3Sp35 step in one launch.  It moves ~32 B/cell (R u,B,A  W u'), so it is NOT
                       HBM-bound: bound = fp64 VALU.  achieved = useful fp64 flops per launch / launch time;
-                      flops per cell-stage come from the committed PMC pass (profiles/r02/pmc_roofline.json:
+                      flops per cell-stage come from the committed PMC pass (profiles/r03/pmc_roofline.json:
                       SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 per launch / executed cell-stages incl. halo), useful
                       cell-stages = 5 * cells (halo recomputation is not counted as useful work).
   roofline_hbm        the north-star kernel: the fused SIA2D+NN RHS stencil (k_dhdt, gridded A) on a working
@@ -66,10 +66,10 @@ B_PER_CELL_DHDT_NN = 32.0  # + the dual-grid A field
 B_PER_CELL_VJPH = 32.0
 B_PER_CELL_FUSED = 24.0  # fused step kernel: R u,B  W u'
 B_PER_CELL_FUSED_NN = 32.0  # + the dual-grid A field
-# fp64 flops per EXECUTED cell-stage of the strip kernel, fallback when profiles/r02/pmc_roofline.json is absent:
+# fp64 flops per EXECUTED cell-stage of the strip kernel, fallback when profiles/r0x/pmc_roofline.json is absent:
 # profiles/r01/pmc_fused_strip_sq.md: (9.60 + 14.03 + 2 x 11.12) M wave-instr x 64 lanes / (2888 tiles x 4096 cells x 5)
 FLOP_PER_CELL_STAGE_FALLBACK = 49.7
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_roofline.json")
+PMC_FILES = [os.path.join(ROOT, "profiles", r, "pmc_roofline.json") for r in ("r03", "r02")]  # newest committed pass first
 
 
 def make_glacier(n, gidx, dx=100.0):
@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-eval", action="store_true")
     ap.add_argument("--no-hbm-sweep", action="store_true")
+    ap.add_argument("--no-full-config", action="store_true", help="skip aux.full_config_one_gpu (all 64 x 1024^2 glaciers of configs[4] on one GPU)")
+    ap.add_argument("--full-config-glaciers", type=int, default=64)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -175,6 +177,8 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks use the same path
             if float(ok.item()) == 0.0:
                 odinn.api._DIST["comm"] = None
+                if "failed" not in comm_note:
+                    comm_note = "torch.distributed (nccl); odinn_comm_init_rank failed on another rank"
     if odinn.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
 
@@ -192,6 +196,8 @@ def main():
                          None, odinn.POST_AFFINE, ph.minA, ph.maxA)
     thetaA = np.random.default_rng(1234).uniform(-0.5, 0.5, mlpA.n_params)
     b.set_law(odinn.LAW_NN_A_GRIDDED, mlpA, thetaA)
+
+    sched_in_effect = b.get_schedule()
 
     def barrier():
         b.sync()
@@ -333,6 +339,43 @@ def main():
         "vjp_theta_GBs": 24.0 * cells / (ms_vjpt * 1e-3) / 1e9,
     }
     aux["hbm_past_infinity_cache"] = hbm
+
+    # ---- the WHOLE configs[4] batch on ONE GPU (64 x 1024^2 resident): the strong-scaling anchor of "8 GPUs vs 1" ----------
+    if rank == 0 and world == 1 and not args.no_full_config:
+        try:
+            Gf = args.full_config_glaciers
+            glf = [gl[k] if k < G else make_glacier(n, k) for k in range(Gf)]
+            bf = odinn.GlacierBatch([(n, n)] * Gf, [100.0] * Gf, A=[g[2] for g in glf], device=local)
+            for k, (H0, B, A) in enumerate(glf):
+                bf.set_fields(k, H0, B)
+                bf.set_T_field(k, temperature_field(H0, B))
+            bf.set_law(odinn.LAW_NN_A_GRIDDED, mlpA, thetaA)
+            ms_full = bf.time_kernel(T.TIMED_SOLVE_STEP, iters=20, warmup=3)
+            full = {"glaciers": Gf, "cells": bf.cells, "solve_step_ms": ms_full,
+                    "cellsteps_per_s": 5.0 * bf.cells / (ms_full * 1e-3),
+                    "note": f"all {Gf} x {n}^2 glaciers of BASELINE configs[4] resident on ONE GPU, same law and launch sequence as "
+                            "`value` (which times the 8-glacier per-GPU share): what 1 GPU does with the whole job"}
+            if not args.no_grad_eval:
+                nnf = odinn.NeuralNetwork(odinn.Parameters(), seed=666)
+                mlpf = odinn.MLPSpec(nnf.widths, nnf.acts, None, odinn.POST_AFFINE, ph.minA, ph.maxA)
+                bf.set_law(odinn.LAW_NN_A_SCALAR, mlpf, nnf.theta)
+                tsf = [2010.0 + k / 12.0 for k in range(25)]
+                for k in range(Gf):
+                    bf.set_reference(k, tsf, [glf[k][0] * (1.0 - 0.002 * j) for j in range(len(tsf))], 3)
+                for nm, fn in (("discrete_adjoint", lambda: bf.loss_grad(tsf, theta=nnf.theta, reltol=1e-8)),
+                               ("continuous_adjoint", lambda: bf.loss_grad_continuous(tsf, theta=nnf.theta, reltol=1e-8))):
+                    fn()  # warm (allocations)
+                    bf.sync()
+                    tq0 = time.perf_counter()
+                    fn()
+                    bf.sync()
+                    full["grad_evals_per_s_" + nm] = Gf / (time.perf_counter() - tq0)
+                full["grad_sample"] = "as grad_evals_per_s.bench_workload (default A(T) MLP, k = 25 monthly snapshots, reltol 1e-8)"
+            aux["full_config_one_gpu"] = full
+            bf.close()
+            del bf, glf
+        except Exception as e:
+            aux["full_config_one_gpu"] = {"error": str(e)[:300]}
 
     # ---- cross-checks: what a plain device copy / triad reaches on this box, and the
     #      PCIe-inclusive rate of the host-pointer seams (never part of `value`) ------------------
@@ -540,12 +583,14 @@ def main():
 
     # ---- roofline of the dominant kernel: fp64 VALU, flops and HBM traffic from the committed PMC passes ----
     pmc, pmc_src = {}, None
-    try:
-        pm = json.load(open(PMC_FILE))
-        if pm.get("workload_cells") == cells:
-            pmc, pmc_src = pm, "profiles/r02/pmc_roofline.json"
-    except Exception:
-        pass
+    for pf in PMC_FILES:
+        try:
+            pm = json.load(open(pf))
+            if pm.get("workload_cells") == cells:
+                pmc, pmc_src = pm, os.path.relpath(pf, ROOT)
+                break
+        except Exception:
+            pass
     kn = pmc.get("fused_step_nn_gridded", {})
     kc = pmc.get("fused_step_constA", {})
     fpcs_nn = kn.get("flop_per_executed_cell_stage", FLOP_PER_CELL_STAGE_FALLBACK)
@@ -578,7 +623,11 @@ def main():
                 "glaciers_per_gpu": G,
                 "grid": [n, n],
                 "cells_per_gpu": cells,
-                "parallelism": f"glacier-sharded x{world}, no data-path collective",
+                "parallelism": f"glacier-sharded x{world}, no data-path collective" + (
+                    "" if world == 1 else f"; [loss, dtheta] all-reduce: {comm_note}"),
+                "schedule": {"forced_fields": {k: v for k, v in sched_in_effect.items() if v != -1},
+                             "odinn_env_set": sorted(k for k in os.environ if k.startswith("ODINN_")),
+                             "note": "odinn_schedule in effect for the timed batch (-1 = automatic for every field not listed)"},
                 "device": odinn.device_name(local),
             },
             "grad_evals_per_s": grad,

@@ -1,4 +1,4 @@
-"""Turn the counter_collection.csv files of tools/pmc_roofline.sh into profiles/r02/pmc_roofline.json."""
+"""Turn the counter_collection.csv files of tools/pmc_roofline.sh into profiles/r03/pmc_roofline.json."""
 import csv, sys, glob, collections, statistics, json, os
 
 root = sys.argv[1]
@@ -14,6 +14,20 @@ def med(tag, pat):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 names.add(r["Kernel_Name"].split("(")[0].replace("void ", ""))
     return {c: statistics.median(v) for c, v in agg.items()}, sorted(names)
+
+
+N_SIMD, N_XCD, N_SE = 1024, 8, 32
+
+
+def valu_busy(bz):
+    """Fraction of the SIMD issue cycles of the launch that carried a VALU instruction: SQ_ACTIVE_INST_VALU counts quad-cycles
+    summed over all SIMDs; the launch lasts GRBM_GUI_ACTIVE / 8 cycles (the counter is summed over the 8 XCDs; where a pass
+    lacks it, SQ_BUSY_CYCLES / 32 -- summed over the 32 shader engines -- is the same clock to within 10 %)."""
+    if "GRBM_GUI_ACTIVE" in bz:
+        cyc = bz["GRBM_GUI_ACTIVE"] / N_XCD
+    else:
+        cyc = bz.get("SQ_BUSY_CYCLES", 0.0) / N_SE
+    return bz.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / max(N_SIMD * cyc, 1.0)
 
 
 cells8, cells32 = 8 * 1024 * 1024, 32 * 1024 * 1024
@@ -36,7 +50,8 @@ for law, key in (("nnA", "fused_step_nn_gridded"), ("const", "fused_step_constA"
          "flop_per_executed_cell_stage": flops / executed, "useful_cell_stages_per_launch": 5 * cells8,
          "halo_redundancy": executed / (5.0 * cells8)}
     if bz:
-        e["valu_busy_frac"] = bz.get("SQ_ACTIVE_INST_VALU", 0) * 4 / max(bz.get("SQ_BUSY_CYCLES", 1), 1)
+        e["valu_busy_frac"] = valu_busy(bz)
+        e["valu_busy_definition"] = "4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)"
         e["sq_raw"] = bz
     if fe and wr:
         e["hbm_bytes_per_launch"] = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0
@@ -59,7 +74,7 @@ if fe and wr:
          "algorithmic_bytes_per_cell": 40.0, "ratio": by / (40.0 * cells8),
          "note": "dense launch on 8 x 1024^2 (320 MiB of lambda, H_j, H_j+1, B, lambda': partly inside the 256 MiB Infinity Cache)"}
     if bz:
-        e["valu_busy_frac"] = bz.get("SQ_ACTIVE_INST_VALU", 0) * 4 / max(bz.get("SQ_BUSY_CYCLES", 1), 1)
+        e["valu_busy_frac"] = valu_busy(bz)
         e["valu_insts_per_wave"] = bz.get("SQ_INSTS_VALU", 0) / max(bz.get("SQ_WAVES", 1), 1)
         e["sq_raw"] = bz
     out["adj_fused_step_8"] = e

@@ -1,4 +1,4 @@
-# PMC passes behind bench.py's roofline block (profiles/r02/pmc_roofline.json): fp64 instruction counts and HBM traffic
+# PMC passes behind bench.py's roofline block (profiles/r03/pmc_roofline.json): fp64 instruction counts and HBM traffic
 # of the fused step kernel (gridded-NN and constant A, 8 x 1024^2) and HBM traffic of the HBM-bound kernels on
 # 32 x 1024^2 (past the Infinity Cache).  Separate --pmc passes, kernel-trace only, as MI355X_MICROARCH.md prescribes.
 R=$GRAFT_REPO_ROOT
@@ -23,5 +23,5 @@ run vjpth32_fetch FETCH_SIZE vjp_theta 32 const
 run vjpth32_write WRITE_SIZE vjp_theta 32 const
 run adjf8_fetch FETCH_SIZE adj_fused_step 8 const
 run adjf8_write WRITE_SIZE adj_fused_step 8 const
-run adjf8_busy "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVES" adj_fused_step 8 const
+run adjf8_busy "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE" adj_fused_step 8 const
 cd $R && python tools/pmc_roofline.py $O > $R/gpurun_out/pmc_roofline.json && cat $R/gpurun_out/pmc_roofline.json
