@@ -253,7 +253,8 @@ int odinn_set_dhdt_loss(odinn_batch* b, double weight);
  * component_abs != 0; normalization nx * ny); the term weight * loss joins odinn_loss / odinn_loss_grad /
  * odinn_loss_grad_continuous, its cotangent dl/dV dt_i / T is pulled back through surface_V at every tLoss_i
  * (VJP_lambda_dsurface_V/dH joins lambda at that stop, /dtheta joins dtheta; gradient.jl:170-215,274, :369-449,538).
- * Every tLoss_i must be among the tstops of the solve (ODINN_ERR_ARG otherwise); A-type laws only (target :A), like LossV.
+ * Every tLoss_i must be among the glacier's stops of the solve (ODINN_ERR_ARG otherwise); every law with a surface-velocity path:
+ * A-type (target :A) and the U law (target :D), like LossV.
  * weight = 0 (default) switches the term off; t2 <= t1 clears a glacier's sample. */
 int odinn_set_avgv_reference(odinn_batch* b, int g, double t1, double t2, const double* Vabs, const double* Vx,
                              const double* Vy);
@@ -264,7 +265,7 @@ int odinn_set_avgv_loss(odinn_batch* b, double weight, double step, int componen
  * weight * (t_m - t_{m-1}) * sum_mask (lap V)^2 with V = |V_from_H(H(t_m))| and mask = is_in_glacier(H(t_m), distance) & V > 0
  * joins the loss; its dL/dH joins lambda at that stop, its dL/dtheta is summed over the stops (odinn_loss_grad) or integrated
  * over the quadrature nodes on the interpolated state with Delta-t = 1 (odinn_loss_grad_continuous, gradient.jl:475-503).
- * `weight` is the MultiLoss lambda of the term relative to the data loss; 0 (default) switches it off.  A-type laws only. */
+ * `weight` is the MultiLoss lambda of the term relative to the data loss; 0 (default) switches it off.  A-type laws and the U law. */
 int odinn_set_velocity_regularization(odinn_batch* b, double weight, int distance);
 
 /* ---- fine-grained seams (host in / host out; parity + drop-in, not the fast path) ---- */

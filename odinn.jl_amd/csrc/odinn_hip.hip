@@ -1135,7 +1135,9 @@ int agg_tables(odinn_batch* b, bool with_grad) {
   b->agg_nslots = 0;
   const bool av = b->avgv_on(), vr = b->vreg_on();
   if (!av && !vr) return ODINN_OK;
-  if (b->lm() >= 2) return fail(ODINN_ERR_STATE, "LossAvgV / VelocityRegularization need an A-type law (target :A)");
+  // generic over the targets in the reference (TimeAggregatedLosses.jl:115-258, Regularization.jl:192-245): every law with a
+  // surface-velocity path here -- A-type (target :A) and the U law (target :D, per-node backprop of dU/dtheta)
+  if (!b->vel_law_ok()) return fail(ODINN_ERR_STATE, "LossAvgV / VelocityRegularization need a law with a surface-velocity path: A-type (target :A) or the U law (target :D)");
   b->wA_h.assign((size_t)k * G, 0.0);
   b->wR_h.assign((size_t)k * G, 0.0);
   std::vector<unsigned char> on(G, 0);
@@ -1211,7 +1213,7 @@ int avgv_forward(odinn_batch* b, bool with_grad) {
   const Pools P = b->pools(true);
   for (int j = 0; j < k; ++j) {
     if (!stop_on(j)) continue;
-    launch_surface_V(b->lm(), b->ntiles, b->stream, P, b->lawdev(), b->d_snaps + (size_t)j * b->ntot, vx, vy, 0, 1.0);
+    launch_surface_V(b->lm(), b->ntiles, b->stream, P, b->lawdev(), b->d_snaps + (size_t)j * b->ntot, vx, vy, 0, 1.0 / b->fV);
     launch_avgv_axpy(b->ntiles, b->stream, P, vx, vy, ax, ay, b->d_wA + (size_t)j * G);
   }
   launch_avgv_cot(b->ntiles, b->stream, P, ax, ay, b->d_aVabs, b->d_aVx, b->d_aVy, b->d_av_on, b->avgv_abs, b->avgv_weight);
@@ -1223,8 +1225,14 @@ int avgv_forward(odinn_batch* b, bool with_grad) {
       A.H = b->d_snaps + (size_t)j * b->ntot; A.dVx = ax; A.dVy = ay; A.out = b->d_aggH + (size_t)b->agg_slot_h[j] * b->ntot;
       A.wv = b->d_wA + (size_t)j * G; A.ntot = b->ntot;
       A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
+      A.finv = 1.0 / b->fV;
+      if (b->vel_nn()) {  // U law: dU/dtheta backpropagated per node, reduced into d_dth
+        CHK(ensure_theta_scratch(b, b->ntiles));
+        A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
+      }
       launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, b->lawdev(), A, 0);
-      launch_sum_part(G, b->stream, P, 3, b->d_Gsum, 1, 0);
+      if (b->vel_nn()) launch_sum_part_theta(b->P, G, b->stream, P, b->d_part_theta, b->d_dth, 1, 0);
+      else launch_sum_part(G, b->stream, P, 3, b->d_Gsum, 1, 0);
     }
   }
   HIPCHK(hipGetLastError());
@@ -1237,7 +1245,7 @@ int avgv_forward(odinn_batch* b, bool with_grad) {
 static int vreg_at(odinn_batch* b, const double* H, const double* w, bool add_loss, double* outH, bool theta) {
   const Pools P = b->pools(true);
   double *vx = b->d_avg, *vy = b->d_avg + b->ntot, *va = b->d_avg + 2 * b->ntot, *r = b->d_avg + 3 * b->ntot;
-  launch_surface_V(b->lm(), b->ntiles, b->stream, P, b->lawdev(), H, vx, vy, 0, 1.0);
+  launch_surface_V(b->lm(), b->ntiles, b->stream, P, b->lawdev(), H, vx, vy, 0, 1.0 / b->fV);
   launch_vreg_prep(b->ntiles, b->stream, P, H, vx, vy, w, b->vreg_dist, va, b->d_vrm);
   launch_vreg_lap(b->ntiles, b->stream, P, va, b->d_vrm, w, r);
   if (add_loss) launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
@@ -1247,10 +1255,16 @@ static int vreg_at(odinn_batch* b, const double* H, const double* w, bool add_lo
     A.H = H; A.dVx = vx; A.dVy = vy; A.out = outH ? outH : r;  // (r is dead by now: a sink for the unused H-part)
     A.wv = w; A.ntot = b->ntot;
     A.Gacc = (theta && b->wants_Gacc()) ? b->d_Gacc : nullptr;
+    A.finv = 1.0 / b->fV;
+    if (theta && b->vel_nn()) {  // U law: dU/dtheta backpropagated per node, reduced into d_dth
+      CHK(ensure_theta_scratch(b, b->ntiles));
+      A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
+    }
     // nobody wants dL/dH (the quadrature nodes of the continuous adjoint), closed-form law: the theta-part alone
     if (!outH && theta && b->lm() <= 1 && !b->vel_nn()) launch_surfV_theta_only(b->lm(), b->ntiles, b->stream, P, A);
     else launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, b->lawdev(), A, 0);
-    if (theta) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
+    if (theta && b->vel_nn()) launch_sum_part_theta(b->P, b->G, b->stream, P, b->d_part_theta, b->d_dth, 1, 0);
+    else if (theta) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
   }
   HIPCHK(hipGetLastError());
   return ODINN_OK;

@@ -166,7 +166,7 @@ def test_avgv_ragged_batch_gridded_law_and_errors(gpu):
     b.set_reference(0, ts, refs[0], 3)
     b.set_avgv_reference(0, a.t1, a.t2, a.Vabs, a.Vx, a.Vy)
     b.set_avgv_loss(1.0, step, "xy")
-    with pytest.raises(gpu.OdinnError, match="A-type law"):
+    with pytest.raises(gpu.OdinnError, match="surface-velocity path"):
         b.loss_grad(ts, theta=th2, reltol=1e-8)
     b.close()
 

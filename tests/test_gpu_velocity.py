@@ -221,3 +221,52 @@ def test_lossV_with_the_U_law_target_D(gpu, adjoint):
     with pytest.raises(gpu.OdinnError, match="target :D"):
         b.surface_V(0, O.synthetic_alpine(*shapes[0])[0])
     b.close()
+
+
+@pytest.mark.parametrize("term", ["avgv", "vreg"])
+def test_time_aggregated_velocity_terms_with_the_U_law(gpu, term):
+    """LossAvgV and VelocityRegularization are generic over the targets in the reference (TimeAggregatedLosses.jl:115-258,
+    Regularization.jl:192-245: they go through V_from_H and VJP_lambda_dsurface_V/d{H, theta}): with the U law (target :D),
+    next to LossH, through both adjoints against the oracle."""
+    from test_gpu_avgv import _sample
+    ph = O.Phys()
+    om, gm, th = _u_law(gpu, ph)
+    law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, fV=0.8)
+    step = 1.0 / 96.0
+    ts = [2010.0 + j * step for j in range(7)]
+    nx, ny = 56, 40
+    H0, B = O.synthetic_alpine(nx, ny, hmax=150.0, slope=0.1)
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    cfg = O.SimConfig(tstops=ts, reltol=1e-10)
+    ref, _, _ = O.forward(gl, law, cfg)
+    ref = [r * (1.0 - 0.01 * j) for j, r in enumerate(ref)]
+    b = gpu.GlacierBatch([(nx, ny)], [50.0])
+    b.set_fields(0, H0, B)
+    b.set_reference(0, ts, ref, 3)
+    b.set_law(gpu.LAW_NN_U, gm, th)
+    b.set_surface_velocity_factor(0.8)
+    if term == "avgv":
+        a = _sample(gl, law, cfg, ts, 1, 5, "xy")
+        cfg.avgv, cfg.avgv_weight = a, 2.0
+        b.set_avgv_reference(0, a.t1, a.t2, a.Vabs, a.Vx, a.Vy)
+        b.set_avgv_loss(2.0, a.step, "xy")
+    else:
+        tV = ts[1::2]
+        cfg.vreg_times, cfg.vreg_distance, cfg.vreg_weight = tV, 3, 1e3
+        z = [np.zeros((nx, ny))] * len(tV)
+        b.set_velocity_reference(0, tV, z, z, z)  # only the dates matter
+        b.set_velocity_regularization(1e3, 3)
+    Lo, go, _ = O.loss_and_grad(gl, law, cfg, ref, ts)
+    Lg, gg = b.loss_grad(ts, theta=th, reltol=1e-10)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo), (Lg, Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-8 and relerr < 1e-5, (term, ratio, angle, relerr)
+    Lo, go, _, _ = O.loss_and_grad_continuous(gl, law, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=8))
+    Lg, gg = b.loss_grad_continuous(ts, theta=th, reltol=1e-10, n_quadrature=8)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo), (Lg, Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-8 and relerr < 1e-5, (term, ratio, angle, relerr)
+    # the term is in there
+    L0, g0 = (b.set_avgv_loss(0.0, step, "xy") if term == "avgv" else b.set_velocity_regularization(0.0, 3)) or b.loss_grad(ts, theta=th, reltol=1e-10)
+    assert abs(L0 - Lg) > 1e-6 * abs(Lg)
+    b.close()
