@@ -275,7 +275,11 @@ int odinn_sia2d_vjp_H(odinn_batch* b, int g, const double* lam, const double* H,
 int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double* H, double t,
                           double* dtheta, int P);
 /* Huginn.surface_V / V_from_H (restated from adjoint.jl:268-350): Vx, Vy are nx*ny with the
- * reference's inn1 pairing (dual node (i,j) at element [i,j]; last row and column 0).  A-type laws. */
+ * reference's inn1 pairing (dual node (i,j) at element [i,j]; last row and column 0).  Every law: Velocity^ of target :A
+ * (target_A.jl:94-142), :D (U / f, target_D_pure.jl:206-255) and :D_hybrid AS THE REFERENCE WRITES IT
+ * (target_D_hybrid.jl:210-372: the value uses the diffusivity's Gamma = 2 (rho g)^n / (n + 2), its H-partial a forward
+ * difference of compute_D, its slope partial and theta-weight Gamma^ = 2 (rho g)^n / (n + 1); dY/dtheta exact per node or on
+ * the knots of create_interpolation per odinn_set_grad_interpolation -- upstream has no test of that target's velocity path). */
 int odinn_surface_V(odinn_batch* b, int g, const double* H, double* Vx, double* Vy);
 /* VJP_lambda_dsurface_V/dH and /dtheta (DiscreteVJP), src/inverse/SIA2D/VJPs.jl:61-69 */
 int odinn_surface_V_vjp_H(odinn_batch* b, int g, const double* dVx, const double* dVy, const double* H, double* out);

@@ -234,8 +234,12 @@ struct odinn_batch {
   std::vector<std::vector<double>> t_vref;                // per glacier
   // f_surface_velocity_factor of the simulation parameters (target :D: Velocity^ = U / f, target_D_pure.jl:206-255)
   double fV = 1.0;
-  bool vel_law_ok() const { return law_kind < ODINN_LAW_NN_Y || law_kind == ODINN_LAW_NN_U; }
-  bool vel_nn() const { return law_kind == ODINN_LAW_NN_U; }
+  // surface-velocity path: every law has one -- A-type (target :A, closed form), U (target :D) and Y (target :D_hybrid, as the
+  // reference writes it) through the per-node network in the velocity kernels
+  bool vel_law_ok() const { return true; }
+  bool vel_nn() const { return law_kind == ODINN_LAW_NN_U || law_kind == ODINN_LAW_NN_Y; }
+  // Y law with the target's default `:Linear` interpolation of dY/dtheta: the velocity kernels emit (Hbar, node weight)
+  bool vel_emit() const { return law_kind == ODINN_LAW_NN_Y && grad_interp == ODINN_GRAD_INTERP_LINEAR; }
   // LossV's simple loss: 0 = L2Sum, > 0 = LogSum(eps) (component :abs only; Losses.jl:34-49,207-229); h_log_eps: LossH's
   double v_log_eps = 0.0, h_log_eps = 0.0;
   std::vector<std::vector<std::vector<double>>> v_edge;  // per glacier per slot: V_ref > 0 on the last row / column
@@ -439,6 +443,10 @@ struct odinn_batch {
     return L;
   }
 };
+
+static int vel_theta_args(odinn_batch* b, VArgs& A, int g);
+static int vel_theta_finish(odinn_batch* b, int g, bool accumulate, const Pools& P);
+static int interp_prepare(odinn_batch* b, int g, bool linU);
 
 namespace {
 
@@ -896,7 +904,6 @@ int launch_lossV(odinn_batch* b, int j, const double* Hj, double* out, bool with
     }
   }
   if (!any) return ODINN_OK;
-  if (!b->vel_law_ok()) return fail(ODINN_ERR_STATE, "LossV needs an A-type law (target :A) or the U law (target :D)");
   if (b->v_log_eps > 0.0 && !b->v_abs)
     return fail(ODINN_ERR_ARG, "LogSum needs non-negative fields (Losses.jl:214): use it with component :abs");
   VArgs A{};
@@ -905,14 +912,12 @@ int launch_lossV(odinn_batch* b, int j, const double* Hj, double* out, bool with
   A.ntot = b->ntot; A.component_abs = b->v_abs; A.log_eps = b->v_abs ? b->v_log_eps : 0.0;
   A.Gacc = (with_grad && b->wants_Gacc()) ? b->d_Gacc : nullptr;
   A.finv = 1.0 / b->fV;
-  if (with_grad && b->vel_nn()) {  // U law: per-node backprop of dU/dtheta, reduced into d_dth like the theta-VJP of the RHS
-    CHK(ensure_theta_scratch(b, b->ntiles));
-    A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
-  }
+  // U / Y law: the network's theta-gradient per node (backprop, or the knot interpolation of the Y law), reduced into d_dth
+  if (with_grad) CHK(vel_theta_args(b, A, -1));
   const Pools P = b->pools(true);
   launch_surfV_vjp(b->lm(), 1, b->ntiles, b->stream, P, b->lawdev(), A, 0);
   launch_sum_part(b->G, b->stream, P, 1, b->d_lossacc, 1, 0);
-  if (with_grad && b->vel_nn()) launch_sum_part_theta(b->P, b->G, b->stream, P, b->d_part_theta, b->d_dth, 1, 0);
+  if (with_grad && b->vel_nn()) CHK(vel_theta_finish(b, -1, true, P));
   else if (with_grad) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
@@ -1137,7 +1142,6 @@ int agg_tables(odinn_batch* b, bool with_grad) {
   if (!av && !vr) return ODINN_OK;
   // generic over the targets in the reference (TimeAggregatedLosses.jl:115-258, Regularization.jl:192-245): every law with a
   // surface-velocity path here -- A-type (target :A) and the U law (target :D, per-node backprop of dU/dtheta)
-  if (!b->vel_law_ok()) return fail(ODINN_ERR_STATE, "LossAvgV / VelocityRegularization need a law with a surface-velocity path: A-type (target :A) or the U law (target :D)");
   b->wA_h.assign((size_t)k * G, 0.0);
   b->wR_h.assign((size_t)k * G, 0.0);
   std::vector<unsigned char> on(G, 0);
@@ -1226,12 +1230,9 @@ int avgv_forward(odinn_batch* b, bool with_grad) {
       A.wv = b->d_wA + (size_t)j * G; A.ntot = b->ntot;
       A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
       A.finv = 1.0 / b->fV;
-      if (b->vel_nn()) {  // U law: dU/dtheta backpropagated per node, reduced into d_dth
-        CHK(ensure_theta_scratch(b, b->ntiles));
-        A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
-      }
+      CHK(vel_theta_args(b, A, -1));  // U / Y law: the network's theta-gradient per node, reduced into d_dth
       launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, b->lawdev(), A, 0);
-      if (b->vel_nn()) launch_sum_part_theta(b->P, G, b->stream, P, b->d_part_theta, b->d_dth, 1, 0);
+      if (b->vel_nn()) CHK(vel_theta_finish(b, -1, true, P));
       else launch_sum_part(G, b->stream, P, 3, b->d_Gsum, 1, 0);
     }
   }
@@ -1256,14 +1257,11 @@ static int vreg_at(odinn_batch* b, const double* H, const double* w, bool add_lo
     A.wv = w; A.ntot = b->ntot;
     A.Gacc = (theta && b->wants_Gacc()) ? b->d_Gacc : nullptr;
     A.finv = 1.0 / b->fV;
-    if (theta && b->vel_nn()) {  // U law: dU/dtheta backpropagated per node, reduced into d_dth
-      CHK(ensure_theta_scratch(b, b->ntiles));
-      A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
-    }
+    if (theta) CHK(vel_theta_args(b, A, -1));  // U / Y law: the network's theta-gradient per node, reduced into d_dth
     // nobody wants dL/dH (the quadrature nodes of the continuous adjoint), closed-form law: the theta-part alone
     if (!outH && theta && b->lm() <= 1 && !b->vel_nn()) launch_surfV_theta_only(b->lm(), b->ntiles, b->stream, P, A);
     else launch_surfV_vjp(b->lm(), 2, b->ntiles, b->stream, P, b->lawdev(), A, 0);
-    if (theta && b->vel_nn()) launch_sum_part_theta(b->P, b->G, b->stream, P, b->d_part_theta, b->d_dth, 1, 0);
+    if (theta && b->vel_nn()) CHK(vel_theta_finish(b, -1, true, P));
     else if (theta) launch_sum_part(b->G, b->stream, P, 3, b->d_Gsum, 1, 0);
   }
   HIPCHK(hipGetLastError());
@@ -1839,6 +1837,40 @@ static int check_interp_bounds(odinn_batch* b) {
                              "interpolant (Laws.jl:128-131, interpolation = :Linear)");
 }
 
+// `:Linear` interpolation of d law / d theta (k_interp.hip): zero the (Hbar, weight[, slope]) node arrays of glacier g (-1: all)
+// before a kernel emits into them ...
+static int interp_prepare(odinn_batch* b, int g, bool linU) {
+  CHK(ensure_interp_scratch(b));
+  const int g0 = g < 0 ? 0 : g, g1 = g < 0 ? b->G : g + 1;
+  const long long lo = b->gd[g0].offd;
+  const long long hi = g1 < b->G ? b->gd[g1].offd : b->ntotd;
+  HIPCHK(hipMemsetAsync(b->d_nodeH + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
+  HIPCHK(hipMemsetAsync(b->d_nodeV + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
+  if (linU) HIPCHK(hipMemsetAsync(b->d_nodeS + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
+  return ODINN_OK;
+}
+static int interp_contract(odinn_batch* b, int g, bool linU, bool accumulate, const Pools& P);
+
+// theta-part of a surface-velocity pull-back with a per-node network (U and Y laws): where the node contributions go ...
+static int vel_theta_args(odinn_batch* b, VArgs& A, int g) {
+  if (!b->vel_nn()) return ODINN_OK;
+  CHK(ensure_theta_scratch(b, g < 0 ? b->ntiles : b->gd[g].ntiles));
+  if (b->vel_emit()) {
+    CHK(interp_prepare(b, g, false));
+    A.emitH = b->d_nodeH; A.emitV = b->d_nodeV;
+  } else {
+    A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
+  }
+  return ODINN_OK;
+}
+// ... and their reduction into d_dth after the launch (added onto what is there unless !accumulate)
+static int vel_theta_finish(odinn_batch* b, int g, bool accumulate, const Pools& P) {
+  if (!b->vel_nn()) return ODINN_OK;
+  if (b->vel_emit()) return interp_contract(b, g, false, accumulate, P);
+  launch_sum_part_theta(b->P, g < 0 ? b->G : 1, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g < 0 ? 0 : g);
+  return ODINN_OK;
+}
+
 static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
                             bool accumulate, double* part_deferred = nullptr, bool inplace = false,
                             const double* lam_alt = nullptr, const double* snaps = nullptr, const AdjState* adj = nullptr) {
@@ -1851,15 +1883,7 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   if (nn_node) CHK(ensure_theta_scratch(b, nblk));
   const bool linear = b->law_kind >= ODINN_LAW_NN_Y && b->grad_interp == ODINN_GRAD_INTERP_LINEAR;
   const bool linU = linear && b->law_kind == ODINN_LAW_NN_U;
-  if (linear) {
-    CHK(ensure_interp_scratch(b));
-    const int g0 = g < 0 ? 0 : g, g1 = g < 0 ? b->G : g + 1;
-    const long long lo = b->gd[g0].offd;
-    const long long hi = g1 < b->G ? b->gd[g1].offd : b->ntotd;
-    HIPCHK(hipMemsetAsync(b->d_nodeH + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
-    HIPCHK(hipMemsetAsync(b->d_nodeV + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
-    if (linU) HIPCHK(hipMemsetAsync(b->d_nodeS + lo, 0, (size_t)(hi - lo) * sizeof(double), b->stream));
-  }
+  if (linear) CHK(interp_prepare(b, g, linU));
   ThArgs A{};
   A.emitH = linear ? b->d_nodeH : nullptr; A.emitV = linear ? b->d_nodeV : nullptr; A.emitS = linU ? b->d_nodeS : nullptr;
   A.H = H; A.lam = lam; A.lam_alt = lam_alt; A.scales = scales;
@@ -1873,6 +1897,21 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   launch_vjp_theta(b, nblk, P, b->lawdev(), A, base);
   const int ng = g < 0 ? b->G : 1, g0 = g < 0 ? 0 : g;
   if (linear) {
+    CHK(interp_contract(b, g, linU, accumulate, P));
+  } else if (part_deferred) {
+  } else if (nn_node)
+    launch_sum_part_theta(b->P, ng, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g0);
+  else
+    launch_sum_part(ng, b->stream, P, 2, b->d_Gsum, accumulate ? 1 : 0, g0);
+  HIPCHK(hipGetLastError());
+  return ODINN_OK;
+}
+
+// ... and contract them: dtheta_g (+)= sum_knots c_k d law / d theta (knot_k) -- sort the glacier's nodes by Hbar, build its knots,
+// sum the node weights per interval, backpropagate at the knots only
+static int interp_contract(odinn_batch* b, int g, bool linU, bool accumulate, const Pools& P) {
+  const int ng = g < 0 ? b->G : 1, g0 = g < 0 ? 0 : g;
+  {
     // dtheta_g (+)= sum_knots c_k dY/dtheta(T_g, knot_k): sort the glacier's nodes by Hbar, build its knots, sum per interval
     const LawDev L = b->lawdev();
     // Y law: all glaciers of the call in one sequence of launches (ODINN_INTERP_BATCH=0: one sequence per glacier)
@@ -1919,11 +1958,7 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
         HIPCHK(hipEventRecord(b->ev_join[l], b->side[l]));
         HIPCHK(hipStreamWaitEvent(b->stream, b->ev_join[l], 0));
       }
-  } else if (part_deferred) {
-  } else if (nn_node)
-    launch_sum_part_theta(b->P, ng, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g0);
-  else
-    launch_sum_part(ng, b->stream, P, 2, b->d_Gsum, accumulate ? 1 : 0, g0);
+  }
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -2127,7 +2162,6 @@ int odinn_surface_V(odinn_batch* b, int g, const double* H, double* Vx, double* 
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!H || !Vx || !Vy) return fail(ODINN_ERR_ARG, "null field");
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
-  if (!b->vel_law_ok()) return fail(ODINN_ERR_STATE, "surface velocity needs an A-type law (target :A) or the U law (target :D)");
   CHK(up_field(b, g, b->d_tmpA, H));
   launch_surface_V(b->lm(), b->gd[g].ntiles, b->stream, b->pools(false), b->lawdev(), b->d_tmpA, b->d_tmpB, b->d_lam[1], b->gd[g].tile0, 1.0 / b->fV);
   HIPCHK(hipGetLastError());
@@ -2139,7 +2173,6 @@ static int surfV_vjp_common(odinn_batch* b, int g, const double* dVx, const doub
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!H || !dVx || !dVy) return fail(ODINN_ERR_ARG, "null field");
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
-  if (!b->vel_law_ok()) return fail(ODINN_ERR_STATE, "surface velocity needs an A-type law (target :A) or the U law (target :D)");
   CHK(up_field(b, g, b->d_tmpA, H));
   CHK(up_field(b, g, b->d_lam[0], dVx));
   CHK(up_field(b, g, b->d_lam[1], dVy));
@@ -2150,13 +2183,10 @@ static int surfV_vjp_common(odinn_batch* b, int g, const double* dVx, const doub
   A.H = b->d_tmpA; A.dVx = b->d_lam[0]; A.dVy = b->d_lam[1]; A.out = b->d_tmpB;
   A.Gacc = b->law_kind == ODINN_LAW_NN_A_GRIDDED ? b->d_Gacc : nullptr;
   A.finv = 1.0 / b->fV;
-  if (b->vel_nn()) {
-    CHK(ensure_theta_scratch(b, r.ntiles));
-    A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
-  }
+  CHK(vel_theta_args(b, A, g));
   const Pools P = b->pools(false);
   launch_surfV_vjp(b->lm(), 0, r.ntiles, b->stream, P, b->lawdev(), A, r.tile0);
-  if (b->vel_nn()) launch_sum_part_theta(b->P, 1, b->stream, P, b->d_part_theta, b->d_dth, 0, g);
+  if (b->vel_nn()) CHK(vel_theta_finish(b, g, false, P));
   else launch_sum_part(1, b->stream, P, 3, b->d_Gsum, 0, g);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
@@ -2501,7 +2531,6 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
                                double* loss, double* dtheta, odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
   if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
   const bool useV = b->loss_kind != ODINN_LOSS_H;
-  if (useV && !b->vel_law_ok()) return fail(ODINN_ERR_STATE, "LossV needs an A-type law (target :A) or the U law (target :D)");
   odinn_adjoint_opts ao{1e-8, 1e-8, 1.0 / 12.0, 200, 0, 1000000};  // AdjointTypes.jl:58-67
   if (aopts) ao = *aopts;
   if (ao.reltol <= 0) ao.reltol = 1e-8;
@@ -2656,10 +2685,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     VQ.wv = b->d_wvq; VQ.scale = b->d_vscq; VQ.refslot = b->d_zeroslot; VQ.ntot = b->ntot; VQ.component_abs = b->v_abs; VQ.log_eps = b->v_abs ? b->v_log_eps : 0.0;
     VQ.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
     VQ.finv = 1.0 / b->fV;
-    if (b->vel_nn()) {
-      CHK(ensure_theta_scratch(b, b->ntiles));
-      VQ.gscratch = b->d_gscratch; VQ.part_theta = b->d_part_theta;
-    }
+    CHK(vel_theta_args(b, VQ, -1));  // (Y law with `:Linear`: the node arrays are zeroed again before every launch below)
     HIPCHK(hipMemsetAsync(b->d_tmpB, 0, (size_t)b->ntot * sizeof(double), b->stream));
   }
   const double wq = b->loss_kind == ODINN_LOSS_HV ? b->hv_scaling : 1.0;
@@ -2811,8 +2837,9 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
         } else {
           launch_vref_itp(b->ntiles, b->stream, Pl, VI);
           launch_vref_scale(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_vscq, b->d_wvq);
+          if (b->vel_emit()) CHK(interp_prepare(b, -1, false));
           launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VQ, 0);
-          if (b->vel_nn()) launch_sum_part_theta(b->P, G, b->stream, Pl, b->d_part_theta, b->d_dth, 1, 0);
+          if (b->vel_nn()) CHK(vel_theta_finish(b, -1, true, Pl));
           else launch_sum_part(G, b->stream, Pl, 3, b->d_Gsum, 1, 0);
         }
       }

@@ -53,6 +53,37 @@ __device__ __forceinline__ double node_Vup_U(const LawDev& L, double Hb, double 
   return mlp_eval_any(L, Hb, gS) * finv;
 }
 
+// target :D_hybrid AS WRITTEN in the reference (target_D_hybrid.jl:210-372; restated in the oracle, which also records the
+// inconsistencies -- upstream has no test of this path):
+//   Velocity^      = S H^(p-q+1) |gS|^(p-1) + Y Gamma H^(n_H+1) |gS|^(n_S-1)        with the DIFFUSIVITY's Gamma = 2 (rho g)^n / (n+2)
+//   dVelocity^/dH  = (p-q+1) S H^(p-q) |gS|^(p-1) + (n_H+1) Y Gamma H^n_H |gS|^(n_S-1)
+//                    + [compute_D(Y(H + 1e-4)) - compute_D(Y(H))] / 1e-4             (compute_D: H^(n_H+2), the diffusivity)
+//   dVelocity^/dgS = (p-1) S H^(p-q+1) |gS|^(p-3) + Gamma^ Y (n_S-1) H^(n_H+2) |gS|^(n_S-3)   with Gamma^ = 2 (rho g)^n / (n+1)
+//   spat (x dY/dtheta) = Gamma^ H^(n_H+1) |gS|^(n_S-1)
+__device__ __forceinline__ double node_Vup_Y(const GDev& g, const LawDev& L, double Hb, double gS2, double& alpha, double& beta,
+                                             double& spat) {
+  const double dH = 1e-4;
+  const double Gu = g.Gam * (g.n + 2.0) / (g.n + 1.0);  // Gamma^
+  const double Y = mlp_eval_any(L, g.T, Hb), Yp = mlp_eval_any(L, g.T, Hb + dH);
+  const double sS1 = spow(gS2, g.nS - 1.0);
+  const double h1 = upow(Hb, g.nH + 1.0), h2 = upow(Hb, g.nH + 2.0);
+  double D = Y * g.Gam * h1 * sS1;
+  const double geoD = g.Gam * h2 * sS1;
+  double slide = 0.0;
+  alpha = (g.nH + 1.0) * Y * g.Gam * upow(Hb, g.nH) * sS1;
+  beta = Gu * Y * (g.nS - 1.0) * h2 * spow(gS2, g.nS - 3.0);
+  if (g.Sc != 0.0) {
+    const double hs = upow(Hb, g.p - g.q + 1.0), sp1 = spow(gS2, g.p - 1.0);
+    slide = g.Sc * hs * sp1;
+    D += slide;
+    alpha += (g.p - g.q + 1.0) * g.Sc * upow(Hb, g.p - g.q) * sp1;
+    beta += (g.p - 1.0) * g.Sc * hs * spow(gS2, g.p - 3.0);
+  }
+  alpha += ((slide + Yp * geoD) - (slide + Y * geoD)) / dH;
+  spat = Gu * h1 * sS1;
+  return D;
+}
+
 template <int LM>
 __global__ __launch_bounds__(NT) void k_surface_V(Pools P, LawDev L, const double* __restrict__ U, double* __restrict__ Vx,
                                                   double* __restrict__ Vy, int tile_base, double finv) {
@@ -75,7 +106,12 @@ __global__ __launch_bounds__(NT) void k_surface_V(Pools P, LawDev L, const doubl
         node_geom<LDW>(g, &sHS[r][tx + 1], gx, gy, Hb);
         double D;
         if constexpr (LM == LM_NN) {
-          D = mlp_eval_any(L, Hb, sqrt(gx * gx + gy * gy)) * finv;
+          if (L.kind == 3) {  // Y law, target :D_hybrid
+            double al, be, sp;
+            D = node_Vup_Y(g, L, Hb, gx * gx + gy * gy, al, be, sp);
+          } else {
+            D = mlp_eval_any(L, Hb, sqrt(gx * gx + gy * gy)) * finv;
+          }
         } else {
           double An = g.A;
           if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
@@ -119,6 +155,10 @@ struct VArgs {
   double finv;
   double* gscratch;
   double* part_theta;
+  // Y law (target :D_hybrid) with `:Linear` interpolation of the law gradient: per owned dual node, Hbar and the node weight
+  // (dual pooled arrays, pre-zeroed by the caller) instead of the per-node backprop
+  double* emitH;
+  double* emitV;
 };
 
 template <int MODE, int LM>
@@ -177,8 +217,12 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
       double al, be, sp = 0.0, D;
       [[maybe_unused]] double gS = 0.0;
       if constexpr (LM == LM_NN) {
-        gS = sqrt(gx * gx + gy * gy);
-        D = node_Vup_U(L, Hb, gS, A.finv, al, be);
+        if (L.kind == 3) {  // Y law, target :D_hybrid
+          D = node_Vup_Y(g, L, Hb, gx * gx + gy * gy, al, be, sp);
+        } else {
+          gS = sqrt(gx * gx + gy * gy);
+          D = node_Vup_U(L, Hb, gS, A.finv, al, be);
+        }
       } else {
         double An = g.A;
         if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
@@ -218,8 +262,21 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
       Qx = fma(be * gx, W, D * dvx);
       Qy = fma(be * gy, W, D * dvy);
       if (owned) {
-        if constexpr (LM == LM_NN) {  // dVelocity^/dtheta = (Hbar > 0) dU/dtheta / f, exact backprop per node (:None branch)
-          if (gth && Hb > 0.0) mlp_grad(L, Hb, gS, -wv * W * A.finv, gth, gstride);
+        if constexpr (LM == LM_NN) {
+          if (L.kind == 3) {
+            // Y law: dVelocity^/dtheta = spat x dY/dtheta(T, Hbar) -- exact backprop per node (:None), or, for the target's
+            // default `:Linear`, Hbar and the node weight emitted for the knot interpolation (k_interp.hip), as k_vjp_theta does
+            const double wn = -wv * W * sp;
+            if (A.emitH) {
+              const long long q = g.offd + gi + (long long)(g.nx - 1) * gj;
+              A.emitH[q] = Hb;
+              A.emitV[q] = wn;
+            } else if (gth && Hb > 0.0) {
+              mlp_grad(L, g.T, Hb, wn, gth, gstride);
+            }
+          } else if (gth && Hb > 0.0) {  // U law: dVelocity^/dtheta = (Hbar > 0) dU/dtheta / f, exact backprop per node (:None branch)
+            mlp_grad(L, Hb, gS, -wv * W * A.finv, gth, gstride);
+          }
         } else {
           const double t = sp * W;
           gsum += t;

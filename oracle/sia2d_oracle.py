@@ -1629,10 +1629,35 @@ def _A_dual(law: Law, ph: Phys, theta=None):
     return law_value(law, ph, None, None, theta)
 
 
+def _velocity_up_hybrid(law: Law, ph: Phys, Hbar, gradS, Y):
+    """compute_Velocity^ of target :D_hybrid AS WRITTEN (target_D_hybrid.jl:353-372): the sliding term of the diffusivity
+    and Y Gamma H^(n_H+1) |grad S|^(n_gradS-1) with Gamma = 2 (rho g)^n / (n + 2) -- the DIFFUSIVITY's Gamma (the variable is
+    named Gamma^_no_A but assigned Gamma(...), :362), not Gamma^ = 2 (rho g)^n / (n + 1)."""
+    nH, nS = _hyb_exps(law, ph)
+    D = Y * gamma_no_A(ph) * _pow(Hbar, nH + 1.0) * _pow(gradS, nS - 1.0)
+    Sc = sliding_S(ph)
+    if Sc != 0.0:
+        D = D + Sc * _pow(Hbar, ph.p - ph.q + 1.0) * _pow(gradS, ph.p - 1.0)
+    return D
+
+
+def _diffusivity_hybrid_with_Y(law: Law, ph: Phys, Hbar, gradS, Y):
+    """compute_D(target, Y; ...) of target :D_hybrid (target_D_hybrid.jl:190-208)."""
+    nH, nS = _hyb_exps(law, ph)
+    D = Y * gamma_no_A(ph) * _pow(Hbar, nH + 2.0) * _pow(gradS, nS - 1.0)
+    Sc = sliding_S(ph)
+    if Sc != 0.0:
+        D = Sc * _pow(Hbar, ph.p - ph.q + 1.0) * _pow(gradS, ph.p - 1.0) + D
+    return D
+
+
 def velocity_up(law: Law, ph: Phys, Hbar, gradS, theta=None):
-    """Velocity^ (target_A.jl:94-108), sliding term exactly as written there; target :D: U / f (target_D_pure.jl:206-217)."""
+    """Velocity^ (target_A.jl:94-108), sliding term exactly as written there; target :D: U / f (target_D_pure.jl:206-217);
+    target :D_hybrid: _velocity_up_hybrid."""
     if law.kind == LAW_NN_U:
         return law_value(law, ph, Hbar, gradS, theta) / law.fV
+    if law.kind == LAW_NN_Y:
+        return _velocity_up_hybrid(law, ph, Hbar, gradS, law_value(law, ph, Hbar, gradS, theta))
     A = _A_dual(law, ph, theta)
     D = A * gamma_up_no_A(ph) * _pow(Hbar, ph.n + 1.0) * _pow(gradS, ph.n - 1.0)
     Sc = sliding_S(ph)
@@ -1646,6 +1671,20 @@ def d_velocity_up_dH(law: Law, ph: Phys, Hbar, gradS, theta=None):
     if law.kind == LAW_NN_U:
         d = 1e-4
         return (1.0 / law.fV) * (law_value(law, ph, Hbar + d, gradS, theta) - law_value(law, ph, Hbar - d, gradS, theta)) / (2.0 * d)
+    if law.kind == LAW_NN_Y:
+        # dVelocity^/dH of target :D_hybrid AS WRITTEN (target_D_hybrid.jl:226-262): the closed-form part differentiates
+        # Y Gamma H^(n_H+1) and the sliding term; the network part is a forward difference (1e-4) of compute_D -- the
+        # DIFFUSIVITY (H^(n_H+2)), not of compute_Velocity^ -- with Y evaluated at Hbar + dH and at Hbar.
+        nH, nS = _hyb_exps(law, ph)
+        Y = law_value(law, ph, Hbar, gradS, theta)
+        out = (nH + 1.0) * Y * gamma_no_A(ph) * _pow(Hbar, nH) * _pow(gradS, nS - 1.0)
+        Sc = sliding_S(ph)
+        if Sc != 0.0:
+            out = (ph.p - ph.q + 1.0) * Sc * _pow(Hbar, ph.p - ph.q) * _pow(gradS, ph.p - 1.0) + out
+        d = 1e-4
+        a = _diffusivity_hybrid_with_Y(law, ph, Hbar, gradS, law_value(law, ph, Hbar + d, gradS, theta))
+        b = _diffusivity_hybrid_with_Y(law, ph, Hbar, gradS, Y)
+        return out + (a - b) / d
     A = _A_dual(law, ph, theta)
     out = A * gamma_up_no_A(ph) * (ph.n + 1.0) * _pow(Hbar, ph.n) * _pow(gradS, ph.n - 1.0)
     Sc = sliding_S(ph)
@@ -1660,6 +1699,14 @@ def d_velocity_up_dgradS(law: Law, ph: Phys, Hbar, gradS, theta=None):
     if law.kind == LAW_NN_U:
         d = 1e-6
         return (1.0 / law.fV) * (law_value(law, ph, Hbar, gradS + d, theta) - law_value(law, ph, Hbar, gradS - d, theta)) / (2.0 * d)
+    if law.kind == LAW_NN_Y:
+        # AS WRITTEN (target_D_hybrid.jl:264-285): Gamma^ = 2 (rho g)^n / (n + 1) and H^(n_H+2) here
+        nH, nS = _hyb_exps(law, ph)
+        out = gamma_up_no_A(ph) * law_value(law, ph, Hbar, gradS, theta) * (nS - 1.0) * _pow(Hbar, nH + 2.0) * _pow(gradS, nS - 3.0)
+        Sc = sliding_S(ph)
+        if Sc != 0.0:
+            out = (ph.p - 1.0) * Sc * _pow(Hbar, ph.p - ph.q + 1.0) * _pow(gradS, ph.p - 3.0) + out
+        return out
     A = _A_dual(law, ph, theta)
     out = A * gamma_up_no_A(ph) * (ph.n - 1.0) * _pow(Hbar, ph.n + 1.0) * _pow(gradS, ph.n - 3.0)
     Sc = sliding_S(ph)
@@ -1705,6 +1752,18 @@ def vjp_surface_V_theta(dVx, dVy, H, B, dx, dy, ph: Phys, law: Law, theta=None):
     gSdV = gSx * inn1(dVx) + gSy * inn1(dVy)
     if law.kind == LAW_NN_U:  # dVelocity^/dtheta = dU/dtheta / f with dU/dtheta = (Hbar > 0) x backprop (target_D_pure.jl:139-176,247-255)
         return -np.tensordot(law_grad_theta(law, ph, Hbar, gS, theta), (Hbar > 0.0) * gSdV / law.fV, axes=([1, 2], [0, 1]))
+    if law.kind == LAW_NN_Y:
+        # dVelocity^/dtheta of target :D_hybrid (target_D_hybrid.jl:287-351): Gamma^ H^(n_H+1) |grad S|^(n_gradS-1) x dY/dtheta,
+        # the law gradient exact per node (:None) or interpolated linearly in Hbar on create_interpolation's knots (:Linear,
+        # the target's default) -- the same two branches as dDiffusivity/dtheta
+        nH, nS = _hyb_exps(law, ph)
+        spatial = gamma_up_no_A(ph) * _pow(Hbar, nH + 1.0) * _pow(gS, nS - 1.0) * gSdV
+        kind, nhalf = law.interp()
+        if kind == "linear" and Hbar.max() > 0.0:
+            g = law_grad_theta_linear(law, ph, Hbar, gS, theta, nhalf)
+        else:
+            g = law_grad_theta(law, ph, Hbar, gS, theta)
+        return -np.tensordot(g, spatial, axes=([1, 2], [0, 1]))
     spatial = gamma_up_no_A(ph) * _pow(Hbar, ph.n + 1.0) * _pow(gS, ph.n - 1.0) * gSdV
     if law.kind == LAW_CONST_A:
         return -np.array([np.sum(spatial)])

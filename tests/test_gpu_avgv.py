@@ -158,17 +158,6 @@ def test_avgv_ragged_batch_gridded_law_and_errors(gpu):
     with pytest.raises(gpu.OdinnError, match="not among the tstops"):
         b.loss_grad(ts, theta=th, reltol=1e-8)
     b.close()
-    # per-node MLP laws (targets :D_hybrid / :D) have no surface-velocity path here, as for LossV
-    om2, gm2, th2 = _mlp_pair(gpu, [2, 3, 1], [1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
-    b = gpu.GlacierBatch([shapes[0]], [50.0], T=[-5.0])
-    b.set_fields(0, gls[0].H0, gls[0].B)
-    b.set_law(gpu.LAW_NN_Y, gm2, th2)
-    b.set_reference(0, ts, refs[0], 3)
-    b.set_avgv_reference(0, a.t1, a.t2, a.Vabs, a.Vx, a.Vy)
-    b.set_avgv_loss(1.0, step, "xy")
-    with pytest.raises(gpu.OdinnError, match="surface-velocity path"):
-        b.loss_grad(ts, theta=th2, reltol=1e-8)
-    b.close()
 
 
 def test_multiloss_with_lossavgv_through_the_api(gpu):

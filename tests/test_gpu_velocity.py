@@ -212,26 +212,104 @@ def test_lossV_with_the_U_law_target_D(gpu, adjoint):
     ratio, angle, relerr = stats_err_arrays(gg, go)
     assert abs(ratio) < 1e-5 and abs(angle) < 1e-8 and relerr < 1e-5, (ratio, angle, relerr)
     b.close()
-    # the Y law (target :D_hybrid) has no surface-velocity path here
-    b = gpu.GlacierBatch([shapes[0]], [50.0], T=[-5.0])
+
+
+def _y_law(gpu, ph, arch="default"):
     from test_gpu_parity import _mlp_pair
-    om2, gm2, th2 = _mlp_pair(gpu, [2, 3, 1], [1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
-    b.set_fields(0, *O.synthetic_alpine(*shapes[0]))
-    b.set_law(gpu.LAW_NN_Y, gm2, th2)
-    with pytest.raises(gpu.OdinnError, match="target :D"):
-        b.surface_V(0, O.synthetic_alpine(*shapes[0])[0])
+    widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "light": ([2, 3, 1], [1, 2])}[arch]
+    return _mlp_pair(gpu, widths, acts, [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+
+
+@pytest.mark.parametrize("interp", ["linear", "none"])
+@pytest.mark.parametrize("C", [0.0, 7e-8])
+def test_surface_V_with_the_Y_law_target_D_hybrid(gpu, interp, C):
+    """Target :D_hybrid (target_D_hybrid.jl:210-372) AS WRITTEN: Velocity^ with the diffusivity's Gamma, its H-partial with a
+    forward difference of compute_D, its slope partial and the theta-weight with Gamma^ (the oracle records the
+    inconsistencies; upstream never runs this path).  surface_V and both VJPs against the oracle, the theta-VJP through the
+    target's default `:Linear` interpolation of dY/dtheta (knots of create_interpolation) and through `:None`."""
+    ph = O.Phys(C=C, p=3.0, q=1.0) if C else O.Phys()
+    om, gm, th = _y_law(gpu, ph)
+    law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=-5.0, interpolation=interp, n_interp_half=20)
+    nx, ny = 70, 53
+    H0, B = O.synthetic_alpine(nx, ny)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], phys=[gpu.PhysicalParameters(C=C, p=3.0, q=1.0)] if C else None, T=[-5.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_Y, gm, th)
+    if interp == "linear":
+        b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, 20)
+    else:
+        b.set_grad_interpolation(gpu._lib.GRAD_INTERP_NONE, 75)
+    vx, vy = O.surface_V(H0, B, 50.0, 50.0, ph, law)
+    Vx, Vy = b.surface_V(0, H0)
+    assert rel_l2(Vx[:-1, :-1], vx) < 1e-12 and rel_l2(Vy[:-1, :-1], vy) < 1e-12
+    rng = np.random.default_rng(7)
+    w1, w2 = rng.standard_normal((nx, ny)), rng.standard_normal((nx, ny))
+    # (the H-partial contains a forward difference with step 1e-4: two evaluations agree to ~1e-16 / 1e-4 of the law's scale)
+    assert rel_l2(b.surface_V_vjp_H(0, w1, w2, H0), O.vjp_surface_V_H(w1, w2, H0, B, 50.0, 50.0, ph, law)) < 1e-7
+    assert rel_l2(b.surface_V_vjp_theta(0, w1, w2, H0), O.vjp_surface_V_theta(w1, w2, H0, B, 50.0, 50.0, ph, law)) < 1e-9
     b.close()
 
 
+@pytest.mark.parametrize("adjoint", ["discrete", "continuous"])
+@pytest.mark.parametrize("kind", ["V", "HV"])
+def test_velocity_losses_with_the_Y_law_target_D_hybrid(gpu, adjoint, kind):
+    """LossV / LossHV with target :D_hybrid through both adjoints against the oracle (two glaciers, `:Linear` law gradients)."""
+    ph = O.Phys()
+    om, gm, th = _y_law(gpu, ph)
+    step = 1.0 / 96.0
+    ts = [2010.0 + j * step for j in range(5)]
+    shapes = [(56, 40), (64, 48)]
+    b = gpu.GlacierBatch(shapes, [50.0] * 2, T=[-5.0, -8.0])
+    vspec = O.LossVSpec(component="xy", scale_loss=True)
+    Lo, go = 0.0, 0.0
+    for k, (nx, ny) in enumerate(shapes):
+        law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=[-5.0, -8.0][k], interpolation="linear", n_interp_half=20)
+        H0, B = O.synthetic_alpine(nx, ny, hmax=150.0, slope=0.1)
+        gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+        cfg = O.SimConfig(tstops=ts, reltol=1e-10)
+        ref, _, _ = O.forward(gl, law, cfg)
+        tV = ts if adjoint == "continuous" else ts[1 + k::2]
+        Vref = []
+        for t in tV:
+            Vx, Vy, V = O.V_from_H(ref[ts.index(t)], B, 50.0, 50.0, ph, law)
+            Vref.append((1.1 * V, 1.1 * Vx, 1.1 * Vy))
+        ref = [r * (1.0 - 0.01 * j) for j, r in enumerate(ref)]
+        b.set_fields(k, H0, B)
+        b.set_reference(k, ts, ref, 3)
+        b.set_velocity_reference(k, tV, [v[0] for v in Vref], [v[1] for v in Vref], [v[2] for v in Vref])
+        if adjoint == "discrete":
+            l, g, _ = O.loss_and_grad_HV(gl, law, cfg, ref, ts, Vref, tV, vspec, loss_kind=kind, scaling=0.7)
+        else:
+            l, g, _, _ = O.loss_and_grad_continuous(gl, law, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=6),
+                                                    V_ref=Vref, tV_ref=tV, vspec=vspec, loss_kind=kind, scaling=0.7)
+        Lo, go = Lo + l, go + g
+    b.set_law(gpu.LAW_NN_Y, gm, th)
+    b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, 20)
+    b.set_loss(gpu._lib.LOSS_V if kind == "V" else gpu._lib.LOSS_HV, "xy", True, 0.7)
+    if adjoint == "discrete":
+        Lg, gg = b.loss_grad(ts, theta=th, reltol=1e-10)
+    else:
+        Lg, gg = b.loss_grad_continuous(ts, theta=th, reltol=1e-10, n_quadrature=6)
+    b.close()
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo), (Lg, Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-8 and relerr < 1e-5, (ratio, angle, relerr)
+
+
+@pytest.mark.parametrize("lawkind", ["U", "Y"])
 @pytest.mark.parametrize("term", ["avgv", "vreg"])
-def test_time_aggregated_velocity_terms_with_the_U_law(gpu, term):
+def test_time_aggregated_velocity_terms_with_the_U_law(gpu, term, lawkind):
     """LossAvgV and VelocityRegularization are generic over the targets in the reference (TimeAggregatedLosses.jl:115-258,
     Regularization.jl:192-245: they go through V_from_H and VJP_lambda_dsurface_V/d{H, theta}): with the U law (target :D),
     next to LossH, through both adjoints against the oracle."""
     from test_gpu_avgv import _sample
     ph = O.Phys()
-    om, gm, th = _u_law(gpu, ph)
-    law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, fV=0.8)
+    if lawkind == "U":
+        om, gm, th = _u_law(gpu, ph)
+        law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, fV=0.8)
+    else:  # target :D_hybrid, `:Linear` law gradients (the target's default)
+        om, gm, th = _y_law(gpu, ph)
+        law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=-5.0, interpolation="linear", n_interp_half=20)
     step = 1.0 / 96.0
     ts = [2010.0 + j * step for j in range(7)]
     nx, ny = 56, 40
@@ -240,11 +318,15 @@ def test_time_aggregated_velocity_terms_with_the_U_law(gpu, term):
     cfg = O.SimConfig(tstops=ts, reltol=1e-10)
     ref, _, _ = O.forward(gl, law, cfg)
     ref = [r * (1.0 - 0.01 * j) for j, r in enumerate(ref)]
-    b = gpu.GlacierBatch([(nx, ny)], [50.0])
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-5.0])
     b.set_fields(0, H0, B)
     b.set_reference(0, ts, ref, 3)
-    b.set_law(gpu.LAW_NN_U, gm, th)
-    b.set_surface_velocity_factor(0.8)
+    if lawkind == "U":
+        b.set_law(gpu.LAW_NN_U, gm, th)
+        b.set_surface_velocity_factor(0.8)
+    else:
+        b.set_law(gpu.LAW_NN_Y, gm, th)
+        b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, 20)
     if term == "avgv":
         a = _sample(gl, law, cfg, ts, 1, 5, "xy")
         cfg.avgv, cfg.avgv_weight = a, 2.0

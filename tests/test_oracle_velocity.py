@@ -129,3 +129,27 @@ def test_continuous_adjoint_with_lossV_vs_fd():
     with pytest.raises(ValueError):  # velocity data that do not span tspan
         O.loss_and_grad_continuous(gl, law0, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=4),
                                    V_ref=Vref[2::2], tV_ref=ts[2::2], vspec=vs, loss_kind="V")
+
+
+def test_D_hybrid_velocity_is_restated_as_written_not_as_consistent():
+    """Target :D_hybrid's Velocity^ (target_D_hybrid.jl:210-372) mixes Gamma = 2 (rho g)^n / (n + 2) in the value with
+    Gamma^ = 2 (rho g)^n / (n + 1) in the theta-weight: the restated dVelocity^/dtheta is (n + 2) / (n + 1) times the true
+    derivative of the restated value.  This test pins that the oracle reproduces the reference's text, not a corrected one."""
+    ph = O.Phys()
+    om = O.MLP([2, 3, 10, 3, 1], [1, 1, 1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+    th = om.init_theta(np.random.default_rng(9))
+    H, B = O.synthetic_valley(48, 40, 50.0)
+    rng = np.random.default_rng(1)
+    w1, w2 = rng.standard_normal(H.shape), rng.standard_normal(H.shape)
+    law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=-5.0, interpolation="none")
+    g = O.vjp_surface_V_theta(w1, w2, H, B, 50.0, 50.0, ph, law)
+
+    def f(t):
+        vx, vy, _ = O.V_from_H(H, B, 50.0, 50.0, ph, O.Law(kind=O.LAW_NN_Y, mlp=om, theta=t, T=-5.0))
+        return np.sum(vx * w1 + vy * w2)
+
+    for q in (3, 17, 40):
+        e = np.zeros_like(th)
+        e[q] = 1e-6
+        fd = (f(th + e) - f(th - e)) / 2e-6
+        assert abs(fd / g[q] - (ph.n + 1.0) / (ph.n + 2.0)) < 1e-5, (q, fd, g[q])
