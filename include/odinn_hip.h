@@ -306,7 +306,8 @@ int odinn_set_glacier_stops(odinn_batch* b, int g, int n, const double* t);
  * A mass-balance time that is not a stop of the glacier makes its integrator land there and apply the mass balance without
  * adding a snapshot to the result -- PeriodicCallback(mb_action!, step_MB) of inversion_utils.jl:498-517 with
  * step_MB not a multiple of solver.step.  (odinn_loss_grad rejects such times like the reference's DiscreteAdjoint,
- * gradient.jl:131; odinn_loss_grad_continuous: ODINN_ERR_UNSUPPORTED.)
+ * gradient.jl:131; odinn_loss_grad_continuous stops its reverse solve there too and adds VJP_MB(lambda, H_itp(t) - MB_t), the
+ * reverse PeriodicCallback of gradient.jl:413-432.)
  * stats: array of n_glaciers entries (may be NULL). */
 int odinn_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times,
                 const odinn_solver_opts* opts, odinn_solve_stats* stats);

@@ -374,7 +374,7 @@ struct odinn_batch {
   size_t reg_cap = 0, regp_cap = 0;
   // reverse (continuous-adjoint) solve tables
   double *d_rtau = nullptr, *d_rqw = nullptr, *d_tsnap = nullptr, *d_qw = nullptr;
-  int *d_rsnap = nullptr, *d_rmbf = nullptr, *d_rmbs = nullptr, *d_nr = nullptr, *d_ksn = nullptr, *d_lastseg = nullptr;
+  int *d_rsnap = nullptr, *d_rmbf = nullptr, *d_rmbs = nullptr, *d_rhid = nullptr, *d_nr = nullptr, *d_ksn = nullptr, *d_lastseg = nullptr;
   double* d_zerow = nullptr;
   AdjState* d_adj = nullptr;
   int rev_cap = 0, tsnap_cap = 0;
@@ -1556,7 +1556,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
   dfree(b->d_snapslot); dfree(b->d_nst); dfree(b->d_mbf_res); dfree(b->d_mbs_res); dfree(b->d_nr); dfree(b->d_ksn); dfree(b->d_lastseg);
-  dfree(b->d_zerow); dfree(b->d_swq); dfree(b->d_sgq);
+  dfree(b->d_zerow); dfree(b->d_swq); dfree(b->d_sgq); dfree(b->d_rhid);
   dfree(b->d_aVabs); dfree(b->d_aVx); dfree(b->d_aVy); dfree(b->d_avg); dfree(b->d_wA); dfree(b->d_aggH);
   if (b->d_agg_slot) (void)hipFree(b->d_agg_slot);
   if (b->d_av_on) (void)hipFree(b->d_av_on);
@@ -2542,9 +2542,6 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   CHK(do_loss(b, &const_loss));  // forward loss over the snapshots -> d_lossacc
   const int k = b->K(), G = b->G;
   const double t0 = tstops[0], t1 = tstops[n_stops - 1];
-  if (b->nhid > 0)
-    return fail(ODINN_ERR_UNSUPPORTED, "continuous adjoint: mass-balance times that are not result stops are not supported "
-                                       "(the forward solve handles them; make step_MB a multiple of the solver step here)");
   // ---- reverse stop tables, per glacier: tau = -t ascending over the glacier's own snapshots and the quadrature nodes (:457) ----
   std::vector<double> gx, gw;
   gauss_legendre(ao.n_quadrature, gx, gw);
@@ -2555,23 +2552,28 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   }
   if (b->vreg_on())  // VelocityRegularization: dL/dH at its stops, dL/dtheta by the quadrature (its loss is in do_loss)
     CHK(vreg_forward(b, true, false, ao.n_quadrature, qt.data(), qwt.data()));
-  struct Stop { double tau; int snap; double qw; };
+  struct Stop { double tau; int snap; double qw; int hid, mbs; };  // hid > 0: mass-balance-only stop (hidden snapshot slot + 1)
   std::vector<std::vector<Stop>> stg(G);
   int nr = 0;
   for (int g = 0; g < G; ++g) {
     std::vector<Stop>& st = stg[g];
     const std::vector<double>& tsg = b->ts_g[g];
     st.reserve(tsg.size() + ao.n_quadrature);
-    for (int j = 0; j < (int)tsg.size(); ++j) st.push_back({-tsg[j], j, 0.0});
-    for (int i = 0; i < ao.n_quadrature; ++i) st.push_back({-qt[i], -1, qwt[i]});
+    for (int j = 0; j < (int)tsg.size(); ++j) st.push_back({-tsg[j], j, 0.0, 0, 0});
+    for (int i = 0; i < ao.n_quadrature; ++i) st.push_back({-qt[i], -1, qwt[i], 0, 0});
+    // mass-balance times that are not result stops: the reverse PeriodicCallback (gradient.jl:426-432) stops there as well
+    for (int i = 0; i < b->it_n[g]; ++i) {
+      const size_t q = (size_t)i * G + g;
+      if (b->it_snap[q] >= b->kmax) st.push_back({-b->it_t[q], -1, 0.0, b->it_snap[q] + 1, b->it_mbs[q]});
+    }
     std::stable_sort(st.begin(), st.end(), [](const Stop& a, const Stop& c) { return a.tau < c.tau; });
     for (size_t i = 1; i < st.size(); ++i)
-      if (!(st[i].tau > st[i - 1].tau)) return fail(ODINN_ERR_ARG, "a quadrature node coincides with a snapshot time");
+      if (!(st[i].tau > st[i - 1].tau)) return fail(ODINN_ERR_ARG, "a quadrature node coincides with a snapshot or mass-balance time");
     nr = std::max(nr, (int)st.size());
   }
   const size_t nrG = (size_t)nr * G;
   std::vector<double> h_tau(nrG, -t0), h_qw(nrG, 0.0), h_tsnap((size_t)k * G, t1);
-  std::vector<int> h_snap(nrG, -1), h_mbf(nrG, 0), h_mbs(nrG, 0), h_nr(G), h_ksn(G);
+  std::vector<int> h_snap(nrG, -1), h_mbf(nrG, 0), h_mbs(nrG, 0), h_hid(nrG, 0), h_nr(G), h_ksn(G);
   for (int g = 0; g < G; ++g) {
     const std::vector<Stop>& st = stg[g];
     h_nr[g] = (int)st.size(); h_ksn[g] = b->nres(g);
@@ -2580,12 +2582,13 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       const size_t q = (size_t)i * G + g;
       h_tau[q] = st[i].tau; h_qw[q] = st[i].qw; h_snap[q] = st[i].snap;
       if (st[i].snap >= 1 && b->any_mb && b->mbf_res[(size_t)st[i].snap * G + g]) { h_mbf[q] = 1; h_mbs[q] = b->mbs_res[(size_t)st[i].snap * G + g]; }
+      if (st[i].hid > 0) { h_mbf[q] = 1; h_mbs[q] = st[i].mbs; h_hid[q] = st[i].hid; }
     }
   }
   if ((int)nrG > b->rev_cap) {
-    dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_rsnap); dfree(b->d_rmbf); dfree(b->d_rmbs);
+    dfree(b->d_rtau); dfree(b->d_rqw); dfree(b->d_rsnap); dfree(b->d_rmbf); dfree(b->d_rmbs); dfree(b->d_rhid);
     CHK(dalloc(&b->d_rtau, nrG)); CHK(dalloc(&b->d_rqw, nrG)); CHK(dalloc(&b->d_rsnap, nrG));
-    CHK(dalloc(&b->d_rmbf, nrG)); CHK(dalloc(&b->d_rmbs, nrG));
+    CHK(dalloc(&b->d_rmbf, nrG)); CHK(dalloc(&b->d_rmbs, nrG)); CHK(dalloc(&b->d_rhid, nrG));
     b->rev_cap = (int)nrG;
   }
   if (k * G > b->tsnap_cap) { dfree(b->d_tsnap); CHK(dalloc(&b->d_tsnap, (size_t)k * G)); b->tsnap_cap = k * G; }
@@ -2596,6 +2599,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   HIPCHK(hipMemcpyAsync(b->d_rsnap, h_snap.data(), nrG * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_rmbf, h_mbf.data(), nrG * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_rmbs, h_mbs.data(), nrG * sizeof(int), hipMemcpyHostToDevice, b->stream));
+  HIPCHK(hipMemcpyAsync(b->d_rhid, h_hid.data(), nrG * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_tsnap, h_tsnap.data(), (size_t)k * G * sizeof(double), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_nr, h_nr.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipMemcpyAsync(b->d_ksn, h_ksn.data(), (size_t)G * sizeof(int), hipMemcpyHostToDevice, b->stream));
@@ -2714,6 +2718,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   C.tstops = b->d_rtau; C.nstops = b->d_nr; C.G = G; C.mb_flag = b->d_rmbf; C.mb_slot = b->d_rmbs; C.dtmax = ao.dtmax;
   C.adaptive = 1; C.fixed_dt = 0.0; C.n_active = b->d_nactive; C.errpart = b->d_part; C.stride = 4; C.fused = 0;
   C.adj = b->d_adj; C.tsnap = b->d_tsnap; C.stop_snap = b->d_rsnap; C.stop_qw = b->d_rqw; C.qw_out = b->d_qw;
+  C.stop_hid = b->nhid > 0 ? b->d_rhid : nullptr;
   AdjStageArgs SA{};
   SA.snaps = b->d_snaps; SA.ntot = b->ntot; SA.adj = b->d_adj; SA.S2 = b->d_S2; SA.S3 = b->d_S3; SA.E = b->d_E;
   SA.abstol = ao.abstol; SA.reltol = ao.reltol;

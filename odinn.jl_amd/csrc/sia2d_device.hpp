@@ -145,7 +145,8 @@ struct AdjState {  // per-glacier state of the reverse (continuous-adjoint) solv
   int seg;        // H_itp segment [tsnap[seg], tsnap[seg+1]] that contains the coming step
   int seg_stop;   // segment that contains the stop just reached
   int snapj;      // forward snapshot index of the stop just reached (-1: not a snapshot time)
-  int pad;
+  int pad;        // > 0: the stop is a mass-balance time that is not a result stop; pad - 1 = the hidden snapshot slot that
+                  // holds the forward state right after that mass balance (0 otherwise)
   double qw;      // Gauss-Legendre weight of the stop just reached (0: not a quadrature node)
   double s_stop;  // interpolation weight of the stop inside seg_stop
   double sitp[5]; // interpolation weights at the five stage times tau + c_i dt of the coming step
@@ -1174,6 +1175,7 @@ struct CtrlArgs {
   const double* tsnap;    // [kmax][G] forward snapshot times t_0 < ... < t_{k_g - 1} of every glacier
   const int* stop_snap;   // [imax][G] per stop: forward snapshot index, -1 for a quadrature node
   const double* stop_qw;  // [imax][G] per stop: quadrature weight, 0 for a snapshot time
+  const int* stop_hid;    // [imax][G] (nullable) per stop: hidden snapshot slot + 1 of a mass-balance-only stop, else 0
   double* qw_out;         // per glacier: weight of the node reached by this step (0 otherwise)
 };
 
@@ -1272,7 +1274,7 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
   double t = st.t;
   st.at_stop = 0;
   st.mb_now = 0;
-  if (C.adj) { ad.qw = 0.0; ad.snapj = -1; }
+  if (C.adj) { ad.qw = 0.0; ad.snapj = -1; ad.pad = 0; }
   if (accept) {
     st.naccept++;
     st.accepted = 1;
@@ -1286,6 +1288,7 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
       if (C.adj) {
         AdjState* a = &ad;
         a->snapj = C.at(C.stop_snap, st.istop, gidx);
+        a->pad = C.stop_hid ? C.at(C.stop_hid, st.istop, gidx) : 0;
         a->qw = C.stop_qw[(long long)st.istop * C.G + gidx];
         a->seg_stop = a->seg;
         const double ta = C.tsnap[(long long)a->seg * C.G + gidx];
@@ -2575,6 +2578,10 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
     if (w != 0.0) roff = (long long)A.refslot[(long long)a.snapj * A.G + t4.x] * A.ntot;
   }
   const bool do_mb = a.snapj >= 0 && gs->mb_now && g.has_mb;
+  // a mass-balance time that is not a result stop (the reverse PeriodicCallback, gradient.jl:413-432): lam += VJP_MB(lam, H_pre)
+  // with H_pre = H_itp(t) - MB_t as the reference forms it -- H_itp from the RESULT snapshots, MB_t = (state after) - (state
+  // before) the mass balance of the forward solve at t (hidden snapshot slot, pre-MB slot)
+  const bool mb_only = a.snapj < 0 && a.pad > 0 && gs->mb_now && g.has_mb;
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
     const int gj = j0 + ty + NW * m;
@@ -2611,6 +2618,21 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
         }
         if (!A.loss_first) l += dl + dagg;
         U[id] = l;
+      }
+      if (mb_only) {
+        const double l = U[id];
+        const double ha = A.snaps[(long long)a.seg_stop * A.ntot + id];
+        const double hb = A.snaps[(long long)(a.seg_stop + 1) * A.ntot + id];
+        const double post = A.snaps[(long long)(a.pad - 1) * A.ntot + id];
+        const double pre = A.premb[(long long)gs->mb_slot * A.ntot + id];
+        const double h = fma(a.s_stop, hb - ha, ha) - (post - pre);
+        double dmb;
+        const double mb = mb_value(g, A.mb0[id], A.Sref ? A.Sref[id] : 0.0, h, P.B[id], dmb);
+        const bool msk = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
+        double vv = 0.0;
+        if (msk) vv = dmb * l;
+        if (msk && h + mb < 0.0) vv = -l;
+        U[id] = l + vv;
       }
       if (A.Hq && ((a.qw != 0.0 && !A.hq_snap_only) || a.snapj >= 0)) {  // H_itp at the stop, for the velocity loss term (the theta-VJP forms it itself)
         const double ha = A.snaps[(long long)a.seg_stop * A.ntot + id];

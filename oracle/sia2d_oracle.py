@@ -1434,9 +1434,19 @@ def loss_and_grad_continuous(gl: Glacier, law: Law, cfg: SimConfig, H_ref, tH_re
     lam1 = effect_mb(t[-1], lam1)  # PeriodicCallback(initial_affect = true) :431-432
     snap_tau = [-x for x in reversed(t)]
     stops = sorted(set(snap_tau) | set(-float(x) for x in nodes))  # :457
-    cb = lambda u, tau: effect_agg(-tau, effect_loss(-tau, effect_mb(-tau, u)))  # CallbackSet order: MB, loss, aggregated :437
+    tset = set(t)
+    # mass-balance times that are not result stops (step_MB not a multiple of solver.step): the reverse PeriodicCallback
+    # (:426-432) stops the integrator there too and adds VJP_MB(lambda, H_itp(t) - MB_t) -- H_itp interpolates the RESULT
+    mb_only = sorted(-x for x in mbt if x not in tset and t[0] < x < t[-1])
+
+    def cb(u, tau):  # CallbackSet order: MB, loss, aggregated :437
+        tt = -tau
+        if tt in tset:
+            return effect_agg(tt, effect_loss(tt, effect_mb(tt, u)))
+        return effect_mb(tt, u)
+
     lam_s, st_rev, _ = solve(f_rev, lam1, stops, adj.reltol, adj.abstol, adj.dtmax, adj.maxiters,
-                             callback=cb, callback_times=snap_tau[1:], time_dependent=True)
+                             callback=cb, callback_times=snap_tau[1:] + mb_only, time_dependent=True)
     P = 1 if law.kind == LAW_CONST_A else law.mlp.n_params
     dLdtheta = np.zeros(P)
     at = {tau: i for i, tau in enumerate(stops)}

@@ -268,3 +268,42 @@ def test_inversion_api_builds_the_stop_table_per_glacier(gpu, adjoint):
     assert np.allclose(dth, go, rtol=2e-5)
     res = gpu.run_b(gpu.Prediction(gpu.Model(gpu.SIA2Dmodel(p, A=gpu.ConstantA(3e-17))), gl, p))
     assert [r.t for r in res] == own and [len(r.H) for r in res] == [len(o) for o in own]
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_continuous_adjoint_with_mass_balance_steps_that_are_not_result_stops(gpu, monkeypatch, fused):
+    """ContinuousAdjoint with step_MB = 1/48 yr and result stops every 1/24 yr: the reverse PeriodicCallback (gradient.jl:413-432)
+    stops the reverse integrator at the in-between mass-balance times too and adds VJP_MB(lambda, H_itp(t) - MB_t), H_itp being
+    the interpolant of the RESULT snapshots -- against the oracle's restatement."""
+    monkeypatch.setenv("ODINN_ADJ_FUSED", fused)
+    ph = O.Phys()
+    nx, ny = 64, 48
+    H0, B = O.synthetic_valley(nx, ny, 50.0)
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    ts = [T0 + j / 24.0 for j in range(4)]
+    mbt = [T0 + (m + 1) / 48.0 for m in range(6)]
+    mb = _mb(H0, B, step=1.0 / 48.0)
+    om = O.default_nn(1, light=False, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
+    gm = gpu.MLPSpec(om.widths, om.acts, None, O.POST_AFFINE, ph.minA, ph.maxA)
+    th_true, th0 = om.init_theta(np.random.default_rng(42)), om.init_theta(np.random.default_rng(1234))
+    cfg = O.SimConfig(tstops=ts, reltol=1e-8, mb=mb, mb_times=mbt)
+    ref, _, _ = O.forward(gl, O.Law(kind=O.LAW_NN_A_SCALAR, mlp=om, theta=th_true, T=-2.0), cfg)
+    law0 = O.Law(kind=O.LAW_NN_A_SCALAR, mlp=om, theta=th0, T=-2.0)
+    adj = O.ContinuousAdjointCfg(n_quadrature=10)
+    Lo, go, lam0, st_o = O.loss_and_grad_continuous(gl, law0, cfg, ref, ts, adj)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-2.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_A_SCALAR, gm, th0)
+    b.set_reference(0, ts, ref, 3)
+    b.set_mass_balance(0, mb.mb0, mb.dmb_dS, mb.S_ref, mb.mb_max)
+    Lg, gg = b.loss_grad_continuous(ts, theta=th0, mb_times=mbt, reltol=1e-8, n_quadrature=10)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-9 and relerr < 1e-5, (ratio, angle, relerr)
+    assert rel_l2(b.lambda0(0), lam0) < 1e-5
+    sr = b.last_stats_rev[0]
+    assert abs(sr.naccept - st_o.naccept) <= 2 and abs(sr.nreject - st_o.nreject) <= 2, (sr, st_o)
+    # without the in-between applications the gradient is another one
+    Lh, gh = b.loss_grad_continuous(ts, theta=th0, mb_times=ts[1:], reltol=1e-8, n_quadrature=10)
+    assert rel_l2(gh, gg) > 1e-4
+    b.close()
