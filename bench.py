@@ -139,6 +139,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args.gpus)  # does not return
 
+    # stdout carries ONE JSON line and nothing else: libraries that print banners on file descriptor 1 (RCCL's version block at
+    # communicator creation, gloo's rank messages) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    _stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     import _odinn_import
@@ -681,7 +687,10 @@ def main():
             "cpu_baseline": cpu,
             "aux": aux,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(_stdout_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     b.close()
     if dist is not None:
         dist.destroy_process_group()
