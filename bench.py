@@ -645,6 +645,11 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": ach_tf / FP64_PEAK_TFLOPS,
                 "traffic": traffic,
+                "valu_busy_frac": kn.get("valu_busy_frac"),
+                "valu_busy_note": "committed PMC pass: 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles of the launch.  A pure v_fma_f64 stream at 4 waves "
+                                  "per SIMD issues one wave-instruction per 5.3-6.0 cycles on this part (profiles/r02/valu_issue_cost_ubench.txt), "
+                                  "i.e. reaches 0.67-0.75 by this measure: the kernel sits at the fp64 pipe's sustained issue rate, and only "
+                                  "fewer instructions per cell-stage (now 43.8 flop in 51.6 VALU instructions, halo redundancy 1.41) move it",
                 "ms_per_launch": ms_fused_nn,
                 "flop_per_cell_stage": fpcs_nn,
                 "flop_source": (pmc_src + ": 64 x (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + 2 FMA_F64) per launch / executed cell-stages "

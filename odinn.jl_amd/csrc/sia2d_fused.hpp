@@ -439,11 +439,29 @@ __device__ __forceinline__ double2 cell_HS(double uu, double b) {
 // sE[buf][w][0 | 1][lane]: {Hc, S} of the first | last row of wavefront w's strip
 typedef double2 (*StripEdges)[TNW][2][FRX];
 
+// Neighbour synchronisation of the strips (ODINN_STRIP_FLAGSYNC): a stage of wavefront w needs the edge rows of wavefronts
+// w - 1 and w + 1 only, so instead of a workgroup barrier per stage every wavefront publishes a stage counter in LDS after
+// its edge rows and waits for its two neighbours' counters.  (The edge rows are double-buffered: wavefront w overwrites the
+// buffer of stage s at the end of stage s + 2, which it can only reach after its neighbours published stage s + 1, i.e.
+// after they read the stage-s rows.)
+#ifndef ODINN_STRIP_FLAGSYNC
+#define ODINN_STRIP_FLAGSYNC 0
+#endif
+__device__ __forceinline__ void strip_flag_sync(volatile int* f, int w, int stage) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63) == 0) f[w] = stage;
+  if (w > 0)
+    while (f[w - 1] < stage) __builtin_amdgcn_s_sleep(1);
+  if (w + 1 < TNW)
+    while (f[w + 1] < stage) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 template <int S, bool AF, int NR, bool UPL, bool SQ>
 __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                              const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                              double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
-                                             double (&E)[NR], const double (&bb)[NR]) {
+                                             double (&E)[NR], const double (&bb)[NR], volatile int* sFlag) {
   // src, Afield: based at the glacier's first cell / dual node (block-uniform), cells addressed by 32-bit indices;
   // gic: gi clamped into the grid; dtl: dt on the lanes with 1 <= gi <= nx-2, else 0
   constexpr int rd = (S - 1) & 1, wr = S & 1;  // stage S reads the edge rows from buffer rd, publishes into wr
@@ -542,7 +560,8 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   if (S < 5) {
     sE[wr][w][0][lane] = cell_HS(u[0], bb[0]);
     sE[wr][w][1][lane] = cell_HS(u[NR - 1], bb[NR - 1]);
-    __syncthreads();
+    if (ODINN_STRIP_FLAGSYNC) strip_flag_sync(sFlag, w, S);
+    else __syncthreads();
   }
 }
 
@@ -550,12 +569,12 @@ template <bool AF, int NR, bool UPL, bool SQ>
 __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                               const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                               double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
-                                              double (&E)[NR], const double (&bb)[NR]) {
-  strip_stage<1, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<2, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<3, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<4, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
-  strip_stage<5, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb);
+                                              double (&E)[NR], const double (&bb)[NR], volatile int* sFlag) {
+  strip_stage<1, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+  strip_stage<2, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+  strip_stage<3, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+  strip_stage<4, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+  strip_stage<5, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
 }
 
 // ---- self-controlled step (SC): no controller / post-step launches ---------------------------------------
@@ -644,6 +663,9 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
                                                                     ScArgs A) {
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double red[TNW];
+  __shared__ int sFlagS[TNW];
+  volatile int* sFlag = sFlagS;
+  if ((threadIdx.x & 63) == 0) sFlagS[threadIdx.x >> 6] = 0;  // (a workgroup barrier follows before the first stage)
   __shared__ GState s_state;
   // gridded A: the thread's own nodes (rows r0-1 .. r0+NR-1 of its column) in private LDS slots -- read in each of the
   // five stages, fetched from global memory once (0 on nodes outside the dual grid: they only feed frozen cells)
@@ -824,7 +846,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
 #pragma unroll
     for (int m = 0; m <= NR; ++m) sA[AF ? m : 0][threadIdx.x] = aa[AF ? m : 0] * Gq;
   }
-  strip_stages<AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb);
+  strip_stages<AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb, sFlag);
   // ---- output rows [FH, (NR * TNW)-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
   double upf[NR];
