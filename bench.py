@@ -689,6 +689,22 @@ def main():
                 "working_set": hbm["working_set_note"],
                 "traffic": pmc.get("rk_stage2_32", {}).get("hbm_bytes_per_launch"),
             } if r_st else None),
+            "roofline_adjoint": {
+                "bound": "fp64-valu",
+                "kernel": "k_adj_fused_strip<constant A, dense, 7 rows> (a whole RDPK3Sp35 step of the reverse ODE of the continuous adjoint: "
+                          "the reference's default gradient, gradient.jl:276-539)",
+                "ms_per_launch": ms_adjf,
+                "algorithmic_bytes_per_launch": 40.0 * cells,
+                "hbm_algorithmic_GBs": 40.0 * cells / (ms_adjf * 1e-3) / 1e9,
+                "hbm_algorithmic_frac_of_peak": 40.0 * cells / (ms_adjf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": pmc.get("adj_fused_step_8", {}).get("hbm_bytes_per_launch"),
+                "traffic_over_algorithmic": pmc.get("adj_fused_step_8", {}).get("ratio"),
+                "valu_busy_frac": pmc.get("adj_fused_step_8", {}).get("valu_busy_frac"),
+                "valu_insts_per_wave": pmc.get("adj_fused_step_8", {}).get("valu_insts_per_wave"),
+                "note": "issue-bound like the forward step kernel (4230 VALU instructions per wavefront-step x 27 968 wavefronts at the fp64 "
+                        "pipe's sustained issue rate = the launch time); the 2.55 x traffic (stage-invariant H_j, dH, B re-read in stages "
+                        "2-5 past a 4 MB L2) is hidden behind it -- DESIGN.md section 5, 'what bounds the two fused kernels'",
+            },
             "cpu_baseline": cpu,
             "aux": aux,
         }
