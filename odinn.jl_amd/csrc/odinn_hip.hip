@@ -3140,6 +3140,7 @@ static int timed_prepare(odinn_batch* b) {
     const int rc = build_stop_tables(b, 2, ts, 0, nullptr);
     b->own_stops.swap(keep);
     CHK(rc);
+    b->solved = false;  // (the snapshot slots no longer belong to a solve's stop tables)
   }
   // two identical forward snapshots + reverse-solve state for ODINN_TIMED_ADJ_STAGE2
   if (b->nstops_alloc < 2) {
@@ -3225,7 +3226,11 @@ static int timed_one(odinn_batch* b, int which, int it) {
       FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
       FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = 1e-8; FA.reltol = 1e-8;
       if (sched_val(b->sched.adj_segs, "ODINN_ADJ_SEGS") != 0) FA.segs = b->d_segs;
-      launch_adj_fused_strip(b->ntilesFt, b->gd[0].use_Afield, std::getenv("ODINN_TIMED_ADJ_SKIP") ? 1 : 0, TRPT, b->stream, P, FA);
+      // (odinn_schedule.adj_rows = 4 times the 4-rows-per-thread instantiation: 54 x 22 tiles, which needs the segment pairs)
+      const bool rows4 = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS") == 4 && FA.segs;
+      if (rows4) { FA.partF = b->d_partFv; FA.tilesF = b->d_tilesFv; }
+      launch_adj_fused_strip(rows4 ? b->ntilesFv : b->ntilesFt, b->gd[0].use_Afield, std::getenv("ODINN_TIMED_ADJ_SKIP") ? 1 : 0,
+                             rows4 ? 4 : TRPT, b->stream, P, FA);
       return ODINN_OK;
     }
     case ODINN_TIMED_LAW_FIELD:
