@@ -236,7 +236,6 @@ struct odinn_batch {
   double fV = 1.0;
   // surface-velocity path: every law has one -- A-type (target :A, closed form), U (target :D) and Y (target :D_hybrid, as the
   // reference writes it) through the per-node network in the velocity kernels
-  bool vel_law_ok() const { return true; }
   bool vel_nn() const { return law_kind == ODINN_LAW_NN_U || law_kind == ODINN_LAW_NN_Y; }
   // Y law with the target's default `:Linear` interpolation of dY/dtheta: the velocity kernels emit (Hbar, node weight)
   bool vel_emit() const { return law_kind == ODINN_LAW_NN_Y && grad_interp == ODINN_GRAD_INTERP_LINEAR; }

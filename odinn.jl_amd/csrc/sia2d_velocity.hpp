@@ -53,7 +53,7 @@ __device__ __forceinline__ double node_Vup_U(const LawDev& L, double Hb, double 
   return mlp_eval_any(L, Hb, gS) * finv;
 }
 
-// target :D_hybrid AS WRITTEN in the reference (target_D_hybrid.jl:210-372; restated in the oracle, which also records the
+// target :D_hybrid AS WRITTEN in the reference (target_D_hybrid.jl:210-372; the CPU restatement under tests/ records the
 // inconsistencies -- upstream has no test of this path):
 //   Velocity^      = S H^(p-q+1) |gS|^(p-1) + Y Gamma H^(n_H+1) |gS|^(n_S-1)        with the DIFFUSIVITY's Gamma = 2 (rho g)^n / (n+2)
 //   dVelocity^/dH  = (p-q+1) S H^(p-q) |gS|^(p-1) + (n_H+1) Y Gamma H^n_H |gS|^(n_S-1)
