@@ -37,7 +37,7 @@ __all__ = [
     "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
     "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DummyAdjoint", "DiscreteVJP", "ContinuousVJP", "MultiLoss", "TikhonovRegularization",
     "InitialThicknessRegularization", "RheologyRegularization", "InitialCondition", "evaluate_H0", "evaluate_dH0",
-    "sigma_zang", "dsigma_zang", "TrainingResult", "save_inversion_file", "load_inversion_file", "ScalarLogger",
+    "sigma_zang", "dsigma_zang", "TrainingResult", "save_inversion_file", "load_inversion_file", "ScalarLogger", "TBLogger", "read_event_file",
     "callback_diagnosis",
     "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "LogSum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
@@ -877,6 +877,142 @@ class ScalarLogger:
 
     def close(self):
         self._f.close()
+
+
+def _crc32c_table():
+    t = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+        t.append(c)
+    return t
+
+
+_CRC32C = _crc32c_table()
+
+
+def _crc32c(data: bytes) -> int:
+    c = 0xFFFFFFFF
+    for x in data:
+        c = _CRC32C[(c ^ x) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _masked_crc(data: bytes) -> int:
+    c = _crc32c(data)
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _pb_varint(v: int) -> bytes:
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _pb_bytes(field: int, payload: bytes) -> bytes:
+    return _pb_varint(field << 3 | 2) + _pb_varint(len(payload)) + payload
+
+
+class TBLogger(ScalarLogger):
+    """TensorBoardLogger.TBLogger(logdir) as callback_diagnosis uses it (callback_utils.jl:84-98): scalars written as a
+    TensorBoard event file (`events.out.tfevents.<time>.<host>`: TFRecord framing with masked CRC-32C, `Event{wall_time,
+    step, summary{value{tag, simple_value}}}` records after the `brain.Event:2` version record), so `tensorboard --logdir`
+    reads a run of this package like a run of the reference."""
+
+    def __init__(self, logdir: str):
+        import os
+        import socket
+        import struct
+
+        os.makedirs(logdir, exist_ok=True)
+        self.logdir = logdir
+        self.file = os.path.join(logdir, f"events.out.tfevents.{int(time.time())}.{socket.gethostname()}")
+        self._f = open(self.file, "ab")
+        self._record(struct.pack("<Bd", 0x09, time.time()) + _pb_bytes(3, b"brain.Event:2"))
+
+    def _record(self, event: bytes):
+        import struct
+
+        head = struct.pack("<Q", len(event))
+        self._f.write(head + struct.pack("<I", _masked_crc(head)) + event + struct.pack("<I", _masked_crc(event)))
+        self._f.flush()
+
+    def log_value(self, tag: str, value: float, step: int):
+        import struct
+
+        val = _pb_bytes(1, tag.encode()) + struct.pack("<Bf", 0x15, float(value))   # Summary.Value{tag = 1, simple_value = 2}
+        event = struct.pack("<Bd", 0x09, time.time()) + b"\x10" + _pb_varint(int(step)) + _pb_bytes(5, _pb_bytes(1, val))
+        self._record(event)
+
+
+def read_event_file(file: str):
+    """Scalars of a TensorBoard event file as [(tag, step, value)], every CRC checked (the reader side of TBLogger; used by
+    the tests and to reload a run's curves)."""
+    import struct
+
+    def varint(b, i):
+        v = s_ = 0
+        while True:
+            v |= (b[i] & 0x7F) << s_
+            s_ += 7
+            i += 1
+            if not b[i - 1] & 0x80:
+                return v, i
+
+    def fields(b):
+        i = 0
+        while i < len(b):
+            key, i = varint(b, i)
+            f, w = key >> 3, key & 7
+            if w == 0:
+                v, i = varint(b, i)
+            elif w == 1:
+                v, i = b[i:i + 8], i + 8
+            elif w == 5:
+                v, i = b[i:i + 4], i + 4
+            elif w == 2:
+                n, i = varint(b, i)
+                v, i = b[i:i + n], i + n
+            else:
+                raise ValueError(f"wire type {w}")
+            yield f, w, v
+
+    out = []
+    raw = open(file, "rb").read()
+    i = 0
+    while i < len(raw):
+        head = raw[i:i + 8]
+        (n,) = struct.unpack("<Q", head)
+        if struct.unpack("<I", raw[i + 8:i + 12])[0] != _masked_crc(head):
+            raise ValueError("event file: bad length CRC")
+        ev = raw[i + 12:i + 12 + n]
+        if struct.unpack("<I", raw[i + 12 + n:i + 16 + n])[0] != _masked_crc(ev):
+            raise ValueError("event file: bad data CRC")
+        i += 16 + n
+        step, summ = 0, None
+        for f, w, v in fields(ev):
+            if f == 2 and w == 0:
+                step = v
+            elif f == 5 and w == 2:
+                summ = v
+        if summ is None:
+            continue
+        for f, w, v in fields(summ):
+            if f == 1 and w == 2:
+                tag, val = None, None
+                for f2, w2, v2 in fields(v):
+                    if f2 == 1 and w2 == 2:
+                        tag = v2.decode()
+                    elif f2 == 2 and w2 == 5:
+                        (val,) = struct.unpack("<f", v2)
+                out.append((tag, step, val))
+    return out
 
 
 def callback_diagnosis(theta, loss, grad, simulation, save: bool = False, tbLogger: Optional[ScalarLogger] = None,

@@ -126,6 +126,43 @@ def test_training_result_file_and_scalar_log(odinn, tmp_path):
     assert sum(r["tag"] == "train/time_per_iter" for r in rows) == 2  # not on the first call (callback_utils.jl:93)
 
 
+def test_tensorboard_event_file(odinn, tmp_path):
+    """TBLogger writes what TensorBoardLogger.jl writes for callback_diagnosis (callback_utils.jl:84-98): a tfevents file
+    whose records carry masked CRC-32C checksums (known answer: crc32c("123456789") = 0xE3069283), first record
+    `brain.Event:2`, then one scalar per log_value with the reference's tags and steps."""
+    import glob
+    import struct
+    import types
+
+    _crc32c, _masked_crc = odinn.api._crc32c, odinn.api._masked_crc
+
+    assert _crc32c(b"123456789") == 0xE3069283 and _crc32c(b"") == 0
+    assert _masked_crc(b"123456789") == ((((0xE3069283 >> 15) | (0xE3069283 << 17)) + 0xA282EAD8) & 0xFFFFFFFF)
+    sim = types.SimpleNamespace(stats=odinn.TrainingStats(), parameters=odinn.Parameters())
+    log = odinn.TBLogger(str(tmp_path / "tb"))
+    for it in range(3):
+        odinn.callback_diagnosis(np.arange(4.0), 8.0 / (it + 1), np.full(4, 2.0), sim, tbLogger=log)
+    log.log_value("train/loss", 1e-3, 300)  # a two-byte varint step
+    log.close()
+    files = glob.glob(str(tmp_path / "tb" / "events.out.tfevents.*"))
+    assert len(files) == 1
+    raw = open(files[0], "rb").read()
+    (n0,) = struct.unpack("<Q", raw[:8])
+    assert b"brain.Event:2" in raw[12:12 + n0]
+    rows = odinn.read_event_file(files[0])
+    assert [r[0] for r in rows[:2]] == ["train/loss", "train/norm_grad"] and rows[0][1] == 1
+    assert sum(r[0] == "train/time_per_iter" for r in rows) == 2
+    losses = [r for r in rows if r[0] == "train/loss"]
+    assert [r[1] for r in losses] == [1, 2, 3, 300]
+    assert np.allclose([r[2] for r in losses], [8.0, 4.0, 8.0 / 3, 1e-3], rtol=1e-7)
+    assert np.isclose([r[2] for r in rows if r[0] == "train/norm_grad"][0], 4.0)
+    bad = bytearray(raw)
+    bad[-6] ^= 1  # a flipped payload bit is caught by the data CRC
+    open(files[0], "wb").write(bytes(bad))
+    with pytest.raises(ValueError, match="CRC"):
+        odinn.read_event_file(files[0])
+
+
 def test_load_gridded_glacier_reads_oggm_style_files(odinn, tmp_path):
     """Real-glacier ingestion seam: an OGGM-style gridded file (NetCDF-3 through scipy, or .npz):
     (y, x) variables with y descending are returned as [x, y] with both axes increasing, thickness masked by
