@@ -132,14 +132,16 @@ __device__ __forceinline__ void interval_sums_body(const double* __restrict__ sH
     if (threadIdx.x == 0) { ab[k] = 0.0; ab[KMAX + k] = 0.0; }
     return;
   }
-  const double x0 = knots[k], x1 = knots[k + 1], inv = 1.0 / (x1 - x0);
+  // (w by a true division: the margin of an advancing glacier carries subnormal thicknesses, the lowest quantile knots of a
+  //  small glacier land among them, and 1 / (x1 - x0) overflows for such an interval while (Hbar - x0) / (x1 - x0) <= 1)
+  const double x0 = knots[k], x1 = knots[k + 1], wid = x1 - x0;
   // (a node with Hbar == 0 carries the weight 0 -- spat has a positive power of Hbar -- and ice-free nodes can be half of
   //  the domain, all in interval 0: they are skipped)
   const long long lo = x0 > 0.0 ? lower_bound_d(sH, nd, x0) : upper_bound_d(sH, nd, 0.0);
   const long long hi = (k == M - 2) ? nd : lower_bound_d(sH, nd, x1);
   double a = 0.0, b = 0.0;
   for (long long i = lo + threadIdx.x; i < hi; i += NT) {
-    const double w = (sH[i] - x0) * inv, v = sV[i];
+    const double w = (sH[i] - x0) / wid, v = sV[i];
     a = fma(v, 1.0 - w, a);
     b = fma(v, w, b);
   }

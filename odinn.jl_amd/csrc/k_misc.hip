@@ -109,8 +109,8 @@ void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, const int* 
                       const int* mb_slots) {
   hipLaunchKernelGGL(k_adj_begin, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, n_snaps, tau0, mb_flags, mb_slots);
 }
-void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, int all_at_end) {
-  hipLaunchKernelGGL(k_adj_itp, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, tsnap, all_at_end);
+void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, const int* n_snaps, int all_at_end) {
+  hipLaunchKernelGGL(k_adj_itp, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, tsnap, n_snaps, all_at_end);
 }
 void launch_adj_poststep(int nblk, hipStream_t st, Pools P, AdjPostArgs A, double* Ua, double* Ub) {
   hipLaunchKernelGGL(k_adj_poststep, dim3(nblk), dim3(NT), 0, st, P, A, Ua, Ub);

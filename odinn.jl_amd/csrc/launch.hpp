@@ -116,7 +116,7 @@ void launch_vref_scale(int G, hipStream_t st, Pools P, const AdjState* adj, cons
                        double* scale_out, double* w_out);
 void launch_adj_begin(int G, hipStream_t st, Pools P, AdjState* adj, const int* n_snaps, double tau0, const int* mb_flags,
                       const int* mb_slots);
-void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, int all_at_end);
+void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double* tsnap, const int* n_snaps, int all_at_end);
 void launch_tikhonov(hipStream_t st, const double* a, const unsigned char* mask, double* r, double* grad,
                      double* partial, int nx, int ny, double dx, double dy);
 void launch_adj_poststep(int nblk, hipStream_t st, Pools P, AdjPostArgs A, double* Ua, double* Ub);

@@ -750,6 +750,7 @@ int ensure_tables(odinn_batch* b, int n_stops) {
     CHK(dalloc(&b->d_ws, (size_t)n_stops * b->G));
     CHK(dalloc(&b->d_refslot, (size_t)n_stops * b->G));
     b->tab_cap = n_stops;
+    b->tab_key_ptr = nullptr;  // the loss tables went with the old buffers (a new buffer may get the old address)
   }
   return ODINN_OK;
 }
@@ -2701,7 +2702,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     launch_vjp_H(b, 0, b->ntiles, Pl, L, A, 0);  // f0
     launch_initdt_norms(b->ntiles, b->stream, Pl, b->d_lam[0], b->d_S2, nullptr, ao.abstol, ao.reltol);
     launch_initdt_ctrl(G, b->stream, Pl, 0, tspan, ao.dtmax, b->d_dt0);
-    launch_adj_itp(G, b->stream, Pl, b->d_adj, b->d_tsnap, 1);
+    launch_adj_itp(G, b->stream, Pl, b->d_adj, b->d_tsnap, b->d_ksn, 1);
     launch_axpy_g(b->ntiles, b->stream, Pl, b->d_S2, b->d_lam[0], b->d_lam[1]);
     A.snaps = b->d_snaps; A.adj = b->d_adj; A.lam = b->d_lam[1]; A.out = b->d_E;
     launch_vjp_H(b, 0, b->ntiles, Pl, L, A, 0);  // f1 at tau0 + dt0
@@ -2710,7 +2711,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     nrhs_extra = 2;
   }
   launch_begin(G, b->stream, Pl, b->d_rtau, ao.dtmax, 0.0);
-  launch_adj_itp(G, b->stream, Pl, b->d_adj, b->d_tsnap, 0);
+  launch_adj_itp(G, b->stream, Pl, b->d_adj, b->d_tsnap, b->d_ksn, 0);
   int nact = G;
   HIPCHK(hipMemcpyAsync(b->d_nactive, &nact, sizeof(int), hipMemcpyHostToDevice, b->stream));
   CtrlArgs C{};
@@ -2718,6 +2719,14 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   C.adaptive = 1; C.fixed_dt = 0.0; C.n_active = b->d_nactive; C.errpart = b->d_part; C.stride = 4; C.fused = 0;
   C.adj = b->d_adj; C.tsnap = b->d_tsnap; C.stop_snap = b->d_rsnap; C.stop_qw = b->d_rqw; C.qw_out = b->d_qw;
   C.stop_hid = b->nhid > 0 ? b->d_rhid : nullptr;
+  // ODINN_TRACE_STEPS=n: the first n attempts of glacier 0's reverse solve (tau, dt, error estimate, +-step factor) on stderr
+  double* d_trace = nullptr;
+  const int ntrace = std::getenv("ODINN_TRACE_STEPS") ? std::atoi(std::getenv("ODINN_TRACE_STEPS")) : 0;
+  if (ntrace > 0) {
+    HIPCHK(hipMalloc(&d_trace, (size_t)ntrace * 4 * sizeof(double)));
+    HIPCHK(hipMemsetAsync(d_trace, 0, (size_t)ntrace * 4 * sizeof(double), b->stream));
+    C.trace = d_trace; C.trace_cap = ntrace;
+  }
   AdjStageArgs SA{};
   SA.snaps = b->d_snaps; SA.ntot = b->ntot; SA.adj = b->d_adj; SA.S2 = b->d_S2; SA.S3 = b->d_S3; SA.E = b->d_E;
   SA.abstol = ao.abstol; SA.reltol = ao.reltol;
@@ -2873,6 +2882,14 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   }
   std::vector<GState> gs(G);
   HIPCHK(hipMemcpy(gs.data(), b->d_gs, sizeof(GState) * G, hipMemcpyDeviceToHost));
+  if (d_trace) {
+    std::vector<double> tr((size_t)ntrace * 4);
+    HIPCHK(hipMemcpy(tr.data(), d_trace, tr.size() * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_trace);
+    const long long n = std::min<long long>(ntrace, gs[0].naccept + gs[0].nreject);
+    for (long long q = 0; q < n; ++q)
+      std::fprintf(stderr, "[odinn reverse step %lld] tau %.17g dt %.17g EEst %.17g factor %.17g\n", q, tr[4 * q], tr[4 * q + 1], tr[4 * q + 2], tr[4 * q + 3]);
+  }
   bool mixed = false;
   for (int g = 0; g < G; ++g) {
     if (gs[g].nonfinite) return fail(ODINN_ERR_NONFINITE, "non-finite error estimate in the reverse solve of glacier %d", g);

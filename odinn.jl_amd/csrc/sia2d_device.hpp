@@ -1177,6 +1177,8 @@ struct CtrlArgs {
   const double* stop_qw;  // [imax][G] per stop: quadrature weight, 0 for a snapshot time
   const int* stop_hid;    // [imax][G] (nullable) per stop: hidden snapshot slot + 1 of a mass-balance-only stop, else 0
   double* qw_out;         // per glacier: weight of the node reached by this step (0 otherwise)
+  double* trace;          // (nullable, diagnostics: ODINN_TRACE_STEPS) [trace_cap][4] of glacier 0: t, dt, EEst, +-factor per attempt
+  int trace_cap;
 };
 
 // self-controlled fused step (sia2d_fused.hpp, k_rk_fused_strip<..., SC = true>)
@@ -1272,6 +1274,10 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
     if (accept) { st.e3 = st.e2; st.e2 = e1; }
   }
   double t = st.t;
+  if (C.trace && gidx == 0) {
+    const long long q = st.naccept + st.nreject;
+    if (q < C.trace_cap) { C.trace[4 * q] = t; C.trace[4 * q + 1] = h; C.trace[4 * q + 2] = st.EEst; C.trace[4 * q + 3] = accept ? fac : -fac; }
+  }
   st.at_stop = 0;
   st.mb_now = 0;
   if (C.adj) { ad.qw = 0.0; ad.snapj = -1; ad.pad = 0; }
@@ -2547,11 +2553,19 @@ __global__ void k_adj_begin(Pools P, int n, AdjState* adj, const int* n_snaps /*
 }
 // weights for the coming step (all_at_end: every weight at tau + dt, used for the second RHS of
 // the initial-step heuristic)
-__global__ void k_adj_itp(Pools P, int n, AdjState* adj, const double* tsnap, int all_at_end) {
+__global__ void k_adj_itp(Pools P, int n, AdjState* adj, const double* tsnap, const int* n_snaps, int all_at_end) {
   const int gidx = blockIdx.x * blockDim.x + threadIdx.x;
   if (gidx >= n) return;
   const GState* gs = P.gs + gidx;
-  adj_stage_weights(adj + gidx, tsnap, n, gidx, gs->t, gs->dt, all_at_end != 0);
+  AdjState* a = adj + gidx;
+  // the reverse solve starts in the last snapshot interval; the probe of the initial-step heuristic sits at tau_0 + dt_0,
+  // which may lie below the snapshot under it (H_itp interpolates over ALL snapshots, gradient.jl:287): its own interval
+  a->seg = n_snaps[gidx] - 2;
+  if (all_at_end) {
+    const double t = -(gs->t + gs->dt);
+    while (a->seg > 0 && t < tsnap[(long long)a->seg * n + gidx]) a->seg--;
+  }
+  adj_stage_weights(a, tsnap, n, gidx, gs->t, gs->dt, all_at_end != 0);
 }
 
 // post-step of the reverse solve (pointwise, no-op for glaciers not at a stop):

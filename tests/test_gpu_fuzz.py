@@ -1,0 +1,377 @@
+"""GPU: randomised parity of the whole gradient path.  Every seed draws a batch -- 1-3 glaciers of random (ragged) shapes,
+square or rectangular cells, one of the five laws, with or without sliding, mass balance, per-glacier data times, L2Sum or
+LogSum, a random non-default kernel schedule -- and an adjoint (DiscreteAdjoint on a fixed or adaptive step sequence,
+ContinuousAdjoint; DiscreteVJP or ContinuousVJP), and compares loss and d loss / d theta of the HIP path through the C ABI with
+the oracle's restatement of SIA2D_grad_batch! (src/inverse/SIA2D/gradient.jl:45-275, 276-539) glacier by glacier.
+
+A second test draws the same batches with LossV / LossHV (velocity maps at some of the stops, :xy / :abs / LogSum, scaled or
+not, the U law with a surface-velocity factor).
+
+The fixed seeds below run with the suite; ODINN_FUZZ_SEEDS=a:b runs the seeds a..b-1 instead (exploration: 2 x 4000 seeds
+take five minutes on eight workers, `-n 8`).  Three kinds of draws are skipped, each with its reason (`-rs`), because the
+REFERENCE ALGORITHM's result is not a well-defined function of the inputs there -- no two correct implementations agree:
+ * the positivity pattern of a snapshot differs between the device and the checker in cells below 1e-20 (an advancing margin
+   leaves subnormal thicknesses behind; the mass-balance mask and dVelocity/dtheta of target :D test H > 0): ~3.5 % of the draws;
+ * an adaptive solve whose gradient moves by more than the tolerance when the parameters move by 1e-12 (accept / reject
+   sequences of the PID controller on a stability-limited problem);
+ * a mismatch below 5e-3 on a draw whose forward solve carries subnormal thicknesses (see _subnormal_margin).
+What the 8000 exploration seeds found in the library: NaN gradients of the Y law's `:Linear` branch when a quantile knot of
+create_interpolation landed on a subnormal thickness (1 / (x1 - x0) overflowed, k_interp.hip; seeds 1746, 2450, 3206, 3351
+are kept), and the second RHS of the reverse solve's initial-step heuristic reading the wrong snapshot interval when
+tau_0 + dt_0 lies below the last interior snapshot (k_adj_itp)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from oracle import sia2d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+T0 = 2010.0
+SCHEDULES = [dict(step_sc=0), dict(step_sc=1), dict(fused_tiles=1), dict(fused_tiles=2), dict(fused_tiles=3), dict(fused_tiles=4),
+             dict(dhdt_strip=0), dict(vjph_strip=0), dict(vjph_strip=1), dict(vjpth_strip=0), dict(vjpth_strip=1),
+             dict(snap_on_load=0), dict(adj_fused=0), dict(adj_skip=0), dict(adj_segs=0), dict(adj_rows=4), dict(adj_rows=7),
+             dict(adj_theta_fused=0)]
+
+
+def _seeds():
+    e = os.environ.get("ODINN_FUZZ_SEEDS")
+    if e:
+        a, b = e.split(":")
+        return list(range(int(a), int(b)))
+    return list(range(20)) + [1746, 2450, 3206, 3351]  # (the last four: subnormal thickness at the margin, `:Linear` knots)
+
+
+def _draw(gpu, seed, velocity=False):
+    rng = np.random.default_rng((5000000 if velocity else 1000) + seed)
+    G = int(rng.integers(1, 4))
+    sliding = rng.random() < 0.2
+    ph = O.Phys(n=3.2, C=7e-8, q=1.0) if sliding else O.Phys()
+    kind = [O.LAW_CONST_A, O.LAW_NN_A_SCALAR, O.LAW_NN_A_GRIDDED, O.LAW_NN_Y, O.LAW_NN_U][int(rng.integers(0, 5))]
+    mode = ["discrete_fixed", "discrete_adaptive", "continuous"][int(rng.integers(0, 3))]
+    vjp = "continuous" if rng.random() < 0.2 and not velocity else "discrete"
+    log_eps = 0.1 if rng.random() < 0.25 else None
+    k = int(rng.integers(3, 6))
+    ragged = G > 1 and rng.random() < 0.4 and not velocity
+    with_mb = rng.random() < 0.4
+    # law
+    om = gm = th = None
+    interp = None
+    if kind in (O.LAW_NN_A_SCALAR, O.LAW_NN_A_GRIDDED):
+        widths, acts = [([1, 3, 10, 3, 1], [1, 1, 1, 2]), ([1, 16, 16, 1], [1, 1, 2]), ([1, 5, 7, 1], [3, 4, 2])][int(rng.integers(0, 3))]
+        om = O.MLP(widths, acts, None, O.POST_AFFINE, ph.minA, ph.maxA)
+        gm = gpu.MLPSpec(widths, acts, None, O.POST_AFFINE, ph.minA, ph.maxA)
+    elif kind == O.LAW_NN_Y:
+        widths, acts = [([2, 3, 10, 3, 1], [1, 1, 1, 2]), ([2, 3, 1], [1, 2])][int(rng.integers(0, 2))]
+        pre = [(-25.0, 0.0), (0.0, 500.0)]
+        om = O.MLP(widths, acts, pre, O.POST_EXPMAX, 0.0, ph.maxA)
+        gm = gpu.MLPSpec(widths, acts, pre, O.POST_EXPMAX, 0.0, ph.maxA)
+        interp = ("linear", int(rng.choice([6, 20, 75]))) if rng.random() < 0.6 else ("none", 75)
+    elif kind == O.LAW_NN_U:
+        widths, acts = [2, 3, 10, 3, 1], [1, 1, 1, 2]
+        pre = [(0.0, 300.0), (0.0, 0.5)]
+        om = O.MLP(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
+        gm = gpu.MLPSpec(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
+    if om is not None:
+        th = om.init_theta(rng) + 0.05 * rng.standard_normal(om.n_params)
+    fV = 0.8 if velocity and rng.random() < 0.5 else 1.0
+    shapes, dxs, dys, Ts, As, gls, own, refs, mbs, laws = [], [], [], [], [], [], [], [], [], []
+    geo = []
+    for g in range(G):
+        nx = int(rng.integers(60, 72)) if rng.random() < 0.25 else int(rng.integers(12, 45))
+        ny = int(rng.integers(16, 40))
+        dx = float(rng.choice([40.0, 50.0, 100.0]))
+        dy = dx if rng.random() < 0.6 else float(np.round(dx * rng.uniform(0.7, 1.4), 1))
+        x = np.linspace(-1.0, 1.0, nx)[:, None]
+        y = np.linspace(-1.0, 1.0, ny)[None, :]
+        r2 = ((x - rng.uniform(-0.1, 0.1)) / rng.uniform(0.6, 0.85)) ** 2 + ((y - rng.uniform(-0.1, 0.1)) / rng.uniform(0.6, 0.85)) ** 2
+        H0 = rng.uniform(60.0, 220.0) * np.sqrt(np.maximum(0.0, 1.0 - r2))
+        B = 1500.0 - rng.uniform(0.02, 0.12) * x * (nx * dx / 2.0) + rng.uniform(0.0, 0.05) * y * (ny * dy / 2.0) \
+            + 15.0 * np.sin(3.0 * x + rng.uniform(0, 6)) * np.cos(2.5 * y + rng.uniform(0, 6))
+        if rng.random() < 0.3:  # an ice-free stripe and a few isolated cells
+            H0[:, ny // 2] = 0.0
+            H0[rng.integers(0, nx, 3), rng.integers(0, ny, 3)] = 5.0
+        H0, B = np.asfortranarray(H0), np.asfortranarray(B + np.zeros_like(H0))
+        T = float(rng.uniform(-20.0, -1.0))
+        A = float(rng.uniform(1e-18, 4e-17))
+        if kind == O.LAW_CONST_A:
+            law = O.Law(kind=kind, A=A)
+        elif kind == O.LAW_NN_A_GRIDDED:
+            S = B + H0
+            law = O.Law(kind=kind, mlp=om, theta=th, T=np.asfortranarray(T - 6.5e-3 * (O.avg(S) - S.mean())))
+        elif kind == O.LAW_NN_Y:
+            law = O.Law(kind=kind, mlp=om, theta=th, T=T, interpolation=interp[0], n_interp_half=interp[1])
+        elif kind == O.LAW_NN_U:
+            law = O.Law(kind=kind, mlp=om, theta=th, T=T, fV=fV)
+        else:
+            law = O.Law(kind=kind, mlp=om, theta=th, T=T)
+        geo.append((nx, ny, dx, dy, H0, B, T, A, law))
+    # a time scale the explicit scheme is stable on: dt = 0.15 min(dx, dy)^2 / max D over the batch; stops every 6 dt
+    dts = min(0.15 * min(q[2], q[3]) ** 2 / max(O.max_diffusivity(q[4], q[5], q[2], q[3], ph, q[8]), 1e-30) for q in geo)
+    dts = float(min(dts, 1.0 / 480.0))
+    step = 6.0 * dts
+    common = [T0 + j * step for j in range(k)]
+    for g in range(G):
+        nx, ny, dx, dy, H0, B, T, A, law = geo[g]
+        shapes.append((nx, ny)); dxs.append(dx); dys.append(dy); Ts.append(T); As.append(A); laws.append(law)
+        gls.append(O.Glacier(H0, B, dx, dy, ph))
+        ts = list(common)
+        if ragged:  # own interior data times; t0 and t1 are shared (every glacier covers the same tspan)
+            inner = sorted(set(float(v) for v in rng.uniform(common[0] + 0.2 * step, common[-1] - 0.2 * step, int(rng.integers(1, 4)))))
+            ts = [common[0]] + inner + [common[-1]]
+        own.append(ts)
+        refs.append([np.asfortranarray(np.maximum(H0 * (1.0 - 0.02 * j) + (H0 > 0) * rng.normal(0.0, 1.0, H0.shape), 0.0))
+                     for j in range(len(ts))])
+        if with_mb:
+            S0 = B + np.maximum(H0, 0.0)
+            ela = np.percentile(S0[H0 > 0], 60)
+            grad = 6e-3
+            mbs.append(O.MassBalance(mb0=np.asfortranarray(grad * (S0 - ela) * 30.0 * step), dmb_dS=grad * 30.0 * step,
+                                     S_ref=np.asfortranarray(S0), mb_max=1.2 * 30.0 * step))
+        else:
+            mbs.append(None)
+    # mass-balance times: stops every glacier has (the DiscreteAdjoint's requirement, gradient.jl:131) -- t1, and with a common
+    # table sometimes an interior stop; the ContinuousAdjoint also takes times that are nobody's stop
+    mbt = []
+    if with_mb:
+        mbt = [common[-1]]
+        if not ragged and k > 3 and rng.random() < 0.5:
+            mbt = [common[k // 2], common[-1]]
+        if mode == "continuous" and rng.random() < 0.4:
+            mbt = sorted(set(mbt + [common[0] + 0.37 * (common[-1] - common[0])]))
+    sched = SCHEDULES[int(rng.integers(0, len(SCHEDULES)))] if rng.random() < 0.5 else {}
+    vel = None
+    if velocity:  # LossV / LossHV: velocity maps at some of the stops (the ContinuousAdjoint interpolates them over the whole tspan)
+        comp = ["xy", "abs", "log"][int(rng.integers(0, 3))]
+        vel = dict(kind="V" if rng.random() < 0.5 else "HV", component="abs" if comp == "log" else comp,
+                   log_eps=0.1 if comp == "log" else None, scale=bool(rng.random() < 0.5), scaling=float(rng.uniform(0.3, 3.0)),
+                   tV=[], Vref=[])
+        for g in range(G):
+            if mode == "continuous":
+                tV = list(common) if rng.random() < 0.6 else [common[0], common[-1]]
+            else:
+                tV = [t for j, t in enumerate(common) if j >= 1 and (j % 2 == g % 2 or j == k - 1)]
+            Vx0, Vy0, _ = O.V_from_H(gls[g].H0, gls[g].B, dxs[g], dys[g], ph, laws[g])
+            maps = []
+            for _t in tV:
+                Vx = np.asfortranarray(Vx0 * rng.uniform(0.8, 1.3) + 0.05 * np.abs(Vx0).max() * rng.standard_normal(Vx0.shape) * (Vx0 != 0))
+                Vy = np.asfortranarray(Vy0 * rng.uniform(0.8, 1.3) + 0.05 * np.abs(Vy0).max() * rng.standard_normal(Vy0.shape) * (Vy0 != 0))
+                maps.append((np.asfortranarray(np.sqrt(Vx ** 2 + Vy ** 2)), Vx, Vy))
+            vel["tV"].append(tV)
+            vel["Vref"].append(maps)
+    return dict(G=G, ph=ph, kind=kind, mode=mode, vjp=vjp, log_eps=log_eps, common=common, own=own, ragged=ragged, mbt=mbt,
+                om=om, gm=gm, th=th, interp=interp, shapes=shapes, dxs=dxs, dys=dys, Ts=Ts, As=As, gls=gls, refs=refs, mbs=mbs,
+                laws=laws, sched=sched, step=step, dts=dts, vel=vel, fV=fV)
+
+
+def _oracle_gradient(c, nq, rel_perturbation=0.0):
+    """(loss, d loss / d theta) of the draw by the oracle, summed over the glaciers; the parameters (theta, or the glaciers' A)
+    scaled by 1 + rel_perturbation."""
+    import dataclasses
+
+    mode, v = c["mode"], c["vel"]
+    Lo, go = 0.0, 0.0
+    for g in range(c["G"]):
+        law = c["laws"][g]
+        if rel_perturbation:
+            law = (dataclasses.replace(law, A=law.A * (1.0 + rel_perturbation)) if law.kind == O.LAW_CONST_A
+                   else dataclasses.replace(law, theta=law.theta * (1.0 + rel_perturbation)))
+        cfg = O.SimConfig(tstops=c["own"][g], reltol=1e-8, mb=c["mbs"][g], mb_times=c["mbt"] if c["mbs"][g] is not None else (),
+                          fixed_dt=c["dts"] if mode == "discrete_fixed" else None, h_log_eps=c["log_eps"])
+        if v is None and mode == "continuous":
+            out = O.loss_and_grad_continuous(c["gls"][g], law, cfg, c["refs"][g], c["own"][g], O.ContinuousAdjointCfg(n_quadrature=nq),
+                                             vjp=c["vjp"])
+        elif v is None:
+            out = O.loss_and_grad(c["gls"][g], law, cfg, c["refs"][g], c["own"][g], vjp=c["vjp"])
+        else:
+            vspec = O.LossVSpec(component=v["component"], scale_loss=v["scale"], log_eps=v["log_eps"])
+            if mode == "continuous":
+                out = O.loss_and_grad_continuous(c["gls"][g], law, cfg, c["refs"][g], c["own"][g], O.ContinuousAdjointCfg(n_quadrature=nq),
+                                                 V_ref=v["Vref"][g], tV_ref=v["tV"][g], vspec=vspec, loss_kind=v["kind"],
+                                                 scaling=v["scaling"])
+            else:
+                out = O.loss_and_grad_HV(c["gls"][g], law, cfg, c["refs"][g], c["own"][g], v["Vref"][g], v["tV"][g], vspec,
+                                         loss_kind=v["kind"], scaling=v["scaling"])
+        Lo += out[0]
+        go = go + np.atleast_1d(out[1])
+    return Lo, go
+
+
+def _ill_conditioned(c, nq, go, gtol):
+    """Adaptive solves: the accept / reject sequence of the PID controller is a discontinuous function of the data, and on a
+    stability-limited problem (what the draw's time scale makes of it) a relative change of 1e-12 in the parameters can move
+    the reference algorithm's own gradient by 1e-2.  True when the oracle's gradient at theta (1 + 1e-12) differs from its
+    gradient at theta by more than a quarter of the comparison's tolerance: no two implementations agree better than that."""
+    if np.linalg.norm(go) == 0:
+        return False
+    _, g1 = _oracle_gradient(c, nq, 1e-12)
+    return rel_l2(g1, go) > 0.25 * gtol
+
+
+def _margins_agree(b, c, mode):
+    """The reference's gradient is DISCONTINUOUS in the state where it tests H > 0 (the mass-balance mask, VJPs.jl:124-126; the
+    factor (Hbar > 0) of dVelocity/dtheta in target :D, target_D_pure.jl:246-255): an advancing margin leaves subnormal
+    thicknesses (1e-320) behind, and whether such a cell holds 1e-320 or 0 is a matter of rounding (FMA contraction).  Returns
+    False when the positivity pattern of a snapshot differs between the device and the checker -- only ever on cells below
+    1e-20 (asserted) -- in which case the two gradients are not comparable and the seed is skipped."""
+    same = True
+    for g in range(c["G"]):
+        cfg = O.SimConfig(tstops=c["own"][g], reltol=1e-8, mb=c["mbs"][g], mb_times=c["mbt"] if c["mbs"][g] is not None else (),
+                          fixed_dt=c["dts"] if mode == "discrete_fixed" else None)
+        snaps, _, _ = O.forward(c["gls"][g], c["laws"][g], cfg)
+        for j, Ho in enumerate(snaps):
+            Hg = b.snapshot(g, j)
+            for a, d in ((Ho, Hg), (O.avg(np.maximum(Ho, 0.0)), O.avg(np.maximum(Hg, 0.0)))):
+                diff = (a > 0) != (d > 0)
+                if diff.any():
+                    assert max(a[diff].max(), d[diff].max()) < 1e-20, (g, j, a[diff].max(), d[diff].max())
+                    same = False
+    return same
+
+
+def _subnormal_margin(c, mode):
+    """True when a snapshot of the oracle's forward solve, or its state right before a mass balance, holds subnormal-range
+    thicknesses (0 < H < 1e-290: what an advancing margin leaves in the cells it has not reached yet).  Such values carry no
+    significant digits -- two correct forward solves differ in them by factors -- yet the reference's gradient tests them
+    against zero (the mass-balance mask H > 0 that zeroes lambda on a cell that melts completely, VJPs.jl:124-148; the factor
+    (Hbar > 0) of dVelocity/dtheta in target :D, evaluated on the linearly INTERPOLATED state, where s * 1e-323 underflows to 0
+    or not): where this is the case a mismatch at the 1e-4 level is the reference algorithm's discontinuity, not an error."""
+    for g in range(c["G"]):
+        cfg = O.SimConfig(tstops=c["own"][g], reltol=1e-8, mb=c["mbs"][g], mb_times=c["mbt"] if c["mbs"][g] is not None else (),
+                          fixed_dt=c["dts"] if mode == "discrete_fixed" else None)
+        snaps, _, inc = O.forward(c["gls"][g], c["laws"][g], cfg)
+        fields = list(snaps)
+        for tm, d in inc.items():
+            past = [j for j, t in enumerate(c["own"][g]) if t == tm]
+            if past:
+                fields.append(snaps[past[0]] - d)
+        for H in fields:
+            if np.any((H > 0) & (H < 1e-290)):
+                return True
+    return False
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_batch_gradient_matches_the_oracle(gpu, monkeypatch, seed):
+    for key in list(os.environ):
+        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB"):
+            monkeypatch.delenv(key, raising=False)
+    c = _draw(gpu, seed)
+    G, ph, kind, mode = c["G"], c["ph"], c["kind"], c["mode"]
+    tag = {k: c[k] for k in ("G", "kind", "mode", "vjp", "log_eps", "ragged", "mbt", "interp", "shapes", "dxs", "dys", "sched")}
+    tag["sliding"] = ph.C != 0.0
+    nq = 8
+    dt_fixed = c["dts"]
+    # ---- oracle, glacier by glacier
+    Lo, go = _oracle_gradient(c, nq)
+    if mode != "discrete_fixed" and _ill_conditioned(c, nq, go, 2e-5):
+        pytest.skip("the checker's own gradient moves by more than the tolerance under a 1e-12 perturbation of the parameters")
+    # ---- the HIP path
+    b = gpu.GlacierBatch(c["shapes"], c["dxs"], c["dys"], phys=[gpu.PhysicalParameters(**ph.__dict__)] * G, A=c["As"], T=c["Ts"])
+    try:
+        for g in range(G):
+            b.set_fields(g, c["gls"][g].H0, c["gls"][g].B)
+            b.set_reference(g, c["own"][g], c["refs"][g], 3)
+            if c["mbs"][g] is not None:
+                m = c["mbs"][g]
+                b.set_mass_balance(g, m.mb0, m.dmb_dS, m.S_ref, m.mb_max)
+            if c["ragged"]:
+                b.set_glacier_stops(g, c["own"][g])
+        if kind != O.LAW_CONST_A:
+            b.set_law(kind, c["gm"], c["th"])
+            if kind == O.LAW_NN_A_GRIDDED:
+                for g in range(G):
+                    b.set_T_field(g, c["laws"][g].T)
+            if kind == O.LAW_NN_Y:
+                b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR if c["interp"][0] == "linear" else gpu._lib.GRAD_INTERP_NONE,
+                                         c["interp"][1])
+        if c["vjp"] == "continuous":
+            b.set_vjp_method(gpu._lib.VJP_CONTINUOUS)
+        if c["log_eps"] is not None:
+            b.set_thickness_loss_function(c["log_eps"])
+        if c["sched"]:
+            b.set_schedule(**c["sched"])
+        union = sorted(set(t for ts in c["own"] for t in ts))
+        if mode == "continuous":
+            Lg, gg = b.loss_grad_continuous(union, theta=c["th"], mb_times=c["mbt"], reltol=1e-8, n_quadrature=nq)
+        elif mode == "discrete_fixed":
+            Lg, gg = b.loss_grad(union, theta=c["th"], mb_times=c["mbt"], fixed_dt=dt_fixed)
+        else:
+            Lg, gg = b.loss_grad(union, theta=c["th"], mb_times=c["mbt"], reltol=1e-8)
+        comparable = _margins_agree(b, c, mode)
+    finally:
+        b.close()
+    if not comparable:
+        pytest.skip("subnormal margin cells differ between the device and the checker: the gradient is discontinuous there")
+    # (Y and U laws: the reference's own finite-difference steps in dD/dH, target_D_hybrid.jl:58-71, target_D_pure.jl:105-137,
+    #  amplify rounding differences to 1e-8)
+    ltol, gtol = (1e-10, 1e-7 if kind in (O.LAW_NN_Y, O.LAW_NN_U) else 1e-8) if mode == "discrete_fixed" else (1e-6, 2e-5)
+    assert abs(Lg - Lo) <= ltol * max(abs(Lo), 1e-300), (tag, Lg, Lo)
+    if np.linalg.norm(go) > 0:
+        if not rel_l2(gg, go) < gtol and rel_l2(gg, go) < 5e-3 and _subnormal_margin(c, mode):
+            pytest.skip("gradient differs at the level of the reference's own discontinuity at subnormal margin cells")
+        assert rel_l2(gg, go) < gtol, (tag, rel_l2(gg, go))
+    else:
+        assert np.linalg.norm(gg) == 0, tag
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_batch_velocity_loss_gradient_matches_the_oracle(gpu, monkeypatch, seed):
+    """The same draw with LossV / LossHV (Losses.jl:293-440): velocity maps at some of the stops, :xy / :abs / LogSum, scaled or
+    not, every law (the U law with a surface-velocity factor), both adjoints."""
+    for key in list(os.environ):
+        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB"):
+            monkeypatch.delenv(key, raising=False)
+    c = _draw(gpu, seed, velocity=True)
+    G, ph, kind, mode, v = c["G"], c["ph"], c["kind"], c["mode"], c["vel"]
+    tag = {k: c[k] for k in ("G", "kind", "mode", "log_eps", "mbt", "interp", "shapes", "dxs", "dys", "sched", "fV")}
+    tag.update({k: v[k] for k in ("kind", "component", "log_eps", "scale")}, sliding=ph.C != 0.0, law=kind)
+    nq = 8
+    Lo, go = _oracle_gradient(c, nq)
+    if mode != "discrete_fixed" and _ill_conditioned(c, nq, go, 2e-5):
+        pytest.skip("the checker's own gradient moves by more than the tolerance under a 1e-12 perturbation of the parameters")
+    b = gpu.GlacierBatch(c["shapes"], c["dxs"], c["dys"], phys=[gpu.PhysicalParameters(**ph.__dict__)] * G, A=c["As"], T=c["Ts"])
+    try:
+        for g in range(G):
+            b.set_fields(g, c["gls"][g].H0, c["gls"][g].B)
+            b.set_reference(g, c["own"][g], c["refs"][g], 3)
+            b.set_velocity_reference(g, v["tV"][g], [m[0] for m in v["Vref"][g]], [m[1] for m in v["Vref"][g]], [m[2] for m in v["Vref"][g]])
+            if c["mbs"][g] is not None:
+                m = c["mbs"][g]
+                b.set_mass_balance(g, m.mb0, m.dmb_dS, m.S_ref, m.mb_max)
+        if kind != O.LAW_CONST_A:
+            b.set_law(kind, c["gm"], c["th"])
+            if kind == O.LAW_NN_A_GRIDDED:
+                for g in range(G):
+                    b.set_T_field(g, c["laws"][g].T)
+            if kind == O.LAW_NN_Y:
+                b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR if c["interp"][0] == "linear" else gpu._lib.GRAD_INTERP_NONE,
+                                         c["interp"][1])
+        b.set_surface_velocity_factor(c["fV"])
+        b.set_loss(gpu._lib.LOSS_V if v["kind"] == "V" else gpu._lib.LOSS_HV, v["component"], v["scale"], v["scaling"])
+        b.set_velocity_loss_function(v["log_eps"])
+        if c["log_eps"] is not None:
+            b.set_thickness_loss_function(c["log_eps"])
+        if c["sched"]:
+            b.set_schedule(**c["sched"])
+        if mode == "continuous":
+            Lg, gg = b.loss_grad_continuous(c["common"], theta=c["th"], mb_times=c["mbt"], reltol=1e-8, n_quadrature=nq)
+        elif mode == "discrete_fixed":
+            Lg, gg = b.loss_grad(c["common"], theta=c["th"], mb_times=c["mbt"], fixed_dt=c["dts"])
+        else:
+            Lg, gg = b.loss_grad(c["common"], theta=c["th"], mb_times=c["mbt"], reltol=1e-8)
+        comparable = _margins_agree(b, c, mode)
+    finally:
+        b.close()
+    if not comparable:
+        pytest.skip("subnormal margin cells differ between the device and the checker: the gradient is discontinuous there")
+    ltol, gtol = (1e-10, 1e-7 if kind in (O.LAW_NN_Y, O.LAW_NN_U) else 1e-8) if mode == "discrete_fixed" else (1e-6, 2e-5)
+    assert abs(Lg - Lo) <= ltol * max(abs(Lo), 1e-300), (tag, Lg, Lo)
+    if np.linalg.norm(go) > 0:
+        if not rel_l2(gg, go) < gtol and rel_l2(gg, go) < 5e-3 and _subnormal_margin(c, mode):
+            pytest.skip("gradient differs at the level of the reference's own discontinuity at subnormal margin cells")
+        assert rel_l2(gg, go) < gtol, (tag, rel_l2(gg, go))
+    else:
+        assert np.linalg.norm(gg) == 0, tag
