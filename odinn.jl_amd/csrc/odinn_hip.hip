@@ -2720,7 +2720,8 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   C.adj = b->d_adj; C.tsnap = b->d_tsnap; C.stop_snap = b->d_rsnap; C.stop_qw = b->d_rqw; C.qw_out = b->d_qw;
   C.stop_hid = b->nhid > 0 ? b->d_rhid : nullptr;
   // ODINN_TRACE_STEPS=n: the first n attempts of glacier 0's reverse solve (tau, dt, error estimate, +-step factor) on stderr
-  double* d_trace = nullptr;
+  struct TraceBuf { double* p = nullptr; ~TraceBuf() { if (p) (void)hipFree(p); } } trace_buf;
+  double*& d_trace = trace_buf.p;
   const int ntrace = std::getenv("ODINN_TRACE_STEPS") ? std::atoi(std::getenv("ODINN_TRACE_STEPS")) : 0;
   if (ntrace > 0) {
     HIPCHK(hipMalloc(&d_trace, (size_t)ntrace * 4 * sizeof(double)));
@@ -2885,7 +2886,6 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
   if (d_trace) {
     std::vector<double> tr((size_t)ntrace * 4);
     HIPCHK(hipMemcpy(tr.data(), d_trace, tr.size() * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(d_trace);
     const long long n = std::min<long long>(ntrace, gs[0].naccept + gs[0].nreject);
     for (long long q = 0; q < n; ++q)
       std::fprintf(stderr, "[odinn reverse step %lld] tau %.17g dt %.17g EEst %.17g factor %.17g\n", q, tr[4 * q], tr[4 * q + 1], tr[4 * q + 2], tr[4 * q + 3]);

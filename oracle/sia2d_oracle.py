@@ -751,7 +751,14 @@ def vjp_theta_continuous(lam, H, B, dx, dy, ph: Phys, law: Law, theta=None):
 
     if law.kind == LAW_CONST_A:
         return np.array([contract(spat)])
-    g = law_grad_theta(law, ph, Hbar, gS, theta)
+    # dDiffusivity/dtheta(target; ...) (:634-639) is the same call as in the discrete VJP: it honours target.interpolation
+    kind, nhalf = law.interp()
+    if kind == "linear" and law.kind == LAW_NN_Y and Hbar.max() > 0.0:
+        g = law_grad_theta_linear(law, ph, Hbar, gS, theta, nhalf)
+    elif kind == "linear" and law.kind == LAW_NN_U:
+        g = law_grad_theta_bilinear(law, ph, Hbar, gS, theta, nhalf)
+    else:
+        g = law_grad_theta(law, ph, Hbar, gS, theta)
     if law.kind == LAW_NN_A_SCALAR:
         return g.reshape(-1) * contract(spat)
     return np.array([contract(spat * g[k]) for k in range(g.shape[0])])

@@ -375,3 +375,128 @@ def test_random_batch_velocity_loss_gradient_matches_the_oracle(gpu, monkeypatch
         assert rel_l2(gg, go) < gtol, (tag, rel_l2(gg, go))
     else:
         assert np.linalg.norm(gg) == 0, tag
+
+
+def _draw_seam(gpu, seed):
+    rng = np.random.default_rng(77000 + seed)
+    nx = int(rng.choice([3, 4, 17, 63, 64, 65, 66, 130])) if rng.random() < 0.4 else int(rng.integers(3, 100))
+    ny = int(rng.choice([3, 4, 15, 16, 17, 33])) if rng.random() < 0.4 else int(rng.integers(3, 70))
+    dx = float(rng.choice([25.0, 50.0, 100.0, 200.0]))
+    dy = dx if rng.random() < 0.5 else float(np.round(dx * rng.uniform(0.6, 1.6), 2))
+    ph = [O.Phys(), O.Phys(n=3.2, C=7e-8, q=1.0), O.Phys(n=2.5), O.Phys(eta0=0.7), O.Phys(n=3.0, C=3e-8, p=2.0, q=1.0),
+          O.Phys(n=4.0, eta0=1.3)][int(rng.integers(0, 6))]
+    kind = [O.LAW_CONST_A, O.LAW_NN_A_SCALAR, O.LAW_NN_A_GRIDDED, O.LAW_NN_Y, O.LAW_NN_U][int(rng.integers(0, 5))]
+    x = np.linspace(-1.0, 1.0, nx)[:, None]
+    y = np.linspace(-1.0, 1.0, ny)[None, :]
+    style = int(rng.integers(0, 4))
+    # (off-centre: on an exactly symmetric field the nodes that tie with max(Hbar) bit for bit decide the quantile knots of
+    #  create_interpolation)
+    H = rng.uniform(20.0, 300.0) * np.maximum(0.0, 1.0 - ((x - rng.uniform(-0.13, 0.13)) / rng.uniform(0.5, 1.5)) ** 2
+                                              - ((y - rng.uniform(-0.13, 0.13)) / rng.uniform(0.5, 1.5)) ** 2) + 0.0 * x * y
+    if style == 1:
+        H = H + rng.normal(0.0, 5.0, H.shape)                       # negative entries where the ice is thin or absent
+    elif style == 2:
+        H = np.round(H / 10.0) * 10.0                               # plateaus: equal neighbours, ties in the clamp
+    elif style == 3:
+        H = H * (rng.random(H.shape) > 0.3)                         # holes
+    B = 1000.0 + rng.uniform(-0.2, 0.2) * x * nx * dx / 2 + rng.uniform(-0.2, 0.2) * y * ny * dy / 2 \
+        + rng.uniform(0.0, 30.0) * np.sin(4.0 * x) * np.cos(3.0 * y)
+    if style == 2 and rng.random() < 0.5:
+        B = np.round(B / 10.0) * 10.0                               # ... with S = B + H on a lattice too
+    H, B = np.asfortranarray(H), np.asfortranarray(B + np.zeros_like(H))
+    T = float(rng.uniform(-20.0, -1.0))
+    A = float(rng.uniform(1e-18, 4e-17))
+    om = gm = th = None
+    interp = None
+    if kind in (O.LAW_NN_A_SCALAR, O.LAW_NN_A_GRIDDED):
+        widths, acts = [([1, 3, 10, 3, 1], [1, 1, 1, 2]), ([1, 16, 16, 1], [1, 1, 2]), ([1, 5, 7, 1], [3, 4, 2])][int(rng.integers(0, 3))]
+        om = O.MLP(widths, acts, None, O.POST_AFFINE, ph.minA, ph.maxA)
+        gm = gpu.MLPSpec(widths, acts, None, O.POST_AFFINE, ph.minA, ph.maxA)
+    elif kind == O.LAW_NN_Y:
+        widths, acts = [([2, 3, 10, 3, 1], [1, 1, 1, 2]), ([2, 3, 1], [1, 2]), ([2, 16, 16, 1], [1, 1, 2])][int(rng.integers(0, 3))]
+        pre = [(-25.0, 0.0), (0.0, 500.0)]
+        om = O.MLP(widths, acts, pre, O.POST_EXPMAX, 0.0, ph.maxA)
+        gm = gpu.MLPSpec(widths, acts, pre, O.POST_EXPMAX, 0.0, ph.maxA)
+        interp = ("linear", int(rng.choice([3, 10, 75]))) if rng.random() < 0.5 else ("none", 75)
+    elif kind == O.LAW_NN_U:
+        widths, acts = [2, 3, 10, 3, 1], [1, 1, 1, 2]
+        pre = [(0.0, 300.0), (0.0, 0.5)]
+        om = O.MLP(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
+        gm = gpu.MLPSpec(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
+    if om is not None:
+        th = om.init_theta(rng) + 0.05 * rng.standard_normal(om.n_params)
+    if kind == O.LAW_CONST_A:
+        law = O.Law(kind=kind, A=A)
+    elif kind == O.LAW_NN_A_GRIDDED:
+        law = O.Law(kind=kind, mlp=om, theta=th, T=np.asfortranarray(T + rng.uniform(-3, 3, (nx - 1, ny - 1))))
+    elif kind == O.LAW_NN_Y:
+        law = O.Law(kind=kind, mlp=om, theta=th, T=T, interpolation=interp[0], n_interp_half=interp[1])
+    else:
+        law = O.Law(kind=kind, mlp=om, theta=th, T=T)
+    lam = rng.standard_normal(H.shape)
+    return dict(nx=nx, ny=ny, dx=dx, dy=dy, ph=ph, kind=kind, style=style, H=H, B=B, T=T, A=A, om=om, gm=gm, th=th, interp=interp,
+                law=law, lam=lam)
+
+
+def _seam_seeds():
+    e = os.environ.get("ODINN_FUZZ_SEEDS")
+    if e:
+        a, b = e.split(":")
+        return list(range(int(a), int(b)))
+    return list(range(40))
+
+
+@pytest.mark.parametrize("seed", _seam_seeds())
+def test_random_seams_match_the_oracle(gpu, monkeypatch, seed):
+    """The four seams of the path on random inputs: SIA2D! (adjoint.jl:52-97), VJP_lambda_dSIA/dH discrete (:99-151) and
+    continuous (:442-553), VJP_lambda_dSIA/dtheta (:178-255) -- random shapes from 3 x 3 up across the 64-lane and tile
+    boundaries, rectangular cells, n != 3, sliding with several (p, q), eta0 != 1, the five laws, thickness fields with
+    ice-free areas, negative entries (clamped, :52), integer values (ties in the slope clamp, inversion_utils.jl:22-43) and
+    cells on the boundary ring."""
+    for key in list(os.environ):
+        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB"):
+            monkeypatch.delenv(key, raising=False)
+    q = _draw_seam(gpu, seed)
+    nx, ny, dx, dy, ph, kind, style, H, B, T, A = (q[k] for k in ("nx", "ny", "dx", "dy", "ph", "kind", "style", "H", "B", "T", "A"))
+    gm, th, interp, law, lam = (q[k] for k in ("gm", "th", "interp", "law", "lam"))
+    tag = dict(shape=(nx, ny), dx=dx, dy=dy, ph=ph, kind=kind, style=style, interp=interp)
+    b = gpu.GlacierBatch([(nx, ny)], [dx], [dy], phys=[gpu.PhysicalParameters(**ph.__dict__)], A=[A], T=[T])
+    try:
+        b.set_fields(0, H, B)
+        if kind != O.LAW_CONST_A:
+            b.set_law(kind, gm, th)
+            if kind == O.LAW_NN_A_GRIDDED:
+                b.set_T_field(0, law.T)
+            if kind == O.LAW_NN_Y:
+                b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR if interp[0] == "linear" else gpu._lib.GRAD_INTERP_NONE, interp[1])
+        dH = b.dhdt(0, H)
+        vH = b.vjp_H(0, lam, H)
+        vT = np.atleast_1d(b.vjp_theta(0, lam, H))
+        b.set_vjp_method(gpu._lib.VJP_CONTINUOUS)
+        vHc = b.vjp_H(0, lam, H)
+        vTc = np.atleast_1d(b.vjp_theta(0, lam, H))
+    finally:
+        b.close()
+
+    def close(a, r, tol, what):
+        r = np.atleast_1d(r)
+        if not np.all(np.isfinite(r)):
+            # an exponent below 3 (n < 3, or sliding with p < 3) on a field with nodes where grad S = 0 exactly (the lattice
+            # style): the reference's beta = dD/d|grad S| / |grad S| carries |grad S|^(n - 3) (target_A.jl:46-62) -- Inf, and
+            # Inf * 0 = NaN in its VJP; nothing to compare (the device returns NaN or the limit, as its FMA contraction falls)
+            assert ph.n < 3.0 or (ph.C > 0.0 and ph.p < 3.0), ("oracle not finite", ph, style, (nx, ny), what)
+            return
+        assert np.all(np.isfinite(a)), ("device not finite", tag, what)
+        if np.linalg.norm(r) == 0:
+            assert np.linalg.norm(a) == 0, (tag, what)
+        else:
+            assert rel_l2(a, r) < tol, (tag, what, rel_l2(a, r))
+
+    # (Y and U laws: the reference's finite-difference steps inside dD/dH, dD/d|grad S| amplify rounding to 1e-8 / 1e-6)
+    tolH = {O.LAW_NN_Y: 1e-7, O.LAW_NN_U: 1e-5}.get(kind, 1e-10)
+    close(dH, O.sia2d_rhs(H, B, dx, dy, ph, law), 1e-11, "dhdt")
+    assert np.all(dH[0, :] == 0) and np.all(dH[-1, :] == 0) and np.all(dH[:, 0] == 0) and np.all(dH[:, -1] == 0)
+    close(vH, O.vjp_H(lam, H, B, dx, dy, ph, law), tolH, "vjp_H")
+    close(vT, O.vjp_theta(lam, H, B, dx, dy, ph, law), 1e-9, "vjp_theta")
+    close(vHc, O.vjp_H_continuous(lam, H, B, dx, dy, ph, law), tolH, "vjp_H continuous")
+    close(vTc, O.vjp_theta_continuous(lam, H, B, dx, dy, ph, law), 1e-9, "vjp_theta continuous")
