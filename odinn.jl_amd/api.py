@@ -354,7 +354,9 @@ def _avgv_times(g, loss) -> List[float]:
     if v is None or v.date1 is None or v.date2 is None or len(v.date1) != 1 or len(v.date2) != 1:
         raise ValueError("With LossAvgV the velocity data should contain exactly one sample.")  # :356
     t1, t2 = float(v.date1[0]), float(v.date2[0])
-    n = int(math.floor((t2 - t1) / loss.step + 1e-9))
+    n = int(round((t2 - t1) / loss.step))  # length of a Julia float range (see odinn_hip.hip, agg_tables)
+    if t1 + n * loss.step > t2 + 4.0 * 2.220446049250313e-16 * max(abs(t1), abs(t2)):
+        n -= 1
     return [t1 + i * loss.step for i in range(n)]
 
 

@@ -1149,7 +1149,10 @@ int agg_tables(odinn_batch* b, bool with_grad) {
     for (int g = 0; g < G; ++g) {  // LossAvgV: tLoss = collect(t1:step:t2) without its last point, weights dt_i / T
       const double t1 = b->av_t1[g], t2 = b->av_t2[g], st = b->avgv_step;
       if (!(t2 > t1)) continue;
-      const int n = (int)std::floor((t2 - t1) / st + 1e-9);
+      // length of t1:step:t2 as Julia's float ranges find it: the nearest integer to (t2 - t1) / step, one less when that
+      // point lies beyond t2 by more than rounding
+      int n = (int)std::llround((t2 - t1) / st);
+      if (t1 + n * st > t2 + 4.0 * 2.220446049250313e-16 * std::fmax(std::fabs(t1), std::fabs(t2))) --n;
       if (n < 1) return fail(ODINN_ERR_ARG, "LossAvgV: (t1, t2) = (%g, %g) of glacier %d holds no interval of length step = %g", t1, t2, g, st);
       double T = 0.0;
       for (int i = 0; i < n; ++i) T += (t1 + (i + 1) * st) - (t1 + i * st);

@@ -1180,7 +1180,11 @@ class AvgVData:
 
 def avgv_times(a: AvgVData):
     """tLoss = collect(t1:step:t2), dt = diff(tLoss), tLoss[begin:end-1]  (TimeAggregatedLosses.jl:201-204)."""
-    n = int(math.floor((a.t2 - a.t1) / a.step + 1e-9))
+    # length of a Julia float range: the nearest integer to (t2 - t1) / step, one less when that point overshoots t2 by more
+    # than rounding
+    n = int(round((a.t2 - a.t1) / a.step))
+    if a.t1 + n * a.step > a.t2 + 4.0 * np.finfo(F).eps * max(abs(a.t1), abs(a.t2)):
+        n -= 1
     tl = [a.t1 + i * a.step for i in range(n + 1)]
     dt = [tl[i + 1] - tl[i] for i in range(n)]
     return tl[:-1], dt

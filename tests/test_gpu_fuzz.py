@@ -179,7 +179,8 @@ def _oracle_gradient(c, nq, rel_perturbation=0.0):
             law = (dataclasses.replace(law, A=law.A * (1.0 + rel_perturbation)) if law.kind == O.LAW_CONST_A
                    else dataclasses.replace(law, theta=law.theta * (1.0 + rel_perturbation)))
         cfg = O.SimConfig(tstops=c["own"][g], reltol=1e-8, mb=c["mbs"][g], mb_times=c["mbt"] if c["mbs"][g] is not None else (),
-                          fixed_dt=c["dts"] if mode == "discrete_fixed" else None, h_log_eps=c["log_eps"])
+                          fixed_dt=c["dts"] if mode == "discrete_fixed" else None, h_log_eps=c["log_eps"],
+                          **(c["cfg_extra"][g] if c.get("cfg_extra") else {}))
         if v is None and mode == "continuous":
             out = O.loss_and_grad_continuous(c["gls"][g], law, cfg, c["refs"][g], c["own"][g], O.ContinuousAdjointCfg(n_quadrature=nq),
                                              vjp=c["vjp"])
@@ -500,3 +501,105 @@ def test_random_seams_match_the_oracle(gpu, monkeypatch, seed):
     close(vT, O.vjp_theta(lam, H, B, dx, dy, ph, law), 1e-9, "vjp_theta")
     close(vHc, O.vjp_H_continuous(lam, H, B, dx, dy, ph, law), tolH, "vjp_H continuous")
     close(vTc, O.vjp_theta_continuous(lam, H, B, dx, dy, ph, law), 1e-9, "vjp_theta continuous")
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_batch_time_aggregated_terms_match_the_oracle(gpu, monkeypatch, seed):
+    """The draw of the first test with LossH and a random subset of the time-aggregated terms of a MultiLoss: LossDhdt
+    (TimeAggregatedLosses.jl:38-113), LossAvgV (:115-258, :xy / :abs), VelocityRegularization (Regularization.jl:64-79,
+    192-245), with random weights and windows, every law, both adjoints."""
+    for key in list(os.environ):
+        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB"):
+            monkeypatch.delenv(key, raising=False)
+    c = _draw(gpu, 700000 + seed)
+    rng = np.random.default_rng(31000 + seed)
+    G, ph, kind, mode = c["G"], c["ph"], c["kind"], c["mode"]
+    c["vjp"] = "discrete"
+    if c["ragged"]:  # the windows of the aggregated terms sit on the common table
+        c["ragged"] = False
+        for g in range(G):
+            c["own"][g] = list(c["common"])
+            c["refs"][g] = [c["refs"][g][min(j, len(c["refs"][g]) - 1)] for j in range(len(c["common"]))]
+    ts, k = c["common"], len(c["common"])
+    terms = [t for t in ("dhdt", "avgv", "vreg") if rng.random() < 0.55] or ["dhdt"]
+    w = dict(dhdt=float(rng.uniform(0.5, 5.0)), avgv=float(rng.uniform(0.5, 5.0)), vreg=float(rng.uniform(5.0, 80.0)))
+    comp = "abs" if rng.random() < 0.5 else "xy"
+    dist = int(rng.integers(0, 4))
+    extra, avg, tVs = [], [], []
+    for g in range(G):
+        e = {}
+        if "dhdt" in terms:
+            i0 = int(rng.integers(0, k - 1)); i1 = int(rng.integers(i0 + 1, k))
+            e.update(dhdt=(ts[i0], ts[i1], float(rng.uniform(-5.0, 1.0))), dhdt_weight=w["dhdt"])
+        if "avgv" in terms:
+            i1 = int(rng.integers(0, k - 1)); i2 = int(rng.integers(i1 + 1, k))
+            Vx0, Vy0, _ = O.V_from_H(c["gls"][g].H0, c["gls"][g].B, c["dxs"][g], c["dys"][g], ph, c["laws"][g])
+            Vx, Vy = np.asfortranarray(1.15 * Vx0), np.asfortranarray(0.9 * Vy0)
+            a = O.AvgVData(ts[i1], ts[i2], np.asfortranarray(np.sqrt(Vx ** 2 + Vy ** 2)), Vx, Vy, comp, c["step"])
+            e.update(avgv=a, avgv_weight=w["avgv"])
+            avg.append(a)
+        if "vreg" in terms:
+            tV = [ts[j] for j in sorted(rng.choice(k, size=int(rng.integers(2, k + 1)), replace=False))]  # (the weights are date differences)
+            e.update(vreg_times=tV, vreg_distance=dist, vreg_weight=w["vreg"])
+            tVs.append(tV)
+        extra.append(e)
+    c["cfg_extra"] = extra
+    tag = {q: c[q] for q in ("G", "kind", "mode", "log_eps", "mbt", "interp", "shapes", "dxs", "dys", "sched")}
+    tag.update(terms=terms, comp=comp, dist=dist, sliding=ph.C != 0.0)
+    nq = 8
+    Lo, go = _oracle_gradient(c, nq)
+    if mode != "discrete_fixed" and _ill_conditioned(c, nq, go, 2e-5):
+        pytest.skip("the checker's own gradient moves by more than the tolerance under a 1e-12 perturbation of the parameters")
+    b = gpu.GlacierBatch(c["shapes"], c["dxs"], c["dys"], phys=[gpu.PhysicalParameters(**ph.__dict__)] * G, A=c["As"], T=c["Ts"])
+    try:
+        for g in range(G):
+            b.set_fields(g, c["gls"][g].H0, c["gls"][g].B)
+            b.set_reference(g, c["own"][g], c["refs"][g], 3)
+            if c["mbs"][g] is not None:
+                m = c["mbs"][g]
+                b.set_mass_balance(g, m.mb0, m.dmb_dS, m.S_ref, m.mb_max)
+            if "dhdt" in terms:
+                b.set_dhdt_reference(g, *extra[g]["dhdt"])
+            if "avgv" in terms:
+                a = avg[g]
+                b.set_avgv_reference(g, a.t1, a.t2, a.Vabs, a.Vx, a.Vy)
+            if "vreg" in terms:
+                z = [np.zeros(c["shapes"][g])] * len(tVs[g])
+                b.set_velocity_reference(g, tVs[g], z, z, z)  # only the dates matter
+        if kind != O.LAW_CONST_A:
+            b.set_law(kind, c["gm"], c["th"])
+            if kind == O.LAW_NN_A_GRIDDED:
+                for g in range(G):
+                    b.set_T_field(g, c["laws"][g].T)
+            if kind == O.LAW_NN_Y:
+                b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR if c["interp"][0] == "linear" else gpu._lib.GRAD_INTERP_NONE,
+                                         c["interp"][1])
+        if "dhdt" in terms:
+            b.set_dhdt_loss(w["dhdt"])
+        if "avgv" in terms:
+            b.set_avgv_loss(w["avgv"], c["step"], comp)
+        if "vreg" in terms:
+            b.set_velocity_regularization(w["vreg"], dist)
+        if c["log_eps"] is not None:
+            b.set_thickness_loss_function(c["log_eps"])
+        if c["sched"]:
+            b.set_schedule(**c["sched"])
+        if mode == "continuous":
+            Lg, gg = b.loss_grad_continuous(ts, theta=c["th"], mb_times=c["mbt"], reltol=1e-8, n_quadrature=nq)
+        elif mode == "discrete_fixed":
+            Lg, gg = b.loss_grad(ts, theta=c["th"], mb_times=c["mbt"], fixed_dt=c["dts"])
+        else:
+            Lg, gg = b.loss_grad(ts, theta=c["th"], mb_times=c["mbt"], reltol=1e-8)
+        comparable = _margins_agree(b, c, mode)
+    finally:
+        b.close()
+    if not comparable:
+        pytest.skip("subnormal margin cells differ between the device and the checker: the gradient is discontinuous there")
+    ltol, gtol = (1e-10, 1e-7 if kind in (O.LAW_NN_Y, O.LAW_NN_U) else 1e-8) if mode == "discrete_fixed" else (1e-6, 2e-5)
+    assert abs(Lg - Lo) <= ltol * max(abs(Lo), 1e-300), (tag, Lg, Lo)
+    if np.linalg.norm(go) > 0:
+        if not rel_l2(gg, go) < gtol and rel_l2(gg, go) < 5e-3 and _subnormal_margin(c, mode):
+            pytest.skip("gradient differs at the level of the reference's own discontinuity at subnormal margin cells")
+        assert rel_l2(gg, go) < gtol, (tag, rel_l2(gg, go))
+    else:
+        assert np.linalg.norm(gg) == 0, tag
