@@ -148,6 +148,7 @@ class GlacierBatch:
         self.P = 0
         self.law_kind = L.LAW_CONST_A
         self.tstops = None
+        self._A_field = set()  # glaciers that carry a dual-grid A field (odinn_set_A_field)
 
     # -- lifetime -------------------------------------------------------------------
     def close(self):
@@ -172,6 +173,7 @@ class GlacierBatch:
 
     def set_A(self, g, A):
         L.check(L.lib().odinn_set_A(self._h, g, float(A)))
+        self._A_field.discard(g)  # (odinn_set_A drops the glacier's A field)
 
     def _dual(self, g):
         return (self.shapes[g][0] - 1, self.shapes[g][1] - 1)
@@ -179,6 +181,7 @@ class GlacierBatch:
     def set_A_field(self, g, A):
         A = _f(A, self._dual(g))
         L.check(L.lib().odinn_set_A_field(self._h, g, _p(A)))
+        self._A_field.add(g)
 
     def set_T_field(self, g, T):
         T = _f(T, self._dual(g))
@@ -334,7 +337,9 @@ class GlacierBatch:
         return out
 
     def eval_law(self, g, H=None):
-        scalar = self.law_kind in (L.LAW_NN_A_SCALAR,)
+        # one value per glacier: A = NN(T) with a scalar T, or the constant-A law without an A field (odinn_eval_law writes
+        # out[0] only)
+        scalar = self.law_kind == L.LAW_NN_A_SCALAR or (self.law_kind == L.LAW_CONST_A and g not in self._A_field)
         if scalar:
             out = np.empty(1)
             L.check(L.lib().odinn_eval_law(self._h, g, None, _p(out), 1))

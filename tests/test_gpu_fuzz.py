@@ -439,6 +439,13 @@ def _draw_seam(gpu, seed):
                 law=law, lam=lam)
 
 
+def _gradS(H, B, dx, dy):
+    S = B + np.maximum(H, 0.0)
+    gx = O.avg_y(O.diff_x(S) / dx)
+    gy = O.avg_x(O.diff_y(S) / dy)
+    return np.sqrt(gx ** 2 + gy ** 2)
+
+
 def _seam_seeds():
     e = os.environ.get("ODINN_FUZZ_SEEDS")
     if e:
@@ -476,6 +483,22 @@ def test_random_seams_match_the_oracle(gpu, monkeypatch, seed):
         b.set_vjp_method(gpu._lib.VJP_CONTINUOUS)
         vHc = b.vjp_H(0, lam, H)
         vTc = np.atleast_1d(b.vjp_theta(0, lam, H))
+        # surface velocity (Huginn.surface_V, adjoint.jl:268-413) and the mass-balance seams (VJPs.jl:107-151)
+        rng2 = np.random.default_rng(88000 + seed)
+        fV = 0.8 if rng2.random() < 0.5 else 1.0
+        law.fV = fV
+        b.set_surface_velocity_factor(fV)
+        w1, w2 = rng2.standard_normal(H.shape), rng2.standard_normal(H.shape)
+        Vx, Vy = b.surface_V(0, H)
+        sH = b.surface_V_vjp_H(0, w1, w2, H)
+        sT = np.atleast_1d(b.surface_V_vjp_theta(0, w1, w2, H))
+        S0 = B + np.maximum(H, 0.0)
+        mb = O.MassBalance(mb0=np.asfortranarray(rng2.uniform(-2.0, 1.0) + 4e-3 * (S0 - S0.mean())), dmb_dS=float(rng2.choice([0.0, 4e-3])),
+                           S_ref=np.asfortranarray(S0 + rng2.normal(0.0, 3.0, H.shape)), mb_max=float(rng2.choice([0.5, 1e9])))
+        b.set_mass_balance(0, mb.mb0, mb.dmb_dS, mb.S_ref, mb.mb_max)
+        Hn, MB = b.mb_apply(0, H)
+        mV = b.mb_vjp_H(0, lam, H)
+        lawv = np.atleast_1d(b.eval_law(0, H))
     finally:
         b.close()
 
@@ -501,6 +524,19 @@ def test_random_seams_match_the_oracle(gpu, monkeypatch, seed):
     close(vT, O.vjp_theta(lam, H, B, dx, dy, ph, law), 1e-9, "vjp_theta")
     close(vHc, O.vjp_H_continuous(lam, H, B, dx, dy, ph, law), tolH, "vjp_H continuous")
     close(vTc, O.vjp_theta_continuous(lam, H, B, dx, dy, ph, law), 1e-9, "vjp_theta continuous")
+    vx, vy = O.surface_V(H, B, dx, dy, ph, law)
+    close(Vx[:-1, :-1], vx, 1e-11, "surface_V x")
+    close(Vy[:-1, :-1], vy, 1e-11, "surface_V y")
+    assert np.all(Vx[-1, :] == 0) and np.all(Vx[:, -1] == 0) and np.all(Vy[-1, :] == 0) and np.all(Vy[:, -1] == 0)
+    close(sH, O.vjp_surface_V_H(w1, w2, H, B, dx, dy, ph, law), tolH, "surface_V vjp_H")
+    close(sT, O.vjp_surface_V_theta(w1, w2, H, B, dx, dy, ph, law), 1e-9, "surface_V vjp_theta")
+    Hr, MBr = O.mb_apply(mb, np.maximum(H, 0.0) if False else H, B)
+    assert np.allclose(Hn, Hr, rtol=1e-13, atol=1e-13) and np.allclose(MB, MBr, rtol=1e-12, atol=1e-14), (tag, "mb_apply")
+    assert np.allclose(mV, O.vjp_mb(mb, lam, H, B), rtol=1e-13, atol=0), (tag, "mb_vjp")
+    if kind == O.LAW_CONST_A:
+        assert lawv.shape == (1,) and lawv[0] == A, (tag, "eval_law")
+    else:
+        close(lawv.ravel(), np.atleast_1d(O.law_value(law, ph, O.avg(np.maximum(H, 0.0)), _gradS(H, B, dx, dy))).ravel(), 1e-12, "eval_law")
 
 
 @pytest.mark.parametrize("seed", _seeds())
