@@ -26,7 +26,7 @@ def oracle(c, g, mode, nq=8):
 def device(c, idx, mode, sched=None, nq=8, kind=None):
     v = c["vel"]; ph = c["ph"]; G = len(idx)
     b = gpu.GlacierBatch([c["shapes"][i] for i in idx], [c["dxs"][i] for i in idx], [c["dys"][i] for i in idx],
-                         phys=[gpu.PhysicalParameters(**ph.__dict__)] * G, A=[c["As"][i] for i in idx], T=[c["Ts"][i] for i in idx])
+                         phys=[gpu.PhysicalParameters(**c["phs"][i].__dict__) for i in idx], A=[c["As"][i] for i in idx], T=[c["Ts"][i] for i in idx])
     for k, i in enumerate(idx):
         b.set_fields(k, c["gls"][i].H0, c["gls"][i].B)
         b.set_reference(k, c["own"][i], c["refs"][i], 3)
