@@ -2573,13 +2573,17 @@ __global__ void k_adj_itp(Pools P, int n, AdjState* adj, const double* tsnap, co
 //    mass balance first (CallbackSet order :437) except at the very first stop (loss_first);
 //  * quadrature node: Hq = H_itp(t_node) for the theta-VJP that follows (:497-503).
 
-__global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, double* __restrict__ Ua,
-                                                     double* __restrict__ Ub) {
-  const int4 t4 = P.tiles[blockIdx.x];
+// (one workgroup takes ADJ_POST_TILES tiles in turn: most launches of the reverse loop find no glacier on a stop, and a
+//  launch of ntiles workgroups that read two words and leave costs 12 us at 8 x 1024^2 against 2 us for an eighth of them)
+constexpr int ADJ_POST_TILES = 8;
+__device__ __forceinline__ void adj_poststep_tile(const Pools& P, const AdjPostArgs& A, double* __restrict__ Ua,
+                                                  double* __restrict__ Ub, const int4 t4) {
   const GState* gs = P.gs + t4.x;
   if (!gs->at_stop) return;
   const GDev g = P.gd[t4.x];
   const AdjState a = A.adj[t4.x];
+  // a quadrature node whose H_itp nobody asked for: nothing to do on this tile
+  if (a.snapj < 0 && !(a.pad > 0 && gs->mb_now && g.has_mb) && !(A.Hq && a.qw != 0.0 && !A.hq_snap_only)) return;
   double* __restrict__ U = gs->cur ? Ub : Ua;
   const int i0 = t4.y * TX, j0 = t4.z * TY;
   const int tx = threadIdx.x & 63, ty = wave_id();
@@ -2655,6 +2659,12 @@ __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, dou
       }
     }
   }
+}
+__global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, double* __restrict__ Ua,
+                                                     double* __restrict__ Ub, int ntiles) {
+  const int t0 = blockIdx.x * ADJ_POST_TILES;
+  const int t1 = t0 + ADJ_POST_TILES < ntiles ? t0 + ADJ_POST_TILES : ntiles;
+  for (int t = t0; t < t1; ++t) adj_poststep_tile(P, A, Ua, Ub, P.tiles[t]);
 }
 
 
