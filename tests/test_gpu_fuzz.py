@@ -172,7 +172,7 @@ def _draw(gpu, seed, velocity=False):
                 laws=laws, sched=sched, step=step, dts=dts, vel=vel, fV=fV, phs=phs)
 
 
-def _oracle_gradient(c, nq, rel_perturbation=0.0):
+def _oracle_gradient(c, nq, rel_perturbation=0.0, parts=None):
     """(loss, d loss / d theta) of the draw by the oracle, summed over the glaciers; the parameters (theta, or the glaciers' A)
     scaled by 1 + rel_perturbation."""
     import dataclasses
@@ -203,6 +203,8 @@ def _oracle_gradient(c, nq, rel_perturbation=0.0):
                                          loss_kind=v["kind"], scaling=v["scaling"])
         Lo += out[0]
         go = go + np.atleast_1d(out[1])
+        if parts is not None:
+            parts.append(out)
     return Lo, go
 
 
@@ -272,7 +274,8 @@ def test_random_batch_gradient_matches_the_oracle(gpu, monkeypatch, seed):
     nq = 8
     dt_fixed = c["dts"]
     # ---- oracle, glacier by glacier
-    Lo, go = _oracle_gradient(c, nq)
+    per = []
+    Lo, go = _oracle_gradient(c, nq, parts=per)
     if mode != "discrete_fixed" and _ill_conditioned(c, nq, go, 2e-5):
         pytest.skip("the checker's own gradient moves by more than the tolerance under a 1e-12 perturbation of the parameters")
     # ---- the HIP path
@@ -308,10 +311,19 @@ def test_random_batch_gradient_matches_the_oracle(gpu, monkeypatch, seed):
         else:
             Lg, gg = b.loss_grad(union, theta=c["th"], mb_times=c["mbt"], reltol=1e-8)
         comparable = _margins_agree(b, c, mode)
+        loss_g, G_g = b.grad_parts()  # odinn_get_grad_parts: per-glacier loss and dL/dA (A-type laws)
+        lam0 = [b.lambda0(g) for g in range(G)]
     finally:
         b.close()
     if not comparable:
         pytest.skip("subnormal margin cells differ between the device and the checker: the gradient is discontinuous there")
+    if mode == "discrete_fixed":  # the per-glacier results (PerGlacierModel slots, Model.jl:214-216; lambda(t0) of the IC gradient)
+        for g in range(G):
+            assert abs(loss_g[g] - per[g][0]) <= 1e-10 * max(abs(per[g][0]), 1e-300), (tag, g, "loss of the glacier")
+            if kind == O.LAW_CONST_A and per[g][1][0] != 0.0:
+                assert abs(G_g[g] - per[g][1][0]) <= 1e-8 * abs(per[g][1][0]), (tag, g, "dL/dA of the glacier")
+            if np.linalg.norm(per[g][2]) > 0:
+                assert rel_l2(lam0[g], per[g][2]) < (1e-6 if kind in (O.LAW_NN_Y, O.LAW_NN_U) else 1e-8), (tag, g, "lambda(t0)")
     # (Y and U laws: the reference's own finite-difference steps in dD/dH, target_D_hybrid.jl:58-71, target_D_pure.jl:105-137,
     #  amplify rounding differences to 1e-8)
     ltol, gtol = (1e-10, 1e-7 if kind in (O.LAW_NN_Y, O.LAW_NN_U) else 1e-8) if mode == "discrete_fixed" else (1e-6, 2e-5)
