@@ -450,6 +450,7 @@ static int interp_prepare(odinn_batch* b, int g, bool linU);
 namespace {
 
 int use_dev(odinn_batch* b) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
   HIPCHK(hipSetDevice(b->device));
   return ODINN_OK;
 }
@@ -1595,6 +1596,7 @@ int odinn_batch_sync(odinn_batch* b) {
 }
 
 int64_t odinn_batch_cells(odinn_batch* b) {
+  if (!b) return 0;
   int64_t n = 0;
   for (int g = 0; g < b->G; ++g) n += (int64_t)b->gd[g].nx * b->gd[g].ny;
   return n;
