@@ -1,7 +1,7 @@
 """GPU: no entry point of the C ABI may crash the host process on arguments a binding can get wrong -- "every function returns
 int status ... no exceptions cross the boundary" (SURVEY 8(b)).  Two sweeps over every symbol of include/odinn_hip.h (taken
 from the ctypes signature table): (1) a NULL batch handle with every other argument zero / NULL, (2) a VALID batch with every
-pointer argument NULL and every count zero.  Each call runs in a child process, so that a segmentation fault is a test failure
+pointer argument NULL and every count / index zero, (3) the same with every count / index -1.  Each call runs in a child process, so that a segmentation fault is a test failure
 and not the end of the test session; a call must come back with a status (0 where NULL is a documented "nothing" -- e.g.
 odinn_set_glacier_stops(n = 0) clears the table) and leave odinn_last_error() readable."""
 import subprocess
@@ -18,7 +18,8 @@ import _odinn_import
 odinn = _odinn_import.load()
 L = odinn._lib
 lib = L.lib()
-valid = sys.argv[1] == "valid"
+valid = sys.argv[1] in ("valid", "negative")
+ival = -1 if sys.argv[1] == "negative" else 0
 import numpy as np
 b = None
 if valid:
@@ -36,7 +37,7 @@ for name, (res, args) in L.SIGNATURES.items():
         if k == 0 and a is L._vp and valid and not name.startswith("odinn_comm"):
             vals.append(b._h)
         elif a in (C.c_int, C.c_int64, C.c_longlong):
-            vals.append(0)
+            vals.append(ival)
         elif a is C.c_double:
             vals.append(0.0)
         else:
@@ -53,7 +54,7 @@ print("SWEEP-OK", len(done))
 '''
 
 
-@pytest.mark.parametrize("mode", ["null", "valid"])
+@pytest.mark.parametrize("mode", ["null", "valid", "negative"])
 def test_abi_calls_with_null_and_zero_arguments_return_a_status(gpu, mode):
     import os
 
