@@ -113,7 +113,8 @@ void launch_adj_itp(int G, hipStream_t st, Pools P, AdjState* adj, const double*
   hipLaunchKernelGGL(k_adj_itp, dim3((G + 63) / 64), dim3(64), 0, st, P, G, adj, tsnap, n_snaps, all_at_end);
 }
 void launch_adj_poststep(int nblk, hipStream_t st, Pools P, AdjPostArgs A, double* Ua, double* Ub) {
-  hipLaunchKernelGGL(k_adj_poststep, dim3((nblk + ADJ_POST_TILES - 1) / ADJ_POST_TILES), dim3(NT), 0, st, P, A, Ua, Ub, nblk);
+  const int per_wg = nblk / 512 < 1 ? 1 : (nblk / 512 > ADJ_POST_TILES ? ADJ_POST_TILES : nblk / 512);
+  hipLaunchKernelGGL(k_adj_poststep, dim3((nblk + per_wg - 1) / per_wg), dim3(NT), 0, st, P, A, Ua, Ub, nblk, per_wg);
 }
 void launch_vreg_prep(int nblk, hipStream_t st, Pools P, const double* H, const double* vx, const double* vy, const double* w,
                       int dist, double* Vabs, unsigned char* mask) {

@@ -2573,8 +2573,10 @@ __global__ void k_adj_itp(Pools P, int n, AdjState* adj, const double* tsnap, co
 //    mass balance first (CallbackSet order :437) except at the very first stop (loss_first);
 //  * quadrature node: Hq = H_itp(t_node) for the theta-VJP that follows (:497-503).
 
-// (one workgroup takes ADJ_POST_TILES tiles in turn: most launches of the reverse loop find no glacier on a stop, and a
-//  launch of ntiles workgroups that read two words and leave costs 12 us at 8 x 1024^2 against 2 us for an eighth of them)
+// (one workgroup takes up to ADJ_POST_TILES tiles in turn once the launch has more than 512 workgroups left: most launches
+//  of the reverse loop find no glacier on a stop, and a launch of ntiles workgroups that read two words and leave costs 12 us
+//  at 8 x 1024^2 against 2 us for an eighth of them; small batches keep one tile per workgroup -- the stops that do have work
+//  would otherwise serialise it, 4 alpine glaciers: 54 instead of 7 us per snapshot stop)
 constexpr int ADJ_POST_TILES = 8;
 __device__ __forceinline__ void adj_poststep_tile(const Pools& P, const AdjPostArgs& A, double* __restrict__ Ua,
                                                   double* __restrict__ Ub, const int4 t4) {
@@ -2661,9 +2663,9 @@ __device__ __forceinline__ void adj_poststep_tile(const Pools& P, const AdjPostA
   }
 }
 __global__ __launch_bounds__(NT) void k_adj_poststep(Pools P, AdjPostArgs A, double* __restrict__ Ua,
-                                                     double* __restrict__ Ub, int ntiles) {
-  const int t0 = blockIdx.x * ADJ_POST_TILES;
-  const int t1 = t0 + ADJ_POST_TILES < ntiles ? t0 + ADJ_POST_TILES : ntiles;
+                                                     double* __restrict__ Ub, int ntiles, int per_wg) {
+  const int t0 = blockIdx.x * per_wg;
+  const int t1 = t0 + per_wg < ntiles ? t0 + per_wg : ntiles;
   for (int t = t0; t < t1; ++t) adj_poststep_tile(P, A, Ua, Ub, P.tiles[t]);
 }
 
