@@ -649,7 +649,8 @@ def test_random_batch_time_aggregated_terms_match_the_oracle(gpu, monkeypatch, s
         b.close()
     if not comparable:
         pytest.skip("subnormal margin cells differ between the device and the checker: the gradient is discontinuous there")
-    ltol, gtol = (1e-10, 1e-7 if kind in (O.LAW_NN_Y, O.LAW_NN_U) else 1e-8) if mode == "discrete_fixed" else (1e-6, 2e-5)
+    # (the Laplacian of VelocityRegularization and the small differences of LossAvgV amplify rounding in the LOSS to 1e-9)
+    ltol, gtol = (1e-8, 1e-7 if kind in (O.LAW_NN_Y, O.LAW_NN_U) else 1e-8) if mode == "discrete_fixed" else (1e-6, 2e-5)
     assert abs(Lg - Lo) <= ltol * max(abs(Lo), 1e-300), (tag, Lg, Lo)
     if np.linalg.norm(go) > 0:
         if not rel_l2(gg, go) < gtol and rel_l2(gg, go) < 5e-3 and _subnormal_margin(c, mode):
