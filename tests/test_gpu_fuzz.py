@@ -444,6 +444,13 @@ def _draw_seam(gpu, seed):
         pre = [(0.0, 300.0), (0.0, 0.5)]
         om = O.MLP(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
         gm = gpu.MLPSpec(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
+        if np.random.default_rng(66000 + seed).random() < 0.35:
+            # SIA2D_D_target(interpolation = :Linear): the law's node grid spans [0, 100] on both axes and does not extrapolate
+            # (Laws.jl:128-131): thickness kept below 100 m
+            interp = ("linear", int(np.random.default_rng(67000 + seed).choice([2, 5, 100])))
+            H = np.asfortranarray(H * (95.0 / max(float(H.max()), 95.0)))
+            if style == 2:  # stay on the lattice: (B + H) - B == H exactly, so that the slope clamp sees exact ties, not near-ties
+                H = np.asfortranarray(np.round(H / 10.0) * 10.0)
     if om is not None:
         th = om.init_theta(rng) + 0.05 * rng.standard_normal(om.n_params)
     if kind == O.LAW_CONST_A:
@@ -451,6 +458,8 @@ def _draw_seam(gpu, seed):
     elif kind == O.LAW_NN_A_GRIDDED:
         law = O.Law(kind=kind, mlp=om, theta=th, T=np.asfortranarray(T + rng.uniform(-3, 3, (nx - 1, ny - 1))))
     elif kind == O.LAW_NN_Y:
+        law = O.Law(kind=kind, mlp=om, theta=th, T=T, interpolation=interp[0], n_interp_half=interp[1])
+    elif kind == O.LAW_NN_U and interp is not None:
         law = O.Law(kind=kind, mlp=om, theta=th, T=T, interpolation=interp[0], n_interp_half=interp[1])
     else:
         law = O.Law(kind=kind, mlp=om, theta=th, T=T)
@@ -495,7 +504,7 @@ def test_random_seams_match_the_oracle(gpu, monkeypatch, seed):
             b.set_law(kind, gm, th)
             if kind == O.LAW_NN_A_GRIDDED:
                 b.set_T_field(0, law.T)
-            if kind == O.LAW_NN_Y:
+            if kind == O.LAW_NN_Y or (kind == O.LAW_NN_U and interp is not None):
                 b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR if interp[0] == "linear" else gpu._lib.GRAD_INTERP_NONE, interp[1])
         dH = b.dhdt(0, H)
         vH = b.vjp_H(0, lam, H)
