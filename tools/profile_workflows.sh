@@ -1,7 +1,7 @@
 # The other workflows at bench scale under rocprofv3 --kernel-trace --stats (run on the GPU box via gpurun):
-# wall-clock lines of the probes + top kernels -> gpurun_out/r02w/workflows_kernel_stats.txt (copy into profiles/r02/).
+# wall-clock lines of the probes + top kernels -> gpurun_out/r02w/workflows_kernel_stats.txt (copy into profiles/r03/).
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02w; mkdir -p $O
+O=$R/gpurun_out/r03w; mkdir -p $O
 OUT=$O/workflows_kernel_stats.txt
 {
   echo "# Other workflows under rocprofv3 --kernel-trace --stats at bench scale (tools/profile_workflows.sh: workflow_probe.py,"
