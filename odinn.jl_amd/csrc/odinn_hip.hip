@@ -238,7 +238,11 @@ struct odinn_batch {
   // reference writes it) through the per-node network in the velocity kernels
   bool vel_nn() const { return law_kind == ODINN_LAW_NN_U || law_kind == ODINN_LAW_NN_Y; }
   // Y law with the target's default `:Linear` interpolation of dY/dtheta: the velocity kernels emit (Hbar, node weight)
-  bool vel_emit() const { return law_kind == ODINN_LAW_NN_Y && grad_interp == ODINN_GRAD_INTERP_LINEAR; }
+  // theta-part of the surface-velocity pull-backs through the target's `:Linear` law-gradient interpolation: the kernels emit
+  // (Hbar, weight[, |grad S|]) per dual node for k_interp.hip instead of backpropagating per node (Y law: the knots of
+  // create_interpolation, target_D_hybrid.jl:321-345; U law: LawU's node grid, dU/dtheta / f of target_D_pure.jl:179-193,247-255)
+  bool vel_emit() const { return law_kind >= ODINN_LAW_NN_Y && grad_interp == ODINN_GRAD_INTERP_LINEAR; }
+  bool vel_emit_U() const { return vel_emit() && law_kind == ODINN_LAW_NN_U; }
   // LossV's simple loss: 0 = L2Sum, > 0 = LogSum(eps) (component :abs only; Losses.jl:34-49,207-229); h_log_eps: LossH's
   double v_log_eps = 0.0, h_log_eps = 0.0;
   std::vector<std::vector<std::vector<double>>> v_edge;  // per glacier per slot: V_ref > 0 on the last row / column
@@ -762,23 +766,14 @@ int ensure_tables(odinn_batch* b, int n_stops) {
 int build_stop_tables(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times) {
   const int G = b->G;
   const double t0 = tstops[0], t1 = tstops[n_stops - 1];
-  b->tstops.assign(tstops, tstops + n_stops);
+  // validate everything BEFORE the batch's tables are touched: a rejected call leaves the previous solve's tables (and its
+  // snapshots) consistent
   b->own_stops.resize(G);
-  b->ts_g.assign(G, std::vector<double>());
-  b->ragged = false;
-  int kmax = 0;
   for (int g = 0; g < G; ++g) {
     const std::vector<double>& o = b->own_stops[g];
-    if (o.empty()) {
-      b->ts_g[g] = b->tstops;
-    } else {
-      if (o.front() != t0 || o.back() != t1)
-        return fail(ODINN_ERR_ARG, "the stops of glacier %d span [%.12g, %.12g], the call's tstops [%.12g, %.12g]: every glacier "
-                                   "covers the same tspan", g, o.front(), o.back(), t0, t1);
-      b->ts_g[g] = o;
-      if (o != b->tstops) b->ragged = true;
-    }
-    kmax = std::max(kmax, (int)b->ts_g[g].size());
+    if (!o.empty() && (o.front() != t0 || o.back() != t1))
+      return fail(ODINN_ERR_ARG, "the stops of glacier %d span [%.12g, %.12g], the call's tstops [%.12g, %.12g]: every glacier "
+                                 "covers the same tspan", g, o.front(), o.back(), t0, t1);
   }
   std::vector<double> mbt;
   if (b->any_mb)
@@ -788,6 +783,21 @@ int build_stop_tables(odinn_batch* b, int n_stops, const double* tstops, int n_m
       if (m > 0 && !(mb_times[m] > mb_times[m - 1])) return fail(ODINN_ERR_ARG, "mb_times must be strictly increasing");
       mbt.push_back(mb_times[m]);
     }
+  b->solved = false;  // from here on the tables no longer describe the stored snapshots; do_solve sets it again at its end
+  b->tstops.assign(tstops, tstops + n_stops);
+  b->ts_g.assign(G, std::vector<double>());
+  b->ragged = false;
+  int kmax = 0;
+  for (int g = 0; g < G; ++g) {
+    const std::vector<double>& o = b->own_stops[g];
+    if (o.empty()) {
+      b->ts_g[g] = b->tstops;
+    } else {
+      b->ts_g[g] = o;
+      if (o != b->tstops) b->ragged = true;
+    }
+    kmax = std::max(kmax, (int)b->ts_g[g].size());
+  }
   struct It { double t; int res, mb, mbs, snap; };
   std::vector<std::vector<It>> its(G);
   int imax = 0, nhid = 0, nmbs = 0;
@@ -1292,10 +1302,11 @@ int vreg_forward(odinn_batch* b, bool with_grad, bool add_loss, int nq, const do
       if (b->t_vref[g].size() >= 2)
         for (int n = 0; n < nq; ++n) wq[(size_t)n * G + g] = b->vreg_weight * qw[n];
     // segment and weight of every node in every glacier's own snapshots, interpolate((t,), H, Gridded(Linear())) (gradient.jl:287)
-    std::vector<int> sg((size_t)nq * G, -1);
+    // (glaciers without two velocity dates carry weight 0 but are interpolated like the others: the kernels below run over the
+    //  whole batch, and 0 * whatever-the-buffer-held-before must not be 0 * NaN)
+    std::vector<int> sg((size_t)nq * G, 0);
     std::vector<double> sw((size_t)nq * G, 0.0);
     for (int g = 0; g < G; ++g) {
-      if (b->t_vref[g].size() < 2) continue;
       const std::vector<double>& tsg = b->ts_g[g];
       const int kg = (int)tsg.size();
       for (int n = 0; n < nq; ++n) {
@@ -1861,8 +1872,8 @@ static int vel_theta_args(odinn_batch* b, VArgs& A, int g) {
   if (!b->vel_nn()) return ODINN_OK;
   CHK(ensure_theta_scratch(b, g < 0 ? b->ntiles : b->gd[g].ntiles));
   if (b->vel_emit()) {
-    CHK(interp_prepare(b, g, false));
-    A.emitH = b->d_nodeH; A.emitV = b->d_nodeV;
+    CHK(interp_prepare(b, g, b->vel_emit_U()));
+    A.emitH = b->d_nodeH; A.emitV = b->d_nodeV; A.emitS = b->vel_emit_U() ? b->d_nodeS : nullptr;
   } else {
     A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
   }
@@ -1871,7 +1882,7 @@ static int vel_theta_args(odinn_batch* b, VArgs& A, int g) {
 // ... and their reduction into d_dth after the launch (added onto what is there unless !accumulate)
 static int vel_theta_finish(odinn_batch* b, int g, bool accumulate, const Pools& P) {
   if (!b->vel_nn()) return ODINN_OK;
-  if (b->vel_emit()) return interp_contract(b, g, false, accumulate, P);
+  if (b->vel_emit()) return interp_contract(b, g, b->vel_emit_U(), accumulate, P);
   launch_sum_part_theta(b->P, g < 0 ? b->G : 1, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g < 0 ? 0 : g);
   return ODINN_OK;
 }
@@ -1996,7 +2007,6 @@ int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double
   if (!H || !lam || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
-  CHK(check_loss_terms(b));
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
   CHK(up_field(b, g, b->d_tmpA, H));
   CHK(up_field(b, g, b->d_lam[0], lam));
@@ -2209,7 +2219,6 @@ int odinn_surface_V_vjp_theta(odinn_batch* b, int g, const double* dVx, const do
   CHK(check_g(b, g));
   const int Pexp = b->law_kind == ODINN_LAW_CONST_A ? 1 : b->P;
   if (P != Pexp) return fail(ODINN_ERR_ARG, "dtheta has %d entries, expected %d", P, Pexp);
-  CHK(check_loss_terms(b));
   CHK(surfV_vjp_common(b, g, dVx, dVy, H));
   const GDev& r = b->gd[g];
   if (b->law_kind == ODINN_LAW_NN_A_GRIDDED) return gridded_law_grad(b, r.offd, (long long)(r.nx - 1) * (r.ny - 1), dtheta);
@@ -2293,10 +2302,11 @@ int odinn_set_glacier_stops(odinn_batch* b, int g, int n, const double* t) {
 int odinn_set_schedule(odinn_batch* b, const odinn_schedule* sc) {
   if (!b) return fail(ODINN_ERR_ARG, "null batch");
   const odinn_schedule automatic = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
-  b->sched = sc ? *sc : automatic;
-  if (b->sched.adj_rows >= 0 && b->sched.adj_rows != 4 && b->sched.adj_rows != 7)
+  const odinn_schedule want = sc ? *sc : automatic;  // (validated as a local: a rejected schedule leaves the old one in effect)
+  if (want.adj_rows >= 0 && want.adj_rows != 4 && want.adj_rows != 7)
     return fail(ODINN_ERR_ARG, "odinn_schedule.adj_rows must be -1, 4 or 7");
-  if (b->sched.fused_tiles > 4) return fail(ODINN_ERR_ARG, "odinn_schedule.fused_tiles must be -1 ... 4");
+  if (want.fused_tiles > 4) return fail(ODINN_ERR_ARG, "odinn_schedule.fused_tiles must be -1 ... 4");
+  b->sched = want;
   return ODINN_OK;
 }
 
@@ -2324,7 +2334,6 @@ int odinn_get_schedule(odinn_batch* b, odinn_schedule* out) {
 
 int odinn_get_snapshot(odinn_batch* b, int g, int istop, double* H_out) {
   CHK(check_g(b, g)); CHK(use_dev(b));
-  if (!b->solved) return fail(ODINN_ERR_STATE, "no solve has been run");
   if (!b->solved || g >= (int)b->ts_g.size()) return fail(ODINN_ERR_STATE, "no solve has been run");
   // (istop counts the glacier's OWN result stops: the table of odinn_set_glacier_stops, or the tstops of the solve)
   if (istop < 0 || istop >= b->nres(g)) return fail(ODINN_ERR_ARG, "istop out of range");
@@ -2333,7 +2342,7 @@ int odinn_get_snapshot(odinn_batch* b, int g, int istop, double* H_out) {
 
 int odinn_get_H(odinn_batch* b, int g, double* H_out) {
   CHK(check_g(b, g)); CHK(use_dev(b));
-  if (!b->solved) return down_field(b, g, b->d_H0, H_out);
+  if (!b->solved || g >= (int)b->ts_g.size() || b->nres(g) < 1) return down_field(b, g, b->d_H0, H_out);
   return down_field(b, g, b->d_snaps + (size_t)(b->nres(g) - 1) * b->ntot, H_out);
 }
 
@@ -2856,7 +2865,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
         } else {
           launch_vref_itp(b->ntiles, b->stream, Pl, VI);
           launch_vref_scale(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_vscq, b->d_wvq);
-          if (b->vel_emit()) CHK(interp_prepare(b, -1, false));
+          if (b->vel_emit()) CHK(interp_prepare(b, -1, b->vel_emit_U()));
           launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VQ, 0);
           if (b->vel_nn()) CHK(vel_theta_finish(b, -1, true, Pl));
           else launch_sum_part(G, b->stream, Pl, 3, b->d_Gsum, 1, 0);

@@ -159,6 +159,7 @@ struct VArgs {
   // (dual pooled arrays, pre-zeroed by the caller) instead of the per-node backprop
   double* emitH;
   double* emitV;
+  double* emitS;  // U law (target :D) with `:Linear`: |grad S| of the node as well (second axis of LawU's gradient interpolant)
 };
 
 template <int MODE, int LM>
@@ -274,6 +275,12 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
             } else if (gth && Hb > 0.0) {
               mlp_grad(L, g.T, Hb, wn, gth, gstride);
             }
+          } else if (A.emitH) {
+            // U law, `:Linear`: dVelocity^/dtheta = (Hbar > 0) grad_itp(Hbar, |grad S|) / f (target_D_pure.jl:179-193,247-255)
+            const long long q = g.offd + gi + (long long)(g.nx - 1) * gj;
+            A.emitH[q] = Hb;
+            A.emitV[q] = Hb > 0.0 ? -wv * W * A.finv : 0.0;
+            A.emitS[q] = gS;
           } else if (gth && Hb > 0.0) {  // U law: dVelocity^/dtheta = (Hbar > 0) dU/dtheta / f, exact backprop per node (:None branch)
             mlp_grad(L, Hb, gS, -wv * W * A.finv, gth, gstride);
           }

@@ -1771,8 +1771,15 @@ def vjp_surface_V_theta(dVx, dVy, H, B, dx, dy, ph: Phys, law: Law, theta=None):
     """VJP_lambda_dsurface_V/dtheta_discrete (adjoint.jl:352-413)."""
     Hc, S, gSx, gSy, gS, Hbar, *_ = _forward_intermediates(H, B, dx, dy, ph)
     gSdV = gSx * inn1(dVx) + gSy * inn1(dVy)
-    if law.kind == LAW_NN_U:  # dVelocity^/dtheta = dU/dtheta / f with dU/dtheta = (Hbar > 0) x backprop (target_D_pure.jl:139-176,247-255)
-        return -np.tensordot(law_grad_theta(law, ph, Hbar, gS, theta), (Hbar > 0.0) * gSdV / law.fV, axes=([1, 2], [0, 1]))
+    if law.kind == LAW_NN_U:
+        # dVelocity^/dtheta = dU/dtheta / f (target_D_pure.jl:247-255) with dU/dtheta = (Hbar > 0) x the law gradient, exact per
+        # node (:None, :163-176) or interpolated bilinearly on LawU's node grid (:Linear, :179-193) -- target.interpolation
+        kind, nhalf = law.interp()
+        if kind == "linear":
+            g = law_grad_theta_bilinear(law, ph, Hbar, gS, theta, nhalf)
+        else:
+            g = law_grad_theta(law, ph, Hbar, gS, theta)
+        return -np.tensordot(g, (Hbar > 0.0) * gSdV / law.fV, axes=([1, 2], [0, 1]))
     if law.kind == LAW_NN_Y:
         # dVelocity^/dtheta of target :D_hybrid (target_D_hybrid.jl:287-351): Gamma^ H^(n_H+1) |grad S|^(n_gradS-1) x dY/dtheta,
         # the law gradient exact per node (:None) or interpolated linearly in Hbar on create_interpolation's knots (:Linear,

@@ -214,6 +214,70 @@ def test_lossV_with_the_U_law_target_D(gpu, adjoint):
     b.close()
 
 
+@pytest.mark.parametrize("adjoint", ["seam", "discrete", "continuous"])
+def test_velocity_theta_path_of_the_U_law_honours_linear_interpolation(gpu, adjoint):
+    """dVelocity^/dtheta of target :D is dU/dtheta / f (target_D_pure.jl:247-255), and dU/dtheta honours target.interpolation
+    (:163-193): with `:Linear` the law gradient comes from LawU's (2 n_interp_half)^2 node grid, bilinear in (Hbar, |grad S|)
+    -- in the surface-velocity pull-back too, not only in the diffusivity's theta-VJP.  Seam and LossV through both adjoints."""
+    ph = O.Phys()
+    om, gm, th = _u_law(gpu, ph)
+    n_half = 40
+    law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, fV=0.8, interpolation="linear", n_interp_half=n_half)
+    law_none = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th, fV=0.8)
+    if adjoint == "seam":
+        nx, ny = 70, 53
+        H0, B = O.synthetic_alpine(nx, ny, hmax=90.0)
+        b = gpu.GlacierBatch([(nx, ny)], [50.0])
+        b.set_fields(0, H0, B)
+        b.set_law(gpu.LAW_NN_U, gm, th)
+        b.set_surface_velocity_factor(0.8)
+        rng = np.random.default_rng(11)
+        w1, w2 = rng.standard_normal((nx, ny)), rng.standard_normal((nx, ny))
+        exact = b.surface_V_vjp_theta(0, w1, w2, H0)
+        assert rel_l2(exact, O.vjp_surface_V_theta(w1, w2, H0, B, 50.0, 50.0, ph, law_none)) < 1e-10
+        b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, n_half)
+        got = b.surface_V_vjp_theta(0, w1, w2, H0)
+        assert rel_l2(got, O.vjp_surface_V_theta(w1, w2, H0, B, 50.0, 50.0, ph, law)) < 1e-10
+        assert np.array_equal(got, b.surface_V_vjp_theta(0, w1, w2, H0))
+        assert 1e-12 < rel_l2(got, exact) < 0.9  # the two branches differ by the interpolation error
+        with pytest.raises(gpu.OdinnError, match="BoundsError"):  # Hbar > 100: the interpolant does not extrapolate
+            b.surface_V_vjp_theta(0, w1, w2, H0 * 1.5)
+        b.close()
+        return
+    step = 1.0 / 96.0
+    ts = [2010.0 + j * step for j in range(5)]
+    nx, ny = 56, 40
+    H0, B = O.synthetic_alpine(nx, ny, hmax=80.0, slope=0.1)
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    cfg = O.SimConfig(tstops=ts, reltol=1e-10)
+    ref, _, _ = O.forward(gl, law, cfg)
+    tV = ts if adjoint == "continuous" else ts[1::2]
+    Vref = []
+    for t in tV:
+        Vx, Vy, V = O.V_from_H(ref[ts.index(t)], B, 50.0, 50.0, ph, law)
+        Vref.append((1.1 * V, 1.1 * Vx, 1.1 * Vy))
+    vspec = O.LossVSpec(component="xy", scale_loss=True)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0])
+    b.set_fields(0, H0, B)
+    b.set_reference(0, ts, ref, 3)
+    b.set_velocity_reference(0, tV, [v[0] for v in Vref], [v[1] for v in Vref], [v[2] for v in Vref])
+    b.set_law(gpu.LAW_NN_U, gm, th)
+    b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, n_half)
+    b.set_surface_velocity_factor(0.8)
+    b.set_loss(gpu._lib.LOSS_V, "xy", True, 1.0)
+    if adjoint == "discrete":
+        Lo, go, _ = O.loss_and_grad_HV(gl, law, cfg, ref, ts, Vref, tV, vspec, loss_kind="V")
+        Lg, gg = b.loss_grad(ts, theta=th, reltol=1e-10)
+    else:
+        Lo, go, _, _ = O.loss_and_grad_continuous(gl, law, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=8),
+                                                  V_ref=Vref, tV_ref=tV, vspec=vspec, loss_kind="V")
+        Lg, gg = b.loss_grad_continuous(ts, theta=th, reltol=1e-10, n_quadrature=8)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo), (Lg, Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 1e-5 and abs(angle) < 1e-8 and relerr < 1e-5, (ratio, angle, relerr)
+    b.close()
+
+
 def _y_law(gpu, ph, arch="default"):
     from test_gpu_parity import _mlp_pair
     widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "light": ([2, 3, 1], [1, 2])}[arch]
