@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the SIA2D(+NN_theta) hot path on MI355X.
 
-Workload (BASELINE.json configs[4], the config the scaling metric is quoted on; its per-GPU share
-fits one GPU): every GPU holds 8 synthetic 1024x1024 fp64 ice caps (per-glacier random radius, bed
-phase, seed 1234 + global glacier index), resident in HBM, with the "CuffeyPaterson-style" law of
-configs[2]: A = NN_theta(T) -- a 2-hidden-layer x 16-unit MLP on a gridded long-term temperature,
-hoisted into a dual-grid A field once per theta exactly as the reference evaluates LawA
-(src/laws/Laws.jl:339-358).
+Workload (BASELINE.json configs[4], the config the scaling metric is quoted on, and it fits one GPU): the JOB is 64
+synthetic 1024x1024 fp64 ice caps (per-glacier random radius, bed phase, seed 1234 + global glacier index), sharded over
+the N GPUs of the run -- all 64 on one GPU at N = 1, 8 per GPU at N = 8 (strong scaling: "glacier-batch throughput at 8
+GPUs vs 1") -- resident in HBM, with the "CuffeyPaterson-style" law of configs[2]: A = NN_theta(T) -- a 2-hidden-layer x
+16-unit MLP on a gridded long-term temperature, hoisted into a dual-grid A field once per theta exactly as the reference
+evaluates LawA (src/laws/Laws.jl:339-358).  The fixed 8-glaciers-per-GPU (weak) figure is in aux.weak_8_per_gpu.
 
 A "step" is one pass of the hot path over that batch exactly as odinn_solve launches it: one
 RDPK3Sp35 time step (5 RHS + stage updates per cell) + the controller (error-norm reduction, PID);
@@ -21,8 +21,9 @@ odinn_solve runs by default (shortcut on) is in aux.
     python bench.py --gpus N --steps K --warmup W
     (N > 1 without a torch.distributed environment: re-executes itself under
      `python -m torch.distributed.run --nproc-per-node N`, one rank per GPU; fails if fewer than N
-     devices are visible.  Glaciers shard with no data-path collective -> weak scaling; the only
-     collective of the path, the all-reduce of [loss, dtheta], runs in the grad-eval leg.)
+     devices are visible.  Glaciers shard with no data-path collective; the only collective of the path,
+     ONE ncclAllReduce of [n_failed, loss, dtheta] inside libodinn_hip (odinn_batch_loss_grad), runs in the grad-eval leg.
+     If the library's communicator cannot be created the run FAILS -- no silent fallback to another reduction.)
 
 Prints ONE JSON line (rank 0):
   roofline            dominant kernel of the timed region, k_rk_fused_strip<gridded A, 8 rows>: a whole
@@ -69,7 +70,7 @@ B_PER_CELL_FUSED_NN = 32.0  # + the dual-grid A field
 # fp64 flops per EXECUTED cell-stage of the strip kernel, fallback when profiles/r0x/pmc_roofline.json is absent:
 # profiles/r01/pmc_fused_strip_sq.md: (9.60 + 14.03 + 2 x 11.12) M wave-instr x 64 lanes / (2888 tiles x 4096 cells x 5)
 FLOP_PER_CELL_STAGE_FALLBACK = 49.7
-PMC_FILES = [os.path.join(ROOT, "profiles", r, "pmc_roofline.json") for r in ("r03", "r02")]  # newest committed pass first
+PMC_FILES = [os.path.join(ROOT, "profiles", r, "pmc_roofline.json") for r in ("r04", "r03", "r02")]  # newest committed pass first
 
 
 def make_glacier(n, gidx, dx=100.0):
@@ -126,13 +127,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--glaciers-per-gpu", type=int, default=8)
+    ap.add_argument("--glaciers", type=int, default=64, help="glaciers of the whole job (BASELINE configs[4]: 64), sharded over the GPUs")
+    ap.add_argument("--glaciers-per-gpu", type=int, default=0, help="> 0: fix the per-GPU share instead (weak scaling; the job is then N x this)")
     ap.add_argument("--hbm-glaciers", type=int, default=32, help="batch for the HBM-bound per-kernel figures (past the Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-grad-eval", action="store_true")
     ap.add_argument("--no-hbm-sweep", action="store_true")
-    ap.add_argument("--no-full-config", action="store_true", help="skip aux.full_config_one_gpu (all 64 x 1024^2 glaciers of configs[4] on one GPU)")
-    ap.add_argument("--full-config-glaciers", type=int, default=64)
+    ap.add_argument("--no-full-config", action="store_true", help="(accepted for old command lines; the 64-glacier job IS the timed workload now)")
+    ap.add_argument("--no-weak", action="store_true", help="skip aux.weak_8_per_gpu (the fixed 8-glaciers-per-GPU figure)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -171,32 +173,50 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         odinn.api._DIST.update(init=True, rank=rank, world=world, local=local, device=red_dev)
-        comm_note = "torch.distributed (" + backend + ")"
+        comm_note = "torch.distributed (" + backend + "): explicit dry-run backend, NOT the library's communicator"
         if backend == "nccl":  # the all-reduce of [loss, dtheta] runs inside libodinn_hip (odinn_comm_*, RCCL over xGMI)
+            err = ""
             try:
                 odinn.api.attach_rccl_comm(local)
-                comm_note = "libodinn_hip odinn_comm_* (ncclAllReduce inside the library)"
-            except Exception as e:  # never lose the scaling line to the communicator: torch's RCCL group reduces instead
+            except Exception as e:
                 odinn.api._DIST["comm"] = None
-                comm_note = f"torch.distributed (nccl); odinn_comm_init_rank failed: {str(e)[:160]}"
+                err = str(e)[:300]
             ok = torch.tensor([1.0 if odinn.api._DIST.get("comm") is not None else 0.0], device=red_dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # all ranks use the same path
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank learns whether ANY rank failed
             if float(ok.item()) == 0.0:
-                odinn.api._DIST["comm"] = None
-                if "failed" not in comm_note:
-                    comm_note = "torch.distributed (nccl); odinn_comm_init_rank failed on another rank"
+                # never credit a scaling line to a path that is not the library's: no fallback to torch's group
+                raise SystemExit(f"bench.py: odinn_comm_init_rank failed on rank {rank if err else '(another)'}: {err} -- refusing to "
+                                 "run the N-GPU bench with a different reduction")
+            comm_rank, comm_n = odinn.api._DIST["comm"].rank_size()
+            if comm_n != world:
+                raise SystemExit(f"bench.py: the library's communicator has {comm_n} ranks, WORLD_SIZE is {world}")
+            comm_note = f"libodinn_hip odinn_comm_* (ncclAllReduce inside the library, communicator of {comm_n} ranks)"
     if odinn.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
 
     T = odinn._lib
     ph = odinn.PhysicalParameters()
-    n, G = args.size, args.glaciers_per_gpu
-    gl = [make_glacier(n, rank * G + k) for k in range(G)]
-    b = odinn.GlacierBatch([(n, n)] * G, [100.0] * G, A=[g[2] for g in gl], device=local)
-    for k, (H0, B, A) in enumerate(gl):
-        b.set_fields(k, H0, B)
-        b.set_T_field(k, temperature_field(H0, B))
+    n = args.size
+    if args.glaciers_per_gpu > 0:  # weak scaling on request: fixed per-GPU share
+        G, first, G_job, scaling = args.glaciers_per_gpu, rank * args.glaciers_per_gpu, world * args.glaciers_per_gpu, "weak"
+    else:  # the configs[4] job, sharded: rank r owns a contiguous block (the first G_job % world ranks hold one more)
+        G_job, scaling = args.glaciers, "strong"
+        if G_job < world:
+            raise SystemExit(f"bench.py: {G_job} glaciers cannot be sharded over {world} GPUs")
+        G = G_job // world + (1 if rank < G_job % world else 0)
+        first = rank * (G_job // world) + min(rank, G_job % world)
+    gl = [make_glacier(n, first + k) for k in range(G)]
+
+    def make_batch(glist):
+        bb_ = odinn.GlacierBatch([(n, n)] * len(glist), [100.0] * len(glist), A=[g[2] for g in glist], device=local)
+        for k, (H0, B, A) in enumerate(glist):
+            bb_.set_fields(k, H0, B)
+            bb_.set_T_field(k, temperature_field(H0, B))
+        return bb_
+
+    b = make_batch(gl)
     cells = b.cells
+    cells_job = G_job * n * n
     # configs[2]: "2-layer/16-unit NN_theta law (CuffeyPaterson-style)": A = minA + (maxA - minA) MLP(T)
     mlpA = odinn.MLPSpec([1, 16, 16, 1], [odinn.ACT_SOFTPLUS, odinn.ACT_SOFTPLUS, odinn.ACT_SIGMOID],
                          None, odinn.POST_AFFINE, ph.minA, ph.maxA)
@@ -226,8 +246,35 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         dist.barrier()
-    cellsteps = 5.0 * cells * args.steps * world
+    cellsteps = 5.0 * cells_job * args.steps  # the whole job: every rank's glaciers
     value = cellsteps / elapsed
+
+    # ---- the fixed per-GPU share (8 glaciers per GPU, weak scaling): same launches, same bracket -------------------
+    weak = None
+    if not args.no_weak and args.glaciers_per_gpu <= 0:
+        if G == 8:
+            weak = {"value": value, "ms_per_step": elapsed / args.steps * 1e3, "note": "the timed job already has 8 glaciers per GPU"}
+        else:
+            b8 = make_batch(gl[:8] if G >= 8 else [make_glacier(n, first + k) for k in range(8)])
+            b8.set_law(odinn.LAW_NN_A_GRIDDED, mlpA, thetaA)
+            b8.bench_prepare()
+            b8.bench_enqueue(T.TIMED_SOLVE_STEP, 0, args.warmup)
+            b8.sync(); barrier()
+            tw0 = time.perf_counter()
+            b8.bench_enqueue(T.TIMED_SOLVE_STEP, args.warmup, args.steps)
+            b8.sync()
+            tw = time.perf_counter() - tw0
+            if dist is not None:
+                tt = torch.tensor([tw], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tw = float(tt.item())
+            weak = {"value": 5.0 * b8.cells * world * args.steps / tw, "ms_per_step": tw / args.steps * 1e3,
+                    "fused_step_kernel_ms": b8.time_kernel(T.TIMED_FUSED_STEP, iters=30, warmup=5),
+                    "dhdt_nn_gridded_in_cache_GBs": B_PER_CELL_DHDT_NN * b8.cells / (b8.time_kernel(T.TIMED_DHDT, iters=50, warmup=5) * 1e-3) / 1e9,
+                    "note": f"8 x {n}^2 glaciers per GPU on each of the {world} GPU(s) (the round-1..3 headline workload; working sets of "
+                            "192-448 MiB sit partly in the 256 MiB Infinity Cache): whole-job cell-steps/s, max over ranks"}
+            b8.close()
+            del b8
 
     # ---- the same launches bracketed by HIP events on the library's own stream ----------------------
     ev = lambda which, iters=30, warmup=5: b.time_kernel(which, iters=iters, warmup=warmup)
@@ -244,7 +291,8 @@ def main():
         "law_field_ms": ms_law,
         "law_field_note": "k_law_field: the 2x16 MLP evaluated on every dual node, once per theta (= once per solve; outside the timed steps, inside full_solve)",
         "fused_step_with_ice_free_shortcut_ms": ms_fused_nn_skip,
-        "fused_step_with_ice_free_shortcut_cellsteps_per_s": 5.0 * cells * world / (ms_fused_nn_skip * 1e-3),
+        "fused_step_with_ice_free_shortcut_cellsteps_per_s": 5.0 * cells / (ms_fused_nn_skip * 1e-3),
+        "per_rank_note": "HIP-event figures in aux and the roofline blocks are measured on rank 0's shard (its own stream)",
         "ice_free_shortcut_note": "odinn_solve's default: workgroups whose halo region has u == 0 skip the stages "
                                   "(bit-identical); `value` is measured with the shortcut OFF (dense work)",
     })
@@ -260,7 +308,7 @@ def main():
         tf = time.perf_counter() - tf0
         nst = [s_.naccept + s_.nreject for s_ in st_f]
         aux["full_solve"] = {
-            "ms": tf * 1e3, "steps_per_glacier": nst, "cellsteps_per_s": 5.0 * (n * n) * sum(nst) * world / tf,
+            "ms": tf * 1e3, "steps_per_glacier": nst if len(nst) <= 8 else [min(nst), max(nst)], "cellsteps_per_s": 5.0 * (n * n) * sum(nst) / tf,
             "us_per_step_of_the_slowest_glacier": tf * 1e6 / max(nst),
             "note": "odinn_solve(6 monthly stops, reltol 1e-6, dense work) with A = NN_theta(T): hoisted-law evaluation, Hairer-Wanner "
                     "initial step, every accepted and rejected RDPK3Sp35 step, snapshots and host polls included; glaciers step "
@@ -280,14 +328,14 @@ def main():
     ms_adj = ev(T.TIMED_ADJ_STAGE2, 20, 3)
     aux.update({
         "constA_ms_per_step": ms_step_c,
-        "constA_cellsteps_per_s": 5.0 * cells * world / (ms_step_c * 1e-3),
+        "constA_cellsteps_per_s": 5.0 * cells / (ms_step_c * 1e-3),
         "constA_fused_step_kernel_ms": ms_fused_c,
         "constA_fused_step_with_ice_free_shortcut_ms": ms_fused_c_skip,
         "constA_note": "BASELINE configs[1]: constant A per glacier, same grids, same launch sequence (HIP events)",
         "per_stage_schedule_ms_per_step": ms_solve_staged,
-        "per_stage_schedule_cellsteps_per_s": 5.0 * cells * world / (ms_solve_staged * 1e-3),
+        "per_stage_schedule_cellsteps_per_s": 5.0 * cells / (ms_solve_staged * 1e-3),
         "euler_cfl_step_ms": ms_cfl,
-        "euler_cfl_cellsteps_per_s": cells * world / (ms_cfl * 1e-3),
+        "euler_cfl_cellsteps_per_s": cells / (ms_cfl * 1e-3),
         "euler_cfl_note": "explicit Euler with CFL-limited dt (scheme 3): ONE cell-step per cell per launch, 24 B per cell-step",
         "adj_fused_step_ms": ms_adjf,
         "adj_stage2_ms": ms_adj,
@@ -297,15 +345,14 @@ def main():
     })
 
     # ---- HBM-bound kernels on a working set past the 256 MiB Infinity Cache -------------------------
+    # (rank 0's shard itself when it holds >= 32 glaciers -- the 64-glacier job at N = 1 --, otherwise a 32-glacier batch)
     hbm = {}
     if rank == 0 and not args.no_hbm_sweep:
         try:
-            Gb = args.hbm_glaciers
-            glb = [gl[k] if k < G else make_glacier(n, 1000 + k) for k in range(Gb)]
-            bb = odinn.GlacierBatch([(n, n)] * Gb, [100.0] * Gb, A=[g[2] for g in glb], device=local)
-            for k, (H0, B, A) in enumerate(glb):
-                bb.set_fields(k, H0, B)
-                bb.set_T_field(k, temperature_field(H0, B))
+            own = G >= args.hbm_glaciers
+            Gb = G if own else args.hbm_glaciers
+            bb = b if own else make_batch([gl[k] if k < G else make_glacier(n, 1000 + k) for k in range(Gb)])
+            bb.set_law(odinn.LAW_CONST_A)
             cb = bb.cells
             evb = lambda which, iters=20, warmup=3: bb.time_kernel(which, iters=iters, warmup=warmup)
             rows = {}
@@ -327,61 +374,13 @@ def main():
             rows["solve_step_nn_gridded"] = {"ms": ms_step_big_nn, "cellsteps_per_s": 5.0 * cb / (ms_step_big_nn * 1e-3)}
             hbm = {"glaciers": Gb, "cells": cb, "working_set_note": f"{Gb} x {n}^2 fp64: {8 * cb / 2**20:.0f} MiB per field "
                    "(every kernel's working set > 512 MiB, past the 256 MiB Infinity Cache)", "kernels": rows}
-            bb.close()
-            del bb, glb
+            if not own:
+                bb.close()
+                del bb
         except Exception as e:
             hbm = {"error": str(e)[:300]}
-    # the same HBM-bound kernels on the 8-glacier batch (working sets of 192-448 MiB: partly Infinity-Cache resident)
-    ms_dhdt = ev(T.TIMED_DHDT, 50, 5)
-    ms_stage = ev(T.TIMED_RK_STAGE2, 50, 5)
-    ms_vjp = ev(T.TIMED_VJP_H, 20, 3)
-    ms_vjpt = ev(T.TIMED_VJP_THETA, 20, 3)
-    aux["in_cache_figures_8_glaciers"] = {
-        "note": f"{G} x {n}^2: working sets of 192-448 MiB sit partly in the 256 MiB Infinity Cache; NOT HBM rates -- see hbm_past_infinity_cache",
-        "dhdt_GBs": B_PER_CELL_DHDT * cells / (ms_dhdt * 1e-3) / 1e9,
-        "dhdt_nn_gridded_GBs": B_PER_CELL_DHDT_NN * cells / (ms_dhdt_nn * 1e-3) / 1e9,
-        "rk_stage2_GBs": B_PER_CELL_STAGE2 * cells / (ms_stage * 1e-3) / 1e9,
-        "vjp_H_GBs": B_PER_CELL_VJPH * cells / (ms_vjp * 1e-3) / 1e9,
-        "vjp_theta_GBs": 24.0 * cells / (ms_vjpt * 1e-3) / 1e9,
-    }
     aux["hbm_past_infinity_cache"] = hbm
-
-    # ---- the WHOLE configs[4] batch on ONE GPU (64 x 1024^2 resident): the strong-scaling anchor of "8 GPUs vs 1" ----------
-    if rank == 0 and world == 1 and not args.no_full_config:
-        try:
-            Gf = args.full_config_glaciers
-            glf = [gl[k] if k < G else make_glacier(n, k) for k in range(Gf)]
-            bf = odinn.GlacierBatch([(n, n)] * Gf, [100.0] * Gf, A=[g[2] for g in glf], device=local)
-            for k, (H0, B, A) in enumerate(glf):
-                bf.set_fields(k, H0, B)
-                bf.set_T_field(k, temperature_field(H0, B))
-            bf.set_law(odinn.LAW_NN_A_GRIDDED, mlpA, thetaA)
-            ms_full = bf.time_kernel(T.TIMED_SOLVE_STEP, iters=20, warmup=3)
-            full = {"glaciers": Gf, "cells": bf.cells, "solve_step_ms": ms_full,
-                    "cellsteps_per_s": 5.0 * bf.cells / (ms_full * 1e-3),
-                    "note": f"all {Gf} x {n}^2 glaciers of BASELINE configs[4] resident on ONE GPU, same law and launch sequence as "
-                            "`value` (which times the 8-glacier per-GPU share): what 1 GPU does with the whole job"}
-            if not args.no_grad_eval:
-                nnf = odinn.NeuralNetwork(odinn.Parameters(), seed=666)
-                mlpf = odinn.MLPSpec(nnf.widths, nnf.acts, None, odinn.POST_AFFINE, ph.minA, ph.maxA)
-                bf.set_law(odinn.LAW_NN_A_SCALAR, mlpf, nnf.theta)
-                tsf = [2010.0 + k / 12.0 for k in range(25)]
-                for k in range(Gf):
-                    bf.set_reference(k, tsf, [glf[k][0] * (1.0 - 0.002 * j) for j in range(len(tsf))], 3)
-                for nm, fn in (("discrete_adjoint", lambda: bf.loss_grad(tsf, theta=nnf.theta, reltol=1e-8)),
-                               ("continuous_adjoint", lambda: bf.loss_grad_continuous(tsf, theta=nnf.theta, reltol=1e-8))):
-                    fn()  # warm (allocations)
-                    bf.sync()
-                    tq0 = time.perf_counter()
-                    fn()
-                    bf.sync()
-                    full["grad_evals_per_s_" + nm] = Gf / (time.perf_counter() - tq0)
-                full["grad_sample"] = "as grad_evals_per_s.bench_workload (default A(T) MLP, k = 25 monthly snapshots, reltol 1e-8)"
-            aux["full_config_one_gpu"] = full
-            bf.close()
-            del bf, glf
-        except Exception as e:
-            aux["full_config_one_gpu"] = {"error": str(e)[:300]}
+    aux["weak_8_per_gpu"] = weak
 
     # ---- cross-checks: what a plain device copy / triad reaches on this box, and the
     #      PCIe-inclusive rate of the host-pointer seams (never part of `value`) ------------------
@@ -427,7 +426,7 @@ def main():
         for k in range(G):
             b.H(k)
         ms_d2h = (time.perf_counter() - tp0) * 1e3
-        ms_job = elapsed * 1e3
+        ms_job = elapsed * 1e3  # (rank 0's share of the job: its G glaciers, the timed steps)
         aux["pcie_dhdt_host_pointers_ms_per_call"] = ms_host
         aux["pcie_dhdt_host_pointers_cells_per_s"] = n * n / (ms_host * 1e-3)
         aux["pcie_upload_H0_B_ms"] = ms_h2d
@@ -452,36 +451,55 @@ def main():
             for k in range(G):
                 b.set_reference(k, ts, [gl[k][0] * (1.0 - 0.002 * j) for j in range(len(ts))], 3)
 
-            def timed(fn):
+            comm = odinn.api._DIST.get("comm") if world > 1 else None  # the library's RCCL communicator (None: one rank)
+            torch_reduce = world > 1 and comm is None  # only the explicit ODINN_BENCH_BACKEND=gloo dry run
+
+            def timed(continuous, theta):
+                # SIA2D_grad! == odinn_batch_loss_grad: this rank's forward solve + adjoint, then ONE ncclAllReduce of
+                # [n_failed, loss, dtheta] inside the library; every rank returns the global loss and gradient
+                def fn():
+                    L_, g_ = b.batch_loss_grad(comm, ts, theta=theta, continuous=continuous, reltol=1e-8)
+                    if torch_reduce:
+                        L_, g_ = odinn.allreduce_loss_grad(L_, g_)
+                    return L_, g_
+
                 fn()  # warm
                 barrier()
                 tg0 = time.perf_counter()
-                loss, dth = fn()
-                loss, dth = odinn.allreduce_loss_grad(loss, dth)
+                fn()
                 b.sync()
-                return time.perf_counter() - tg0
+                tg_ = time.perf_counter() - tg0
+                if dist is not None:
+                    tt_ = torch.tensor([tg_], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+                    tg_ = float(tt_.item())
+                return tg_
 
-            tg = timed(lambda: b.loss_grad(ts, theta=nn.theta, reltol=1e-8))
+            tg = timed(False, nn.theta)
             st = b.last_stats
-            tgc = timed(lambda: b.loss_grad_continuous(ts, theta=nn.theta, reltol=1e-8))
+            tgc = timed(True, nn.theta)
+            rev = b.last_stats_rev[0] if getattr(b, "last_stats_rev", None) else None
             grad["bench_workload"] = {
-                "discrete_adjoint": G * world / tg,
-                "continuous_adjoint": G * world / tgc,
-                "sample": f"{G} x {n}^2 glaciers per GPU, default A(T) MLP ({len(nn.theta)} params), k = 25 monthly thickness "
-                          f"snapshots over 2 yr, reltol 1e-8: {st[0].naccept}+{st[0].nreject} forward RK steps, 24 reverse-Euler "
+                "discrete_adjoint": G_job / tg,
+                "continuous_adjoint": G_job / tgc,
+                "allreduce": comm_note if world > 1 else "none (one rank: odinn_batch_loss_grad with comm = NULL)",
+                "comm_nranks": (comm.rank_size()[1] if comm is not None else 1),
+                "sample": f"the {G_job} x {n}^2 glaciers of the job ({G} on this rank), default A(T) MLP ({len(nn.theta)} params), k = 25 monthly "
+                          f"thickness snapshots over 2 yr, reltol 1e-8: {st[0].naccept}+{st[0].nreject} forward RK steps, 24 reverse-Euler "
                           f"VJP pairs (DiscreteAdjoint); ContinuousAdjoint defaults (reltol = abstol = 1e-8, dtmax = 1/12, 200 "
-                          f"Gauss-Legendre nodes): {b.last_stats_rev[0].naccept}+{b.last_stats_rev[0].nreject} reverse RK steps",
+                          f"Gauss-Legendre nodes)" + (f": {rev.naccept}+{rev.nreject} reverse RK steps" if rev else "")
+                          + "; one odinn_batch_loss_grad per evaluation (forward solve + adjoint + the all-reduce), max over ranks",
                 "ms_per_grad_eval_batch_discrete": tg * 1e3,
                 "ms_per_grad_eval_batch_continuous": tgc * 1e3,
             }
             # (i') the same with the headline's law: A = NN_theta(T) on the dual grid (2x16 MLP, 321 parameters; dtheta through
             #      the dual-grid accumulator and the wave-reduced backprop kernel)
             b.set_law(odinn.LAW_NN_A_GRIDDED, mlpA, thetaA)
-            tgg = timed(lambda: b.loss_grad(ts, theta=thetaA, reltol=1e-8))
-            tggc = timed(lambda: b.loss_grad_continuous(ts, theta=thetaA, reltol=1e-8))
+            tgg = timed(False, thetaA)
+            tggc = timed(True, thetaA)
             grad["bench_workload_gridded_law"] = {
-                "discrete_adjoint": G * world / tgg,
-                "continuous_adjoint": G * world / tggc,
+                "discrete_adjoint": G_job / tgg,
+                "continuous_adjoint": G_job / tggc,
                 "sample": f"as bench_workload, but A = NN_theta(T) gridded with the 2x16 MLP ({len(thetaA)} params) of the headline",
             }
             b.set_law(odinn.LAW_CONST_A)
@@ -527,7 +545,7 @@ def main():
             b.set_law(odinn.LAW_NN_Y, mlp16, np.random.default_rng(1234).uniform(-0.5, 0.5, mlp16.n_params))
             ms_nn = ev(T.TIMED_SOLVE_STEP, 3, 1)
             aux["nn_inlined_2x16_ms_per_step"] = ms_nn
-            aux["nn_inlined_2x16_cellsteps_per_s"] = 5.0 * cells * world / (ms_nn * 1e-3)
+            aux["nn_inlined_2x16_cellsteps_per_s"] = 5.0 * cells / (ms_nn * 1e-3)
             aux["nn_inlined_2x16_note"] = "LawY: Y = NN_theta(T, Hbar) evaluated per dual node inside the stencil (Laws.jl:258-265)"
             # its own roofline: fp64 vector pipe.  Flops per node evaluation as SURVEY section 7 counts them: 2 x (2*16 + 16*16
             # + 16) = 608 for the matrix-vector products + 33 activations (32 softplus = exp + log1p, 1 sigmoid) at 25 flop
@@ -552,7 +570,11 @@ def main():
 
             H0, B, A = gl[0]
             cores = CO.lib().oc_num_threads()
-            ms = CO.MultiStepper(cores, H0, B, 100.0, 100.0, O.Phys(), A)  # one glacier per host thread
+            # the SAME work as the GPU's timed steps: the hoisted law as a dual-grid A field read in every stage
+            # (A = minA + (maxA - minA) MLP(T), evaluated once on the host like the reference's LawA, Laws.jl:339-358)
+            omlp = O.MLP(list(mlpA.widths), list(mlpA.acts), None, O.POST_AFFINE, ph.minA, ph.maxA)
+            Afield = np.asfortranarray(O.mlp_eval(omlp, thetaA, temperature_field(H0, B)[None]))
+            ms = CO.MultiStepper(cores, H0, B, 100.0, 100.0, O.Phys(), Afield)  # one glacier per host thread
             ms.run(1, 1e-6)
             tc0 = time.perf_counter()
             nst = 0
@@ -562,7 +584,7 @@ def main():
             tc = time.perf_counter() - tc0
             # (i) of SURVEY 8(d): the same restatement on ONE host thread (bounded: ~3 s)
             CO.lib().oc_set_threads(1)
-            st1 = CO.Stepper(H0, B, 100.0, 100.0, O.Phys(), A)
+            st1 = CO.Stepper(H0, B, 100.0, 100.0, O.Phys(), Afield)
             st1.step(1e-6)
             t10 = time.perf_counter()
             n1 = 0
@@ -579,7 +601,8 @@ def main():
                 "value_1_thread": 5.0 * n * n * n1 / t1c,
                 "sample": f"{cores} copies of ONE {n}x{n} glacier of the workload, one host thread each "
                           f"(the reference's pmap-over-glaciers pattern), {nst} RDPK3Sp35 steps each, "
-                          f"oracle/sia2d_oracle.c (A scalar per glacier: the hoisted NN costs the CPU path nothing per step), {tc:.1f} s",
+                          f"oracle/sia2d_oracle.c with the gridded law hoisted into a dual-grid A field read in every stage, exactly the "
+                          f"GPU's timed work (R u,B,A  W u' + the 3S*+ registers), {tc:.1f} s",
                 "reference_note": "Julia reference not timed (toolchain absent): no julia binary in the image or on the GPU box; "
                                   "this is the C restatement of the same algorithm (oracle/), kind = port",
             }
@@ -588,20 +611,22 @@ def main():
                    "reference_note": "Julia reference not timed (toolchain absent)"}
 
     # ---- roofline of the dominant kernel: fp64 VALU, flops and HBM traffic from the committed PMC passes ----
-    pmc, pmc_src = {}, None
-    for pf in PMC_FILES:
-        try:
-            pm = json.load(open(pf))
-            if pm.get("workload_cells") == cells:
-                pmc, pmc_src = pm, os.path.relpath(pf, ROOT)
-                break
-        except Exception:
-            pass
+    pmc, pmc_src, pmc_scale = {}, None, 1.0
+    for exact in (True, False):  # a pass on exactly this workload first; otherwise the newest one, its per-launch bytes scaled by cells
+        for pf in PMC_FILES:
+            try:
+                pm = json.load(open(pf))
+                if pmc_src is None and (pm.get("workload_cells") == cells or (not exact and pm.get("workload_cells"))):
+                    pmc, pmc_src, pmc_scale = pm, os.path.relpath(pf, ROOT), cells / float(pm["workload_cells"])
+            except Exception:
+                pass
     kn = pmc.get("fused_step_nn_gridded", {})
     kc = pmc.get("fused_step_constA", {})
     fpcs_nn = kn.get("flop_per_executed_cell_stage", FLOP_PER_CELL_STAGE_FALLBACK)
     fpcs_c = kc.get("flop_per_executed_cell_stage", FLOP_PER_CELL_STAGE_FALLBACK)
     traffic = kn.get("hbm_bytes_per_launch")
+    if traffic:
+        traffic *= pmc_scale  # (per-cell figure of the committed pass x the cells of this launch when the batch differs)
     flops_useful = fpcs_nn * 5.0 * cells
     ach_tf = flops_useful / (ms_fused_nn * 1e-3) / 1e12
     big = hbm.get("kernels", {}) if isinstance(hbm, dict) else {}
@@ -617,18 +642,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{G} synthetic {n}x{n} fp64 ice caps per GPU (BASELINE configs[4] per-GPU share) with the configs[2] law "
+                "workload": f"BASELINE configs[4]: {G_job} synthetic {n}x{n} fp64 ice caps sharded over {world} GPU(s) ({G} on rank 0) with the configs[2] law "
                             "A = NN_theta(T) (2 hidden layers x 16 units, gridded T, hoisted once per theta as the reference's LawA); "
                             "one RDPK3Sp35 step (5 cell-steps per cell) = RK step kernel + controller, exactly odinn_solve's launch sequence for this batch "
                             "(the hoisted law itself: aux.law_field_ms once per solve, included in aux.full_solve)",
+                "glaciers": G_job,
                 "glaciers_per_gpu": G,
                 "grid": [n, n],
+                "cells": cells_job,
                 "cells_per_gpu": cells,
+                "hip_force_dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG") + " (set for this process by bench.py unless the "
+                                         "environment says otherwise; the ROCm 7.2 / gfx950 default -- DESIGN.md 'Launch latency')",
                 "parallelism": f"glacier-sharded x{world}, no data-path collective" + (
                     "" if world == 1 else f"; [loss, dtheta] all-reduce: {comm_note}"),
                 "schedule": {"forced_fields": {k: v for k, v in sched_in_effect.items() if v != -1},
@@ -679,7 +708,7 @@ def main():
                 "ms_per_launch": r_nn["ms"], "algorithmic_bytes_per_launch": B_PER_CELL_DHDT_NN * hbm["cells"],
                 "working_set": hbm["working_set_note"],
                 "traffic": pmc.get("dhdt_nn_gridded_32", {}).get("hbm_bytes_per_launch"),
-                "in_infinity_cache_8_glaciers_GBs": B_PER_CELL_DHDT_NN * cells / (ms_dhdt_nn * 1e-3) / 1e9,
+                "in_infinity_cache_8_glaciers_GBs": (weak or {}).get("dhdt_nn_gridded_in_cache_GBs"),
             } if r_nn else None),
             "roofline_per_stage": ({
                 "bound": "hbm",
@@ -691,13 +720,13 @@ def main():
             } if r_st else None),
             "roofline_adjoint": {
                 "bound": "fp64-valu",
-                "kernel": "k_adj_fused_strip<constant A, dense, 7 rows> (a whole RDPK3Sp35 step of the reverse ODE of the continuous adjoint: "
+                "kernel": "k_adj_fused_strip<constant A, dense, 7 rows> on rank 0's shard (a whole RDPK3Sp35 step of the reverse ODE of the continuous adjoint: "
                           "the reference's default gradient, gradient.jl:276-539)",
                 "ms_per_launch": ms_adjf,
                 "algorithmic_bytes_per_launch": 40.0 * cells,
                 "hbm_algorithmic_GBs": 40.0 * cells / (ms_adjf * 1e-3) / 1e9,
                 "hbm_algorithmic_frac_of_peak": 40.0 * cells / (ms_adjf * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": pmc.get("adj_fused_step_8", {}).get("hbm_bytes_per_launch"),
+                "traffic": (pmc.get("adj_fused_step_8", {}).get("hbm_bytes_per_launch") or 0.0) * pmc_scale or None,
                 "traffic_over_algorithmic": pmc.get("adj_fused_step_8", {}).get("ratio"),
                 "valu_busy_frac": pmc.get("adj_fused_step_8", {}).get("valu_busy_frac"),
                 "valu_insts_per_wave": pmc.get("adj_fused_step_8", {}).get("valu_insts_per_wave"),

@@ -104,6 +104,12 @@ class Comm:
         self.nranks, self.rank, self.device = nranks, rank, device
         L.check(L.lib().odinn_comm_init_rank(device, nranks, rank, C.c_char_p(uid), C.byref(self._h)))
 
+    def rank_size(self):
+        """(rank, nranks) of the communicator as the library reports them (odinn_comm_rank -> ncclCommUserRank / ncclCommCount)"""
+        r, n = C.c_int(-1), C.c_int(-1)
+        L.check(L.lib().odinn_comm_rank(self._h, C.byref(r), C.byref(n)))
+        return int(r.value), int(n.value)
+
     def allreduce_sum(self, a: np.ndarray) -> np.ndarray:
         buf = np.ascontiguousarray(a, dtype=np.float64).copy()
         L.check(L.lib().odinn_comm_allreduce_sum(self._h, _p(buf), buf.size))
@@ -455,6 +461,8 @@ class GlacierBatch:
             ts.size, _p(ts), mb.size, _p(mb) if mb.size else None, C.byref(o), C.byref(ao), C.byref(loss), _p(dth), st, sr))
         self.tstops = ts
         self.last_stats = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in st]
+        if continuous:
+            self.last_stats_rev = [SolveStats(s.naccept, s.nreject, s.nrhs, s.t_final, s.dt_last) for s in sr]
         return float(loss.value), dth
 
     def set_vjp_method(self, method=L.VJP_DISCRETE):

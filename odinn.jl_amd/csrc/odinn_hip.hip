@@ -3001,6 +3001,8 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;      // (optional: odinn_comm_rank falls back to the values of
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;   //  odinn_comm_init_rank when the library lacks them)
   std::string err;
 };
 static RcclApi* rccl() {
@@ -3024,6 +3026,8 @@ static RcclApi* rccl() {
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.handle, "ncclAllReduce"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+  api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.handle, "ncclCommCount"));
+  api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.handle, "ncclCommUserRank"));
   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetErrorString) {
     dlclose(api.handle);
     api.handle = nullptr;
@@ -3091,8 +3095,18 @@ int odinn_comm_destroy(odinn_comm* c) {
 
 int odinn_comm_rank(const odinn_comm* c, int* rank, int* nranks) {
   if (!c) return fail(ODINN_ERR_ARG, "null communicator");
-  if (rank) *rank = c->rank;
-  if (nranks) *nranks = c->nranks;
+  int r = c->rank, n = c->nranks;
+  // what RCCL itself says about the communicator (ncclCommUserRank / ncclCommCount), so that a caller reporting "N ranks"
+  // reports the group the all-reduce really runs over
+  RcclApi* R = rccl();
+  if (R && c->comm && R->CommCount && R->CommUserRank) {
+    NCCLCHK(R->CommCount(c->comm, &n));
+    NCCLCHK(R->CommUserRank(c->comm, &r));
+    if (n != c->nranks || r != c->rank)
+      return fail(ODINN_ERR_STATE, "communicator reports rank %d of %d, it was created as rank %d of %d", r, n, c->rank, c->nranks);
+  }
+  if (rank) *rank = r;
+  if (nranks) *nranks = n;
   return ODINN_OK;
 }
 

@@ -32,6 +32,12 @@ def lib():
                                            C.c_double, C.c_double, C.c_double, C.c_double, _dp]
         _lib.oc_multi_steps.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_dp), _dp, C.c_double, C.c_double,
                                         C.POINTER(OcPhys), C.c_double, C.c_double, C.POINTER(_dp)]
+        _lib.oc_sia2d_rhs_field.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double, C.POINTER(OcPhys), _dp, _dp, _dp]
+        _lib.oc_rdpk3sp35_step_field.restype = C.c_double
+        _lib.oc_rdpk3sp35_step_field.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_double, C.c_double, C.POINTER(OcPhys),
+                                                 _dp, C.c_double, C.c_double, C.c_double, _dp]
+        _lib.oc_multi_steps_field.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_dp), _dp, C.c_double, C.c_double,
+                                              C.POINTER(OcPhys), _dp, C.c_double, C.POINTER(_dp)]
         _lib.oc_vjp_H.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.POINTER(OcPhys),
                                   C.c_double, _dp, _dp]
     return _lib
@@ -46,12 +52,18 @@ def _phys(ph):
 
 
 def rhs(H, B, dx, dy, ph, A):
+    """A: scalar, or an (nx-1, ny-1) field on the dual grid (gridded LawA, hoisted)"""
     nx, ny = H.shape
     Hf, Bf = np.asfortranarray(H, dtype=np.float64), np.asfortranarray(B, dtype=np.float64)
     out = np.empty((nx, ny), order="F")
     work = np.empty(3 * nx * ny)
     p = _phys(ph)
-    lib().oc_sia2d_rhs(nx, ny, _p(Hf), _p(Bf), dx, dy, C.byref(p), A, _p(out), _p(work))
+    if np.ndim(A) == 2:
+        Af = np.asfortranarray(A, dtype=np.float64)
+        assert Af.shape == (nx - 1, ny - 1)
+        lib().oc_sia2d_rhs_field(nx, ny, _p(Hf), _p(Bf), dx, dy, C.byref(p), _p(Af), _p(out), _p(work))
+    else:
+        lib().oc_sia2d_rhs(nx, ny, _p(Hf), _p(Bf), dx, dy, C.byref(p), A, _p(out), _p(work))
     return out
 
 
@@ -73,10 +85,14 @@ class Stepper:
         self.u = np.asfortranarray(H0, dtype=np.float64).copy(order="F")
         self.B = np.asfortranarray(B, dtype=np.float64)
         self.dx, self.dy, self.A = dx, dy, A
+        self.Af = np.asfortranarray(A, dtype=np.float64) if np.ndim(A) == 2 else None  # dual-grid A field
         self.ph = _phys(ph)
         self.work = np.empty(7 * self.nx * self.ny)
 
     def step(self, dt, abstol=1e-6, reltol=1e-8):
+        if self.Af is not None:
+            return lib().oc_rdpk3sp35_step_field(self.nx, self.ny, _p(self.u), _p(self.B), self.dx, self.dy, C.byref(self.ph),
+                                                 _p(self.Af), dt, abstol, reltol, _p(self.work))
         return lib().oc_rdpk3sp35_step(self.nx, self.ny, _p(self.u), _p(self.B), self.dx, self.dy, C.byref(self.ph),
                                        self.A, dt, abstol, reltol, _p(self.work))
 
@@ -92,10 +108,15 @@ class MultiStepper:
         self.works = [np.empty(7 * self.nx * self.ny) for _ in range(G)]
         self.B = np.asfortranarray(B, dtype=np.float64)
         self.dx, self.dy, self.A = dx, dy, A
+        self.Af = np.asfortranarray(A, dtype=np.float64) if np.ndim(A) == 2 else None
         self.ph = _phys(ph)
         self._up = (_dp * G)(*[_p(u) for u in self.us])
         self._wp = (_dp * G)(*[_p(w) for w in self.works])
 
     def run(self, nsteps, dt):
+        if self.Af is not None:
+            lib().oc_multi_steps_field(self.G, nsteps, self.nx, self.ny, self._up, _p(self.B), self.dx, self.dy,
+                                       C.byref(self.ph), _p(self.Af), dt, self._wp)
+            return
         lib().oc_multi_steps(self.G, nsteps, self.nx, self.ny, self._up, _p(self.B), self.dx, self.dy,
                              C.byref(self.ph), self.A, dt, self._wp)

@@ -45,8 +45,10 @@ void oc_set_threads(int n) {
 }
 
 /* D on the dual grid (nx-1)*(ny-1); Hc = max(H,0), S = B+Hc are filled too (adjoint.jl:52-84) */
+/* Af != NULL: A on the dual grid (a gridded LawA hoisted once per theta, Laws.jl:339-358: A.value broadcasts against Hbar in
+ * target_A.jl:25-29), read per node instead of the scalar A */
 static void oc_diffusivity(int nx, int ny, const double* H, const double* B, double dx, double dy, const oc_phys* ph,
-                           double A, double* Hc, double* S, double* D) {
+                           double A0, const double* Af, double* Hc, double* S, double* D) {
   const double Gam = 2.0 * pow(ph->rho * ph->g, ph->n) / (ph->n + 2.0);
   const double Sc = ph->C * pow(ph->rho * ph->g, ph->p - ph->q);
   const int fast = (ph->n == 3.0 && Sc == 0.0);
@@ -66,6 +68,7 @@ static void oc_diffusivity(int nx, int ny, const double* H, const double* B, dou
       const double gy = 0.5 * ((S[a + nx] - S[a]) / dy + (S[a + nx + 1] - S[a + 1]) / dy);
       const double Hb = 0.25 * (Hc[a] + Hc[a + 1] + Hc[a + nx] + Hc[a + nx + 1]);
       const double g2 = gx * gx + gy * gy;
+      const double A = Af ? Af[i + (size_t)(nx - 1) * j] : A0;
       double d;
       if (fast) {
         const double h2 = Hb * Hb;
@@ -80,12 +83,12 @@ static void oc_diffusivity(int nx, int ny, const double* H, const double* B, dou
 }
 
 /* dH = SIA2D(H)  (Huginn.SIA2D!, restated from adjoint.jl:52-97).  work: 3*nx*ny doubles */
-void oc_sia2d_rhs(int nx, int ny, const double* H, const double* B, double dx, double dy, const oc_phys* ph, double A,
-                  double* dH, double* work) {
+static void oc_rhs_impl(int nx, int ny, const double* H, const double* B, double dx, double dy, const oc_phys* ph, double A,
+                        const double* Af, double* dH, double* work) {
   double* Hc = work;
   double* S = work + (size_t)nx * ny;
   double* D = work + 2 * (size_t)nx * ny;
-  oc_diffusivity(nx, ny, H, B, dx, dy, ph, A, Hc, S, D);
+  oc_diffusivity(nx, ny, H, B, dx, dy, ph, A, Af, Hc, S, D);
   const double e0 = ph->eta0;
   const int nd = nx - 1;
 #pragma omp parallel for schedule(static)
@@ -106,6 +109,16 @@ void oc_sia2d_rhs(int nx, int ny, const double* H, const double* B, double dx, d
     }
 }
 
+void oc_sia2d_rhs(int nx, int ny, const double* H, const double* B, double dx, double dy, const oc_phys* ph, double A,
+                  double* dH, double* work) {
+  oc_rhs_impl(nx, ny, H, B, dx, dy, ph, A, NULL, dH, work);
+}
+/* the same with A given on the dual grid ((nx-1)*(ny-1), element [i,j] at i + (nx-1)*j) */
+void oc_sia2d_rhs_field(int nx, int ny, const double* H, const double* B, double dx, double dy, const oc_phys* ph,
+                        const double* Afield, double* dH, double* work) {
+  oc_rhs_impl(nx, ny, H, B, dx, dy, ph, 0.0, Afield, dH, work);
+}
+
 /* RDPK3Sp35 (Ranocha et al. 2022), 3S*+ registers */
 static const double G1[5] = {0.0, 2.587771979725733308135192812685323706e-01, -1.324380360140723382965420909764953437e-01,
                              5.056033948190826045833606441415585735e-02, 5.670532000739313812633197158607642990e-01};
@@ -124,8 +137,8 @@ static const double BH[5] = {1.046363371354093758897668305991705199e-01, 9.52043
 
 /* one step u -> u (in place); returns the scaled RMS error estimate.
  * work: 7*nx*ny doubles (k, tmp, uprev, utilde + 3 for the RHS) */
-double oc_rdpk3sp35_step(int nx, int ny, double* u, const double* B, double dx, double dy, const oc_phys* ph, double A,
-                         double dt, double abstol, double reltol, double* work) {
+static double oc_step_impl(int nx, int ny, double* u, const double* B, double dx, double dy, const oc_phys* ph, double A,
+                           const double* Af, double dt, double abstol, double reltol, double* work) {
   const size_t N = (size_t)nx * ny;
   double* k = work;
   double* tmp = work + N;
@@ -134,14 +147,14 @@ double oc_rdpk3sp35_step(int nx, int ny, double* u, const double* B, double dx, 
   double* w2 = work + 4 * N;
   memcpy(up, u, N * sizeof(double));
   memcpy(tmp, u, N * sizeof(double));
-  oc_sia2d_rhs(nx, ny, u, B, dx, dy, ph, A, k, w2);
+  oc_rhs_impl(nx, ny, u, B, dx, dy, ph, A, Af, k, w2);
 #pragma omp parallel for schedule(static)
   for (size_t c = 0; c < N; ++c) {
     u[c] = tmp[c] + BT[0] * dt * k[c];
     ut[c] = BH[0] * dt * k[c];
   }
   for (int s = 1; s < 5; ++s) {
-    oc_sia2d_rhs(nx, ny, u, B, dx, dy, ph, A, k, w2);
+    oc_rhs_impl(nx, ny, u, B, dx, dy, ph, A, Af, k, w2);
 #pragma omp parallel for schedule(static)
     for (size_t c = 0; c < N; ++c) {
       tmp[c] = tmp[c] + DL[s] * u[c];
@@ -158,6 +171,14 @@ double oc_rdpk3sp35_step(int nx, int ny, double* u, const double* B, double dx, 
   }
   return sqrt(acc / (double)N);
 }
+double oc_rdpk3sp35_step(int nx, int ny, double* u, const double* B, double dx, double dy, const oc_phys* ph, double A,
+                         double dt, double abstol, double reltol, double* work) {
+  return oc_step_impl(nx, ny, u, B, dx, dy, ph, A, NULL, dt, abstol, reltol, work);
+}
+double oc_rdpk3sp35_step_field(int nx, int ny, double* u, const double* B, double dx, double dy, const oc_phys* ph,
+                               const double* Afield, double dt, double abstol, double reltol, double* work) {
+  return oc_step_impl(nx, ny, u, B, dx, dy, ph, 0.0, Afield, dt, abstol, reltol, work);
+}
 
 /* discrete H-VJP, written as the reference writes it: explicit scatter-style transposes on
  * full scratch arrays (adjoint.jl:99-148, inversion_utils.jl:3-66).  work: 14*nx*ny doubles */
@@ -170,7 +191,7 @@ void oc_vjp_H(int nx, int ny, const double* lam, const double* H, const double* 
   double* be = work + 6 * N;    double* Da = work + 7 * N;   double* Fxa = work + 8 * N;
   double* Fya = work + 9 * N;   double* exs = work + 10 * N; double* eys = work + 11 * N;
   double* T = work + 12 * N;    double* U = work + 13 * N;
-  oc_diffusivity(nx, ny, H, B, dx, dy, ph, A, Hc, S, D);
+  oc_diffusivity(nx, ny, H, B, dx, dy, ph, A, NULL, Hc, S, D);
   const double Gam = 2.0 * pow(ph->rho * ph->g, ph->n) / (ph->n + 2.0);
   const double Sc = ph->C * pow(ph->rho * ph->g, ph->p - ph->q);
   const double e0 = ph->eta0;
@@ -260,4 +281,12 @@ void oc_multi_steps(int G, int nsteps, int nx, int ny, double** u, const double*
 #pragma omp parallel for schedule(dynamic, 1)
   for (int g = 0; g < G; ++g)
     for (int s = 0; s < nsteps; ++s) oc_rdpk3sp35_step(nx, ny, u[g], B, dx, dy, ph, A, dt, 1e-6, 1e-8, work[g]);
+}
+/* the same with a dual-grid A field shared by the G copies (bench.py's cpu_baseline on the headline's workload: the GPU reads
+ * the hoisted A = NN_theta(T) field in every stage, +8 B per cell-stage, and so does this) */
+void oc_multi_steps_field(int G, int nsteps, int nx, int ny, double** u, const double* B, double dx, double dy,
+                          const oc_phys* ph, const double* Afield, double dt, double** work) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int g = 0; g < G; ++g)
+    for (int s = 0; s < nsteps; ++s) oc_step_impl(nx, ny, u[g], B, dx, dy, ph, 0.0, Afield, dt, 1e-6, 1e-8, work[g]);
 }
