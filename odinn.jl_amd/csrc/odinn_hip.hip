@@ -2225,7 +2225,7 @@ int odinn_surface_V_vjp_theta(odinn_batch* b, int g, const double* dVx, const do
   if (b->vel_nn()) {
     HIPCHK(hipMemcpyAsync(dtheta, b->d_dth + (size_t)g * b->P, sizeof(double) * b->P, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    return ODINN_OK;
+    return check_interp_bounds(b);  // (U law with `:Linear`: a node outside the gradient interpolant's grid)
   }
   double Gs = 0.0;
   HIPCHK(hipMemcpyAsync(&Gs, b->d_Gsum + g, sizeof(double), hipMemcpyDeviceToHost, b->stream));

@@ -686,6 +686,217 @@ __device__ __forceinline__ double mlp_eval_lm(const LawDev& L, double x0, double
   else return mlp_eval_any(L, x0, x1);
 }
 
+// ---- the network at x AND at x + delta e_d for a few tiny perturbations, for the price of ~1.5 evaluations ----------------
+// The reference forms dD/dHbar and dD/d|grad S| of the per-node-MLP laws by FINITE DIFFERENCES of the law (Y: one forward
+// difference with 1e-4, target_D_hybrid.jl:58-71; U: central differences with 1e-4 and 1e-6, target_D_pure.jl:105-137):
+// 2 resp. 5 network evaluations per dual node and stage, which is what bounds the reverse kernels of these laws (fp64
+// transcendentals: ~45 instructions per softplus).  The perturbed evaluations differ from the central one by |dz| ~ 1e-6 in
+// every pre-activation, so they are evaluated through the local Taylor expansion of each activation around the central
+// pre-activation,
+//     a(z + dz) - a(z) = dz (a1 + dz (a2 / 2 + dz (a3 / 6 + dz (a4 / 24 + dz a5 / 120)))),   ak = k-th derivative of a at z,
+// whose coefficients are polynomials of sigma(z) = 1 / (1 + exp(-z)) -- the same exponential the activation itself needs --
+// and the perturbation dz of the next layer is the exact linear map W da.  Truncation |dz|^6 / 720 < 1e-17 relative for
+// |dz| <= 2e-3, i.e. the perturbed VALUES are those of a direct evaluation to below its own rounding (the perturbation itself
+// carries a relative error of 1e-16, a direct evaluation an absolute one of 1e-16 |a|), and the finite differences formed
+// from them keep the reference's semantics including their truncation error.  A wavefront in which any |dz| exceeds 2e-3
+// (huge weights, no input scaling) evaluates the perturbed points directly.
+// CODE 1 softplus, 2 sigmoid.  c[k] = (k+1)-th derivative of the activation at z, divided by (k+1)!.
+template <int CODE>
+__device__ __forceinline__ double act_taylor(double z, double (&c)[5]) {
+  const double t = exp_nonpos(-fabs(z));
+  const double r = fast_div(1.0, 1.0 + t);
+  const bool pos = z >= 0.0;
+  const double tr = t * r;
+  const double s = pos ? r : tr;                     // sigma(z)
+  const double u = tr * r;                           // sigma (1 - sigma) = t / (1 + t)^2: no cancellation
+  const double m0 = (1.0 - t) * r;
+  const double m = pos ? -m0 : m0;                   // 1 - 2 sigma
+  const double um = u * m, q6 = fma(-6.0, u, 1.0), q12 = fma(-12.0, u, 1.0);
+  if (CODE == 1) {  // softplus: derivatives s, u, u m, u (1 - 6u), u m (1 - 12u)
+    c[0] = s; c[1] = 0.5 * u; c[2] = um * (1.0 / 6.0); c[3] = u * q6 * (1.0 / 24.0); c[4] = um * q12 * (1.0 / 120.0);
+    return log1p_01(t) + fmax(z, 0.0);
+  }
+  // sigmoid: derivatives u, u m, u (1 - 6u), u m (1 - 12u), u (1 - 30u + 120u^2)
+  c[0] = u; c[1] = 0.5 * um; c[2] = u * q6 * (1.0 / 6.0); c[3] = um * q12 * (1.0 / 24.0);
+  c[4] = u * fma(u, fma(120.0, u, -30.0), 1.0) * (1.0 / 120.0);
+  return s;
+}
+
+constexpr double PERT_DZ_MAX = 2e-3;
+// units between two scheduling fences: 1 = strictly one unit at a time (fewest registers, longest dependent chains),
+// 2-3 = that many exponentials in flight (the kernels run 2 waves per SIMD: some instruction-level parallelism is needed)
+// (per number of perturbations: the Y law's single perturbation leaves registers for more units in flight than the U law's four)
+#ifndef ODINN_PERT_Y
+#define ODINN_PERT_Y 1
+#endif
+#ifndef ODINN_PERT_GROUP1
+#define ODINN_PERT_GROUP1 5
+#endif
+#ifndef ODINN_PERT_GROUP4
+#define ODINN_PERT_GROUP4 2
+#endif
+#ifndef ODINN_PERT_INLINE
+#define ODINN_PERT_INLINE __forceinline__
+#endif
+
+// Scheduling fence of the perturbed evaluation: one unit at a time.  Left alone the scheduler interleaves all units of a
+// layer (every exponential in flight at once) and spills hundreds of registers.  The empty statement "rewrites" `next` --
+// a value the NEXT unit starts from -- together with what this unit produced last, so the next unit cannot begin before
+// this one is done; it emits nothing.
+template <int NP>
+__device__ __forceinline__ void pert_fence(double& next, double& a, double (&d)[NP]) {
+  if constexpr (NP == 4) asm volatile("" : "+v"(next), "+v"(a), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+  else if constexpr (NP == 1) asm volatile("" : "+v"(next), "+v"(a), "+v"(d[0]));
+  else asm volatile("" : "+v"(next), "+v"(a));
+}
+
+// One layer.  ZGIVEN: v / dv hold this layer's pre-activations (accumulated by the previous layer's push) and are overwritten
+// in place by the activations.  Otherwise v / dv hold the previous layer's activations and every unit PULLs its
+// pre-activation from them; its activation is then either STOREd (n / dn = this layer's activations) or, when the next
+// layer is not wider than this one, PUSHed into the next layer's pre-activation accumulators (n / dn, started from the
+// biases): the wide hidden layer of 2-3-10-3-1 never exists as a vector.  The order of the fused multiply-adds of every
+// pre-activation is bias first, then inputs ascending -- exactly mlp_layer_fixed's, so the central value is bit-identical.
+template <class AR, int l, int NP, bool ZGIVEN, bool PUSH>
+__device__ __forceinline__ void mlp_layer_pert(const double* __restrict__ th, double (&v)[AR::MAXW], double (&dv)[NP][AR::MAXW],
+                                               double (&n)[AR::MAXW], double (&dn)[NP][AR::MAXW], double& dzmax) {
+  constexpr int nin = AR::W[l], nout = AR::W[l + 1], off = arch_off<AR>(l);
+  static_assert(AR::A[l] == 1 || AR::A[l] == 2, "perturbed evaluation: softplus / sigmoid layers");
+  constexpr int nnext = PUSH ? AR::W[l + 2] : 0, offn = PUSH ? arch_off<AR>(l + 1) : 0;
+  if constexpr (PUSH) {
+#pragma unroll
+    for (int k = 0; k < nnext; ++k) {
+      n[k] = th[offn + nout * nnext + k];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) dn[q][k] = 0.0;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < nout; ++o) {
+    double z, dz[NP];
+    if constexpr (ZGIVEN) {
+      z = v[o];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) dz[q] = dv[q][o];
+    } else {
+      z = th[off + nin * nout + o];
+#pragma unroll
+      for (int i = 0; i < nin; ++i) z = fma(th[off + o + nout * i], v[i], z);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        dz[q] = 0.0;
+#pragma unroll
+        for (int i = 0; i < nin; ++i) dz[q] = fma(th[off + o + nout * i], dv[q][i], dz[q]);
+      }
+    }
+    double c[5];
+    double a = act_taylor<AR::A[l]>(z, c);
+    double da[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      dzmax = fmax(dzmax, fabs(dz[q]));
+      da[q] = dz[q] * fma(dz[q], fma(dz[q], fma(dz[q], fma(dz[q], c[4], c[3]), c[2]), c[1]), c[0]);
+    }
+    constexpr int grp = NP == 1 ? ODINN_PERT_GROUP1 : ODINN_PERT_GROUP4;
+    const bool fence = (o % grp) == grp - 1;  // (folded: the unit loop is fully unrolled)
+    if constexpr (ZGIVEN) {
+      if (fence) pert_fence<NP>(v[o + 1 < nout ? o + 1 : 0], a, da);
+      v[o] = a;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) dv[q][o] = da[q];
+    } else if constexpr (PUSH) {
+#pragma unroll
+      for (int k = 0; k < nnext; ++k) {
+        n[k] = fma(th[offn + k + nnext * o], a, n[k]);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dn[q][k] = fma(th[offn + k + nnext * o], da[q], dn[q][k]);
+      }
+      if (fence) {
+        double last[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) last[q] = dn[q][nnext - 1];
+        pert_fence<NP>(v[0], n[nnext - 1], last);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dn[q][nnext - 1] = last[q];
+      }
+    } else {
+      if (fence) pert_fence<NP>(v[0], a, da);
+      n[o] = a;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) dn[q][o] = da[q];
+    }
+  }
+}
+
+template <class AR>
+__device__ __noinline__ double mlp_eval_fixed_ni(const LawDev& L, double x0, double x1) { return mlp_eval_fixed<AR>(L, x0, x1); }
+
+// layers l .. NL-1; on entry (cur, dcur) hold pre-activations of layer l (ZGIVEN) or activations of layer l-1
+template <class AR, int l, int NP, bool ZGIVEN>
+__device__ __forceinline__ void mlp_pert_from(const double* __restrict__ th, double (&cur)[AR::MAXW], double (&dcur)[NP][AR::MAXW],
+                                              double (&oth)[AR::MAXW], double (&doth)[NP][AR::MAXW], double& dzmax, double& y,
+                                              double (&dy)[NP]) {
+  if constexpr (ZGIVEN) {  // in place; the next layer pulls from cur
+    mlp_layer_pert<AR, l, NP, true, false>(th, cur, dcur, oth, doth, dzmax);
+    if constexpr (l + 1 < AR::NL) mlp_pert_from<AR, l + 1, NP, false>(th, cur, dcur, oth, doth, dzmax, y, dy);
+    else {
+      y = cur[0];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) dy[q] = dcur[q][0];
+    }
+  } else if constexpr (l + 1 < AR::NL && AR::W[l + 2] <= AR::W[l + 1]) {  // push into the next layer's accumulators
+    mlp_layer_pert<AR, l, NP, false, true>(th, cur, dcur, oth, doth, dzmax);
+    mlp_pert_from<AR, l + 1, NP, true>(th, oth, doth, cur, dcur, dzmax, y, dy);
+  } else {  // store
+    mlp_layer_pert<AR, l, NP, false, false>(th, cur, dcur, oth, doth, dzmax);
+    if constexpr (l + 1 < AR::NL) mlp_pert_from<AR, l + 1, NP, false>(th, oth, doth, cur, dcur, dzmax, y, dy);
+    else {
+      y = oth[0];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) dy[q] = doth[q][0];
+    }
+  }
+}
+
+// y = net(x0, x1); yp[q] = net with input pd[q] shifted by dlt[q] (raw input units, before the pre-scaling)
+template <class AR, int NP>
+__device__ ODINN_PERT_INLINE double mlp_eval_pert(const LawDev& L, double x0, double x1, const int (&pd)[NP],
+                                                  const double (&dlt)[NP], double (&yp)[NP]) {
+  double h0[AR::MAXW], h1[AR::MAXW], d0[NP][AR::MAXW], d1[NP][AR::MAXW];
+  h0[0] = L.has_pre ? (x0 - L.pre_lo[0]) * L.pre_inv[0] - 0.5 : x0;
+  h0[1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    const double sc = L.has_pre ? L.pre_inv[pd[q]] : 1.0;
+    d0[q][0] = pd[q] == 0 ? dlt[q] * sc : 0.0;
+    d0[q][1] = pd[q] == 1 ? dlt[q] * sc : 0.0;
+  }
+  double dzmax = 0.0, y, dy[NP];
+  mlp_pert_from<AR, 0, NP, false>(L.theta, h0, d0, h1, d1, dzmax, y, dy);
+  if (__builtin_amdgcn_ballot_w64(dzmax > PERT_DZ_MAX) != 0) {  // wave-uniform; rare: evaluate the perturbed points directly
+#pragma unroll 1
+    for (int q = 0; q < NP; ++q)
+      yp[q] = mlp_eval_fixed_ni<AR>(L, pd[q] == 0 ? x0 + dlt[q] : x0, pd[q] == 1 ? x1 + dlt[q] : x1);
+  } else {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) yp[q] = postscale_f(L, y + dy[q]);
+  }
+  return postscale_f(L, y);
+}
+
+template <int LM, int NP>
+__device__ __forceinline__ double mlp_eval_pert_lm(const LawDev& L, double x0, double x1, const int (&pd)[NP],
+                                                   const double (&dlt)[NP], double (&yp)[NP]) {
+  if constexpr (LM == LM_NN_DEF) return mlp_eval_pert<ArchDef, NP>(L, x0, x1, pd, dlt, yp);
+  else if constexpr (LM == LM_NN_16) return mlp_eval_pert<Arch16, NP>(L, x0, x1, pd, dlt, yp);
+  else if constexpr (LM == LM_NN_LIGHT) return mlp_eval_pert<ArchLight, NP>(L, x0, x1, pd, dlt, yp);
+  else {  // run-time architecture (any activation): direct evaluations
+#pragma unroll 1
+    for (int q = 0; q < NP; ++q) yp[q] = mlp_eval_any(L, pd[q] == 0 ? x0 + dlt[q] : x0, pd[q] == 1 ? x1 + dlt[q] : x1);
+    return mlp_eval_any(L, x0, x1);
+  }
+}
+
+
 // ---- powers with a per-glacier (wave-uniform) exponent -----------------------------------------
 // The exponents of the diffusivity (n + 2, n - 1, p - q + 1, ... -- target_A.jl:25-61) are physical constants of a
 // glacier, in practice small integers (n = 3, p = 3, q = 0 or 1).  ocml's pow costs ~280 fp64 instructions; with a
@@ -756,7 +967,22 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
   // (every term carries a positive power of Hbar), so the MLP is not evaluated there.
   const bool ice = Hb > 0.0;
   if (L.kind == 3) {  // Y law, :D_hybrid
-    const double Y = ice ? mlp_eval_lm<LM>(L, g.T, Hb) : 0.0;
+    double Y = 0.0;
+    [[maybe_unused]] double Yp = 0.0;
+    if (ice) {
+      if constexpr (ADJ && !ODINN_PERT_Y) {
+        Y = mlp_eval_lm<LM>(L, g.T, Hb);
+        Yp = mlp_eval_lm<LM>(L, g.T, Hb + 1e-4);
+      } else if constexpr (ADJ) {  // Y(Hbar) and Y(Hbar + 1e-4) (the forward difference of target_D_hybrid.jl:58-71) in one pass
+        const int pd[1] = {1};
+        const double dl[1] = {1e-4};
+        double yp[1];
+        Y = mlp_eval_pert_lm<LM, 1>(L, g.T, Hb, pd, dl, yp);
+        Yp = yp[0];
+      } else {
+        Y = mlp_eval_lm<LM>(L, g.T, Hb);
+      }
+    }
     const double sS1 = spow(gS2, g.nS - 1.0);
     const double geo = g.Gam * upow(Hb, g.nH + 2.0) * sS1;
     double D = Y * geo;
@@ -768,7 +994,6 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
     }
     if (ADJ) {
       const double dH = 1e-4;  // target_D_hybrid.jl:58
-      const double Yp = ice ? mlp_eval_lm<LM>(L, g.T, Hb + dH) : 0.0;
       const double slide = g.Sc != 0.0 ? g.Sc * hs * sp1 : 0.0;
       alpha = (g.nH + 2.0) * Y * g.Gam * upow(Hb, g.nH + 1.0) * sS1 +
               ((slide + Yp * geo) - (slide + Y * geo)) / dH;
@@ -787,18 +1012,24 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
     return 0.0;
   }
   const double gS = sqrt(gS2);
-  const double U = mlp_eval_lm<LM>(L, Hb, gS);
-  if (ADJ) {
+  if constexpr (ADJ) {
     const double dH = 1e-4, dS = 1e-6;  // target_D_pure.jl:109,125
-    const double Dp = mlp_eval_lm<LM>(L, Hb + dH, gS) * (Hb + dH);
-    const double Dm = mlp_eval_lm<LM>(L, Hb - dH, gS) * (Hb - dH);
+    // U at the node and at the four points of the two central differences in one pass (mlp_eval_pert)
+    const int pd[4] = {0, 0, 1, 1};
+    const double dl[4] = {dH, -dH, dS, -dS};
+    double up[4];
+    const double U = mlp_eval_pert_lm<LM, 4>(L, Hb, gS, pd, dl, up);
+    const double Dp = up[0] * (Hb + dH);
+    const double Dm = up[1] * (Hb - dH);
     alpha = (Dp - Dm) / (2.0 * dH);
-    const double Ep = mlp_eval_lm<LM>(L, Hb, gS + dS) * Hb;
-    const double Em = mlp_eval_lm<LM>(L, Hb, gS - dS) * Hb;
+    const double Ep = up[2] * Hb;
+    const double Em = up[3] * Hb;
     beta = (Ep - Em) / (2.0 * dS);
     spat = Hb;
+    return Hb * U;
+  } else {
+    return Hb * mlp_eval_lm<LM>(L, Hb, gS);
   }
-  return Hb * U;
 }
 
 // ---- tile geometry -------------------------------------------------------------------
@@ -1581,6 +1812,17 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
   if (gi < 0 || gi > g.nx - 2 || gj < 0 || gj > g.ny - 2) return;
   const double2* p = &sHS[b][a];
   const double* pl = &sL[b][a];
+  double al, be, sp, Dnn = 0.0;
+  if constexpr (lm_is_nn(LM)) {
+    // per-node network: evaluate the law FIRST, from the node's thickness and slope alone, so that none of the node's other
+    // quantities (corner values, bounds, lambda differences) is live across the ~2000 instructions of the network; the
+    // corner values are read again from LDS afterwards (the memory clobber keeps the two sets of loads apart)
+    const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
+    const double gx = ((c10.y - c00.y) + (c11.y - c01.y)) * g.hinv_dx, gy = ((c01.y - c00.y) + (c11.y - c10.y)) * g.hinv_dy;
+    const double Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
+    Dnn = node_D<true, LM>(g, L, Hb, gx * gx + gy * gy, g.A, al, be, sp);
+    asm volatile("" ::: "memory");
+  }
   const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
   const double l00 = pl[0], l10 = pl[1], l01 = pl[LDW], l11 = pl[LDW + 1];
   const double dxl = c10.y - c00.y, dxu = c11.y - c01.y, dyl = c01.y - c00.y, dyr = c11.y - c10.y;
@@ -1593,10 +1835,14 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
   const double ax = fma(qxu, clampn(dxu, e11, e01), qxl * clampn(dxl, e10, e00));
   const double ay = fma(qyr, clampn(dyr, e11, e10), qyl * clampn(dyl, e01, e00));
   const double Da = -fma(g.hinv_dx2, ax, g.hinv_dy2 * ay);
-  double An = g.A;
-  if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
-  double al, be, sp;
-  const double D = node_D<true, LM>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
+  double D;
+  if constexpr (lm_is_nn(LM)) {
+    D = Dnn;
+  } else {
+    double An = g.A;
+    if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
+    D = node_D<true, LM>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
+  }
   // first term: avg^T(alpha Da) + dx^T(ay^T(beta gx Da))/dx + dy^T(ax^T(beta gy Da))/dy
   const double ad = 0.25 * al * Da, bd = be * Da;
   const double bx = g.hinv_dx * (bd * gx), by = g.hinv_dy * (bd * gy);
@@ -1944,20 +2190,25 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_
   double* __restrict__ S2 = A.S2;
   double* __restrict__ S3 = A.S3;
   double* __restrict__ E = A.E;
-  // the 3S*+ stream registers are fetched now so that their latency hides behind the stencil work
+  // the 3S*+ stream registers are fetched now so that their latency hides behind the stencil work (per-node network laws:
+  // AFTER it -- those kernels are bound by the network's arithmetic and 24 more live registers across it mean spills)
   double pup[RPT], ptm[RPT], pe[RPT];
+  auto fetch_streams = [&]() {
 #pragma unroll
-  for (int m = 0; m < RPT; ++m) {
-    const int gj = j0 + ty + NW * m;
-    pup[m] = ptm[m] = pe[m] = 0.0;
-    if (STAGE > 1 && gi < g.nx && gj < g.ny) {
-      const long long id = g.off + gi + (long long)g.nx * gj;
-      if (STAGE == 2 || STAGE >= 4) pup[m] = __builtin_nontemporal_load(&S3[id]);
-      if (STAGE != 2) ptm[m] = __builtin_nontemporal_load(&S2[id]);
-      pe[m] = __builtin_nontemporal_load(&E[id]);
+    for (int m = 0; m < RPT; ++m) {
+      const int gj = j0 + ty + NW * m;
+      pup[m] = ptm[m] = pe[m] = 0.0;
+      if (STAGE > 1 && gi < g.nx && gj < g.ny) {
+        const long long id = g.off + gi + (long long)g.nx * gj;
+        if (STAGE == 2 || STAGE >= 4) pup[m] = __builtin_nontemporal_load(&S3[id]);
+        if (STAGE != 2) ptm[m] = __builtin_nontemporal_load(&S2[id]);
+        pe[m] = __builtin_nontemporal_load(&E[id]);
+      }
     }
-  }
+  };
+  if constexpr (!lm_is_nn(LM)) fetch_streams();
   vjpH_tile_or_zero<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
+  if constexpr (lm_is_nn(LM)) fetch_streams();
   constexpr int s = STAGE - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
   double errsq = 0.0;
