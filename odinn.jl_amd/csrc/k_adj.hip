@@ -11,29 +11,36 @@
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 namespace odinn {
+// Compile-time architectures (law modes 3..5): one instantiation per law kind (NK = 3: Y law, 4: U law; see node_D); the other
+// law modes read the kind from the descriptor (NK = 0)
+#if ODINN_LM >= 3
+#define ODINN_NK_DISPATCH(CALL) { if (L.kind == 3) { constexpr int NK = 3; CALL; } else { constexpr int NK = 4; CALL; } }
+#else
+#define ODINN_NK_DISPATCH(CALL) { constexpr int NK = 0; CALL; }
+#endif
 // vj: 0 = DiscreteVJP stencil, 1 = ContinuousVJP stencil
 void CAT(launch_vjp_H_lm, ODINN_LM)(int mode, int vj, int nblk, hipStream_t st, Pools P, LawDev L, AdjArgs A, int base) {
   if (vj) {
-    if (mode == 0) hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM, 1>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
-    else hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM, 1>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+    if (mode == 0) ODINN_NK_DISPATCH(hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM, 1, NK>), dim3(nblk), dim3(NT), 0, st, P, L, A, base))
+    else ODINN_NK_DISPATCH(hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM, 1, NK>), dim3(nblk), dim3(NT), 0, st, P, L, A, base))
     return;
   }
-  if (mode == 0) hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
-  else hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM>), dim3(nblk), dim3(NT), 0, st, P, L, A, base);
+  if (mode == 0) ODINN_NK_DISPATCH(hipLaunchKernelGGL((k_vjp_H<0, ODINN_LM, 0, NK>), dim3(nblk), dim3(NT), 0, st, P, L, A, base))
+  else ODINN_NK_DISPATCH(hipLaunchKernelGGL((k_vjp_H<1, ODINN_LM, 0, NK>), dim3(nblk), dim3(NT), 0, st, P, L, A, base))
 }
-template <int VJ>
+template <int VJ, int NK>
 static void adj_stage_dispatch(int stage, int nblk, hipStream_t st, Pools P, LawDev L, AdjStageArgs A) {
   switch (stage) {
-    case 1: hipLaunchKernelGGL((k_adj_stage<1, ODINN_LM, VJ>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
-    case 2: hipLaunchKernelGGL((k_adj_stage<2, ODINN_LM, VJ>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
-    case 3: hipLaunchKernelGGL((k_adj_stage<3, ODINN_LM, VJ>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
-    case 4: hipLaunchKernelGGL((k_adj_stage<4, ODINN_LM, VJ>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
-    default: hipLaunchKernelGGL((k_adj_stage<5, ODINN_LM, VJ>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+    case 1: hipLaunchKernelGGL((k_adj_stage<1, ODINN_LM, VJ, NK>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+    case 2: hipLaunchKernelGGL((k_adj_stage<2, ODINN_LM, VJ, NK>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+    case 3: hipLaunchKernelGGL((k_adj_stage<3, ODINN_LM, VJ, NK>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+    case 4: hipLaunchKernelGGL((k_adj_stage<4, ODINN_LM, VJ, NK>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
+    default: hipLaunchKernelGGL((k_adj_stage<5, ODINN_LM, VJ, NK>), dim3(nblk), dim3(NT), 0, st, P, L, A); break;
   }
 }
 void CAT(launch_adj_stage_lm, ODINN_LM)(int stage, int vj, int nblk, hipStream_t st, Pools P, LawDev L, AdjStageArgs A) {
-  if (vj) { adj_stage_dispatch<1>(stage, nblk, st, P, L, A); return; }
-  adj_stage_dispatch<0>(stage, nblk, st, P, L, A);
+  if (vj) { ODINN_NK_DISPATCH((adj_stage_dispatch<1, NK>(stage, nblk, st, P, L, A))) return; }
+  ODINN_NK_DISPATCH((adj_stage_dispatch<0, NK>(stage, nblk, st, P, L, A)))
 }
 void CAT(launch_vjp_theta_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base) {
 #if ODINN_LM >= 3

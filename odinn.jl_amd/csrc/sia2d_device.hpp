@@ -727,7 +727,7 @@ constexpr double PERT_DZ_MAX = 2e-3;
 // 2-3 = that many exponentials in flight (the kernels run 2 waves per SIMD: some instruction-level parallelism is needed)
 // (per number of perturbations: the Y law's single perturbation leaves registers for more units in flight than the U law's four)
 #ifndef ODINN_PERT_Y
-#define ODINN_PERT_Y 1
+#define ODINN_PERT_Y 0
 #endif
 #ifndef ODINN_PERT_GROUP1
 #define ODINN_PERT_GROUP1 5
@@ -929,7 +929,10 @@ __device__ __forceinline__ double spow(double gS2, double e) {
 // "dD/dgradH", i.e. (dD/d|gradS|)/|gradS| for the closed forms) -- target_A.jl:16-62,
 // target_D_hybrid.jl:22-96,168-208, target_D_pure.jl:78-137 -- and `spat`, the spatial
 // factor of dD/dtheta (target_A.jl:71-72, target_D_hybrid.jl:117-118, target_D_pure.jl:142).
-template <bool ADJ, int LM>
+// NK: 0 = the law's kind is read from L (one kernel for both per-node-network laws), 3 / 4 = compile-time Y / U law -- the
+// reverse kernels are instantiated per law: the U law's four perturbations and the Y law's single one want different
+// register budgets, and in a shared kernel the allocation of the one spills the other
+template <bool ADJ, int LM, int NK = 0>
 __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double Hb, double gS2, double Anode,
                                          double& alpha, double& beta, double& spat) {
   if (!lm_is_nn(LM)) {  // A-type laws (scalar or field A)
@@ -966,22 +969,22 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
   // On ice-free nodes (Hbar == 0) D, alpha, beta and the theta-weight vanish identically
   // (every term carries a positive power of Hbar), so the MLP is not evaluated there.
   const bool ice = Hb > 0.0;
-  if (L.kind == 3) {  // Y law, :D_hybrid
-    double Y = 0.0;
-    [[maybe_unused]] double Yp = 0.0;
-    if (ice) {
-      if constexpr (ADJ && !ODINN_PERT_Y) {
-        Y = mlp_eval_lm<LM>(L, g.T, Hb);
-        Yp = mlp_eval_lm<LM>(L, g.T, Hb + 1e-4);
-      } else if constexpr (ADJ) {  // Y(Hbar) and Y(Hbar + 1e-4) (the forward difference of target_D_hybrid.jl:58-71) in one pass
+  if ((NK ? NK : L.kind) == 3) {  // Y law, :D_hybrid
+    // (the single forward-difference point of this law is evaluated directly: the perturbed evaluation -- see the U law below --
+    //  was measured at +5 ... +10 % on the Y law's reverse kernels, its Taylor coefficients cost what the second evaluation costs;
+    //  -DODINN_PERT_Y=1 selects it)
+    double Y, Yp_pert = 0.0;
+    if constexpr (ADJ && ODINN_PERT_Y) {
+      Y = 0.0;
+      if (ice) {
         const int pd[1] = {1};
         const double dl[1] = {1e-4};
         double yp[1];
         Y = mlp_eval_pert_lm<LM, 1>(L, g.T, Hb, pd, dl, yp);
-        Yp = yp[0];
-      } else {
-        Y = mlp_eval_lm<LM>(L, g.T, Hb);
+        Yp_pert = yp[0];
       }
+    } else {
+      Y = ice ? mlp_eval_lm<LM>(L, g.T, Hb) : 0.0;
     }
     const double sS1 = spow(gS2, g.nS - 1.0);
     const double geo = g.Gam * upow(Hb, g.nH + 2.0) * sS1;
@@ -994,6 +997,9 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
     }
     if (ADJ) {
       const double dH = 1e-4;  // target_D_hybrid.jl:58
+      double Yp;
+      if constexpr (ODINN_PERT_Y) Yp = Yp_pert;
+      else Yp = ice ? mlp_eval_lm<LM>(L, g.T, Hb + dH) : 0.0;
       const double slide = g.Sc != 0.0 ? g.Sc * hs * sp1 : 0.0;
       alpha = (g.nH + 2.0) * Y * g.Gam * upow(Hb, g.nH + 1.0) * sS1 +
               ((slide + Yp * geo) - (slide + Y * geo)) / dH;
@@ -1804,7 +1810,7 @@ struct AdjArgs {
 // cells {SW, SE, NW, NE} -- the diffusivity term (adjoint.jl:123-127) AND its share D_node of the
 // clamp/flux term of its four edges (adjoint.jl:130-144, inversion_utils.jl:22-43); the clamped
 // slopes and their bounds are already at hand from D_adjoint (adjoint.jl:99-104).
-template <int LM>
+template <int LM, int NK = 0>
 __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const Pools& P, const double2 (*sHS)[LDW],
                                           const double (*sL)[LDW], int i0, int j0, int a, int b, double (&k)[4]) {
   const int gi = i0 - 1 + a, gj = j0 - 1 + b;
@@ -1813,14 +1819,15 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
   const double2* p = &sHS[b][a];
   const double* pl = &sL[b][a];
   double al, be, sp, Dnn = 0.0;
-  if constexpr (lm_is_nn(LM)) {
+  constexpr bool LAW_FIRST = lm_is_nn(LM) && NK == 4;  // (measured: pays for the U law's five-point evaluation, costs the Y law 18 %)
+  if constexpr (LAW_FIRST) {
     // per-node network: evaluate the law FIRST, from the node's thickness and slope alone, so that none of the node's other
     // quantities (corner values, bounds, lambda differences) is live across the ~2000 instructions of the network; the
     // corner values are read again from LDS afterwards (the memory clobber keeps the two sets of loads apart)
     const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
     const double gx = ((c10.y - c00.y) + (c11.y - c01.y)) * g.hinv_dx, gy = ((c01.y - c00.y) + (c11.y - c10.y)) * g.hinv_dy;
     const double Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
-    Dnn = node_D<true, LM>(g, L, Hb, gx * gx + gy * gy, g.A, al, be, sp);
+    Dnn = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, g.A, al, be, sp);
     asm volatile("" ::: "memory");
   }
   const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
@@ -1836,12 +1843,12 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
   const double ay = fma(qyr, clampn(dyr, e11, e10), qyl * clampn(dyl, e01, e00));
   const double Da = -fma(g.hinv_dx2, ax, g.hinv_dy2 * ay);
   double D;
-  if constexpr (lm_is_nn(LM)) {
+  if constexpr (LAW_FIRST) {
     D = Dnn;
   } else {
     double An = g.A;
     if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
-    D = node_D<true, LM>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
+    D = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
   }
   // first term: avg^T(alpha Da) + dx^T(ay^T(beta gx Da))/dx + dy^T(ax^T(beta gy Da))/dy
   const double ad = 0.25 * al * Da, bd = be * Da;
@@ -1888,7 +1895,7 @@ struct VjpHLds {
 // on the interior, q = <grad S, grad lam> on the dual grid (:534-538), slopes unclamped, lambda raw.
 // The divergence terms are linear in the node's D, q beta gS: k[c] is what the node adds to corner
 // cell c; the product term needs the corner sums of alpha and q separately (a4 = alpha/4, q4 = q/4).
-template <int LM>
+template <int LM, int NK = 0>
 __device__ __forceinline__ void vjpHc_node(const GDev& g, const LawDev& L, const Pools& P, const double2 (*sHS)[LDW],
                                            const double (*sL)[LDW], int i0, int j0, int a, int b, double (&k)[4],
                                            double& a4, double& q4) {
@@ -1906,7 +1913,7 @@ __device__ __forceinline__ void vjpHc_node(const GDev& g, const LawDev& L, const
   double An = g.A;
   if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
   double al, be, sp;
-  const double D = node_D<true, LM>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
+  const double D = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
   const double mxl = l10 - l00, mxu = l11 - l01, myl = l01 - l00, myr = l11 - l10;
   const double q = fma(g.hinv_dx2, fma(dxu, mxu, dxl * mxl), g.hinv_dy2 * fma(dyr, myr, dyl * myl));
   const double wx = D * g.hinv_dx2, wy = D * g.hinv_dy2;
@@ -1922,7 +1929,7 @@ __device__ __forceinline__ void vjpHc_node(const GDev& g, const LawDev& L, const
 // v[m] = (J_H(H)^T lam)[cell m of this thread] from tiles already in LDS (and synchronised).
 // Phase A: every thread evaluates its (up to 5) nodes; phase B: every cell adds the four numbers
 // its corner nodes left for it, masked by H > 0 (adjoint.jl:148).
-template <int LM, int VJ = 0>
+template <int LM, int VJ = 0, int NK = 0>
 __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const Pools& P, double2* smem, int i0,
                                           int j0, const double (&ownH)[RPT], double (&v)[RPT]) {
   using S = VjpHLds<LM, VJ>;
@@ -1940,8 +1947,8 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
     if constexpr (S::ALIAS) {  // closed-form A laws: the node results are staged in registers, their LDS aliases the tiles
       double kk[RPT + 1][4], aa[RPT + 1], qq[RPT + 1];
 #pragma unroll
-      for (int m = 0; m < RPT; ++m) vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m], aa[m], qq[m]);
-      if (extra) vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT], aa[RPT], qq[RPT]);
+      for (int m = 0; m < RPT; ++m) vjpHc_node<LM, NK>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m], aa[m], qq[m]);
+      if (extra) vjpHc_node<LM, NK>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT], aa[RPT], qq[RPT]);
       __syncthreads();
 #pragma unroll
       for (int m = 0; m < RPT; ++m) {
@@ -1960,7 +1967,7 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
         const int a = m < RPT ? tx : ea, b = m < RPT ? ty + NW * m : eb;
         if (m < RPT || extra) {
           double k[4], a4, q4;
-          vjpHc_node<LM>(g, L, P, sHS, sL, i0, j0, a, b, k, a4, q4);
+          vjpHc_node<LM, NK>(g, L, P, sHS, sL, i0, j0, a, b, k, a4, q4);
           sCa[b][a] = make_double2(k[0], k[1]);
           sCb[b][a] = make_double2(k[2], k[3]);
           sCc[b][a] = make_double2(a4, q4);
@@ -1985,8 +1992,8 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
   if constexpr (S::ALIAS) {
     double kk[RPT + 1][4];
 #pragma unroll
-    for (int m = 0; m < RPT; ++m) vjpH_node<LM>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m]);
-    if (extra) vjpH_node<LM>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT]);
+    for (int m = 0; m < RPT; ++m) vjpH_node<LM, NK>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m]);
+    if (extra) vjpH_node<LM, NK>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT]);
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < RPT; ++m) {
@@ -2003,7 +2010,7 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
       const int a = m < RPT ? tx : ea, b = m < RPT ? ty + NW * m : eb;
       if (m < RPT || extra) {
         double k[4];
-        vjpH_node<LM>(g, L, P, sHS, sL, i0, j0, a, b, k);
+        vjpH_node<LM, NK>(g, L, P, sHS, sL, i0, j0, a, b, k);
         sCa[b][a] = make_double2(k[0], k[1]);
         sCb[b][a] = make_double2(k[2], k[3]);
       }
@@ -2023,7 +2030,7 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
 // Barrier (the tiles are complete) + vjpH_tile, or the exact shortcut v = 0 when no own cell of the
 // tile carries ice (DiscreteVJP only: its result is masked by the cell's own H > 0).  Returns whether
 // the stencil ran.
-template <int LM, int VJ>
+template <int LM, int VJ, int NK = 0>
 __device__ __forceinline__ bool vjpH_tile_or_zero(const GDev& g, const LawDev& L, const Pools& P, double2* smem, int i0,
                                                   int j0, const double (&ownH)[RPT], double (&v)[RPT]) {
   if constexpr (VJ == 0 && !lm_is_nn(LM)) {  // (a conditional stencil makes the MLP variants spill, see tile_has_ice)
@@ -2038,11 +2045,11 @@ __device__ __forceinline__ bool vjpH_tile_or_zero(const GDev& g, const LawDev& L
   } else {
     __syncthreads();
   }
-  vjpH_tile<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
+  vjpH_tile<LM, VJ, NK>(g, L, P, smem, i0, j0, ownH, v);
   return true;
 }
 
-template <int MODE, int LM, int VJ = 0>
+template <int MODE, int LM, int VJ = 0, int NK = 0>
 __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
   __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
   __shared__ double red[NW];
@@ -2103,7 +2110,7 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_
   }
   // DiscreteVJP: the result is masked by H > 0 of the cell itself (adjoint.jl:148), so a tile whose own
   // cells are all ice-free yields exactly 0 whatever its nodes would contribute: skip the stencil
-  vjpH_tile_or_zero<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
+  vjpH_tile_or_zero<LM, VJ, NK>(g, L, P, smem, i0, j0, ownH, v);
   const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
   double lsum = 0.0;
 #pragma unroll
@@ -2165,7 +2172,7 @@ struct AdjFusedArgs {
 };
 
 
-template <int STAGE, int LM, int VJ = 0>
+template <int STAGE, int LM, int VJ = 0, int NK = 0>
 __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_stage(Pools P, LawDev L, AdjStageArgs A) {
   __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
   __shared__ double red[NW];
@@ -2190,8 +2197,8 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_
   double* __restrict__ S2 = A.S2;
   double* __restrict__ S3 = A.S3;
   double* __restrict__ E = A.E;
-  // the 3S*+ stream registers are fetched now so that their latency hides behind the stencil work (per-node network laws:
-  // AFTER it -- those kernels are bound by the network's arithmetic and 24 more live registers across it mean spills)
+  // the 3S*+ stream registers are fetched now so that their latency hides behind the stencil work (the U law's kernels:
+  // AFTER it -- they are bound by the network's arithmetic and 24 more live registers across it mean spills)
   double pup[RPT], ptm[RPT], pe[RPT];
   auto fetch_streams = [&]() {
 #pragma unroll
@@ -2206,9 +2213,9 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_
       }
     }
   };
-  if constexpr (!lm_is_nn(LM)) fetch_streams();
-  vjpH_tile_or_zero<LM, VJ>(g, L, P, smem, i0, j0, ownH, v);
-  if constexpr (lm_is_nn(LM)) fetch_streams();
+  if constexpr (NK != 4) fetch_streams();
+  vjpH_tile_or_zero<LM, VJ, NK>(g, L, P, smem, i0, j0, ownH, v);
+  if constexpr (NK == 4) fetch_streams();
   constexpr int s = STAGE - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
   double errsq = 0.0;
