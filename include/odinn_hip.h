@@ -167,9 +167,7 @@ typedef struct odinn_schedule {
   int32_t adj_segs;        /* ODINN_ADJ_SEGS: 0 = read the two snapshots instead of the interleaved {H_j, H_j+1 - H_j} pairs       */
   int32_t adj_rows;        /* ODINN_ADJ_ROWS: 4 | 7 rows per thread of the fused reverse step                                      */
   int32_t adj_theta_fused; /* ODINN_ADJ_THETA_FUSED: 0 = theta-VJP of a quadrature node in launches of its own                     */
-  int32_t interp_select;   /* ODINN_INTERP_SELECT: 0 = sort every dual node by Hbar for the `:Linear` interpolation of the Y law
-                              instead of the selection path (histogram + the <= 2 n_interp_half order statistics, no sort)          */
-  int32_t reserved[4];     /* zero                                                                                                 */
+  int32_t reserved[5];     /* zero                                                                                                 */
 } odinn_schedule;
 
 typedef struct odinn_batch odinn_batch;

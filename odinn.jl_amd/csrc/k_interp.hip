@@ -16,6 +16,7 @@
 // (launch_interp_theta_batch below); the per-glacier sequence remains for the U law and as the A/B reference.
 #include <algorithm>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include "launch.hpp"
 #include <rocprim/rocprim.hpp>
@@ -168,9 +169,9 @@ __global__ __launch_bounds__(NT) void k_interval_sums_b(Pools P, int g0, int g_l
 }
 
 // ---- the whole batch in one sequence of launches --------------------------------------------------------------------
-// One radix sort of ALL dual nodes of the glaciers [g0, g0 + ng) by Hbar (values: node index), one stable radix sort of
-// the result by glacier (the few bits of the glacier index): every glacier's nodes, sorted by Hbar, at its own pooled
-// offset again.  Then knots and interval sums with one block row per glacier, and the contraction with the knot gradients
+// ONE radix sort of ALL dual nodes of the glaciers [g0, g0 + ng) by the composite key (glacier, Hbar) (k_interp_keys; values:
+// node index): every glacier's nodes, sorted by Hbar, at its own pooled offset again.  (Round 3 sorted by Hbar and then
+// stably by glacier: 10 instead of 7 sort passes and a third more of rocPRIM's memsets.)  Then knots and interval sums with one block row per glacier, and the contraction with the knot gradients
 // as ONE wave-reduced backprop per glacier whose lane weights are the knot coefficients c_k (dtheta = sum_k c_k dY/dtheta
 // (T, knot_k) is the gradient of sum_k c_k Y(T, knot_k)): ~20 launches per evaluation whatever the number of glaciers,
 // instead of 23 per glacier.
@@ -386,12 +387,31 @@ static bool interp_law_is(const LawDev& L) {
   return true;
 }
 size_t interp_batch_temp_bytes(long long n_max) {
-  size_t b1 = 0, b2 = 0;
+  size_t b1 = 0, b2 = 0, b3 = 0;
   (void)rocprim::radix_sort_pairs(nullptr, b1, (const double*)nullptr, (double*)nullptr, (const unsigned*)nullptr, (unsigned*)nullptr,
                                   (size_t)n_max, 0, 64, nullptr);
   (void)rocprim::radix_sort_pairs(nullptr, b2, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr,
                                   (unsigned*)nullptr, (size_t)n_max, 0, 32, nullptr);
-  return b1 > b2 ? b1 : b2;
+  (void)rocprim::radix_sort_pairs(nullptr, b3, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                  (const unsigned*)nullptr, (unsigned*)nullptr, (size_t)n_max, 0, 64, nullptr);
+  return std::max(b1, std::max(b2, b3));
+}
+// composite sort key of a dual node: glacier index (relative to g0) in the top gbits bits, below it the bit pattern of
+// Hbar * 2^-e.  Positive doubles order like their patterns, and multiplying by a power of two is EXACT (the mantissa is
+// untouched) as long as the result stays normal: e is chosen so that every thickness below 2^15 m lands in the lowest
+// 2^(12 - gbits) binades, i.e. its pattern leaves the top gbits bits free.  ONE radix sort then leaves every glacier's nodes
+// in exact Hbar order at the glacier's pooled offset.  With gbits <= 6 (64 glaciers per call) the exact range reaches down to
+// 2^-48 m = 3.6e-15 m; thinner ice (the subnormal thicknesses an advancing margin leaves) keeps its order up to the rounding
+// of the scaled value and stays behind the exact zeros.  More than 128 glaciers per call sort twice (by Hbar, then by glacier).
+constexpr int INTERP_KEY_GBITS_MAX = 7;
+__global__ void k_interp_keys(const unsigned* __restrict__ gid, const double* __restrict__ H, long long n, unsigned g0, int gbits,
+                              double scale, unsigned long long* __restrict__ keys) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double h = fmin(fmax(H[i], 0.0), 32767.0);
+    unsigned long long low = (unsigned long long)__double_as_longlong(h * scale);
+    if (h > 0.0 && !low) low = 1;  // (underflow to zero: still behind the exact zeros)
+    keys[i] = gbits ? (((unsigned long long)(gid[i] - g0) << (64 - gbits)) | low) : low;
+  }
 }
 void launch_fill_gid(hipStream_t st, Pools P, int G, long long ntotd, unsigned* gid, unsigned* iota) {
   hipLaunchKernelGGL(k_fill_gid, dim3(1024), dim3(256), 0, st, P, G, ntotd, gid, iota);
@@ -405,347 +425,27 @@ int launch_interp_theta_batch(hipStream_t st, Pools P, const LawDev& L, int n_ha
                               double* knots, int* M, double* ab, double* dth, int accumulate) {
   if (2 * n_half > KMAX || n_half < 2 || n >= (1ll << 32)) return 1;
   const unsigned nb = (unsigned)std::min<long long>((n + 255) / 256, 4096);
-  if (rocprim::radix_sort_pairs(tmp, tmp_bytes, nodeH + lo, sH, iota, iA, (size_t)n, 0, 64, st) != hipSuccess) return 2;
   const unsigned* order = iA;
-  if (ng > 1) {
-    int bits = 1;
-    while ((1ll << bits) < (long long)(g0 + ng)) ++bits;
+  int bits = 0;
+  while ((1ll << bits) < (long long)ng) ++bits;
+  if (bits <= INTERP_KEY_GBITS_MAX) {
+    // one sort by (glacier, Hbar): the keys live in sH / sV, which k_gather_HV fills only afterwards
+    unsigned long long* kin = reinterpret_cast<unsigned long long*>(sH);
+    unsigned long long* kout = reinterpret_cast<unsigned long long*>(sV);
+    const double scale = bits ? std::ldexp(1.0, -(1023 - (1 << (12 - bits)) + 15)) : 1.0;
+    hipLaunchKernelGGL(k_interp_keys, dim3(nb), dim3(256), 0, st, gid + lo, nodeH + lo, n, (unsigned)g0, bits, scale, kin);
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, iota, iA, (size_t)n, 0, 64, st) != hipSuccess) return 2;
+  } else {  // (thousands of glaciers in one call: sort by Hbar, then stably by glacier)
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, nodeH + lo, sH, iota, iA, (size_t)n, 0, 64, st) != hipSuccess) return 2;
+    int gb = 1;
+    while ((1ll << gb) < (long long)(g0 + ng)) ++gb;
     hipLaunchKernelGGL(k_gather_gid, dim3(nb), dim3(256), 0, st, gid + lo, iA, n, kA);
-    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, kA, kB, iA, iB, (size_t)n, 0, bits, st) != hipSuccess) return 2;
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, kA, kB, iA, iB, (size_t)n, 0, gb, st) != hipSuccess) return 2;
     order = iB;
   }
   hipLaunchKernelGGL(k_gather_HV, dim3(nb), dim3(256), 0, st, nodeH + lo, nodeV + lo, order, n, sH, sV);
   hipLaunchKernelGGL(k_knots_b, dim3(ng), dim3(KMAX), 0, st, P, g0, g0 + ng - 1, lo, lo + n, sH, n_half, knots, M);
   hipLaunchKernelGGL(k_interval_sums_b, dim3(2 * n_half, ng), dim3(NT), 0, st, P, g0, g0 + ng - 1, lo, lo + n, sH, sV, knots, M, ab);
-  const size_t dyn = interp_batch_lds_bytes(L.P);
-  if (interp_law_is<ArchDef>(L))
-    hipLaunchKernelGGL((k_knot_backprop<ArchDef, true>), dim3(ng), dim3(NT), dyn, st, P, L, g0, knots, M, ab, dth, accumulate);
-  else if (interp_law_is<Arch16>(L))
-    hipLaunchKernelGGL((k_knot_backprop<Arch16, true>), dim3(ng), dim3(NT), dyn, st, P, L, g0, knots, M, ab, dth, accumulate);
-  else
-    hipLaunchKernelGGL((k_knot_backprop<ArchRT, false>), dim3(ng), dim3(NT), dyn, st, P, L, g0, knots, M, ab, dth, accumulate);
-  return 0;
-}
-
-// ---- the same contraction WITHOUT sorting the nodes (odinn_schedule.interp_select, the default for the Y law) ---------------------
-// The sort served two purposes: the type-7 quantiles of Hbar need <= 2 n_interp_half order statistics, and in Hbar order every
-// knot interval is a contiguous range.  Neither needs the other 10^6 nodes in order:
-//   1. k_sel_max:     per glacier max(Hbar) (integer atomicMax on the bit pattern: positive doubles order like their bits);
-//   2. k_sel_hist:    histogram of the entries strictly inside (0, max) over SEL_NB equal-width bins (integer atomics);
-//   3. k_sel_plan:    one workgroup per glacier: prefix sums of the histogram, the bin and the rank-within-bin of each of the
-//                     <= 2 n order statistics, and a slot range in a candidate buffer for every bin that holds one;
-//   4. k_sel_gather:  the values of the needed bins into their slot ranges (the order inside a range is whatever the atomics
-//                     produce -- the next step sorts it away);
-//   5. k_sel_knots:   bitonic sort of the <= SEL_CAP candidates in LDS (bins are value ranges and the ranges are laid out in bin
-//                     order, so after the sort every range holds ITS values ascending), the quantiles, the uniform knots, the
-//                     sorted-unique union -- from there on exactly knots_body;
-//   6. k_sel_sums:    every node finds its knot interval by bisection and its two weights; the 64 contributions of a wavefront
-//                     are summed interval by interval (wave reductions in a fixed order), the wavefronts' and workgroups' partial
-//                     sums in a fixed order: no floating-point atomics, bitwise reproducible;
-//   7. k_knot_backprop as before.
-// 7 launches and one memset per evaluation whatever the number of glaciers, instead of two radix sorts (14 launches, 24 memsets of
-// rocPRIM's) + gathers: the continuous adjoint evaluates this at each of its 200 quadrature nodes.  A glacier whose needed bins
-// hold more than SEL_CAP values (a plateau of equal thickness) raises sel_flag: the caller repeats the evaluation on the sort path.
-constexpr int SEL_NB = 65536, SEL_CAP = 4096, SEL_BLK = 32;  // bins, candidates per glacier, workgroups per glacier in pass 6
-// per-glacier int block: [0..1] max(Hbar) bits, [2] candidates in use, [3] unused, then hist[SEL_NB] (becomes the bins' fill cursor)
-constexpr int SEL_ISTRIDE = 4 + SEL_NB;
-
-__device__ __forceinline__ int sel_bin(double h, double scale) {
-  const int b = (int)(h * scale);
-  return b > SEL_NB - 1 ? SEL_NB - 1 : b;
-}
-__device__ __forceinline__ double sel_amax(const int* __restrict__ ib) {
-  return __longlong_as_double(*reinterpret_cast<const long long*>(ib));
-}
-
-__global__ __launch_bounds__(256) void k_sel_max(Pools P, int g0, int g_last, long long lo, long long end_all,
-                                                 const double* __restrict__ nodeH, int* __restrict__ ibuf) {
-  const int gidx = g0 + blockIdx.y;
-  const long long off = P.gd[gidx].offd, n = seg_len(P, gidx, g_last, end_all);
-  double m = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) m = fmax(m, nodeH[off + i]);
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.0)
-    atomicMax(reinterpret_cast<unsigned long long*>(ibuf + (size_t)blockIdx.y * SEL_ISTRIDE), (unsigned long long)__double_as_longlong(m));
-}
-
-__global__ __launch_bounds__(256) void k_sel_hist(Pools P, int g0, int g_last, long long lo, long long end_all,
-                                                  const double* __restrict__ nodeH, int* __restrict__ ibuf) {
-  const int gidx = g0 + blockIdx.y;
-  int* ib = ibuf + (size_t)blockIdx.y * SEL_ISTRIDE;
-  const double amax = sel_amax(ib);
-  if (!(amax > 0.0)) return;
-  const double scale = (double)SEL_NB / amax;
-  const long long off = P.gd[gidx].offd, n = seg_len(P, gidx, g_last, end_all);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const double h = nodeH[off + i];
-    if (h > 0.0 && h < amax) atomicAdd(ib + 4 + sel_bin(h, scale), 1);
-  }
-}
-
-// quantile i (0-based, i < n) of a glacier: the two order statistics it interpolates between, as positions in the candidate
-// buffer, and the interpolation weight (quantile(...; type 7) as knots_body computes it)
-struct SelQ { int posA, posB; double gam; };
-
-__global__ __launch_bounds__(KMAX) void k_sel_plan(int n, int* __restrict__ ibuf, int* __restrict__ slot0, SelQ* __restrict__ qs,
-                                                   int* __restrict__ flag) {
-  // slot0[bin]: first candidate slot of a needed bin, -1 otherwise
-  __shared__ int part[KMAX + 1];
-  __shared__ int need_cnt[KMAX];
-  __shared__ int rbin[2 * KMAX], rloc[2 * KMAX];
-  int* ib = ibuf + (size_t)blockIdx.x * SEL_ISTRIDE;
-  int* hist = ib + 4;
-  int* s0 = slot0 + (size_t)blockIdx.x * SEL_NB;
-  SelQ* q = qs + (size_t)blockIdx.x * KMAX;
-  const int t = threadIdx.x;
-  constexpr int PER = SEL_NB / KMAX;  // bins per thread (contiguous)
-  int s = 0;
-  for (int k = 0; k < PER; ++k) s += hist[t * PER + k];
-  part[t + 1] = s;
-  if (t == 0) part[0] = 0;
-  __syncthreads();
-  if (t == 0)
-    for (int k = 1; k <= KMAX; ++k) part[k] += part[k - 1];  // (512 adds by one lane: 2 us, once per glacier)
-  __syncthreads();
-  const long long m = part[KMAX];  // entries strictly inside (0, max)
-  // the order statistics wanted: ranks j and j + 1 of quantile t (t < n)
-  long long j = 0, j1 = 0;
-  double gam = 0.0;
-  const bool isq = t < n && m > 0;
-  if (isq) {
-    const double p = (double)(t + 1) / (double)(n + 1);
-    const double h = (double)(m - 1) * p;
-    j = (long long)floor(h);
-    const long long jmax = m >= 2 ? m - 2 : 0;
-    if (j > jmax) j = jmax;
-    if (j < 0) j = 0;
-    gam = h - (double)j;
-    gam = gam < 0.0 ? 0.0 : (gam > 1.0 ? 1.0 : gam);
-    j1 = j + 1 < m ? j + 1 : m - 1;
-  }
-  auto locate = [&](long long r, int& bin, int& loc) {  // bin holding rank r: first the thread-chunk, then inside it
-    int lo_ = 0, hi_ = KMAX - 1;
-    while (lo_ < hi_) {
-      const int mid = (lo_ + hi_ + 1) >> 1;
-      if (part[mid] <= r) lo_ = mid; else hi_ = mid - 1;
-    }
-    long long acc = part[lo_];
-    int b = lo_ * PER;
-    for (;; ++b) {
-      const int c = hist[b];
-      if (r < acc + c) break;
-      acc += c;
-    }
-    bin = b; loc = (int)(r - acc);
-  };
-  rbin[2 * t] = rbin[2 * t + 1] = -1;
-  if (isq) { locate(j, rbin[2 * t], rloc[2 * t]); locate(j1, rbin[2 * t + 1], rloc[2 * t + 1]); }
-  __syncthreads();
-  // needed bins -> slot ranges, in bin order: thread t owns bins [t PER, (t+1) PER); a bin is needed iff some rank lies in it
-  for (int k = 0; k < PER; ++k) s0[t * PER + k] = -1;
-  __syncthreads();
-  if (isq) { s0[rbin[2 * t]] = 0; s0[rbin[2 * t + 1]] = 0; }  // (benign races: every writer stores 0)
-  __syncthreads();
-  int cnt = 0;
-  for (int k = 0; k < PER; ++k) if (s0[t * PER + k] == 0) cnt += hist[t * PER + k];
-  need_cnt[t] = cnt;
-  __syncthreads();
-  if (t == 0) {
-    int acc = 0;
-    for (int k = 0; k < KMAX; ++k) { const int c = need_cnt[k]; need_cnt[k] = acc; acc += c; }
-    ib[2] = acc;
-    if (acc > SEL_CAP) atomicExch(flag, 1);
-  }
-  __syncthreads();
-  int acc = need_cnt[t];
-  for (int k = 0; k < PER; ++k)
-    if (s0[t * PER + k] == 0) { s0[t * PER + k] = acc; acc += hist[t * PER + k]; }
-  __syncthreads();
-  if (isq) {
-    q[t].posA = s0[rbin[2 * t]] + rloc[2 * t];
-    q[t].posB = s0[rbin[2 * t + 1]] + rloc[2 * t + 1];
-    q[t].gam = gam;
-  }
-  __syncthreads();
-  for (int k = 0; k < PER; ++k) hist[t * PER + k] = 0;  // the histogram becomes the bins' fill cursor of pass 4
-}
-
-__global__ __launch_bounds__(256) void k_sel_gather(Pools P, int g0, int g_last, long long lo, long long end_all,
-                                                    const double* __restrict__ nodeH, int* __restrict__ ibuf,
-                                                    const int* __restrict__ slot0, double* __restrict__ cand) {
-  const int gidx = g0 + blockIdx.y;
-  int* ib = ibuf + (size_t)blockIdx.y * SEL_ISTRIDE;
-  const double amax = sel_amax(ib);
-  if (!(amax > 0.0) || ib[2] > SEL_CAP) return;
-  const double scale = (double)SEL_NB / amax;
-  const int* s0 = slot0 + (size_t)blockIdx.y * SEL_NB;
-  double* cd = cand + (size_t)blockIdx.y * SEL_CAP;
-  const long long off = P.gd[gidx].offd, n = seg_len(P, gidx, g_last, end_all);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const double h = nodeH[off + i];
-    if (h > 0.0 && h < amax) {
-      const int b = sel_bin(h, scale), s = s0[b];
-      if (s >= 0) cd[s + atomicAdd(ib + 4 + b, 1)] = h;
-    }
-  }
-}
-
-__global__ __launch_bounds__(KMAX) void k_sel_knots(int n, const int* __restrict__ ibuf, const SelQ* __restrict__ qs,
-                                                    const double* __restrict__ cand, double* __restrict__ knots_all,
-                                                    int* __restrict__ M_all) {
-  __shared__ double sc[SEL_CAP];
-  __shared__ double c[KMAX];
-  __shared__ int first[KMAX];
-  const int* ib = ibuf + (size_t)blockIdx.x * SEL_ISTRIDE;
-  const double amax = sel_amax(ib);
-  const int i = threadIdx.x;
-  double* knots = knots_all + (size_t)blockIdx.x * KMAX;
-  if (!(amax > 0.0) || ib[2] > SEL_CAP) {
-    if (i == 0) M_all[blockIdx.x] = 0;
-    return;
-  }
-  const int nc = ib[2];
-  int np2 = 1;
-  while (np2 < nc) np2 <<= 1;
-  const double* cd = cand + (size_t)blockIdx.x * SEL_CAP;
-  for (int k = i; k < np2; k += KMAX) sc[k] = k < nc ? cd[k] : 1.7976931348623157e308;
-  __syncthreads();
-  for (int size = 2; size <= np2; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int k = i; k < (np2 >> 1); k += KMAX) {
-        const int a = 2 * k - (k & (stride - 1)), b = a + stride;  // a: k with a 0 inserted at the stride bit
-        const bool up = (a & size) == 0;
-        const double x = sc[a], y = sc[b];
-        if ((x > y) == up) { sc[a] = y; sc[b] = x; }
-      }
-      __syncthreads();
-    }
-  // from here on knots_body with the order statistics read from the sorted candidates
-  bool valid = false;
-  double v = 0.0;
-  if (i < n) {
-    const double t = (double)i / (double)(n - 1);
-    v = (1.0 - t) * 0.0 + t * amax;
-    valid = true;
-  } else if (i < 2 * n && nc > 0) {
-    const SelQ q = qs[(size_t)blockIdx.x * KMAX + (i - n)];
-    const double a = sc[q.posA], b = sc[q.posB];
-    v = a + q.gam * (b - a);
-    valid = true;
-  }
-  c[i] = valid ? v : -1.0;
-  __syncthreads();
-  int isfirst = valid ? 1 : 0;
-  if (valid)
-    for (int j = 0; j < i; ++j)
-      if (c[j] == v) { isfirst = 0; break; }
-  first[i] = isfirst;
-  __syncthreads();
-  if (isfirst) {
-    int rank = 0;
-    for (int j = 0; j < 2 * n; ++j) rank += (first[j] && c[j] < v) ? 1 : 0;
-    knots[rank] = v;
-  }
-  if (i == 0) {
-    int M = 0;
-    for (int j = 0; j < 2 * n; ++j) M += first[j];
-    M_all[blockIdx.x] = M;
-  }
-}
-
-// pass 6: part[(glacier, block)][2][KMAX]
-__global__ __launch_bounds__(NT) void k_sel_sums(Pools P, int g0, int g_last, long long lo, long long end_all,
-                                                 const double* __restrict__ nodeH, const double* __restrict__ nodeV,
-                                                 const double* __restrict__ knots_all, const int* __restrict__ M_all,
-                                                 double* __restrict__ part) {
-  __shared__ double sk[KMAX];
-  __shared__ double acc[NW][2][KMAX];
-  const int gidx = g0 + blockIdx.y, M = M_all[blockIdx.y];
-  double* out = part + ((size_t)blockIdx.y * SEL_BLK + blockIdx.x) * 2 * KMAX;
-  const int w = wave_id(), lane = threadIdx.x & 63;
-  for (int k = threadIdx.x; k < KMAX; k += NT) {
-    sk[k] = k < M ? knots_all[(size_t)blockIdx.y * KMAX + k] : 0.0;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) { acc[ww][0][k] = 0.0; acc[ww][1][k] = 0.0; }
-  }
-  __syncthreads();
-  if (M >= 2) {
-    const long long off = P.gd[gidx].offd, n = seg_len(P, gidx, g_last, end_all);
-    // a contiguous chunk of the glacier's nodes per workgroup, 64 consecutive nodes per wavefront pass
-    const long long chunk = ((n + SEL_BLK - 1) / SEL_BLK + 63) & ~63ll;
-    const long long c0 = (long long)blockIdx.x * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
-    for (long long base = c0 + 64 * w; base < c1; base += 64 * NW) {
-      const long long i = base + lane;
-      double h = 0.0, v = 0.0;
-      if (i < c1) { h = nodeH[off + i]; v = nodeV[off + i]; }
-      int k = -1;
-      double a = 0.0, b = 0.0;
-      if (h > 0.0 && v != 0.0) {  // (Hbar == 0 carries the weight 0; a zero weight adds nothing)
-        // interval k: knots[k] <= h < knots[k+1], the last one closed (interval_sums_body's ranges)
-        int lo_ = 0, hi_ = M - 2;
-        while (lo_ < hi_) {
-          const int mid = (lo_ + hi_ + 1) >> 1;
-          if (sk[mid] <= h) lo_ = mid; else hi_ = mid - 1;
-        }
-        k = lo_;
-        const double x0 = sk[k], wgt = (h - x0) / (sk[k + 1] - x0);
-        a = v * (1.0 - wgt);
-        b = v * wgt;
-      }
-      unsigned long long todo = __builtin_amdgcn_ballot_w64(k >= 0);
-      while (todo) {
-        const int src = __builtin_ctzll(todo);
-        const int k0 = __builtin_amdgcn_readlane(k, src);
-        const bool mine = k == k0;
-        const double sa = wave_sum(mine ? a : 0.0), sb = wave_sum(mine ? b : 0.0);
-        if (lane == 0) { acc[w][0][k0] += sa; acc[w][1][k0] += sb; }
-        todo &= ~__builtin_amdgcn_ballot_w64(mine);
-      }
-    }
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < KMAX; k += NT) {
-    double sa = 0.0, sb = 0.0;
-#pragma unroll
-    for (int ww = 0; ww < NW; ++ww) { sa += acc[ww][0][k]; sb += acc[ww][1][k]; }
-    out[k] = sa;
-    out[KMAX + k] = sb;
-  }
-}
-__global__ __launch_bounds__(KMAX) void k_sel_ab(const double* __restrict__ part, double* __restrict__ ab_all) {
-  const int k = threadIdx.x;
-  double sa = 0.0, sb = 0.0;
-  for (int bl = 0; bl < SEL_BLK; ++bl) {
-    const double* p = part + ((size_t)blockIdx.x * SEL_BLK + bl) * 2 * KMAX;
-    sa += p[k];
-    sb += p[KMAX + k];
-  }
-  ab_all[(size_t)blockIdx.x * 2 * KMAX + k] = sa;
-  ab_all[(size_t)blockIdx.x * 2 * KMAX + KMAX + k] = sb;
-}
-
-size_t interp_select_int_count(int ng) { return (size_t)ng * SEL_ISTRIDE; }
-size_t interp_select_slot_count(int ng) { return (size_t)ng * SEL_NB; }
-size_t interp_select_cand_count(int ng) { return (size_t)ng * SEL_CAP; }
-size_t interp_select_part_count(int ng) { return (size_t)ng * SEL_BLK * 2 * KMAX; }
-size_t interp_select_q_bytes(int ng) { return (size_t)ng * KMAX * sizeof(SelQ); }
-// scratch: ibuf (interp_select_int_count ints), slot0 (..slot_count ints), qs (..q_bytes), cand (..cand_count doubles),
-// part (..part_count doubles), knots (ng KMAX), M (ng), ab (ng 2 KMAX); flag: device int, raised when a glacier overflows SEL_CAP
-int launch_interp_theta_select(hipStream_t st, Pools P, const LawDev& L, int n_half, int g0, int ng, long long lo, long long n,
-                               const double* nodeH, const double* nodeV, int* ibuf, int* slot0, void* qs, double* cand,
-                               double* part, int* flag, double* knots, int* M, double* ab, double* dth, int accumulate) {
-  if (2 * n_half > KMAX || n_half < 2) return 1;
-  if (hipMemsetAsync(ibuf, 0, interp_select_int_count(ng) * sizeof(int), st) != hipSuccess) return 2;
-  const long long per = (n + ng - 1) / ng;
-  const unsigned nb = (unsigned)std::max<long long>(1, std::min<long long>((per + 2047) / 2048, 256));
-  const int g_last = g0 + ng - 1;
-  hipLaunchKernelGGL(k_sel_max, dim3(nb, ng), dim3(256), 0, st, P, g0, g_last, lo, lo + n, nodeH, ibuf);
-  hipLaunchKernelGGL(k_sel_hist, dim3(nb, ng), dim3(256), 0, st, P, g0, g_last, lo, lo + n, nodeH, ibuf);
-  hipLaunchKernelGGL(k_sel_plan, dim3(ng), dim3(KMAX), 0, st, n_half, ibuf, slot0, static_cast<SelQ*>(qs), flag);
-  hipLaunchKernelGGL(k_sel_gather, dim3(nb, ng), dim3(256), 0, st, P, g0, g_last, lo, lo + n, nodeH, ibuf, slot0, cand);
-  hipLaunchKernelGGL(k_sel_knots, dim3(ng), dim3(KMAX), 0, st, n_half, ibuf, static_cast<const SelQ*>(qs), cand, knots, M);
-  hipLaunchKernelGGL(k_sel_sums, dim3(SEL_BLK, ng), dim3(NT), 0, st, P, g0, g_last, lo, lo + n, nodeH, nodeV, knots, M, part);
-  hipLaunchKernelGGL(k_sel_ab, dim3(ng), dim3(KMAX), 0, st, part, ab);
   const size_t dyn = interp_batch_lds_bytes(L.P);
   if (interp_law_is<ArchDef>(L))
     hipLaunchKernelGGL((k_knot_backprop<ArchDef, true>), dim3(ng), dim3(NT), dyn, st, P, L, g0, knots, M, ab, dth, accumulate);

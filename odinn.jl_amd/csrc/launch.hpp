@@ -40,14 +40,6 @@ void launch_vjp_theta_strip(int gacc, int itp, int nblk, hipStream_t st, Pools P
 constexpr int INTERP_KMAX = 512;
 size_t interp_batch_temp_bytes(long long n_max);
 size_t interp_batch_lds_bytes(int P);
-size_t interp_select_int_count(int ng);
-size_t interp_select_slot_count(int ng);
-size_t interp_select_cand_count(int ng);
-size_t interp_select_part_count(int ng);
-size_t interp_select_q_bytes(int ng);
-int launch_interp_theta_select(hipStream_t st, Pools P, const LawDev& L, int n_half, int g0, int ng, long long lo, long long n,
-                               const double* nodeH, const double* nodeV, int* ibuf, int* slot0, void* qs, double* cand,
-                               double* part, int* flag, double* knots, int* M, double* ab, double* dth, int accumulate);
 void launch_fill_gid(hipStream_t st, Pools P, int G, long long ntotd, unsigned* gid, unsigned* iota);
 int launch_interp_theta_batch(hipStream_t st, Pools P, const LawDev& L, int n_half, int g0, int ng, long long lo, long long n,
                               const double* nodeH, const double* nodeV, const unsigned* gid, const unsigned* iota, double* sH,

@@ -146,7 +146,7 @@ static int sched_val(int field, const char* env) {
 }
 
 struct odinn_batch {
-  odinn_schedule sched = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
+  odinn_schedule sched = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -331,12 +331,6 @@ struct odinn_batch {
   unsigned *d_ib_gid = nullptr, *d_ib_iota = nullptr, *d_ib_iA = nullptr, *d_ib_iB = nullptr, *d_ib_kA = nullptr, *d_ib_kB = nullptr;
   double *d_ib_sH = nullptr, *d_ib_sV = nullptr, *d_ib_knots = nullptr, *d_ib_ab = nullptr;
   int* d_ib_M = nullptr;
-  // ... or without any sort (launch_interp_theta_select): histogram / plan / candidate scratch; sel_off: a glacier overflowed
-  // the candidate buffer once (a plateau of equal thickness), the batch stays on the sort path from then on
-  int *d_sel_i = nullptr, *d_sel_slot = nullptr, *d_sel_flag = nullptr;
-  void* d_sel_q = nullptr;
-  double *d_sel_cand = nullptr, *d_sel_part = nullptr;
-  bool sel_off = false;
   void* d_ib_tmp = nullptr;
   size_t ib_tmp_bytes = 0;
   static constexpr int INTERP_LANES_MAX = 8;
@@ -1591,8 +1585,6 @@ int odinn_batch_destroy(odinn_batch* b) {
   if (b->d_sorttmp) { (void)hipFree(b->d_sorttmp); b->d_sorttmp = nullptr; }
   dfree(b->d_ib_gid); dfree(b->d_ib_iota); dfree(b->d_ib_iA); dfree(b->d_ib_iB); dfree(b->d_ib_kA); dfree(b->d_ib_kB);
   dfree(b->d_ib_sH); dfree(b->d_ib_sV); dfree(b->d_ib_knots); dfree(b->d_ib_ab); dfree(b->d_ib_M);
-  dfree(b->d_sel_i); dfree(b->d_sel_slot); dfree(b->d_sel_flag); dfree(b->d_sel_cand); dfree(b->d_sel_part);
-  if (b->d_sel_q) { (void)hipFree(b->d_sel_q); b->d_sel_q = nullptr; }
   if (b->d_ib_tmp) { (void)hipFree(b->d_ib_tmp); b->d_ib_tmp = nullptr; }
   for (int l = 0; l < odinn_batch::INTERP_LANES_MAX; ++l) {
     if (b->side[l]) (void)hipStreamDestroy(b->side[l]);
@@ -1840,13 +1832,6 @@ static int ensure_interp_scratch(odinn_batch* b) {
     HIPCHK(hipMalloc(&b->d_ib_tmp, std::max<size_t>(b->ib_tmp_bytes, 256)));
     launch_fill_gid(b->stream, b->pools(true), b->G, b->ntotd, b->d_ib_gid, b->d_ib_iota);
   }
-  if (b->law_kind == ODINN_LAW_NN_Y && !b->d_sel_i) {
-    CHK(dalloc(&b->d_sel_i, interp_select_int_count(b->G))); CHK(dalloc(&b->d_sel_slot, interp_select_slot_count(b->G)));
-    CHK(dalloc(&b->d_sel_cand, interp_select_cand_count(b->G))); CHK(dalloc(&b->d_sel_part, interp_select_part_count(b->G)));
-    CHK(dalloc(&b->d_sel_flag, 1));
-    HIPCHK(hipMalloc(&b->d_sel_q, interp_select_q_bytes(b->G)));
-    HIPCHK(hipMemsetAsync(b->d_sel_flag, 0, sizeof(int), b->stream));
-  }
   const size_t need = (size_t)std::max(b->P, 1) * INTERP_KMAX * b->interp_lanes;
   if (need > b->knotG_cap) {
     dfree(b->d_knotG);
@@ -1858,9 +1843,7 @@ static int ensure_interp_scratch(odinn_batch* b) {
 
 // U law, `:Linear`: Interpolations.Gridded(Linear()) does not extrapolate -- the reference throws a BoundsError when a
 // dual node has Hbar > 100 (or |grad S| > 100); reported once the stream has been synchronised
-static int check_select_overflow(odinn_batch* b);
 static int check_interp_bounds(odinn_batch* b) {
-  if (b->law_kind == ODINN_LAW_NN_Y) return check_select_overflow(b);
   if (!b->d_interp_err) return ODINN_OK;
   int e = 0;
   HIPCHK(hipMemcpy(&e, b->d_interp_err, sizeof(int), hipMemcpyDeviceToHost));
@@ -1868,20 +1851,6 @@ static int check_interp_bounds(odinn_batch* b) {
   HIPCHK(hipMemset(b->d_interp_err, 0, sizeof(int)));
   return fail(ODINN_ERR_ARG, "BoundsError: a dual node lies outside [0, 100] x [0, 100], the domain of the U law's gradient "
                              "interpolant (Laws.jl:128-131, interpolation = :Linear)");
-}
-
-// Y law, `:Linear`, selection path: a glacier whose needed histogram bins held more values than the candidate buffer (a plateau
-// of bit-identical thicknesses) has no knots -- its part of dtheta is wrong.  Reported after the stream has been synchronised;
-// the batch switches to the sort path for good and the public entry point repeats the evaluation (ODINN_RETRY_SORT is internal).
-constexpr int ODINN_RETRY_SORT = 1000;
-static int check_select_overflow(odinn_batch* b) {
-  if (!b->d_sel_flag || b->sel_off) return ODINN_OK;
-  int e = 0;
-  HIPCHK(hipMemcpy(&e, b->d_sel_flag, sizeof(int), hipMemcpyDeviceToHost));
-  if (!e) return ODINN_OK;
-  HIPCHK(hipMemset(b->d_sel_flag, 0, sizeof(int)));
-  b->sel_off = true;
-  return ODINN_RETRY_SORT;
 }
 
 // `:Linear` interpolation of d law / d theta (k_interp.hip): zero the (Hbar, weight[, slope]) node arrays of glacier g (-1: all)
@@ -1966,16 +1935,6 @@ static int interp_contract(odinn_batch* b, int g, bool linU, bool accumulate, co
     if (!linU && b->d_ib_gid && eb != 0 && interp_batch_lds_bytes(b->P) <= 30 * 1024) {
       const long long lo = b->gd[g0].offd;
       const long long hi = g0 + ng < b->G ? b->gd[g0 + ng].offd : b->ntotd;
-      if (!b->sel_off && b->d_sel_i && sched_val(b->sched.interp_select, "ODINN_INTERP_SELECT") != 0) {
-        // no sort: histogram + the <= 2 n_interp_half order statistics (k_interp.hip); an overflow of the candidate buffer is
-        // reported by check_select_overflow once the stream has been synchronised, and the caller repeats on the sort path
-        const int rc = launch_interp_theta_select(b->stream, P, L, b->n_interp_half, g0, ng, lo, hi - lo, b->d_nodeH, b->d_nodeV,
-                                                  b->d_sel_i, b->d_sel_slot, b->d_sel_q, b->d_sel_cand, b->d_sel_part, b->d_sel_flag,
-                                                  b->d_ib_knots, b->d_ib_M, b->d_ib_ab, b->d_dth, accumulate ? 1 : 0);
-        if (rc) return fail(ODINN_ERR_HIP, "gradient interpolation (selection path) failed (code %d)", rc);
-        HIPCHK(hipGetLastError());
-        return ODINN_OK;
-      }
       const int rc = launch_interp_theta_batch(b->stream, P, L, b->n_interp_half, g0, ng, lo, hi - lo, b->d_nodeH, b->d_nodeV,
                                                b->d_ib_gid, b->d_ib_iota, b->d_ib_sH, b->d_ib_sV, b->d_ib_iA, b->d_ib_iB, b->d_ib_kA,
                                                b->d_ib_kB, b->d_ib_tmp, b->ib_tmp_bytes, b->d_ib_knots, b->d_ib_M, b->d_ib_ab,
@@ -2042,7 +2001,7 @@ static int gridded_law_grad(odinn_batch* b, long long lo, long long n, double* d
   return ODINN_OK;
 }
 
-static int odinn_sia2d_vjp_theta_impl(odinn_batch* b, int g, const double* lam, const double* H, double t, double* dtheta, int P) {
+int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double* H, double t, double* dtheta, int P) {
   (void)t;
   CHK(check_g(b, g)); CHK(use_dev(b));
   if (!H || !lam || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
@@ -2254,7 +2213,7 @@ int odinn_surface_V_vjp_H(odinn_batch* b, int g, const double* dVx, const double
   return down_field(b, g, b->d_tmpB, out);
 }
 
-static int odinn_surface_V_vjp_theta_impl(odinn_batch* b, int g, const double* dVx, const double* dVy, const double* H,
+int odinn_surface_V_vjp_theta(odinn_batch* b, int g, const double* dVx, const double* dVy, const double* H,
                               double* dtheta, int P) {
   if (!dtheta) return fail(ODINN_ERR_ARG, "null argument");
   CHK(check_g(b, g));
@@ -2342,7 +2301,7 @@ int odinn_set_glacier_stops(odinn_batch* b, int g, int n, const double* t) {
 
 int odinn_set_schedule(odinn_batch* b, const odinn_schedule* sc) {
   if (!b) return fail(ODINN_ERR_ARG, "null batch");
-  const odinn_schedule automatic = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
+  const odinn_schedule automatic = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
   const odinn_schedule want = sc ? *sc : automatic;  // (validated as a local: a rejected schedule leaves the old one in effect)
   if (want.adj_rows >= 0 && want.adj_rows != 4 && want.adj_rows != 7)
     return fail(ODINN_ERR_ARG, "odinn_schedule.adj_rows must be -1, 4 or 7");
@@ -2370,7 +2329,6 @@ int odinn_get_schedule(odinn_batch* b, odinn_schedule* out) {
   out->adj_segs = sched_val(b->sched.adj_segs, "ODINN_ADJ_SEGS");
   out->adj_rows = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS");
   out->adj_theta_fused = sched_val(b->sched.adj_theta_fused, "ODINN_ADJ_THETA_FUSED");
-  out->interp_select = sched_val(b->sched.interp_select, "ODINN_INTERP_SELECT");
   return ODINN_OK;
 }
 
@@ -2437,7 +2395,7 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
 }
 static int grad_finish(odinn_batch* b, int k, int P, double const_loss, double* loss, double* dtheta);
 
-static int odinn_loss_grad_impl(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
                     const double* mb_times, const odinn_solver_opts* opts, double* loss, double* dtheta,
                     odinn_solve_stats* stats) {
   if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
@@ -2582,7 +2540,7 @@ static void gauss_legendre(int n, std::vector<double>& x, std::vector<double>& w
 // The reverse ODE dlam/dtau = J_H(H_itp(-tau))^T lam runs on the same device-side RDPK3Sp35 + PID
 // machinery as the forward solve (one k_adj_stage per stage); its stops are the snapshot times
 // (loss and mass-balance callbacks) and the Gauss-Legendre nodes (theta-VJP quadrature).
-static int odinn_loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
                                const double* mb_times, const odinn_solver_opts* opts, const odinn_adjoint_opts* aopts,
                                double* loss, double* dtheta, odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
   if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
@@ -3022,35 +2980,6 @@ int odinn_get_grad_field(odinn_batch* b, int g, double* dLdA_dual) {
 int odinn_get_lambda0(odinn_batch* b, int g, double* lam0) {
   CHK(check_g(b, g)); CHK(use_dev(b));
   return down_field(b, g, b->d_lam[0], lam0);
-}
-
-// The public gradient entry points: the evaluation itself (*_impl), repeated ONCE on the sort path when the selection path of
-// the Y law's `:Linear` interpolation overflowed its candidate buffer (check_select_overflow; the batch then stays on the
-// sort path).  The first attempt's results are overwritten; nothing of it is visible to the caller.
-int odinn_sia2d_vjp_theta(odinn_batch* b, int g, const double* lam, const double* H, double t, double* dtheta, int P) {
-  int rc = odinn_sia2d_vjp_theta_impl(b, g, lam, H, t, dtheta, P);
-  if (rc == ODINN_RETRY_SORT) rc = odinn_sia2d_vjp_theta_impl(b, g, lam, H, t, dtheta, P);
-  return rc;
-}
-int odinn_surface_V_vjp_theta(odinn_batch* b, int g, const double* dVx, const double* dVy, const double* H, double* dtheta, int P) {
-  int rc = odinn_surface_V_vjp_theta_impl(b, g, dVx, dVy, H, dtheta, P);
-  if (rc == ODINN_RETRY_SORT) rc = odinn_surface_V_vjp_theta_impl(b, g, dVx, dVy, H, dtheta, P);
-  return rc;
-}
-int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
-                    const double* mb_times, const odinn_solver_opts* opts, double* loss, double* dtheta,
-                    odinn_solve_stats* stats) {
-  int rc = odinn_loss_grad_impl(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, loss, dtheta, stats);
-  if (rc == ODINN_RETRY_SORT) rc = odinn_loss_grad_impl(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, loss, dtheta, stats);
-  return rc;
-}
-int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
-                               const double* mb_times, const odinn_solver_opts* opts, const odinn_adjoint_opts* aopts,
-                               double* loss, double* dtheta, odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
-  int rc = odinn_loss_grad_continuous_impl(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, aopts, loss, dtheta, stats, stats_rev);
-  if (rc == ODINN_RETRY_SORT)
-    rc = odinn_loss_grad_continuous_impl(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, aopts, loss, dtheta, stats, stats_rev);
-  return rc;
 }
 
 // ---- multi-GPU: RCCL communicator behind the C ABI (SIA2D_grad!, gradient.jl:6-31) ----------------------------

@@ -834,63 +834,6 @@ def test_Y_law_interpolation_batched_and_per_glacier_sequences_agree(gpu, monkey
     assert np.linalg.norm(out[0][1]) > 0.0
 
 
-def test_Y_law_interpolation_selection_path_equals_the_sort_path(gpu):
-    """The `:Linear` gradient without sorting the nodes (odinn_schedule.interp_select, the default): per glacier a histogram
-    of Hbar, the <= 2 n_interp_half order statistics the quantile knots need selected from the few bins that hold them, knot
-    intervals found by bisection, interval sums reduced in a fixed order.  Same knots as the sort path (create_interpolation,
-    target_utils.jl:245-293), so the gradients agree to the rounding of the interval sums; against the oracle; repeatable to
-    the bit; and a glacier with a PLATEAU of bit-identical thicknesses (more equal values in one bin than the candidate
-    buffer holds) makes the call fall back to the sort path by itself -- same result, and the batch keeps working."""
-    ph = O.Phys()
-    om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
-    shapes = [(150, 131), (80, 48), (40, 33), (96, 200)]
-    Ts = [-5.0, -2.0, -7.0, -4.0]
-    fields = []
-    for k, (nx, ny) in enumerate(shapes):
-        H0, B = O.synthetic_icecap(nx, ny, 100.0) if k != 1 else O.synthetic_valley(nx, ny, 100.0)
-        fields.append((H0 * (0.0 if k == 2 else 0.5), B))  # glacier 2: no ice at all
-    rng = np.random.default_rng(9)
-    lams = [rng.standard_normal(sh) for sh in shapes]
-
-    def grads(select, plateau=False):
-        b = gpu.GlacierBatch(shapes, [100.0] * 4, T=Ts)
-        fl = list(fields)
-        if plateau:  # 120 x 100 cells of exactly 50 m inside glacier 0: 11 781 dual nodes with the same Hbar
-            H0 = fl[0][0].copy()
-            H0[15:135, 15:115] = 50.0
-            fl[0] = (H0, fl[0][1])
-        for k, (H0, B) in enumerate(fl):
-            b.set_fields(k, H0, B)
-        b.set_law(gpu.LAW_NN_Y, gm, th)
-        b.set_schedule(interp_select=select)
-        out = [b.vjp_theta(k, lams[k], fl[k][0]) for k in range(4)]
-        again = [b.vjp_theta(k, lams[k], fl[k][0]) for k in range(4)]
-        ts = [0.0, 0.5, 1.0]
-        for k, (H0, B) in enumerate(fl):
-            b.set_reference(k, ts, [H0 * (1.0 - 0.05 * j) for j in range(3)], 3)
-        L, g = b.loss_grad(ts, theta=th, reltol=1e-8)
-        Lc, gc = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
-        b.close()
-        return out, again, (L, np.asarray(g)), (Lc, np.asarray(gc)), fl
-
-    for plateau in (False, True):
-        sel, sel2, dsel, csel, fl = grads(1, plateau)
-        srt, _, dsrt, csrt, _ = grads(0, plateau)
-        for k in range(4):
-            assert np.array_equal(sel[k], sel2[k])  # bitwise reproducible
-            if k == 2:
-                assert np.all(sel[k] == 0.0) and np.all(srt[k] == 0.0)
-                continue
-            assert rel_l2(sel[k], srt[k]) < 1e-12, (plateau, k)
-            law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=Ts[k])  # the law's default: :Linear, n_interp_half = 75
-            ref = O.vjp_theta(lams[k], fl[k][0], fl[k][1], 100.0, 100.0, ph, law)
-            # (the ice caps are symmetric: how many nodes tie with max(Hbar) bit for bit depends on the rounding of Hbar, and the
-            #  quantile knots move with that count -- DESIGN.md section 8; both device paths see the same Hbar)
-            assert rel_l2(sel[k], ref) < (1e-10 if k == 1 else 5e-6), (plateau, k)
-        assert dsel[0] == dsrt[0] and rel_l2(dsel[1], dsrt[1]) < 1e-12
-        assert abs(csel[0] - csrt[0]) <= 1e-12 * abs(csrt[0]) and rel_l2(csel[1], csrt[1]) < 1e-10
-
-
 def test_U_law_theta_gradient_bilinear_interpolation(gpu):
     """SIA2D_D_target(interpolation = :Linear) (target_D_pure.jl:179-193): gradients of the U law on the fixed
     (2 n_interp_half)^2 node grid of LawU's p_VJP! (Laws.jl:128-169), bilinear in (Hbar, |grad S|).  On the device: dual
