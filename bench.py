@@ -547,16 +547,54 @@ def main():
             aux["nn_inlined_2x16_ms_per_step"] = ms_nn
             aux["nn_inlined_2x16_cellsteps_per_s"] = 5.0 * cells / (ms_nn * 1e-3)
             aux["nn_inlined_2x16_note"] = "LawY: Y = NN_theta(T, Hbar) evaluated per dual node inside the stencil (Laws.jl:258-265)"
-            # its own roofline: fp64 vector pipe.  Flops per node evaluation as SURVEY section 7 counts them: 2 x (2*16 + 16*16
-            # + 16) = 608 for the matrix-vector products + 33 activations (32 softplus = exp + log1p, 1 sigmoid) at 25 flop
-            # each (the survey's 20-30) = 1433, + the stencil's own flops per cell-stage
-            fl = 608.0 + 33.0 * 25.0 + FLOP_PER_CELL_STAGE_FALLBACK
+            # its own roofline: fp64 vector pipe, flops per cell-stage from the committed PMC pass of the per-stage kernel with this
+            # network (profiles/r04/pmc_roofline.json: 64 x (ADD + MUL + 2 FMA + TRANS)_F64 per launch / cells)
+            pm_nn, pm_nn_src = {}, "n/a"
+            for pf in PMC_FILES:
+                try:
+                    pm_nn = json.load(open(pf))
+                    if "rk_stage2_nnY16_8x1024" in pm_nn:
+                        pm_nn_src = os.path.relpath(pf, ROOT)
+                        break
+                except Exception:
+                    pass
+            k16 = pm_nn.get("rk_stage2_nnY16_8x1024", {})
+            fl = k16.get("flop_per_useful_cell_stage", 608.0 + 33.0 * 25.0 + FLOP_PER_CELL_STAGE_FALLBACK)
             ach = fl * 5.0 * cells / (ms_nn * 1e-3) / 1e12
             aux["roofline_nn_inlined"] = {
                 "bound": "fp64-valu", "kernel": "k_rk_stage<LM 4> x 5 or k_rk_fused<LM 4> (2 -> 16 -> 16 -> 1 MLP inlined per dual node and stage)",
-                "flop_per_cell_stage": fl, "flop_definition": "608 (MLP FMAs x 2) + 33 activations x 25 + stencil; the softplus / sigmoid "
-                "of the kernel cost ~50 fp64 instructions each (exp, log1p, division at <= 2 ulp), so the instruction count is ~2x this",
+                "flop_per_cell_stage": fl, "flop_source": ("PMC: SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of k_rk_stage<2, 4> on 8 x 1024^2, "
+                "%d VALU instructions per cell-stage, %.0f %% of the fp64 instructions are FMAs" % (
+                    k16.get("valu_insts_per_useful_cell_stage", 0), 100.0 * k16.get("fma_share_of_f64_insts", 0.0))) if k16 else
+                "model: 608 (MLP FMAs x 2) + 33 activations x 25 + stencil",
                 "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "ms_per_step": ms_nn}
+            # the reverse stage kernels of the per-node-network laws (default 2-3-10-3-1 net; the continuous adjoint of targets
+            # :D_hybrid / :D runs five of them per reverse step): HIP events here, flops per cell-stage from the same PMC file
+            radj = {}
+            for nm, kind, pre, post_hi, key in (("Y", odinn.LAW_NN_Y, [(-25.0, 0.0), (0.0, 500.0)], ph.maxA, "adj_stage2_nnY_8x512"),
+                                                ("U", odinn.LAW_NN_U, [(0.0, 300.0), (0.0, 0.5)], 50.0, "adj_stage2_nnU_8x512")):
+                mdef = odinn.MLPSpec([2, 3, 10, 3, 1], [odinn.ACT_SOFTPLUS] * 3 + [odinn.ACT_SIGMOID], pre, odinn.POST_EXPMAX, 0.0, post_hi)
+                b.set_law(kind, mdef, np.random.default_rng(1234).uniform(-0.5, 0.5, mdef.n_params))
+                ms_a = ev(T.TIMED_ADJ_STAGE2, 5, 1)
+                ms_f = ev(T.TIMED_RK_STAGE2, 5, 1)
+                ka = pm_nn.get(key, {})
+                kf = pm_nn.get(key.replace("adj_stage2", "rk_stage2"), {})
+                e = {"adj_stage_ms": ms_a, "fwd_stage_ms": ms_f}
+                if ka:
+                    fa = ka["flop_per_useful_cell_stage"]
+                    e.update({"flop_per_cell_stage": fa, "valu_insts_per_cell_stage": ka.get("valu_insts_per_useful_cell_stage"),
+                              "achieved": fa * cells / (ms_a * 1e-3) / 1e12, "frac": fa * cells / (ms_a * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                              "issue_bound_ms": ka.get("valu_insts_per_useful_cell_stage", 0.0) * cells / 64.0 / 1024.0 * 5.5 / 2.4e9 * 1e3})
+                if kf:
+                    e["fwd_frac"] = kf["flop_per_useful_cell_stage"] * cells / (ms_f * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+                radj[nm] = e
+            aux["roofline_adjoint_nn"] = {
+                "bound": "fp64-valu", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "kernel": "k_adj_stage<2, LM 3, DiscreteVJP, NK> (one RDPK3Sp35 stage of the reverse ODE, 2-3-10-3-1 network inlined per dual "
+                          "node: Y law two direct evaluations, U law one perturbed five-point evaluation)",
+                "laws": radj,
+                "note": "issue_bound_ms = VALU instructions per cell-stage x cells / (1024 SIMDs x 64 lanes) x 5.5 cycles at 2.4 GHz: the time the "
+                        "kernel's instruction stream needs at the fp64 pipe's sustained issue rate; flop counts from " + pm_nn_src}
             b.set_law(odinn.LAW_CONST_A)
         except Exception as e:
             aux["nn_inlined_error"] = str(e)[:200]
@@ -707,7 +745,7 @@ def main():
                 "achieved": r_nn["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_nn["frac_of_hbm_peak"],
                 "ms_per_launch": r_nn["ms"], "algorithmic_bytes_per_launch": B_PER_CELL_DHDT_NN * hbm["cells"],
                 "working_set": hbm["working_set_note"],
-                "traffic": pmc.get("dhdt_nn_gridded_32", {}).get("hbm_bytes_per_launch"),
+                "traffic": (lambda k_: (k_.get("hbm_bytes_per_cell") or 0.0) * hbm["cells"] or None)(pmc.get("dhdt_nn_gridded_64", pmc.get("dhdt_nn_gridded_32", {}))),
                 "in_infinity_cache_8_glaciers_GBs": (weak or {}).get("dhdt_nn_gridded_in_cache_GBs"),
             } if r_nn else None),
             "roofline_per_stage": ({
@@ -716,24 +754,32 @@ def main():
                 "achieved": r_st["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_st["frac_of_hbm_peak"],
                 "ms_per_launch": r_st["ms"], "algorithmic_bytes_per_launch": B_PER_CELL_STAGE2 * hbm["cells"],
                 "working_set": hbm["working_set_note"],
-                "traffic": pmc.get("rk_stage2_32", {}).get("hbm_bytes_per_launch"),
+                "traffic": (lambda k_: (k_.get("hbm_bytes_per_cell") or 0.0) * hbm["cells"] or None)(pmc.get("rk_stage2_64", pmc.get("rk_stage2_32", {}))),
             } if r_st else None),
-            "roofline_adjoint": {
+            "roofline_adjoint": (lambda ka: {
                 "bound": "fp64-valu",
                 "kernel": "k_adj_fused_strip<constant A, dense, 7 rows> on rank 0's shard (a whole RDPK3Sp35 step of the reverse ODE of the continuous adjoint: "
                           "the reference's default gradient, gradient.jl:276-539)",
                 "ms_per_launch": ms_adjf,
+                "flop_per_cell_stage": ka.get("flop_per_executed_cell_stage"),
+                "achieved": (ka["flop_per_executed_cell_stage"] * 5.0 * cells / (ms_adjf * 1e-3) / 1e12) if ka.get("flop_per_executed_cell_stage") else None,
+                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (ka["flop_per_executed_cell_stage"] * 5.0 * cells / (ms_adjf * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if ka.get("flop_per_executed_cell_stage") else None,
+                "flop_source": "committed PMC pass: 64 x (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + 2 FMA_F64) per launch / executed cell-stages (halo "
+                               "redundancy %.2f not counted as useful work); %.0f VALU instructions per useful cell-stage, %.0f %% of the fp64 "
+                               "instructions are FMAs" % (ka.get("halo_redundancy", 0.0), ka.get("valu_insts_per_useful_cell_stage", 0.0),
+                                                          100.0 * ka.get("fma_share_of_f64_insts", 0.0)) if ka else None,
                 "algorithmic_bytes_per_launch": 40.0 * cells,
                 "hbm_algorithmic_GBs": 40.0 * cells / (ms_adjf * 1e-3) / 1e9,
                 "hbm_algorithmic_frac_of_peak": 40.0 * cells / (ms_adjf * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "traffic": (pmc.get("adj_fused_step_8", {}).get("hbm_bytes_per_launch") or 0.0) * pmc_scale or None,
-                "traffic_over_algorithmic": pmc.get("adj_fused_step_8", {}).get("ratio"),
-                "valu_busy_frac": pmc.get("adj_fused_step_8", {}).get("valu_busy_frac"),
-                "valu_insts_per_wave": pmc.get("adj_fused_step_8", {}).get("valu_insts_per_wave"),
-                "note": "issue-bound like the forward step kernel (4230 VALU instructions per wavefront-step x 27 968 wavefronts at the fp64 "
-                        "pipe's sustained issue rate = the launch time); the 2.55 x traffic (stage-invariant H_j, dH, B re-read in stages "
-                        "2-5 past a 4 MB L2) is hidden behind it -- DESIGN.md section 5, 'what bounds the two fused kernels'",
-            },
+                "traffic": (ka.get("hbm_bytes_per_cell") or 0.0) * cells or None,
+                "traffic_over_algorithmic": ka.get("ratio"),
+                "valu_busy_frac": ka.get("valu_busy_frac"),
+                "valu_insts_per_wave": ka.get("valu_insts_per_wave"),
+                "note": "issue-bound like the forward step kernel (4230 VALU instructions per wavefront-step at the fp64 pipe's sustained issue "
+                        "rate = the launch time); the 2.6 x traffic (stage-invariant H_j, dH, B re-read in stages 2-5 past a 4 MB L2) is hidden "
+                        "behind it -- DESIGN.md section 5, 'what bounds the two fused kernels'",
+            })(pmc.get("adj_fused_step_64", pmc.get("adj_fused_step_8", {}))),
             "cpu_baseline": cpu,
             "aux": aux,
         }

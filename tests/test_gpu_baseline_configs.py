@@ -113,6 +113,46 @@ def test_config2_512_icecap_with_nn_laws(gpu):
     b2.close()
 
 
+def test_config2_512_forward_ude_and_adjoint_seams_match_the_oracle_at_full_size(gpu):
+    """configs[2] at its FULL size against the oracle, not only through properties: 512^2, the 2 x 16 network,
+    (i) A = NN(T) gridded and (ii) Y = NN(T, Hbar) inlined per dual node -- four fixed RDPK3Sp35 steps of the forward UDE
+    (every kernel form the solve would pick at this size runs the same arithmetic) and the two VJP seams of the gradient
+    (J_H^T lambda, J_theta^T lambda) on the stepped state, against the numpy oracle on the same inputs."""
+    n = 512
+    H0, B = _icecap(n)
+    ph = O.Phys()
+    rng = np.random.default_rng(1234)
+    S = B + H0
+    Tg = -5.0 - 6.5e-3 * (O.avg(S) - S.mean())
+    mA = O.MLP([1, 16, 16, 1], [O.ACT_SOFTPLUS, O.ACT_SOFTPLUS, O.ACT_SIGMOID], None, O.POST_AFFINE, ph.minA, ph.maxA)
+    thA = mA.init_theta(rng)
+    mY = O.MLP([2, 16, 16, 1], [O.ACT_SOFTPLUS, O.ACT_SOFTPLUS, O.ACT_SIGMOID], ((-25.0, 0.0), (0.0, 500.0)),
+               O.POST_EXPMAX, 0.0, ph.maxA)
+    thY = rng.uniform(-0.5, 0.5, mY.n_params)
+    lam = rng.standard_normal((n, n))
+    dt, nsteps = 0.01, 4
+    for name, kind, m, th, law, tol in (
+            ("A(T) gridded", gpu.LAW_NN_A_GRIDDED, mA, thA, O.Law(kind=O.LAW_NN_A_GRIDDED, mlp=mA, theta=thA, T=Tg), 1e-11),
+            ("Y(T, Hbar) inlined", gpu.LAW_NN_Y, mY, thY, O.Law(kind=O.LAW_NN_Y, mlp=mY, theta=thY, T=-5.0, interpolation="none"), 1e-10)):
+        b = gpu.GlacierBatch([(n, n)], [100.0], T=[-5.0])
+        b.set_fields(0, H0, B)
+        if kind == gpu.LAW_NN_A_GRIDDED:
+            b.set_T_field(0, Tg)
+        b.set_law(kind, gpu.MLPSpec(m.widths, m.acts, m.prescale, m.post_kind, m.post_lo, m.post_hi), th)
+        if kind == gpu.LAW_NN_Y:
+            b.set_grad_interpolation(gpu._lib.GRAD_INTERP_NONE, 75)
+        f = lambda H: O.sia2d_rhs(H, B, 100.0, 100.0, ph, law)
+        u = H0
+        for _ in range(nsteps):
+            u, _ = O.rdpk3sp35_step(f, u, dt)
+        b.solve([0.0, dt * nsteps], fixed_dt=dt)
+        H1 = b.snapshot(0, 1)
+        assert rel_l2(H1, u) < 1e-12, name
+        assert rel_l2(b.vjp_H(0, lam, H1), O.vjp_H(lam, u, B, 100.0, 100.0, ph, law)) < (1e-10 if kind == gpu.LAW_NN_A_GRIDDED else 1e-8), name
+        assert rel_l2(b.vjp_theta(0, lam, H1), O.vjp_theta(lam, u, B, 100.0, 100.0, ph, law)) < tol * 10, name
+        b.close()
+
+
 def test_config4_batch_of_1024_glaciers(gpu, monkeypatch):
     """configs[4], per-GPU share: 8 caps at 1024^2 with per-glacier random (R, bed phase, A); one fused
     RDPK3Sp35 step sequence of every glacier == the C oracle stepping that glacier alone, and the
