@@ -35,6 +35,7 @@ from .batch import GlacierBatch, MLPSpec, PhysicalParameters
 __all__ = [
     "Parameters", "SimulationParameters", "SolverParameters", "Hyperparameters", "UDEparameters",
     "Glacier2D", "ThicknessData", "NeuralNetwork", "LawA", "LawY", "LawU", "ConstantA", "SIA2Dmodel", "Model",
+    "TrainableComponents", "InversionBinder",
     "GlacierWideInv", "GriddedInv", "LinearMB", "FieldMB", "Prediction", "Inversion", "FunctionalInversion", "DiscreteAdjoint", "ContinuousAdjoint", "DummyAdjoint", "DiscreteVJP", "ContinuousVJP", "MultiLoss", "TikhonovRegularization",
     "InitialThicknessRegularization", "RheologyRegularization", "InitialCondition", "evaluate_H0", "evaluate_dH0",
     "sigma_zang", "dsigma_zang", "TrainingResult", "save_inversion_file", "load_inversion_file", "ScalarLogger", "TBLogger", "read_event_file",
@@ -106,7 +107,8 @@ class DummyAdjoint:
 @dataclass
 class ContinuousAdjoint:
     """src/inverse/AdjointTypes.jl:53-67 -- the reference's default `grad` (UDEparameters.jl:63).
-    Only VJP_method = DiscreteVJP() and interpolation = :Linear are provided."""
+    VJP_method: DiscreteVJP() (default) or ContinuousVJP() (adjoint.jl:442-662, all three targets); interpolation = :Linear
+    and the RDPK3Sp35 reverse solver are what the reference defines / what the device implements."""
 
     VJP_method: object = field(default_factory=DiscreteVJP)  # DiscreteVJP | ContinuousVJP
     solver: str = "RDPK3Sp35"
@@ -703,6 +705,70 @@ class Model:
         if self.IC is not None:
             main = np.zeros(0) if self.theta is None else self.theta
             self.theta = np.concatenate([main, self.IC.theta])
+        self.trainable_components = TrainableComponents(self)
+
+
+class TrainableComponents:
+    """The trainable sub-models of a Model by the law they feed and the flat parameter vector θ (Model.jl:132-181): regressor
+    slots A, C, n, Y, U, IC (None = emptyTrainableModel()), `target`, and θ = (A | Y | U = ..., IC = ...) concatenated in that
+    order.  A view of the Model that owns it: `model.trainable_components.θ = v` sets `model.theta` (what
+    `container.simulation.model.trainable_components.θ = container.θ` does in inversion_utils.jl:483)."""
+
+    _SLOTS = ("A", "C", "n", "Y", "U", "IC")
+
+    def __init__(self, model: "Model"):
+        self._model = model
+
+    def __getattr__(self, name):
+        if name in TrainableComponents._SLOTS:
+            return self._model.regressors.get(name)
+        raise AttributeError(name)
+
+    @property
+    def target(self):
+        return self._model.target
+
+    @property
+    def theta(self):
+        return self._model.theta
+
+    @theta.setter
+    def theta(self, v):
+        v = np.asarray(v, dtype=float)
+        if self._model.theta is None or v.shape != self._model.theta.shape:
+            raise ValueError("θ does not match the model's parameter vector")
+        self._model.theta = v.copy()
+
+    def split_theta(self, theta, glacier_idx: int):
+        """splitθ (Model.jl:189-200): the part of θ one glacier's simulation sees -- a FunctionalModel's parameters whole, a
+        PerGlacierModel's / the initial condition's own slot only.  Returns {key: array}."""
+        m, out = self._model, {}
+        theta = np.asarray(theta, dtype=float)
+        if m.n_main:
+            main = theta[:m.n_main]
+            key = "U" if m.iceflow.law.kind == L.LAW_NN_U else "Y" if m.iceflow.law.kind == L.LAW_NN_Y else "A"
+            if m.per_glacier is not None:
+                offs = np.concatenate([[0], np.cumsum(m.per_glacier.sizes)])
+                main = main[offs[glacier_idx]:offs[glacier_idx + 1]]
+            out[key] = main
+        if m.IC is not None:
+            offs = np.concatenate([[0], np.cumsum(m.IC.sizes)]) + m.n_main
+            out["IC"] = theta[offs[glacier_idx]:offs[glacier_idx + 1]]
+        return out
+
+
+@dataclass
+class InversionBinder:
+    """Container handed to the ODE problem: the simulation and the θ it is solved with (sciml_utils.jl:21-24).  Here it is what
+    `SIA2D_grad_b` / `run_b` build internally; exposed under the reference's name for callers that construct it themselves."""
+
+    simulation: "_Simulation"
+    theta: np.ndarray
+
+    def apply(self):
+        """simulation.model.trainable_components.θ = θ (inversion_utils.jl:483)"""
+        self.simulation.model.trainable_components.theta = self.theta
+        return self.simulation
 
 
 # ----------------------------------------------------------------------------------------

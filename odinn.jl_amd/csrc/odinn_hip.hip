@@ -3168,6 +3168,11 @@ int odinn_batch_loss_grad(odinn_batch* b, odinn_comm* comm, int adjoint, const d
 }
 
 // ---- measurement --------------------------------------------------------------------------
+// (measurement aid, read once per process: never inside a timed launch sequence)
+static bool timed_adj_skip() {
+  static const bool v = std::getenv("ODINN_TIMED_ADJ_SKIP") != nullptr;
+  return v;
+}
 static int timed_prepare(odinn_batch* b) {
   CHK(use_dev(b));
   CHK(refresh_gd(b)); CHK(refresh_law_field(b));
@@ -3273,7 +3278,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
       // (odinn_schedule.adj_rows = 4 times the 4-rows-per-thread instantiation: 54 x 22 tiles, which needs the segment pairs)
       const bool rows4 = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS") == 4 && FA.segs;
       if (rows4) { FA.partF = b->d_partFv; FA.tilesF = b->d_tilesFv; }
-      launch_adj_fused_strip(rows4 ? b->ntilesFv : b->ntilesFt, b->gd[0].use_Afield, std::getenv("ODINN_TIMED_ADJ_SKIP") ? 1 : 0,
+      launch_adj_fused_strip(rows4 ? b->ntilesFv : b->ntilesFt, b->gd[0].use_Afield, timed_adj_skip() ? 1 : 0,
                              rows4 ? 4 : TRPT, b->stream, P, FA);
       return ODINN_OK;
     }

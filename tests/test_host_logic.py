@@ -260,3 +260,27 @@ def test_log1p_table_recipe_is_within_two_ulp():
         ref = (Decimal(1) + Decimal(t)).ln() if t > 1e-25 else Decimal(t)
         worst = max(worst, float(abs(Decimal(log1p_table(t)) - ref) / Decimal(math.ulp(float(ref)))))
     assert log1p_table(0.0) == 0.0 and worst <= 2.0, worst
+
+
+def test_trainable_components_and_inversion_binder_names(odinn):
+    """Model.trainable_components (Model.jl:132-181: regressor slots by law, target, θ; splitθ :189-200) and InversionBinder
+    (sciml_utils.jl:21-24) under the reference's names."""
+    p = odinn.Parameters()
+    nn = odinn.NeuralNetwork(p)
+    H0 = np.zeros((12, 10)); H0[3:9, 3:7] = 40.0
+    gl = [odinn.Glacier2D(f"g{i}", H0 * (1 + i), np.zeros_like(H0) + 1000.0, 50.0, 50.0) for i in range(2)]
+    ic = odinn.InitialCondition(p, gl)
+    m = odinn.Model(odinn.SIA2Dmodel(p, A=odinn.LawA(nn, p)), regressors={"A": nn, "IC": ic})
+    tc = m.trainable_components
+    assert tc.A is nn and tc.IC is ic and tc.Y is None and tc.U is None and isinstance(tc.target, odinn.SIA2D_A_target)
+    assert tc.theta is m.theta and tc.theta.size == nn.theta.size + 2 * H0.size
+    parts = tc.split_theta(m.theta, 1)
+    assert np.array_equal(parts["A"], nn.theta) and np.array_equal(parts["IC"], ic.theta[H0.size:])
+    inv = odinn.Inversion(m, gl, p)
+    th = m.theta + 1.0
+    assert odinn.InversionBinder(inv, th).apply() is inv and np.array_equal(m.theta, th)
+    with pytest.raises(ValueError):
+        tc.theta = np.zeros(3)
+    reg = odinn.GlacierWideInv(p, gl, "A")
+    m2 = odinn.Model(odinn.SIA2Dmodel(p, A=odinn.LawA(p, scalar=True)), regressors={"A": reg})
+    assert m2.trainable_components.split_theta(m2.theta, 1)["A"].size == 1
