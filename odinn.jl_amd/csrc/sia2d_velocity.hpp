@@ -46,8 +46,28 @@ __device__ __forceinline__ double node_Vup(const GDev& g, double Hb, double gS2,
 
 // target :D (target_D_pure.jl:206-255): Velocity^ = U / f, dVelocity^/dH and /d|grad S| by central differences of the law
 // with steps 1e-4 and 1e-6 (the latter NOT divided by |grad S|, as the reference returns it)
+template <class AR>
+__device__ __forceinline__ bool law_arch_is(const LawDev& L) {  // wave-uniform (the descriptor lives in scalar registers)
+  bool ok = L.n_layers == AR::NL;
+#pragma unroll
+  for (int l = 0; l <= AR::NL; ++l) ok = ok && L.widths[l] == AR::W[l];
+#pragma unroll
+  for (int l = 0; l < AR::NL; ++l) ok = ok && L.acts[l] == AR::A[l];
+  return ok;
+}
 __device__ __forceinline__ double node_Vup_U(const LawDev& L, double Hb, double gS, double finv, double& alpha, double& beta) {
   const double dH = 1e-4, dS = 1e-6;
+  if (law_arch_is<ArchDef>(L)) {
+    // the default 2-3-10-3-1 network: U at the node and at the four points of the two central differences in ONE pass
+    // (mlp_eval_pert, sia2d_device.hpp) instead of five evaluations of the run-time-architecture network
+    const int pd[4] = {0, 0, 1, 1};
+    const double dl[4] = {dH, -dH, dS, -dS};
+    double up[4];
+    const double U = mlp_eval_pert<ArchDef, 4>(L, Hb, gS, pd, dl, up);
+    alpha = finv * ((up[0] - up[1]) / (2.0 * dH));
+    beta = finv * ((up[2] - up[3]) / (2.0 * dS));
+    return U * finv;
+  }
   alpha = finv * ((mlp_eval_any(L, Hb + dH, gS) - mlp_eval_any(L, Hb - dH, gS)) / (2.0 * dH));
   beta = finv * ((mlp_eval_any(L, Hb, gS + dS) - mlp_eval_any(L, Hb, gS - dS)) / (2.0 * dS));
   return mlp_eval_any(L, Hb, gS) * finv;
