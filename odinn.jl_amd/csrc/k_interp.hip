@@ -456,6 +456,75 @@ int launch_interp_theta_batch(hipStream_t st, Pools P, const LawDev& L, int n_ha
   return 0;
 }
 
+// ---- exact per-node backprop of emitted node weights (`interpolation = :None` in the surface-velocity pull-backs) -----------------
+// dth[g] (+)= sum over the dual nodes of glacier g of V[node] * d law / d theta at the node's inputs -- (T_g, Hbar) for the Y law,
+// (Hbar, |grad S|) for the U law -- with the node weights V and inputs emitted by the velocity kernels (k_surfV_vjp: emitH / emitV /
+// emitS).  Wave-reduced like k_law_field_grad_wave: P accumulators per wavefront in LDS, chunks of 64 nodes, chunks without weight
+// skipped, fixed summation order.  The velocity kernels used to keep P accumulators per THREAD in global memory (2 x 8 B x P of
+// traffic per node: 1.48 ms per call at 8 x 512^2 for the 83-parameter default net, ten times a reverse stage).
+constexpr int NBP_BLK = 64;  // workgroups per glacier
+template <class AR, bool FIXED>
+__global__ __launch_bounds__(NT) void k_node_backprop(Pools P, LawDev L, int g0, int g_last, long long end_all,
+                                                      const double* __restrict__ nodeH, const double* __restrict__ nodeS,
+                                                      const double* __restrict__ nodeV, double* __restrict__ part) {
+  extern __shared__ double nb_dyn[];
+  __shared__ double stage[NW][WG_SLOTS][WG_LD];
+  double* accs = nb_dyn;
+  int* order = reinterpret_cast<int*>(nb_dyn + (size_t)NW * L.P);
+  const int lane = threadIdx.x & 63, w = wave_id();
+  for (int k = threadIdx.x; k < NW * L.P; k += NT) accs[k] = 0.0;
+  if (threadIdx.x == 0) mlp_grad_order(L, order);
+  __syncthreads();
+  const WaveAcc A{stage[w], order, accs + (size_t)w * L.P};
+  const int gidx = g0 + blockIdx.y;
+  const long long off = P.gd[gidx].offd, n = seg_len(P, gidx, g_last, end_all);
+  const double T = P.gd[gidx].T;
+  const long long nchunk = (n + 63) / 64;
+  for (long long c = (long long)blockIdx.x * NW + w; c < nchunk; c += (long long)gridDim.x * NW) {
+    const long long i = c * 64 + lane;
+    const bool ok = i < n;
+    const double wgt = ok ? nodeV[off + i] : 0.0;
+    if (__builtin_amdgcn_ballot_w64(wgt != 0.0) == 0) continue;
+    const double hb = ok ? nodeH[off + i] : 0.0;
+    if (L.kind == 3) mlp_grad_wave<AR, FIXED>(L, T, hb, wgt, A, lane);
+    else mlp_grad_wave<AR, FIXED>(L, hb, ok ? nodeS[off + i] : 0.0, wgt, A, lane);
+  }
+  __syncthreads();
+  double* out = part + ((size_t)blockIdx.y * NBP_BLK + blockIdx.x) * L.P;
+  for (int k = threadIdx.x; k < L.P; k += NT) {
+    double s = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) s += accs[(size_t)ww * L.P + k];
+    out[k] = s;
+  }
+}
+__global__ __launch_bounds__(64) void k_node_backprop_sum(int Pn, int g0, const double* __restrict__ part, double* __restrict__ dth,
+                                                          int accumulate) {
+  const int k = blockIdx.x, g = blockIdx.y;
+  double s = 0.0;
+  for (int bl = 0; bl < NBP_BLK; ++bl) s += part[((size_t)g * NBP_BLK + bl) * Pn + k];  // fixed order
+  if (threadIdx.x == 0) {
+    double* o = dth + (size_t)(g0 + g) * Pn + k;
+    *o = accumulate ? *o + s : s;
+  }
+}
+size_t node_backprop_part_count(int ng, int Pn) { return (size_t)ng * NBP_BLK * Pn; }
+// glaciers [g0, g0 + ng); nodeH / nodeS / nodeV point at the POOL's first dual node; part: node_backprop_part_count doubles
+int launch_node_backprop(hipStream_t st, Pools P, const LawDev& L, int g0, int ng, long long end_all, const double* nodeH,
+                         const double* nodeS, const double* nodeV, double* part, double* dth, int accumulate) {
+  const size_t dyn = interp_batch_lds_bytes(L.P);
+  if (dyn > 30 * 1024) return 1;
+  const dim3 grid(NBP_BLK, ng);
+  if (interp_law_is<ArchDef>(L))
+    hipLaunchKernelGGL((k_node_backprop<ArchDef, true>), grid, dim3(NT), dyn, st, P, L, g0, g0 + ng - 1, end_all, nodeH, nodeS, nodeV, part);
+  else if (interp_law_is<Arch16>(L))
+    hipLaunchKernelGGL((k_node_backprop<Arch16, true>), grid, dim3(NT), dyn, st, P, L, g0, g0 + ng - 1, end_all, nodeH, nodeS, nodeV, part);
+  else
+    hipLaunchKernelGGL((k_node_backprop<ArchRT, false>), grid, dim3(NT), dyn, st, P, L, g0, g0 + ng - 1, end_all, nodeH, nodeS, nodeV, part);
+  hipLaunchKernelGGL(k_node_backprop_sum, dim3(L.P, ng), dim3(64), 0, st, L.P, g0, part, dth, accumulate);
+  return 0;
+}
+
 // scratch: sH, sV (nd doubles each), tmp (interp_sort_temp_bytes), knots (KMAX), M (int), G (P * KMAX), ab (2 * KMAX)
 int launch_interp_theta(hipStream_t st, const LawDev& L, double T, int n_half, const double* nodeH, const double* nodeV,
                         long long nd, double* sH, double* sV, void* tmp, size_t tmp_bytes, double* knots, int* M, double* G,

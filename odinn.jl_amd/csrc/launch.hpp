@@ -40,6 +40,9 @@ void launch_vjp_theta_strip(int gacc, int itp, int nblk, hipStream_t st, Pools P
 constexpr int INTERP_KMAX = 512;
 size_t interp_batch_temp_bytes(long long n_max);
 size_t interp_batch_lds_bytes(int P);
+size_t node_backprop_part_count(int ng, int Pn);
+int launch_node_backprop(hipStream_t st, Pools P, const LawDev& L, int g0, int ng, long long end_all, const double* nodeH,
+                         const double* nodeS, const double* nodeV, double* part, double* dth, int accumulate);
 void launch_fill_gid(hipStream_t st, Pools P, int G, long long ntotd, unsigned* gid, unsigned* iota);
 int launch_interp_theta_batch(hipStream_t st, Pools P, const LawDev& L, int n_half, int g0, int ng, long long lo, long long n,
                               const double* nodeH, const double* nodeV, const unsigned* gid, const unsigned* iota, double* sH,

@@ -1870,20 +1870,23 @@ static int interp_contract(odinn_batch* b, int g, bool linU, bool accumulate, co
 // theta-part of a surface-velocity pull-back with a per-node network (U and Y laws): where the node contributions go ...
 static int vel_theta_args(odinn_batch* b, VArgs& A, int g) {
   if (!b->vel_nn()) return ODINN_OK;
-  CHK(ensure_theta_scratch(b, g < 0 ? b->ntiles : b->gd[g].ntiles));
-  if (b->vel_emit()) {
-    CHK(interp_prepare(b, g, b->vel_emit_U()));
-    A.emitH = b->d_nodeH; A.emitV = b->d_nodeV; A.emitS = b->vel_emit_U() ? b->d_nodeS : nullptr;
-  } else {
-    A.gscratch = b->d_gscratch; A.part_theta = b->d_part_theta;
-  }
+  CHK(ensure_theta_scratch(b, std::max(g < 0 ? b->ntiles : b->gd[g].ntiles, (int)node_backprop_part_count(g < 0 ? b->G : 1, 1)), false));
+  // the kernels EMIT (Hbar, weight[, |grad S|]) per dual node; vel_theta_finish turns them into dtheta: through the knot / node-grid
+  // interpolation (`:Linear`) or by exact backprop at every node (`:None`, launch_node_backprop)
+  const bool U = b->law_kind == ODINN_LAW_NN_U;
+  CHK(interp_prepare(b, g, U));
+  A.emitH = b->d_nodeH; A.emitV = b->d_nodeV; A.emitS = U ? b->d_nodeS : nullptr;
   return ODINN_OK;
 }
 // ... and their reduction into d_dth after the launch (added onto what is there unless !accumulate)
 static int vel_theta_finish(odinn_batch* b, int g, bool accumulate, const Pools& P) {
   if (!b->vel_nn()) return ODINN_OK;
   if (b->vel_emit()) return interp_contract(b, g, b->vel_emit_U(), accumulate, P);
-  launch_sum_part_theta(b->P, g < 0 ? b->G : 1, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g < 0 ? 0 : g);
+  const int g0 = g < 0 ? 0 : g, ng = g < 0 ? b->G : 1;
+  if (launch_node_backprop(b->stream, P, b->lawdev(), g0, ng, b->ntotd, b->d_nodeH, b->d_nodeS, b->d_nodeV, b->d_part_theta, b->d_dth,
+                           accumulate ? 1 : 0))
+    return fail(ODINN_ERR_UNSUPPORTED, "the network has too many parameters for the per-node backprop of the velocity pull-back");
+  HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
 
@@ -2865,7 +2868,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
         } else {
           launch_vref_itp(b->ntiles, b->stream, Pl, VI);
           launch_vref_scale(G, b->stream, Pl, b->d_adj, b->d_rvA, b->v_scale_loss, wq, b->d_vscq, b->d_wvq);
-          if (b->vel_emit()) CHK(interp_prepare(b, -1, b->vel_emit_U()));
+          if (b->vel_nn()) CHK(interp_prepare(b, -1, b->law_kind == ODINN_LAW_NN_U));  // (the node arrays are re-emitted at every node)
           launch_surfV_vjp(lm, 1, b->ntiles, b->stream, Pl, L, VQ, 0);
           if (b->vel_nn()) CHK(vel_theta_finish(b, -1, true, Pl));
           else launch_sum_part(G, b->stream, Pl, 3, b->d_Gsum, 1, 0);

@@ -170,16 +170,14 @@ struct VArgs {
   // the row is the snapshot the glacier's reverse solve just reached (nothing to do otherwise)
   const AdjState* adj;
   int G;
-  // U law (target :D): 1 / f_surface_velocity_factor, and the thread-private scratch / per-tile rows of the per-node
-  // backprop of dU/dtheta (null: the theta-part is not wanted)
+  // U law (target :D): 1 / f_surface_velocity_factor
   double finv;
-  double* gscratch;
-  double* part_theta;
-  // Y law (target :D_hybrid) with `:Linear` interpolation of the law gradient: per owned dual node, Hbar and the node weight
-  // (dual pooled arrays, pre-zeroed by the caller) instead of the per-node backprop
+  // per-node-network laws: the theta-part is EMITTED -- per owned dual node Hbar, the node weight and (U law) |grad S| into dual
+  // pooled arrays the caller zeroed; the host contracts them with d law / d theta (per node or through the target's `:Linear`
+  // interpolation).  null: the theta-part is not wanted
   double* emitH;
   double* emitV;
-  double* emitS;  // U law (target :D) with `:Linear`: |grad S| of the node as well (second axis of LawU's gradient interpolant)
+  double* emitS;
 };
 
 template <int MODE, int LM>
@@ -198,8 +196,6 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
     wv = (P.gs[t4.x].at_stop && j >= 0) ? A.wv[q] : 0.0;
     if (wv == 0.0) {
       if (threadIdx.x == 0) { P.part[4 * (long long)t4.w + 3] = 0.0; P.part[4 * (long long)t4.w + 1] = 0.0; }
-      if (LM == LM_NN && A.part_theta)
-        for (int k = threadIdx.x; k < L.P; k += NT) A.part_theta[(long long)t4.w * L.P + k] = 0.0;
       return;
     }
     sc = A.scale[q];
@@ -208,8 +204,6 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
     wv = A.wv[t4.x];
     if (wv == 0.0) {  // no velocity data at this stop for this glacier
       if (threadIdx.x == 0) { P.part[4 * (long long)t4.w + 3] = 0.0; if (MODE == 1) P.part[4 * (long long)t4.w + 1] = 0.0; }
-      if (LM == LM_NN && A.part_theta)
-        for (int k = threadIdx.x; k < L.P; k += NT) A.part_theta[(long long)t4.w * L.P + k] = 0.0;
       return;
     }
     if (MODE == 1) {
@@ -224,10 +218,6 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
   __syncthreads();
   const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
   double gsum = 0.0, lsum = 0.0;
-  const long long gstride = (long long)gridDim.x * NT;
-  double* gth = (LM == LM_NN && A.gscratch) ? A.gscratch + ((long long)blockIdx.x * NT + threadIdx.x) : nullptr;
-  if (gth)
-    for (int k = 0; k < L.P; ++k) gth[(long long)k * gstride] = 0.0;
   for (int idx = threadIdx.x; idx < NNODE; idx += NT) {
     const int b = idx / (TX + 1), a = idx - b * (TX + 1);
     const int gi = i0 - 1 + a, gj = j0 - 1 + b;
@@ -285,24 +275,22 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
       if (owned) {
         if constexpr (LM == LM_NN) {
           if (L.kind == 3) {
-            // Y law: dVelocity^/dtheta = spat x dY/dtheta(T, Hbar) -- exact backprop per node (:None), or, for the target's
-            // default `:Linear`, Hbar and the node weight emitted for the knot interpolation (k_interp.hip), as k_vjp_theta does
+            // Y law: dVelocity^/dtheta = spat x dY/dtheta(T, Hbar): Hbar and the node weight are EMITTED; the host then contracts
+            // them with dY/dtheta -- exact backprop at every node (:None, k_node_backprop) or through the knot interpolation
+            // (`:Linear`, the target's default; k_interp.hip), as k_vjp_theta does
             const double wn = -wv * W * sp;
-            if (A.emitH) {
+            if (A.emitH) {  // (ice-free nodes: spat = 0, the weight vanishes)
               const long long q = g.offd + gi + (long long)(g.nx - 1) * gj;
               A.emitH[q] = Hb;
               A.emitV[q] = wn;
-            } else if (gth && Hb > 0.0) {
-              mlp_grad(L, g.T, Hb, wn, gth, gstride);
             }
           } else if (A.emitH) {
-            // U law, `:Linear`: dVelocity^/dtheta = (Hbar > 0) grad_itp(Hbar, |grad S|) / f (target_D_pure.jl:179-193,247-255)
+            // U law: dVelocity^/dtheta = (Hbar > 0) dU/dtheta / f, emitted likewise: exact backprop per node (:None,
+            // target_D_pure.jl:163-176,247-255) or grad_itp(Hbar, |grad S|) on LawU's node grid (`:Linear`, :179-193)
             const long long q = g.offd + gi + (long long)(g.nx - 1) * gj;
             A.emitH[q] = Hb;
             A.emitV[q] = Hb > 0.0 ? -wv * W * A.finv : 0.0;
             A.emitS[q] = gS;
-          } else if (gth && Hb > 0.0) {  // U law: dVelocity^/dtheta = (Hbar > 0) dU/dtheta / f, exact backprop per node (:None branch)
-            mlp_grad(L, Hb, gS, -wv * W * A.finv, gth, gstride);
           }
         } else {
           const double t = sp * W;
@@ -335,12 +323,6 @@ __global__ __launch_bounds__(NT) void k_surfV_vjp(Pools P, LawDev L, VArgs A, in
   if (threadIdx.x == 0) {
     P.part[4 * (long long)t4.w + 3] = -wv * gt;             // enters dtheta as (dA/dtheta) * sum
     if (MODE == 1) P.part[4 * (long long)t4.w + 1] = lt * Ninv * sc * wv;
-  }
-  if (gth && A.part_theta) {
-    for (int k = 0; k < L.P; ++k) {
-      const double tot = block_sum(gth[(long long)k * gstride], red);
-      if (threadIdx.x == 0) A.part_theta[(long long)t4.w * L.P + k] = tot;
-    }
   }
 }
 
