@@ -1899,24 +1899,32 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   // of Y/U laws in d_dth[g][P]
   const bool nn_node = b->law_kind >= ODINN_LAW_NN_Y;
   const int base = g < 0 ? 0 : b->gd[g].tile0, nblk = g < 0 ? b->ntiles : b->gd[g].ntiles;
-  if (nn_node) CHK(ensure_theta_scratch(b, nblk));
+  const int ng = g < 0 ? b->G : 1, g0 = g < 0 ? 0 : g;
   const bool linear = b->law_kind >= ODINN_LAW_NN_Y && b->grad_interp == ODINN_GRAD_INTERP_LINEAR;
-  const bool linU = linear && b->law_kind == ODINN_LAW_NN_U;
-  if (linear) CHK(interp_prepare(b, g, linU));
+  const bool isU = b->law_kind == ODINN_LAW_NN_U;
+  // run-time architectures (law mode 2) with exact per-node backprop: the kernel emits (Hbar, weight[, |grad S|]) and
+  // k_node_backprop contracts them (wave-reduced); the compile-time architectures backpropagate inside k_vjp_theta_nn
+  const bool emit_rt = nn_node && !linear && b->lm() == 2 && (size_t)NW * b->P * sizeof(double) + (size_t)b->P * sizeof(int) <= 30 * 1024;
+  const bool emit = linear || emit_rt;
+  if (nn_node) CHK(ensure_theta_scratch(b, std::max(nblk, (int)node_backprop_part_count(ng, 1)), !emit));
+  if (emit) CHK(interp_prepare(b, g, isU));
   ThArgs A{};
-  A.emitH = linear ? b->d_nodeH : nullptr; A.emitV = linear ? b->d_nodeV : nullptr; A.emitS = linU ? b->d_nodeS : nullptr;
+  A.emitH = emit ? b->d_nodeH : nullptr; A.emitV = emit ? b->d_nodeV : nullptr; A.emitS = (emit && isU) ? b->d_nodeS : nullptr;
   A.H = H; A.lam = lam; A.lam_alt = lam_alt; A.scales = scales;
   A.snaps = snaps; A.adj = adj; A.ntot = b->ntot;
   A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
   A.part_theta = nn_node ? b->d_part_theta : nullptr;
-  A.gscratch = nn_node ? b->d_gscratch : nullptr;
+  A.gscratch = (nn_node && !emit) ? b->d_gscratch : nullptr;
   A.accum = (inplace && part_deferred && !nn_node) ? 1 : 0;
   Pools P = b->pools(g < 0);
   if (part_deferred) P.part = part_deferred;
   launch_vjp_theta(b, nblk, P, b->lawdev(), A, base);
-  const int ng = g < 0 ? b->G : 1, g0 = g < 0 ? 0 : g;
   if (linear) {
-    CHK(interp_contract(b, g, linU, accumulate, P));
+    CHK(interp_contract(b, g, isU, accumulate, P));
+  } else if (emit_rt) {
+    if (launch_node_backprop(b->stream, P, b->lawdev(), g0, ng, b->ntotd, b->d_nodeH, b->d_nodeS, b->d_nodeV, b->d_part_theta, b->d_dth,
+                             accumulate ? 1 : 0))
+      return fail(ODINN_ERR_HIP, "per-node backprop of the emitted node weights failed");
   } else if (part_deferred) {
   } else if (nn_node)
     launch_sum_part_theta(b->P, ng, b->stream, P, b->d_part_theta, b->d_dth, accumulate ? 1 : 0, g0);
