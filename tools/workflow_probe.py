@@ -2,7 +2,8 @@
   python tools/workflow_probe.py gridded [n G]    A = NN(T) on the dual grid (dual-grid accumulator), LossH and LossHV
   python tools/workflow_probe.py mb [n G]         scalar NN law + linear mass balance at every stop, LossH
   python tools/workflow_probe.py Y [n G]          Y = NN(T, Hbar) (target :D_hybrid, default :Linear interpolation), LossH
-  python tools/workflow_probe.py U [n G]          U = NN(Hbar, |grad S|) (target :D), LossH"""
+  python tools/workflow_probe.py U [n G]          U = NN(Hbar, |grad S|) (target :D), LossH
+  python tools/workflow_probe.py Y|U n G custom   the same with a run-time architecture (2-5-10-5-1, gelu x3 + softplus: law mode 2)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -39,7 +40,11 @@ else:
     model = odinn.SIA2Dmodel(P, **{what: (odinn.LawY if what == "Y" else odinn.LawU)(odinn.NeuralNetwork(P, architecture=odinn.build_default_NN(2), seed=666), P)})
     law = model.law
     theta = law.nn.theta
-    b.set_law(law.kind, law.mlp, theta, law.n_H, law.n_gradS)
+    mlp = law.mlp
+    if len(sys.argv) > 4 and sys.argv[4] == "custom":
+        mlp = odinn.MLPSpec([2, 5, 10, 5, 1], [odinn.ACT_GELU] * 3 + [odinn.ACT_SOFTPLUS], law.mlp.prescale, law.mlp.post_kind, law.mlp.post_lo, law.mlp.post_hi)
+        theta = rng.uniform(-0.5, 0.5, mlp.n_params)
+    b.set_law(law.kind, mlp, theta, law.n_H, law.n_gradS)
 ts = [2010.0 + j / 12.0 for j in range(k)]
 mbt = ts[1:] if what == "mb" else ()
 b.solve(ts, mb_times=mbt, reltol=1e-8)
