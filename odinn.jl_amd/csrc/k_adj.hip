@@ -1,4 +1,4 @@
-// k_adj.hip -- discrete-adjoint stencil kernels for one law mode (-DODINN_LM=0|1|2)
+// k_adj.hip -- discrete-adjoint stencil kernels for one law mode (-DODINN_LM=0 ... 6)
 // inlined-MLP laws: log1p's table lives in LDS in these kernels (mode 2: filled by the tile loader; see sia2d_device.hpp)
 #if defined(ODINN_LM) && ODINN_LM >= 2 && !defined(ODINN_LOG1P_TABLE)
 #define ODINN_LOG1P_TABLE 2
@@ -13,7 +13,7 @@
 namespace odinn {
 // Compile-time architectures (law modes 3..5): one instantiation per law kind (NK = 3: Y law, 4: U law; see node_D); the other
 // law modes read the kind from the descriptor (NK = 0)
-#if ODINN_LM >= 3
+#if ODINN_LM >= 3 && ODINN_LM <= 5
 #define ODINN_NK_DISPATCH(CALL) { if (L.kind == 3) { constexpr int NK = 3; CALL; } else { constexpr int NK = 4; CALL; } }
 #else
 #define ODINN_NK_DISPATCH(CALL) { constexpr int NK = 0; CALL; }
@@ -43,7 +43,7 @@ void CAT(launch_adj_stage_lm, ODINN_LM)(int stage, int vj, int nblk, hipStream_t
   ODINN_NK_DISPATCH((adj_stage_dispatch<0, NK>(stage, nblk, st, P, L, A)))
 }
 void CAT(launch_vjp_theta_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev L, ThArgs A, int base) {
-#if ODINN_LM >= 3
+#if ODINN_LM >= 3 && ODINN_LM <= 5
   if (A.emitH) {  // `:Linear` gradient interpolation: the kernel only emits (Hbar, node weight), no per-node backprop
     hipLaunchKernelGGL(k_vjp_theta<ODINN_LM>, dim3(nblk), dim3(NT), 0, st, P, L, A, base);
     return;

@@ -1,5 +1,5 @@
 // launch.hpp -- host-callable launch wrappers; each law mode (LM) of the stencil kernels is
-// compiled in its own translation unit (k_fwd.hip / k_adj.hip with -DODINN_LM=0|1|2).
+// compiled in its own translation unit (k_fwd.hip / k_adj.hip / k_fused.hip with -DODINN_LM=0 ... 6).
 #pragma once
 #include "sia2d_device.hpp"
 
@@ -21,6 +21,7 @@ ODINN_DECL_LM(2)
 ODINN_DECL_LM(3)
 ODINN_DECL_LM(4)
 ODINN_DECL_LM(5)
+ODINN_DECL_LM(6)
 #undef ODINN_DECL_LM
 
 // k_fused.hip, law mode 0 only

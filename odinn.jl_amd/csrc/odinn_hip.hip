@@ -270,6 +270,8 @@ struct odinn_batch {
   odinn_mlp_desc mlp{};
   std::vector<double> theta;
   double* d_theta = nullptr;
+  double* d_theta_pad = nullptr;  // run-time architectures: padded weight rows + biases (LawDev::theta_pad / bias_pad)
+  int pad_rows = 0, pad_w = 16;
   int P = 0;
   double nH = -1, nS = -1;
   bool has_Afield_const = false;
@@ -405,6 +407,8 @@ struct odinn_batch {
       if (is(4, {2, 3, 10, 3, 1}, {1, 1, 1, 2})) return LM_NN_DEF;
       if (is(3, {2, 16, 16, 1}, {1, 1, 2})) return LM_NN_16;
       if (is(2, {2, 3, 1}, {1, 2})) return LM_NN_LIGHT;
+      for (int l = 0; l < mlp.n_layers; ++l)
+        if (mlp.widths[l] > 16) return LM_NN_WIDE;  // (a layer's INPUTS: the padded weight rows are 32 wide)
       return LM_NN;
     }
     for (const GDev& r : gd)
@@ -443,6 +447,8 @@ struct odinn_batch {
     L.post_lo = mlp.post_lo;
     L.post_hi = mlp.post_hi;
     L.theta = d_theta;
+    L.theta_pad = d_theta_pad;
+    L.bias_pad = d_theta_pad ? d_theta_pad + (size_t)pad_rows * pad_w : nullptr;
     return L;
   }
 };
@@ -577,8 +583,8 @@ int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */
   }
   const Pools P = b->pools(g < 0);
   const int base = g < 0 ? 0 : b->gd[g].tile0, n = g < 0 ? b->ntiles : b->gd[g].ntiles;
-  static void (*const tab[6])(int, hipStream_t, Pools, LawDev, const double*, double*, int) = {
-      launch_dhdt_lm0, launch_dhdt_lm1, launch_dhdt_lm2, launch_dhdt_lm3, launch_dhdt_lm4, launch_dhdt_lm5};
+  static void (*const tab[7])(int, hipStream_t, Pools, LawDev, const double*, double*, int) = {
+      launch_dhdt_lm0, launch_dhdt_lm1, launch_dhdt_lm2, launch_dhdt_lm3, launch_dhdt_lm4, launch_dhdt_lm5, launch_dhdt_lm6};
   tab[b->lm()](n, b->stream, P, b->lawdev(), U, dH, base);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
@@ -587,16 +593,16 @@ int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */
 template <int S>
 void launch_stage(odinn_batch* b, const Pools& P, const LawDev& L, const double* src, double* dst, double abstol,
                   double reltol) {
-  static void (*const tab[6])(int, int, hipStream_t, Pools, LawDev, const double*, double*, double*, double*, double*,
+  static void (*const tab[7])(int, int, hipStream_t, Pools, LawDev, const double*, double*, double*, double*, double*,
                               double, double) = {launch_rk_stage_lm0, launch_rk_stage_lm1, launch_rk_stage_lm2,
-                                                 launch_rk_stage_lm3, launch_rk_stage_lm4, launch_rk_stage_lm5};
+                                                 launch_rk_stage_lm3, launch_rk_stage_lm4, launch_rk_stage_lm5, launch_rk_stage_lm6};
   tab[b->lm()](S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol);
 }
 // vj < 0: the batch's VJP method (odinn_set_vjp_method)
 void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawDev& L, const AdjArgs& A, int base,
                   int vj = -1) {
-  static void (*const tab[6])(int, int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
-      launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5};
+  static void (*const tab[7])(int, int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
+      launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5, launch_vjp_H_lm6};
   // integer-power law, DiscreteVJP, all glaciers at once: the strip-layout kernel on the 62 x 62 tile table
   // (sia2d_adj_fused.hpp: k_vjp_H_strip; ODINN_VJPH_STRIP=0 keeps the 64 x 16 LDS-tile kernel) ...
   // ... where its 62 x 62 tiles are reasonably full: batches of small glaciers (alpine: 96 x 80 ... 192 x 160 fill them to
@@ -614,15 +620,15 @@ void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawD
 }
 void launch_adj_stage(int lm, int vj, int stage, int nblk, hipStream_t st, const Pools& P, const LawDev& L,
                       const AdjStageArgs& A) {
-  static void (*const tab[6])(int, int, int, hipStream_t, Pools, LawDev, AdjStageArgs) = {
+  static void (*const tab[7])(int, int, int, hipStream_t, Pools, LawDev, AdjStageArgs) = {
       launch_adj_stage_lm0, launch_adj_stage_lm1, launch_adj_stage_lm2, launch_adj_stage_lm3, launch_adj_stage_lm4,
-      launch_adj_stage_lm5};
+      launch_adj_stage_lm5, launch_adj_stage_lm6};
   tab[lm](stage, vj, nblk, st, P, L, A);
 }
 void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L, const ThArgs& A, int base) {
-  static void (*const tab[6])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
+  static void (*const tab[7])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
       launch_vjp_theta_lm0, launch_vjp_theta_lm1, launch_vjp_theta_lm2, launch_vjp_theta_lm3, launch_vjp_theta_lm4,
-      launch_vjp_theta_lm5};
+      launch_vjp_theta_lm5, launch_vjp_theta_lm6};
   // integer-power A-type laws, all glaciers at once: the strip-layout reduction (k_vjp_theta_strip), under the same
   // tile-fullness rule as k_vjp_H_strip; ODINN_VJPTH_STRIP=0/1 forces the choice
   const int se = sched_val(b->sched.vjpth_strip, "ODINN_VJPTH_STRIP");
@@ -644,9 +650,9 @@ void launch_euler_cfl(odinn_batch* b, const Pools& P, const LawDev& L, const dou
     launch_euler_cfl_strip(b->ntilesD, b->gd[0].use_Afield, b->stream, P, b->d_tilesD, src, dst, b->d_partD);
     return;
   }
-  static void (*const tab[6])(int, hipStream_t, Pools, LawDev, const double*, double*) = {
+  static void (*const tab[7])(int, hipStream_t, Pools, LawDev, const double*, double*) = {
       launch_euler_cfl_lm0, launch_euler_cfl_lm1, launch_euler_cfl_lm2, launch_euler_cfl_lm3, launch_euler_cfl_lm4,
-      launch_euler_cfl_lm5};
+      launch_euler_cfl_lm5, launch_euler_cfl_lm6};
   tab[b->lm()](b->ntiles, b->stream, P, L, src, dst);
 }
 
@@ -700,8 +706,8 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
     launch_rk_fused_strip(nblk, b->gd[0].use_Afield, small == 3 ? 8 : TRPT, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol,
                           reltol, skip, sc, sq ? 1 : 0);
   } else {
-    static void (*const tab[6])(int, hipStream_t, Pools, LawDev, const int4*, double*, double*, double*, double, double, int, int) = {
-        launch_rk_fused_lm0, launch_rk_fused_lm1, launch_rk_fused_lm2, launch_rk_fused_lm3, launch_rk_fused_lm4, launch_rk_fused_lm5};
+    static void (*const tab[7])(int, hipStream_t, Pools, LawDev, const int4*, double*, double*, double*, double, double, int, int) = {
+        launch_rk_fused_lm0, launch_rk_fused_lm1, launch_rk_fused_lm2, launch_rk_fused_lm3, launch_rk_fused_lm4, launch_rk_fused_lm5, launch_rk_fused_lm6};
     tab[b->lm()](nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
   }
   HIPCHK(hipGetLastError());
@@ -1568,7 +1574,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_partsteps);
   dfree(b->d_rvA); dfree(b->d_rvB); dfree(b->d_zeroslot); dfree(b->d_rvs); dfree(b->d_Vq); dfree(b->d_vscq); dfree(b->d_wvq);
   dfree(b->d_rega); dfree(b->d_regr); dfree(b->d_regg); dfree(b->d_regp); dfree(b->d_regm);
-  dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
+  dfree(b->d_lossacc); dfree(b->d_Gsum); dfree(b->d_theta); dfree(b->d_theta_pad); dfree(b->d_snaps); dfree(b->d_premb); dfree(b->d_Href);
   dfree(b->d_mask); dfree(b->d_part_theta); dfree(b->d_gscratch); dfree(b->d_dth); dfree(b->d_tstops);
   dfree(b->d_snapslot); dfree(b->d_nst); dfree(b->d_mbf_res); dfree(b->d_mbs_res); dfree(b->d_nr); dfree(b->d_ksn); dfree(b->d_lastseg);
   dfree(b->d_zerow); dfree(b->d_swq); dfree(b->d_sgq); dfree(b->d_rhid);
@@ -1668,6 +1674,31 @@ int odinn_set_theta(odinn_batch* b, const double* theta, int P) {
   if (P != b->P || !theta) return fail(ODINN_ERR_ARG, "theta has %d entries, law expects %d", P, b->P);
   b->theta.assign(theta, theta + P);
   HIPCHK(hipMemcpyAsync(b->d_theta, theta, sizeof(double) * P, hipMemcpyHostToDevice, b->stream));
+  {  // the padded rows mlp_eval_rt reads: unit o of layer l -> row (units of the layers before) + o; theta keeps Lux's
+     // layout (weight out x in column-major, then bias, layer after layer)
+    int rows = 0, mw = 1;
+    for (int l = 0; l < b->mlp.n_layers; ++l) { rows += b->mlp.widths[l + 1]; mw = std::max(mw, b->mlp.widths[l]); }
+    const int W = mw <= 16 ? 16 : 32;
+    if (rows != b->pad_rows || W != b->pad_w || !b->d_theta_pad) {
+      dfree(b->d_theta_pad);
+      b->d_theta_pad = nullptr;
+      CHK(dalloc(&b->d_theta_pad, (size_t)rows * (W + 1) + W + 1));  // (+ one spare row and bias: the evaluator reads one unit ahead)
+      b->pad_rows = rows; b->pad_w = W;
+    }
+    std::vector<double> pad((size_t)rows * (W + 1) + W + 1, 0.0);
+    int off = 0, r0 = 0;
+    for (int l = 0; l < b->mlp.n_layers; ++l) {
+      const int nin = b->mlp.widths[l], nout = b->mlp.widths[l + 1];
+      for (int o = 0; o < nout; ++o) {
+        for (int i = 0; i < nin; ++i) pad[(size_t)(r0 + o) * W + i] = theta[off + o + nout * i];
+        pad[(size_t)rows * W + r0 + o] = theta[off + nin * nout + o];
+      }
+      off += nout * (nin + 1);
+      r0 += nout;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_theta_pad, pad.data(), sizeof(double) * pad.size(), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));  // (pad is a local)
+  }
   HIPCHK(hipStreamSynchronize(b->stream));
   b->gd_dirty = true;
   return ODINN_OK;
@@ -1904,7 +1935,7 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   const bool isU = b->law_kind == ODINN_LAW_NN_U;
   // run-time architectures (law mode 2) with exact per-node backprop: the kernel emits (Hbar, weight[, |grad S|]) and
   // k_node_backprop contracts them (wave-reduced); the compile-time architectures backpropagate inside k_vjp_theta_nn
-  const bool emit_rt = nn_node && !linear && b->lm() == 2 && (size_t)NW * b->P * sizeof(double) + (size_t)b->P * sizeof(int) <= 30 * 1024;
+  const bool emit_rt = nn_node && !linear && lm_is_rt(b->lm()) && (size_t)NW * b->P * sizeof(double) + (size_t)b->P * sizeof(int) <= 30 * 1024;
   const bool emit = linear || emit_rt;
   if (nn_node) CHK(ensure_theta_scratch(b, std::max(nblk, (int)node_backprop_part_count(ng, 1)), !emit));
   if (emit) CHK(interp_prepare(b, g, isU));

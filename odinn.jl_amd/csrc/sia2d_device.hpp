@@ -159,6 +159,10 @@ struct LawDev {  // passed by value to kernels
   double pre_lo[2], pre_inv[2];
   double post_lo, post_hi;
   const double* theta;  // device
+  // run-time architectures: one zero-padded row of `padw` (16 | 32) weights per unit, rows in layer / unit order, and the
+  // biases in the same order (odinn_set_theta repacks them) -- a unit's weights are then ONE aligned scalar load
+  const double* theta_pad;
+  const double* bias_pad;
 };
 
 struct Pools {  // pooled device arrays (all glaciers concatenated)
@@ -417,64 +421,74 @@ __device__ __forceinline__ double dpostscale_f(const LawDev& L, double y) {
   }
 }
 
-// Per-lane MLP evaluation (_pred_NN, src/laws/Laws.jl:34-36).  Weights are read with
-// wave-uniform indices (scalar loads through the constant cache); activations live in
-// registers: every index is a compile-time constant, widths are applied as uniform
-// predicates.
-template <int MAXW>
-__device__ __noinline__ double mlp_eval(const LawDev& L, double x0, double x1) {
-  double h[MAXW];
-#pragma unroll
-  for (int i = 0; i < MAXW; ++i) h[i] = 0.0;
+// Per-lane MLP evaluation (_pred_NN, src/laws/Laws.jl:34-36) for run-time architectures; weights are read with wave-uniform
+// addresses (scalar loads through the constant cache), activations live in registers.
+#ifndef ODINN_RT_PREFETCH
+#define ODINN_RT_PREFETCH 1
+#endif
+// Rolled: ONE copy of the unit code (a padded row of weights through one scalar load, MW multiply-adds at compile-time register
+// indices -- the padding multiplies zeros -- one activation, chosen by a uniform branch) looped over the units of a layer and
+// over the layers; the unit's result goes to z[o] with a wave-uniform dynamic register index (s_set_gpr_idx).  Summation order
+// = bias, then the inputs in ascending order, as everywhere else.  (Until round 4 this was a fully unrolled, width-predicated
+// evaluator behind a function call: 16 inlined copies of EVERY activation per layer, its descriptor and weights read with
+// per-lane flat loads because nothing was provably uniform across the call -- 7.5x the default architecture's forward stage
+// and 13x its reverse stage at 8 x 512^2; now 2.3x and 3.2x, profiles/r04/rt_arch.txt.)
+template <int MW>
+__device__ __forceinline__ double mlp_eval_rt(const LawDev& L, double x0, double x1) {
+  typedef double vec __attribute__((ext_vector_type(MW)));
+  vec h = 0.0;
   h[0] = L.has_pre ? (x0 - L.pre_lo[0]) * L.pre_inv[0] - 0.5 : x0;
-  if (MAXW > 1 && L.widths[0] > 1) h[1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
-  const double* __restrict__ th = L.theta;
-  int off = 0;
+  if (L.widths[0] > 1) h[1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
+  const double* __restrict__ w = L.theta_pad;
+  const double* __restrict__ bz = L.bias_pad;
+#if ODINN_RT_PREFETCH
+  // the NEXT unit's row is requested before this unit's arithmetic (the table ends with one spare row): at the two
+  // wavefronts per SIMD these kernels run at, nothing else hides the scalar-cache latency
+  constexpr bool PF = MW <= 16;  // (two rows of 32 weights do not fit the scalar registers)
+#else
+  constexpr bool PF = false;
+#endif
+  double wc[MW], bc = 0.0;
+  if constexpr (PF) {
+#pragma unroll
+    for (int i = 0; i < MW; ++i) wc[i] = w[i];
+    bc = bz[0];
+  }
+#pragma nounroll
   for (int l = 0; l < L.n_layers; ++l) {
-    const int nin = L.widths[l], nout = L.widths[l + 1], a = L.acts[l];
-    double z[MAXW];
+    const int nout = L.widths[l + 1], a = L.acts[l];
+    vec z = 0.0;
+#pragma nounroll
+    for (int o = 0; o < nout; ++o, w += MW, ++bz) {
+      double acc;
+      if constexpr (PF) {
+        double wn[MW];
 #pragma unroll
-    for (int o = 0; o < MAXW; ++o) {
-      z[o] = 0.0;
-      if (o < nout) {
-        double acc = th[off + nin * nout + o];
+        for (int i = 0; i < MW; ++i) wn[i] = w[MW + i];
+        const double bn = bz[1];
+        acc = bc;
 #pragma unroll
-        for (int i = 0; i < MAXW; ++i)
-          if (i < nin) acc = fma(th[off + o + nout * i], h[i], acc);
+        for (int i = 0; i < MW; ++i) acc = fma(wc[i], h[i], acc);
+        z[o] = act_f(a, acc);
+#pragma unroll
+        for (int i = 0; i < MW; ++i) wc[i] = wn[i];
+        bc = bn;
+      } else {
+        acc = bz[0];
+#pragma unroll
+        for (int i = 0; i < MW; ++i) acc = fma(w[i], h[i], acc);
         z[o] = act_f(a, acc);
       }
     }
-#pragma unroll
-    for (int o = 0; o < MAXW; ++o) h[o] = z[o];
-    off += nout * (nin + 1);
+    h = z;
   }
   return postscale_f(L, h[0]);
 }
 
-// wide nets (17..32 units): activations in scratch, plain loops (rare, slow path)
-inline __device__ __noinline__ double mlp_eval_wide(const LawDev& L, double x0, double x1) {
-  double h[32], z[32];
-  h[0] = L.has_pre ? (x0 - L.pre_lo[0]) * L.pre_inv[0] - 0.5 : x0;
-  h[1] = L.has_pre ? (x1 - L.pre_lo[1]) * L.pre_inv[1] - 0.5 : x1;
-  const double* __restrict__ th = L.theta;
-  int off = 0;
-  for (int l = 0; l < L.n_layers; ++l) {
-    const int nin = L.widths[l], nout = L.widths[l + 1], a = L.acts[l];
-    for (int o = 0; o < nout; ++o) {
-      double acc = th[off + nin * nout + o];
-      for (int i = 0; i < nin; ++i) acc = fma(th[off + o + nout * i], h[i], acc);
-      z[o] = act_f(a, acc);
-    }
-    for (int o = 0; o < nout; ++o) h[o] = z[o];
-    off += nout * (nin + 1);
-  }
-  return postscale_f(L, h[0]);
-}
-
+// (kernels that are not instantiated per law mode: the velocity kernels, the hoisted law field, the seams)
 __device__ __forceinline__ double mlp_eval_any(const LawDev& L, double x0, double x1) {
-  if (L.maxw <= 4) return mlp_eval<4>(L, x0, x1);
-  if (L.maxw <= 16) return mlp_eval<16>(L, x0, x1);
-  return mlp_eval_wide(L, x0, x1);
+  if (L.maxw <= 16) return mlp_eval_rt<16>(L, x0, x1);
+  return mlp_eval_rt<32>(L, x0, x1);
 }
 
 // g[k*stride] += wgt * d out / d theta_k at one input (exact backprop; stands in for the
@@ -630,8 +644,11 @@ __device__ __forceinline__ void mlp_grad_wave(const LawDev& L, double x0, double
 //   3: 2 -> 3 -> 10 -> 3 -> 1, softplus x3 + sigmoid   (build_default_NN, ML_utils.jl:31-36)
 //   4: 2 -> 16 -> 16 -> 1,     softplus x2 + sigmoid   (BASELINE configs[2], "2 layers x 16 units")
 //   5: 2 -> 3 -> 1,            softplus + sigmoid      (test_mode light net, ML_utils.jl:26-29)
-constexpr int LM_FAST = 0, LM_POW = 1, LM_NN = 2, LM_NN_DEF = 3, LM_NN_16 = 4, LM_NN_LIGHT = 5;
+constexpr int LM_FAST = 0, LM_POW = 1, LM_NN = 2, LM_NN_DEF = 3, LM_NN_16 = 4, LM_NN_LIGHT = 5, LM_NN_WIDE = 6;
 constexpr bool lm_is_nn(int lm) { return lm >= LM_NN; }
+// run-time architectures: LM_NN (every layer has <= 16 inputs) and LM_NN_WIDE (<= 32) -- kernels of their own, the 32-wide
+// evaluator holds 128 registers of activations and would set the register allocation of the common case
+constexpr bool lm_is_rt(int lm) { return lm == LM_NN || lm == LM_NN_WIDE; }
 
 struct ArchDef   { static constexpr int NL = 4, MAXW = 10; static constexpr int W[5] = {2, 3, 10, 3, 1}; static constexpr int A[4] = {1, 1, 1, 2}; };
 struct Arch16    { static constexpr int NL = 3, MAXW = 16; static constexpr int W[4] = {2, 16, 16, 1};   static constexpr int A[3] = {1, 1, 2}; };
@@ -683,7 +700,8 @@ __device__ __forceinline__ double mlp_eval_lm(const LawDev& L, double x0, double
   if constexpr (LM == LM_NN_DEF) return mlp_eval_fixed<ArchDef>(L, x0, x1);
   else if constexpr (LM == LM_NN_16) return mlp_eval_fixed<Arch16>(L, x0, x1);
   else if constexpr (LM == LM_NN_LIGHT) return mlp_eval_fixed<ArchLight>(L, x0, x1);
-  else return mlp_eval_any(L, x0, x1);
+  else if constexpr (LM == LM_NN_WIDE) return mlp_eval_rt<32>(L, x0, x1);
+  else return mlp_eval_rt<16>(L, x0, x1);
 }
 
 // ---- the network at x AND at x + delta e_d for a few tiny perturbations, for the price of ~1.5 evaluations ----------------
@@ -889,10 +907,24 @@ __device__ __forceinline__ double mlp_eval_pert_lm(const LawDev& L, double x0, d
   if constexpr (LM == LM_NN_DEF) return mlp_eval_pert<ArchDef, NP>(L, x0, x1, pd, dlt, yp);
   else if constexpr (LM == LM_NN_16) return mlp_eval_pert<Arch16, NP>(L, x0, x1, pd, dlt, yp);
   else if constexpr (LM == LM_NN_LIGHT) return mlp_eval_pert<ArchLight, NP>(L, x0, x1, pd, dlt, yp);
-  else {  // run-time architecture (any activation): direct evaluations
+  else {  // run-time architecture (any activation): direct evaluations, ONE inlined copy of the evaluator looped over the points
+    double yc = 0.0;
 #pragma unroll 1
-    for (int q = 0; q < NP; ++q) yp[q] = mlp_eval_any(L, pd[q] == 0 ? x0 + dlt[q] : x0, pd[q] == 1 ? x1 + dlt[q] : x1);
-    return mlp_eval_any(L, x0, x1);
+    for (int q = 0; q <= NP; ++q) {
+      double a0 = x0, a1 = x1;
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        if (q == k) {
+          if (pd[k] == 0) a0 = x0 + dlt[k];
+          else a1 = x1 + dlt[k];
+        }
+      const double v = mlp_eval_lm<LM>(L, a0, a1);
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        if (q == k) yp[k] = v;
+      if (q == NP) yc = v;
+    }
+    return yc;
   }
 }
 
@@ -974,7 +1006,7 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
     //  was measured at +5 ... +10 % on the Y law's reverse kernels, its Taylor coefficients cost what the second evaluation costs;
     //  -DODINN_PERT_Y=1 selects it)
     double Y, Yp_pert = 0.0;
-    if constexpr (ADJ && ODINN_PERT_Y) {
+    if constexpr (ADJ && (ODINN_PERT_Y || lm_is_rt(LM))) {  // (run-time architectures: the loop form shares one evaluator body)
       Y = 0.0;
       if (ice) {
         const int pd[1] = {1};
@@ -998,7 +1030,7 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
     if (ADJ) {
       const double dH = 1e-4;  // target_D_hybrid.jl:58
       double Yp;
-      if constexpr (ODINN_PERT_Y) Yp = Yp_pert;
+      if constexpr (ODINN_PERT_Y || lm_is_rt(LM)) Yp = Yp_pert;
       else Yp = ice ? mlp_eval_lm<LM>(L, g.T, Hb + dH) : 0.0;
       const double slide = g.Sc != 0.0 ? g.Sc * hs * sp1 : 0.0;
       alpha = (g.nH + 2.0) * Y * g.Gam * upow(Hb, g.nH + 1.0) * sS1 +

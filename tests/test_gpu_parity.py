@@ -183,7 +183,7 @@ def test_nn_A_gridded(gpu, monkeypatch, arch, wave):
     b.close()
 
 
-@pytest.mark.parametrize("arch", ["default", "w16", "light", "wide"])
+@pytest.mark.parametrize("arch", ["default", "w16", "light", "gelu5", "wide"])
 def test_nn_Y_inlined(gpu, arch):
     """LawY: per-dual-node MLP(T, Hbar) inlined in the stencil (Laws.jl:258-265), :D_hybrid."""
     ph = O.Phys()
@@ -191,7 +191,8 @@ def test_nn_Y_inlined(gpu, arch):
         "default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]),
         "w16": ([2, 16, 16, 1], [1, 1, 2]),
         "light": ([2, 3, 1], [1, 2]),
-        "wide": ([2, 5, 8, 20, 30, 10, 1], [3, 3, 1, 1, 1, 2]),
+        "gelu5": ([2, 5, 10, 5, 1], [3, 3, 3, 1]),  # run-time architecture, <= 16 units (test/test_grad_loss.jl:182-190)
+        "wide": ([2, 5, 8, 20, 30, 10, 1], [3, 3, 1, 1, 1, 2]),  # run-time, <= 32 units (scripts/MWEs/inversion_diffusivity)
     }[arch]
     om, gm, th = _mlp_pair(gpu, widths, acts, [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
     b, H0, B, _ = _setup(gpu, 80, 48)
@@ -208,10 +209,14 @@ def test_nn_Y_inlined(gpu, arch):
     b.close()
 
 
-def test_nn_U_inlined(gpu):
-    """LawU: D = Hbar * NN(Hbar, gradS) (Laws.jl:114-123), target :D."""
+@pytest.mark.parametrize("arch", ["default", "gelu5", "wide"])
+def test_nn_U_inlined(gpu, arch):
+    """LawU: D = Hbar * NN(Hbar, gradS) (Laws.jl:114-123), target :D.  gelu5 / wide: run-time architectures (the rolled
+    evaluator over padded weight rows, 16 and 32 wide)."""
     ph = O.Phys()
-    om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+    widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "gelu5": ([2, 5, 10, 5, 1], [3, 3, 3, 1]),
+                    "wide": ([2, 5, 8, 20, 30, 10, 1], [3, 3, 1, 1, 1, 2])}[arch]
+    om, gm, th = _mlp_pair(gpu, widths, acts, [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
     b, H0, B, _ = _setup(gpu, 80, 48)
     b.set_law(gpu.LAW_NN_U, gm, th)
     law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th)
@@ -711,7 +716,7 @@ def test_largest_single_gpu_configuration_64x1024(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("tiles", ["small", "large"])
-@pytest.mark.parametrize("case", ["Y_default", "Y_w16", "Y_light", "Y_wide", "U_default"])
+@pytest.mark.parametrize("case", ["Y_default", "Y_w16", "Y_light", "Y_gelu5", "Y_wide", "U_default", "U_gelu5"])
 def test_inlined_mlp_fused_step_matches_per_stage_and_oracle(gpu, monkeypatch, case, tiles):
     """LawY / LawU with the network INLINED in the temporally fused step kernel (k_rk_fused<LM >= 2>: one launch per
     RDPK3Sp35 step, the MLP evaluated once per dual node and stage inside the stencil) against the five per-stage
@@ -720,7 +725,8 @@ def test_inlined_mlp_fused_step_matches_per_stage_and_oracle(gpu, monkeypatch, c
     monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
     ph = O.Phys()
     widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "w16": ([2, 16, 16, 1], [1, 1, 2]),
-                    "light": ([2, 3, 1], [1, 2]), "wide": ([2, 5, 8, 20, 30, 10, 1], [3, 3, 1, 1, 1, 2])}[case.split("_")[1]]
+                    "light": ([2, 3, 1], [1, 2]), "gelu5": ([2, 5, 10, 5, 1], [3, 3, 3, 1]),
+                    "wide": ([2, 5, 8, 20, 30, 10, 1], [3, 3, 1, 1, 1, 2])}[case.split("_")[1]]
     isY = case.startswith("Y")
     if isY:
         om, gm, th = _mlp_pair(gpu, widths, acts, [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)

@@ -44,6 +44,9 @@ else:
     if len(sys.argv) > 4 and sys.argv[4] == "custom":
         mlp = odinn.MLPSpec([2, 5, 10, 5, 1], [odinn.ACT_GELU] * 3 + [odinn.ACT_SOFTPLUS], law.mlp.prescale, law.mlp.post_kind, law.mlp.post_lo, law.mlp.post_hi)
         theta = rng.uniform(-0.5, 0.5, mlp.n_params)
+    elif len(sys.argv) > 4 and sys.argv[4] == "custom_sp":  # the default activations on other widths: isolates the run-time loops
+        mlp = odinn.MLPSpec([2, 4, 10, 3, 1], [odinn.ACT_SOFTPLUS] * 3 + [odinn.ACT_SIGMOID], law.mlp.prescale, law.mlp.post_kind, law.mlp.post_lo, law.mlp.post_hi)
+        theta = rng.uniform(-0.5, 0.5, mlp.n_params)
     b.set_law(law.kind, mlp, theta, law.n_H, law.n_gradS)
 ts = [2010.0 + j / 12.0 for j in range(k)]
 mbt = ts[1:] if what == "mb" else ()
