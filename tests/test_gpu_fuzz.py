@@ -65,6 +65,16 @@ def _skip(test, seed, reason, tag, Lg=None, Lo=None, gg=None, go=None, extra=Non
 def _audit():
     return bool(os.environ.get("ODINN_FUZZ_AUDIT"))
 
+def _maybe_runtime_arch(seed, widths, acts):
+    """One draw in five of the per-node-network laws takes a RUN-TIME architecture (law modes 2 / 6: the rolled evaluator over
+    padded weight rows) -- the reference's gelu net 2-5-10-5-1 (test/test_grad_loss.jl:182-190), a tanh / softplus mix, or a net
+    with a layer wider than 16.  Drawn from a stream of its own, so the other draws are what they were."""
+    r = np.random.default_rng(68000 + seed)
+    if r.random() >= 0.2:
+        return widths, acts
+    return [([2, 5, 10, 5, 1], [3, 3, 3, 2]), ([2, 4, 6, 1], [4, 1, 2]), ([2, 6, 20, 4, 1], [1, 3, 1, 2])][int(r.integers(0, 3))]
+
+
 def _draw(gpu, seed, velocity=False):
     rng = np.random.default_rng((5000000 if velocity else 1000) + seed)
     G = int(rng.integers(1, 4))
@@ -92,12 +102,13 @@ def _draw(gpu, seed, velocity=False):
         gm = gpu.MLPSpec(widths, acts, None, O.POST_AFFINE, ph.minA, ph.maxA)
     elif kind == O.LAW_NN_Y:
         widths, acts = [([2, 3, 10, 3, 1], [1, 1, 1, 2]), ([2, 3, 1], [1, 2])][int(rng.integers(0, 2))]
+        widths, acts = _maybe_runtime_arch(seed, widths, acts)
         pre = [(-25.0, 0.0), (0.0, 500.0)]
         om = O.MLP(widths, acts, pre, O.POST_EXPMAX, 0.0, ph.maxA)
         gm = gpu.MLPSpec(widths, acts, pre, O.POST_EXPMAX, 0.0, ph.maxA)
         interp = ("linear", int(rng.choice([6, 20, 75]))) if rng.random() < 0.6 else ("none", 75)
     elif kind == O.LAW_NN_U:
-        widths, acts = [2, 3, 10, 3, 1], [1, 1, 1, 2]
+        widths, acts = _maybe_runtime_arch(seed, [2, 3, 10, 3, 1], [1, 1, 1, 2])
         pre = [(0.0, 300.0), (0.0, 0.5)]
         om = O.MLP(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
         gm = gpu.MLPSpec(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
@@ -464,12 +475,13 @@ def _draw_seam(gpu, seed):
         gm = gpu.MLPSpec(widths, acts, None, O.POST_AFFINE, ph.minA, ph.maxA)
     elif kind == O.LAW_NN_Y:
         widths, acts = [([2, 3, 10, 3, 1], [1, 1, 1, 2]), ([2, 3, 1], [1, 2]), ([2, 16, 16, 1], [1, 1, 2])][int(rng.integers(0, 3))]
+        widths, acts = _maybe_runtime_arch(seed, widths, acts)
         pre = [(-25.0, 0.0), (0.0, 500.0)]
         om = O.MLP(widths, acts, pre, O.POST_EXPMAX, 0.0, ph.maxA)
         gm = gpu.MLPSpec(widths, acts, pre, O.POST_EXPMAX, 0.0, ph.maxA)
         interp = ("linear", int(rng.choice([3, 10, 75]))) if rng.random() < 0.5 else ("none", 75)
     elif kind == O.LAW_NN_U:
-        widths, acts = [2, 3, 10, 3, 1], [1, 1, 1, 2]
+        widths, acts = _maybe_runtime_arch(seed, [2, 3, 10, 3, 1], [1, 1, 1, 2])
         pre = [(0.0, 300.0), (0.0, 0.5)]
         om = O.MLP(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
         gm = gpu.MLPSpec(widths, acts, pre, O.POST_EXPMAX, 0.0, 50.0)
