@@ -721,7 +721,7 @@ def test_inlined_mlp_fused_step_matches_per_stage_and_oracle(gpu, monkeypatch, c
     """LawY / LawU with the network INLINED in the temporally fused step kernel (k_rk_fused<LM >= 2>: one launch per
     RDPK3Sp35 step, the MLP evaluated once per dual node and stage inside the stencil) against the five per-stage
     kernels and against the oracle's integrator: equal to rounding under a fixed dt, within the solver tolerance under
-    step-size control.  Compile-time architectures (LM 3, 4, 5) and the run-time one (LM 2, "wide"); both tile heights."""
+    step-size control.  Compile-time architectures (LM 3, 4, 5) and the run-time ones (LM 2 "gelu5", LM 6 "wide"); both tile heights."""
     monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
     ph = O.Phys()
     widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "w16": ([2, 16, 16, 1], [1, 1, 2]),
