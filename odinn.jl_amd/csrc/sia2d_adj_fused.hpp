@@ -45,16 +45,37 @@ typedef double (*AdjEdgesL)[TNW][2][FRX];
 #ifndef ODINN_ADJ_APF
 #define ODINN_ADJ_APF 1
 #endif
+// ODINN_ADJ_RC: the gridded-A variants keep everything a stage re-reads -- {H_j, H_j+1 - H_j}, B, the A nodes and lambda at the
+// start of the step -- in registers for the five stages (4 doubles per row + the A row below the strip: 72 VGPRs at 7 rows) and
+// run at 2 wavefronts per SIMD (one workgroup per CU, 256 VGPRs).  At 4 per SIMD the variant spilled 11-17 registers and was
+// HBM-bound on its own re-reads: PMC at 64 x 1024^2, 15.4 GB fetched per launch = 5 x the algorithmic traffic at 5.4 TB/s
+// (3.05 ms; the constant-A variant: 6.3 GB, 2.13 ms) -- the A field is one more 512 MB stream through a 4 MB L2 in every stage.
+#ifndef ODINN_ADJ_RC
+#define ODINN_ADJ_RC 1
+#endif
+#ifndef ODINN_ADJ_RC_EREG  // ... and the embedded-error accumulator too (the LDS column exists for the 128-register variants)
+#define ODINN_ADJ_RC_EREG 1
+#endif
 typedef double (*AdjErr)[FRX];
+// register cache of a thread's stage-invariant inputs (ODINN_ADJ_RC)
+template <int NR>
+struct AdjRowCache {
+  double2 hd[NR];     // {H_j, H_j+1 - H_j}
+  double b[NR];       // bed
+  double An[NR + 1];  // A at the node rows gj0 + r0 - 1 ... gj0 + r0 + NR - 1
+  double u0[NR];      // lambda at the start of the step
+};
 
-template <int S, bool AF, bool SG, int NR, bool GA = false>
+template <int S, bool AF, bool SG, int NR, bool GA = false, bool RC = false>
 __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __restrict__ Afield, const double* __restrict__ Ha,
                                                  const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
                                                  int gic, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
                                                  AdjEdgesL sLm, double (&u)[NR], double (&tmp)[NR], double (&E)[NR],
                                                  const double* __restrict__ Bp, AdjErr sEr, double* __restrict__ th_red,
-                                                 [[maybe_unused]] double* __restrict__ Gp = nullptr) {
+                                                 [[maybe_unused]] double* __restrict__ Gp = nullptr,
+                                                 [[maybe_unused]] const AdjRowCache<RC ? NR : 1>* rc = nullptr) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;
+  constexpr bool ELDS = ODINN_ADJ_ELDS && !(RC && ODINN_ADJ_RC_EREG);
   const int r0 = NR * w;
   [[maybe_unused]] const bool nodex = gi >= 0 && gi <= g.nx - 2;
   const bool intx = gi >= 1 && gi <= g.nx - 2;
@@ -69,6 +90,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   // and B re-read from global memory (L2-resident).  Outside the grid the index is clamped and whatever it picks
   // up is never used: lambda is masked to the interior, so every term that touches such a cell carries a factor 0.
   auto hs_itp = [&](int m, double swt) {
+    if constexpr (RC) return cell_HS(fma(swt, rc->hd[m].y, rc->hd[m].x), rc->b[m]);
     const int gj = gj0 + r0 + m;
     const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
     const unsigned id = (unsigned)(gif + g.nx * gjc);  // zero-extended: scalar base + 32-bit offset addressing
@@ -144,12 +166,14 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     PLn = (dyw > -hs_lo.x && dyw != hs_hi.x) ? -tn : 0.0;
   };
 
-  [[maybe_unused]] auto ld_A = [&](int gj) {
+  [[maybe_unused]] auto ld_A = [&](int k) {  // A at the node row gj0 + r0 + k, k = -1 ... NR - 1
+    if constexpr (RC) return rc->An[k + 1];
+    const int gj = gj0 + r0 + k;
     const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
     return ldg32(Afield, (unsigned)(ok ? gif + (g.nx - 1) * gj : 0));
   };
   [[maybe_unused]] double A_c = 0.0, A_s = 0.0;
-  if constexpr (AF && ODINN_ADJ_APF) { A_s = ld_A(gj0 + r0 - 1); A_c = ld_A(gj0 + r0); }
+  if constexpr (AF && ODINN_ADJ_APF) { A_s = ld_A(-1); A_c = ld_A(0); }
   {  // the node row and the north faces just below the strip
     const double2 e_s = dpp_from_east(hs_s);
     const double lee_s = dpp_shift(le_s, false);
@@ -170,7 +194,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
       if (m + 2 < NR) hs_next = hs_itp(m + 2 < NR ? m + 2 : m, sw);
     }
     [[maybe_unused]] double A_n = 0.0;
-    if constexpr (AF && ODINN_ADJ_APF) { if (m + 1 < NR) A_n = ld_A(gj + 1); }
+    if constexpr (AF && ODINN_ADJ_APF) { if (m + 1 < NR) A_n = ld_A(m + 1 < NR ? m + 1 : m); }
     const double le_n = m + 1 < NR ? lam_e(m + 1 < NR ? m + 1 : m) : le_top;
     const double2 e_n = dpp_from_east(hs_n);
     const double lee_n = dpp_shift(le_n, false);
@@ -197,24 +221,28 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     double un;
     if (S == 1) {
       un = fma(bt, dtk, uo);
-      if (ODINN_ADJ_ELDS) sEr[r0 + m][lane] = bh * dtk; else E[m] = bh * dtk;
+      if (ELDS) sEr[r0 + m][lane] = bh * dtk; else E[m] = bh * dtk;
     } else {
       const double t = fma(dl, uo, tmp[m]);
       un = fma(g1, uo, g2 * t);
       if (S >= 4) {
-        const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
-        un = fma(g3, ldg32(src, (unsigned)(gif + g.nx * gjc)), un);
+        if constexpr (RC) {
+          un = fma(g3, rc->u0[m], un);
+        } else {
+          const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
+          un = fma(g3, ldg32(src, (unsigned)(gif + g.nx * gjc)), un);
+        }
       }
       un = fma(bt, dtk, un);
       if (dl != 0.0) tmp[m] = t;
-      if (ODINN_ADJ_ELDS) sEr[r0 + m][lane] = fma(bh, dtk, sEr[r0 + m][lane]); else E[m] = fma(bh, dtk, E[m]);
+      if (ELDS) sEr[r0 + m][lane] = fma(bh, dtk, sEr[r0 + m][lane]); else E[m] = fma(bh, dtk, E[m]);
     }
     u[m] = un;
     hs_c = hs_n; le_c = le_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; qe_c = qe_n; Pe_c = Pe_n;
     D_s = D_c; C_s = (k01 + dpp_from_west(k11)) + PLn;
     if constexpr (AF && ODINN_ADJ_APF) { A_c = A_n; asm volatile("" : "+v"(A_c)); }
     // row fence (see k_rk_fused_strip): pins the row order of this one-basic-block stage body
-    if (ODINN_ADJ_ELDS) {
+    if (ELDS) {
       if (S == 1)
         asm volatile("" : "+v"(u[m]), "+v"(hs_c.x), "+v"(hs_c.y), "+v"(le_c), "+v"(e_c.x), "+v"(e_c.y), "+v"(qe_c),
                      "+v"(Pe_c), "+v"(D_s), "+v"(C_s), "+v"(gif));
@@ -245,12 +273,15 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
 // SKIP: exact ice-free shortcut (see below)
 // GA (gridded A with a dual-grid accumulator): stage 1 of the step that follows a quadrature node also adds the node
 // weights into A.Gacc (needs A.th_part)
+constexpr bool adj_rc(bool AF, bool SG, int NR) { return ODINN_ADJ_RC && (AF || ODINN_ADJ_RC > 1) && SG && NR > 4; }
 template <bool AF, bool SKIP, bool SG = false, int NR = TRPT, bool GA = false>
-__global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
+__global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : ODINN_FWPE)) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
+  constexpr bool RC = adj_rc(AF, SG, NR);
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double sLm[2][TNW][2][FRX];
   __shared__ double red[TNW];
-  __shared__ double sEr[ODINN_ADJ_ELDS ? (NR * TNW) : 1][FRX];
+  constexpr bool ELDS = ODINN_ADJ_ELDS && !(adj_rc(AF, SG, NR) && ODINN_ADJ_RC_EREG);
+  __shared__ double sEr[ELDS ? (NR * TNW) : 1][FRX];
   const int4 t4 = A.tilesF[blockIdx.x];
   const GState* gs = P.gs + t4.x;
   if (gs->done) return;
@@ -363,23 +394,44 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
     edge(0, 0);
     edge(NR - 1, 1);
   }
+  [[maybe_unused]] AdjRowCache<RC ? NR : 1> rc;
+  if constexpr (RC) {  // every load of the step is issued here (clamped indices: what they pick up outside the grid is never used)
+    const bool nodex = gi >= 0 && gi <= g.nx - 2;
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+      const int gj = gj0 + r0 + m;
+      const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
+      const unsigned id = (unsigned)(gic + g.nx * gjc);
+      rc.hd[m] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Ha) + ((size_t)id << 4));
+      rc.b[m] = ldg32(Bg, id);
+      rc.u0[m] = ldg32(src, id);
+    }
+    if constexpr (AF) {
+#pragma unroll
+      for (int k = 0; k <= NR; ++k) {
+        const int gj = gj0 + r0 + k - 1;
+        const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+        rc.An[k] = ldg32(Afg, (unsigned)(ok ? gic + (g.nx - 1) * gj : 0));
+      }
+    }
+  }
   __syncthreads();
   __shared__ double th_red[TNW];
   // theta-VJP of the quadrature node the previous step reached (a.qw: its Gauss-Legendre weight, 0 otherwise; the controller
   // resets it at every call, so a repeated attempt after a rejection does not count the node twice)
   double* const thr = (A.th_part && a.qw != 0.0) ? th_red : nullptr;
-  adj_strip_stage<1, AF, SG, NR, GA>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr,
-                                     GA ? A.Gacc + g.offd : nullptr);
+  adj_strip_stage<1, AF, SG, NR, GA, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr,
+                                         GA ? A.Gacc + g.offd : nullptr, &rc);
   if (thr && threadIdx.x == 0) {  // the tile's running sum, reduced per glacier once after the reverse solve
     double sum = 0.0;
 #pragma unroll
     for (int k = 0; k < TNW; ++k) sum += th_red[k];
     A.th_part[t4.w] = fma(a.qw, sum, A.th_part[t4.w]);
   }
-  adj_strip_stage<2, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
-  adj_strip_stage<3, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
-  adj_strip_stage<4, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
-  adj_strip_stage<5, AF, SG, NR>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr);
+  adj_strip_stage<2, AF, SG, NR, false, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc);
+  adj_strip_stage<3, AF, SG, NR, false, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc);
+  adj_strip_stage<4, AF, SG, NR, false, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc);
+  adj_strip_stage<5, AF, SG, NR, false, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc);
   // ---- output rows [FH, (NR * TNW)-1-FH]: lam' from the registers, embedded error partial -----------------------
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   double errsq = 0.0;
@@ -388,7 +440,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
   for (int m = 0; m < NR; ++m) {
     const int r = r0 + m, gj = gj0 + r;
     const bool out = r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny;
-    upf[m] = ldg32(src, (unsigned)(out ? id0 + g.nx * m : 0));
+    if constexpr (RC) upf[m] = rc.u0[m];
+    else upf[m] = ldg32(src, (unsigned)(out ? id0 + g.nx * m : 0));
   }
 #pragma unroll
   for (int m = 0; m < NR; ++m) {
@@ -396,7 +449,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_adj_fused_strip(Pools P, Ad
     if (r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny) {
       const double upv = upf[m];
       stg32(dst, (unsigned)(id0 + g.nx * m), u[m]);
-      const double err = (u[m] - upv) - (ODINN_ADJ_ELDS ? sEr[r0 + m][lane] : E[m]);
+      const double err = (u[m] - upv) - (ELDS ? sEr[r0 + m][lane] : E[m]);
       const double sk = A.abstol + fmax(fabs(upv), fabs(u[m])) * A.reltol;
       const double q = err / sk;
       errsq = fma(q, q, errsq);
