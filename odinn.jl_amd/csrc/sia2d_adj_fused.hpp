@@ -476,8 +476,16 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : ODINN_FWPE)) void k_
 // Tiles come from the RHS strip table (tilesD); partials go to the glacier's slots of the regular tile table
 // (tile0 + local index; the slots past ntilesD are zeroed by the glacier's first tile) so that every reduction over
 // P.part keeps working unchanged.
+// ODINN_VJPH_RC: the reverse-Euler form (MODE 1) runs at 2 wavefronts per SIMD with EVERY load of the thread -- bed, A nodes,
+// reference thickness, mask -- issued before the sweep, like MODE 0's H and lambda.  At 128 registers those were fetched one
+// row ahead inside the sweep, i.e. each row waited for its own loads: 0.74 ms per 64 x 1024^2 against 0.36 ms for MODE 0,
+// which moves 32 of MODE 1's 41 B/cell.
+#ifndef ODINN_VJPH_RC
+#define ODINN_VJPH_RC 1
+#endif
 template <bool AF, int MODE>
-__global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_H_strip(Pools P, const int4* __restrict__ tilesD, AdjArgs A) {
+__global__ __launch_bounds__(TNT, ((ODINN_VJPH_RC && MODE == 1) ? 2 : ODINN_FWPE)) void k_vjp_H_strip(Pools P, const int4* __restrict__ tilesD, AdjArgs A) {
+  constexpr bool RCV = ODINN_VJPH_RC && MODE == 1;
   __shared__ double2 sE[TNW][2][FRX];
   __shared__ double sLm[TNW][2][FRX];
   __shared__ double red[TNW];
@@ -506,7 +514,17 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_H_strip(Pools P, const 
     ll[m] = ok ? ldg32(Lg, (unsigned)(id0 + g.nx * m)) : 0.0;
   }
   int idf = id0;
+  [[maybe_unused]] double bbr[RCV ? DNR : 1];
+  if constexpr (RCV) {
+#pragma unroll
+    for (int m = 0; m < DNR; ++m) {
+      const int gj = gj0 + r0 + m;
+      const bool ok = inx && gj >= 0 && gj < g.ny;
+      bbr[m] = ok ? ldg32(Bg, (unsigned)(id0 + g.nx * m)) : 0.0;
+    }
+  }
   auto bed = [&](int m) {
+    if constexpr (RCV) return bbr[m];
     const int gj = gj0 + r0 + m;
     const bool ok = inx && gj >= 0 && gj < g.ny;
     return ok ? ldg32(Bg, (unsigned)(idf + g.nx * m)) : 0.0;
@@ -518,7 +536,17 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_H_strip(Pools P, const 
   const bool nodex = gi >= 0 && gi <= g.nx - 2;
   // idf: the thread's first cell index again, but opaque after every row fence of the sweep -- keeps the loads a row issues
   // (A of the next node row, loss data and lambda of the next row) inside that row instead of all at the top
+  [[maybe_unused]] double anr[(RCV && AF) ? DNR + 1 : 1];
+  if constexpr (RCV && AF) {
+#pragma unroll
+    for (int k = 0; k <= DNR; ++k) {
+      const int gj = gj0 + r0 - 1 + k;
+      const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
+      anr[k] = ok ? ldg32(Afg, (unsigned)(gi + (g.nx - 1) * gj)) : 0.0;
+    }
+  }
   auto a_node = [&](int k) {
+    if constexpr (RCV && AF) return anr[k];
     const int gj = gj0 + r0 - 1 + k;
     const bool ok = nodex && gj >= 0 && gj <= g.ny - 2;
     return ok ? ldg32(Afg, (unsigned)((idf - id0) + gi + (g.nx - 1) * gj)) : 0.0;
@@ -543,6 +571,18 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_H_strip(Pools P, const 
     const int gj = gj0 + r0 + m;
     return (intx && gj >= 1 && gj <= g.ny - 2) ? ll[m] : 0.0;
   };
+  [[maybe_unused]] double hrr[RCV ? DNR : 1];
+  [[maybe_unused]] unsigned mkr[RCV ? DNR : 1];
+  if constexpr (RCV) {  // (clamped to the thread's first cell where it has no output cell: never used there)
+#pragma unroll
+    for (int m = 0; m < DNR; ++m) {
+      const int r = r0 + m, gj = gj0 + r;
+      const bool oc = ocol && r >= 1 && r <= DOY && gj < g.ny;
+      const unsigned id = (unsigned)(oc ? id0 + g.nx * m : (inx && gj0 + r0 >= 0 && gj0 + r0 < g.ny ? id0 : 0));
+      mkr[m] = Mg[id];
+      hrr[m] = ldg32(Rg, id);
+    }
+  }
   bool nz = false;
 #pragma unroll
   for (int m = 0; m < DNR; ++m) nz = nz || (hh[m] > 0.0);
@@ -576,7 +616,13 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_H_strip(Pools P, const 
       if (MODE == 1) {
         const int r = r0 + m, gj = gj0 + r;
         const bool oc = ocol && r >= 1 && r <= DOY && gj < g.ny;
-        if (oc) {
+        if constexpr (RCV) {
+          if (oc) {
+            lo = ll[m];
+            on = wl != 0.0 && mkr[m] != 0;
+            d = on ? hh[m] - hrr[m] : 0.0;
+          }
+        } else if (oc) {
           const unsigned id = (unsigned)(idf + g.nx * m);
           const unsigned char mk = Mg[id];
           const double hr = ldg32(Rg, id);
@@ -670,8 +716,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_H_strip(Pools P, const 
         double o = 0.0;
         if (MODE == 1) {
           o = fma(dt, 0.0, ll[m]);
-          if (wl != 0.0 && Mg[(unsigned)(id0 + g.nx * m)]) {
-            const double hd = hh[m] - ldg32(Rg, (unsigned)(id0 + g.nx * m));
+          if (wl != 0.0 && (RCV ? mkr[m] != 0 : Mg[(unsigned)(id0 + g.nx * m)] != 0)) {
+            const double hd = hh[m] - (RCV ? hrr[m] : ldg32(Rg, (unsigned)(id0 + g.nx * m)));
             o = fma(wl * 2.0 * Ninv, hd, o);
             lsum = fma(hd, hd, lsum);
           }
