@@ -165,7 +165,7 @@ typedef struct odinn_schedule {
   int32_t adj_fused;       /* ODINN_ADJ_FUSED: 0 = five k_adj_stage launches per reverse step instead of the fused reverse step   */
   int32_t adj_skip;        /* ODINN_ADJ_SKIP: 0 = no ice-free shortcut in the fused reverse step                                   */
   int32_t adj_segs;        /* ODINN_ADJ_SEGS: 0 = read the two snapshots instead of the interleaved {H_j, H_j+1 - H_j} pairs       */
-  int32_t adj_rows;        /* ODINN_ADJ_ROWS: 4 | 7 rows per thread of the fused reverse step                                      */
+  int32_t adj_rows;        /* ODINN_ADJ_ROWS: 4 | 7 | 8 rows per thread of the fused reverse step (8: gridded A only, else ignored) */
   int32_t adj_theta_fused; /* ODINN_ADJ_THETA_FUSED: 0 = theta-VJP of a quadrature node in launches of its own                     */
   int32_t reserved[5];     /* zero                                                                                                 */
 } odinn_schedule;

@@ -7,6 +7,16 @@ void launch_adj_fused_strip(int nblk, int afield, int skip, int rows, hipStream_
   // measurement aid: ODINN_ADJ_LDS_PAD=<bytes> of unused dynamic LDS per workgroup (> 2 KB: one workgroup per CU instead of two,
   // i.e. half the per-XCD working set against the 4 MB L2 at half the occupancy)
   static const unsigned pad = std::getenv("ODINN_ADJ_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ODINN_ADJ_LDS_PAD")) : 0u;
+  if (rows == 8) {  // gridded A, register-cached (ODINN_ADJ_RC), the forward kernel's 54 x 54 tiles; the caller guarantees afield and A.segs
+    if (A.Gacc) {
+      if (skip) hipLaunchKernelGGL((k_adj_fused_strip<true, true, true, 8, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+      else hipLaunchKernelGGL((k_adj_fused_strip<true, false, true, 8, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+    } else {
+      if (skip) hipLaunchKernelGGL((k_adj_fused_strip<true, true, true, 8>), dim3(nblk), dim3(TNT), pad, st, P, A);
+      else hipLaunchKernelGGL((k_adj_fused_strip<true, false, true, 8>), dim3(nblk), dim3(TNT), pad, st, P, A);
+    }
+    return;
+  }
   if (A.Gacc) {  // gridded A with the dual-grid accumulator fed by stage 1 (the caller guarantees afield, A.segs, A.th_part)
     if (rows == 4) {
       if (skip) hipLaunchKernelGGL((k_adj_fused_strip<true, true, true, 4, true>), dim3(nblk), dim3(TNT), pad, st, P, A);

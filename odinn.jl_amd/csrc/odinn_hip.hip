@@ -2345,8 +2345,8 @@ int odinn_set_schedule(odinn_batch* b, const odinn_schedule* sc) {
   if (!b) return fail(ODINN_ERR_ARG, "null batch");
   const odinn_schedule automatic = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
   const odinn_schedule want = sc ? *sc : automatic;  // (validated as a local: a rejected schedule leaves the old one in effect)
-  if (want.adj_rows >= 0 && want.adj_rows != 4 && want.adj_rows != 7)
-    return fail(ODINN_ERR_ARG, "odinn_schedule.adj_rows must be -1, 4 or 7");
+  if (want.adj_rows >= 0 && want.adj_rows != 4 && want.adj_rows != 7 && want.adj_rows != 8)
+    return fail(ODINN_ERR_ARG, "odinn_schedule.adj_rows must be -1, 4, 7 or 8");
   if (want.fused_tiles > 4) return fail(ODINN_ERR_ARG, "odinn_schedule.fused_tiles must be -1 ... 4");
   b->sched = want;
   return ODINN_OK;
@@ -2837,13 +2837,21 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       const int er = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS");
       const long cu = b->n_cus();
       const bool model = b->ntilesFt <= 2 * cu && 4 * ((b->ntilesFv + cu - 1) / cu) < 7 * ((b->ntilesFt + cu - 1) / cu);
-      if (er == 4 || er == 7 ? er == 4 : model) {
+      if (er == 4 || er == 7 || er == 8 ? er == 4 : model) {
         adj_rows = 4;
         FA.partF = b->d_partFv; FA.tilesF = b->d_tilesFv;
         C.errpart = b->d_partFv; C.fused = 6;
+      } else if (b->gd[0].use_Afield && b->d_tilesFu &&
+                 (er == 8 || (er < 0 && 8 * ((b->ntilesFu + cu - 1) / cu) <= 7 * ((b->ntilesFt + cu - 1) / cu)))) {
+        // gridded A: the register-cached instantiation (one workgroup per CU, 256 VGPRs) has room for the forward kernel's
+        // 8 rows per thread -- 54 x 54 output tiles: 3 % less halo work and an exact fit of 1024^2 grids (19 x 19 tiles where
+        // the 54 x 46 ones need 19 x 23 and overshoot by 3 %)
+        adj_rows = 8;
+        FA.partF = b->d_partFu; FA.tilesF = b->d_tilesFu;
+        C.errpart = b->d_partFu; C.fused = 4;
       }
     }
-    const int ntilesR = adj_rows == 4 ? b->ntilesFv : b->ntilesFt;
+    const int ntilesR = adj_rows == 4 ? b->ntilesFv : adj_rows == 8 ? b->ntilesFu : b->ntilesFt;
     // A-type laws without a dual-grid accumulator: the theta-VJP of a quadrature node is formed by stage 1 of the step that
     // follows the node (same lambda, same H_itp) instead of a launch of its own (ODINN_ADJ_THETA_FUSED=0: separate launches)
     const int et = sched_val(b->sched.adj_theta_fused, "ODINN_ADJ_THETA_FUSED");
@@ -2862,6 +2870,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
     }
   }
   const bool theta_fused = FA.th_part != nullptr;
+  const int ntilesR_launch = adj_rows == 4 ? b->ntilesFv : adj_rows == 8 ? b->ntilesFu : b->ntilesFt;
   // polls as in do_solve: one step per stop at least, then the controller's estimate of what is left
   if (!b->d_est) CHK(dalloc(&b->d_est, (size_t)G));
   C.est_steps = b->d_est;
@@ -2876,7 +2885,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
       if (fused_rev) {
         // the whole step in one kernel: reads lam[cur], writes lam[1 - cur] per glacier; the controller flips cur
         // on acceptance (a rejected step is simply repeated from the untouched lam[cur])
-        launch_adj_fused_strip(adj_rows == 4 ? b->ntilesFv : b->ntilesFt, b->gd[0].use_Afield, rev_skip, adj_rows, b->stream, Pl, FA);
+        launch_adj_fused_strip(ntilesR_launch, b->gd[0].use_Afield, rev_skip, adj_rows, b->stream, Pl, FA);
         C.next_cur = -1;
       } else {
         // five stages ping-pong lam[p] -> lam[1-p] -> ... ; the step's result lands in lam[1-p]
@@ -3319,9 +3328,11 @@ static int timed_one(odinn_batch* b, int which, int it) {
       if (sched_val(b->sched.adj_segs, "ODINN_ADJ_SEGS") != 0) FA.segs = b->d_segs;
       // (odinn_schedule.adj_rows = 4 times the 4-rows-per-thread instantiation: 54 x 22 tiles, which needs the segment pairs)
       const bool rows4 = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS") == 4 && FA.segs;
+      const bool rows8 = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS") == 8 && FA.segs && b->gd[0].use_Afield && b->d_tilesFu;
       if (rows4) { FA.partF = b->d_partFv; FA.tilesF = b->d_tilesFv; }
-      launch_adj_fused_strip(rows4 ? b->ntilesFv : b->ntilesFt, b->gd[0].use_Afield, timed_adj_skip() ? 1 : 0,
-                             rows4 ? 4 : TRPT, b->stream, P, FA);
+      if (rows8) { FA.partF = b->d_partFu; FA.tilesF = b->d_tilesFu; }
+      launch_adj_fused_strip(rows4 ? b->ntilesFv : rows8 ? b->ntilesFu : b->ntilesFt, b->gd[0].use_Afield, timed_adj_skip() ? 1 : 0,
+                             rows4 ? 4 : rows8 ? 8 : TRPT, b->stream, P, FA);
       return ODINN_OK;
     }
     case ODINN_TIMED_LAW_FIELD:

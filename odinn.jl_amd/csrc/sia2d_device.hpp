@@ -3128,12 +3128,12 @@ __global__ void k_seg_pairs(long long ntot, int n_seg, const double* __restrict_
     segs[i] = make_double2(a, b - a);
   }
 }
-// out[g] += sum of the glacier's entries of a per-tile array on the FOX x FOYT (rows = 7) or FOX x FOYT4 (rows = 4)
-// strip-tile table (fixed order)
+// out[g] += sum of the glacier's entries of a per-tile array on the FOX x FOYT (rows = 7), FOX x FOYT4 (rows = 4) or the forward
+// kernel's FOX x FOYU (rows = 8) strip-tile table (fixed order)
 __global__ __launch_bounds__(64) void k_sum_tilesFt(Pools P, const double* __restrict__ part, double* __restrict__ out, int rows) {
   const int gidx = blockIdx.x;
   const GDev g = P.gd[gidx];
-  const int t0 = rows == 4 ? g.tile0Fv : g.tile0Ft, nt = rows == 4 ? g.ntilesFv : g.ntilesFt;
+  const int t0 = rows == 4 ? g.tile0Fv : rows == 8 ? g.tile0Fu : g.tile0Ft, nt = rows == 4 ? g.ntilesFv : rows == 8 ? g.ntilesFu : g.ntilesFt;
   double s = 0.0;
   for (int k = threadIdx.x; k < nt; k += 64) s += part[t0 + k];
   s = wave_sum(s);
