@@ -50,7 +50,7 @@ def _grads(b, ts, continuous):
 
 GENERIC = [dict(step_sc=0), dict(step_sc=1), dict(fused_tiles=1), dict(fused_tiles=2), dict(fused_tiles=3), dict(fused_tiles=4),
            dict(dhdt_strip=0), dict(vjph_strip=0), dict(vjph_strip=1), dict(vjpth_strip=0), dict(vjpth_strip=1),
-           dict(snap_on_load=0), dict(adj_fused=0), dict(adj_skip=0), dict(adj_segs=0), dict(adj_rows=4), dict(adj_rows=7),
+           dict(snap_on_load=0), dict(adj_fused=0), dict(adj_skip=0), dict(adj_segs=0), dict(adj_rows=4), dict(adj_rows=7), dict(adj_rows=8),
            dict(adj_theta_fused=0)]
 
 
