@@ -167,7 +167,13 @@ typedef struct odinn_schedule {
   int32_t adj_segs;        /* ODINN_ADJ_SEGS: 0 = read the two snapshots instead of the interleaved {H_j, H_j+1 - H_j} pairs       */
   int32_t adj_rows;        /* ODINN_ADJ_ROWS: 4 | 7 | 8 rows per thread of the fused reverse step (8: gridded A only, else ignored) */
   int32_t adj_theta_fused; /* ODINN_ADJ_THETA_FUSED: 0 = theta-VJP of a quadrature node in launches of its own                     */
-  int32_t reserved[5];     /* zero                                                                                                 */
+  int32_t law_table;       /* ODINN_LAW_TABLE: 1 = inside the forward solve and both adjoints the stencil kernels of a batch with
+                              the Y law (ODINN_LAW_NN_Y: inputs = the glacier's scalar temperature and Hbar) read Y(Hbar) from a
+                              per-glacier table of quintics (1024 intervals; rebuilt from the network when theta changes, used only
+                              while its measured deviation from the network is < 1e-12 relative; a solve that leaves the table's
+                              range is repeated with a wider one) instead of evaluating the network per dual node and stage;
+                              0 / -1 = the network itself (the default)                                                            */
+  int32_t reserved[4];     /* zero                                                                                                 */
 } odinn_schedule;
 
 typedef struct odinn_batch odinn_batch;
@@ -184,6 +190,11 @@ int odinn_batch_sync(odinn_batch* b);
 /* sc == NULL: everything automatic.  odinn_get_schedule returns what is in effect (environment overrides applied). */
 int odinn_set_schedule(odinn_batch* b, const odinn_schedule* sc);
 int odinn_get_schedule(odinn_batch* b, odinn_schedule* out);
+/* State of the Y law's table (odinn_schedule.law_table; builds it for the current theta if needed): *usable = 1 when the stencil
+ * kernels of the next solve / gradient will read it, its interval count, its largest measured deviation from the network
+ * (relative; values below 1e-6 of the law's scale relative to the table's largest value) and the Hbar range per glacier
+ * (metres; doubled by a solve that left it).  Any pointer may be NULL.  No counterpart in the reference. */
+int odinn_get_law_table(odinn_batch* b, int* usable, int* n_intervals, double* max_rel_dev, double* hmax_per_glacier);
 int odinn_set_fields(odinn_batch* b, int g, const double* H0, const double* B);
 int odinn_set_A(odinn_batch* b, int g, double A);
 int odinn_set_A_field(odinn_batch* b, int g, const double* A_dual);   /* CONST_A, gridded  */

@@ -68,12 +68,13 @@ class AdjointOpts(C.Structure):
 
 
 SCHEDULE_FIELDS = ("step_sc", "fused_tiles", "dhdt_strip", "vjph_strip", "vjpth_strip", "snap_on_load", "interp_streams",
-                   "interp_batch", "lawgrad_wave", "vq_onepass", "adj_fused", "adj_skip", "adj_segs", "adj_rows", "adj_theta_fused")
+                   "interp_batch", "lawgrad_wave", "vq_onepass", "adj_fused", "adj_skip", "adj_segs", "adj_rows", "adj_theta_fused",
+                   "law_table")
 
 
 class Schedule(C.Structure):
     """odinn_schedule: which of the library's equivalent kernel forms run; every field -1 = automatic."""
-    _fields_ = [(k, C.c_int32) for k in SCHEDULE_FIELDS] + [("reserved", C.c_int32 * 5)]
+    _fields_ = [(k, C.c_int32) for k in SCHEDULE_FIELDS] + [("reserved", C.c_int32 * 4)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -96,6 +97,7 @@ SIGNATURES = {
     "odinn_batch_sync": (C.c_int, [_vp]),
     "odinn_set_schedule": (C.c_int, [_vp, C.POINTER(Schedule)]),
     "odinn_get_schedule": (C.c_int, [_vp, C.POINTER(Schedule)]),
+    "odinn_get_law_table": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp]),
     "odinn_set_fields": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "odinn_set_A": (C.c_int, [_vp, C.c_int, C.c_double]),
     "odinn_set_A_field": (C.c_int, [_vp, C.c_int, _dp]),

@@ -382,6 +382,13 @@ class GlacierBatch:
         L.check(L.lib().odinn_get_schedule(self._h, C.byref(sc)))
         return {k: getattr(sc, k) for k in L.SCHEDULE_FIELDS}
 
+    def law_table(self):
+        """odinn_get_law_table: state of the Y law's table (schedule field law_table) as a dict."""
+        use, ni, dev = C.c_int(0), C.c_int(0), np.zeros(1)
+        hmax = np.zeros(self.G)
+        L.check(L.lib().odinn_get_law_table(self._h, C.byref(use), C.byref(ni), _p(dev), _p(hmax)))
+        return {"usable": bool(use.value), "n_intervals": ni.value, "max_rel_dev": float(dev[0]), "hmax": hmax}
+
     def set_glacier_stops(self, g, t=None):
         """Glacier g's own stop table (the reference builds tstops per glacier, inversion_utils.jl:487-495); None / empty clears.
         The `tstops` of solve / loss_grad* then serve the glaciers without one; first and last stop must equal theirs."""

@@ -1,6 +1,8 @@
 // k_misc.hip -- controller, post-step, reductions, mass balance, hoisted-law kernels
 #define ODINN_MISC_KERNELS 1
 #include <algorithm>
+#include <cmath>
+#include <utility>
 #include "launch.hpp"
 namespace odinn {
 void launch_controller(int G, hipStream_t st, Pools P, CtrlArgs C) { hipLaunchKernelGGL(k_controller, dim3(G), dim3(64), 0, st, P, C); }
@@ -70,6 +72,33 @@ void launch_law_field_grad_scratch(int nblk, hipStream_t st, LawDev L, const dou
 }
 void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, double* out) {
   hipLaunchKernelGGL(k_sum_rows, dim3(Pn), dim3(64), 0, st, part, nrows, Pn, out);
+}
+// table of the Y law for G glaciers x ni intervals (k_ytab_build); stat: 3 zeroed 64-bit words
+void launch_ytab_build(hipStream_t st, Pools P, LawDev L, int G, double* tab, int ni, double floor_abs, unsigned long long* stat) {
+  static const YtabVinv V = [] {
+    YtabVinv v{};
+    long double a[6][12];
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int j = 0; j < 6; ++j) {
+      const long double x = cosl((2 * j + 1) * pi / 12.0L);
+      v.node[j] = (double)x;
+      const long double xd = (long double)v.node[j];  // the nodes the kernel really uses
+      long double pw = 1.0L;
+      for (int k = 0; k < 6; ++k) { a[j][k] = pw; pw *= xd; }
+      for (int k = 0; k < 6; ++k) a[j][6 + k] = j == k ? 1.0L : 0.0L;
+    }
+    for (int c = 0; c < 6; ++c) {  // Gauss-Jordan with partial pivoting: [V | I] -> [I | V^-1]
+      int pv = c;
+      for (int r = c + 1; r < 6; ++r) if (fabsl(a[r][c]) > fabsl(a[pv][c])) pv = r;
+      for (int k = 0; k < 12; ++k) std::swap(a[c][k], a[pv][k]);
+      const long double d = a[c][c];
+      for (int k = 0; k < 12; ++k) a[c][k] /= d;
+      for (int r = 0; r < 6; ++r) if (r != c) { const long double f = a[r][c]; for (int k = 0; k < 12; ++k) a[r][k] -= f * a[c][k]; }
+    }
+    for (int k = 0; k < 6; ++k) for (int j = 0; j < 6; ++j) v.v[k][j] = (double)a[k][6 + j];
+    return v;
+  }();
+  hipLaunchKernelGGL(k_ytab_build, dim3((unsigned)((ni + 255) / 256), (unsigned)G), dim3(256), 0, st, P, L, V, tab, ni, floor_abs, stat);
 }
 void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd) {
   hipLaunchKernelGGL(k_eval_law, dim3((unsigned)((nd + NT - 1) / NT)), dim3(NT), 0, st, P, L, U, out, gidx);

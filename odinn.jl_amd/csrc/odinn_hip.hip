@@ -146,7 +146,7 @@ static int sched_val(int field, const char* env) {
 }
 
 struct odinn_batch {
-  odinn_schedule sched = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
+  odinn_schedule sched = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -415,6 +415,26 @@ struct odinn_batch {
       if (!r.fast) return 1;
     return 0;
   }
+  // ---- tabulated Y law (LM_YTAB; sia2d_device.hpp: ytab_eval, k_ytab_build) ----
+  // odinn_schedule.law_table = 1 (or ODINN_LAW_TABLE=1): inside the forward solve and both adjoints the stencil kernels of a
+  // batch with the Y law read Y(Hbar) from a per-glacier table instead of evaluating the network at every dual node and
+  // stage.  The table is rebuilt whenever theta / the table range changes (refresh_gd) and is only used when its measured
+  // deviation from the network is below YTAB_TOL; the seam calls (arbitrary fields from the caller) always take the network.
+  double* d_ytab = nullptr;
+  int* d_ytab_over = nullptr;
+  unsigned long long* d_ytab_stat = nullptr;
+  int ytab_ni = 1024;
+  size_t ytab_cap = 0;
+  std::vector<double> ytab_hmax, h0max;  // per glacier: table range (0: not chosen yet), largest initial / reference thickness seen
+  bool ytab_ok = false;       // the table on the device belongs to the current theta / ranges and passed the check
+  bool ytab_blocked = false;  // given up for this batch's current fields (range overflow after two widenings)
+  int ytab_scope = 0;         // > 0 inside do_solve / odinn_loss_grad / odinn_loss_grad_continuous
+  double ytab_err_rel = 0.0, ytab_err_abs = 0.0, ytab_ymax = 0.0;
+  bool ytab_wanted() const {
+    return law_kind == ODINN_LAW_NN_Y && !ytab_blocked && sched_val(sched.law_table, "ODINN_LAW_TABLE") == 1;
+  }
+  // law mode of the stencil kernels that evaluate the law per node and stage (forward stages, H-VJP, reverse stages)
+  int lm_kern() const { return (ytab_scope > 0 && ytab_ok) ? LM_YTAB : lm(); }
   // dL/dA is accumulated on the dual grid when A is a field (hoisted NN or prescribed)
   bool wants_Gacc() const {
     return law_kind == ODINN_LAW_NN_A_GRIDDED || (law_kind == ODINN_LAW_CONST_A && has_Afield_const);
@@ -449,6 +469,9 @@ struct odinn_batch {
     L.theta = d_theta;
     L.theta_pad = d_theta_pad;
     L.bias_pad = d_theta_pad ? d_theta_pad + (size_t)pad_rows * pad_w : nullptr;
+    L.ytab = d_ytab;
+    L.ytab_over = d_ytab_over;
+    L.ytab_ni = ytab_ni;
     return L;
   }
 };
@@ -483,6 +506,52 @@ void dfree(T*& p) {
 }
 
 // derived per-glacier constants + hoisted scalar law; uploads d_gd when dirty
+// Build the Y law's table for the current theta / ranges and decide whether the kernels may use it: the deviation from the
+// network measured by k_ytab_build between the interpolation nodes must stay below YTAB_TOL relative to the law's value
+// (values below 1e-6 of the law's scale: relative to the largest value in the table).
+constexpr double YTAB_TOL = 1e-12;
+int ytab_refresh(odinn_batch* b) {
+  const size_t need = (size_t)b->G * 6 * b->ytab_ni;
+  if (need > b->ytab_cap || !b->d_ytab) {
+    dfree(b->d_ytab);
+    b->d_ytab = nullptr;
+    CHK(dalloc(&b->d_ytab, need));
+    b->ytab_cap = need;
+  }
+  if (!b->d_ytab_over) {
+    CHK(dalloc(&b->d_ytab_over, (size_t)1));
+    HIPCHK(hipMemsetAsync(b->d_ytab_over, 0, sizeof(int), b->stream));
+  }
+  if (!b->d_ytab_stat) CHK(dalloc(&b->d_ytab_stat, (size_t)3));
+  HIPCHK(hipMemsetAsync(b->d_ytab_stat, 0, 3 * sizeof(unsigned long long), b->stream));
+  const double floor_abs = 1e-6 * std::fabs(b->mlp.post_hi != 0.0 ? b->mlp.post_hi : 1.0);
+  launch_ytab_build(b->stream, b->pools(false), b->lawdev(), b->G, b->d_ytab, b->ytab_ni, floor_abs, b->d_ytab_stat);
+  HIPCHK(hipGetLastError());
+  double st[3];
+  HIPCHK(hipMemcpyAsync(st, b->d_ytab_stat, sizeof(st), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  b->ytab_err_rel = st[0]; b->ytab_err_abs = st[1]; b->ytab_ymax = st[2];
+  b->ytab_ok = st[0] <= YTAB_TOL && st[1] <= YTAB_TOL * std::max(st[2], floor_abs) && std::isfinite(st[2]);
+  static const bool verbose = std::getenv("ODINN_LAW_TABLE_VERBOSE") != nullptr;
+  if (verbose)
+    std::fprintf(stderr, "[odinn ytab] %d x %d intervals, rel %.3g abs %.3g ymax %.3g -> %s\n", b->G, b->ytab_ni, st[0], st[1], st[2],
+                 b->ytab_ok ? "table" : "network");
+  return ODINN_OK;
+}
+// did any node leave the table since the last call?  (clears the flag)
+int ytab_overflowed(odinn_batch* b, bool* over) {
+  *over = false;
+  if (!b->d_ytab_over) return ODINN_OK;
+  int f = 0;
+  HIPCHK(hipMemcpyAsync(&f, b->d_ytab_over, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  if (f) {
+    HIPCHK(hipMemsetAsync(b->d_ytab_over, 0, sizeof(int), b->stream));
+    *over = true;
+  }
+  return ODINN_OK;
+}
+
 int refresh_gd(odinn_batch* b) {
   if (!b->gd_dirty) return ODINN_OK;
   for (int g = 0; g < b->G; ++g) {
@@ -512,9 +581,27 @@ int refresh_gd(odinn_batch* b) {
       r.use_Afield = 0;
     }
   }
+  const bool ytab = b->ytab_wanted();
+  b->ytab_ok = false;
+  if (ytab) {
+    b->ytab_hmax.resize(b->G, 0.0);
+    b->h0max.resize(b->G, 0.0);
+    for (int g = 0; g < b->G; ++g) {
+      // range of the table: generously above the thickest ice the glacier's data shows; a solve that leaves it raises the
+      // overflow flag and is repeated with twice the range (do_solve)
+      if (!(b->ytab_hmax[g] > 0.0)) {
+        b->ytab_hmax[g] = std::max(200.0, 1.25 * b->h0max[g] + 50.0);
+        if (const char* e = std::getenv("ODINN_LAW_TABLE_HMAX"))  // (test aid: a first range small enough to overflow)
+          if (std::atof(e) > 0.0) b->ytab_hmax[g] = std::atof(e);
+      }
+      b->gd[g].yt_inv_h = (double)b->ytab_ni / b->ytab_hmax[g];
+      b->gd[g].yt_off = (long long)g * 6 * b->ytab_ni;
+    }
+  }
   HIPCHK(hipMemcpyAsync(b->d_gd, b->gd.data(), sizeof(GDev) * b->G, hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   b->gd_dirty = false;
+  if (ytab) CHK(ytab_refresh(b));
   return ODINN_OK;
 }
 
@@ -583,9 +670,9 @@ int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */
   }
   const Pools P = b->pools(g < 0);
   const int base = g < 0 ? 0 : b->gd[g].tile0, n = g < 0 ? b->ntiles : b->gd[g].ntiles;
-  static void (*const tab[7])(int, hipStream_t, Pools, LawDev, const double*, double*, int) = {
-      launch_dhdt_lm0, launch_dhdt_lm1, launch_dhdt_lm2, launch_dhdt_lm3, launch_dhdt_lm4, launch_dhdt_lm5, launch_dhdt_lm6};
-  tab[b->lm()](n, b->stream, P, b->lawdev(), U, dH, base);
+  static void (*const tab[8])(int, hipStream_t, Pools, LawDev, const double*, double*, int) = {
+      launch_dhdt_lm0, launch_dhdt_lm1, launch_dhdt_lm2, launch_dhdt_lm3, launch_dhdt_lm4, launch_dhdt_lm5, launch_dhdt_lm6, launch_dhdt_lm7};
+  tab[b->lm_kern()](n, b->stream, P, b->lawdev(), U, dH, base);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
 }
@@ -593,16 +680,16 @@ int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */
 template <int S>
 void launch_stage(odinn_batch* b, const Pools& P, const LawDev& L, const double* src, double* dst, double abstol,
                   double reltol) {
-  static void (*const tab[7])(int, int, hipStream_t, Pools, LawDev, const double*, double*, double*, double*, double*,
+  static void (*const tab[8])(int, int, hipStream_t, Pools, LawDev, const double*, double*, double*, double*, double*,
                               double, double) = {launch_rk_stage_lm0, launch_rk_stage_lm1, launch_rk_stage_lm2,
-                                                 launch_rk_stage_lm3, launch_rk_stage_lm4, launch_rk_stage_lm5, launch_rk_stage_lm6};
-  tab[b->lm()](S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol);
+                                                 launch_rk_stage_lm3, launch_rk_stage_lm4, launch_rk_stage_lm5, launch_rk_stage_lm6, launch_rk_stage_lm7};
+  tab[b->lm_kern()](S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol);
 }
 // vj < 0: the batch's VJP method (odinn_set_vjp_method)
 void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawDev& L, const AdjArgs& A, int base,
                   int vj = -1) {
-  static void (*const tab[7])(int, int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
-      launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5, launch_vjp_H_lm6};
+  static void (*const tab[8])(int, int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
+      launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5, launch_vjp_H_lm6, launch_vjp_H_lm7};
   // integer-power law, DiscreteVJP, all glaciers at once: the strip-layout kernel on the 62 x 62 tile table
   // (sia2d_adj_fused.hpp: k_vjp_H_strip; ODINN_VJPH_STRIP=0 keeps the 64 x 16 LDS-tile kernel) ...
   // ... where its 62 x 62 tiles are reasonably full: batches of small glaciers (alpine: 96 x 80 ... 192 x 160 fill them to
@@ -616,17 +703,17 @@ void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawD
     launch_vjp_H_strip(mode, b->gd[0].use_Afield ? 1 : 0, b->ntilesD, b->stream, P, b->d_tilesD, A);
     return;
   }
-  tab[b->lm()](mode, vje, nblk, b->stream, P, L, A, base);
+  tab[b->lm_kern()](mode, vje, nblk, b->stream, P, L, A, base);
 }
 void launch_adj_stage(int lm, int vj, int stage, int nblk, hipStream_t st, const Pools& P, const LawDev& L,
                       const AdjStageArgs& A) {
-  static void (*const tab[7])(int, int, int, hipStream_t, Pools, LawDev, AdjStageArgs) = {
+  static void (*const tab[8])(int, int, int, hipStream_t, Pools, LawDev, AdjStageArgs) = {
       launch_adj_stage_lm0, launch_adj_stage_lm1, launch_adj_stage_lm2, launch_adj_stage_lm3, launch_adj_stage_lm4,
-      launch_adj_stage_lm5, launch_adj_stage_lm6};
+      launch_adj_stage_lm5, launch_adj_stage_lm6, launch_adj_stage_lm7};
   tab[lm](stage, vj, nblk, st, P, L, A);
 }
 void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L, const ThArgs& A, int base) {
-  static void (*const tab[7])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
+  static void (*const tab[8])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
       launch_vjp_theta_lm0, launch_vjp_theta_lm1, launch_vjp_theta_lm2, launch_vjp_theta_lm3, launch_vjp_theta_lm4,
       launch_vjp_theta_lm5, launch_vjp_theta_lm6};
   // integer-power A-type laws, all glaciers at once: the strip-layout reduction (k_vjp_theta_strip), under the same
@@ -650,10 +737,10 @@ void launch_euler_cfl(odinn_batch* b, const Pools& P, const LawDev& L, const dou
     launch_euler_cfl_strip(b->ntilesD, b->gd[0].use_Afield, b->stream, P, b->d_tilesD, src, dst, b->d_partD);
     return;
   }
-  static void (*const tab[7])(int, hipStream_t, Pools, LawDev, const double*, double*) = {
+  static void (*const tab[8])(int, hipStream_t, Pools, LawDev, const double*, double*) = {
       launch_euler_cfl_lm0, launch_euler_cfl_lm1, launch_euler_cfl_lm2, launch_euler_cfl_lm3, launch_euler_cfl_lm4,
-      launch_euler_cfl_lm5, launch_euler_cfl_lm6};
-  tab[b->lm()](b->ntiles, b->stream, P, L, src, dst);
+      launch_euler_cfl_lm5, launch_euler_cfl_lm6, launch_euler_cfl_lm7};
+  tab[b->lm_kern()](b->ntiles, b->stream, P, L, src, dst);
 }
 
 // one RDPK3Sp35 step for all glaciers: 5 fused stage kernels.  parity p: state in U[p].
@@ -687,7 +774,7 @@ int pick_scheme(const odinn_batch* b, int requested) {
   // ODINN_SCHEME=2) forces it at any size.
   // Measured (2x16 Y law, us per step, per-stage vs fused): 4 alpine glaciers 201 vs 128, 1 x 512^2 216 vs 357,
   // 64 alpine 600 vs 755, 8 x 1024^2 2797 vs 3614 -- fused while its latency tiles do not fill the GPU
-  if (b->lm() >= 2 && s == 0) s = b->ntilesFs <= ODINN_NN_FUSED_MAX_TILES ? 2 : 1;
+  if (lm_is_nn(b->lm_kern()) && s == 0) s = b->ntilesFs <= ODINN_NN_FUSED_MAX_TILES ? 2 : 1;
   if (s == 0) s = 2;
   return s;
 }
@@ -706,9 +793,9 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
     launch_rk_fused_strip(nblk, b->gd[0].use_Afield, small == 3 ? 8 : TRPT, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol,
                           reltol, skip, sc, sq ? 1 : 0);
   } else {
-    static void (*const tab[7])(int, hipStream_t, Pools, LawDev, const int4*, double*, double*, double*, double, double, int, int) = {
-        launch_rk_fused_lm0, launch_rk_fused_lm1, launch_rk_fused_lm2, launch_rk_fused_lm3, launch_rk_fused_lm4, launch_rk_fused_lm5, launch_rk_fused_lm6};
-    tab[b->lm()](nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
+    static void (*const tab[8])(int, hipStream_t, Pools, LawDev, const int4*, double*, double*, double*, double, double, int, int) = {
+        launch_rk_fused_lm0, launch_rk_fused_lm1, launch_rk_fused_lm2, launch_rk_fused_lm3, launch_rk_fused_lm4, launch_rk_fused_lm5, launch_rk_fused_lm6, launch_rk_fused_lm7};
+    tab[b->lm_kern()](nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
   }
   HIPCHK(hipGetLastError());
   return ODINN_OK;
@@ -940,8 +1027,44 @@ int launch_lossV(odinn_batch* b, int j, const double* Hj, double* out, bool with
   return ODINN_OK;
 }
 
+int do_solve_once(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times,
+                  const odinn_solver_opts* o, odinn_solve_stats* stats);
+// The forward solve; with the tabulated Y law (lm_kern) a solve in which some node left the table's range is repeated with
+// twice the range, after two widenings with the network itself.
 int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times,
              const odinn_solver_opts* o, odinn_solve_stats* stats) {
+  for (int attempt = 0;; ++attempt) {
+    ++b->ytab_scope;
+    const int rc = do_solve_once(b, n_stops, tstops, n_mb, mb_times, o, stats);
+    --b->ytab_scope;
+    if (!b->ytab_ok) return rc;
+    bool over = false;
+    if (ytab_overflowed(b, &over) != ODINN_OK || !over) return rc;  // (a failed solve that left the table is repeated as well)
+    if (attempt >= 2) b->ytab_blocked = true;
+    else for (double& h : b->ytab_hmax) h *= 2.0;
+    b->gd_dirty = true;
+    b->solved = false;
+  }
+}
+// The gradient drivers run inside the same scope (their reverse passes read snapshots of a forward solve that stayed inside
+// the table, and H interpolated between two of them, so they cannot leave it; should the flag be raised all the same, the
+// call is repeated with the network).
+template <class F>
+int with_law_table(odinn_batch* b, F&& f) {
+  for (;;) {
+    ++b->ytab_scope;
+    const int rc = f();
+    --b->ytab_scope;
+    if (!b->ytab_ok) return rc;
+    bool over = false;
+    if (ytab_overflowed(b, &over) != ODINN_OK || !over) return rc;
+    b->ytab_blocked = true;
+    b->gd_dirty = true;
+    b->solved = false;
+  }
+}
+int do_solve_once(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const double* mb_times,
+                  const odinn_solver_opts* o, odinn_solve_stats* stats) {
   if (n_stops < 2) return fail(ODINN_ERR_ARG, "need at least 2 tstops");
   for (int j = 1; j < n_stops; ++j)
     if (!(tstops[j] > tstops[j - 1])) return fail(ODINN_ERR_ARG, "tstops must be strictly increasing");
@@ -1566,6 +1689,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_tilesD); dfree(b->d_partD);
   dfree(b->d_dh_i0); dfree(b->d_dh_i1); dfree(b->d_dh_coef); dfree(b->d_dh_part); dfree(b->d_dh_dt); dfree(b->d_dh_ref);
   dfree(b->d_tiles); dfree(b->d_tiles_nat); dfree(b->d_tilesF); dfree(b->d_partF); dfree(b->d_gd); dfree(b->d_gs);
+  dfree(b->d_ytab); dfree(b->d_ytab_over); dfree(b->d_ytab_stat);
   dfree(b->d_B); dfree(b->d_H0); dfree(b->d_U[0]); dfree(b->d_U[1]); dfree(b->d_S2); dfree(b->d_S3); dfree(b->d_E);
   dfree(b->d_lam[0]); dfree(b->d_lam[1]); dfree(b->d_tmpA); dfree(b->d_tmpB); dfree(b->d_mb0); dfree(b->d_Sref);
   dfree(b->d_Afield); dfree(b->d_Tfield); dfree(b->d_Gacc); dfree(b->d_part); dfree(b->d_nactive); dfree(b->d_dt0); dfree(b->d_tilesFs); dfree(b->d_partFs); dfree(b->d_tilesFt); dfree(b->d_partFt); dfree(b->d_tilesFu); dfree(b->d_partFu); dfree(b->d_tilesFv); dfree(b->d_partFv); dfree(b->d_est); dfree(b->d_gs2); dfree(b->d_part2);
@@ -1625,6 +1749,17 @@ int odinn_set_fields(odinn_batch* b, int g, const double* H0, const double* B) {
   CHK(up_field(b, g, b->d_H0, H0));
   CHK(up_field(b, g, b->d_B, B));
   b->solved = false;
+  {  // range of the Y law's table (refresh_gd): follows the thickest ice of the new state
+    b->h0max.resize(b->G, 0.0);
+    b->ytab_hmax.resize(b->G, 0.0);
+    double m = 0.0;
+    const size_t n = (size_t)b->gd[g].nx * b->gd[g].ny;
+    for (size_t i = 0; i < n; ++i) if (H0[i] > m) m = H0[i];
+    b->h0max[g] = m;
+    b->ytab_hmax[g] = 0.0;
+    b->ytab_blocked = false;
+    if (b->law_kind == ODINN_LAW_NN_Y) b->gd_dirty = true;
+  }
   return ODINN_OK;
 }
 
@@ -2343,11 +2478,12 @@ int odinn_set_glacier_stops(odinn_batch* b, int g, int n, const double* t) {
 
 int odinn_set_schedule(odinn_batch* b, const odinn_schedule* sc) {
   if (!b) return fail(ODINN_ERR_ARG, "null batch");
-  const odinn_schedule automatic = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
+  const odinn_schedule automatic = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
   const odinn_schedule want = sc ? *sc : automatic;  // (validated as a local: a rejected schedule leaves the old one in effect)
   if (want.adj_rows >= 0 && want.adj_rows != 4 && want.adj_rows != 7 && want.adj_rows != 8)
     return fail(ODINN_ERR_ARG, "odinn_schedule.adj_rows must be -1, 4, 7 or 8");
   if (want.fused_tiles > 4) return fail(ODINN_ERR_ARG, "odinn_schedule.fused_tiles must be -1 ... 4");
+  if (want.law_table != b->sched.law_table) b->gd_dirty = true;  // (the Y law's table is built by refresh_gd)
   b->sched = want;
   return ODINN_OK;
 }
@@ -2371,6 +2507,19 @@ int odinn_get_schedule(odinn_batch* b, odinn_schedule* out) {
   out->adj_segs = sched_val(b->sched.adj_segs, "ODINN_ADJ_SEGS");
   out->adj_rows = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS");
   out->adj_theta_fused = sched_val(b->sched.adj_theta_fused, "ODINN_ADJ_THETA_FUSED");
+  out->law_table = sched_val(b->sched.law_table, "ODINN_LAW_TABLE");
+  return ODINN_OK;
+}
+
+int odinn_get_law_table(odinn_batch* b, int* usable, int* n_intervals, double* max_rel_dev, double* hmax_per_glacier) {
+  if (!b) return fail(ODINN_ERR_ARG, "null batch");
+  CHK(use_dev(b));
+  CHK(refresh_gd(b));
+  if (usable) *usable = b->ytab_ok ? 1 : 0;
+  if (n_intervals) *n_intervals = b->ytab_ni;
+  if (max_rel_dev) *max_rel_dev = b->ytab_ok || b->ytab_wanted() ? std::max(b->ytab_err_rel, b->ytab_ymax > 0.0 ? b->ytab_err_abs / b->ytab_ymax : 0.0) : 0.0;
+  if (hmax_per_glacier)
+    for (int g = 0; g < b->G; ++g) hmax_per_glacier[g] = g < (int)b->ytab_hmax.size() && b->ytab_wanted() ? b->ytab_hmax[g] : 0.0;
   return ODINN_OK;
 }
 
@@ -2437,10 +2586,18 @@ static int grad_prepare(odinn_batch* b, const double* theta, int P, int n_stops,
 }
 static int grad_finish(odinn_batch* b, int k, int P, double const_loss, double* loss, double* dtheta);
 
+static int loss_grad_impl(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+                          const double* mb_times, const odinn_solver_opts* opts, double* loss, double* dtheta,
+                          odinn_solve_stats* stats);
 int odinn_loss_grad(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
                     const double* mb_times, const odinn_solver_opts* opts, double* loss, double* dtheta,
                     odinn_solve_stats* stats) {
   if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
+  return with_law_table(b, [&] { return loss_grad_impl(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, loss, dtheta, stats); });
+}
+static int loss_grad_impl(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+                          const double* mb_times, const odinn_solver_opts* opts, double* loss, double* dtheta,
+                          odinn_solve_stats* stats) {
   CHK(grad_prepare(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, stats));
   // ---- reverse loop: gradient.jl:191-253 -------------------------------------------------
   // Row j of the per-glacier tables = the glacier's own j-th stop (t = result.t of THAT glacier, gradient.jl:71-73): a
@@ -2582,10 +2739,20 @@ static void gauss_legendre(int n, std::vector<double>& x, std::vector<double>& w
 // The reverse ODE dlam/dtau = J_H(H_itp(-tau))^T lam runs on the same device-side RDPK3Sp35 + PID
 // machinery as the forward solve (one k_adj_stage per stage); its stops are the snapshot times
 // (loss and mass-balance callbacks) and the Gauss-Legendre nodes (theta-VJP quadrature).
+static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+                                     const double* mb_times, const odinn_solver_opts* opts, const odinn_adjoint_opts* aopts,
+                                     double* loss, double* dtheta, odinn_solve_stats* stats, odinn_solve_stats* stats_rev);
 int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
                                const double* mb_times, const odinn_solver_opts* opts, const odinn_adjoint_opts* aopts,
                                double* loss, double* dtheta, odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
   if (!b || !tstops || !loss || !dtheta) return fail(ODINN_ERR_ARG, "null argument");
+  return with_law_table(b, [&] {
+    return loss_grad_continuous_impl(b, theta, P, n_stops, tstops, n_mb, mb_times, opts, aopts, loss, dtheta, stats, stats_rev);
+  });
+}
+static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P, int n_stops, const double* tstops, int n_mb,
+                                     const double* mb_times, const odinn_solver_opts* opts, const odinn_adjoint_opts* aopts,
+                                     double* loss, double* dtheta, odinn_solve_stats* stats, odinn_solve_stats* stats_rev) {
   const bool useV = b->loss_kind != ODINN_LOSS_H;
   odinn_adjoint_opts ao{1e-8, 1e-8, 1.0 / 12.0, 200, 0, 1000000};  // AdjointTypes.jl:58-67
   if (aopts) ao = *aopts;
@@ -2893,7 +3060,7 @@ int odinn_loss_grad_continuous(odinn_batch* b, const double* theta, int P, int n
         double* dst = a1;
         for (int stg = 1; stg <= 5; ++stg) {
           SA.src = src; SA.dst = dst;
-          launch_adj_stage(lm, b->vjp_method, stg, b->ntiles, b->stream, Pl, L, SA);
+          launch_adj_stage(b->lm_kern(), b->vjp_method, stg, b->ntiles, b->stream, Pl, L, SA);
           double* t_ = const_cast<double*>(src);
           src = dst;
           dst = t_;

@@ -125,6 +125,10 @@ struct GDev {  // per-glacier constants
   int use_Afield;  // A read from the dual-grid field
   int has_mb;
   double dmb_dS, mb_max;
+  // tabulated Y law (law mode LM_YTAB): this glacier's table starts at yt_off doubles, interval i covers
+  // [i, i + 1) / yt_inv_h metres of Hbar
+  double yt_inv_h;
+  long long yt_off;
 };
 
 struct GState {  // per-glacier integrator state (written by the controller kernel)
@@ -163,6 +167,11 @@ struct LawDev {  // passed by value to kernels
   // biases in the same order (odinn_set_theta repacks them) -- a unit's weights are then ONE aligned scalar load
   const double* theta_pad;
   const double* bias_pad;
+  // tabulated Y law (LM_YTAB): ytab_ni intervals per glacier, six Chebyshev-basis-free monomial coefficients each (ytab_eval);
+  // *ytab_over is raised by any node whose Hbar lies beyond the table
+  const double* ytab;
+  int* ytab_over;
+  int ytab_ni;
 };
 
 struct Pools {  // pooled device arrays (all glaciers concatenated)
@@ -644,8 +653,10 @@ __device__ __forceinline__ void mlp_grad_wave(const LawDev& L, double x0, double
 //   3: 2 -> 3 -> 10 -> 3 -> 1, softplus x3 + sigmoid   (build_default_NN, ML_utils.jl:31-36)
 //   4: 2 -> 16 -> 16 -> 1,     softplus x2 + sigmoid   (BASELINE configs[2], "2 layers x 16 units")
 //   5: 2 -> 3 -> 1,            softplus + sigmoid      (test_mode light net, ML_utils.jl:26-29)
-constexpr int LM_FAST = 0, LM_POW = 1, LM_NN = 2, LM_NN_DEF = 3, LM_NN_16 = 4, LM_NN_LIGHT = 5, LM_NN_WIDE = 6;
-constexpr bool lm_is_nn(int lm) { return lm >= LM_NN; }
+//   7: the Y law of target :D_hybrid through a per-glacier TABLE of Y(Hbar) (its other input, the glacier's temperature, is a
+//      scalar: LawY's inputs are (T, Hbar), Laws.jl:240-273) -- structurally a closed-form law: no network in the kernel
+constexpr int LM_FAST = 0, LM_POW = 1, LM_NN = 2, LM_NN_DEF = 3, LM_NN_16 = 4, LM_NN_LIGHT = 5, LM_NN_WIDE = 6, LM_YTAB = 7;
+constexpr bool lm_is_nn(int lm) { return lm >= LM_NN && lm <= LM_NN_WIDE; }
 // run-time architectures: LM_NN (every layer has <= 16 inputs) and LM_NN_WIDE (<= 32) -- kernels of their own, the 32-wide
 // evaluator holds 128 registers of activations and would set the register allocation of the common case
 constexpr bool lm_is_rt(int lm) { return lm == LM_NN || lm == LM_NN_WIDE; }
@@ -964,9 +975,67 @@ __device__ __forceinline__ double spow(double gS2, double e) {
 // NK: 0 = the law's kind is read from L (one kernel for both per-node-network laws), 3 / 4 = compile-time Y / U law -- the
 // reverse kernels are instantiated per law: the U law's four perturbations and the Y law's single one want different
 // register budgets, and in a shared kernel the allocation of the one spills the other
+// ---- tabulated Y law (LM_YTAB) -------------------------------------------------------------------------------------------
+// LawY's inputs are the glacier's long-term air temperature -- a SCALAR per glacier -- and Hbar (Laws.jl:240-273), so for a
+// given theta the law of one glacier is a function of ONE variable.  k_ytab_build evaluates the network exactly on six Chebyshev
+// nodes of each of ytab_ni equal intervals of [0, Hmax_g] and stores the interpolating quintic in s = 2 (Hbar / h - i) - 1 as
+// monomial coefficients c0 .. c5 (48 bytes per interval); the build also measures the table against the network between the
+// nodes and the host keeps the exact kernels unless the worst relative deviation is below 1e-12 (odinn_hip.hip: ytab_refresh).
+// The reference's forward difference (Y(Hbar + 1e-4) - Y(Hbar)) / 1e-4 (target_D_hybrid.jl:58-71) keeps its semantics: the
+// perturbed value is the SAME quintic at s + ds, formed as Y + [p(s + ds) - p(s)] with the exact finite Taylor shift of the
+// polynomial, ds from the perturbation the reference really applies, fl(Hbar + 1e-4) - Hbar.  A node beyond the table takes the
+// table's last value and raises *ytab_over: the host repeats the call with a wider table (or the exact kernels).
+template <bool ADJ>
+__device__ __forceinline__ double ytab_eval(const GDev& g, const LawDev& L, double Hb, double& Yp) {
+  double x = Hb * g.yt_inv_h;
+  if (!(x < (double)L.ytab_ni)) {  // beyond the table (or NaN): the table's last value, so that the doomed solve stays tame
+    x = (double)L.ytab_ni;
+    *L.ytab_over = 1;
+  }
+  const int i = min((int)x, L.ytab_ni - 1);  // Hbar >= 0
+  const double s = fma(2.0, x - (double)i, -1.0);
+  const double2* __restrict__ c = reinterpret_cast<const double2*>(L.ytab + g.yt_off) + 3 * i;
+  const double2 c01 = c[0], c23 = c[1], c45 = c[2];
+  const double Y = fma(fma(fma(fma(fma(c45.y, s, c45.x), s, c23.y), s, c23.x), s, c01.y), s, c01.x);
+  if (ADJ) {
+    const double ds = 2.0 * (((Hb + 1e-4) - Hb) * g.yt_inv_h);
+    const double p1 = fma(fma(fma(fma(5.0 * c45.y, s, 4.0 * c45.x), s, 3.0 * c23.y), s, 2.0 * c23.x), s, c01.y);
+    const double p2 = fma(fma(fma(10.0 * c45.y, s, 6.0 * c45.x), s, 3.0 * c23.y), s, c23.x);
+    const double p3 = fma(fma(10.0 * c45.y, s, 4.0 * c45.x), s, c23.y);
+    const double p4 = fma(5.0 * c45.y, s, c45.x);
+    Yp = fma(ds, fma(ds, fma(ds, fma(ds, fma(ds, c45.y, p4), p3), p2), p1), Y);
+  }
+  return Y;
+}
+
 template <bool ADJ, int LM, int NK = 0>
 __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double Hb, double gS2, double Anode,
                                          double& alpha, double& beta, double& spat) {
+  if constexpr (LM == LM_YTAB) {  // the Y law's closed form below with Y (and Y at Hbar + 1e-4) from the table
+    double Yp = 0.0;
+    const double Y = ytab_eval<ADJ>(g, L, Hb, Yp);
+    const double sS1 = spow(gS2, g.nS - 1.0);
+    const double geo = g.Gam * upow(Hb, g.nH + 2.0) * sS1;
+    double D = Y * geo;
+    double hs = 0.0, sp1 = 0.0;
+    if (g.Sc != 0.0) {
+      hs = upow(Hb, g.p - g.q + 1.0);
+      sp1 = spow(gS2, g.p - 1.0);
+      D += g.Sc * hs * sp1;
+    }
+    if (ADJ) {
+      const double dH = 1e-4;  // target_D_hybrid.jl:58
+      const double slide = g.Sc != 0.0 ? g.Sc * hs * sp1 : 0.0;
+      alpha = (g.nH + 2.0) * Y * g.Gam * upow(Hb, g.nH + 1.0) * sS1 + ((slide + Yp * geo) - (slide + Y * geo)) / dH;
+      beta = g.Gam * Y * (g.nS - 1.0) * upow(Hb, g.nH + 2.0) * spow(gS2, g.nS - 3.0);
+      if (g.Sc != 0.0) {
+        alpha += (g.p - g.q + 1.0) * g.Sc * upow(Hb, g.p - g.q) * sp1;
+        beta += g.Sc * (g.p - 1.0) * hs * spow(gS2, g.p - 3.0);
+      }
+      spat = geo;
+    }
+    return D;
+  }
   if (!lm_is_nn(LM)) {  // A-type laws (scalar or field A)
     if (LM == LM_FAST) {
       const double H2 = Hb * Hb, H4 = H2 * H2;
@@ -1912,7 +1981,7 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
 // which needs a third double2 per node ({alpha/4, q/4}).
 template <int LM, int VJ = 0>
 struct VjpHLds {
-  static constexpr bool ALIAS = LM <= LM_POW;
+  static constexpr bool ALIAS = !lm_is_nn(LM);
   static constexpr int A_D2 = (TY + 2) * LDW + ((TY + 2) * LDW + 1) / 2;  // in double2 units
   static constexpr int B_D2 = (VJ ? 3 : 2) * (TY + 1) * LDN;
   static constexpr int SIZE = ALIAS ? (A_D2 > B_D2 ? A_D2 : B_D2) : A_D2 + B_D2;
@@ -2710,6 +2779,53 @@ __global__ __launch_bounds__(NT) void k_eval_law(Pools P, LawDev L, const double
   else if (L.kind == 4) v = mlp_eval_any(L, Hb, sqrt(gx * gx + gy * gy));
   else v = g.use_Afield ? P.Afield[g.offd + i] : g.A;
   out[i] = v;
+}
+
+// ---- table of the Y law (LM_YTAB, ytab_eval) -------------------------------------------------------------------------
+// One thread per interval i of glacier blockIdx.y: the network at the six Chebyshev nodes s_j = cos((2 j + 1) pi / 12) of the
+// interval, the interpolating quintic's monomial coefficients c = Vinv f (Vinv: inverse Vandermonde matrix of the nodes, formed
+// on the host in long double), and the table's deviation from the network at six points between the nodes.  stat[0] = largest
+// |table - network| / max(|network|, 1e-6 largest |network| seen so far ...) is not order-independent, so the kernel reduces the
+// two ingredients separately: stat[0] = max |table - network| / |network| over points with |network| >= floor, stat[1] =
+// max |table - network| over the others, stat[2] = max |network|; the host forms the verdict.  (Non-negative doubles order like
+// their bit patterns: atomicMax on the 64-bit integers.)
+struct YtabVinv { double v[6][6]; double node[6]; };
+__global__ __launch_bounds__(256) void k_ytab_build(Pools P, LawDev L, YtabVinv V, double* __restrict__ tab, int ni, double floor_abs,
+                                                    unsigned long long* __restrict__ stat) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ni) return;
+  const GDev g = P.gd[blockIdx.y];
+  const double h = 1.0 / g.yt_inv_h;
+  double f[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) f[j] = mlp_eval_any(L, g.T, ((double)i + 0.5 + 0.5 * V.node[j]) * h);
+  double c[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) a = fma(V.v[k][j], f[j], a);
+    c[k] = a;
+  }
+  double* __restrict__ o = tab + g.yt_off + 6 * (long long)i;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o[k] = c[k];
+  const double chk[6] = {-0.985, -0.55, -0.13, 0.31, 0.68, 0.995};
+  double erel = 0.0, eabs = 0.0, ymax = 0.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const double sj = chk[j];
+    const double y = mlp_eval_any(L, g.T, ((double)i + 0.5 + 0.5 * sj) * h);
+    const double p = fma(fma(fma(fma(fma(c[5], sj, c[4]), sj, c[3]), sj, c[2]), sj, c[1]), sj, c[0]);
+    const double e = fabs(p - y), ay = fabs(y);
+    if (!(e == e)) erel = 1e300;  // NaN anywhere: no table
+    if (ay >= floor_abs) erel = fmax(erel, e / ay);
+    else eabs = fmax(eabs, e);
+    ymax = fmax(ymax, ay);
+  }
+  atomicMax(&stat[0], (unsigned long long)__double_as_longlong(erel));
+  atomicMax(&stat[1], (unsigned long long)__double_as_longlong(eabs));
+  atomicMax(&stat[2], (unsigned long long)__double_as_longlong(ymax));
 }
 
 // ---- misc elementwise over pooled arrays ---------------------------------------------
