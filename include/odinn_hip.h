@@ -173,7 +173,9 @@ typedef struct odinn_schedule {
                               while its measured deviation from the network is < 1e-12 relative; a solve that leaves the table's
                               range is repeated with a wider one) instead of evaluating the network per dual node and stage;
                               0 / -1 = the network itself (the default)                                                            */
-  int32_t reserved[4];     /* zero                                                                                                 */
+  int32_t interp_async;    /* ODINN_INTERP_ASYNC: 0 = the Y law's `:Linear` contraction of a quadrature node on the batch's own stream
+                              instead of overlapped with the following reverse steps on a second stream (continuous adjoint)       */
+  int32_t reserved[3];     /* zero                                                                                                 */
 } odinn_schedule;
 
 typedef struct odinn_batch odinn_batch;

@@ -146,7 +146,7 @@ static int sched_val(int field, const char* env) {
 }
 
 struct odinn_batch {
-  odinn_schedule sched = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
+  odinn_schedule sched = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -340,6 +340,15 @@ struct odinn_batch {
   long long interp_ndmax = 0;
   hipStream_t side[INTERP_LANES_MAX] = {};
   hipEvent_t ev_fork = nullptr, ev_join[INTERP_LANES_MAX] = {};
+  // continuous adjoint with the Y law's `:Linear` gradient interpolation: the sort / knots / interval sums / knot backprop of a
+  // quadrature node run on a stream of their own while the batch's stream goes on with the reverse steps (interp_async_*):
+  // two sets of emitted node arrays, ev_emit[s] = "set s is written", ev_done[s] = "set s has been contracted into d_dth"
+  bool interp_async = false;
+  int ia_slot = 0;
+  bool ia_pending[2] = {false, false};
+  double *d_nodeH2 = nullptr, *d_nodeV2 = nullptr;
+  hipStream_t ia_stream = nullptr;
+  hipEvent_t ev_emit[2] = {}, ev_done[2] = {};
   size_t sorttmp_bytes = 0, knotG_cap = 0;
   double *d_part_theta = nullptr, *d_gscratch = nullptr, *d_dth = nullptr;
   size_t part_theta_cap = 0, gscratch_cap = 0, dth_cap = 0;
@@ -1721,6 +1730,12 @@ int odinn_batch_destroy(odinn_batch* b) {
     if (b->ev_join[l]) (void)hipEventDestroy(b->ev_join[l]);
   }
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+  if (b->ia_stream) { (void)hipStreamSynchronize(b->ia_stream); (void)hipStreamDestroy(b->ia_stream); }
+  for (int s_ = 0; s_ < 2; ++s_) {
+    if (b->ev_emit[s_]) (void)hipEventDestroy(b->ev_emit[s_]);
+    if (b->ev_done[s_]) (void)hipEventDestroy(b->ev_done[s_]);
+  }
+  dfree(b->d_nodeH2); dfree(b->d_nodeV2);
   dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
   dfree(b->d_Vabs); dfree(b->d_Vxr); dfree(b->d_Vyr); dfree(b->d_wv); dfree(b->d_vsc); dfree(b->d_vslot);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -2056,6 +2071,74 @@ static int vel_theta_finish(odinn_batch* b, int g, bool accumulate, const Pools&
   return ODINN_OK;
 }
 
+// ---- the Y law's `:Linear` contraction off the critical path of the reverse solve --------------------------------------------
+// The theta-integrand of a quadrature node does not feed back into the reverse ODE, so its contraction (a radix sort of all
+// dual nodes, the knots, the interval sums, the backprop at the knots: ~15 dependent launches that leave most of the GPU idle)
+// runs on ia_stream while the batch's stream takes the next reverse steps.  The emitting kernel alternates between two sets
+// of node arrays; contractions are issued in the order of the nodes on ONE stream, so d_dth sees the same additions in the same
+// order as without the overlap (bit-identical gradients).  ODINN_INTERP_ASYNC=0 / odinn_schedule.interp_async = 0 turns it off.
+static bool interp_async_possible(odinn_batch* b, bool useV) {
+  if (useV || b->law_kind != ODINN_LAW_NN_Y || b->grad_interp != ODINN_GRAD_INTERP_LINEAR) return false;
+  if (sched_val(b->sched.interp_async, "ODINN_INTERP_ASYNC") == 0) return false;
+  if (sched_val(b->sched.interp_batch, "ODINN_INTERP_BATCH") == 0) return false;
+  return b->d_ib_gid && interp_batch_lds_bytes(b->P) <= 30 * 1024;
+}
+static int interp_async_setup(odinn_batch* b) {
+  if (!b->ia_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&b->ia_stream, hipStreamNonBlocking));
+    for (int s = 0; s < 2; ++s) {
+      HIPCHK(hipEventCreateWithFlags(&b->ev_emit[s], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&b->ev_done[s], hipEventDisableTiming));
+    }
+  }
+  if (!b->d_nodeH2) { CHK(dalloc(&b->d_nodeH2, (size_t)b->ntotd)); CHK(dalloc(&b->d_nodeV2, (size_t)b->ntotd)); }
+  b->ia_slot = 0;
+  b->ia_pending[0] = b->ia_pending[1] = false;
+  return ODINN_OK;
+}
+// node arrays the next emitting launch may write (zeroed, on the batch's stream, once their previous contraction is through)
+static int interp_async_begin(odinn_batch* b, double** nH, double** nV) {
+  const int s = b->ia_slot;
+  *nH = s ? b->d_nodeH2 : b->d_nodeH;
+  *nV = s ? b->d_nodeV2 : b->d_nodeV;
+  if (b->ia_pending[s]) HIPCHK(hipStreamWaitEvent(b->stream, b->ev_done[s], 0));
+  HIPCHK(hipMemsetAsync(*nH, 0, (size_t)b->ntotd * sizeof(double), b->stream));
+  HIPCHK(hipMemsetAsync(*nV, 0, (size_t)b->ntotd * sizeof(double), b->stream));
+  return ODINN_OK;
+}
+static int interp_async_contract(odinn_batch* b, const double* nH, const double* nV, const Pools& P) {
+  const int s = b->ia_slot;
+  HIPCHK(hipEventRecord(b->ev_emit[s], b->stream));
+  HIPCHK(hipStreamWaitEvent(b->ia_stream, b->ev_emit[s], 0));
+  const int rc = launch_interp_theta_batch(b->ia_stream, P, b->lawdev(), b->n_interp_half, 0, b->G, 0, b->ntotd, nH, nV, b->d_ib_gid,
+                                           b->d_ib_iota, b->d_ib_sH, b->d_ib_sV, b->d_ib_iA, b->d_ib_iB, b->d_ib_kA, b->d_ib_kB,
+                                           b->d_ib_tmp, b->ib_tmp_bytes, b->d_ib_knots, b->d_ib_M, b->d_ib_ab, b->d_dth, 1);
+  if (rc) return fail(ODINN_ERR_HIP, "gradient interpolation failed (code %d)", rc);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(b->ev_done[s], b->ia_stream));
+  b->ia_pending[s] = true;
+  b->ia_slot = 1 - s;
+  return ODINN_OK;
+}
+// the batch's stream waits for every contraction issued so far
+static int interp_async_join(odinn_batch* b) {
+  for (int s = 0; s < 2; ++s)
+    if (b->ia_pending[s]) {
+      HIPCHK(hipStreamWaitEvent(b->stream, b->ev_done[s], 0));
+      b->ia_pending[s] = false;
+    }
+  return ODINN_OK;
+}
+struct InterpAsyncScope {  // leaves no work behind on ia_stream, whichever way the driver returns
+  odinn_batch* b;
+  ~InterpAsyncScope() {
+    if (!b->interp_async) return;
+    b->interp_async = false;
+    if (b->ia_stream) (void)hipStreamSynchronize(b->ia_stream);
+    b->ia_pending[0] = b->ia_pending[1] = false;
+  }
+};
+
 static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
                             bool accumulate, double* part_deferred = nullptr, bool inplace = false,
                             const double* lam_alt = nullptr, const double* snaps = nullptr, const AdjState* adj = nullptr) {
@@ -2073,9 +2156,13 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   const bool emit_rt = nn_node && !linear && lm_is_rt(b->lm()) && (size_t)NW * b->P * sizeof(double) + (size_t)b->P * sizeof(int) <= 30 * 1024;
   const bool emit = linear || emit_rt;
   if (nn_node) CHK(ensure_theta_scratch(b, std::max(nblk, (int)node_backprop_part_count(ng, 1)), !emit));
-  if (emit) CHK(interp_prepare(b, g, isU));
+  const bool async = linear && !isU && g < 0 && accumulate && b->interp_async;
+  double *nH = b->d_nodeH, *nV = b->d_nodeV;
+  if (async) CHK(interp_async_begin(b, &nH, &nV));
+  else if (emit) CHK(interp_prepare(b, g, isU));
+  if (emit && !async) { nH = b->d_nodeH; nV = b->d_nodeV; }  // (allocated by interp_prepare)
   ThArgs A{};
-  A.emitH = emit ? b->d_nodeH : nullptr; A.emitV = emit ? b->d_nodeV : nullptr; A.emitS = (emit && isU) ? b->d_nodeS : nullptr;
+  A.emitH = emit ? nH : nullptr; A.emitV = emit ? nV : nullptr; A.emitS = (emit && isU) ? b->d_nodeS : nullptr;
   A.H = H; A.lam = lam; A.lam_alt = lam_alt; A.scales = scales;
   A.snaps = snaps; A.adj = adj; A.ntot = b->ntot;
   A.Gacc = b->wants_Gacc() ? b->d_Gacc : nullptr;
@@ -2085,7 +2172,9 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   Pools P = b->pools(g < 0);
   if (part_deferred) P.part = part_deferred;
   launch_vjp_theta(b, nblk, P, b->lawdev(), A, base);
-  if (linear) {
+  if (async) {
+    CHK(interp_async_contract(b, nH, nV, P));
+  } else if (linear) {
     CHK(interp_contract(b, g, isU, accumulate, P));
   } else if (emit_rt) {
     if (launch_node_backprop(b->stream, P, b->lawdev(), g0, ng, b->ntotd, b->d_nodeH, b->d_nodeS, b->d_nodeV, b->d_part_theta, b->d_dth,
@@ -2478,7 +2567,7 @@ int odinn_set_glacier_stops(odinn_batch* b, int g, int n, const double* t) {
 
 int odinn_set_schedule(odinn_batch* b, const odinn_schedule* sc) {
   if (!b) return fail(ODINN_ERR_ARG, "null batch");
-  const odinn_schedule automatic = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
+  const odinn_schedule automatic = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
   const odinn_schedule want = sc ? *sc : automatic;  // (validated as a local: a rejected schedule leaves the old one in effect)
   if (want.adj_rows >= 0 && want.adj_rows != 4 && want.adj_rows != 7 && want.adj_rows != 8)
     return fail(ODINN_ERR_ARG, "odinn_schedule.adj_rows must be -1, 4, 7 or 8");
@@ -2508,6 +2597,7 @@ int odinn_get_schedule(odinn_batch* b, odinn_schedule* out) {
   out->adj_rows = sched_val(b->sched.adj_rows, "ODINN_ADJ_ROWS");
   out->adj_theta_fused = sched_val(b->sched.adj_theta_fused, "ODINN_ADJ_THETA_FUSED");
   out->law_table = sched_val(b->sched.law_table, "ODINN_LAW_TABLE");
+  out->interp_async = sched_val(b->sched.interp_async, "ODINN_INTERP_ASYNC");
   return ODINN_OK;
 }
 
@@ -3045,6 +3135,14 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
   int chunk = std::max(2, std::min(256, nr & ~1));
   long long steps = 0;
   int p = 0;
+  InterpAsyncScope ia_scope{b};
+  if (b->law_kind == ODINN_LAW_NN_Y) {
+    CHK(ensure_interp_scratch(b));
+    if (interp_async_possible(b, useV)) {
+      CHK(interp_async_setup(b));
+      b->interp_async = true;
+    }
+  }
   while (nact > 0) {
     for (int s_ = 0; s_ < chunk; ++s_) {
       double* a0 = b->d_lam[p];
@@ -3134,6 +3232,7 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
       stats_rev[g].dt_last = gs[g].dt;
     }
   }
+  if (b->interp_async) CHK(interp_async_join(b));
   if (acc_inplace) launch_sum_part_steps(G, b->stream, Pl, b->d_partsteps, 4LL * b->ntiles, 0, 0, 2, b->d_Gsum);
   if (theta_fused) launch_sum_tilesFt(G, adj_rows, b->stream, Pl, b->d_partTh, b->d_Gsum);
   // lambda(t0) of every glacier -> d_lam[0] (glaciers finish in different ping-pong buffers)
