@@ -167,12 +167,12 @@ typedef struct odinn_schedule {
   int32_t adj_segs;        /* ODINN_ADJ_SEGS: 0 = read the two snapshots instead of the interleaved {H_j, H_j+1 - H_j} pairs       */
   int32_t adj_rows;        /* ODINN_ADJ_ROWS: 4 | 7 | 8 rows per thread of the fused reverse step (8: gridded A only, else ignored) */
   int32_t adj_theta_fused; /* ODINN_ADJ_THETA_FUSED: 0 = theta-VJP of a quadrature node in launches of its own                     */
-  int32_t law_table;       /* ODINN_LAW_TABLE: 1 = inside the forward solve and both adjoints the stencil kernels of a batch with
-                              the Y law (ODINN_LAW_NN_Y: inputs = the glacier's scalar temperature and Hbar) read Y(Hbar) from a
-                              per-glacier table of quintics (1024 intervals; rebuilt from the network when theta changes, used only
-                              while its measured deviation from the network is < 1e-12 relative; a solve that leaves the table's
-                              range is repeated with a wider one) instead of evaluating the network per dual node and stage;
-                              0 / -1 = the network itself (the default)                                                            */
+  int32_t law_table;       /* ODINN_LAW_TABLE: 0 = the stencil kernels of a batch with the Y law (ODINN_LAW_NN_Y: inputs = the
+                              glacier's scalar temperature and Hbar) evaluate the network at every dual node and stage.  Default
+                              (-1 / 1): inside the forward solve and both adjoints they read Y(Hbar) from a per-glacier table of
+                              quintics (1024 intervals; rebuilt from the network whenever theta changes, used only while its
+                              measured deviation from the network is < 1e-12 relative -- else the network; a solve that leaves the
+                              table's range is repeated with a wider one).  The seam calls always evaluate the network           */
   int32_t interp_async;    /* ODINN_INTERP_ASYNC: 0 = the Y law's `:Linear` contraction of a quadrature node on the batch's own stream
                               instead of overlapped with the following reverse steps on a second stream (continuous adjoint)       */
   int32_t reserved[3];     /* zero                                                                                                 */

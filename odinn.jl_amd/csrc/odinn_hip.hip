@@ -425,9 +425,9 @@ struct odinn_batch {
     return 0;
   }
   // ---- tabulated Y law (LM_YTAB; sia2d_device.hpp: ytab_eval, k_ytab_build) ----
-  // odinn_schedule.law_table = 1 (or ODINN_LAW_TABLE=1): inside the forward solve and both adjoints the stencil kernels of a
-  // batch with the Y law read Y(Hbar) from a per-glacier table instead of evaluating the network at every dual node and
-  // stage.  The table is rebuilt whenever theta / the table range changes (refresh_gd) and is only used when its measured
+  // Inside the forward solve and both adjoints the stencil kernels of a batch with the Y law read Y(Hbar) from a per-glacier
+  // table instead of evaluating the network at every dual node and stage (odinn_schedule.law_table = 0 / ODINN_LAW_TABLE=0:
+  // always the network).  The table is rebuilt whenever theta / the table range changes (refresh_gd) and is only used when its measured
   // deviation from the network is below YTAB_TOL; the seam calls (arbitrary fields from the caller) always take the network.
   double* d_ytab = nullptr;
   int* d_ytab_over = nullptr;
@@ -440,7 +440,7 @@ struct odinn_batch {
   int ytab_scope = 0;         // > 0 inside do_solve / odinn_loss_grad / odinn_loss_grad_continuous
   double ytab_err_rel = 0.0, ytab_err_abs = 0.0, ytab_ymax = 0.0;
   bool ytab_wanted() const {
-    return law_kind == ODINN_LAW_NN_Y && !ytab_blocked && sched_val(sched.law_table, "ODINN_LAW_TABLE") == 1;
+    return law_kind == ODINN_LAW_NN_Y && !ytab_blocked && sched_val(sched.law_table, "ODINN_LAW_TABLE") != 0;
   }
   // law mode of the stencil kernels that evaluate the law per node and stage (forward stages, H-VJP, reverse stages)
   int lm_kern() const { return (ytab_scope > 0 && ytab_ok) ? LM_YTAB : lm(); }

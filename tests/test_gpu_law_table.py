@@ -1,5 +1,5 @@
 """GPU: the tabulated Y law (odinn_schedule.law_table, law mode LM_YTAB).  LawY's inputs are the glacier's scalar temperature
-and Hbar (Laws.jl:240-273), so per glacier and theta the law is a function of one variable; with law_table = 1 the stencil
+and Hbar (Laws.jl:240-273), so per glacier and theta the law is a function of one variable; unless law_table = 0 the stencil
 kernels of the forward solve and of both adjoints read it from a table of quintics built from the network itself.  The table
 path must reproduce the network path -- forward states to 1e-11, gradients to 1e-8 (the reference's finite-difference
 partial of the law, target_D_hybrid.jl:58-71, amplifies any difference in Y by 1e4) -- stay within the oracle tolerances of the
@@ -11,6 +11,12 @@ from conftest import rel_l2, stats_err_arrays
 from oracle import sia2d_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _no_overrides(monkeypatch):  # (the suite is also run under ODINN_LAW_TABLE=1 / ODINN_INTERP_ASYNC=0: these tests set the fields)
+    monkeypatch.delenv("ODINN_LAW_TABLE", raising=False)
+    monkeypatch.delenv("ODINN_INTERP_ASYNC", raising=False)
 
 ARCHS = {"light": ([2, 3, 1], [1, 2]), "default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "x16": ([2, 16, 16, 1], [1, 1, 2]),
          "runtime": ([2, 5, 10, 5, 1], [3, 3, 3, 1])}
@@ -37,6 +43,7 @@ def test_table_reproduces_the_network_in_the_solve_and_in_both_gradients(gpu, ar
     shapes, Ts = ((56, 40), (70, 57)), (-5.0, -11.0)
     b, om, th, fields, ph = _batch(gpu, arch, shapes, Ts)
     ts = [2010.0 + j / 24.0 for j in range(4)]
+    b.set_schedule(law_table=0)
     b.solve(ts, reltol=1e-8)
     Hn = [b.snapshot(g, 3) for g in range(2)]
     for g in range(2):
@@ -44,7 +51,7 @@ def test_table_reproduces_the_network_in_the_solve_and_in_both_gradients(gpu, ar
     Ln, gn = b.loss_grad(ts, theta=th, reltol=1e-8)
     Lc, gc = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
     assert not b.law_table()["usable"]
-    b.set_schedule(law_table=1)
+    b.set_schedule()  # automatic: the table
     info = b.law_table()
     assert info["usable"] and info["max_rel_dev"] < 1e-12 and (info["hmax"] >= 200.0).all(), info
     st = b.solve(ts, reltol=1e-8)
@@ -57,14 +64,15 @@ def test_table_reproduces_the_network_in_the_solve_and_in_both_gradients(gpu, ar
     # the table follows theta (rebuilt by the gradient call) ...
     th2 = th * 1.03
     Lt2, gt2 = b.loss_grad(ts, theta=th2, reltol=1e-8)
-    b.set_schedule()
+    b.set_schedule(law_table=0)
     Ln2, gn2 = b.loss_grad(ts, theta=th2, reltol=1e-8)
     assert Ln2 != Ln and abs(Lt2 - Ln2) <= 1e-10 * abs(Ln2) and rel_l2(gt2, gn2) < 1e-8
     # ... and the seams never use it (arbitrary fields from the caller): bit-identical with the schedule on or off
     lam = np.random.default_rng(5).standard_normal(shapes[0])
-    v0 = b.vjp_H(0, lam, fields[0][0])
-    b.set_schedule(law_table=1)
-    assert np.array_equal(b.vjp_H(0, lam, fields[0][0]), v0) and np.array_equal(b.dhdt(0, fields[0][0]), b.dhdt(0, fields[0][0]))
+    v0, d0 = b.vjp_H(0, lam, fields[0][0]), b.dhdt(0, fields[0][0])
+    b.set_schedule()
+    assert b.law_table()["usable"]
+    assert np.array_equal(b.vjp_H(0, lam, fields[0][0]), v0) and np.array_equal(b.dhdt(0, fields[0][0]), d0)
     b.close()
 
 
@@ -77,7 +85,7 @@ def test_table_path_against_the_oracle(gpu):
     law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=-5.0)
     cfg = O.SimConfig(tstops=ts, reltol=1e-8)
     ref, _, _ = O.forward(gl, law, cfg)
-    b.set_schedule(law_table=1)
+    assert b.law_table()["usable"]
     b.solve(ts, reltol=1e-8)
     assert rel_l2(b.snapshot(0, 3), ref[3]) < 1e-6
     ref = [r * (1.0 + 0.02 * j) for j, r in enumerate(ref)]
@@ -100,11 +108,12 @@ def test_a_solve_that_leaves_the_table_is_repeated_with_a_wider_one(gpu, monkeyp
     monkeypatch.setenv("ODINN_LAW_TABLE_HMAX", "40")  # the ice is up to 150 m thick: two widenings (40 -> 80 -> 160)
     b, om, th, fields, ph = _batch(gpu, "default")
     ts = [2010.0 + j / 24.0 for j in range(3)]
+    b.set_schedule(law_table=0)
     b.solve(ts, reltol=1e-8)
     Hn = b.snapshot(0, 2)
     b.set_reference(0, ts, [fields[0][0]] * 3, 3)
     Ln, gn = b.loss_grad(ts, theta=th, reltol=1e-8)
-    b.set_schedule(law_table=1)
+    b.set_schedule()
     assert b.law_table()["hmax"][0] == 40.0
     b.solve(ts, reltol=1e-8)
     assert b.law_table()["hmax"][0] == 160.0 and b.law_table()["usable"]
@@ -126,13 +135,12 @@ def test_a_table_that_misses_the_tolerance_is_not_used(gpu):
     th2 = th.copy()  # 2 -> 3 -> 1: every hidden unit softplus(4000 (Hbar_norm + 0.3)), a kink at Hbar = 100 m one interval wide
     th2[0:3], th2[3:6], th2[6:9] = 0.0, 4000.0, 1200.0
     b.set_theta(th2)
-    b.set_schedule(law_table=1)
     info = b.law_table()
     assert not info["usable"] and info["max_rel_dev"] > 1e-12, info
     ts = [2010.0, 2010.02]
     b.solve(ts, reltol=1e-8)
     H1 = b.snapshot(0, 1)
-    b.set_schedule()
+    b.set_schedule(law_table=0)
     b.solve(ts, reltol=1e-8)
     assert np.array_equal(b.snapshot(0, 1), H1)
     b.close()
@@ -151,7 +159,7 @@ def test_overlapped_interpolation_is_bit_identical(gpu, table):
     assert b.get_schedule()["interp_async"] != 0
     res = {}
     for mode in (-1, 0, -1):
-        b.set_schedule(law_table=table, interp_async=mode)
+        b.set_schedule(law_table=table - 1 if table else 0, interp_async=mode)  # (table: automatic)
         res.setdefault(mode, []).append(b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=24))
     (La, ga), (La2, ga2) = res[-1]
     Ls, gs = res[0][0]

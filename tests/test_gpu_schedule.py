@@ -57,7 +57,8 @@ GENERIC = [dict(step_sc=0), dict(step_sc=1), dict(fused_tiles=1), dict(fused_til
 @pytest.mark.parametrize("sched", GENERIC, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
 def test_every_schedule_field_selects_an_equivalent_kernel_form(gpu, monkeypatch, sched):
     for k in ("ODINN_STEP_SC", "ODINN_FUSED_TILES", "ODINN_DHDT_STRIP", "ODINN_VJPH_STRIP", "ODINN_VJPTH_STRIP", "ODINN_SNAP_ON_LOAD",
-              "ODINN_ADJ_FUSED", "ODINN_ADJ_SKIP", "ODINN_ADJ_SEGS", "ODINN_ADJ_ROWS", "ODINN_ADJ_THETA_FUSED", "ODINN_SCHEME"):
+              "ODINN_ADJ_FUSED", "ODINN_ADJ_SKIP", "ODINN_ADJ_SEGS", "ODINN_ADJ_ROWS", "ODINN_ADJ_THETA_FUSED", "ODINN_SCHEME",
+              "ODINN_LAW_TABLE", "ODINN_INTERP_ASYNC"):
         monkeypatch.delenv(k, raising=False)
     b, ts = _case(gpu)
     assert all(v == -1 for v in b.get_schedule().values())
