@@ -547,6 +547,34 @@ def main():
             aux["nn_inlined_2x16_ms_per_step"] = ms_nn
             aux["nn_inlined_2x16_cellsteps_per_s"] = 5.0 * cells / (ms_nn * 1e-3)
             aux["nn_inlined_2x16_note"] = "LawY: Y = NN_theta(T, Hbar) evaluated per dual node inside the stencil (Laws.jl:258-265)"
+            # the same law through its per-glacier table Y(Hbar) (odinn_schedule.law_table, the library's default inside solves and
+            # gradients; the TIMED_* kernels above always evaluate the network): whole forward solves through the public API
+            try:
+                tsy = [2010.0, 2010.0 + 1.0 / 24.0]
+                ytab = {}
+                for nm_, tab_ in (("network", 0), ("table", -1)):
+                    b.set_schedule(law_table=tab_)
+                    b.solve(tsy, reltol=1e-8)
+                    b.sync()
+                    tq0 = time.perf_counter()
+                    st_ = b.solve(tsy, reltol=1e-8)
+                    b.sync()
+                    n_att = max(1, max(s_.naccept + s_.nreject for s_ in st_))
+                    ytab[nm_ + "_ms_per_step"] = (time.perf_counter() - tq0) * 1e3 / n_att
+                    ytab[nm_ + "_steps"] = n_att
+                info_ = b.law_table()
+                ytab["cellsteps_per_s_table"] = 5.0 * cells / (ytab["table_ms_per_step"] * 1e-3)
+                ytab["cellsteps_per_s_network"] = 5.0 * cells / (ytab["network_ms_per_step"] * 1e-3)
+                ytab["table_usable"] = info_["usable"]
+                ytab["table_max_rel_dev_from_network"] = info_["max_rel_dev"]
+                ytab["note"] = ("LawY's inputs are (T_glacier, Hbar): per glacier and theta a function of Hbar alone; the stencil kernels read it from "
+                                "1024 quintics per glacier built from the network (used only while the measured deviation is < 1e-12); wall-clock "
+                                "per attempted step of a solve over 1/24 yr incl. the initial-step heuristic and the host loop")
+                aux["y_law_table_2x16"] = ytab
+                b.set_schedule()
+            except Exception as e:
+                aux["y_law_table_2x16"] = {"error": str(e)[:200]}
+                b.set_schedule()
             # its own roofline: fp64 vector pipe, flops per cell-stage from the committed PMC pass of the per-stage kernel with this
             # network (profiles/r04/pmc_roofline.json: 64 x (ADD + MUL + 2 FMA + TRANS)_F64 per launch / cells)
             pm_nn, pm_nn_src = {}, "n/a"
