@@ -173,8 +173,10 @@ typedef struct odinn_schedule {
                               quintics (1024 intervals; rebuilt from the network whenever theta changes, used only while its
                               measured deviation from the network is < 1e-12 relative -- else the network; a solve that leaves the
                               table's range is repeated with a wider one).  The seam calls always evaluate the network           */
-  int32_t interp_async;    /* ODINN_INTERP_ASYNC: 0 = the Y law's `:Linear` contraction of a quadrature node on the batch's own stream
-                              instead of overlapped with the following reverse steps on a second stream (continuous adjoint)       */
+  int32_t interp_async;    /* ODINN_INTERP_ASYNC: 0 = the Y law's `:Linear` contraction of a stop (sort, knots, interval sums, knot
+                              backprop) on the batch's own stream; n = 1 ... 4: overlapped with the following reverse steps of both
+                              adjoints on n lane streams (default: 3 in the DiscreteAdjoint, 1 in the ContinuousAdjoint; results
+                              bit-identical: every contribution has its own slot, the slots are added in the order of the stops)  */
   int32_t reserved[3];     /* zero                                                                                                 */
 } odinn_schedule;
 

@@ -73,6 +73,9 @@ void launch_law_field_grad_scratch(int nblk, hipStream_t st, LawDev L, const dou
 void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, double* out) {
   hipLaunchKernelGGL(k_sum_rows, dim3(Pn), dim3(64), 0, st, part, nrows, Pn, out);
 }
+void launch_sum_slots(hipStream_t st, long long n, int nslots, const double* slots, double* out) {
+  hipLaunchKernelGGL(k_sum_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, nslots, slots, out);
+}
 // table of the Y law for G glaciers x ni intervals (k_ytab_build); stat: 3 zeroed 64-bit words
 void launch_ytab_build(hipStream_t st, Pools P, LawDev L, int G, double* tab, int ni, double floor_abs, unsigned long long* stat) {
   static const YtabVinv V = [] {

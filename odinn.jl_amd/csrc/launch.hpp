@@ -93,6 +93,7 @@ int launch_law_field_grad(hipStream_t st, LawDev L, const double* T, const doubl
 void launch_law_field_grad_scratch(int nblk, hipStream_t st, LawDev L, const double* T, const double* G, long long n,
                                    double* gscratch, double* part_theta);
 void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, double* out);
+void launch_sum_slots(hipStream_t st, long long n, int nslots, const double* slots, double* out);
 void launch_ytab_build(hipStream_t st, Pools P, LawDev L, int G, double* tab, int ni, double floor_abs, unsigned long long* stat);
 void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd);
 void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const double* y, double* z);

@@ -340,15 +340,31 @@ struct odinn_batch {
   long long interp_ndmax = 0;
   hipStream_t side[INTERP_LANES_MAX] = {};
   hipEvent_t ev_fork = nullptr, ev_join[INTERP_LANES_MAX] = {};
-  // continuous adjoint with the Y law's `:Linear` gradient interpolation: the sort / knots / interval sums / knot backprop of a
-  // quadrature node run on a stream of their own while the batch's stream goes on with the reverse steps (interp_async_*):
-  // two sets of emitted node arrays, ev_emit[s] = "set s is written", ev_done[s] = "set s has been contracted into d_dth"
+  // Y law's `:Linear` gradient interpolation inside the adjoints: the sort / knots / interval sums / knot backprop of a stop run on
+  // lane streams of their own while the batch's stream goes on with the reverse steps (interp_async_*): per lane a set of emitted
+  // node arrays and sort scratch (lane 0: the batch's own), ev_emit[l] = "lane l's node arrays are written", ev_done[l] = "... have
+  // been contracted"; contribution q lands in its own slot of d_dthq and the slots are added onto d_dth in order at the join
+  static constexpr int IA_LANES_MAX = 4, IA_SLOTS = 256;
+  struct IaLane {
+    double *sH = nullptr, *sV = nullptr, *knots = nullptr, *ab = nullptr;
+    unsigned *iA = nullptr, *iB = nullptr, *kA = nullptr, *kB = nullptr;
+    void* tmp = nullptr;
+    int* M = nullptr;
+  } ia_lane[IA_LANES_MAX];
+  // node arrays: one SET more than lanes (set q % ia_sets, lane q % ia_lanes), so that the emitting kernel does not wait for the
+  // contraction that is still running on the lane it will use
+  static constexpr int IA_SETS_MAX = IA_LANES_MAX + 1;
+  double *ia_nodeH[IA_SETS_MAX] = {}, *ia_nodeV[IA_SETS_MAX] = {};
+  hipEvent_t ev_set_done[IA_SETS_MAX] = {};
+  bool ia_set_pending[IA_SETS_MAX] = {};
+  int ia_sets = 0;
   bool interp_async = false;
-  int ia_slot = 0;
-  bool ia_pending[2] = {false, false};
-  double *d_nodeH2 = nullptr, *d_nodeV2 = nullptr;
-  hipStream_t ia_stream = nullptr;
-  hipEvent_t ev_emit[2] = {}, ev_done[2] = {};
+  int ia_lanes = 0, ia_q = 0, ia_alloc = 0;
+  bool ia_pending[IA_LANES_MAX] = {};
+  double* d_dthq = nullptr;
+  size_t dthq_cap = 0;
+  hipStream_t ia_stream[IA_LANES_MAX] = {};
+  hipEvent_t ev_emit[IA_LANES_MAX] = {}, ev_done[IA_LANES_MAX] = {};
   size_t sorttmp_bytes = 0, knotG_cap = 0;
   double *d_part_theta = nullptr, *d_gscratch = nullptr, *d_dth = nullptr;
   size_t part_theta_cap = 0, gscratch_cap = 0, dth_cap = 0;
@@ -1730,12 +1746,22 @@ int odinn_batch_destroy(odinn_batch* b) {
     if (b->ev_join[l]) (void)hipEventDestroy(b->ev_join[l]);
   }
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-  if (b->ia_stream) { (void)hipStreamSynchronize(b->ia_stream); (void)hipStreamDestroy(b->ia_stream); }
-  for (int s_ = 0; s_ < 2; ++s_) {
-    if (b->ev_emit[s_]) (void)hipEventDestroy(b->ev_emit[s_]);
-    if (b->ev_done[s_]) (void)hipEventDestroy(b->ev_done[s_]);
+  for (int l = 0; l < odinn_batch::IA_LANES_MAX; ++l) {
+    if (b->ia_stream[l]) { (void)hipStreamSynchronize(b->ia_stream[l]); (void)hipStreamDestroy(b->ia_stream[l]); }
+    if (b->ev_emit[l]) (void)hipEventDestroy(b->ev_emit[l]);
+    if (b->ev_done[l]) (void)hipEventDestroy(b->ev_done[l]);
+    if (l > 0) {  // (lane 0 aliases the batch's own arrays)
+      odinn_batch::IaLane& a = b->ia_lane[l];
+      dfree(a.sH); dfree(a.sV); dfree(a.knots); dfree(a.ab); dfree(a.iA); dfree(a.iB); dfree(a.kA); dfree(a.kB);
+      dfree(a.M);
+      if (a.tmp) (void)hipFree(a.tmp);
+    }
   }
-  dfree(b->d_nodeH2); dfree(b->d_nodeV2);
+  for (int q_ = 0; q_ < odinn_batch::IA_SETS_MAX; ++q_) {
+    if (q_ > 0) { dfree(b->ia_nodeH[q_]); dfree(b->ia_nodeV[q_]); }  // (set 0 aliases d_nodeH / d_nodeV)
+    if (b->ev_set_done[q_]) (void)hipEventDestroy(b->ev_set_done[q_]);
+  }
+  dfree(b->d_dthq);
   dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
   dfree(b->d_Vabs); dfree(b->d_Vxr); dfree(b->d_Vyr); dfree(b->d_wv); dfree(b->d_vsc); dfree(b->d_vslot);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -2071,73 +2097,137 @@ static int vel_theta_finish(odinn_batch* b, int g, bool accumulate, const Pools&
   return ODINN_OK;
 }
 
-// ---- the Y law's `:Linear` contraction off the critical path of the reverse solve --------------------------------------------
-// The theta-integrand of a quadrature node does not feed back into the reverse ODE, so its contraction (a radix sort of all
-// dual nodes, the knots, the interval sums, the backprop at the knots: ~15 dependent launches that leave most of the GPU idle)
-// runs on ia_stream while the batch's stream takes the next reverse steps.  The emitting kernel alternates between two sets
-// of node arrays; contractions are issued in the order of the nodes on ONE stream, so d_dth sees the same additions in the same
-// order as without the overlap (bit-identical gradients).  ODINN_INTERP_ASYNC=0 / odinn_schedule.interp_async = 0 turns it off.
-static bool interp_async_possible(odinn_batch* b, bool useV) {
-  if (useV || b->law_kind != ODINN_LAW_NN_Y || b->grad_interp != ODINN_GRAD_INTERP_LINEAR) return false;
-  if (sched_val(b->sched.interp_async, "ODINN_INTERP_ASYNC") == 0) return false;
-  if (sched_val(b->sched.interp_batch, "ODINN_INTERP_BATCH") == 0) return false;
-  return b->d_ib_gid && interp_batch_lds_bytes(b->P) <= 30 * 1024;
+// ---- the Y law's `:Linear` contraction off the critical path of the adjoints --------------------------------------------------
+// The theta-integrand of a stop does not feed back into the reverse solve, so its contraction (a radix sort of all dual nodes,
+// the knots, the interval sums, the backprop at the knots: ~35 dependent launches that leave most of the GPU idle) runs on a
+// lane stream while the batch's stream takes the next reverse steps, and the contractions of consecutive stops run side by
+// side on up to IA_LANES_MAX lanes (own node arrays and sort scratch each).  Contribution q is WRITTEN to slot q of d_dthq and
+// the slots are added onto d_dth in the order of the stops when the lanes are joined -- the additions, and their order, of the
+// sequence on one stream: bit-identical gradients.  odinn_schedule.interp_async / ODINN_INTERP_ASYNC: 0 = off, n = n lanes.
+static int interp_async_lanes(odinn_batch* b, bool useV, int lanes_default) {
+  if (useV || b->law_kind != ODINN_LAW_NN_Y || b->grad_interp != ODINN_GRAD_INTERP_LINEAR) return 0;
+  const int e = sched_val(b->sched.interp_async, "ODINN_INTERP_ASYNC");
+  if (e == 0) return 0;
+  if (sched_val(b->sched.interp_batch, "ODINN_INTERP_BATCH") == 0) return 0;
+  if (!b->d_ib_gid || interp_batch_lds_bytes(b->P) > 30 * 1024) return 0;
+  int lanes = e < 0 ? lanes_default : std::min(e, (int)odinn_batch::IA_LANES_MAX);
+  // a lane's arrays: ~72 B per dual node + the sort's scratch; keep the extra lanes below 8 GB
+  const double per_lane = 72.0 * (double)b->ntotd + (double)b->ib_tmp_bytes;
+  while (lanes > 1 && per_lane * (lanes - 1) > 8e9) --lanes;
+  return lanes;
 }
-static int interp_async_setup(odinn_batch* b) {
-  if (!b->ia_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&b->ia_stream, hipStreamNonBlocking));
-    for (int s = 0; s < 2; ++s) {
-      HIPCHK(hipEventCreateWithFlags(&b->ev_emit[s], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&b->ev_done[s], hipEventDisableTiming));
+static int interp_async_setup(odinn_batch* b, int lanes) {
+  const size_t N = (size_t)b->ntotd;
+  for (int l = 0; l < lanes; ++l) {
+    if (!b->ia_stream[l]) {
+      // (measured: low-priority lane streams starve -- 8 x 512^2 continuous gradient 150 -> 470 ms, the batch's stream ends up
+      //  waiting for their node arrays)
+      HIPCHK(hipStreamCreateWithFlags(&b->ia_stream[l], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&b->ev_emit[l], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&b->ev_done[l], hipEventDisableTiming));
     }
+    odinn_batch::IaLane& a = b->ia_lane[l];
+    if (l == 0) {
+      a.sH = b->d_ib_sH; a.sV = b->d_ib_sV; a.knots = b->d_ib_knots; a.ab = b->d_ib_ab;
+      a.iA = b->d_ib_iA; a.iB = b->d_ib_iB; a.kA = b->d_ib_kA; a.kB = b->d_ib_kB; a.tmp = b->d_ib_tmp; a.M = b->d_ib_M;
+    } else if (!a.sH) {
+      CHK(dalloc(&a.sH, N)); CHK(dalloc(&a.sV, N));
+      CHK(dalloc(&a.iA, N)); CHK(dalloc(&a.iB, N)); CHK(dalloc(&a.kA, N)); CHK(dalloc(&a.kB, N));
+      CHK(dalloc(&a.knots, (size_t)b->G * INTERP_KMAX)); CHK(dalloc(&a.ab, (size_t)b->G * 2 * INTERP_KMAX)); CHK(dalloc(&a.M, (size_t)b->G));
+      HIPCHK(hipMalloc(&a.tmp, std::max<size_t>(b->ib_tmp_bytes, 256)));
+    }
+    b->ia_pending[l] = false;
   }
-  if (!b->d_nodeH2) { CHK(dalloc(&b->d_nodeH2, (size_t)b->ntotd)); CHK(dalloc(&b->d_nodeV2, (size_t)b->ntotd)); }
-  b->ia_slot = 0;
-  b->ia_pending[0] = b->ia_pending[1] = false;
+  int sets = lanes + 1;
+  if (const char* e = std::getenv("ODINN_INTERP_SETS")) sets = std::max(lanes, std::min(std::atoi(e), (int)odinn_batch::IA_SETS_MAX));  // (A/B aid)
+  for (int q = 0; q < sets; ++q) {
+    if (q == 0) { b->ia_nodeH[0] = b->d_nodeH; b->ia_nodeV[0] = b->d_nodeV; }
+    else if (!b->ia_nodeH[q]) { CHK(dalloc(&b->ia_nodeH[q], N)); CHK(dalloc(&b->ia_nodeV[q], N)); }
+    if (!b->ev_set_done[q]) HIPCHK(hipEventCreateWithFlags(&b->ev_set_done[q], hipEventDisableTiming));
+    b->ia_set_pending[q] = false;
+  }
+  b->ia_sets = sets;
+  const size_t need = (size_t)odinn_batch::IA_SLOTS * b->G * b->P;
+  if (need > b->dthq_cap) {
+    dfree(b->d_dthq);
+    CHK(dalloc(&b->d_dthq, need));
+    b->dthq_cap = need;
+  }
+  b->ia_lanes = lanes;
+  b->ia_q = 0;
+  return ODINN_OK;
+}
+// the batch's stream waits for every contraction issued so far and adds their slots onto d_dth, in order
+static int interp_async_join(odinn_batch* b) {
+  for (int l = 0; l < b->ia_lanes; ++l)
+    if (b->ia_pending[l]) {
+      HIPCHK(hipStreamWaitEvent(b->stream, b->ev_done[l], 0));
+      b->ia_pending[l] = false;
+    }
+  for (int q = 0; q < b->ia_sets; ++q) b->ia_set_pending[q] = false;  // (covered by the lanes' last events)
+  if (b->ia_q > 0) {
+    launch_sum_slots(b->stream, (long long)b->G * b->P, b->ia_q, b->d_dthq, b->d_dth);
+    HIPCHK(hipGetLastError());
+    b->ia_q = 0;
+  }
   return ODINN_OK;
 }
 // node arrays the next emitting launch may write (zeroed, on the batch's stream, once their previous contraction is through)
 static int interp_async_begin(odinn_batch* b, double** nH, double** nV) {
-  const int s = b->ia_slot;
-  *nH = s ? b->d_nodeH2 : b->d_nodeH;
-  *nV = s ? b->d_nodeV2 : b->d_nodeV;
-  if (b->ia_pending[s]) HIPCHK(hipStreamWaitEvent(b->stream, b->ev_done[s], 0));
+  if (b->ia_q >= odinn_batch::IA_SLOTS) CHK(interp_async_join(b));
+  const int q = b->ia_q % b->ia_sets;
+  *nH = b->ia_nodeH[q];
+  *nV = b->ia_nodeV[q];
+  if (b->ia_set_pending[q]) HIPCHK(hipStreamWaitEvent(b->stream, b->ev_set_done[q], 0));
   HIPCHK(hipMemsetAsync(*nH, 0, (size_t)b->ntotd * sizeof(double), b->stream));
   HIPCHK(hipMemsetAsync(*nV, 0, (size_t)b->ntotd * sizeof(double), b->stream));
   return ODINN_OK;
 }
-static int interp_async_contract(odinn_batch* b, const double* nH, const double* nV, const Pools& P) {
-  const int s = b->ia_slot;
-  HIPCHK(hipEventRecord(b->ev_emit[s], b->stream));
-  HIPCHK(hipStreamWaitEvent(b->ia_stream, b->ev_emit[s], 0));
-  const int rc = launch_interp_theta_batch(b->ia_stream, P, b->lawdev(), b->n_interp_half, 0, b->G, 0, b->ntotd, nH, nV, b->d_ib_gid,
-                                           b->d_ib_iota, b->d_ib_sH, b->d_ib_sV, b->d_ib_iA, b->d_ib_iB, b->d_ib_kA, b->d_ib_kB,
-                                           b->d_ib_tmp, b->ib_tmp_bytes, b->d_ib_knots, b->d_ib_M, b->d_ib_ab, b->d_dth, 1);
+static int interp_async_contract(odinn_batch* b, const Pools& P) {
+  const int l = b->ia_q % b->ia_lanes, qs = b->ia_q % b->ia_sets;
+  const odinn_batch::IaLane& a = b->ia_lane[l];
+  HIPCHK(hipEventRecord(b->ev_emit[l], b->stream));
+  HIPCHK(hipStreamWaitEvent(b->ia_stream[l], b->ev_emit[l], 0));
+  const int rc = launch_interp_theta_batch(b->ia_stream[l], P, b->lawdev(), b->n_interp_half, 0, b->G, 0, b->ntotd, b->ia_nodeH[qs],
+                                           b->ia_nodeV[qs],
+                                           b->d_ib_gid, b->d_ib_iota, a.sH, a.sV, a.iA, a.iB, a.kA, a.kB, a.tmp, b->ib_tmp_bytes, a.knots,
+                                           a.M, a.ab, b->d_dthq + (size_t)b->ia_q * b->G * b->P, 0);
   if (rc) return fail(ODINN_ERR_HIP, "gradient interpolation failed (code %d)", rc);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(b->ev_done[s], b->ia_stream));
-  b->ia_pending[s] = true;
-  b->ia_slot = 1 - s;
+  HIPCHK(hipEventRecord(b->ev_done[l], b->ia_stream[l]));
+  HIPCHK(hipEventRecord(b->ev_set_done[qs], b->ia_stream[l]));
+  b->ia_pending[l] = true;
+  b->ia_set_pending[qs] = true;
+  ++b->ia_q;
   return ODINN_OK;
 }
-// the batch's stream waits for every contraction issued so far
-static int interp_async_join(odinn_batch* b) {
-  for (int s = 0; s < 2; ++s)
-    if (b->ia_pending[s]) {
-      HIPCHK(hipStreamWaitEvent(b->stream, b->ev_done[s], 0));
-      b->ia_pending[s] = false;
-    }
-  return ODINN_OK;
-}
-struct InterpAsyncScope {  // leaves no work behind on ia_stream, whichever way the driver returns
+struct InterpAsyncScope {  // leaves no work behind on the lane streams, whichever way the driver returns
   odinn_batch* b;
   ~InterpAsyncScope() {
     if (!b->interp_async) return;
     b->interp_async = false;
-    if (b->ia_stream) (void)hipStreamSynchronize(b->ia_stream);
-    b->ia_pending[0] = b->ia_pending[1] = false;
+    for (int l = 0; l < b->ia_lanes; ++l) {
+      if (b->ia_stream[l]) (void)hipStreamSynchronize(b->ia_stream[l]);
+      b->ia_pending[l] = false;
+    }
+    for (int q = 0; q < b->ia_sets; ++q) b->ia_set_pending[q] = false;
+    b->ia_q = 0;
   }
 };
+// the adjoint drivers switch the overlap on for their reverse loop ...
+// Lanes by default (8 x 512^2, table path, ms per gradient; profiles/r04/ytab_lanes.txt): the reverse-Euler loop of the
+// DiscreteAdjoint is short and its contractions are the longer chain -- 0 / 1 / 2 / 3 lanes: 9.7 / 9.3 / 8.4 / 8.4; the reverse
+// ODE of the ContinuousAdjoint keeps the GPU busy itself and more than one lane only takes bandwidth from it: 212 / 151 / 190 / 179
+// (low-priority lanes: 470; a high-priority batch stream brings 2 - 3 lanes back to 152, no better than one lane).
+static int interp_async_enable(odinn_batch* b, bool useV, int lanes_default) {
+  if (b->law_kind != ODINN_LAW_NN_Y) return ODINN_OK;
+  CHK(ensure_interp_scratch(b));
+  const int lanes = interp_async_lanes(b, useV, lanes_default);
+  if (lanes < 1) return ODINN_OK;
+  CHK(interp_async_setup(b, lanes));
+  b->interp_async = true;
+  return ODINN_OK;
+}
 
 static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, const double* scales, int g,
                             bool accumulate, double* part_deferred = nullptr, bool inplace = false,
@@ -2173,7 +2263,7 @@ static int theta_vjp_launch(odinn_batch* b, const double* H, const double* lam, 
   if (part_deferred) P.part = part_deferred;
   launch_vjp_theta(b, nblk, P, b->lawdev(), A, base);
   if (async) {
-    CHK(interp_async_contract(b, nH, nV, P));
+    CHK(interp_async_contract(b, P));
   } else if (linear) {
     CHK(interp_contract(b, g, isU, accumulate, P));
   } else if (emit_rt) {
@@ -2710,6 +2800,8 @@ static int loss_grad_impl(odinn_batch* b, const double* theta, int P, int n_stop
     CHK(dalloc(&b->d_partsteps, (size_t)k * pstride));
     b->partsteps_cap = (size_t)k * pstride;
   }
+  InterpAsyncScope ia_scope{b};
+  CHK(interp_async_enable(b, b->loss_kind != ODINN_LOSS_H, 3));
   for (int j = k - 1; j >= 1; --j) {
     double* lam = b->d_lam[cur];
     double* lam_new = b->d_lam[1 - cur];
@@ -2744,6 +2836,7 @@ static int loss_grad_impl(odinn_batch* b, const double* theta, int P, int n_stop
     CHK(theta_vjp_launch(b, Hj, lam_new, b->d_dts + (size_t)j * b->G, -1, true, defer ? Pj.part : nullptr));  // :245-249
     cur = 1 - cur;
   }
+  if (b->interp_async) CHK(interp_async_join(b));
   if (defer && k > 1) {
     launch_sum_part_steps(b->G, b->stream, Psw, b->d_partsteps, pstride, k - 1, 1, 1, b->d_lossacc);
     launch_sum_part_steps(b->G, b->stream, Psw, b->d_partsteps, pstride, k - 1, 1, 2, b->d_Gsum);
@@ -3136,13 +3229,7 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
   long long steps = 0;
   int p = 0;
   InterpAsyncScope ia_scope{b};
-  if (b->law_kind == ODINN_LAW_NN_Y) {
-    CHK(ensure_interp_scratch(b));
-    if (interp_async_possible(b, useV)) {
-      CHK(interp_async_setup(b));
-      b->interp_async = true;
-    }
-  }
+  CHK(interp_async_enable(b, useV, 1));
   while (nact > 0) {
     for (int s_ = 0; s_ < chunk; ++s_) {
       double* a0 = b->d_lam[p];

@@ -2828,6 +2828,15 @@ __global__ __launch_bounds__(256) void k_ytab_build(Pools P, LawDev L, YtabVinv 
   atomicMax(&stat[2], (unsigned long long)__double_as_longlong(ymax));
 }
 
+// out[i] = ((out[i] + slot_0[i]) + slot_1[i]) + ... : the slots of the overlapped `:Linear` contractions added in the order of the stops
+__global__ void k_sum_slots(long long n, int nslots, const double* __restrict__ slots, double* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = out[i];
+  for (int q = 0; q < nslots; ++q) s += slots[(long long)q * n + i];
+  out[i] = s;
+}
+
 // ---- misc elementwise over pooled arrays ---------------------------------------------
 __global__ void k_axpy(long long n, double a, const double* __restrict__ x, const double* __restrict__ y,
                        double* __restrict__ z) {  // z = y + a*x

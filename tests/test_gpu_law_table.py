@@ -148,9 +148,9 @@ def test_a_table_that_misses_the_tolerance_is_not_used(gpu):
 
 @pytest.mark.parametrize("table", [0, 1])
 def test_overlapped_interpolation_is_bit_identical(gpu, table):
-    """Continuous adjoint of the Y law: the `:Linear` contraction of a quadrature node on a second stream, overlapped with the
-    following reverse steps (odinn_schedule.interp_async, the default), adds the same numbers in the same order as the
-    sequence on the batch's own stream."""
+    """Both adjoints of the Y law: the `:Linear` contraction of a stop on lane streams, overlapped with the following reverse
+    steps (odinn_schedule.interp_async: the default 3 lanes, 1, 4), adds the same numbers in the same order as the sequence on
+    the batch's own stream (0) -- every contribution has its own slot, the slots are added in the order of the stops."""
     shapes, Ts = ((56, 40), (70, 57), (131, 64)), (-5.0, -11.0, -2.0)
     b, om, th, fields, ph = _batch(gpu, "default", shapes, Ts)
     ts = [2010.0 + j / 24.0 for j in range(4)]
@@ -158,11 +158,14 @@ def test_overlapped_interpolation_is_bit_identical(gpu, table):
         b.set_reference(g, ts, [fields[g][0] * (1.0 - 0.01 * j) for j in range(4)], 3)
     assert b.get_schedule()["interp_async"] != 0
     res = {}
-    for mode in (-1, 0, -1):
-        b.set_schedule(law_table=table - 1 if table else 0, interp_async=mode)  # (table: automatic)
-        res.setdefault(mode, []).append(b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=24))
-    (La, ga), (La2, ga2) = res[-1]
-    Ls, gs = res[0][0]
-    assert La == Ls and np.array_equal(ga, gs) and La2 == La and np.array_equal(ga2, ga)
-    assert np.isfinite(ga).all() and np.linalg.norm(ga) > 0
+    for mode in (-1, 0, 1, 4, -1):
+        b.set_schedule(law_table=-1 if table else 0, interp_async=mode)
+        res.setdefault(mode, []).append((b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=24),
+                                         b.loss_grad(ts, theta=th, reltol=1e-8)))
+    (Lc, gc), (Ld, gd) = res[0][0]
+    assert np.isfinite(gc).all() and np.linalg.norm(gc) > 0 and np.isfinite(gd).all() and np.linalg.norm(gd) > 0
+    for mode, runs in res.items():
+        for (Lc2, gc2), (Ld2, gd2) in runs:
+            assert Lc2 == Lc and np.array_equal(gc2, gc), mode
+            assert Ld2 == Ld and np.array_equal(gd2, gd), mode
     b.close()

@@ -14,10 +14,11 @@ head -8 $O/bench_kernel_stats.csv
 rm -rf $O/profg; rocprofv3 --kernel-trace --stats --output-format csv -d $O/profg -- python $R/bench.py --steps 40 --no-cpu-baseline --no-hbm-sweep --no-weak > $O/grad_under_rocprof.json 2> $O/profg.err
 find $O/profg -name "*kernel_stats.csv" -exec cp {} $O/grad_kernel_stats.csv \;
 rm -rf $O/profg
-( for w in "Y 512 8" "U 512 8"; do
+( for w in "Y 512 8" "NET Y 512 8" "U 512 8"; do
     rm -rf $O/profw
-    rocprofv3 --kernel-trace --stats --output-format csv -d $O/profw -- python $R/tools/workflow_probe.py $w > $O/probe.txt 2>&1
-    echo "=== python tools/workflow_probe.py $w"; grep -E "solve ms|LossH" $O/probe.txt
+    e=""; if [ "${w%% *}" = NET ]; then e="ODINN_LAW_TABLE=0 ODINN_INTERP_ASYNC=0"; w=${w#NET }; fi  # (the Y law without its table and without the overlap)
+    env $e rocprofv3 --kernel-trace --stats --output-format csv -d $O/profw -- python $R/tools/workflow_probe.py $w > $O/probe.txt 2>&1
+    echo "=== $e python tools/workflow_probe.py $w"; grep -E "solve ms|LossH" $O/probe.txt
     python $R/tools/kstats.py $O/profw 14
     rm -rf $O/profw
   done ) > $O/workflows_kernel_stats.txt 2>&1
