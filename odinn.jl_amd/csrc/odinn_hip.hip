@@ -621,6 +621,7 @@ int refresh_gd(odinn_batch* b) {
       }
       b->gd[g].yt_inv_h = (double)b->ytab_ni / b->ytab_hmax[g];
       b->gd[g].yt_off = (long long)g * 6 * b->ytab_ni;
+      b->gd[g].yt_fast = (b->gd[g].fast && b->gd[g].nH == 3.0 && b->gd[g].nS == 3.0 && !std::getenv("ODINN_LAW_TABLE_NOFAST")) ? 1 : 0;
     }
   }
   HIPCHK(hipMemcpyAsync(b->d_gd, b->gd.data(), sizeof(GDev) * b->G, hipMemcpyHostToDevice, b->stream));

@@ -129,6 +129,8 @@ struct GDev {  // per-glacier constants
   // [i, i + 1) / yt_inv_h metres of Hbar
   double yt_inv_h;
   long long yt_off;
+  int yt_fast;  // n_H = n_gradS = 3, no sliding: the integer-power form of the Y law's geometry factor (no upow / spow)
+  int yt_pad;
 };
 
 struct GState {  // per-glacier integrator state (written by the controller kernel)
@@ -1014,6 +1016,16 @@ __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double 
   if constexpr (LM == LM_YTAB) {  // the Y law's closed form below with Y (and Y at Hbar + 1e-4) from the table
     double Yp = 0.0;
     const double Y = ytab_eval<ADJ>(g, L, Hb, Yp);
+    if (g.yt_fast) {  // (wave-uniform) the products of node_D<LM_FAST> with Y in A's place; the same expressions as the general form
+      const double H2 = Hb * Hb, H4 = H2 * H2, H5 = H4 * Hb;
+      const double geo = g.Gam * H5 * gS2;
+      if (ADJ) {
+        alpha = 5.0 * Y * g.Gam * H4 * gS2 + (Yp * geo - Y * geo) / 1e-4;
+        beta = g.Gam * Y * 2.0 * H5;
+        spat = geo;
+      }
+      return Y * geo;
+    }
     const double sS1 = spow(gS2, g.nS - 1.0);
     const double geo = g.Gam * upow(Hb, g.nH + 2.0) * sS1;
     double D = Y * geo;
