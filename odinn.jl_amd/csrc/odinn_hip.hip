@@ -3671,7 +3671,7 @@ static int timed_one(odinn_batch* b, int which, int it) {
       AdjStageArgs SA{};
       SA.snaps = b->d_snaps; SA.ntot = b->ntot; SA.adj = b->d_adj; SA.S2 = b->d_S2; SA.S3 = b->d_S3; SA.E = b->d_E;
       SA.abstol = 1e-8; SA.reltol = 1e-8; SA.src = b->d_lam[0]; SA.dst = b->d_lam[1];
-      launch_adj_stage(b->lm(), 0, 2, b->ntiles, b->stream, P, L, SA);
+      launch_adj_stage(b->lm_kern(), 0, 2, b->ntiles, b->stream, P, L, SA);
       return ODINN_OK;
     }
     case ODINN_TIMED_ADJ_FUSED_STEP: {
@@ -3701,9 +3701,18 @@ int odinn_bench_prepare(odinn_batch* b) {
   return timed_prepare(b);
 }
 
+// The timed launches evaluate the Y law's network, as the seams do -- unless the schedule FIELD law_table is 1 (not just the
+// default): then they run the table's kernels, which is how bench.py times k_rk_stage / k_adj_stage<., LM_YTAB>.
+struct TimedTableScope {
+  odinn_batch* b;
+  bool on;
+  explicit TimedTableScope(odinn_batch* b_) : b(b_), on(b_->sched.law_table == 1) { if (on) ++b->ytab_scope; }
+  ~TimedTableScope() { if (on) --b->ytab_scope; }
+};
 int odinn_bench_enqueue(odinn_batch* b, int which, int first_iter, int n) {
   if (!b || n < 0) return fail(ODINN_ERR_ARG, "bad arguments");
   CHK(use_dev(b));
+  TimedTableScope tts(b);
   for (int i = 0; i < n; ++i) CHK(timed_one(b, which, first_iter + i));
   HIPCHK(hipGetLastError());
   return ODINN_OK;
@@ -3712,6 +3721,7 @@ int odinn_bench_enqueue(odinn_batch* b, int which, int first_iter, int n) {
 int odinn_time_kernel(odinn_batch* b, int which, int warmup, int iters, double* ms_total) {
   if (!b || !ms_total || iters <= 0) return fail(ODINN_ERR_ARG, "bad arguments");
   CHK(timed_prepare(b));
+  TimedTableScope tts(b);
   for (int i = 0; i < warmup; ++i) CHK(timed_one(b, which, i));
   const char* eg = std::getenv("ODINN_TIME_GRAPH");
   if (eg && eg[0] == '1') {
