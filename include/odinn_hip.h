@@ -175,7 +175,7 @@ typedef struct odinn_schedule {
                               table's range is repeated with a wider one).  The seam calls always evaluate the network           */
   int32_t interp_async;    /* ODINN_INTERP_ASYNC: 0 = the Y law's `:Linear` contraction of a stop (sort, knots, interval sums, knot
                               backprop) on the batch's own stream; n = 1 ... 4: overlapped with the following reverse steps of both
-                              adjoints on n lane streams (default: 3 in the DiscreteAdjoint, 1 in the ContinuousAdjoint; results
+                              adjoints on n lane streams (default: 3 in the DiscreteAdjoint, 1 or 4 in the ContinuousAdjoint; results
                               bit-identical: every contribution has its own slot, the slots are added in the order of the stops)  */
   int32_t reserved[3];     /* zero                                                                                                 */
 } odinn_schedule;

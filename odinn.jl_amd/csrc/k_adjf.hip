@@ -7,6 +7,19 @@ void launch_adj_fused_strip(int nblk, int afield, int skip, int rows, hipStream_
   // measurement aid: ODINN_ADJ_LDS_PAD=<bytes> of unused dynamic LDS per workgroup (> 2 KB: one workgroup per CU instead of two,
   // i.e. half the per-XCD working set against the 4 MB L2 at half the occupancy)
   static const unsigned pad = std::getenv("ODINN_ADJ_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ODINN_ADJ_LDS_PAD")) : 0u;
+  if (A.ytab) {  // the Y law through its table (the caller guarantees !afield, no th_part / Gacc, rows 4 or 7)
+    if (rows == 4) {
+      if (skip) hipLaunchKernelGGL((k_adj_fused_strip<false, true, true, 4, false, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+      else hipLaunchKernelGGL((k_adj_fused_strip<false, false, true, 4, false, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+    } else if (A.segs) {
+      if (skip) hipLaunchKernelGGL((k_adj_fused_strip<false, true, true, TRPT, false, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+      else hipLaunchKernelGGL((k_adj_fused_strip<false, false, true, TRPT, false, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+    } else {
+      if (skip) hipLaunchKernelGGL((k_adj_fused_strip<false, true, false, TRPT, false, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+      else hipLaunchKernelGGL((k_adj_fused_strip<false, false, false, TRPT, false, true>), dim3(nblk), dim3(TNT), pad, st, P, A);
+    }
+    return;
+  }
   if (rows == 8) {  // gridded A, register-cached (ODINN_ADJ_RC), the forward kernel's 54 x 54 tiles; the caller guarantees afield and A.segs
     if (A.Gacc) {
       if (skip) hipLaunchKernelGGL((k_adj_fused_strip<true, true, true, 8, true>), dim3(nblk), dim3(TNT), pad, st, P, A);

@@ -2219,7 +2219,8 @@ struct InterpAsyncScope {  // leaves no work behind on the lane streams, whichev
 // Lanes by default (8 x 512^2, table path, ms per gradient; profiles/r04/ytab_lanes.txt): the reverse-Euler loop of the
 // DiscreteAdjoint is short and its contractions are the longer chain -- 0 / 1 / 2 / 3 lanes: 9.7 / 9.3 / 8.4 / 8.4; the reverse
 // ODE of the ContinuousAdjoint keeps the GPU busy itself and more than one lane only takes bandwidth from it: 212 / 151 / 190 / 179
-// (low-priority lanes: 470; a high-priority batch stream brings 2 - 3 lanes back to 152, no better than one lane).
+// (low-priority lanes: 470; a high-priority batch stream brings 2 - 3 lanes back to 152, no better than one lane) -- that is with
+// five stage launches per reverse step; with ONE fused launch (k_adj_fused_strip<..., YT>) the lanes are the longer chain: 4.
 static int interp_async_enable(odinn_batch* b, bool useV, int lanes_default) {
   if (b->law_kind != ODINN_LAW_NN_Y) return ODINN_OK;
   CHK(ensure_interp_scratch(b));
@@ -3152,7 +3153,11 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
   // current lambda buffer): the five stages of a reverse step run as ONE kernel
   // (sia2d_adj_fused.hpp) -- measured faster at every batch size, 4 alpine glaciers included; ODINN_ADJ_FUSED=0
   // selects the five k_adj_stage launches
-  bool fused_rev = lm == 0 && b->vjp_method == ODINN_VJP_DISCRETE;
+  // (round 4: also the Y law through its table where that is the integer-power law with Y(Hbar) in A's place -- n_H = n_gradS = 3,
+  //  no sliding, GDev::yt_fast on every glacier; its theta-integrand stays with theta_vjp_launch)
+  bool ytab_rev = b->lm_kern() == LM_YTAB;
+  for (const GDev& r : b->gd) ytab_rev = ytab_rev && r.yt_fast;
+  bool fused_rev = (lm == 0 || ytab_rev) && b->vjp_method == ODINN_VJP_DISCRETE;
   fused_rev = fused_rev && sched_val(b->sched.adj_fused, "ODINN_ADJ_FUSED") != 0;
   const int rev_skip = sched_val(b->sched.adj_skip, "ODINN_ADJ_SKIP") == 0 ? 0 : 1;
   AdjFusedArgs FA{};
@@ -3160,6 +3165,7 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
   if (fused_rev) {
     FA.snaps = b->d_snaps; FA.ntot = b->ntot; FA.adj = b->d_adj; FA.lam0 = b->d_lam[0]; FA.lam1 = b->d_lam[1];
     FA.partF = b->d_partFt; FA.tilesF = b->d_tilesFt; FA.abstol = ao.abstol; FA.reltol = ao.reltol;
+    if (ytab_rev) { FA.ytab = b->d_ytab; FA.ytab_over = b->d_ytab_over; FA.ytab_ni = b->ytab_ni; }
     C.errpart = b->d_partFt; C.stride = 1; C.fused = 3;
     // the two bracketing snapshots of every segment interleaved as {H_j, H_j+1 - H_j}: one 16-byte load per cell and
     // stage instead of two 8-byte ones (ODINN_ADJ_SEGS=0: read the snapshots themselves)
@@ -3230,7 +3236,9 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
   long long steps = 0;
   int p = 0;
   InterpAsyncScope ia_scope{b};
-  CHK(interp_async_enable(b, useV, 1));
+  // (one lane while the five stage launches keep the GPU busy; with the fused reverse step of the tabulated Y law the contractions
+  //  are the longer chain again -- 8 x 512^2, ms per gradient for 1 / 2 / 3 / 4 lanes: 145 / 135 / 126 / 121)
+  CHK(interp_async_enable(b, useV, (fused_rev && ytab_rev) ? 4 : 1));
   while (nact > 0) {
     for (int s_ = 0; s_ < chunk; ++s_) {
       double* a0 = b->d_lam[p];

@@ -66,14 +66,15 @@ struct AdjRowCache {
   double u0[NR];      // lambda at the start of the step
 };
 
-template <int S, bool AF, bool SG, int NR, bool GA = false, bool RC = false>
+template <int S, bool AF, bool SG, int NR, bool GA = false, bool RC = false, bool YT = false>
 __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __restrict__ Afield, const double* __restrict__ Ha,
                                                  const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
                                                  int gic, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
                                                  AdjEdgesL sLm, double (&u)[NR], double (&tmp)[NR], double (&E)[NR],
                                                  const double* __restrict__ Bp, AdjErr sEr, double* __restrict__ th_red,
                                                  [[maybe_unused]] double* __restrict__ Gp = nullptr,
-                                                 [[maybe_unused]] const AdjRowCache<RC ? NR : 1>* rc = nullptr) {
+                                                 [[maybe_unused]] const AdjRowCache<RC ? NR : 1>* rc = nullptr,
+                                                 [[maybe_unused]] const YtabRef yt = YtabRef{nullptr, nullptr, 0}) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;
   constexpr bool ELDS = ODINN_ADJ_ELDS && !(RC && ODINN_ADJ_RC_EREG);
   const int r0 = NR * w;
@@ -146,6 +147,10 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
         An = ldg32(Afield, (unsigned)(ok ? gif + (g.nx - 1) * gj : 0));  // Afield: the glacier's first dual node (ok: gif == gi)
       }
     }
+    // YT: the Y law of target :D_hybrid with n_H = n_gradS = 3 and no sliding is this law with Y(Hbar) in A's place (node_D<LM_YTAB>,
+    // yt_fast), plus the reference's finite-difference term of dD/dHbar (target_D_hybrid.jl:58-71) in alpha below
+    [[maybe_unused]] double Yp = 0.0;
+    if constexpr (YT) An = ytab_eval_core<true>(yt.tab, yt.ni, yt.over, g.yt_inv_h, 0.25 * Hs, Yp);
     const double Kq = An * Gq;
     const double H2 = Hs * Hs, H4 = H2 * H2, H5 = H4 * Hs;
     D = (Kq * H5) * gS2;
@@ -154,7 +159,11 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     // (adjoint.jl:235-250; k_vjp_theta_strip's expression): stage 1 sits exactly on the state the reverse solve has just
     // reached, so a quadrature node reached by the previous step gets its theta-VJP here instead of in a launch of its own
     tw = S == 1 ? ((Gq * H5) * gS2) * Da : 0.0;
-    const double ad = (((Kq * 5.0) * H4) * gS2) * Da;  // alpha Da / 4
+    double ad = (((Kq * 5.0) * H4) * gS2) * Da;  // alpha Da / 4
+    if constexpr (YT) {
+      const double geo = (Gq * H5) * gS2;  // Gam Hbar^5 |grad S|^2
+      ad = fma(0.25 * ((Yp * geo - An * geo) / 1e-4), Da, ad);
+    }
     const double bd = ((Kq * 2.0) * H5) * Da;           // beta Da
     const double bx = g.hinv_dx * (bd * gx), by = g.hinv_dy * (bd * gy);
     const double am = ad - bx, ap = ad + bx;
@@ -274,8 +283,12 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
 // GA (gridded A with a dual-grid accumulator): stage 1 of the step that follows a quadrature node also adds the node
 // weights into A.Gacc (needs A.th_part)
 constexpr bool adj_rc(bool AF, bool SG, int NR) { return ODINN_ADJ_RC && (AF || ODINN_ADJ_RC > 1) && SG && NR > 4; }
-template <bool AF, bool SKIP, bool SG = false, int NR = TRPT, bool GA = false>
-__global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : ODINN_FWPE)) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
+#ifndef ODINN_ADJ_YT_WPE
+#define ODINN_ADJ_YT_WPE ODINN_FWPE
+#endif
+template <bool AF, bool SKIP, bool SG = false, int NR = TRPT, bool GA = false, bool YT = false>
+__global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_WPE : ODINN_FWPE))) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
+  static_assert(!YT || (!AF && !GA), "the table's instantiation replaces the scalar A");
   constexpr bool RC = adj_rc(AF, SG, NR);
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double sLm[2][TNW][2][FRX];
@@ -420,18 +433,19 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : ODINN_FWPE)) void k_
   // theta-VJP of the quadrature node the previous step reached (a.qw: its Gauss-Legendre weight, 0 otherwise; the controller
   // resets it at every call, so a repeated attempt after a rejection does not count the node twice)
   double* const thr = (A.th_part && a.qw != 0.0) ? th_red : nullptr;
-  adj_strip_stage<1, AF, SG, NR, GA, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr,
-                                         GA ? A.Gacc + g.offd : nullptr, &rc);
+  const YtabRef yt{YT ? A.ytab + g.yt_off : nullptr, A.ytab_over, A.ytab_ni};
+  adj_strip_stage<1, AF, SG, NR, GA, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr,
+                                             GA ? A.Gacc + g.offd : nullptr, &rc, yt);
   if (thr && threadIdx.x == 0) {  // the tile's running sum, reduced per glacier once after the reverse solve
     double sum = 0.0;
 #pragma unroll
     for (int k = 0; k < TNW; ++k) sum += th_red[k];
     A.th_part[t4.w] = fma(a.qw, sum, A.th_part[t4.w]);
   }
-  adj_strip_stage<2, AF, SG, NR, false, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc);
-  adj_strip_stage<3, AF, SG, NR, false, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc);
-  adj_strip_stage<4, AF, SG, NR, false, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc);
-  adj_strip_stage<5, AF, SG, NR, false, RC>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc);
+  adj_strip_stage<2, AF, SG, NR, false, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt);
+  adj_strip_stage<3, AF, SG, NR, false, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt);
+  adj_strip_stage<4, AF, SG, NR, false, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt);
+  adj_strip_stage<5, AF, SG, NR, false, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt);
   // ---- output rows [FH, (NR * TNW)-1-FH]: lam' from the registers, embedded error partial -----------------------
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   double errsq = 0.0;

@@ -987,20 +987,25 @@ __device__ __forceinline__ double spow(double gS2, double e) {
 // perturbed value is the SAME quintic at s + ds, formed as Y + [p(s + ds) - p(s)] with the exact finite Taylor shift of the
 // polynomial, ds from the perturbation the reference really applies, fl(Hbar + 1e-4) - Hbar.  A node beyond the table takes the
 // table's last value and raises *ytab_over: the host repeats the call with a wider table (or the exact kernels).
+struct YtabRef {  // one glacier's table as the strip kernels take it (AdjFusedArgs): base of the glacier's coefficients, flag, size
+  const double* tab;
+  int* over;
+  int ni;
+};
 template <bool ADJ>
-__device__ __forceinline__ double ytab_eval(const GDev& g, const LawDev& L, double Hb, double& Yp) {
-  double x = Hb * g.yt_inv_h;
-  if (!(x < (double)L.ytab_ni)) {  // beyond the table (or NaN): the table's last value, so that the doomed solve stays tame
-    x = (double)L.ytab_ni;
-    *L.ytab_over = 1;
+__device__ __forceinline__ double ytab_eval_core(const double* __restrict__ tab, int ni, int* over, double inv_h, double Hb, double& Yp) {
+  double x = Hb * inv_h;
+  if (!(x < (double)ni)) {  // beyond the table (or NaN): the table's last value, so that the doomed solve stays tame
+    x = (double)ni;
+    *over = 1;
   }
-  const int i = min((int)x, L.ytab_ni - 1);  // Hbar >= 0
+  const int i = min((int)x, ni - 1);  // Hbar >= 0
   const double s = fma(2.0, x - (double)i, -1.0);
-  const double2* __restrict__ c = reinterpret_cast<const double2*>(L.ytab + g.yt_off) + 3 * i;
+  const double2* __restrict__ c = reinterpret_cast<const double2*>(tab) + 3 * i;
   const double2 c01 = c[0], c23 = c[1], c45 = c[2];
   const double Y = fma(fma(fma(fma(fma(c45.y, s, c45.x), s, c23.y), s, c23.x), s, c01.y), s, c01.x);
   if (ADJ) {
-    const double ds = 2.0 * (((Hb + 1e-4) - Hb) * g.yt_inv_h);
+    const double ds = 2.0 * (((Hb + 1e-4) - Hb) * inv_h);
     const double p1 = fma(fma(fma(fma(5.0 * c45.y, s, 4.0 * c45.x), s, 3.0 * c23.y), s, 2.0 * c23.x), s, c01.y);
     const double p2 = fma(fma(fma(10.0 * c45.y, s, 6.0 * c45.x), s, 3.0 * c23.y), s, c23.x);
     const double p3 = fma(fma(10.0 * c45.y, s, 4.0 * c45.x), s, c23.y);
@@ -1008,6 +1013,10 @@ __device__ __forceinline__ double ytab_eval(const GDev& g, const LawDev& L, doub
     Yp = fma(ds, fma(ds, fma(ds, fma(ds, fma(ds, c45.y, p4), p3), p2), p1), Y);
   }
   return Y;
+}
+template <bool ADJ>
+__device__ __forceinline__ double ytab_eval(const GDev& g, const LawDev& L, double Hb, double& Yp) {
+  return ytab_eval_core<ADJ>(L.ytab + g.yt_off, L.ytab_ni, L.ytab_over, g.yt_inv_h, Hb, Yp);
 }
 
 template <bool ADJ, int LM, int NK = 0>
@@ -2282,6 +2291,9 @@ struct AdjFusedArgs {
   double* th_part;      // non-null (A-type laws): per-tile running sums of the theta-VJP at the quadrature nodes, formed in
                         //   stage 1 of the step that follows a node (same tile table)
   double* Gacc;         // non-null (gridded A; needs th_part and segs): the dual-grid accumulator gets the node weights there too
+  const double* ytab;   // non-null: the Y law through its table (LM_YTAB, every glacier yt_fast) -- the kernel's YT instantiation
+  int* ytab_over;
+  int ytab_ni;
 };
 
 

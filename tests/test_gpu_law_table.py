@@ -169,3 +169,27 @@ def test_overlapped_interpolation_is_bit_identical(gpu, table):
             assert Lc2 == Lc and np.array_equal(gc2, gc), mode
             assert Ld2 == Ld and np.array_equal(gd2, gd), mode
     b.close()
+
+
+def test_fused_reverse_step_with_the_table_matches_the_staged_one(gpu):
+    """n_H = n_gradS = 3 without sliding: the Y law is the integer-power law with Y(Hbar) in A's place, and the ContinuousAdjoint's
+    reverse step runs as ONE k_adj_fused_strip<..., YT> launch instead of five k_adj_stage<., LM_YTAB> (adj_fused = 0): same step
+    counts, gradients equal to the rounding of two compilations of the same expressions; 4- and 7-row tiles, with and without the
+    interleaved snapshot pairs."""
+    shapes, Ts = ((70, 57), (131, 64)), (-5.0, -9.0)
+    b, om, th, fields, ph = _batch(gpu, "default", shapes, Ts)
+    ts = [2010.0 + j / 24.0 for j in range(4)]
+    for g in range(2):
+        b.set_reference(g, ts, [fields[g][0] * (1.0 - 0.01 * j) for j in range(4)], 3)
+    b.set_schedule(adj_fused=0)
+    Ls, gs = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=16)
+    rev_s = [(s.naccept, s.nreject) for s in b.last_stats_rev]
+    for sched in (dict(), dict(adj_rows=4), dict(adj_rows=7), dict(adj_rows=7, adj_segs=0), dict(adj_skip=0)):
+        b.set_schedule(**sched)
+        Lf, gf = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=16)
+        assert [(s.naccept, s.nreject) for s in b.last_stats_rev] == rev_s, sched
+        assert abs(Lf - Ls) <= 1e-12 * abs(Ls) and rel_l2(gf, gs) < 1e-9, (sched, rel_l2(gf, gs))
+    b.set_schedule(law_table=0)  # the network: five stage launches, as before
+    Ln, gn = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=16)
+    assert rel_l2(gf, gn) < 1e-7
+    b.close()
