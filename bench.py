@@ -502,6 +502,30 @@ def main():
                 "continuous_adjoint": G_job / tggc,
                 "sample": f"as bench_workload, but A = NN_theta(T) gridded with the 2x16 MLP ({len(thetaA)} params) of the headline",
             }
+            # (i'') the per-node law Y = NN_theta(T_glacier, Hbar) (target :D_hybrid, default 2-3-10-3-1 net, the reference's default
+            #       `:Linear` gradient interpolation) through its per-glacier table -- the library's default; the network itself in the
+            #       stencil (law_table = 0) only with the cheaper DiscreteAdjoint
+            try:
+                mY = odinn.MLPSpec([2, 3, 10, 3, 1], [odinn.ACT_SOFTPLUS] * 3 + [odinn.ACT_SIGMOID], [(-25.0, 0.0), (0.0, 500.0)],
+                                   odinn.POST_EXPMAX, 0.0, ph.maxA)
+                thY = np.random.default_rng(1234).uniform(-0.5, 0.5, mY.n_params)
+                b.set_law(odinn.LAW_NN_Y, mY, thY)
+                tyd = timed(False, thY)
+                tyc = timed(True, thY)
+                revy = b.last_stats_rev[0] if getattr(b, "last_stats_rev", None) else None
+                b.set_schedule(law_table=0)
+                tynd = timed(False, thY)
+                b.set_schedule()
+                grad["bench_workload_Y_law"] = {
+                    "discrete_adjoint": G_job / tyd, "continuous_adjoint": G_job / tyc, "discrete_adjoint_network_in_stencil": G_job / tynd,
+                    "table_usable": b.law_table()["usable"],
+                    "sample": "as bench_workload, but the Y law (86 parameters) with its table Y(Hbar) per glacier; ContinuousAdjoint: one fused "
+                              "reverse launch per step" + (f", {revy.naccept}+{revy.nreject} reverse RK steps" if revy else "") +
+                              ", the `:Linear` contractions of the quadrature nodes on lane streams",
+                }
+            except Exception as e:
+                grad["bench_workload_Y_law"] = {"error": str(e)[:300]}
+                b.set_schedule()
             b.set_law(odinn.LAW_CONST_A)
             # (ii) BASELINE configs[3]: 4 alpine glaciers (synthetic stand-ins of the README set), and the same set
             #      replicated to fill the GPU (the reference maps one glacier per worker process)
