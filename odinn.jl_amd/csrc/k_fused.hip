@@ -1,4 +1,4 @@
-// k_fused.hip -- temporally fused RDPK3Sp35 step for one law mode (-DODINN_LM=0 ... 7)
+// k_fused.hip -- temporally fused RDPK3Sp35 step for one law mode (-DODINN_LM=0 ... 8)
 #include <cstdlib>
 // inlined-MLP laws: log1p's table lives in LDS in these kernels (mode 2: filled with the tile; see sia2d_device.hpp)
 #if defined(ODINN_LM) && ODINN_LM >= 2 && ODINN_LM <= 6 && !defined(ODINN_LOG1P_TABLE)

@@ -1,4 +1,4 @@
-// k_fwd.hip -- forward stencil kernels for one law mode (compile with -DODINN_LM=0 ... 7)
+// k_fwd.hip -- forward stencil kernels for one law mode (compile with -DODINN_LM=0 ... 8)
 // inlined-MLP laws: log1p's table lives in LDS in these kernels (mode 2: filled by the tile loader; see sia2d_device.hpp)
 #if defined(ODINN_LM) && ODINN_LM >= 2 && ODINN_LM <= 6 && !defined(ODINN_LOG1P_TABLE)
 #define ODINN_LOG1P_TABLE 2

@@ -77,7 +77,7 @@ void launch_sum_slots(hipStream_t st, long long n, int nslots, const double* slo
   hipLaunchKernelGGL(k_sum_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, nslots, slots, out);
 }
 // table of the Y law for G glaciers x ni intervals (k_ytab_build); stat: 3 zeroed 64-bit words
-void launch_ytab_build(hipStream_t st, Pools P, LawDev L, int G, double* tab, int ni, double floor_abs, unsigned long long* stat) {
+static const YtabVinv& ytab_vinv() {
   static const YtabVinv V = [] {
     YtabVinv v{};
     long double a[6][12];
@@ -101,7 +101,15 @@ void launch_ytab_build(hipStream_t st, Pools P, LawDev L, int G, double* tab, in
     for (int k = 0; k < 6; ++k) for (int j = 0; j < 6; ++j) v.v[k][j] = (double)a[k][6 + j];
     return v;
   }();
-  hipLaunchKernelGGL(k_ytab_build, dim3((unsigned)((ni + 255) / 256), (unsigned)G), dim3(256), 0, st, P, L, V, tab, ni, floor_abs, stat);
+  return V;
+}
+void launch_ytab_build(hipStream_t st, Pools P, LawDev L, int G, double* tab, int ni, double floor_abs, unsigned long long* stat) {
+  hipLaunchKernelGGL(k_ytab_build, dim3((unsigned)((ni + 255) / 256), (unsigned)G), dim3(256), 0, st, P, L, ytab_vinv(), tab, ni, floor_abs, stat);
+}
+// table of the U law: nh x ns patches (k_utab_build)
+void launch_utab_build(hipStream_t st, LawDev L, double* tab, int nh, int ns, double floor_abs, unsigned long long* stat) {
+  const long long np = (long long)nh * ns;
+  hipLaunchKernelGGL(k_utab_build, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, L, ytab_vinv(), tab, nh, ns, floor_abs, stat);
 }
 void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd) {
   hipLaunchKernelGGL(k_eval_law, dim3((unsigned)((nd + NT - 1) / NT)), dim3(NT), 0, st, P, L, U, out, gidx);

@@ -1,5 +1,5 @@
 // launch.hpp -- host-callable launch wrappers; each law mode (LM) of the stencil kernels is
-// compiled in its own translation unit (k_fwd.hip / k_adj.hip / k_fused.hip with -DODINN_LM=0 ... 7).
+// compiled in its own translation unit (k_fwd.hip / k_adj.hip / k_fused.hip with -DODINN_LM=0 ... 8).
 #pragma once
 #include "sia2d_device.hpp"
 
@@ -23,6 +23,7 @@ ODINN_DECL_LM(4)
 ODINN_DECL_LM(5)
 ODINN_DECL_LM(6)
 ODINN_DECL_LM(7)  // the Y law through its per-glacier table (LM_YTAB)
+ODINN_DECL_LM(8)  // the U law through the batch's bivariate table (LM_UTAB)
 #undef ODINN_DECL_LM
 
 // k_fused.hip, law mode 0 only
@@ -94,6 +95,7 @@ void launch_law_field_grad_scratch(int nblk, hipStream_t st, LawDev L, const dou
                                    double* gscratch, double* part_theta);
 void launch_sum_rows(int Pn, hipStream_t st, const double* part, int nrows, double* out);
 void launch_sum_slots(hipStream_t st, long long n, int nslots, const double* slots, double* out);
+void launch_utab_build(hipStream_t st, LawDev L, double* tab, int nh, int ns, double floor_abs, unsigned long long* stat);
 void launch_ytab_build(hipStream_t st, Pools P, LawDev L, int G, double* tab, int ni, double floor_abs, unsigned long long* stat);
 void launch_eval_law(hipStream_t st, Pools P, LawDev L, const double* U, double* out, int gidx, long long nd);
 void launch_axpy_g(int nblk, hipStream_t st, Pools P, const double* x, const double* y, double* z);

@@ -456,10 +456,15 @@ struct odinn_batch {
   int ytab_scope = 0;         // > 0 inside do_solve / odinn_loss_grad / odinn_loss_grad_continuous
   double ytab_err_rel = 0.0, ytab_err_abs = 0.0, ytab_ymax = 0.0;
   bool ytab_wanted() const {
-    return law_kind == ODINN_LAW_NN_Y && !ytab_blocked && sched_val(sched.law_table, "ODINN_LAW_TABLE") != 0;
+    return (law_kind == ODINN_LAW_NN_Y || law_kind == ODINN_LAW_NN_U) && !ytab_blocked && sched_val(sched.law_table, "ODINN_LAW_TABLE") != 0;
   }
+  // U law: ONE bivariate table U(Hbar, |grad S|) for the batch (LM_UTAB), the same life cycle -- built from the network at every
+  // theta update, used while it agrees with it to YTAB_TOL, a solve that leaves [0, utab_hmax] x [0, utab_smax] is repeated with
+  // twice the range (d_ytab / d_ytab_over / d_ytab_stat are shared with the Y law's table)
+  int utab_nh = 128, utab_ns = 64;
+  double utab_hmax = 0.0, utab_smax = 0.0;
   // law mode of the stencil kernels that evaluate the law per node and stage (forward stages, H-VJP, reverse stages)
-  int lm_kern() const { return (ytab_scope > 0 && ytab_ok) ? LM_YTAB : lm(); }
+  int lm_kern() const { return (ytab_scope > 0 && ytab_ok) ? (law_kind == ODINN_LAW_NN_U ? LM_UTAB : LM_YTAB) : lm(); }
   // dL/dA is accumulated on the dual grid when A is a field (hoisted NN or prescribed)
   bool wants_Gacc() const {
     return law_kind == ODINN_LAW_NN_A_GRIDDED || (law_kind == ODINN_LAW_CONST_A && has_Afield_const);
@@ -497,6 +502,10 @@ struct odinn_batch {
     L.ytab = d_ytab;
     L.ytab_over = d_ytab_over;
     L.ytab_ni = ytab_ni;
+    L.utab = d_ytab;
+    L.utab_nh = utab_nh; L.utab_ns = utab_ns;
+    L.ut_inv_h = utab_hmax > 0.0 ? (double)utab_nh / utab_hmax : 1.0;
+    L.ut_inv_s = utab_smax > 0.0 ? (double)utab_ns / utab_smax : 1.0;
     return L;
   }
 };
@@ -533,10 +542,11 @@ void dfree(T*& p) {
 // derived per-glacier constants + hoisted scalar law; uploads d_gd when dirty
 // Build the Y law's table for the current theta / ranges and decide whether the kernels may use it: the deviation from the
 // network measured by k_ytab_build between the interpolation nodes must stay below YTAB_TOL relative to the law's value
-// (values below 1e-6 of the law's scale: relative to the largest value in the table).
+// (values below 1e-3 of the largest value in the table: relative to that largest value).
 constexpr double YTAB_TOL = 1e-12;
 int ytab_refresh(odinn_batch* b) {
-  const size_t need = (size_t)b->G * 6 * b->ytab_ni;
+  const bool isU = b->law_kind == ODINN_LAW_NN_U;
+  const size_t need = isU ? (size_t)36 * b->utab_nh * b->utab_ns : (size_t)b->G * 6 * b->ytab_ni;
   if (need > b->ytab_cap || !b->d_ytab) {
     dfree(b->d_ytab);
     b->d_ytab = nullptr;
@@ -548,19 +558,27 @@ int ytab_refresh(odinn_batch* b) {
     HIPCHK(hipMemsetAsync(b->d_ytab_over, 0, sizeof(int), b->stream));
   }
   if (!b->d_ytab_stat) CHK(dalloc(&b->d_ytab_stat, (size_t)3));
-  HIPCHK(hipMemsetAsync(b->d_ytab_stat, 0, 3 * sizeof(unsigned long long), b->stream));
-  const double floor_abs = 1e-6 * std::fabs(b->mlp.post_hi != 0.0 ? b->mlp.post_hi : 1.0);
-  launch_ytab_build(b->stream, b->pools(false), b->lawdev(), b->G, b->d_ytab, b->ytab_ni, floor_abs, b->d_ytab_stat);
-  HIPCHK(hipGetLastError());
-  double st[3];
-  HIPCHK(hipMemcpyAsync(st, b->d_ytab_stat, sizeof(st), hipMemcpyDeviceToHost, b->stream));
-  HIPCHK(hipStreamSynchronize(b->stream));
+  // two passes: the first finds the law's largest value on the table's range, the second measures the deviation -- relative to the
+  // law's value where that is at least a thousandth of the largest, relative to the largest below (where the law all but vanishes,
+  // e.g. exp((y - 1) / y) for y -> 0 far outside the range the network was scaled for, its RELATIVE curvature is unbounded and
+  // nothing flows)
+  double st[3] = {0.0, 0.0, 0.0};
+  double floor_abs = 1e300;
+  for (int pass = 0; pass < 2; ++pass) {
+    HIPCHK(hipMemsetAsync(b->d_ytab_stat, 0, 3 * sizeof(unsigned long long), b->stream));
+    if (isU) launch_utab_build(b->stream, b->lawdev(), b->d_ytab, b->utab_nh, b->utab_ns, floor_abs, b->d_ytab_stat);
+    else launch_ytab_build(b->stream, b->pools(false), b->lawdev(), b->G, b->d_ytab, b->ytab_ni, floor_abs, b->d_ytab_stat);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(st, b->d_ytab_stat, sizeof(st), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    floor_abs = 1e-3 * st[2];
+  }
   b->ytab_err_rel = st[0]; b->ytab_err_abs = st[1]; b->ytab_ymax = st[2];
-  b->ytab_ok = st[0] <= YTAB_TOL && st[1] <= YTAB_TOL * std::max(st[2], floor_abs) && std::isfinite(st[2]);
+  b->ytab_ok = st[0] <= YTAB_TOL && st[1] <= YTAB_TOL * st[2] && std::isfinite(st[2]) && st[2] > 0.0;
   static const bool verbose = std::getenv("ODINN_LAW_TABLE_VERBOSE") != nullptr;
   if (verbose)
-    std::fprintf(stderr, "[odinn ytab] %d x %d intervals, rel %.3g abs %.3g ymax %.3g -> %s\n", b->G, b->ytab_ni, st[0], st[1], st[2],
-                 b->ytab_ok ? "table" : "network");
+    std::fprintf(stderr, "[odinn %s] %d x %d %s, rel %.3g abs %.3g max %.3g -> %s\n", isU ? "utab" : "ytab", isU ? b->utab_nh : b->G,
+                 isU ? b->utab_ns : b->ytab_ni, isU ? "patches" : "intervals", st[0], st[1], st[2], b->ytab_ok ? "table" : "network");
   return ODINN_OK;
 }
 // did any node leave the table since the last call?  (clears the flag)
@@ -608,7 +626,18 @@ int refresh_gd(odinn_batch* b) {
   }
   const bool ytab = b->ytab_wanted();
   b->ytab_ok = false;
-  if (ytab) {
+  if (ytab && b->law_kind == ODINN_LAW_NN_U) {
+    b->h0max.resize(b->G, 0.0);
+    if (!(b->utab_hmax > 0.0)) {
+      double m = 0.0;
+      for (int g = 0; g < b->G; ++g) m = std::max(m, b->h0max[g]);
+      b->utab_hmax = std::max(200.0, 1.25 * m + 50.0);
+      // slopes: twice the upper bound of the law's input scaling, at least 1 (a solve that meets a steeper node widens it)
+      b->utab_smax = std::max(1.0, b->mlp.has_prescale ? 2.0 * b->mlp.pre_hi[1] : 1.0);
+      if (const char* e = std::getenv("ODINN_LAW_TABLE_HMAX"))  // (test aid)
+        if (std::atof(e) > 0.0) b->utab_hmax = std::atof(e);
+    }
+  } else if (ytab) {
     b->ytab_hmax.resize(b->G, 0.0);
     b->h0max.resize(b->G, 0.0);
     for (int g = 0; g < b->G; ++g) {
@@ -696,8 +725,8 @@ int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */
   }
   const Pools P = b->pools(g < 0);
   const int base = g < 0 ? 0 : b->gd[g].tile0, n = g < 0 ? b->ntiles : b->gd[g].ntiles;
-  static void (*const tab[8])(int, hipStream_t, Pools, LawDev, const double*, double*, int) = {
-      launch_dhdt_lm0, launch_dhdt_lm1, launch_dhdt_lm2, launch_dhdt_lm3, launch_dhdt_lm4, launch_dhdt_lm5, launch_dhdt_lm6, launch_dhdt_lm7};
+  static void (*const tab[9])(int, hipStream_t, Pools, LawDev, const double*, double*, int) = {
+      launch_dhdt_lm0, launch_dhdt_lm1, launch_dhdt_lm2, launch_dhdt_lm3, launch_dhdt_lm4, launch_dhdt_lm5, launch_dhdt_lm6, launch_dhdt_lm7, launch_dhdt_lm8};
   tab[b->lm_kern()](n, b->stream, P, b->lawdev(), U, dH, base);
   HIPCHK(hipGetLastError());
   return ODINN_OK;
@@ -706,16 +735,16 @@ int launch_dhdt(odinn_batch* b, const double* U, double* dH, int g /* -1: all */
 template <int S>
 void launch_stage(odinn_batch* b, const Pools& P, const LawDev& L, const double* src, double* dst, double abstol,
                   double reltol) {
-  static void (*const tab[8])(int, int, hipStream_t, Pools, LawDev, const double*, double*, double*, double*, double*,
+  static void (*const tab[9])(int, int, hipStream_t, Pools, LawDev, const double*, double*, double*, double*, double*,
                               double, double) = {launch_rk_stage_lm0, launch_rk_stage_lm1, launch_rk_stage_lm2,
-                                                 launch_rk_stage_lm3, launch_rk_stage_lm4, launch_rk_stage_lm5, launch_rk_stage_lm6, launch_rk_stage_lm7};
+                                                 launch_rk_stage_lm3, launch_rk_stage_lm4, launch_rk_stage_lm5, launch_rk_stage_lm6, launch_rk_stage_lm7, launch_rk_stage_lm8};
   tab[b->lm_kern()](S, b->ntiles, b->stream, P, L, src, dst, b->d_S2, b->d_S3, b->d_E, abstol, reltol);
 }
 // vj < 0: the batch's VJP method (odinn_set_vjp_method)
 void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawDev& L, const AdjArgs& A, int base,
                   int vj = -1) {
-  static void (*const tab[8])(int, int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
-      launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5, launch_vjp_H_lm6, launch_vjp_H_lm7};
+  static void (*const tab[9])(int, int, int, hipStream_t, Pools, LawDev, AdjArgs, int) = {
+      launch_vjp_H_lm0, launch_vjp_H_lm1, launch_vjp_H_lm2, launch_vjp_H_lm3, launch_vjp_H_lm4, launch_vjp_H_lm5, launch_vjp_H_lm6, launch_vjp_H_lm7, launch_vjp_H_lm8};
   // integer-power law, DiscreteVJP, all glaciers at once: the strip-layout kernel on the 62 x 62 tile table
   // (sia2d_adj_fused.hpp: k_vjp_H_strip; ODINN_VJPH_STRIP=0 keeps the 64 x 16 LDS-tile kernel) ...
   // ... where its 62 x 62 tiles are reasonably full: batches of small glaciers (alpine: 96 x 80 ... 192 x 160 fill them to
@@ -733,13 +762,13 @@ void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawD
 }
 void launch_adj_stage(int lm, int vj, int stage, int nblk, hipStream_t st, const Pools& P, const LawDev& L,
                       const AdjStageArgs& A) {
-  static void (*const tab[8])(int, int, int, hipStream_t, Pools, LawDev, AdjStageArgs) = {
+  static void (*const tab[9])(int, int, int, hipStream_t, Pools, LawDev, AdjStageArgs) = {
       launch_adj_stage_lm0, launch_adj_stage_lm1, launch_adj_stage_lm2, launch_adj_stage_lm3, launch_adj_stage_lm4,
-      launch_adj_stage_lm5, launch_adj_stage_lm6, launch_adj_stage_lm7};
+      launch_adj_stage_lm5, launch_adj_stage_lm6, launch_adj_stage_lm7, launch_adj_stage_lm8};
   tab[lm](stage, vj, nblk, st, P, L, A);
 }
 void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L, const ThArgs& A, int base) {
-  static void (*const tab[8])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
+  static void (*const tab[7])(int, hipStream_t, Pools, LawDev, ThArgs, int) = {
       launch_vjp_theta_lm0, launch_vjp_theta_lm1, launch_vjp_theta_lm2, launch_vjp_theta_lm3, launch_vjp_theta_lm4,
       launch_vjp_theta_lm5, launch_vjp_theta_lm6};
   // integer-power A-type laws, all glaciers at once: the strip-layout reduction (k_vjp_theta_strip), under the same
@@ -763,9 +792,9 @@ void launch_euler_cfl(odinn_batch* b, const Pools& P, const LawDev& L, const dou
     launch_euler_cfl_strip(b->ntilesD, b->gd[0].use_Afield, b->stream, P, b->d_tilesD, src, dst, b->d_partD);
     return;
   }
-  static void (*const tab[8])(int, hipStream_t, Pools, LawDev, const double*, double*) = {
+  static void (*const tab[9])(int, hipStream_t, Pools, LawDev, const double*, double*) = {
       launch_euler_cfl_lm0, launch_euler_cfl_lm1, launch_euler_cfl_lm2, launch_euler_cfl_lm3, launch_euler_cfl_lm4,
-      launch_euler_cfl_lm5, launch_euler_cfl_lm6, launch_euler_cfl_lm7};
+      launch_euler_cfl_lm5, launch_euler_cfl_lm6, launch_euler_cfl_lm7, launch_euler_cfl_lm8};
   tab[b->lm_kern()](b->ntiles, b->stream, P, L, src, dst);
 }
 
@@ -819,8 +848,8 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
     launch_rk_fused_strip(nblk, b->gd[0].use_Afield, small == 3 ? 8 : TRPT, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol,
                           reltol, skip, sc, sq ? 1 : 0);
   } else {
-    static void (*const tab[8])(int, hipStream_t, Pools, LawDev, const int4*, double*, double*, double*, double, double, int, int) = {
-        launch_rk_fused_lm0, launch_rk_fused_lm1, launch_rk_fused_lm2, launch_rk_fused_lm3, launch_rk_fused_lm4, launch_rk_fused_lm5, launch_rk_fused_lm6, launch_rk_fused_lm7};
+    static void (*const tab[9])(int, hipStream_t, Pools, LawDev, const int4*, double*, double*, double*, double, double, int, int) = {
+        launch_rk_fused_lm0, launch_rk_fused_lm1, launch_rk_fused_lm2, launch_rk_fused_lm3, launch_rk_fused_lm4, launch_rk_fused_lm5, launch_rk_fused_lm6, launch_rk_fused_lm7, launch_rk_fused_lm8};
     tab[b->lm_kern()](nblk, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol, reltol, skip, small);
   }
   HIPCHK(hipGetLastError());
@@ -1067,6 +1096,7 @@ int do_solve(odinn_batch* b, int n_stops, const double* tstops, int n_mb, const 
     bool over = false;
     if (ytab_overflowed(b, &over) != ODINN_OK || !over) return rc;  // (a failed solve that left the table is repeated as well)
     if (attempt >= 2) b->ytab_blocked = true;
+    else if (b->law_kind == ODINN_LAW_NN_U) { b->utab_hmax *= 2.0; b->utab_smax *= 2.0; }
     else for (double& h : b->ytab_hmax) h *= 2.0;
     b->gd_dirty = true;
     b->solved = false;
@@ -1799,8 +1829,9 @@ int odinn_set_fields(odinn_batch* b, int g, const double* H0, const double* B) {
     for (size_t i = 0; i < n; ++i) if (H0[i] > m) m = H0[i];
     b->h0max[g] = m;
     b->ytab_hmax[g] = 0.0;
+    b->utab_hmax = 0.0;
     b->ytab_blocked = false;
-    if (b->law_kind == ODINN_LAW_NN_Y) b->gd_dirty = true;
+    if (b->law_kind == ODINN_LAW_NN_Y || b->law_kind == ODINN_LAW_NN_U) b->gd_dirty = true;
   }
   return ODINN_OK;
 }
@@ -2701,7 +2732,9 @@ int odinn_get_law_table(odinn_batch* b, int* usable, int* n_intervals, double* m
   if (n_intervals) *n_intervals = b->ytab_ni;
   if (max_rel_dev) *max_rel_dev = b->ytab_ok || b->ytab_wanted() ? std::max(b->ytab_err_rel, b->ytab_ymax > 0.0 ? b->ytab_err_abs / b->ytab_ymax : 0.0) : 0.0;
   if (hmax_per_glacier)
-    for (int g = 0; g < b->G; ++g) hmax_per_glacier[g] = g < (int)b->ytab_hmax.size() && b->ytab_wanted() ? b->ytab_hmax[g] : 0.0;
+    for (int g = 0; g < b->G; ++g)
+      hmax_per_glacier[g] = !b->ytab_wanted() ? 0.0 : b->law_kind == ODINN_LAW_NN_U ? b->utab_hmax : g < (int)b->ytab_hmax.size() ? b->ytab_hmax[g] : 0.0;
+  if (n_intervals && b->law_kind == ODINN_LAW_NN_U) *n_intervals = b->utab_nh * b->utab_ns;
   return ODINN_OK;
 }
 

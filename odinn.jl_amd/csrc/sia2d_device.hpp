@@ -174,6 +174,12 @@ struct LawDev {  // passed by value to kernels
   const double* ytab;
   int* ytab_over;
   int ytab_ni;
+  // tabulated U law (LM_UTAB): ONE table for the batch (the law's inputs are both fields: Hbar and |grad S|) of utab_nh x utab_ns
+  // patches, 36 coefficients c[a][b] of u^a v^b each (utab_eval); patch (i, j) covers [i, i + 1) / ut_inv_h metres of Hbar and
+  // [j, j + 1) / ut_inv_s of |grad S|; overflow raises *ytab_over as well
+  const double* utab;
+  int utab_nh, utab_ns;
+  double ut_inv_h, ut_inv_s;
 };
 
 struct Pools {  // pooled device arrays (all glaciers concatenated)
@@ -657,8 +663,9 @@ __device__ __forceinline__ void mlp_grad_wave(const LawDev& L, double x0, double
 //   5: 2 -> 3 -> 1,            softplus + sigmoid      (test_mode light net, ML_utils.jl:26-29)
 //   7: the Y law of target :D_hybrid through a per-glacier TABLE of Y(Hbar) (its other input, the glacier's temperature, is a
 //      scalar: LawY's inputs are (T, Hbar), Laws.jl:240-273) -- structurally a closed-form law: no network in the kernel
-constexpr int LM_FAST = 0, LM_POW = 1, LM_NN = 2, LM_NN_DEF = 3, LM_NN_16 = 4, LM_NN_LIGHT = 5, LM_NN_WIDE = 6, LM_YTAB = 7;
-constexpr bool lm_is_nn(int lm) { return lm >= LM_NN && lm <= LM_NN_WIDE; }
+//   8: the U law of target :D through ONE bivariate table U(Hbar, |grad S|) for the batch -- same idea, two variables
+constexpr int LM_FAST = 0, LM_POW = 1, LM_NN = 2, LM_NN_DEF = 3, LM_NN_16 = 4, LM_NN_LIGHT = 5, LM_NN_WIDE = 6, LM_YTAB = 7, LM_UTAB = 8;
+constexpr bool lm_is_nn(int lm) { return lm >= LM_NN && lm <= LM_NN_WIDE; }  // (7, 8: tables -- structurally closed-form laws)
 // run-time architectures: LM_NN (every layer has <= 16 inputs) and LM_NN_WIDE (<= 32) -- kernels of their own, the 32-wide
 // evaluator holds 128 registers of activations and would set the register allocation of the common case
 constexpr bool lm_is_rt(int lm) { return lm == LM_NN || lm == LM_NN_WIDE; }
@@ -1019,9 +1026,75 @@ __device__ __forceinline__ double ytab_eval(const GDev& g, const LawDev& L, doub
   return ytab_eval_core<ADJ>(L.ytab + g.yt_off, L.ytab_ni, L.ytab_over, g.yt_inv_h, Hb, Yp);
 }
 
+// ---- tabulated U law (LM_UTAB) -------------------------------------------------------------------------------------------
+// LawU's inputs are Hbar and |grad S| (Laws.jl:97-183): a function of two variables, the same for every glacier of the batch.
+// k_utab_build evaluates the network on the 6 x 6 tensor grid of Chebyshev nodes of each patch of [0, Hmax] x [0, Smax] and stores
+// the interpolating bi-quintic as monomial coefficients c[a][b] of u^a v^b, u = 2 (Hbar / h_H - i) - 1, v = 2 (|grad S| / h_S - j) - 1
+// (288 bytes per patch); table against network between the nodes decides whether the kernels may use it, as for the Y law.
+// The reference's central differences (U at Hbar +- 1e-4 and at |grad S| +- 1e-6, target_D_pure.jl:105-137) are taken on the SAME
+// patch: the bi-quintic is collapsed to a quintic in u at the node's v (and to one in v at the node's u), whose values at u +- du
+// come from the exact finite Taylor shift -- the quotients carry the reference's truncation error, not the cancellation noise of
+// separate evaluations.  up[0..3] = U(H + dH, s), U(H - dH, s), U(H, s + dS), U(H, s - dS).
+__device__ __forceinline__ void quintic_shift(const double (&q)[6], double x, double dx, double& val, double& plus, double& minus) {
+  val = fma(fma(fma(fma(fma(q[5], x, q[4]), x, q[3]), x, q[2]), x, q[1]), x, q[0]);
+  const double p1 = fma(fma(fma(fma(5.0 * q[5], x, 4.0 * q[4]), x, 3.0 * q[3]), x, 2.0 * q[2]), x, q[1]);
+  const double p2 = fma(fma(fma(10.0 * q[5], x, 6.0 * q[4]), x, 3.0 * q[3]), x, q[2]);
+  const double p3 = fma(fma(10.0 * q[5], x, 4.0 * q[4]), x, q[3]);
+  const double p4 = fma(5.0 * q[5], x, q[4]);
+  const double d2 = dx * dx;
+  const double ev = d2 * fma(d2, p4, p2);                     // even part of p(x + dx) - p(x)
+  const double od = dx * fma(d2, fma(d2, q[5], p3), p1);      // odd part
+  plus = val + (ev + od);
+  minus = val + (ev - od);
+}
+template <bool ADJ>
+__device__ __forceinline__ double utab_eval(const LawDev& L, double Hb, double gS, double (&up)[4]) {
+  double xh = Hb * L.ut_inv_h, xs = gS * L.ut_inv_s;
+  if (!(xh < (double)L.utab_nh)) { xh = (double)L.utab_nh; *L.ytab_over = 1; }  // beyond the table (or NaN): its edge value
+  if (!(xs < (double)L.utab_ns)) { xs = (double)L.utab_ns; *L.ytab_over = 1; }
+  const int ih = min((int)xh, L.utab_nh - 1), is = min((int)xs, L.utab_ns - 1);
+  const double u = fma(2.0, xh - (double)ih, -1.0), v = fma(2.0, xs - (double)is, -1.0);
+  const double2* __restrict__ c = reinterpret_cast<const double2*>(L.utab) + 18 * ((long long)ih * L.utab_ns + is);
+  double cc[6][6];  // cc[a][b]
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const double2 c0 = c[3 * a], c1 = c[3 * a + 1], c2 = c[3 * a + 2];
+    cc[a][0] = c0.x; cc[a][1] = c0.y; cc[a][2] = c1.x; cc[a][3] = c1.y; cc[a][4] = c2.x; cc[a][5] = c2.y;
+  }
+  double qu[6];  // the quintic in u at the node's v
+#pragma unroll
+  for (int a = 0; a < 6; ++a) qu[a] = fma(fma(fma(fma(fma(cc[a][5], v, cc[a][4]), v, cc[a][3]), v, cc[a][2]), v, cc[a][1]), v, cc[a][0]);
+  if (!ADJ) return fma(fma(fma(fma(fma(qu[5], u, qu[4]), u, qu[3]), u, qu[2]), u, qu[1]), u, qu[0]);
+  double qv[6];  // the quintic in v at the node's u
+#pragma unroll
+  for (int b = 0; b < 6; ++b) qv[b] = fma(fma(fma(fma(fma(cc[5][b], u, cc[4][b]), u, cc[3][b]), u, cc[2][b]), u, cc[1][b]), u, cc[0][b]);
+  double U, U2;
+  quintic_shift(qu, u, 2.0 * (1e-4 * L.ut_inv_h), U, up[0], up[1]);
+  quintic_shift(qv, v, 2.0 * (1e-6 * L.ut_inv_s), U2, up[2], up[3]);
+  return U;
+}
+
 template <bool ADJ, int LM, int NK = 0>
 __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double Hb, double gS2, double Anode,
                                          double& alpha, double& beta, double& spat) {
+  if constexpr (LM == LM_UTAB) {  // the U law's branch below with U and its four finite-difference points from the table
+    if (!(Hb > 0.0)) {
+      if (ADJ) { alpha = 0.0; beta = 0.0; spat = 0.0; }
+      return 0.0;
+    }
+    const double gS = sqrt(gS2);
+    double up[4];
+    const double U = utab_eval<ADJ>(L, Hb, gS, up);
+    if (ADJ) {
+      const double dH = 1e-4, dS = 1e-6;  // target_D_pure.jl:109,125
+      const double Dp = up[0] * (Hb + dH), Dm = up[1] * (Hb - dH);
+      alpha = (Dp - Dm) / (2.0 * dH);
+      const double Ep = up[2] * Hb, Em = up[3] * Hb;
+      beta = (Ep - Em) / (2.0 * dS);
+      spat = Hb;
+    }
+    return Hb * U;
+  }
   if constexpr (LM == LM_YTAB) {  // the Y law's closed form below with Y (and Y at Hbar + 1e-4) from the table
     double Yp = 0.0;
     const double Y = ytab_eval<ADJ>(g, L, Hb, Yp);
@@ -2859,6 +2932,60 @@ __global__ void k_sum_slots(long long n, int nslots, const double* __restrict__ 
   double s = out[i];
   for (int q = 0; q < nslots; ++q) s += slots[(long long)q * n + i];
   out[i] = s;
+}
+
+// ---- table of the U law (LM_UTAB, utab_eval): one thread per patch; stat as in k_ytab_build --------------------------------------
+__global__ __launch_bounds__(64) void k_utab_build(LawDev L, YtabVinv V, double* __restrict__ tab, int nh, int ns, double floor_abs,
+                                                   unsigned long long* __restrict__ stat) {
+  const long long pidx = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (pidx >= (long long)nh * ns) return;
+  const int ih = (int)(pidx / ns), is = (int)(pidx - (long long)ih * ns);
+  const double hh = 1.0 / L.ut_inv_h, hs = 1.0 / L.ut_inv_s;
+  double c[6][6];  // first F[j][k], then c[a][k] = sum_j V[a][j] F[j][k], then c[a][b] = sum_k c[a][k] V[b][k]
+  for (int j = 0; j < 6; ++j)
+    for (int k = 0; k < 6; ++k)
+      c[j][k] = mlp_eval_any(L, ((double)ih + 0.5 + 0.5 * V.node[j]) * hh, ((double)is + 0.5 + 0.5 * V.node[k]) * hs);
+  for (int k = 0; k < 6; ++k) {
+    double t[6];
+    for (int a = 0; a < 6; ++a) {
+      double acc = 0.0;
+      for (int j = 0; j < 6; ++j) acc = fma(V.v[a][j], c[j][k], acc);
+      t[a] = acc;
+    }
+    for (int a = 0; a < 6; ++a) c[a][k] = t[a];
+  }
+  for (int a = 0; a < 6; ++a) {
+    double t[6];
+    for (int b = 0; b < 6; ++b) {
+      double acc = 0.0;
+      for (int k = 0; k < 6; ++k) acc = fma(V.v[b][k], c[a][k], acc);
+      t[b] = acc;
+    }
+    for (int b = 0; b < 6; ++b) c[a][b] = t[b];
+  }
+  double* __restrict__ o = tab + 36 * pidx;
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 6; ++b) o[6 * a + b] = c[a][b];
+  const double chk[4] = {-0.97, -0.31, 0.23, 0.96};
+  double erel = 0.0, eabs = 0.0, ymax = 0.0;
+  for (int j = 0; j < 4; ++j)
+    for (int k = 0; k < 4; ++k) {
+      const double u = chk[j], v = chk[(k + j) & 3];
+      const double y = mlp_eval_any(L, ((double)ih + 0.5 + 0.5 * u) * hh, ((double)is + 0.5 + 0.5 * v) * hs);
+      double p = 0.0;
+      for (int a = 5; a >= 0; --a) {
+        const double qa = fma(fma(fma(fma(fma(c[a][5], v, c[a][4]), v, c[a][3]), v, c[a][2]), v, c[a][1]), v, c[a][0]);
+        p = fma(p, u, qa);
+      }
+      const double e = fabs(p - y), ay = fabs(y);
+      if (!(e == e)) erel = 1e300;
+      if (ay >= floor_abs) erel = fmax(erel, e / ay);
+      else eabs = fmax(eabs, e);
+      ymax = fmax(ymax, ay);
+    }
+  atomicMax(&stat[0], (unsigned long long)__double_as_longlong(erel));
+  atomicMax(&stat[1], (unsigned long long)__double_as_longlong(eabs));
+  atomicMax(&stat[2], (unsigned long long)__double_as_longlong(ymax));
 }
 
 // ---- misc elementwise over pooled arrays ---------------------------------------------

@@ -1,0 +1,99 @@
+"""GPU: the tabulated U law (law mode LM_UTAB): LawU's inputs are Hbar and |grad S| (Laws.jl:97-183) -- one bivariate function for
+the whole batch, read by the stencil kernels of the solve and of both adjoints from 128 x 64 bi-quintic patches built from the
+network (and checked against it to 1e-12) unless odinn_schedule.law_table = 0.  Same contract as the Y law's table
+(test_gpu_law_table.py): table == network to 1e-11 (states) / 1e-7 (gradients: central differences with 1e-4 and 1e-6 amplify any
+difference in U), oracle tolerances of the network path, overflow repeats the solve, the seams keep the network."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2, stats_err_arrays
+from oracle import sia2d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _no_overrides(monkeypatch):
+    monkeypatch.delenv("ODINN_LAW_TABLE", raising=False)
+
+
+def _batch(gpu, arch="default", shapes=((56, 40), (70, 57))):
+    from test_gpu_parity import _mlp_pair
+
+    widths, acts = {"light": ([2, 3, 1], [1, 2]), "default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "runtime": ([2, 5, 10, 5, 1], [3, 3, 3, 1])}[arch]
+    om, gm, th = _mlp_pair(gpu, widths, acts, [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+    b = gpu.GlacierBatch(list(shapes), [50.0] * len(shapes))
+    fields = []
+    for g, (nx, ny) in enumerate(shapes):
+        H0, B = O.synthetic_alpine(nx, ny, hmax=150.0 + 30.0 * g, slope=0.1)
+        b.set_fields(g, H0, B)
+        fields.append((H0, B))
+    b.set_law(gpu.LAW_NN_U, gm, th)
+    return b, om, th, fields
+
+
+@pytest.mark.parametrize("arch", ["light", "default", "runtime"])
+def test_table_reproduces_the_network(gpu, arch):
+    b, om, th, fields = _batch(gpu, arch)
+    ts = [2010.0 + j / 24.0 for j in range(4)]
+    b.set_schedule(law_table=0)
+    assert not b.law_table()["usable"]
+    b.solve(ts, reltol=1e-8)
+    Hn = [b.snapshot(g, 3) for g in range(2)]
+    for g in range(2):
+        b.set_reference(g, ts, [fields[g][0] * (1.0 - 0.01 * j) for j in range(4)], 3)
+    Ln, gn = b.loss_grad(ts, theta=th, reltol=1e-8)
+    Lc, gc = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+    b.set_schedule()
+    info = b.law_table()
+    assert info["usable"] and info["max_rel_dev"] < 1e-12 and info["n_intervals"] == 128 * 64, info
+    b.solve(ts, reltol=1e-8)
+    for g in range(2):
+        assert rel_l2(b.snapshot(g, 3), Hn[g]) < 1e-11
+    Lt, gt = b.loss_grad(ts, theta=th, reltol=1e-8)
+    assert abs(Lt - Ln) <= 1e-10 * abs(Ln) and rel_l2(gt, gn) < 1e-7, (Lt, Ln, rel_l2(gt, gn))
+    Ltc, gtc = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+    assert abs(Ltc - Lc) <= 1e-10 * abs(Lc) and rel_l2(gtc, gc) < 1e-6, (Ltc, Lc, rel_l2(gtc, gc))
+    lam = np.random.default_rng(5).standard_normal(fields[0][0].shape)
+    v1, d1 = b.vjp_H(0, lam, fields[0][0]), b.dhdt(0, fields[0][0])
+    b.set_schedule(law_table=0)
+    assert np.array_equal(b.vjp_H(0, lam, fields[0][0]), v1) and np.array_equal(b.dhdt(0, fields[0][0]), d1)  # seams: the network
+    b.close()
+
+
+def test_table_path_against_the_oracle(gpu):
+    b, om, th, fields = _batch(gpu, "default", ((56, 40),))
+    H0, B = fields[0]
+    ph = O.Phys()
+    ts = [2010.0 + j / 48.0 for j in range(4)]
+    gl = O.Glacier(H0, B, 50.0, 50.0, ph)
+    law = O.Law(kind=O.LAW_NN_U, mlp=om, theta=th)
+    cfg = O.SimConfig(tstops=ts, reltol=1e-8)
+    ref, _, _ = O.forward(gl, law, cfg)
+    assert b.law_table()["usable"]
+    b.solve(ts, reltol=1e-8)
+    assert rel_l2(b.snapshot(0, 3), ref[3]) < 1e-6
+    ref = [r * (1.0 + 0.02 * j) for j, r in enumerate(ref)]
+    b.set_reference(0, ts, ref, 3)
+    Lo, go, lam0, _ = O.loss_and_grad_continuous(gl, law, cfg, ref, ts, O.ContinuousAdjointCfg(n_quadrature=8))
+    Lg, gg = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+    assert abs(Lg - Lo) <= 1e-6 * abs(Lo)
+    ratio, angle, relerr = stats_err_arrays(gg, go)
+    assert abs(ratio) < 2e-4 and relerr < 2e-4, (ratio, angle, relerr)
+    assert rel_l2(b.lambda0(0), lam0) < 2e-4
+    b.close()
+
+
+def test_overflow_widens_the_table(gpu, monkeypatch):
+    monkeypatch.setenv("ODINN_LAW_TABLE_HMAX", "60")  # ice up to 180 m: 60 -> 120 -> 240
+    b, om, th, fields = _batch(gpu, "default")
+    ts = [2010.0 + j / 24.0 for j in range(3)]
+    b.set_schedule(law_table=0)
+    b.solve(ts, reltol=1e-8)
+    Hn = b.snapshot(1, 2)
+    b.set_schedule()
+    assert b.law_table()["hmax"][0] == 60.0
+    b.solve(ts, reltol=1e-8)
+    assert b.law_table()["hmax"][0] == 240.0 and b.law_table()["usable"]
+    assert rel_l2(b.snapshot(1, 2), Hn) < 1e-11
+    b.close()

@@ -3,6 +3,7 @@
   python tools/workflow_probe.py mb [n G]         scalar NN law + linear mass balance at every stop, LossH
   python tools/workflow_probe.py Y [n G]          Y = NN(T, Hbar) (target :D_hybrid, default :Linear interpolation), LossH
   python tools/workflow_probe.py U [n G]          U = NN(Hbar, |grad S|) (target :D), LossH
+  python tools/workflow_probe.py U n G scaled      LawU with prescale_bounds = [(0, 300), (0, 0.5)], max_NN = 50 (the table can follow it)
   python tools/workflow_probe.py Y|U n G custom   the same with a run-time architecture (2-5-10-5-1, gelu x3 + softplus: law mode 2)"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +38,10 @@ elif what == "mb":
         S = B + H0
         b.set_mass_balance(j, np.full_like(H0, -0.05), 1e-4, np.full_like(H0, float(S.mean())), 0.2)
 else:
-    model = odinn.SIA2Dmodel(P, **{what: (odinn.LawY if what == "Y" else odinn.LawU)(odinn.NeuralNetwork(P, architecture=odinn.build_default_NN(2), seed=666), P)})
+    kwU = {}
+    if what == "U" and len(sys.argv) > 4 and sys.argv[4] == "scaled":  # LawU as the reference's tests build it (test/SIA2D_adjoint.jl): inputs scaled, U <= 50 m/yr
+        kwU = dict(prescale_bounds=[(0.0, 300.0), (0.0, 0.5)], max_NN=50.0)
+    model = odinn.SIA2Dmodel(P, **{what: (odinn.LawY if what == "Y" else odinn.LawU)(odinn.NeuralNetwork(P, architecture=odinn.build_default_NN(2), seed=666), P, **kwU)})
     law = model.law
     theta = law.nn.theta
     mlp = law.mlp
