@@ -661,6 +661,27 @@ def main():
             except Exception as e:
                 radj["Y_table"] = {"error": str(e)[:200]}
                 b.set_schedule()
+            # ... and the U law through the batch's bivariate table (LM_UTAB): 18 x 16 B of coefficients per dual node from a 2.4 MB table
+            try:
+                mdefU = odinn.MLPSpec([2, 3, 10, 3, 1], [odinn.ACT_SOFTPLUS] * 3 + [odinn.ACT_SIGMOID], [(0.0, 300.0), (0.0, 0.5)],
+                                      odinn.POST_EXPMAX, 0.0, 50.0)
+                b.set_law(odinn.LAW_NN_U, mdefU, np.random.default_rng(1234).uniform(-0.5, 0.5, mdefU.n_params))
+                b.set_schedule(law_table=1)
+                ms_au, ms_fu = ev(T.TIMED_ADJ_STAGE2, 10, 2), ev(T.TIMED_RK_STAGE2, 10, 2)
+                info_ = b.law_table()
+                b.set_schedule()
+                radj["U_table"] = {
+                    "adj_stage_ms": ms_au, "fwd_stage_ms": ms_fu, "bound": "hbm / L2 gather", "table_usable": info_["usable"],
+                    "table_max_rel_dev_from_network": info_["max_rel_dev"],
+                    "adj_bytes_per_cell": 72, "adj_achieved_GBps": 72.0 * cells / (ms_au * 1e-3) / 1e9,
+                    "adj_frac": 72.0 * cells / (ms_au * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "fwd_bytes_per_cell": 56, "fwd_achieved_GBps": 56.0 * cells / (ms_fu * 1e-3) / 1e9,
+                    "fwd_frac": 56.0 * cells / (ms_fu * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "kernel": "k_adj_stage<2, LM_UTAB> / k_rk_stage<2, LM_UTAB>: U(Hbar, |grad S|) from 128 x 64 bi-quintic patches (288 B per dual "
+                              "node gathered from the L2-resident table, not counted in the algorithmic bytes)"}
+            except Exception as e:
+                radj["U_table"] = {"error": str(e)[:200]}
+                b.set_schedule()
             aux["roofline_adjoint_nn"] = {
                 "bound": "fp64-valu", "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "kernel": "k_adj_stage<2, LM 3, DiscreteVJP, NK> (one RDPK3Sp35 stage of the reverse ODE, 2-3-10-3-1 network inlined per dual "

@@ -168,11 +168,13 @@ typedef struct odinn_schedule {
   int32_t adj_rows;        /* ODINN_ADJ_ROWS: 4 | 7 | 8 rows per thread of the fused reverse step (8: gridded A only, else ignored) */
   int32_t adj_theta_fused; /* ODINN_ADJ_THETA_FUSED: 0 = theta-VJP of a quadrature node in launches of its own                     */
   int32_t law_table;       /* ODINN_LAW_TABLE: 0 = the stencil kernels of a batch with the Y law (ODINN_LAW_NN_Y: inputs = the
-                              glacier's scalar temperature and Hbar) evaluate the network at every dual node and stage.  Default
-                              (-1 / 1): inside the forward solve and both adjoints they read Y(Hbar) from a per-glacier table of
-                              quintics (1024 intervals; rebuilt from the network whenever theta changes, used only while its
-                              measured deviation from the network is < 1e-12 relative -- else the network; a solve that leaves the
-                              table's range is repeated with a wider one).  The seam calls always evaluate the network           */
+                              glacier's scalar temperature and Hbar) or the U law (ODINN_LAW_NN_U: inputs = Hbar and |grad S|)
+                              evaluate the network at every dual node and stage.  Default (-1 / 1): inside the forward solve and
+                              both adjoints they read the law from a table -- Y(Hbar) per glacier in 1024 quintics, U(Hbar, |grad S|)
+                              for the batch in 128 x 64 bi-quintic patches -- rebuilt from the network whenever theta changes, used
+                              only while its measured deviation from the network is < 1e-12 relative (else the network); a solve
+                              that leaves the table's range is repeated with a wider one.  The seam calls always evaluate the
+                              network                                                                                              */
   int32_t interp_async;    /* ODINN_INTERP_ASYNC: 0 = the Y law's `:Linear` contraction of a stop (sort, knots, interval sums, knot
                               backprop) on the batch's own stream; n = 1 ... 4: overlapped with the following reverse steps of both
                               adjoints on n lane streams (default: 3 in the DiscreteAdjoint, 1 or 4 in the ContinuousAdjoint; results
