@@ -1937,6 +1937,8 @@ int odinn_set_law(odinn_batch* b, int kind, const odinn_mlp_desc* mlp, const dou
   b->law_kind = kind;
   b->mlp = *mlp;
   b->P = P;
+  b->ytab_blocked = false;  // (a new law: its table gets its chance)
+  b->utab_hmax = 0.0;
   b->nH = n_H; b->nS = n_gradS;
   // the reference's defaults: SIA2D_D_hybrid_target(interpolation = :Linear, n_interp_half = 75) (target_D_hybrid.jl:12-15),
   // SIA2D_D_target(interpolation = :None) (target_D_pure.jl:34-39); A-type laws have no spatial law gradient

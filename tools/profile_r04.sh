@@ -14,7 +14,7 @@ head -8 $O/bench_kernel_stats.csv
 rm -rf $O/profg; rocprofv3 --kernel-trace --stats --output-format csv -d $O/profg -- python $R/bench.py --steps 40 --no-cpu-baseline --no-hbm-sweep --no-weak > $O/grad_under_rocprof.json 2> $O/profg.err
 find $O/profg -name "*kernel_stats.csv" -exec cp {} $O/grad_kernel_stats.csv \;
 rm -rf $O/profg
-( for w in "Y 512 8" "NET Y 512 8" "U 512 8"; do
+( for w in "Y 512 8" "NET Y 512 8" "U 512 8 scaled" "NET U 512 8 scaled" "U 512 8"; do
     rm -rf $O/profw
     e=""; if [ "${w%% *}" = NET ]; then e="ODINN_LAW_TABLE=0 ODINN_INTERP_ASYNC=0"; w=${w#NET }; fi  # (the Y law without its table and without the overlap)
     env $e rocprofv3 --kernel-trace --stats --output-format csv -d $O/profw -- python $R/tools/workflow_probe.py $w > $O/probe.txt 2>&1
