@@ -2145,9 +2145,14 @@ static int interp_async_lanes(odinn_batch* b, bool useV, int lanes_default) {
   if (sched_val(b->sched.interp_batch, "ODINN_INTERP_BATCH") == 0) return 0;
   if (!b->d_ib_gid || interp_batch_lds_bytes(b->P) > 30 * 1024) return 0;
   int lanes = e < 0 ? lanes_default : std::min(e, (int)odinn_batch::IA_LANES_MAX);
-  // a lane's arrays: ~72 B per dual node + the sort's scratch; keep the extra lanes below 8 GB
+  // a lane's arrays: ~72 B per dual node + the sort's scratch (4.9 GB at 64 x 1024^2); the lanes not yet allocated must fit into a
+  // quarter of what is free of the 288 GB
   const double per_lane = 72.0 * (double)b->ntotd + (double)b->ib_tmp_bytes;
-  while (lanes > 1 && per_lane * (lanes - 1) > 8e9) --lanes;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  int have = 1;
+  for (int l = 1; l < (int)odinn_batch::IA_LANES_MAX; ++l) have += b->ia_lane[l].sH ? 1 : 0;
+  while (lanes > have && per_lane * (lanes - have) > 0.25 * (double)free_b) --lanes;
   return lanes;
 }
 static int interp_async_setup(odinn_batch* b, int lanes) {
