@@ -3195,7 +3195,7 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
   // selects the five k_adj_stage launches
   // (round 4: also the Y law through its table where that is the integer-power law with Y(Hbar) in A's place -- n_H = n_gradS = 3,
   //  no sliding, GDev::yt_fast on every glacier; its theta-integrand stays with theta_vjp_launch)
-  bool ytab_rev = b->lm_kern() == LM_YTAB;
+  bool ytab_rev = b->lm_kern() == LM_YTAB && b->ytab_ni == 1024;  // (the kernel's LDS copy of the table is laid out for that size)
   for (const GDev& r : b->gd) ytab_rev = ytab_rev && r.yt_fast;
   bool fused_rev = (lm == 0 || ytab_rev) && b->vjp_method == ODINN_VJP_DISCRETE;
   fused_rev = fused_rev && sched_val(b->sched.adj_fused, "ODINN_ADJ_FUSED") != 0;

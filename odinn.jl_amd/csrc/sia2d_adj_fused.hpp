@@ -283,9 +283,19 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
 // GA (gridded A with a dual-grid accumulator): stage 1 of the step that follows a quadrature node also adds the node
 // weights into A.Gacc (needs A.th_part)
 constexpr bool adj_rc(bool AF, bool SG, int NR) { return ODINN_ADJ_RC && (AF || ODINN_ADJ_RC > 1) && SG && NR > 4; }
-#ifndef ODINN_ADJ_YT_WPE
-#define ODINN_ADJ_YT_WPE ODINN_FWPE
+// The YT instantiation (Y law through its table) reads the glacier's table from global memory (L1 / L2-resident; two workgroups per
+// CU, ~30 spilled registers at 128).  Measured against it and not adopted: -DODINN_ADJ_YT_LDS=1, the table in LDS (1024 intervals x
+// 48 B = 48 KB next to the kernel's 76 KB, i.e. one workgroup per CU and 256 registers, three ds_read_b128 per node instead of three
+// dependent L2 gathers) -- 174 -> 165 us per launch beside the contraction lanes at 8 x 512^2, 120.9 vs 121.2 ms per continuous
+// gradient, 10.66 vs 10.68 gradient evaluations per second at 64 x 1024^2: the gathers are not what this kernel waits for;
+// -DODINN_ADJ_YT_WPE=2 alone (256 registers, no spills): the same kernel time.
+#ifndef ODINN_ADJ_YT_LDS
+#define ODINN_ADJ_YT_LDS 0
 #endif
+#ifndef ODINN_ADJ_YT_WPE
+#define ODINN_ADJ_YT_WPE (ODINN_ADJ_YT_LDS ? 2 : ODINN_FWPE)
+#endif
+constexpr int YT_LDS_NI = 1024;  // the table size the LDS copy is laid out for (odinn_batch::ytab_ni)
 template <bool AF, bool SKIP, bool SG = false, int NR = TRPT, bool GA = false, bool YT = false>
 __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_WPE : ODINN_FWPE))) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
   static_assert(!YT || (!AF && !GA), "the table's instantiation replaces the scalar A");
@@ -428,12 +438,18 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
       }
     }
   }
+  constexpr bool YTL = YT && ODINN_ADJ_YT_LDS;
+  __shared__ double2 sYt[YTL ? 3 * YT_LDS_NI : 1];
+  if constexpr (YTL) {  // (the barrier below publishes it)
+    const double2* __restrict__ tg = reinterpret_cast<const double2*>(A.ytab + g.yt_off);
+    for (int k = threadIdx.x; k < 3 * YT_LDS_NI; k += TNT) sYt[k] = tg[k];
+  }
   __syncthreads();
   __shared__ double th_red[TNW];
   // theta-VJP of the quadrature node the previous step reached (a.qw: its Gauss-Legendre weight, 0 otherwise; the controller
   // resets it at every call, so a repeated attempt after a rejection does not count the node twice)
   double* const thr = (A.th_part && a.qw != 0.0) ? th_red : nullptr;
-  const YtabRef yt{YT ? A.ytab + g.yt_off : nullptr, A.ytab_over, A.ytab_ni};
+  const YtabRef yt{YTL ? reinterpret_cast<const double*>(sYt) : (YT ? A.ytab + g.yt_off : nullptr), A.ytab_over, A.ytab_ni};
   adj_strip_stage<1, AF, SG, NR, GA, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr,
                                              GA ? A.Gacc + g.offd : nullptr, &rc, yt);
   if (thr && threadIdx.x == 0) {  // the tile's running sum, reduced per glacier once after the reverse solve
