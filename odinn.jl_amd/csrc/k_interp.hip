@@ -456,6 +456,125 @@ int launch_interp_theta_batch(hipStream_t st, Pools P, const LawDev& L, int n_ha
   return 0;
 }
 
+// ---- the same over the ACTIVE nodes only ------------------------------------------------------------------------------------------
+// Inside one gradient evaluation every H the contraction sees is a snapshot of the forward solve or a convex combination of two
+// of them, so a dual node none of whose four cells carries ice in ANY snapshot has Hbar = 0 and weight 0 at every stop: it is neither
+// among the quantiles (strictly inside (0, max)) nor in an interval sum.  launch_interp_active builds the list of the other nodes
+// once per gradient (flags from the snapshot store, a stable rocprim::select, the glaciers' offsets in the list); the per-stop
+// sequence then sorts, gathers and sums n_act entries instead of all dual nodes -- half of them for an ice cap on its square grid,
+// a quarter for an alpine glacier.  Same keys, same stable sort: the active nodes come out in the order they have in the full sort.
+__global__ void k_active_flags(Pools P, const unsigned* __restrict__ gid, const double* __restrict__ snaps, int nslots, long long ntot,
+                               long long ntotd, unsigned char* __restrict__ flags) {
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < ntotd; q += (long long)gridDim.x * blockDim.x) {
+    const GDev& g = P.gd[gid[q]];
+    const long long li = q - g.offd;
+    const int a = (int)(li % (g.nx - 1)), b = (int)(li / (g.nx - 1));
+    unsigned char f = 0;
+    if (b <= g.ny - 2) {
+      const long long c0 = g.off + a + (long long)g.nx * b;
+      for (int s = 0; s < nslots && !f; ++s) {
+        const double* __restrict__ H = snaps + (long long)s * ntot;
+        f = (H[c0] > 0.0 || H[c0 + 1] > 0.0 || H[c0 + g.nx] > 0.0 || H[c0 + g.nx + 1] > 0.0) ? 1 : 0;
+      }
+    }
+    flags[q] = f;
+  }
+}
+__global__ void k_active_offsets(Pools P, int G, const unsigned* __restrict__ act, const unsigned* __restrict__ n_act_p,
+                                 long long* __restrict__ aoff) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > G) return;
+  const long long n = (long long)*n_act_p;
+  if (g == G) { aoff[G] = n; return; }
+  const long long target = P.gd[g].offd;  // first active entry with node index >= offd_g
+  long long lo = 0, hi = n;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if ((long long)act[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  aoff[g] = lo;
+}
+__global__ void k_gather_gid_n(const unsigned* __restrict__ gid, const unsigned* __restrict__ idx, const unsigned* __restrict__ n_p,
+                               unsigned* __restrict__ out) {
+  const long long n = (long long)*n_p;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = gid[idx[i]];
+}
+size_t interp_active_temp_bytes(long long n) {
+  size_t bytes = 0;
+  (void)rocprim::select(nullptr, bytes, (const unsigned*)nullptr, (const unsigned char*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
+                        (size_t)n, (hipStream_t) nullptr, false);
+  return bytes;
+}
+// act[0 .. *n_act) = the active dual nodes in ascending order, gid_act their glaciers, aoff[0 .. G] the glaciers' offsets in act
+int launch_interp_active(hipStream_t st, Pools P, int G, long long ntotd, const unsigned* gid, const unsigned* iota, const double* snaps,
+                         int nslots, long long ntot, unsigned char* flags, void* tmp, size_t tmp_bytes, unsigned* act, unsigned* gid_act,
+                         long long* aoff, unsigned* n_act_dev) {
+  const unsigned nb = (unsigned)std::min<long long>((ntotd + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_active_flags, dim3(nb), dim3(256), 0, st, P, gid, snaps, nslots, ntot, ntotd, flags);
+  if (rocprim::select(tmp, tmp_bytes, iota, flags, act, n_act_dev, (size_t)ntotd, st, false) != hipSuccess) return 2;
+  hipLaunchKernelGGL(k_active_offsets, dim3((G + 1 + 63) / 64), dim3(64), 0, st, P, G, act, n_act_dev, aoff);
+  hipLaunchKernelGGL(k_gather_gid_n, dim3(nb), dim3(256), 0, st, gid, act, n_act_dev, gid_act);
+  return 0;
+}
+__global__ void k_interp_keys_act(const unsigned* __restrict__ gid_act, const unsigned* __restrict__ act, const double* __restrict__ H,
+                                  long long n, int gbits, double scale, unsigned long long* __restrict__ keys) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double h = fmin(fmax(H[act[i]], 0.0), 32767.0);
+    unsigned long long low = (unsigned long long)__double_as_longlong(h * scale);
+    if (h > 0.0 && !low) low = 1;
+    keys[i] = gbits ? (((unsigned long long)gid_act[i] << (64 - gbits)) | low) : low;
+  }
+}
+__global__ void k_gather_HV_act(const double* __restrict__ H, const double* __restrict__ V, const unsigned* __restrict__ act,
+                                const unsigned* __restrict__ idx, long long n, double* __restrict__ sH, double* __restrict__ sV) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned j = act[idx[i]];
+    sH[i] = H[j];
+    sV[i] = V[j];
+  }
+}
+__global__ __launch_bounds__(KMAX) void k_knots_a(const long long* __restrict__ aoff, const double* __restrict__ sHall, int n,
+                                                  double* __restrict__ knots_all, int* __restrict__ M_all) {
+  __shared__ double c[KMAX];
+  __shared__ int first[KMAX];
+  knots_body(sHall + aoff[blockIdx.x], aoff[blockIdx.x + 1] - aoff[blockIdx.x], n, knots_all + (size_t)blockIdx.x * KMAX, M_all + blockIdx.x,
+             c, first);
+}
+__global__ __launch_bounds__(NT) void k_interval_sums_a(const long long* __restrict__ aoff, const double* __restrict__ sHall,
+                                                        const double* __restrict__ sVall, const double* __restrict__ knots_all,
+                                                        const int* __restrict__ M_all, double* __restrict__ ab_all) {
+  __shared__ double red[NW];
+  const long long off = aoff[blockIdx.y];
+  interval_sums_body(sHall + off, sVall + off, aoff[blockIdx.y + 1] - off, knots_all + (size_t)blockIdx.y * KMAX, M_all + blockIdx.y,
+                     ab_all + (size_t)blockIdx.y * 2 * KMAX, red);
+}
+// all G glaciers of the batch; n_act entries (host copy of *n_act_dev); iota holds 0, 1, 2, ...
+int launch_interp_theta_active(hipStream_t st, Pools P, const LawDev& L, int n_half, int G, long long n_act, const double* nodeH,
+                               const double* nodeV, const unsigned* act, const unsigned* gid_act, const long long* aoff,
+                               const unsigned* iota, double* sH, double* sV, unsigned* iA, void* tmp, size_t tmp_bytes, double* knots, int* M,
+                               double* ab, double* dth, int accumulate) {
+  int bits = 0;
+  while ((1ll << bits) < (long long)G) ++bits;
+  if (2 * n_half > KMAX || n_half < 2 || n_act < 1 || n_act >= (1ll << 32) || bits > INTERP_KEY_GBITS_MAX) return 1;
+  const unsigned nb = (unsigned)std::min<long long>((n_act + 255) / 256, 4096);
+  unsigned long long* kin = reinterpret_cast<unsigned long long*>(sH);
+  unsigned long long* kout = reinterpret_cast<unsigned long long*>(sV);
+  const double scale = bits ? std::ldexp(1.0, -(1023 - (1 << (12 - bits)) + 15)) : 1.0;
+  hipLaunchKernelGGL(k_interp_keys_act, dim3(nb), dim3(256), 0, st, gid_act, act, nodeH, n_act, bits, scale, kin);
+  if (rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, iota, iA, (size_t)n_act, 0, 64, st) != hipSuccess) return 2;
+  hipLaunchKernelGGL(k_gather_HV_act, dim3(nb), dim3(256), 0, st, nodeH, nodeV, act, iA, n_act, sH, sV);
+  hipLaunchKernelGGL(k_knots_a, dim3(G), dim3(KMAX), 0, st, aoff, sH, n_half, knots, M);
+  hipLaunchKernelGGL(k_interval_sums_a, dim3(2 * n_half, G), dim3(NT), 0, st, aoff, sH, sV, knots, M, ab);
+  const size_t dyn = interp_batch_lds_bytes(L.P);
+  if (interp_law_is<ArchDef>(L))
+    hipLaunchKernelGGL((k_knot_backprop<ArchDef, true>), dim3(G), dim3(NT), dyn, st, P, L, 0, knots, M, ab, dth, accumulate);
+  else if (interp_law_is<Arch16>(L))
+    hipLaunchKernelGGL((k_knot_backprop<Arch16, true>), dim3(G), dim3(NT), dyn, st, P, L, 0, knots, M, ab, dth, accumulate);
+  else
+    hipLaunchKernelGGL((k_knot_backprop<ArchRT, false>), dim3(G), dim3(NT), dyn, st, P, L, 0, knots, M, ab, dth, accumulate);
+  return 0;
+}
+
 // ---- exact per-node backprop of emitted node weights (`interpolation = :None` in the surface-velocity pull-backs) -----------------
 // dth[g] (+)= sum over the dual nodes of glacier g of V[node] * d law / d theta at the node's inputs -- (T_g, Hbar) for the Y law,
 // (Hbar, |grad S|) for the U law -- with the node weights V and inputs emitted by the velocity kernels (k_surfV_vjp: emitH / emitV /

@@ -51,6 +51,14 @@ int launch_interp_theta_batch(hipStream_t st, Pools P, const LawDev& L, int n_ha
                               const double* nodeH, const double* nodeV, const unsigned* gid, const unsigned* iota, double* sH,
                               double* sV, unsigned* iA, unsigned* iB, unsigned* kA, unsigned* kB, void* tmp, size_t tmp_bytes,
                               double* knots, int* M, double* ab, double* dth, int accumulate);
+size_t interp_active_temp_bytes(long long n);
+int launch_interp_active(hipStream_t st, Pools P, int G, long long ntotd, const unsigned* gid, const unsigned* iota, const double* snaps,
+                         int nslots, long long ntot, unsigned char* flags, void* tmp, size_t tmp_bytes, unsigned* act, unsigned* gid_act,
+                         long long* aoff, unsigned* n_act_dev);
+int launch_interp_theta_active(hipStream_t st, Pools P, const LawDev& L, int n_half, int G, long long n_act, const double* nodeH,
+                               const double* nodeV, const unsigned* act, const unsigned* gid_act, const long long* aoff,
+                               const unsigned* iota, double* sH, double* sV, unsigned* iA, void* tmp, size_t tmp_bytes, double* knots, int* M,
+                               double* ab, double* dth, int accumulate);
 size_t interp_sort_temp_bytes(long long nd_max);
 int launch_interp_theta(hipStream_t st, const LawDev& L, double T, int n_half, const double* nodeH, const double* nodeV,
                         long long nd, double* sH, double* sV, void* tmp, size_t tmp_bytes, double* knots, int* M, double* G,

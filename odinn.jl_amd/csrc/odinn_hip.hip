@@ -358,6 +358,14 @@ struct odinn_batch {
   hipEvent_t ev_set_done[IA_SETS_MAX] = {};
   bool ia_set_pending[IA_SETS_MAX] = {};
   int ia_sets = 0;
+  // the dual nodes that carry ice in at least one snapshot of the current forward solve (launch_interp_active): the contractions of
+  // this gradient sort / gather / sum these only
+  unsigned char* ia_flags = nullptr;
+  unsigned *ia_act = nullptr, *ia_gid_act = nullptr, *ia_nact_dev = nullptr;
+  long long* ia_aoff = nullptr;
+  void* ia_sel_tmp = nullptr;
+  size_t ia_sel_bytes = 0;
+  long long ia_nact = 0;  // 0: the dense sequence
   bool interp_async = false;
   int ia_lanes = 0, ia_q = 0, ia_alloc = 0;
   bool ia_pending[IA_LANES_MAX] = {};
@@ -1788,6 +1796,8 @@ int odinn_batch_destroy(odinn_batch* b) {
       if (a.tmp) (void)hipFree(a.tmp);
     }
   }
+  dfree(b->ia_flags); dfree(b->ia_act); dfree(b->ia_gid_act); dfree(b->ia_nact_dev); dfree(b->ia_aoff);
+  if (b->ia_sel_tmp) (void)hipFree(b->ia_sel_tmp);
   for (int q_ = 0; q_ < odinn_batch::IA_SETS_MAX; ++q_) {
     if (q_ > 0) { dfree(b->ia_nodeH[q_]); dfree(b->ia_nodeV[q_]); }  // (set 0 aliases d_nodeH / d_nodeV)
     if (b->ev_set_done[q_]) (void)hipEventDestroy(b->ev_set_done[q_]);
@@ -2194,6 +2204,27 @@ static int interp_async_setup(odinn_batch* b, int lanes) {
   }
   b->ia_lanes = lanes;
   b->ia_q = 0;
+  // the active nodes of this gradient's snapshots (ODINN_INTERP_ACTIVE=0: the dense sequence over all dual nodes)
+  b->ia_nact = 0;
+  static const bool dense = std::getenv("ODINN_INTERP_ACTIVE") && std::getenv("ODINN_INTERP_ACTIVE")[0] == '0';
+  int gbits = 0;
+  while ((1ll << gbits) < (long long)b->G) ++gbits;
+  if (!dense && gbits <= 7 && b->solved) {
+    if (!b->ia_flags) {
+      CHK(dalloc(&b->ia_flags, N)); CHK(dalloc(&b->ia_act, N)); CHK(dalloc(&b->ia_gid_act, N)); CHK(dalloc(&b->ia_nact_dev, (size_t)1));
+      CHK(dalloc(&b->ia_aoff, (size_t)b->G + 1));
+      b->ia_sel_bytes = interp_active_temp_bytes(b->ntotd);
+      HIPCHK(hipMalloc(&b->ia_sel_tmp, std::max<size_t>(b->ia_sel_bytes, 256)));
+    }
+    if (launch_interp_active(b->stream, b->pools(false), b->G, b->ntotd, b->d_ib_gid, b->d_ib_iota, b->d_snaps, b->kmax + b->nhid, b->ntot,
+                             b->ia_flags, b->ia_sel_tmp, b->ia_sel_bytes, b->ia_act, b->ia_gid_act, b->ia_aoff, b->ia_nact_dev))
+      return fail(ODINN_ERR_HIP, "selection of the active dual nodes failed");
+    HIPCHK(hipGetLastError());
+    unsigned na = 0;
+    HIPCHK(hipMemcpyAsync(&na, b->ia_nact_dev, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->ia_nact = (long long)na;
+  }
   return ODINN_OK;
 }
 // the batch's stream waits for every contraction issued so far and adds their slots onto d_dth, in order
@@ -2227,7 +2258,11 @@ static int interp_async_contract(odinn_batch* b, const Pools& P) {
   const odinn_batch::IaLane& a = b->ia_lane[l];
   HIPCHK(hipEventRecord(b->ev_emit[l], b->stream));
   HIPCHK(hipStreamWaitEvent(b->ia_stream[l], b->ev_emit[l], 0));
-  const int rc = launch_interp_theta_batch(b->ia_stream[l], P, b->lawdev(), b->n_interp_half, 0, b->G, 0, b->ntotd, b->ia_nodeH[qs],
+  const int rc = b->ia_nact > 0
+                     ? launch_interp_theta_active(b->ia_stream[l], P, b->lawdev(), b->n_interp_half, b->G, b->ia_nact, b->ia_nodeH[qs],
+                                                  b->ia_nodeV[qs], b->ia_act, b->ia_gid_act, b->ia_aoff, b->d_ib_iota, a.sH, a.sV, a.iA, a.tmp,
+                                                  b->ib_tmp_bytes, a.knots, a.M, a.ab, b->d_dthq + (size_t)b->ia_q * b->G * b->P, 0)
+                     : launch_interp_theta_batch(b->ia_stream[l], P, b->lawdev(), b->n_interp_half, 0, b->G, 0, b->ntotd, b->ia_nodeH[qs],
                                            b->ia_nodeV[qs],
                                            b->d_ib_gid, b->d_ib_iota, a.sH, a.sV, a.iA, a.iB, a.kA, a.kB, a.tmp, b->ib_tmp_bytes, a.knots,
                                            a.M, a.ab, b->d_dthq + (size_t)b->ia_q * b->G * b->P, 0);

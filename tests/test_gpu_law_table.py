@@ -193,3 +193,28 @@ def test_fused_reverse_step_with_the_table_matches_the_staged_one(gpu):
     Ln, gn = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=16)
     assert rel_l2(gf, gn) < 1e-7
     b.close()
+
+
+def test_contraction_over_the_active_nodes_matches_the_dense_one(gpu):
+    """The overlapped `:Linear` contractions of a gradient sort / gather / sum only the dual nodes that carry ice in at least one
+    snapshot of its forward solve (launch_interp_active); the one-stream sequence (interp_async = 0) still runs over all dual
+    nodes.  Same keys, same stable sort, the dropped nodes have Hbar = 0 and weight 0 at every stop: gradients agree to the
+    rounding of the interval sums' block partition, in both adjoints, on a ragged batch with a glacier that is mostly ice-free."""
+    shapes, Ts = ((56, 40), (131, 64), (70, 57)), (-5.0, -11.0, -2.0)
+    b, om, th, fields, ph = _batch(gpu, "default", shapes, Ts)
+    H1, B1 = fields[1]
+    H1 = H1.copy(); H1[:, : H1.shape[1] // 2] = 0.0  # half of glacier 1 without ice
+    b.set_fields(1, np.asfortranarray(H1), B1)
+    fields[1] = (H1, B1)
+    ts = [2010.0 + j / 24.0 for j in range(4)]
+    for g in range(3):
+        b.set_reference(g, ts, [fields[g][0] * (1.0 - 0.01 * j) for j in range(4)], 3)
+    out = {}
+    for mode in (0, -1):
+        b.set_schedule(interp_async=mode)
+        out[mode] = (b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=24), b.loss_grad(ts, theta=th, reltol=1e-8))
+    for k in range(2):
+        (La, ga), (Ld, gd) = out[-1][k], out[0][k]
+        assert abs(La - Ld) <= 1e-13 * abs(Ld) and rel_l2(ga, gd) < 1e-12, (k, rel_l2(ga, gd))
+        assert np.isfinite(ga).all() and np.linalg.norm(ga) > 0
+    b.close()
