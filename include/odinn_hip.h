@@ -179,7 +179,10 @@ typedef struct odinn_schedule {
                               backprop) on the batch's own stream; n = 1 ... 4: overlapped with the following reverse steps of both
                               adjoints on n lane streams (default: 3 in the DiscreteAdjoint, 1 or 4 in the ContinuousAdjoint; results
                               bit-identical: every contribution has its own slot, the slots are added in the order of the stops)  */
-  int32_t reserved[3];     /* zero                                                                                                 */
+  int32_t adj_sc;          /* ODINN_ADJ_SC: 1 = self-controlled reverse step of the ContinuousAdjoint (the fused reverse step decides
+                              the previous attempt and does the post-step of a stop itself: one launch per reverse step), 0 = the
+                              three-launch loop (fused step, controller, post-step); same decisions, same arithmetic             */
+  int32_t reserved[2];     /* zero                                                                                                 */
 } odinn_schedule;
 
 typedef struct odinn_batch odinn_batch;

@@ -296,7 +296,21 @@ constexpr bool adj_rc(bool AF, bool SG, int NR) { return ODINN_ADJ_RC && (AF || 
 #define ODINN_ADJ_YT_WPE (ODINN_ADJ_YT_LDS ? 2 : ODINN_FWPE)
 #endif
 constexpr int YT_LDS_NI = 1024;  // the table size the LDS copy is laid out for (odinn_batch::ytab_ni)
-template <bool AF, bool SKIP, bool SG = false, int NR = TRPT, bool GA = false, bool YT = false>
+// SC -- the self-controlled reverse step: no controller / post-step launches (the forward solve's SC loop, sia2d_fused.hpp, for
+// the reverse ODE).  Every workgroup of launch n first DECIDES attempt n - 1 of its glacier itself: wavefront 0 sums the glacier's
+// error partials of launch n - 1 (controller_errsum: k_controller's order) and runs controller_decide -- the PID controller, the
+// stop tables, the AdjState of the coming step -- on the state in A.gin / A.adj_in; all workgroups of a glacier compute the same
+// decision from the same numbers, the one that owns tile (0, 0) publishes the new state to A.gout / A.adj_out (the two state arrays
+// and the two partial arrays alternate between launches).  GState::pad bit 0 = an attempt awaits its decision.  When the decided
+// step landed on a stop that changes lambda (a snapshot time: loss cotangent, mass-balance VJP, time-aggregated terms; a
+// mass-balance-only stop), THIS launch is that glacier's post-step instead of an attempt: every workgroup applies adj_post_cell to
+// its own output cells, lam[cur] -> lam[1 - cur], and the published state flips cur (pointwise: no halo, nobody reads what the
+// launch writes); the next launch attempts the step the controller prepared.  A quadrature node needs nothing here: its theta-VJP
+// is stage 1 of the next attempt (a.qw, A.th_part), as in the three-launch loop.
+__device__ __forceinline__ double wave_uniform(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+template <bool AF, bool SKIP, bool SG = false, int NR = TRPT, bool GA = false, bool YT = false, bool SC = false>
 __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_WPE : ODINN_FWPE))) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
   static_assert(!YT || (!AF && !GA), "the table's instantiation replaces the scalar A");
   constexpr bool RC = adj_rc(AF, SG, NR);
@@ -306,14 +320,115 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
   constexpr bool ELDS = ODINN_ADJ_ELDS && !(adj_rc(AF, SG, NR) && ODINN_ADJ_RC_EREG);
   __shared__ double sEr[ELDS ? (NR * TNW) : 1][FRX];
   const int4 t4 = A.tilesF[blockIdx.x];
-  const GState* gs = P.gs + t4.x;
-  if (gs->done) return;
   const GDev g = P.gd[t4.x];
-  const AdjState a = A.adj[t4.x];
-  const double dt = gs->dt;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * (NR * TNW - 2 * FH) - FH;
+  const int gi = gi0 + lane, r0 = NR * w;
+  const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
+  const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
+  const int id0 = gi + g.nx * (gj0 + r0);
+  const double* __restrict__ Bg = P.B + g.off;
+  const double* __restrict__ Afg = AF ? P.Afield + g.offd : nullptr;
+  auto idc = [&](int m) {  // the thread's cell of row m, clamped into the grid (what a clamped index picks up is never used)
+    const int gj = gj0 + r0 + m;
+    const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
+    return (unsigned)(gic + g.nx * gjc);
+  };
+  AdjState a;
+  double dt;
+  int cur;
+  if constexpr (SC) {
+    static_assert(SG, "the self-controlled instantiations read the interleaved snapshot pairs");
+    __shared__ GState s_gs;
+    __shared__ AdjState s_ad;
+    __shared__ int s_mode;  // 0: attempt a step, 1: this launch is the glacier's post-step, 2: the glacier is done
+    if (threadIdx.x < 64) {
+      GState sn = A.gin[t4.x];
+      AdjState ad = A.adj_in[t4.x];
+      // Everything the decision may read is requested at once, before the first use (one round trip through memory instead of
+      // four dependent ones: state -> error partials -> stop tables -> snapshot times): the stop the attempt aimed at and the
+      // one behind it, the snapshot times of the current segment.  (Rows past the glacier's table: clamped, never used.)
+      CtrlPre pre;
+      pre.is = sn.istop; pre.seg = ad.seg;
+      {
+        const int i0 = sn.istop < A.C.nrows ? sn.istop : A.C.nrows - 1, i1 = sn.istop + 1 < A.C.nrows ? sn.istop + 1 : A.C.nrows - 1;
+        pre.n_stops = A.C.nstops[t4.x];
+        pre.t_is = A.C.tstop(i0, t4.x); pre.t_is1 = A.C.tstop(i1, t4.x); pre.t_last = A.C.t_last;
+        pre.mbf = A.C.at(A.C.mb_flag, i0, t4.x); pre.mbs = A.C.at(A.C.mb_slot, i0, t4.x);
+        pre.snap = A.C.at(A.C.stop_snap, i0, t4.x); pre.hid = A.C.stop_hid ? A.C.at(A.C.stop_hid, i0, t4.x) : 0;
+        pre.qw = A.C.stop_qw[(long long)i0 * A.C.G + t4.x];
+        pre.ta = A.C.tsnap[(long long)ad.seg * A.C.G + t4.x]; pre.tb = A.C.tsnap[(long long)(ad.seg + 1) * A.C.G + t4.x];
+      }
+      double s, pw0, pw1, pw2;
+      controller_errsum(A.C, g, sn.e2, sn.e3, lane, s, pw0, pw1, pw2);
+      s = __shfl(s, 0, 64);
+      int est = -1, mode = 0;
+      bool newly_done = false;
+      if (sn.done) {
+        mode = 2;
+      } else if (sn.pad & 1) {
+        newly_done = controller_decide(sn, ad, g, A.C, t4.x, s, pw0, pw1, pw2, est, &pre) != 0;
+        const bool post = sn.accepted && sn.at_stop && (ad.snapj >= 0 || (ad.pad > 0 && sn.mb_now && g.has_mb));
+        mode = post ? 1 : (sn.done ? 2 : 0);
+      }
+      if (lane == 0) {
+        s_gs = sn; s_ad = ad; s_mode = mode;
+        if (t4.y == 0 && t4.z == 0) {  // the glacier's designated workgroup publishes the state for the next launch
+          GState so = sn;
+          if (mode == 1) so.cur = 1 - sn.cur;  // the post-step below leaves lambda in the other buffer
+          so.pad = mode == 0 ? 1 : 0;
+          A.gout[t4.x] = so;
+          A.adj_out[t4.x] = ad;
+          if (newly_done) atomicSub(A.C.n_active, 1);
+          if (A.C.est_steps && est >= 0) A.C.est_steps[t4.x] = est;
+          if (A.C.qw_out) A.C.qw_out[t4.x] = ad.qw;
+        }
+      }
+    }
+    __syncthreads();
+    const int mode = __builtin_amdgcn_readfirstlane(s_mode);
+    if (mode == 2) return;
+    cur = __builtin_amdgcn_readfirstlane(s_gs.cur);
+    dt = wave_uniform(s_gs.dt);
+    a.seg = __builtin_amdgcn_readfirstlane(s_ad.seg); a.seg_stop = __builtin_amdgcn_readfirstlane(s_ad.seg_stop);
+    a.snapj = __builtin_amdgcn_readfirstlane(s_ad.snapj); a.pad = __builtin_amdgcn_readfirstlane(s_ad.pad);
+    a.qw = wave_uniform(s_ad.qw); a.s_stop = wave_uniform(s_ad.s_stop);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) a.sitp[k] = wave_uniform(s_ad.sitp[k]);
+    if (mode == 1) {
+      const int mb_now = __builtin_amdgcn_readfirstlane(s_gs.mb_now), mb_slot = __builtin_amdgcn_readfirstlane(s_gs.mb_slot);
+      const double* __restrict__ ps = (cur ? A.lam1 : A.lam0);
+      double* __restrict__ pd = (cur ? A.lam0 : A.lam1);
+      const double Ninv = 1.0 / ((double)g.nx * (double)g.ny);
+      double wl = 0.0;
+      long long roff = 0;
+      if (a.snapj >= 0 && A.post.ws) {
+        wl = A.post.ws[(long long)a.snapj * A.post.G + t4.x];
+        if (wl != 0.0) roff = (long long)A.post.refslot[(long long)a.snapj * A.post.G + t4.x] * A.post.ntot;
+      }
+      if (lane >= FH && lane < FH + FOX && inx) {
+#pragma unroll
+        for (int m = 0; m < NR; ++m) {
+          const int r = r0 + m, gj = gj0 + r;
+          if (r >= FH && r <= (NR * TNW) - 1 - FH && gj < g.ny) {
+            const long long id = g.off + gi + (long long)g.nx * gj;
+            pd[id] = adj_post_cell(g, a, A.post, P.B, t4.x, mb_now, mb_slot, wl, roff, Ninv, id, ps[id]);
+          }
+        }
+      }
+      return;
+    }
+  } else {
+    const GState* gs = P.gs + t4.x;
+    if (gs->done) return;
+    a = A.adj[t4.x];
+    dt = gs->dt;
+    cur = gs->cur;
+  }
   // everything below is addressed relative to the glacier's first cell (block-uniform bases, 32-bit cell indices)
-  const double* __restrict__ src = (gs->cur ? A.lam1 : A.lam0) + g.off;
-  double* __restrict__ dst = (gs->cur ? A.lam0 : A.lam1) + g.off;
+  const double* __restrict__ src = (cur ? A.lam1 : A.lam0) + g.off;
+  double* __restrict__ dst = (cur ? A.lam0 : A.lam1) + g.off;
   const double* __restrict__ Ha = SG ? reinterpret_cast<const double*>(A.segs + (long long)a.seg * A.ntot + g.off)
                                      : A.snaps + (long long)a.seg * A.ntot + g.off;
   const double* __restrict__ Hb = Ha + A.ntot;  // (unused with SG)
@@ -325,15 +440,6 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
       ha = ldg32(Ha, id); hb = ldg32(Hb, id);
     }
   };
-  const double* __restrict__ Bg = P.B + g.off;
-  const double* __restrict__ Afg = AF ? P.Afield + g.offd : nullptr;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int gi0 = t4.y * FOX - FH, gj0 = t4.z * (NR * TNW - 2 * FH) - FH;
-  const int gi = gi0 + lane, r0 = NR * w;
-  const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
-  const int gic = gi < 0 ? 0 : (gi > g.nx - 1 ? g.nx - 1 : gi);
-  const int id0 = gi + g.nx * (gj0 + r0);
   if (SKIP) {
     // Exact shortcut: if neither bracketing snapshot has ice anywhere on the halo region (and the five stage weights
     // lie in [0, 1], so that no interpolant has either), Hc = 0 on the region at every stage: every D and every
@@ -342,11 +448,8 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
     bool ice = false;
 #pragma unroll
     for (int m = 0; m < NR; ++m) {
-      const int gj = gj0 + r0 + m;
-      const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
-      const unsigned id = (unsigned)(gic + g.nx * gjc);
       double ha, hb;
-      ld_ab(id, ha, hb);
+      ld_ab(idc(m), ha, hb);
       ice = ice || ha > 0.0 || hb > 0.0;
     }
 #pragma unroll
@@ -422,9 +525,7 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
     const bool nodex = gi >= 0 && gi <= g.nx - 2;
 #pragma unroll
     for (int m = 0; m < NR; ++m) {
-      const int gj = gj0 + r0 + m;
-      const int gjc = gj < 0 ? 0 : (gj > g.ny - 1 ? g.ny - 1 : gj);
-      const unsigned id = (unsigned)(gic + g.nx * gjc);
+      const unsigned id = idc(m);
       rc.hd[m] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Ha) + ((size_t)id << 4));
       rc.b[m] = ldg32(Bg, id);
       rc.u0[m] = ldg32(src, id);

@@ -66,6 +66,7 @@ constexpr int TNT = 64 * TNW;         // same thread's registers: TNW wavefronts
 constexpr int TRY = TRPT * TNW;
 constexpr int FOYT = TRY - 2 * FH;
 constexpr int FOYT4 = 4 * TNW - 2 * FH;  // fused reverse step of small batches with 4 rows per thread: 54 x 22 output tiles
+constexpr int FOYT2 = 2 * TNW - 2 * FH;  // ... of the smallest batches with 2 rows per thread: 54 x 6 output tiles (see odinn_hip.hip: rows of the reverse step)
 constexpr int FOYT8 = 8 * TNW - 2 * FH;  // forward strip kernel with 8 rows per thread: 54 x 54 output tiles
 constexpr int FLD = FRX + 1;          // LDS row stride (odd)
 
@@ -110,6 +111,7 @@ struct GDev {  // per-glacier constants
   int tile0Ft, ntilesFt; // ... and in the table of FOX x FOYT "strip" tiles
   int tile0Fu, ntilesFu; // ... and in the table of FOX x FOYT8 strip tiles (forward kernel, 8 rows per thread)
   int tile0Fv, ntilesFv; // ... and in the table of FOX x FOYT4 strip tiles (fused reverse step of small batches, 4 rows per thread)
+  int tile0Fw, ntilesFw; // ... and in the table of FOX x FOYT2 strip tiles (fused reverse step of the smallest batches, 2 rows per thread)
   int tile0D, ntilesD;   // ... and in the table of 62 x 62 tiles of the RHS-only / CFL-Euler strip kernel
   long long off;   // offset of this glacier in the pooled primal arrays  [doubles]
   long long offd;  // offset in the pooled dual arrays
@@ -1597,7 +1599,7 @@ struct CtrlArgs {
   int next_cur;  // ping-pong buffer that holds u_new of this step; -1: flip the glacier's own `cur`
   const double* errpart;  // per-tile error partials: errpart[stride * tile]
   int stride;
-  int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles, 3: FOYT tiles, 4: FOYT8 tiles, 5: 62 x 62 tiles, 6: FOYT4 tiles)
+  int fused;              // partials are indexed by the fused-step tile table (1: FOY tiles, 2: FOYS tiles, 3: FOYT tiles, 4: FOYT8 tiles, 5: 62 x 62 tiles, 6: FOYT4 tiles, 7: FOYT2 tiles)
   int* est_steps;         // [G] (nullable): estimated steps still needed, for the host's poll spacing
   double cfl;             // > 0: explicit Euler with dt = cfl*min(dx,dy)^2/(4 max D); the partials are tile maxima
   int cfl_prime;          // the launch only measured max D(u0): set the first dt, do not advance
@@ -1611,6 +1613,8 @@ struct CtrlArgs {
   double* qw_out;         // per glacier: weight of the node reached by this step (0 otherwise)
   double* trace;          // (nullable, diagnostics: ODINN_TRACE_STEPS) [trace_cap][4] of glacier 0: t, dt, EEst, +-factor per attempt
   int trace_cap;
+  int nrows;              // rows of the stop tables; t_last: the time of every glacier's last stop (self-controlled reverse step:
+  double t_last;          //   CtrlPre)
 };
 
 // self-controlled fused step (sia2d_fused.hpp, k_rk_fused_strip<..., SC = true>)
@@ -1631,6 +1635,15 @@ struct ScArgs {
 
 // interpolation weights of H_itp at the five stage times of the step [tau, tau + dt]
 __device__ __forceinline__ void adj_stage_weights(AdjState* a, const double* tsnap, int G, int gidx, double tau, double dt,
+                                                  bool all_at_end, double ta, double tb) {
+  const double inv = 1.0 / (tb - ta);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double t = -(tau + (all_at_end ? 1.0 : c_cc[i]) * dt);
+    a->sitp[i] = fmin(fmax((t - ta) * inv, 0.0), 1.0);
+  }
+}
+__device__ __forceinline__ void adj_stage_weights(AdjState* a, const double* tsnap, int G, int gidx, double tau, double dt,
                                                   bool all_at_end) {
   const double ta = tsnap[(long long)a->seg * G + gidx], inv = 1.0 / (tsnap[(long long)(a->seg + 1) * G + gidx] - ta);
 #pragma unroll
@@ -1648,8 +1661,8 @@ __device__ __forceinline__ void controller_errsum(const CtrlArgs& C, const GDev&
                                                   double& pw0, double& pw1, double& pw2) {
   double s = 0.0;
   {
-    const int t0 = C.fused == 6 ? g.tile0Fv : C.fused == 5 ? g.tile0D : C.fused == 4 ? g.tile0Fu : C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
-    const int nt = C.fused == 6 ? g.ntilesFv : C.fused == 5 ? g.ntilesD : C.fused == 4 ? g.ntilesFu : C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
+    const int t0 = C.fused == 7 ? g.tile0Fw : C.fused == 6 ? g.tile0Fv : C.fused == 5 ? g.tile0D : C.fused == 4 ? g.tile0Fu : C.fused == 3 ? g.tile0Ft : C.fused == 2 ? g.tile0Fs : (C.fused ? g.tile0F : g.tile0);
+    const int nt = C.fused == 7 ? g.ntilesFw : C.fused == 6 ? g.ntilesFv : C.fused == 5 ? g.ntilesD : C.fused == 4 ? g.ntilesFu : C.fused == 3 ? g.ntilesFt : C.fused == 2 ? g.ntilesFs : (C.fused ? g.ntilesF : g.ntiles);
     if (C.cfl > 0.0) {
       for (int k = lane; k < nt; k += 64) s = fmax(s, C.errpart[(long long)C.stride * (t0 + k)]);
     } else {
@@ -1687,9 +1700,23 @@ __device__ __forceinline__ void controller_errsum(const CtrlArgs& C, const GDev&
 }
 // the decision itself (PID controller, accept / reject, stop handling, next step size; the reverse solve's AdjState),
 // on values in registers: one thread.  Returns 1 when the glacier has just finished; est: steps still needed (-1: n/a).
+// pre (self-controlled reverse step): table entries requested before the decision starts -- stop `is` (the one the attempt
+// aimed at), the time of stop is + 1, the last stop's time, the snapshot times of segment `seg`; the same values the tables hold
+struct CtrlPre {
+  int is, seg, n_stops, mbf, mbs, snap, hid;
+  double t_is, t_is1, t_last, qw, ta, tb;
+};
 __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const GDev& g, const CtrlArgs& C, int gidx, double s,
-                                                 double pw0, double pw1, double pw2, int& est) {
-  const int n_stops = C.nstops[gidx];
+                                                 double pw0, double pw1, double pw2, int& est, const CtrlPre* pre = nullptr) {
+  const int n_stops = pre ? pre->n_stops : C.nstops[gidx];
+  auto tstop_at = [&](int i) {
+    if (pre) {
+      if (i == pre->is) return pre->t_is;
+      if (i == pre->is + 1) return pre->t_is1;
+      if (i == n_stops - 1) return pre->t_last;
+    }
+    return C.tstop(i, gidx);
+  };
   est = -1;
   const double h = st.dt;
   double fac = 1.0;
@@ -1718,19 +1745,19 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
     st.accepted = 1;
     st.cur = C.next_cur >= 0 ? C.next_cur : 1 - st.cur;
     if (st.clipped) {
-      t = C.tstop(st.istop, gidx);
+      t = tstop_at(st.istop);
       st.at_stop = 1;
-      st.mb_now = C.at(C.mb_flag, st.istop, gidx);
-      st.mb_slot = C.at(C.mb_slot, st.istop, gidx);
+      st.mb_now = pre ? pre->mbf : C.at(C.mb_flag, st.istop, gidx);
+      st.mb_slot = pre ? pre->mbs : C.at(C.mb_slot, st.istop, gidx);
       st.snap_slot = C.snap_slot ? C.at(C.snap_slot, st.istop, gidx) : st.istop;
       if (C.adj) {
         AdjState* a = &ad;
-        a->snapj = C.at(C.stop_snap, st.istop, gidx);
-        a->pad = C.stop_hid ? C.at(C.stop_hid, st.istop, gidx) : 0;
-        a->qw = C.stop_qw[(long long)st.istop * C.G + gidx];
+        a->snapj = pre ? pre->snap : C.at(C.stop_snap, st.istop, gidx);
+        a->pad = pre ? pre->hid : (C.stop_hid ? C.at(C.stop_hid, st.istop, gidx) : 0);
+        a->qw = pre ? pre->qw : C.stop_qw[(long long)st.istop * C.G + gidx];
         a->seg_stop = a->seg;
-        const double ta = C.tsnap[(long long)a->seg * C.G + gidx];
-        a->s_stop = a->snapj >= 0 ? (a->snapj == a->seg ? 0.0 : 1.0) : (-t - ta) / (C.tsnap[(long long)(a->seg + 1) * C.G + gidx] - ta);
+        const double ta = pre ? pre->ta : C.tsnap[(long long)a->seg * C.G + gidx];
+        a->s_stop = a->snapj >= 0 ? (a->snapj == a->seg ? 0.0 : 1.0) : (-t - ta) / ((pre ? pre->tb : C.tsnap[(long long)(a->seg + 1) * C.G + gidx]) - ta);
         if (a->snapj >= 1) a->seg = a->snapj - 1;  // the next steps run below snapshot j
       }
       st.istop++;
@@ -1756,7 +1783,7 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
   }
   double dtn = C.adaptive ? h * fac : C.fixed_dt;
   if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
-  const double rem = C.tstop(st.istop, gidx) - t;
+  const double rem = tstop_at(st.istop) - t;
   // snap to the stop when the step would end within 100 ulp of it
   if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {
     dtn = rem;
@@ -1766,11 +1793,14 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
   }
   st.dt = dtn;
   {  // at the current step size, and at least one step per remaining stop
-    const double e = ceil((C.tstop(n_stops - 1, gidx) - t) / (C.adaptive ? h * fac : dtn));
+    const double e = ceil((tstop_at(n_stops - 1) - t) / (C.adaptive ? h * fac : dtn));
     const int stops_left = n_stops - st.istop;
     est = e < (double)stops_left ? stops_left : (e > 1e6 ? 1000000 : (int)e);
   }
-  if (C.adj) adj_stage_weights(&ad, C.tsnap, C.G, gidx, t, dtn, false);
+  if (C.adj) {
+    if (pre && ad.seg == pre->seg) adj_stage_weights(&ad, C.tsnap, C.G, gidx, t, dtn, false, pre->ta, pre->tb);
+    else adj_stage_weights(&ad, C.tsnap, C.G, gidx, t, dtn, false);
+  }
   return 0;
 }
 
@@ -2349,6 +2379,62 @@ struct AdjStageArgs {
   double abstol, reltol;
 };
 
+// One cell of the reverse solve's post-step at a stop (k_adj_poststep and the self-controlled fused reverse step share it):
+// lambda after the stop's terms.  Snapshot time t_j: lam += VJP_MB(lam, H_j - MB_j) (gradient.jl:413-425) and
+// lam += w_j dl/dH(H_j) (:331-365) plus the time-aggregated cotangents, mass balance first (CallbackSet order :437) except at the
+// very first stop (loss_first); a mass-balance time that is not a result stop (the reverse PeriodicCallback, :413-432):
+// lam += VJP_MB(lam, H_pre) with H_pre = H_itp(t) - MB_t as the reference forms it -- H_itp from the RESULT snapshots,
+// MB_t = (state after) - (state before) the mass balance of the forward solve at t (hidden snapshot slot, pre-MB slot).
+// id: pooled cell index; w / roff: loss weight and reference offset of the stop's snapshot (0 / 0: no thickness term).
+__device__ __forceinline__ double adj_post_cell(const GDev& g, const AdjState& a, const AdjPostArgs& A, const double* __restrict__ Bp,
+                                                int gidx, int mb_now, int mb_slot, double w, long long roff, double Ninv,
+                                                long long id, double l) {
+  if (a.snapj >= 0) {
+    double dl = 0.0;
+    if (w != 0.0 && A.mask[roff + id]) {
+      double d, q;
+      simple_loss_terms(A.snaps[(long long)a.snapj * A.ntot + id], A.Href[roff + id], A.h_log_eps, d, q);
+      dl = w * 2.0 * Ninv * d;
+    }
+    double dagg = 0.0;
+    if (A.dh_coef) {
+      const int q0 = A.dh_i0[gidx], q1 = A.dh_i1[gidx];
+      if (q0 >= 0 && (a.snapj == q0 || a.snapj == q1) && A.snaps[(long long)q0 * A.ntot + id] > 1e-2)
+        dagg = a.snapj == q1 ? A.dh_coef[gidx] : -A.dh_coef[gidx];
+    }
+    if (A.aggH) {
+      const int sl = A.agg_slot[a.snapj];
+      if (sl >= 0) dagg += A.aggH[(long long)sl * A.ntot + id];
+    }
+    if (A.loss_first) l += dl + dagg;
+    if (mb_now && g.has_mb) {
+      const double h = A.premb[(long long)mb_slot * A.ntot + id];
+      double dmb;
+      const double mb = mb_value(g, A.mb0[id], A.Sref ? A.Sref[id] : 0.0, h, Bp[id], dmb);
+      const bool msk = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
+      double vv = 0.0;
+      if (msk) vv = dmb * l;
+      if (msk && h + mb < 0.0) vv = -l;
+      l += vv;
+    }
+    if (!A.loss_first) l += dl + dagg;
+  } else if (a.pad > 0 && mb_now && g.has_mb) {
+    const double ha = A.snaps[(long long)a.seg_stop * A.ntot + id];
+    const double hb = A.snaps[(long long)(a.seg_stop + 1) * A.ntot + id];
+    const double post = A.snaps[(long long)(a.pad - 1) * A.ntot + id];
+    const double pre = A.premb[(long long)mb_slot * A.ntot + id];
+    const double h = fma(a.s_stop, hb - ha, ha) - (post - pre);
+    double dmb;
+    const double mb = mb_value(g, A.mb0[id], A.Sref ? A.Sref[id] : 0.0, h, Bp[id], dmb);
+    const bool msk = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
+    double vv = 0.0;
+    if (msk) vv = dmb * l;
+    if (msk && h + mb < 0.0) vv = -l;
+    l += vv;
+  }
+  return l;
+}
+
 // arguments of k_adj_fused_strip (sia2d_adj_fused.hpp): the five stages of a reverse step in one kernel
 struct AdjFusedArgs {
   const double2* segs;  // non-null: {H_j, H_j+1 - H_j} interleaved per segment [n_snap - 1][ntot] (k_seg_pairs): one 16-byte
@@ -2367,6 +2453,15 @@ struct AdjFusedArgs {
   const double* ytab;   // non-null: the Y law through its table (LM_YTAB, every glacier yt_fast) -- the kernel's YT instantiation
   int* ytab_over;
   int ytab_ni;
+  // self-controlled reverse step (the kernel's SC instantiations; see k_adj_fused_strip): launch n decides attempt n - 1 itself.
+  // State, AdjState and error partials alternate between two arrays from launch to launch (nobody reads what another
+  // workgroup of the same launch writes); C.errpart must point at the partials the PREVIOUS launch wrote.
+  const GState* gin;
+  GState* gout;
+  const AdjState* adj_in;
+  AdjState* adj_out;
+  CtrlArgs C;
+  AdjPostArgs post;     // what k_adj_poststep would get (loss_first = 0, Hq = null)
 };
 
 
@@ -3163,63 +3258,13 @@ __device__ __forceinline__ void adj_poststep_tile(const Pools& P, const AdjPostA
     w = A.ws[(long long)a.snapj * A.G + t4.x];
     if (w != 0.0) roff = (long long)A.refslot[(long long)a.snapj * A.G + t4.x] * A.ntot;
   }
-  const bool do_mb = a.snapj >= 0 && gs->mb_now && g.has_mb;
-  // a mass-balance time that is not a result stop (the reverse PeriodicCallback, gradient.jl:413-432): lam += VJP_MB(lam, H_pre)
-  // with H_pre = H_itp(t) - MB_t as the reference forms it -- H_itp from the RESULT snapshots, MB_t = (state after) - (state
-  // before) the mass balance of the forward solve at t (hidden snapshot slot, pre-MB slot)
-  const bool mb_only = a.snapj < 0 && a.pad > 0 && gs->mb_now && g.has_mb;
+  const bool touches = a.snapj >= 0 || (a.pad > 0 && gs->mb_now && g.has_mb);
 #pragma unroll
   for (int m = 0; m < RPT; ++m) {
     const int gj = j0 + ty + NW * m;
     if (gi < g.nx && gj < g.ny) {
       const long long id = g.off + gi + (long long)g.nx * gj;
-      if (a.snapj >= 0) {
-        double l = U[id];
-        double dl = 0.0;
-        if (w != 0.0 && A.mask[roff + id]) {
-          double d, q;
-          simple_loss_terms(A.snaps[(long long)a.snapj * A.ntot + id], A.Href[roff + id], A.h_log_eps, d, q);
-          dl = w * 2.0 * Ninv * d;
-        }
-        double dagg = 0.0;
-        if (A.dh_coef) {
-          const int q0 = A.dh_i0[t4.x], q1 = A.dh_i1[t4.x];
-          if (q0 >= 0 && (a.snapj == q0 || a.snapj == q1) && A.snaps[(long long)q0 * A.ntot + id] > 1e-2)
-            dagg = a.snapj == q1 ? A.dh_coef[t4.x] : -A.dh_coef[t4.x];
-        }
-        if (A.aggH) {
-          const int sl = A.agg_slot[a.snapj];
-          if (sl >= 0) dagg += A.aggH[(long long)sl * A.ntot + id];
-        }
-        if (A.loss_first) l += dl + dagg;
-        if (do_mb) {
-          const double h = A.premb[(long long)gs->mb_slot * A.ntot + id];
-          double dmb;
-          const double mb = mb_value(g, A.mb0[id], A.Sref ? A.Sref[id] : 0.0, h, P.B[id], dmb);
-          const bool msk = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
-          double vv = 0.0;
-          if (msk) vv = dmb * l;
-          if (msk && h + mb < 0.0) vv = -l;
-          l += vv;
-        }
-        if (!A.loss_first) l += dl + dagg;
-        U[id] = l;
-      }
-      if (mb_only) {
-        const double l = U[id];
-        const double ha = A.snaps[(long long)a.seg_stop * A.ntot + id];
-        const double hb = A.snaps[(long long)(a.seg_stop + 1) * A.ntot + id];
-        const double post = A.snaps[(long long)(a.pad - 1) * A.ntot + id];
-        const double pre = A.premb[(long long)gs->mb_slot * A.ntot + id];
-        const double h = fma(a.s_stop, hb - ha, ha) - (post - pre);
-        double dmb;
-        const double mb = mb_value(g, A.mb0[id], A.Sref ? A.Sref[id] : 0.0, h, P.B[id], dmb);
-        const bool msk = (h > 0.0 && mb < 0.0) || (h > 10.0 && mb >= 0.0);
-        double vv = 0.0;
-        if (msk) vv = dmb * l;
-        if (msk && h + mb < 0.0) vv = -l;
-        U[id] = l + vv;
-      }
+      if (touches) U[id] = adj_post_cell(g, a, A, P.B, t4.x, gs->mb_now, gs->mb_slot, w, roff, Ninv, id, U[id]);
       if (A.Hq && ((a.qw != 0.0 && !A.hq_snap_only) || a.snapj >= 0)) {  // H_itp at the stop, for the velocity loss term (the theta-VJP forms it itself)
         const double ha = A.snaps[(long long)a.seg_stop * A.ntot + id];
         const double hb = A.snaps[(long long)(a.seg_stop + 1) * A.ntot + id];
@@ -3409,7 +3454,8 @@ __global__ void k_seg_pairs(long long ntot, int n_seg, const double* __restrict_
 __global__ __launch_bounds__(64) void k_sum_tilesFt(Pools P, const double* __restrict__ part, double* __restrict__ out, int rows) {
   const int gidx = blockIdx.x;
   const GDev g = P.gd[gidx];
-  const int t0 = rows == 4 ? g.tile0Fv : rows == 8 ? g.tile0Fu : g.tile0Ft, nt = rows == 4 ? g.ntilesFv : rows == 8 ? g.ntilesFu : g.ntilesFt;
+  const int t0 = rows == 2 ? g.tile0Fw : rows == 4 ? g.tile0Fv : rows == 8 ? g.tile0Fu : g.tile0Ft;
+  const int nt = rows == 2 ? g.ntilesFw : rows == 4 ? g.ntilesFv : rows == 8 ? g.ntilesFu : g.ntilesFt;
   double s = 0.0;
   for (int k = threadIdx.x; k < nt; k += 64) s += part[t0 + k];
   s = wave_sum(s);

@@ -421,7 +421,7 @@ def test_fused_reverse_step_rows_per_thread(gpu, monkeypatch, case):
     monkeypatch.setenv("ODINN_ADJ_FUSED", "1")
     out = {}
     # (8 rows: the register-cached instantiation of the gridded law on the forward kernel's 54 x 54 tiles; ignored otherwise)
-    for rows in ("7", "4") + (("8",) if case == "gridded_nn" else ()):
+    for rows in ("7", "4", "2") + (("8",) if case == "gridded_nn" else ()):
         monkeypatch.setenv("ODINN_ADJ_ROWS", rows)
         out[rows] = _reverse_case(gpu, case)
     for other in [r for r in out if r != "7"]:
@@ -477,3 +477,52 @@ def test_fused_reverse_step_with_rejected_steps(gpu, monkeypatch):
     assert a[2] == f[2] and sum(r for _, r in a[2]) > 0, (a[2], f[2])
     assert np.abs(a[1] - f[1]).max() <= 1e-10 * np.abs(a[1]).max()
     assert rel_l2(f[3], a[3]) < 1e-10
+
+
+@pytest.mark.parametrize("case", ["scalar_nn_mb", "gridded_nn", "ragged_batch", "rejections", "mb_only_stops"])
+@pytest.mark.parametrize("rows", ["7", "4", "2"])
+def test_self_controlled_reverse_step_matches_the_three_launch_loop(gpu, monkeypatch, case, rows):
+    """ODINN_ADJ_SC=1: every workgroup of the fused reverse step decides the previous attempt of its glacier itself (error norm,
+    PID controller, stop tables, the AdjState of the coming step) and a launch that follows a step onto a snapshot time is that
+    glacier's post-step (loss cotangent, mass-balance VJP) -- no k_controller / k_adj_poststep launches.  Same kernel arithmetic
+    and the same decisions as the three-launch loop (ODINN_ADJ_SC=0): same reverse step counts, bit-identical loss, gradient
+    and lambda(t0) -- on a single glacier with a mass balance, the gridded law (dual-grid accumulator fed by stage 1), a ragged
+    batch whose glaciers run out of step, a reverse solve with rejected steps, and mass-balance times that are not result
+    stops."""
+    monkeypatch.setenv("ODINN_ADJ_FUSED", "1")
+    monkeypatch.setenv("ODINN_ADJ_ROWS", rows)
+    out = {}
+    for sc in ("0", "1"):
+        monkeypatch.setenv("ODINN_ADJ_SC", sc)
+        if case == "rejections":
+            shapes = [(130, 97), (96, 80)]
+            b = gpu.GlacierBatch(shapes, [50.0] * 2, A=[6e-17, 4e-17])
+            ts = [2010.0, 2010.5, 2011.0, 2011.5]
+            for k, (nx, ny) in enumerate(shapes):
+                H0, B = O.synthetic_valley(nx, ny, 50.0)
+                b.set_fields(k, H0, B)
+                b.set_reference(k, ts, [H0 * (1.0 - 0.1 * j) for j in range(len(ts))], 3)
+            L, g = b.loss_grad_continuous(ts, reltol=1e-8, adj_reltol=1e-4, adj_abstol=1e-6, adj_dtmax=0.5, n_quadrature=6)
+            out[sc] = (L, np.array(g, dtype=float).ravel(), [b.lambda0(k) for k in range(2)],
+                       [(s.naccept, s.nreject) for s in b.last_stats_rev])
+            b.close()
+        elif case == "mb_only_stops":
+            nx, ny = 96, 80
+            ph, H0, B, ts, om, gm, th0, gl, mb, cfg, ref = _inversion_case(gpu, nx, ny, True)
+            b = _batch(gpu, nx, ny, H0, B, gm, th0, ts, ref, mb)
+            # mass-balance times between the result stops (and on them)
+            mbt = sorted(set(list(ts[1:]) + [0.5 * (ts[j] + ts[j + 1]) for j in range(len(ts) - 1)]))
+            L, g = b.loss_grad_continuous(ts, theta=th0, mb_times=mbt, reltol=1e-8, n_quadrature=16)
+            out[sc] = (L, np.array(g, dtype=float).ravel(), [b.lambda0(0)], [(s.naccept, s.nreject) for s in b.last_stats_rev])
+            b.close()
+        else:
+            out[sc] = _reverse_case(gpu, case)
+    a, f = out["0"], out["1"]
+    if case == "rejections":
+        assert sum(r for _, r in a[3]) > 0
+    assert a[3] == f[3], (a[3], f[3])
+    assert a[0] == f[0]
+    assert np.array_equal(a[1], f[1]), np.abs(a[1] - f[1]).max() / np.abs(a[1]).max()
+    for la, lf in zip(a[2], f[2]):
+        assert np.array_equal(la, lf)
+    assert np.abs(a[1]).max() > 0.0
