@@ -40,7 +40,7 @@ __all__ = [
     "InitialThicknessRegularization", "RheologyRegularization", "InitialCondition", "evaluate_H0", "evaluate_dH0",
     "sigma_zang", "dsigma_zang", "TrainingResult", "save_inversion_file", "load_inversion_file", "ScalarLogger", "TBLogger", "read_event_file",
     "callback_diagnosis",
-    "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "LogSum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "SIA2D_b",
+    "LossH", "LossV", "LossHV", "VelocityData", "V_from_H", "L2Sum", "LogSum", "Adam", "LBFGS", "Results", "TrainingStats", "run_b", "SIA2D_grad_b", "loss_iceflow_transient", "SIA2D_b",
     "VJP_lambda_dSIAdH", "VJP_lambda_dSIAdtheta", "define_callback_steps", "build_default_NN",
     "shard_glaciers", "init_distributed", "allreduce_loss_grad", "load_gridded_glacier", "attach_rccl_comm",
     "SIA2D_A_target", "SIA2D_D_hybrid_target", "SIA2D_D_target", "LossDhdt", "DhdtData", "LossAvgV", "VelocityRegularization",
@@ -256,14 +256,14 @@ class _NoDataTerm(LossH):
 
 def _split_loss(lf):
     """(data loss, its weight, [(regulariser, weight)]) of a loss specification."""
-    if isinstance(lf, _AGGREGATED):
+    if isinstance(lf, _AGGREGATED + (InitialThicknessRegularization, RheologyRegularization)):  # a bare regulariser (runtests.jl:221-223: loss = RheologyRegularization())
         return _NoDataTerm(), 1.0, [(lf, 1.0)]
     if not isinstance(lf, MultiLoss):
         return lf, 1.0, []
     data = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if isinstance(l, (LossH, LossV, LossHV))]
     regs = [(l, w) for l, w in zip(lf.losses, lf.lambdas) if not isinstance(l, (LossH, LossV, LossHV))]
-    if len(data) == 0 and any(isinstance(r, _AGGREGATED) for r, _ in regs):
-        data = [(_NoDataTerm(), 1.0)]  # time-aggregated losses alone: no data term
+    if len(data) == 0 and regs:
+        data = [(_NoDataTerm(), 1.0)]  # time-aggregated losses / regularisers alone: no data term
     if len(data) != 1:
         raise ValueError("MultiLoss needs exactly one data term (LossH, LossV or LossHV)")
     for r, _ in regs:
@@ -1345,9 +1345,10 @@ def V_from_H(simulation: _Simulation, H, t, theta=None, glacier_idx: int = 0):
     return Vx, Vy, np.sqrt(Vx ** 2 + Vy ** 2)
 
 
-def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
+def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion, _loss_only: bool = False):
     """SIA2D_grad!(dθ, θ, simulation): loss and gradient over ALL glaciers of ALL ranks
-    (gradient.jl:6-31).  Returns the loss; dθ is written in place.  θ = [law parameters, IC matrices]."""
+    (gradient.jl:6-31).  Returns the loss; dθ is written in place.  θ = [law parameters, IC matrices].
+    (_loss_only: loss_iceflow_transient's forward-only evaluation of the same loss.)"""
     b = simulation.batch()
     model = simulation.model
     law = model.iceflow.law
@@ -1371,6 +1372,39 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
     theta = np.asarray(theta, dtype=np.float64)
     th_main = theta[:model.n_main]
     dth = np.zeros_like(theta)
+    lf_data = _split_loss(p.UDE.empirical_loss_function)[0]
+    if _loss_only and not any(isinstance(r, _AGGREGATED) for r, _ in regs) and not isinstance(lf_data, _NoDataTerm):
+        # forward solve + the loss over its snapshots (the time-aggregated terms are evaluated by the gradient drivers only)
+        def loss_grad(ts, theta=None, mb_times=(), **opts):  # noqa: F811
+            if theta is not None:
+                b.set_theta(theta)
+            b.solve(ts, mb_times=mb_times, **opts)
+            return float(np.sum(b.loss())), np.zeros(max(model.n_main, 1))
+
+        def grad_parts():
+            return np.zeros(b.G), np.zeros(b.G)
+
+        def grad_field(k):
+            return np.zeros((b.shapes[k][0] - 1, b.shapes[k][1] - 1), order="F")
+
+        def lambda0(k):
+            return np.zeros(b.shapes[k], order="F")
+    elif isinstance(lf_data, _NoDataTerm) and not any(isinstance(r, _AGGREGATED) for r, _ in regs):
+        # regularisers on the parameters alone (loss = RheologyRegularization(), runtests.jl:221-223): no term depends on the
+        # solve -- the reference integrates a zero adjoint; nothing to run on the device
+        def loss_grad(*a, **kw):  # noqa: F811
+            return 0.0, np.zeros(max(model.n_main, 1))
+
+        def grad_parts():
+            return np.zeros(b.G), np.zeros(b.G)
+
+        def grad_field(k):
+            return np.zeros((b.shapes[k][0] - 1, b.shapes[k][1] - 1), order="F")
+
+        def lambda0(k):
+            return np.zeros(b.shapes[k], order="F")
+    else:
+        grad_parts, grad_field, lambda0 = b.grad_parts, b.grad_field, b.lambda0
     if model.IC is not None:
         simulation._apply_IC(theta)
     if law.classical is not None:
@@ -1379,11 +1413,11 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
         loss, _ = loss_grad(simulation._push_stops(), mb_times=simulation.mb_times(), **simulation._solver_opts())
         lo, hi = law.bounds
         sizes, offs = simulation._slots()
-        _, Gg = b.grad_parts()
+        _, Gg = grad_parts()
         for k, gi in enumerate(simulation._mine):
             th = np.asarray(theta[offs[gi]:offs[gi + 1]])
             dA = (hi - lo) / 2.0 * (1.0 - np.tanh(th) ** 2)
-            dLdA = Gg[k] if law.classical == "scalar" else b.grad_field(k).ravel(order="F")
+            dLdA = Gg[k] if law.classical == "scalar" else grad_field(k).ravel(order="F")
             dth[offs[gi]:offs[gi + 1]] = dLdA * dA
     elif model.n_main:
         loss, dth[:model.n_main] = loss_grad(simulation._push_stops(), theta=th_main, mb_times=simulation.mb_times(),
@@ -1395,7 +1429,7 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
         for k, gi in enumerate(simulation._mine):
             g = simulation.glaciers[gi]
             s0 = evaluate_dH0(theta[offs[gi]:offs[gi + 1]], g, p.UDE.initial_condition_filter)
-            dth[offs[gi]:offs[gi + 1]] = (b.lambda0(k) * s0).ravel(order="F")
+            dth[offs[gi]:offs[gi + 1]] = (lambda0(k) * s0).ravel(order="F")
     loss *= w_data  # MultiLoss: sum_k λ_k loss_k, same weights on the gradients (MultiLoss.jl:75-98,148-180)
     dth *= w_data
     tspan = p.simulation.tspan
@@ -1440,6 +1474,19 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion):
                       "Try reducing the temporal stepsize Δt used for reverse simulation.")
     dtheta[...] = dth
     return loss
+
+
+def loss_iceflow_transient(theta: np.ndarray, simulation: Inversion) -> float:
+    """loss_iceflow_transient(θ, simulation, pmap) (inversion_utils.jl:287-296): the loss of SIA2D_grad_b(θ) alone -- forward
+    solves, the empirical loss with its weights, the time-aggregated and regularisation terms -- whatever adjoint is configured
+    (the function the reference's test_grad_finite_diff differences, test/test_grad_loss.jl:262-265)."""
+    p = simulation.parameters
+    saved = p.UDE.grad
+    p.UDE.grad = DummyAdjoint(grad_function=lambda th: np.zeros_like(th), VJP_method=DiscreteVJP())
+    try:
+        return SIA2D_grad_b(np.zeros_like(np.asarray(theta, dtype=np.float64)), theta, simulation, _loss_only=True)
+    finally:
+        p.UDE.grad = saved
 
 
 def _run_prediction(sim: Prediction):
