@@ -407,10 +407,12 @@ end
 # loss / backward_loss(::TikhonovRegularization, a, Δx, Δy, mask) (Regularization.jl:92-126) on one field
 function tikhonov_HIP(b::Batch, a::Matrix{Float64}, Δx::Real, Δy::Real, mask::Union{Nothing, Matrix{Bool}} = nothing)
     l = Ref(0.0); grad = similar(a)
-    m = isnothing(mask) ? C_NULL : pointer(convert(Matrix{UInt8}, mask))
-    GC.@preserve mask check(ccall((:odinn_tikhonov, lib), Cint,
+    # (the UInt8 copy is a local that lives across the ccall: `pointer(convert(...))` of a temporary would dangle, and
+    #  GC.@preserve of the Bool matrix does not root its converted copy)
+    m8 = isnothing(mask) ? nothing : convert(Matrix{UInt8}, mask)
+    GC.@preserve m8 check(ccall((:odinn_tikhonov, lib), Cint,
                 (Ptr{Cvoid}, Cint, Cint, Cdouble, Cdouble, Ptr{Float64}, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}),
-                b.h, size(a, 1), size(a, 2), Δx, Δy, a, m, l, grad))
+                b.h, size(a, 1), size(a, 2), Δx, Δy, a, isnothing(m8) ? Ptr{UInt8}(C_NULL) : pointer(m8), l, grad))
     return l[], grad
 end
 # per-glacier pieces of the last gradient call: θ.IC (gradient.jl:262-271,507-516) and the slots of a PerGlacierModel (Model.jl:208-224)

@@ -739,6 +739,8 @@ class TrainableComponents:
             raise ValueError("θ does not match the model's parameter vector")
         self._model.theta = v.copy()
 
+    θ = theta  # the reference's field name: `model.trainable_components.θ = v` (inversion_utils.jl:483)
+
     def split_theta(self, theta, glacier_idx: int):
         """splitθ (Model.jl:189-200): the part of θ one glacier's simulation sees -- a FunctionalModel's parameters whole, a
         PerGlacierModel's / the initial condition's own slot only.  Returns {key: array}."""

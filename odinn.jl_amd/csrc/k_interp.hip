@@ -582,16 +582,17 @@ int launch_interp_theta_active(hipStream_t st, Pools P, const LawDev& L, int n_h
 // skipped, fixed summation order.  The velocity kernels used to keep P accumulators per THREAD in global memory (2 x 8 B x P of
 // traffic per node: 1.48 ms per call at 8 x 512^2 for the 83-parameter default net, ten times a reverse stage).
 constexpr int NBP_BLK = 64;  // workgroups per glacier
-template <class AR, bool FIXED>
-__global__ __launch_bounds__(NT) void k_node_backprop(Pools P, LawDev L, int g0, int g_last, long long end_all,
+// NWV: wavefronts per workgroup (NW; 1 for networks whose NW x P accumulators do not fit the LDS -- see launch_node_backprop)
+template <class AR, bool FIXED, int NWV = NW>
+__global__ __launch_bounds__(64 * NWV) void k_node_backprop(Pools P, LawDev L, int g0, int g_last, long long end_all,
                                                       const double* __restrict__ nodeH, const double* __restrict__ nodeS,
                                                       const double* __restrict__ nodeV, double* __restrict__ part) {
   extern __shared__ double nb_dyn[];
-  __shared__ double stage[NW][WG_SLOTS][WG_LD];
+  __shared__ double stage[NWV][WG_SLOTS][WG_LD];
   double* accs = nb_dyn;
-  int* order = reinterpret_cast<int*>(nb_dyn + (size_t)NW * L.P);
-  const int lane = threadIdx.x & 63, w = wave_id();
-  for (int k = threadIdx.x; k < NW * L.P; k += NT) accs[k] = 0.0;
+  int* order = reinterpret_cast<int*>(nb_dyn + (size_t)NWV * L.P);
+  const int lane = threadIdx.x & 63, w = NWV == 1 ? 0 : wave_id();
+  for (int k = threadIdx.x; k < NWV * L.P; k += 64 * NWV) accs[k] = 0.0;
   if (threadIdx.x == 0) mlp_grad_order(L, order);
   __syncthreads();
   const WaveAcc A{stage[w], order, accs + (size_t)w * L.P};
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(NT) void k_node_backprop(Pools P, LawDev L, int g0,
   const long long off = P.gd[gidx].offd, n = seg_len(P, gidx, g_last, end_all);
   const double T = P.gd[gidx].T;
   const long long nchunk = (n + 63) / 64;
-  for (long long c = (long long)blockIdx.x * NW + w; c < nchunk; c += (long long)gridDim.x * NW) {
+  for (long long c = (long long)blockIdx.x * NWV + w; c < nchunk; c += (long long)gridDim.x * NWV) {
     const long long i = c * 64 + lane;
     const bool ok = i < n;
     const double wgt = ok ? nodeV[off + i] : 0.0;
@@ -610,10 +611,10 @@ __global__ __launch_bounds__(NT) void k_node_backprop(Pools P, LawDev L, int g0,
   }
   __syncthreads();
   double* out = part + ((size_t)blockIdx.y * NBP_BLK + blockIdx.x) * L.P;
-  for (int k = threadIdx.x; k < L.P; k += NT) {
+  for (int k = threadIdx.x; k < L.P; k += 64 * NWV) {
     double s = 0.0;
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) s += accs[(size_t)ww * L.P + k];
+    for (int ww = 0; ww < NWV; ++ww) s += accs[(size_t)ww * L.P + k];
     out[k] = s;
   }
 }
@@ -632,8 +633,16 @@ size_t node_backprop_part_count(int ng, int Pn) { return (size_t)ng * NBP_BLK * 
 int launch_node_backprop(hipStream_t st, Pools P, const LawDev& L, int g0, int ng, long long end_all, const double* nodeH,
                          const double* nodeS, const double* nodeV, double* part, double* dth, int accumulate) {
   const size_t dyn = interp_batch_lds_bytes(L.P);
-  if (dyn > 30 * 1024) return 1;
   const dim3 grid(NBP_BLK, ng);
+  if (dyn > 30 * 1024) {
+    // wide networks (the 2-5-8-20-30-10-1 net of the reference's diffusivity MWE: P = 1194): NW x P accumulators do not fit next to
+    // the staging area -- one wavefront per workgroup, P accumulators (12 B per parameter: up to MAXP = 2048 parameters)
+    const size_t dyn1 = (size_t)L.P * sizeof(double) + (size_t)L.P * sizeof(int);
+    if (dyn1 > 30 * 1024) return 1;
+    hipLaunchKernelGGL((k_node_backprop<ArchRT, false, 1>), grid, dim3(64), dyn1, st, P, L, g0, g0 + ng - 1, end_all, nodeH, nodeS, nodeV, part);
+    hipLaunchKernelGGL(k_node_backprop_sum, dim3(L.P, ng), dim3(64), 0, st, L.P, g0, part, dth, accumulate);
+    return 0;
+  }
   if (interp_law_is<ArchDef>(L))
     hipLaunchKernelGGL((k_node_backprop<ArchDef, true>), grid, dim3(NT), dyn, st, P, L, g0, g0 + ng - 1, end_all, nodeH, nodeS, nodeV, part);
   else if (interp_law_is<Arch16>(L))

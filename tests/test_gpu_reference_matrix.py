@@ -9,10 +9,10 @@ SIA2D_grad_b / loss_iceflow_transient), on a synthetic stand-in for RGI60-11.036
 cannot be downloaded here).  `tests/REFERENCE_MATRIX.md` maps row -> test id -> achieved numbers; every run appends its
 numbers to gpurun_out/reference_matrix.jsonl.
 
-Set-up differences from the reference, all stated in REFERENCE_MATRIX.md: synthetic glacier(s); mass-balance rows run
-(2010, 2014) instead of (1980, 2019) with a linear-elevation stand-in for TImodel1; finite differences are central
-differences with one Richardson step instead of FiniteDifferences.jl's adaptive central_fdm(3, 1); solver reltol 1e-10 on
-both sides of the comparison."""
+Set-up differences from the reference, all stated in REFERENCE_MATRIX.md: synthetic glacier(s); a linear-elevation stand-in
+for TImodel1 in the mass-balance rows (same tspan (1980, 2019)); finite differences are central differences with one
+Richardson step instead of FiniteDifferences.jl's adaptive central_fdm(3, 1); solver reltol 1e-10 on both sides of the
+comparison."""
 import json
 import os
 

@@ -280,7 +280,8 @@ def test_velocity_theta_path_of_the_U_law_honours_linear_interpolation(gpu, adjo
 
 def _y_law(gpu, ph, arch="default"):
     from test_gpu_parity import _mlp_pair
-    widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "light": ([2, 3, 1], [1, 2])}[arch]
+    widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "light": ([2, 3, 1], [1, 2]),
+                    "wide": ([2, 5, 8, 20, 30, 10, 1], [3, 3, 1, 1, 1, 2])}[arch]  # wide: P = 1194, the reference's diffusivity MWE
     return _mlp_pair(gpu, widths, acts, [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
 
 
@@ -310,6 +311,26 @@ def test_surface_V_with_the_Y_law_target_D_hybrid(gpu, interp, C):
     w1, w2 = rng.standard_normal((nx, ny)), rng.standard_normal((nx, ny))
     # (the H-partial contains a forward difference with step 1e-4: two evaluations agree to ~1e-16 / 1e-4 of the law's scale)
     assert rel_l2(b.surface_V_vjp_H(0, w1, w2, H0), O.vjp_surface_V_H(w1, w2, H0, B, 50.0, 50.0, ph, law)) < 1e-7
+    assert rel_l2(b.surface_V_vjp_theta(0, w1, w2, H0), O.vjp_surface_V_theta(w1, w2, H0, B, 50.0, 50.0, ph, law)) < 1e-9
+    b.close()
+
+
+def test_velocity_pullback_theta_with_a_wide_network_and_exact_backprop(gpu):
+    """interpolation = :None with a network of 1194 parameters (2-5-8-20-30-10-1, scripts/MWEs/inversion_diffusivity): the NW x P
+    wave accumulators of k_node_backprop do not fit the LDS -- the one-wavefront-per-workgroup instantiation takes over (the call
+    used to fail with ODINN_ERR_UNSUPPORTED).  surface_V's theta-VJP against the oracle."""
+    ph = O.Phys()
+    om, gm, th = _y_law(gpu, ph, "wide")
+    assert th.size == 1194
+    law = O.Law(kind=O.LAW_NN_Y, mlp=om, theta=th, T=-5.0, interpolation="none", n_interp_half=20)
+    nx, ny = 70, 53
+    H0, B = O.synthetic_alpine(nx, ny)
+    b = gpu.GlacierBatch([(nx, ny)], [50.0], T=[-5.0])
+    b.set_fields(0, H0, B)
+    b.set_law(gpu.LAW_NN_Y, gm, th)
+    b.set_grad_interpolation(gpu._lib.GRAD_INTERP_NONE, 75)
+    rng = np.random.default_rng(7)
+    w1, w2 = rng.standard_normal((nx, ny)), rng.standard_normal((nx, ny))
     assert rel_l2(b.surface_V_vjp_theta(0, w1, w2, H0), O.vjp_surface_V_theta(w1, w2, H0, B, 50.0, 50.0, ph, law)) < 1e-9
     b.close()
 
