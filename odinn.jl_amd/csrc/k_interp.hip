@@ -575,6 +575,403 @@ int launch_interp_theta_active(hipStream_t st, Pools P, const LawDev& L, int n_h
   return 0;
 }
 
+// ---- the same contraction WITHOUT a sort: order statistics by selection, interval sums by exact binning ----------------------------
+// What the contraction needs from "the nodes in Hbar order" is (a) 2 n order statistics of Hbar per glacier (the type-7 quantiles read
+// sH[lo + j] and sH[lo + j + 1] at n probabilities) and (b) per knot interval the sums of v (1 - w) and v w.  Neither needs the
+// permutation:
+//   (a) SELECTION.  k_sel_max: amax = max Hbar per glacier (atomicMax on the bit patterns).  k_sel_hist: a histogram of the values
+//       strictly inside (0, amax) over SEL_NB equal-width bins of [0, amax) (integer atomics: order-free).  k_sel_targets: the scanned
+//       histogram gives, for every rank the quantiles ask for, its bin and its rank inside the bin.  k_sel_gather: the members of those
+//       (<= 2 n) bins are copied out (in any order -- a multiset).  k_sel_pick: one workgroup per target selects the exact order
+//       statistic inside its bin: MSB-first radix selection on the bit patterns until <= SEL_LDS candidates remain, then a rank count
+//       in LDS.  EXACT: the same doubles the sorted array holds at those ranks, so the knots are bit-identical to the sort's.
+//   (b) BINNING.  Every node finds its knot interval by binary search and adds its two terms into the interval's accumulators.  To keep
+//       the sums independent of the order of the additions (run-to-run bitwise reproducibility, which the sorted, fixed-order
+//       sums had) the accumulators are FIXED-POINT: a term x is split exactly into hi = rint(x / s1), lo = rint((x - hi s1) / s2)
+//       with s1 = 2^(e - 39), s2 = 2^(e - 79), 2^e > max |v| of the glacier; hi and lo are added with 64-bit integer atomics (LDS per
+//       workgroup, then global), |hi|, |lo| < 2^40 per term: exact integer sums for up to 2^23 terms per interval per glacier, the
+//       only rounding is the 2^-80 max|v| quantisation of lo -- 2^27 times finer than a double's ulp at max |v|.
+// Per evaluation: 9 launches and ~48 B per active node instead of the 64-bit-key radix / merge sort (8 passes of 32 B per node or
+// ~12 merge launches), its gathers and its memsets.  ODINN_INTERP_SELECT=0 keeps the sort (A/B, and the knot-identity test).
+constexpr int SEL_NB = 8192;    // histogram bins per glacier
+constexpr int SEL_LDS = 256;    // candidates the final rank count handles in LDS (one per thread of k_sel_pick)
+constexpr int SEL_BLK_MAX = 64; // workgroups per glacier of the streaming kernels
+
+__device__ __forceinline__ int sel_bin(double h, double inv) {
+  int k = (int)(h * inv);
+  return k < 0 ? 0 : (k > SEL_NB - 1 ? SEL_NB - 1 : k);
+}
+// amax[g] = max Hbar, vmax[g] = max |v| over the glacier's active nodes (bit patterns of non-negative doubles order like the values)
+__global__ __launch_bounds__(256) void k_sel_max(const long long* __restrict__ aoff, const unsigned* __restrict__ act,
+                                                 const double* __restrict__ H, const double* __restrict__ V,
+                                                 unsigned long long* __restrict__ amax, unsigned long long* __restrict__ vmax) {
+  const int g = blockIdx.y;
+  const long long lo = aoff[g], hi = aoff[g + 1];
+  double mh = 0.0, mv = 0.0;
+  for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long long)gridDim.x * 256) {
+    const unsigned q = act[i];
+    mh = fmax(mh, H[q]);
+    mv = fmax(mv, fabs(V[q]));
+  }
+  mh = wave_max(mh); mv = wave_max(mv);
+  if ((threadIdx.x & 63) == 0) {
+    if (mh > 0.0) atomicMax(amax + g, (unsigned long long)__double_as_longlong(mh));
+    if (mv > 0.0) atomicMax(vmax + g, (unsigned long long)__double_as_longlong(mv));
+  }
+}
+__global__ __launch_bounds__(256) void k_sel_hist(const long long* __restrict__ aoff, const unsigned* __restrict__ act,
+                                                  const double* __restrict__ H, const unsigned long long* __restrict__ amax,
+                                                  unsigned* __restrict__ hist) {
+  __shared__ unsigned sh[SEL_NB];
+  const int g = blockIdx.y;
+  const double am = __longlong_as_double((long long)amax[g]);
+  if (!(am > 0.0)) return;
+  for (int k = threadIdx.x; k < SEL_NB; k += 256) sh[k] = 0u;
+  __syncthreads();
+  const double inv = (double)SEL_NB / am;
+  const long long lo = aoff[g], hi = aoff[g + 1];
+  for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long long)gridDim.x * 256) {
+    const double h = H[act[i]];
+    if (h > 0.0 && h < am) atomicAdd(&sh[sel_bin(h, inv)], 1u);
+  }
+  __syncthreads();
+  unsigned* out = hist + (size_t)g * SEL_NB;
+  for (int k = threadIdx.x; k < SEL_NB; k += 256)
+    if (sh[k]) atomicAdd(out + k, sh[k]);
+}
+// one workgroup per glacier: m = #values strictly inside (0, amax); for every quantile target its two ranks' (bin, rank in bin);
+// goff[bin] = offset of a needed bin's members in the glacier's gather area (-1: not needed)
+__global__ __launch_bounds__(1024) void k_sel_targets(const unsigned* __restrict__ hist, int n, unsigned* __restrict__ m_all,
+                                                      int* __restrict__ goff, int4* __restrict__ tgt) {
+  __shared__ unsigned cum[SEL_NB];   // inclusive
+  __shared__ unsigned char need[SEL_NB];
+  __shared__ unsigned wsum[16];
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  constexpr int PER = SEL_NB / 1024;
+  const unsigned* hg = hist + (size_t)g * SEL_NB;
+  auto block_excl_scan = [&](unsigned mine, unsigned& total) {  // exclusive prefix of one value per thread (fixed shape)
+    unsigned inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < w) base += wsum[k];
+      tot += wsum[k];
+    }
+    total = tot;
+    return base + inc - mine;
+  };
+  unsigned loc[PER], sum = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { loc[k] = hg[t * PER + k]; sum += loc[k]; }
+  unsigned m;
+  unsigned run = block_excl_scan(sum, m);
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { run += loc[k]; cum[t * PER + k] = run; need[t * PER + k] = 0; }
+  __syncthreads();
+  if (t == 0) m_all[g] = m;
+  auto locate = [&](unsigned r, int& bin, int& rk) {  // first bin with cum[bin] > r
+    int lo = 0, hi = SEL_NB - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cum[mid] > r) hi = mid; else lo = mid + 1;
+    }
+    bin = lo;
+    rk = (int)(r - (lo > 0 ? cum[lo - 1] : 0u));
+  };
+  if (t < n && m > 0) {  // knots_body's quantile arithmetic
+    const double p = (double)(t + 1) / (double)(n + 1);
+    const double h = (double)(m - 1) * p;
+    long long j = (long long)floor(h);
+    const long long jmax = m >= 2 ? (long long)m - 2 : 0;
+    if (j > jmax) j = jmax;
+    if (j < 0) j = 0;
+    const long long j1 = j + 1 < (long long)m ? j + 1 : (long long)m - 1;
+    int4 q;
+    locate((unsigned)j, q.x, q.y);
+    locate((unsigned)j1, q.z, q.w);
+    need[q.x] = 1; need[q.z] = 1;  // (benign races: every writer stores 1)
+    tgt[(size_t)g * KMAX + t] = q;
+  }
+  __syncthreads();
+  unsigned cnt = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) cnt += need[t * PER + k] ? loc[k] : 0u;
+  unsigned tot;
+  unsigned off = block_excl_scan(cnt, tot);
+  int* go = goff + (size_t)g * SEL_NB;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const bool nd = need[t * PER + k] != 0;
+    go[t * PER + k] = nd ? (int)off : -1;
+    if (nd) off += loc[k];
+  }
+}
+__global__ __launch_bounds__(256) void k_sel_gather(const long long* __restrict__ aoff, const unsigned* __restrict__ act,
+                                                    const double* __restrict__ H, const unsigned long long* __restrict__ amax,
+                                                    const int* __restrict__ goff, unsigned* __restrict__ cursor, double* __restrict__ buf) {
+  const int g = blockIdx.y;
+  const double am = __longlong_as_double((long long)amax[g]);
+  if (!(am > 0.0)) return;
+  const double inv = (double)SEL_NB / am;
+  const long long lo = aoff[g], hi = aoff[g + 1];
+  const int* go = goff + (size_t)g * SEL_NB;
+  unsigned* cu = cursor + (size_t)g * SEL_NB;
+  for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long long)gridDim.x * 256) {
+    const double h = H[act[i]];
+    if (h > 0.0 && h < am) {
+      const int b = sel_bin(h, inv);
+      const int o = go[b];
+      if (o >= 0) buf[lo + o + atomicAdd(cu + b, 1u)] = h;
+    }
+  }
+}
+// the rk-th smallest (0-based) of e[0 .. c): radix selection on the bit patterns (positive doubles), then a rank count in LDS
+__device__ double sel_kth(const double* __restrict__ e, unsigned c, unsigned rk, unsigned long long* cand, unsigned* cnt, unsigned* sctl) {
+  unsigned long long prefix = 0ull, mask = 0ull;
+  unsigned cur = c, r = rk;
+  int shift = 56;
+  while (cur > (unsigned)SEL_LDS && shift >= 0) {
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) cnt[k] = 0u;
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < c; i += blockDim.x) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong(e[i]);
+      if ((b & mask) == prefix) atomicAdd(&cnt[(unsigned)(b >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned acc = 0, d = 0;
+      for (; d < 256; ++d) {
+        if (acc + cnt[d] > r) break;
+        acc += cnt[d];
+      }
+      sctl[0] = d; sctl[1] = r - acc; sctl[2] = cnt[d];
+    }
+    __syncthreads();
+    prefix |= (unsigned long long)sctl[0] << shift;
+    mask |= 255ull << shift;
+    r = sctl[1];
+    cur = sctl[2];
+    shift -= 8;
+    __syncthreads();
+  }
+  if (cur > (unsigned)SEL_LDS) return __longlong_as_double((long long)prefix);  // all 64 bits fixed: every candidate is this value
+  // compact the candidates into LDS (any order), then count ranks: the value whose rank interval contains r
+  if (threadIdx.x == 0) sctl[3] = 0u;
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < c; i += blockDim.x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(e[i]);
+    if ((b & mask) == prefix) cand[atomicAdd(&sctl[3], 1u)] = b;
+  }
+  __syncthreads();
+  const unsigned nc = sctl[3];
+  __shared__ unsigned long long s_res;
+  for (unsigned i = threadIdx.x; i < nc; i += blockDim.x) {
+    const unsigned long long v = cand[i];
+    unsigned less = 0, eq = 0;
+#pragma unroll 8
+    for (unsigned j = 0; j < nc; ++j) {
+      const unsigned long long u = cand[j];
+      less += u < v ? 1u : 0u;
+      eq += u == v ? 1u : 0u;
+    }
+    if (less <= r && r < less + eq) s_res = v;  // (every thread that qualifies holds the same value)
+  }
+  __syncthreads();
+  const double out = __longlong_as_double((long long)s_res);
+  __syncthreads();
+  return out;
+}
+__global__ __launch_bounds__(256) void k_sel_pick(const long long* __restrict__ aoff, const unsigned* __restrict__ hist,
+                                                  const unsigned* __restrict__ m_all, const int* __restrict__ goff,
+                                                  const int4* __restrict__ tgt, const double* __restrict__ buf, double2* __restrict__ os) {
+  __shared__ unsigned long long cand[SEL_LDS];
+  __shared__ unsigned cnt[256];
+  __shared__ unsigned sctl[4];
+  const int g = blockIdx.y, t = blockIdx.x;
+  if (m_all[g] == 0u) return;
+  const int4 q = tgt[(size_t)g * KMAX + t];
+  const unsigned* hg = hist + (size_t)g * SEL_NB;
+  const int* go = goff + (size_t)g * SEL_NB;
+  const double* base = buf + aoff[g];
+  const double a = sel_kth(base + go[q.x], hg[q.x], (unsigned)q.y, cand, cnt, sctl);
+  const double b = (q.z == q.x && q.w == q.y) ? a : sel_kth(base + go[q.z], hg[q.z], (unsigned)q.w, cand, cnt, sctl);
+  if (threadIdx.x == 0) os[(size_t)g * KMAX + t] = make_double2(a, b);
+}
+// knots_body with the order statistics handed in (same arithmetic, same de-duplication and ranking)
+__global__ __launch_bounds__(KMAX) void k_sel_knots(const unsigned long long* __restrict__ amax, const unsigned* __restrict__ m_all,
+                                                    const double2* __restrict__ os, int n, double* __restrict__ knots_all,
+                                                    int* __restrict__ M_all) {
+  __shared__ double c[KMAX];
+  __shared__ int first[KMAX];
+  const int g = blockIdx.x, i = threadIdx.x;
+  double* knots = knots_all + (size_t)g * KMAX;
+  const double am = __longlong_as_double((long long)amax[g]);
+  if (!(am > 0.0)) {
+    if (i == 0) M_all[g] = 0;
+    return;
+  }
+  const long long m = (long long)m_all[g];
+  bool valid = false;
+  double v = 0.0;
+  if (i < n) {
+    const double t = (double)i / (double)(n - 1);
+    v = (1.0 - t) * 0.0 + t * am;
+    valid = true;
+  } else if (i < 2 * n && m > 0) {
+    const double p = (double)(i - n + 1) / (double)(n + 1);
+    const double h = (double)(m - 1) * p;
+    long long j = (long long)floor(h);
+    const long long jmax = m >= 2 ? m - 2 : 0;
+    if (j > jmax) j = jmax;
+    if (j < 0) j = 0;
+    double gam = h - (double)j;
+    gam = gam < 0.0 ? 0.0 : (gam > 1.0 ? 1.0 : gam);
+    const double2 ab = os[(size_t)g * KMAX + (i - n)];
+    v = ab.x + gam * (ab.y - ab.x);
+    valid = true;
+  }
+  c[i] = valid ? v : -1.0;
+  __syncthreads();
+  int isfirst = valid ? 1 : 0;
+  if (valid)
+    for (int j = 0; j < i; ++j)
+      if (c[j] == v) { isfirst = 0; break; }
+  first[i] = isfirst;
+  __syncthreads();
+  if (isfirst) {
+    int rank = 0;
+    for (int j = 0; j < 2 * n; ++j) rank += (first[j] && c[j] < v) ? 1 : 0;
+    knots[rank] = v;
+  }
+  if (i == 0) {
+    int M = 0;
+    for (int j = 0; j < 2 * n; ++j) M += first[j];
+    M_all[g] = M;
+  }
+}
+// fixed-point scales of a glacier: s1 = 2^(e - 39), s2 = 2^(e - 79) with 2^e > vmax (0: the glacier contributes nothing)
+__device__ __forceinline__ bool sel_scales(double vmax, double& s1, double& s2) {
+  if (!(vmax > 0x1p-800)) return false;  // (weights below 2^-800 are dropped)
+  int e;
+  (void)frexp(vmax, &e);  // vmax = f 2^e, f in [0.5, 1)
+  s1 = ldexp(1.0, e - 39);
+  s2 = ldexp(1.0, e - 79);
+  return true;
+}
+__global__ __launch_bounds__(256) void k_sel_sums(const long long* __restrict__ aoff, const unsigned* __restrict__ act,
+                                                  const double* __restrict__ H, const double* __restrict__ V,
+                                                  const unsigned long long* __restrict__ vmax, const double* __restrict__ knots_all,
+                                                  const int* __restrict__ M_all, unsigned long long* __restrict__ bins) {
+  __shared__ double kn[KMAX];
+  __shared__ unsigned long long acc[KMAX][4];
+  const int g = blockIdx.y, M = M_all[g];
+  double s1, s2;
+  if (M < 2 || !sel_scales(__longlong_as_double((long long)vmax[g]), s1, s2)) return;
+  for (int k = threadIdx.x; k < M; k += 256) {
+    kn[k] = knots_all[(size_t)g * KMAX + k];
+    acc[k][0] = 0ull; acc[k][1] = 0ull; acc[k][2] = 0ull; acc[k][3] = 0ull;
+  }
+  __syncthreads();
+  const double i1 = 1.0 / s1, i2 = 1.0 / s2;  // (powers of two: exact)
+  auto add = [&](int k, int slot, double x) {
+    const double hi = rint(x * i1);
+    const double lo = rint(fma(-hi, s1, x) * i2);
+    atomicAdd(&acc[k][slot], (unsigned long long)(long long)hi);
+    atomicAdd(&acc[k][slot + 1], (unsigned long long)(long long)lo);
+  };
+  const long long lo_ = aoff[g], hi_ = aoff[g + 1];
+  for (long long i = lo_ + (long long)blockIdx.x * 256 + threadIdx.x; i < hi_; i += (long long)gridDim.x * 256) {
+    const unsigned q = act[i];
+    const double h = H[q], v = V[q];
+    if (!(h > 0.0) || v == 0.0) continue;
+    int a = 0, b = M;  // first knot > h
+    while (a < b) {
+      const int mid = (a + b) >> 1;
+      if (kn[mid] <= h) a = mid + 1; else b = mid;
+    }
+    int k = a - 1;
+    k = k < 0 ? 0 : (k > M - 2 ? M - 2 : k);
+    const double x0 = kn[k], w = (h - x0) / (kn[k + 1] - x0);  // (a true division: see interval_sums_body)
+    add(k, 0, v * (1.0 - w));
+    add(k, 2, v * w);
+  }
+  __syncthreads();
+  unsigned long long* out = bins + (size_t)g * KMAX * 4;
+  for (int k = threadIdx.x; k < 4 * M; k += 256) {
+    const unsigned long long x = acc[k >> 2][k & 3];
+    if (x) atomicAdd(out + k, x);
+  }
+}
+__global__ __launch_bounds__(KMAX) void k_sel_ab(const unsigned long long* __restrict__ vmax, const int* __restrict__ M_all,
+                                                 const unsigned long long* __restrict__ bins, double* __restrict__ ab_all) {
+  const int g = blockIdx.x, k = threadIdx.x;
+  double* ab = ab_all + (size_t)g * 2 * KMAX;
+  double s1, s2, a = 0.0, b = 0.0;
+  if (k < M_all[g] - 1 && sel_scales(__longlong_as_double((long long)vmax[g]), s1, s2)) {
+    const unsigned long long* x = bins + ((size_t)g * KMAX + k) * 4;
+    a = fma((double)(long long)x[0], s1, (double)(long long)x[1] * s2);
+    b = fma((double)(long long)x[2], s1, (double)(long long)x[3] * s2);
+  }
+  ab[k] = a; ab[KMAX + k] = b;
+}
+// scratch of one evaluation (per lane): zeroed block [amax G | vmax G | hist G NB | cursor G NB | bins G KMAX 4] (8-byte words first),
+// then goff (G NB ints), tgt (G KMAX int4), os (G KMAX double2), m (G)
+size_t interp_select_scratch_bytes(int G, size_t* zero_bytes) {
+  const size_t z = (size_t)G * 8 * 2 + (size_t)G * KMAX * 4 * 8 + (size_t)G * SEL_NB * 4 * 2;
+  if (zero_bytes) *zero_bytes = z;
+  return z + (size_t)G * SEL_NB * 4 + (size_t)G * KMAX * 16 * 2 + (size_t)G * 4 + 64;
+}
+// all G glaciers; buf: n_act doubles (the gather areas); same results as launch_interp_theta_active up to the rounding of the sums
+int launch_interp_theta_select(hipStream_t st, Pools P, const LawDev& L, int n_half, int G, long long n_act, const double* nodeH,
+                               const double* nodeV, const unsigned* act, const long long* aoff, double* buf, void* scratch,
+                               double* knots, int* M, double* ab, double* dth, int accumulate, const unsigned long long* amax_in,
+                               const unsigned long long* vmax_in) {
+  // amax_in / vmax_in (both or neither): the per-glacier maxima came with the node arrays (the fused reverse step's emission)
+  if (2 * n_half > KMAX || n_half < 2 || n_act < 1 || n_act >= (1ll << 31)) return 1;
+  size_t zb = 0;
+  (void)interp_select_scratch_bytes(G, &zb);
+  char* p = static_cast<char*>(scratch);
+  unsigned long long* amax_own = reinterpret_cast<unsigned long long*>(p);
+  unsigned long long* vmax_own = amax_own + G;
+  unsigned long long* bins = vmax_own + G;
+  const unsigned long long* amax = amax_in ? amax_in : amax_own;
+  const unsigned long long* vmax = vmax_in ? vmax_in : vmax_own;
+  unsigned* hist = reinterpret_cast<unsigned*>(bins + (size_t)G * KMAX * 4);
+  unsigned* cursor = hist + (size_t)G * SEL_NB;
+  int* goff = reinterpret_cast<int*>(p + zb);
+  int4* tgt = reinterpret_cast<int4*>(goff + (size_t)G * SEL_NB);
+  double2* os = reinterpret_cast<double2*>(tgt + (size_t)G * KMAX);
+  unsigned* m = reinterpret_cast<unsigned*>(os + (size_t)G * KMAX);
+  if (hipMemsetAsync(p, 0, zb, st) != hipSuccess) return 2;
+  const long long per = (n_act + G - 1) / G;
+  const unsigned blk = (unsigned)std::max<long long>(1, std::min<long long>(SEL_BLK_MAX, (per + 4095) / 4096));
+  const dim3 grid(blk, G);
+  if (!amax_in) hipLaunchKernelGGL(k_sel_max, grid, dim3(256), 0, st, aoff, act, nodeH, nodeV, amax_own, vmax_own);
+  hipLaunchKernelGGL(k_sel_hist, grid, dim3(256), 0, st, aoff, act, nodeH, amax, hist);
+  hipLaunchKernelGGL(k_sel_targets, dim3(G), dim3(1024), 0, st, hist, n_half, m, goff, tgt);
+  hipLaunchKernelGGL(k_sel_gather, grid, dim3(256), 0, st, aoff, act, nodeH, amax, goff, cursor, buf);
+  hipLaunchKernelGGL(k_sel_pick, dim3(n_half, G), dim3(256), 0, st, aoff, hist, m, goff, tgt, buf, os);
+  hipLaunchKernelGGL(k_sel_knots, dim3(G), dim3(KMAX), 0, st, amax, m, os, n_half, knots, M);
+  hipLaunchKernelGGL(k_sel_sums, grid, dim3(256), 0, st, aoff, act, nodeH, nodeV, vmax, knots, M, bins);
+  hipLaunchKernelGGL(k_sel_ab, dim3(G), dim3(KMAX), 0, st, vmax, M, bins, ab);
+  const size_t dyn = interp_batch_lds_bytes(L.P);
+  if (interp_law_is<ArchDef>(L))
+    hipLaunchKernelGGL((k_knot_backprop<ArchDef, true>), dim3(G), dim3(NT), dyn, st, P, L, 0, knots, M, ab, dth, accumulate);
+  else if (interp_law_is<Arch16>(L))
+    hipLaunchKernelGGL((k_knot_backprop<Arch16, true>), dim3(G), dim3(NT), dyn, st, P, L, 0, knots, M, ab, dth, accumulate);
+  else
+    hipLaunchKernelGGL((k_knot_backprop<ArchRT, false>), dim3(G), dim3(NT), dyn, st, P, L, 0, knots, M, ab, dth, accumulate);
+  return 0;
+}
+
 // ---- exact per-node backprop of emitted node weights (`interpolation = :None` in the surface-velocity pull-backs) -----------------
 // dth[g] (+)= sum over the dual nodes of glacier g of V[node] * d law / d theta at the node's inputs -- (T_g, Hbar) for the Y law,
 // (Hbar, |grad S|) for the U law -- with the node weights V and inputs emitted by the velocity kernels (k_surfV_vjp: emitH / emitV /

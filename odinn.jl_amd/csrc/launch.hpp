@@ -52,6 +52,11 @@ int launch_interp_theta_batch(hipStream_t st, Pools P, const LawDev& L, int n_ha
                               double* sV, unsigned* iA, unsigned* iB, unsigned* kA, unsigned* kB, void* tmp, size_t tmp_bytes,
                               double* knots, int* M, double* ab, double* dth, int accumulate);
 size_t interp_active_temp_bytes(long long n);
+size_t interp_select_scratch_bytes(int G, size_t* zero_bytes);
+int launch_interp_theta_select(hipStream_t st, Pools P, const LawDev& L, int n_half, int G, long long n_act, const double* nodeH,
+                               const double* nodeV, const unsigned* act, const long long* aoff, double* buf, void* scratch,
+                               double* knots, int* M, double* ab, double* dth, int accumulate,
+                               const unsigned long long* amax_in = nullptr, const unsigned long long* vmax_in = nullptr);
 int launch_interp_active(hipStream_t st, Pools P, int G, long long ntotd, const unsigned* gid, const unsigned* iota, const double* snaps,
                          int nslots, long long ntot, unsigned char* flags, void* tmp, size_t tmp_bytes, unsigned* act, unsigned* gid_act,
                          long long* aoff, unsigned* n_act_dev);

@@ -350,11 +350,14 @@ struct odinn_batch {
     unsigned *iA = nullptr, *iB = nullptr, *kA = nullptr, *kB = nullptr;
     void* tmp = nullptr;
     int* M = nullptr;
+    void* sel = nullptr;  // scratch of the sort-free contraction (launch_interp_theta_select)
   } ia_lane[IA_LANES_MAX];
   // node arrays: one SET more than lanes (set q % ia_sets, lane q % ia_lanes), so that the emitting kernel does not wait for the
   // contraction that is still running on the lane it will use
   static constexpr int IA_SETS_MAX = IA_LANES_MAX + 1;
   double *ia_nodeH[IA_SETS_MAX] = {}, *ia_nodeV[IA_SETS_MAX] = {};
+  unsigned long long* ia_setmax[IA_SETS_MAX] = {};  // [2 G] per set: max Hbar, max |weight| per glacier, raised by the emitting kernel
+  bool ia_emit_fused = false;                        // the node arrays of the current contraction carry those maxima
   hipEvent_t ev_set_done[IA_SETS_MAX] = {};
   bool ia_set_pending[IA_SETS_MAX] = {};
   int ia_sets = 0;
@@ -365,7 +368,8 @@ struct odinn_batch {
   long long* ia_aoff = nullptr;
   void* ia_sel_tmp = nullptr;
   size_t ia_sel_bytes = 0;
-  long long ia_nact = 0;  // 0: the dense sequence
+  long long ia_nact = 0;
+  bool ia_select = true;  // the sort-free contraction (ODINN_INTERP_SELECT=0: the radix sort of the active nodes)  // 0: the dense sequence
   bool interp_async = false;
   int ia_lanes = 0, ia_q = 0, ia_alloc = 0;
   bool ia_pending[IA_LANES_MAX] = {};
@@ -1803,6 +1807,7 @@ int odinn_batch_destroy(odinn_batch* b) {
     if (b->ia_stream[l]) { (void)hipStreamSynchronize(b->ia_stream[l]); (void)hipStreamDestroy(b->ia_stream[l]); }
     if (b->ev_emit[l]) (void)hipEventDestroy(b->ev_emit[l]);
     if (b->ev_done[l]) (void)hipEventDestroy(b->ev_done[l]);
+    if (b->ia_lane[l].sel) (void)hipFree(b->ia_lane[l].sel);
     if (l > 0) {  // (lane 0 aliases the batch's own arrays)
       odinn_batch::IaLane& a = b->ia_lane[l];
       dfree(a.sH); dfree(a.sV); dfree(a.knots); dfree(a.ab); dfree(a.iA); dfree(a.iB); dfree(a.kA); dfree(a.kB);
@@ -1814,6 +1819,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   if (b->ia_sel_tmp) (void)hipFree(b->ia_sel_tmp);
   for (int q_ = 0; q_ < odinn_batch::IA_SETS_MAX; ++q_) {
     if (q_ > 0) { dfree(b->ia_nodeH[q_]); dfree(b->ia_nodeV[q_]); }  // (set 0 aliases d_nodeH / d_nodeV)
+    dfree(b->ia_setmax[q_]);
     if (b->ev_set_done[q_]) (void)hipEventDestroy(b->ev_set_done[q_]);
   }
   dfree(b->d_dthq);
@@ -2199,6 +2205,7 @@ static int interp_async_setup(odinn_batch* b, int lanes) {
       CHK(dalloc(&a.knots, (size_t)b->G * INTERP_KMAX)); CHK(dalloc(&a.ab, (size_t)b->G * 2 * INTERP_KMAX)); CHK(dalloc(&a.M, (size_t)b->G));
       HIPCHK(hipMalloc(&a.tmp, std::max<size_t>(b->ib_tmp_bytes, 256)));
     }
+    if (!a.sel) HIPCHK(hipMalloc(&a.sel, interp_select_scratch_bytes(b->G, nullptr)));
     b->ia_pending[l] = false;
   }
   int sets = lanes + 1;
@@ -2206,6 +2213,7 @@ static int interp_async_setup(odinn_batch* b, int lanes) {
   for (int q = 0; q < sets; ++q) {
     if (q == 0) { b->ia_nodeH[0] = b->d_nodeH; b->ia_nodeV[0] = b->d_nodeV; }
     else if (!b->ia_nodeH[q]) { CHK(dalloc(&b->ia_nodeH[q], N)); CHK(dalloc(&b->ia_nodeV[q], N)); }
+    if (!b->ia_setmax[q]) CHK(dalloc(&b->ia_setmax[q], (size_t)2 * b->G));
     if (!b->ev_set_done[q]) HIPCHK(hipEventCreateWithFlags(&b->ev_set_done[q], hipEventDisableTiming));
     b->ia_set_pending[q] = false;
   }
@@ -2223,7 +2231,9 @@ static int interp_async_setup(odinn_batch* b, int lanes) {
   static const bool dense = std::getenv("ODINN_INTERP_ACTIVE") && std::getenv("ODINN_INTERP_ACTIVE")[0] == '0';
   int gbits = 0;
   while ((1ll << gbits) < (long long)b->G) ++gbits;
-  if (!dense && gbits <= 7 && b->solved) {
+  // (the composite (glacier, Hbar) sort key has room for 128 glaciers; the sort-free contraction has no such limit)
+  b->ia_select = sched_val(-1, "ODINN_INTERP_SELECT") != 0;
+  if (!dense && (gbits <= 7 || b->ia_select) && b->solved) {
     if (!b->ia_flags) {
       CHK(dalloc(&b->ia_flags, N)); CHK(dalloc(&b->ia_act, N)); CHK(dalloc(&b->ia_gid_act, N)); CHK(dalloc(&b->ia_nact_dev, (size_t)1));
       CHK(dalloc(&b->ia_aoff, (size_t)b->G + 1));
@@ -2267,12 +2277,31 @@ static int interp_async_begin(odinn_batch* b, double** nH, double** nV) {
   HIPCHK(hipMemsetAsync(*nV, 0, (size_t)b->ntotd * sizeof(double), b->stream));
   return ODINN_OK;
 }
+// ... the same for the fused reverse step's in-kernel emission: the kernel writes EVERY dual node of the glaciers that emit (zeros on
+// their ice-free tiles) and raises their maxima, so only the 16 G bytes of maxima are cleared -- a glacier whose maxima stay zero did
+// not emit, and the contraction skips it whatever its (stale) node entries hold
+static int interp_async_begin_fused(odinn_batch* b, double** nH, double** nV, unsigned long long** mx) {
+  if (b->ia_q >= odinn_batch::IA_SLOTS) CHK(interp_async_join(b));
+  const int q = b->ia_q % b->ia_sets;
+  *nH = b->ia_nodeH[q];
+  *nV = b->ia_nodeV[q];
+  *mx = b->ia_setmax[q];
+  if (b->ia_set_pending[q]) HIPCHK(hipStreamWaitEvent(b->stream, b->ev_set_done[q], 0));
+  HIPCHK(hipMemsetAsync(*mx, 0, (size_t)2 * b->G * sizeof(unsigned long long), b->stream));
+  return ODINN_OK;
+}
 static int interp_async_contract(odinn_batch* b, const Pools& P) {
   const int l = b->ia_q % b->ia_lanes, qs = b->ia_q % b->ia_sets;
   const odinn_batch::IaLane& a = b->ia_lane[l];
   HIPCHK(hipEventRecord(b->ev_emit[l], b->stream));
   HIPCHK(hipStreamWaitEvent(b->ia_stream[l], b->ev_emit[l], 0));
-  const int rc = b->ia_nact > 0
+  const int rc = (b->ia_nact > 0 && b->ia_select)
+                     ? launch_interp_theta_select(b->ia_stream[l], P, b->lawdev(), b->n_interp_half, b->G, b->ia_nact, b->ia_nodeH[qs],
+                                                  b->ia_nodeV[qs], b->ia_act, b->ia_aoff, a.sH, a.sel, a.knots, a.M, a.ab,
+                                                  b->d_dthq + (size_t)b->ia_q * b->G * b->P, 0,
+                                                  b->ia_emit_fused ? b->ia_setmax[qs] : nullptr,
+                                                  b->ia_emit_fused ? b->ia_setmax[qs] + b->G : nullptr)
+                 : b->ia_nact > 0
                      ? launch_interp_theta_active(b->ia_stream[l], P, b->lawdev(), b->n_interp_half, b->G, b->ia_nact, b->ia_nodeH[qs],
                                                   b->ia_nodeV[qs], b->ia_act, b->ia_gid_act, b->ia_aoff, b->d_ib_iota, a.sH, a.sV, a.iA, a.tmp,
                                                   b->ib_tmp_bytes, a.knots, a.M, a.ab, b->d_dthq + (size_t)b->ia_q * b->G * b->P, 0)
@@ -2309,6 +2338,7 @@ struct InterpAsyncScope {  // leaves no work behind on the lane streams, whichev
 // (low-priority lanes: 470; a high-priority batch stream brings 2 - 3 lanes back to 152, no better than one lane) -- that is with
 // five stage launches per reverse step; with ONE fused launch (k_adj_fused_strip<..., YT>) the lanes are the longer chain: 4.
 static int interp_async_enable(odinn_batch* b, bool useV, int lanes_default) {
+  b->ia_emit_fused = false;  // (the continuous adjoint's driver raises it for its fused emission)
   if (b->law_kind != ODINN_LAW_NN_Y) return ODINN_OK;
   CHK(ensure_interp_scratch(b));
   const int lanes = interp_async_lanes(b, useV, lanes_default);
@@ -3362,16 +3392,24 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
   // theta-VJP of the quadrature nodes in stage 1 (A-type laws), the interleaved snapshot pairs.  The decision is repeated by every
   // workgroup (~2 us), which pays while launch latency is a large part of a step: small and medium batches (measured rule
   // below); odinn_schedule.adj_sc / ODINN_ADJ_SC = 0 | 1 forces either.
-  bool rsc = fused_rev && theta_fused && !useV && FA.segs != nullptr;
-  {
+  // Y law through its table with the sort-free `:Linear` contraction on lanes: stage 1 of the fused step emits the node pairs itself
+  // (AdjFusedArgs::emitH) -- no k_vjp_theta launch, no memsets of the node arrays per step
+  bool emit_fused = false;
+  bool rsc = false;
+  auto decide_rsc = [&] {
+    rsc = fused_rev && (theta_fused || emit_fused) && !useV && FA.segs != nullptr;
     const int e = sched_val(b->sched.adj_sc, "ODINN_ADJ_SC");
     rsc = rsc && (e < 0 ? ntilesR_launch <= ODINN_ADJ_SC_MAX_TILES : e != 0);
-  }
-  if (rsc) {
-    CHK(sc_buffers(b));
-    if (!b->d_adj2) CHK(dalloc(&b->d_adj2, (size_t)G));
-    FA.post = AP; FA.post.loss_first = 0; FA.post.Hq = nullptr;
-  }
+  };
+  auto setup_rsc = [&]() -> int {
+    decide_rsc();
+    if (rsc) {
+      CHK(sc_buffers(b));
+      if (!b->d_adj2) CHK(dalloc(&b->d_adj2, (size_t)G));
+      FA.post = AP; FA.post.loss_first = 0; FA.post.Hq = nullptr;
+    }
+    return ODINN_OK;
+  };
   // polls as in do_solve: one step per stop at least, then the controller's estimate of what is left
   if (!b->d_est) CHK(dalloc(&b->d_est, (size_t)G));
   C.est_steps = b->d_est;
@@ -3385,10 +3423,19 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
   // (one lane while the five stage launches keep the GPU busy; with the fused reverse step of the tabulated Y law the contractions
   //  are the longer chain again -- 8 x 512^2, ms per gradient for 1 / 2 / 3 / 4 lanes: 145 / 135 / 126 / 121)
   CHK(interp_async_enable(b, useV, (fused_rev && ytab_rev) ? 4 : 1));
+  emit_fused = fused_rev && ytab_rev && !useV && b->interp_async && b->ia_select && b->ia_nact > 0 &&
+               b->grad_interp == ODINN_GRAD_INTERP_LINEAR && sched_val(-1, "ODINN_ADJ_EMIT_FUSED") != 0;
+  b->ia_emit_fused = emit_fused;
+  CHK(setup_rsc());
   while (nact > 0) {
     for (int s_ = 0; s_ < chunk; ++s_) {
       double* a0 = b->d_lam[p];
       double* a1 = b->d_lam[1 - p];
+      if (emit_fused) {  // the node arrays / maxima this launch's stage 1 emits into
+        unsigned long long* mx = nullptr;
+        CHK(interp_async_begin_fused(b, &FA.emitH, &FA.emitV, &mx));
+        FA.emit_amax = mx; FA.emit_vmax = mx + G;
+      }
       if (rsc) {
         // launch n reads state / AdjState / partials [n & 1], writes the other ones; it decides attempt n - 1
         const bool odd = (steps & 1) != 0;
@@ -3398,6 +3445,7 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
         FS.partF = odd ? b->d_part2 : FA.partF;
         FS.C = C; FS.C.next_cur = -1; FS.C.errpart = odd ? FA.partF : b->d_part2;
         launch_adj_fused_strip(ntilesR_launch, b->gd[0].use_Afield, rev_skip, adj_rows, b->stream, Pl, FS, 1);
+        if (emit_fused) CHK(interp_async_contract(b, Pl));
         p = 1 - p;
         ++steps;
         continue;
@@ -3444,6 +3492,10 @@ static int loss_grad_continuous_impl(odinn_batch* b, const double* theta, int P,
       // quadrature node reached: dtheta += w * J_theta(H_itp(t))^T lam(t)  (:497-503); A-type laws add
       // onto per-tile running sums that are reduced once after the solve
       if (theta_fused) {
+      } else if (emit_fused) {
+        // (the node the controller just reported is emitted by stage 1 of the NEXT launch; this launch's emission -- the node
+        //  reached by the step before -- is contracted now)
+        CHK(interp_async_contract(b, Pl));
       } else if (fused_rev)
         CHK(theta_vjp_launch(b, b->d_tmpA, b->d_lam[0], b->d_qw, -1, true, acc_inplace ? b->d_partsteps : nullptr, acc_inplace,
                              b->d_lam[1], theta_itp ? b->d_snaps : nullptr, b->d_adj));

@@ -74,7 +74,10 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
                                                  const double* __restrict__ Bp, AdjErr sEr, double* __restrict__ th_red,
                                                  [[maybe_unused]] double* __restrict__ Gp = nullptr,
                                                  [[maybe_unused]] const AdjRowCache<RC ? NR : 1>* rc = nullptr,
-                                                 [[maybe_unused]] const YtabRef yt = YtabRef{nullptr, nullptr, 0}) {
+                                                 [[maybe_unused]] const YtabRef yt = YtabRef{nullptr, nullptr, 0},
+                                                 [[maybe_unused]] double* __restrict__ Eh = nullptr,
+                                                 [[maybe_unused]] double* __restrict__ Ev = nullptr,
+                                                 [[maybe_unused]] double* __restrict__ emax = nullptr) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;
   constexpr bool ELDS = ODINN_ADJ_ELDS && !(RC && ODINN_ADJ_RC_EREG);
   const int r0 = NR * w;
@@ -130,13 +133,14 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
   auto node_face = [&](int gj, double2 hs_lo, double2 e_lo, double le_lo, double dx_lo, double hp_lo, double Pe_lo,
                        double2 hs_hi, double2 e_hi, double le_hi, double dx_hi, double hp_hi, double Pe_hi, double& D,
                        double& k00, double& k10, double& k01, double& k11, double& Mn, double& PLn, double& tw,
-                       [[maybe_unused]] double An_pf) {
+                       [[maybe_unused]] double An_pf, [[maybe_unused]] double* hbar = nullptr) {
     const double dyw = hs_hi.y - hs_lo.y, dye = e_hi.y - e_lo.y;
     const double qn = le_hi - le_lo;
     const double Pn = qn * clampn(dyw, hs_hi.x, hs_lo.x);
     const double Pn_e = dpp_shift(Pn, false);
     const double gx = (dx_lo + dx_hi) * g.hinv_dx, gy = (dyw + dye) * g.hinv_dy;
     const double Hs = hp_lo + hp_hi;  // 4 Hbar
+    if constexpr (YT) { if (S == 1 && hbar) *hbar = 0.25 * Hs; }
     const double gS2 = gx * gx + gy * gy;
     double An = g.A;
     if (AF) {
@@ -210,7 +214,20 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     const double dx_n = e_n.y - hs_n.y, hp_n = hs_n.x + e_n.x, qe_n = lee_n - le_n;
     const double Pe_n = qe_n * clampn(dx_n, e_n.x, hs_n.x);
     double D_c, k00, k10, k01, k11, Mn, PLn, tw;
-    node_face(gj, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, hs_n, e_n, le_n, dx_n, hp_n, Pe_n, D_c, k00, k10, k01, k11, Mn, PLn, tw, A_c);
+    [[maybe_unused]] double hbn = 0.0;
+    node_face(gj, hs_c, e_c, le_c, dx_c, hp_c, Pe_c, hs_n, e_n, le_n, dx_n, hp_n, Pe_n, D_c, k00, k10, k01, k11, Mn, PLn, tw, A_c,
+              (YT && S == 1 && Eh) ? &hbn : nullptr);
+    if constexpr (YT) {
+      if (S == 1 && Eh) {  // emit the node north-east of an OUTPUT cell (every dual node belongs to exactly one thread)
+        const bool own = lane >= FH && lane < FH + FOX && r0 + m >= FH && r0 + m <= (NR * TNW) - 1 - FH && gi <= g.nx - 2 && gj <= g.ny - 2;
+        if (own) {
+          const unsigned q = (unsigned)(gif + (g.nx - 1) * gj);
+          const double wv = a.qw * tw;
+          Eh[q] = hbn; Ev[q] = wv;
+          emax[0] = fmax(emax[0], hbn); emax[1] = fmax(emax[1], fabs(wv));
+        }
+      }
+    }
     if (S == 1 && th_red) {  // the node north-east of an OUTPUT cell belongs to this thread (every dual node to exactly one)
       const bool own = lane >= FH && lane < FH + FOX && r0 + m >= FH && r0 + m <= (NR * TNW) - 1 - FH && gi <= g.nx - 2 && gj <= g.ny - 2;
       thacc += own ? tw : 0.0;
@@ -456,6 +473,20 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
     for (int k = 0; k < 5; ++k) ice = ice || !(a.sitp[k] >= 0.0 && a.sitp[k] <= 1.0);
     if (!__syncthreads_or(ice)) {
       const bool ocol = lane >= FH && lane < FH + FOX && inx;
+      if constexpr (YT) {
+        if (A.emitH && a.qw != 0.0) {  // an ice-free tile of a glacier on a quadrature node: its dual nodes carry (0, 0)
+          double* __restrict__ eh = A.emitH + g.offd;
+          double* __restrict__ ev = A.emitV + g.offd;
+#pragma unroll
+          for (int m = 0; m < NR; ++m) {
+            const int r = r0 + m, gj = gj0 + r;
+            if (ocol && r >= FH && r <= (NR * TNW) - 1 - FH && gi <= g.nx - 2 && gj <= g.ny - 2) {
+              const unsigned q = (unsigned)(gi + (g.nx - 1) * gj);
+              eh[q] = 0.0; ev[q] = 0.0;
+            }
+          }
+        }
+      }
       double errsq = 0.0;
 #pragma unroll
       for (int m = 0; m < NR; ++m) {
@@ -551,8 +582,20 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
   // resets it at every call, so a repeated attempt after a rejection does not count the node twice)
   double* const thr = (A.th_part && a.qw != 0.0) ? th_red : nullptr;
   const YtabRef yt{YTL ? reinterpret_cast<const double*>(sYt) : (YT ? A.ytab + g.yt_off : nullptr), A.ytab_over, A.ytab_ni};
+  [[maybe_unused]] double emx[2] = {0.0, 0.0};
+  [[maybe_unused]] const bool emit = YT && A.emitH != nullptr && a.qw != 0.0;
   adj_strip_stage<1, AF, SG, NR, GA, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr,
-                                             GA ? A.Gacc + g.offd : nullptr, &rc, yt);
+                                             GA ? A.Gacc + g.offd : nullptr, &rc, yt, emit ? A.emitH + g.offd : nullptr,
+                                             emit ? A.emitV + g.offd : nullptr, emx);
+  if constexpr (YT) {
+    if (emit) {
+      const double mh = wave_max(emx[0]), mv = wave_max(emx[1]);
+      if (lane == 0) {
+        if (mh > 0.0) atomicMax(A.emit_amax + t4.x, (unsigned long long)__double_as_longlong(mh));
+        if (mv > 0.0) atomicMax(A.emit_vmax + t4.x, (unsigned long long)__double_as_longlong(mv));
+      }
+    }
+  }
   if (thr && threadIdx.x == 0) {  // the tile's running sum, reduced per glacier once after the reverse solve
     double sum = 0.0;
 #pragma unroll

@@ -2453,6 +2453,14 @@ struct AdjFusedArgs {
   const double* ytab;   // non-null: the Y law through its table (LM_YTAB, every glacier yt_fast) -- the kernel's YT instantiation
   int* ytab_over;
   int ytab_ni;
+  // YT, `:Linear` gradient of the law, sort-free contraction (k_interp.hip): stage 1 of the step that follows a quadrature node EMITS the
+  // node's (Hbar, qw dD/dY D_adjoint) pairs -- k_vjp_theta's emit mode without a launch of its own.  Every dual node of a glacier on a
+  // node is written (zeros on ice-free tiles: no memset of the arrays), and the glacier's max Hbar / max |weight| are raised by
+  // atomicMax on their bit patterns (zeroed per use; still zero = the glacier emitted nothing, the contraction skips it).
+  double* emitH;
+  double* emitV;
+  unsigned long long* emit_amax;
+  unsigned long long* emit_vmax;
   // self-controlled reverse step (the kernel's SC instantiations; see k_adj_fused_strip): launch n decides attempt n - 1 itself.
   // State, AdjState and error partials alternate between two arrays from launch to launch (nobody reads what another
   // workgroup of the same launch writes); C.errpart must point at the partials the PREVIOUS launch wrote.

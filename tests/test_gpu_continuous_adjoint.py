@@ -479,7 +479,7 @@ def test_fused_reverse_step_with_rejected_steps(gpu, monkeypatch):
     assert rel_l2(f[3], a[3]) < 1e-10
 
 
-@pytest.mark.parametrize("case", ["scalar_nn_mb", "gridded_nn", "ragged_batch", "rejections", "mb_only_stops"])
+@pytest.mark.parametrize("case", ["scalar_nn_mb", "gridded_nn", "ragged_batch", "rejections", "mb_only_stops", "y_table"])
 @pytest.mark.parametrize("rows", ["7", "4", "2"])
 def test_self_controlled_reverse_step_matches_the_three_launch_loop(gpu, monkeypatch, case, rows):
     """ODINN_ADJ_SC=1: every workgroup of the fused reverse step decides the previous attempt of its glacier itself (error norm,
@@ -504,6 +504,25 @@ def test_self_controlled_reverse_step_matches_the_three_launch_loop(gpu, monkeyp
                 b.set_reference(k, ts, [H0 * (1.0 - 0.1 * j) for j in range(len(ts))], 3)
             L, g = b.loss_grad_continuous(ts, reltol=1e-8, adj_reltol=1e-4, adj_abstol=1e-6, adj_dtmax=0.5, n_quadrature=6)
             out[sc] = (L, np.array(g, dtype=float).ravel(), [b.lambda0(k) for k in range(2)],
+                       [(s.naccept, s.nreject) for s in b.last_stats_rev])
+            b.close()
+        elif case == "y_table":
+            # the Y law through its table, `:Linear` gradient: stage 1 of the fused step emits the node pairs of a quadrature node
+            # (both loops), the sort-free contraction runs on the lanes
+            from test_gpu_parity import _mlp_pair
+            ph = O.Phys()
+            om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+            shapes = [(70, 57), (131, 64), (54, 46)]
+            b = gpu.GlacierBatch(shapes, [50.0] * 3, T=[-5.0, -11.0, -2.0])
+            ts = [2010.0 + j / 24.0 for j in range(4)]
+            for k, (nx, ny) in enumerate(shapes):
+                H0, B = O.synthetic_alpine(nx, ny, hmax=150.0)
+                b.set_fields(k, H0, B)
+                b.set_reference(k, ts, [H0 * (1.0 - 0.01 * j) for j in range(len(ts))], 3)
+            b.set_law(gpu.LAW_NN_Y, gm, th)
+            assert b.law_table()["usable"]
+            L, g = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=12)
+            out[sc] = (L, np.array(g, dtype=float).ravel(), [b.lambda0(k) for k in range(3)],
                        [(s.naccept, s.nreject) for s in b.last_stats_rev])
             b.close()
         elif case == "mb_only_stops":

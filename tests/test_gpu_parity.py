@@ -840,6 +840,42 @@ def test_Y_law_interpolation_batched_and_per_glacier_sequences_agree(gpu, monkey
     assert np.linalg.norm(out[0][1]) > 0.0
 
 
+@pytest.mark.parametrize("adjoint", ["discrete", "continuous"])
+def test_Y_law_interpolation_by_selection_matches_the_sorted_contraction(gpu, monkeypatch, adjoint):
+    """The sort-free `:Linear` contraction (k_interp.hip: order statistics by histogram + radix selection, interval sums in
+    fixed-point accumulators; the default) against the radix sort of the active nodes it replaces (ODINN_INTERP_SELECT=0):
+    the same knots (the selected order statistics ARE the sorted array's entries) and interval sums that differ only in the
+    rounding of their additions -- gradients equal to 1e-12; bitwise repeatable although its additions are atomic (integer
+    accumulators).  Ragged batch: an ice-free glacier, a valley glacier, and an ice cap whose plateau puts thousands of nearly
+    equal thicknesses into one histogram bin (the selection then narrows the bin digit by digit)."""
+    ph = O.Phys()
+    om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
+    shapes = [(150, 140), (131, 97), (40, 33), (66, 70)]
+    ts = [0.0, 0.25, 0.5]
+    out = []
+    for sel in ("1", "0", "1"):
+        monkeypatch.setenv("ODINN_INTERP_SELECT", sel)
+        b = gpu.GlacierBatch(shapes, [100.0] * 4, T=[-5.0, -2.0, -7.0, -4.0])
+        for k, (nx, ny) in enumerate(shapes):
+            H0, B = O.synthetic_icecap(nx, ny, 100.0) if k != 1 else O.synthetic_valley(nx, ny, 100.0)
+            if k == 0:  # plateau: thicknesses within 0.3 mm of 250 m on a third of the cap
+                H0 = np.asfortranarray(np.minimum(H0, 250.0) + 1e-6 * H0)
+            H0 = H0 * (0.4 if k not in (0, 1) else 1.0) * (0.0 if k == 2 else 1.0)
+            b.set_fields(k, H0, B)
+            b.set_reference(k, ts, [H0 * (1.0 - 0.05 * j) for j in range(3)], 3)
+        b.set_law(gpu.LAW_NN_Y, gm, th)
+        if adjoint == "discrete":
+            L, g = b.loss_grad(ts, theta=th, reltol=1e-8)
+        else:
+            L, g = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+        out.append((L, np.array(g, dtype=float).ravel()))
+        b.close()
+    assert out[0][0] == out[1][0] == out[2][0]
+    assert np.linalg.norm(out[0][1]) > 0.0
+    assert np.array_equal(out[0][1], out[2][1])  # repeatable to the bit
+    assert rel_l2(out[0][1], out[1][1]) < 1e-12
+
+
 def test_U_law_theta_gradient_bilinear_interpolation(gpu):
     """SIA2D_D_target(interpolation = :Linear) (target_D_pure.jl:179-193): gradients of the U law on the fixed
     (2 n_interp_half)^2 node grid of LawU's p_VJP! (Laws.jl:128-169), bilinear in (Hbar, |grad S|).  On the device: dual
