@@ -166,7 +166,9 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     double ad = (((Kq * 5.0) * H4) * gS2) * Da;  // alpha Da / 4
     if constexpr (YT) {
       const double geo = (Gq * H5) * gS2;  // Gam Hbar^5 |grad S|^2
-      ad = fma(0.25 * ((Yp * geo - An * geo) / 1e-4), Da, ad);
+      // (the reference's quotient (D(Hbar + 1e-4) - D(Hbar)) / 1e-4 as a product: 1 / 1e-4 rounded once instead of a division per node
+      //  and stage -- ~30 instructions; the quotient changes in its last bit)
+      ad = fma(0.25 * ((Yp * geo - An * geo) * (1.0 / 1e-4)), Da, ad);
     }
     const double bd = ((Kq * 2.0) * H5) * Da;           // beta Da
     const double bx = g.hinv_dx * (bd * gx), by = g.hinv_dy * (bd * gy);
@@ -309,8 +311,10 @@ constexpr bool adj_rc(bool AF, bool SG, int NR) { return ODINN_ADJ_RC && (AF || 
 #ifndef ODINN_ADJ_YT_LDS
 #define ODINN_ADJ_YT_LDS 0
 #endif
+// (round 5, at 64 x 1024^2, ms per continuous gradient of 13 snapshots: 4 waves per SIMD with ~30 spilled registers 1036, the LDS
+//  copy 938, 2 waves per SIMD and 256 registers without spills 903: the default now)
 #ifndef ODINN_ADJ_YT_WPE
-#define ODINN_ADJ_YT_WPE (ODINN_ADJ_YT_LDS ? 2 : ODINN_FWPE)
+#define ODINN_ADJ_YT_WPE 2
 #endif
 constexpr int YT_LDS_NI = 1024;  // the table size the LDS copy is laid out for (odinn_batch::ytab_ni)
 // SC -- the self-controlled reverse step: no controller / post-step launches (the forward solve's SC loop, sia2d_fused.hpp, for
