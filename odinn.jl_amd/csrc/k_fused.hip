@@ -30,7 +30,7 @@ void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev
 // strip kernel (integer-power law) on the FOX x FOYT (rows = 7) or FOX x FOYT8 (rows = 8) tile table; sc != null:
 // self-controlled step (no controller / post-step launches, see ScArgs)
 void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
-                           double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc, int sq) {
+                           double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc, int sq, int ytab) {
   const ScArgs A = sc ? *sc : ScArgs{};
   // measurement aid: ODINN_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the occupancy (A/B of waves per SIMD)
   static const unsigned pad = std::getenv("ODINN_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ODINN_LDS_PAD")) : 0u;
@@ -43,7 +43,19 @@ void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools
   do { if (sc && !sc->snap_on_load) ODINN_STRIP(SK, AF, NR, true); else ODINN_STRIP(SK, AF, NR, false); } while (0)
 #define ODINN_STRIP_R(SK, AF) \
   do { if (rows == 8) ODINN_STRIP_S(SK, AF, 8); else ODINN_STRIP_S(SK, AF, TRPT); } while (0)
-  if (afield) {
+  if (ytab) {  // the Y law through its table (the caller guarantees !afield and GDev::yt_fast on every glacier)
+#define ODINN_STRIP_YQ(SK, NR, SCV, SQV) \
+  hipLaunchKernelGGL((k_rk_fused_strip<SK, false, NR, SCV, SQV, true>), dim3(nblk), dim3(TNT), pad, st, P, L, tilesF, U0, U1, partF, abstol, reltol, A)
+#define ODINN_STRIP_Y(SK, NR, SCV) \
+  do { if (sq) ODINN_STRIP_YQ(SK, NR, SCV, true); else ODINN_STRIP_YQ(SK, NR, SCV, false); } while (0)
+#define ODINN_STRIP_YS(SK, NR) \
+  do { if (sc && !sc->snap_on_load) ODINN_STRIP_Y(SK, NR, true); else ODINN_STRIP_Y(SK, NR, false); } while (0)
+    if (rows == 8) { if (skip) ODINN_STRIP_YS(true, 8); else ODINN_STRIP_YS(false, 8); }
+    else { if (skip) ODINN_STRIP_YS(true, TRPT); else ODINN_STRIP_YS(false, TRPT); }
+#undef ODINN_STRIP_YS
+#undef ODINN_STRIP_Y
+#undef ODINN_STRIP_YQ
+  } else if (afield) {
     if (skip) ODINN_STRIP_R(true, true); else ODINN_STRIP_R(false, true);
   } else {
     if (skip) ODINN_STRIP_R(true, false); else ODINN_STRIP_R(false, false);

@@ -28,7 +28,8 @@ ODINN_DECL_LM(8)  // the U law through the batch's bivariate table (LM_UTAB)
 
 // k_fused.hip, law mode 0 only
 void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
-                           double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc = nullptr, int sq = 0);
+                           double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc = nullptr, int sq = 0,
+                           int ytab = 0);
 
 void launch_dhdt_strip(int nblk, int afield, int skip, hipStream_t st, Pools P, const int4* tilesD, const double* U, double* dH);
 void launch_euler_cfl_strip(int nblk, int afield, hipStream_t st, Pools P, const int4* tilesD, const double* src, double* dst, double* partD);

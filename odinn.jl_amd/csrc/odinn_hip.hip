@@ -189,12 +189,21 @@ struct odinn_batch {
   // same kernel (a workgroup walks 18 region rows instead of 50: batches too small to fill the 256 CUs), 2 = FOX x FOYT
   // strip kernel (integer-power law).  Measured crossover small <-> strip: ~100 strip tiles (one 512^2 glacier);
   // ODINN_FUSED_TILES=small|large|t overrides.
+  // the Y law through its table where it is the integer-power law with Y(Hbar) in A's place (n_H = n_gradS = 3, no sliding on every
+  // glacier): the strip kernels' YT instantiations take it (ODINN_YT_STRIP=0: the LDS-tile kernels of law mode LM_YTAB)
+  bool ytab_strip() const {
+    if (lm_kern() != LM_YTAB || gd.empty()) return false;
+    for (const GDev& r : gd) if (!r.yt_fast) return false;
+    static const bool off = std::getenv("ODINN_YT_STRIP") && std::getenv("ODINN_YT_STRIP")[0] == '0';
+    return !off;
+  }
+  bool strip_law() const { return lm() == 0 || ytab_strip(); }
   int fused_kind() const {
     const int o = fused_override();
     if (o == 1) return 1;
     if (o == 2) return 0;
-    if (o == 3) return lm() == 0 ? 2 : 0;
-    if (o == 4) return lm() == 0 ? 3 : 0;
+    if (o == 3) return strip_law() ? 2 : 0;
+    if (o == 4) return strip_law() ? 3 : 0;
     // 2 / 3 = strip kernel with 7 / 8 rows per thread (54 x 46 / 54 x 54 tiles).  The kernel is VALU-bound, so a launch
     // lasts about (tiles on the busiest CU) x (rows per thread): 8 rows do less halo work per cell but quantise worse.
     // That model reproduces the measured order on 11 batch shapes (1 x 1024^2: 7 rows win 8 %, 2 x 1024^2: 8 rows win
@@ -202,7 +211,7 @@ struct odinn_batch {
     // Below ~100 strip tiles the 54 x 8 latency tiles win as a KERNEL, but the strip kernel can run the self-controlled
     // step loop (no controller / post-step launches), which wins as a STEP (4 alpine glaciers: 0.64 -> 0.55 ms for 25
     // steps)
-    if (lm() == 0) {
+    if (strip_law()) {
       if (ntilesFt < 96 && sc_env() == 0) return 1;
       const long cu = n_cus();
       return 8 * ((ntilesFu + cu - 1) / cu) <= 7 * ((ntilesFt + cu - 1) / cu) ? 3 : 2;
@@ -767,10 +776,12 @@ void launch_vjp_H(odinn_batch* b, int mode, int nblk, const Pools& P, const LawD
   const int se = sched_val(b->sched.vjph_strip, "ODINN_VJPH_STRIP");
   const bool strip_on = se >= 0 ? se != 0 : (double)b->ntot >= 0.75 * (double)b->ntilesD * (DHDT_OX * DHDT_OY);
   const int vje = vj < 0 ? b->vjp_method : vj;
-  if (strip_on && b->lm() == 0 && vje == ODINN_VJP_DISCRETE && !A.snaps && base == 0 && nblk == b->ntiles &&
+  if (strip_on && b->strip_law() && vje == ODINN_VJP_DISCRETE && !A.snaps && base == 0 && nblk == b->ntiles &&
       !(mode == 1 && b->h_log_eps > 0.0) &&  // (LossH with LogSum: the tile kernel carries that branch)
       (P.tiles == b->d_tiles || b->G == 1)) {
-    launch_vjp_H_strip(mode, b->gd[0].use_Afield ? 1 : 0, b->ntilesD, b->stream, P, b->d_tilesD, A);
+    AdjArgs As = A;
+    if (b->lm() != 0) { As.ytab = L.ytab; As.ytab_over = L.ytab_over; As.ytab_ni = L.ytab_ni; }  // (the Y law through its table)
+    launch_vjp_H_strip(mode, b->gd[0].use_Afield ? 1 : 0, b->ntilesD, b->stream, P, b->d_tilesD, As);
     return;
   }
   tab[b->lm_kern()](mode, vje, nblk, b->stream, P, L, A, base);
@@ -790,7 +801,9 @@ void launch_vjp_theta(odinn_batch* b, int nblk, const Pools& P, const LawDev& L,
   // tile-fullness rule as k_vjp_H_strip; ODINN_VJPTH_STRIP=0/1 forces the choice
   const int se = sched_val(b->sched.vjpth_strip, "ODINN_VJPTH_STRIP");
   const bool strip_on = se >= 0 ? se != 0 : (double)b->ntot >= 0.75 * (double)b->ntilesD * (DHDT_OX * DHDT_OY);
-  if (strip_on && b->lm() == 0 && !A.emitH && base == 0 && nblk == b->ntiles && (P.tiles == b->d_tiles || b->G == 1)) {
+  // (the Y law through its table in emit mode: the same geometry factor, the node pairs written instead of reduced)
+  const bool yt_emit = b->lm() != 0 && b->ytab_strip() && A.emitH && !A.emitS && !A.Gacc;
+  if (strip_on && (yt_emit || (b->lm() == 0 && !A.emitH)) && base == 0 && nblk == b->ntiles && (P.tiles == b->d_tiles || b->G == 1)) {
     launch_vjp_theta_strip(A.Gacc ? 1 : 0, A.snaps ? 1 : 0, b->ntilesD, b->stream, P, b->d_tilesD, A);
     return;
   }
@@ -866,7 +879,7 @@ int launch_fused_step(odinn_batch* b, double abstol, double reltol, int skip, co
     bool sq = true;  // square cells everywhere: the kernel instantiation without the dx / dy ratio (bit-identical, 2.5 % fewer VALU instructions)
     for (const GDev& r : b->gd) sq = sq && r.dx == r.dy;
     launch_rk_fused_strip(nblk, b->gd[0].use_Afield, small == 3 ? 8 : TRPT, b->stream, P, L, tiles, b->d_U[0], b->d_U[1], part, abstol,
-                          reltol, skip, sc, sq ? 1 : 0);
+                          reltol, skip, sc, sq ? 1 : 0, b->lm() != 0 ? 1 : 0);
   } else {
     static void (*const tab[9])(int, hipStream_t, Pools, LawDev, const int4*, double*, double*, double*, double, double, int, int) = {
         launch_rk_fused_lm0, launch_rk_fused_lm1, launch_rk_fused_lm2, launch_rk_fused_lm3, launch_rk_fused_lm4, launch_rk_fused_lm5, launch_rk_fused_lm6, launch_rk_fused_lm7, launch_rk_fused_lm8};

@@ -661,8 +661,11 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
 #ifndef ODINN_VJPH_RC
 #define ODINN_VJPH_RC 1
 #endif
-template <bool AF, int MODE>
-__global__ __launch_bounds__(TNT, ((ODINN_VJPH_RC && MODE == 1) ? 2 : ODINN_FWPE)) void k_vjp_H_strip(Pools P, const int4* __restrict__ tilesD, AdjArgs A) {
+// YT: the Y law through its table with Y(Hbar) in A's place plus the reference's forward-difference term of dD/dHbar (as in
+// adj_strip_stage<..., YT>; 256 registers: the table evaluation does not fit 128 without spills)
+template <bool AF, int MODE, bool YT = false>
+__global__ __launch_bounds__(TNT, (((ODINN_VJPH_RC && MODE == 1) || YT) ? 2 : ODINN_FWPE)) void k_vjp_H_strip(Pools P, const int4* __restrict__ tilesD, AdjArgs A) {
+  static_assert(!YT || !AF, "the table replaces the scalar A");
   constexpr bool RCV = ODINN_VJPH_RC && MODE == 1;
   __shared__ double2 sE[TNW][2][FRX];
   __shared__ double sLm[TNW][2][FRX];
@@ -820,11 +823,18 @@ __global__ __launch_bounds__(TNT, ((ODINN_VJPH_RC && MODE == 1) ? 2 : ODINN_FWPE
       const double gx = (dx_lo + dx_hi) * g.hinv_dx, gy = (dyw + dye) * g.hinv_dy;
       const double Hs = hp_lo + hp_hi;  // 4 Hbar
       const double gS2 = gx * gx + gy * gy;
-      const double Kq = (AF ? an : g.A) * Gq;
+      double An = AF ? an : g.A;
+      [[maybe_unused]] double Yp = 0.0;
+      if constexpr (YT) An = ytab_eval_core<true>(A.ytab + g.yt_off, A.ytab_ni, A.ytab_over, g.yt_inv_h, 0.25 * Hs, Yp);
+      const double Kq = An * Gq;
       const double H2 = Hs * Hs, H4 = H2 * H2, H5 = H4 * Hs;
       D = (Kq * H5) * gS2;
       const double Da = -fma(g.hinv_dx2, Pe_lo + Pe_hi, g.hinv_dy2 * (Pn + Pn_e));
-      const double ad = (((Kq * 5.0) * H4) * gS2) * Da;  // alpha Da / 4
+      double ad = (((Kq * 5.0) * H4) * gS2) * Da;  // alpha Da / 4
+      if constexpr (YT) {
+        const double geo = (Gq * H5) * gS2;  // Gam Hbar^5 |grad S|^2
+        ad = fma(0.25 * ((Yp * geo - An * geo) * (1.0 / 1e-4)), Da, ad);  // (target_D_hybrid.jl:58-71; see adj_strip_stage)
+      }
       const double bd = ((Kq * 2.0) * H5) * Da;           // beta Da
       const double bx = g.hinv_dx * (bd * gx), by = g.hinv_dy * (bd * gy);
       const double am = ad - bx, ap = ad + bx;
@@ -924,7 +934,10 @@ __global__ __launch_bounds__(TNT, ((ODINN_VJPH_RC && MODE == 1) ? 2 : ODINN_FWPE
 // formed from two bracketing snapshots at the stop of the reverse solve) -- with the layout of k_vjp_H_strip.  A thread
 // owns the node at the north-east corner of each of its output cells; D_adjoint of that node comes from the east faces of
 // the row and the row above and the north faces of the cell and its east neighbour (the face form of adj_strip_stage).
-template <bool GACC, bool ITP>
+// EMIT (Y law through its table, `:Linear` gradient of the law): instead of reducing, every owned node writes (Hbar, weight) into
+// A.emitH / A.emitV (pre-zeroed by the caller: tiles that leave early contribute zeros) -- k_vjp_theta's emit mode for the
+// integer-power form of the Y law's geometry factor (GDev::yt_fast)
+template <bool GACC, bool ITP, bool EMIT = false>
 __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_theta_strip(Pools P, const int4* __restrict__ tilesD, ThArgs A) {
   __shared__ double2 sE[TNW][FRX];
   __shared__ double sLm[TNW][FRX];
@@ -935,10 +948,10 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_theta_strip(Pools P, co
   const double scale = A.scales ? A.scales[t4.x] : 1.0;
   // the partial slots of the regular table that this glacier's strip tiles do not use (in-place accumulation: the caller
   // zeroed the whole table once)
-  if (!A.accum && t4.w == g.tile0D)
+  if (!EMIT && !A.accum && t4.w == g.tile0D)
     for (int k = g.ntilesD + threadIdx.x; k < g.ntiles; k += TNT) P.part[4 * (long long)(g.tile0 + k) + 2] = 0.0;
   if (scale == 0.0) {  // this glacier contributes nothing now (e.g. not at a quadrature node)
-    if (threadIdx.x == 0 && !A.accum) P.part[slot] = 0.0;
+    if (!EMIT && threadIdx.x == 0 && !A.accum) P.part[slot] = 0.0;
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -981,7 +994,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_theta_strip(Pools P, co
   sLm[w][lane] = le[0];
   // no ice anywhere on the region: every owned node has Hbar = 0, its weight vanishes identically (k_vjp_theta's shortcut)
   if (!__syncthreads_or(nz)) {
-    if (threadIdx.x == 0 && !A.accum) P.part[slot] = 0.0;
+    if (!EMIT && threadIdx.x == 0 && !A.accum) P.part[slot] = 0.0;
     return;
   }
   const double Gq = g.Gam * (1.0 / 1024.0);
@@ -1011,11 +1024,18 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_vjp_theta_strip(Pools P, co
     const double Da = -fma(g.hinv_dx2, Pe_c + Pe_n, g.hinv_dy2 * (Pn + Pn_e));
     const double wgt = scale * (((Gq * (H4 * Hs)) * gS2) * Da);
     if (ocol && r >= 1 && r <= DOY && gi <= g.nx - 2 && gj <= g.ny - 2) {  // gj >= 0 and gi >= 0 hold for output cells
-      acc += wgt;
-      if (GACC) A.Gacc[g.offd + gi + (long long)(g.nx - 1) * gj] += wgt;
+      if constexpr (EMIT) {
+        const long long q = g.offd + gi + (long long)(g.nx - 1) * gj;
+        A.emitH[q] = 0.25 * Hs;
+        A.emitV[q] = wgt;
+      } else {
+        acc += wgt;
+        if (GACC) A.Gacc[g.offd + gi + (long long)(g.nx - 1) * gj] += wgt;
+      }
     }
     hs_c = hs_n; le_c = le_n; e_c = e_n; dx_c = dx_n; hp_c = hp_n; Pe_c = Pe_n;
   }
+  if constexpr (EMIT) return;
   acc = wave_sum(acc);
   if (lane == 0) red[w] = acc;
   __syncthreads();

@@ -2029,6 +2029,10 @@ struct AdjArgs {
   // MODE 0 only, continuous adjoint: H = H_itp at stage time 0 of each glacier's AdjState
   const double* snaps; // forward snapshots [n_snap][ntot] or null (then H is used)
   const AdjState* adj;
+  // k_vjp_H_strip<..., YT>: the Y law through its table (every glacier yt_fast)
+  const double* ytab;
+  int* ytab_over;
+  int ytab_ni;
 };
 
 // One dual node of k_vjp_H: what node (a,b) of the tile contributes to the VJP of its four corner

@@ -457,7 +457,7 @@ __device__ __forceinline__ void strip_flag_sync(volatile int* f, int w, int stag
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int S, bool AF, int NR, bool UPL, bool SQ>
+template <int S, bool AF, int NR, bool UPL, bool SQ, bool YT = false>
 __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                              const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                              double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
@@ -488,6 +488,17 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
     // multiplication less per node (2.5 % of the kernel's VALU instructions)
     const double gS2 = SQ ? fma(a, a, b * b) : fma(a, a, (ryx * b) * b);
     const double H2 = H4s * H4s, H4 = H2 * H2;
+    if constexpr (YT) {
+      // the Y law of target :D_hybrid with n_H = n_gradS = 3 and no sliding (GDev::yt_fast): this law with Y(Hbar) from the glacier's
+      // table in A's place (node_D<LM_YTAB>) -- three 16-byte loads from an L2-resident table and a quintic per node
+      // Leaving the table's range is reported from stage 1 (every row of the region then holds real data) and from the step's
+      // output cells; in stages 2-5 the rows outside region_S hold whatever the stale neighbours produced -- never read, but
+      // possibly far outside the table, where the evaluation clamps silently.
+      double unused;
+      int over_local = 0;
+      const double Y = ytab_eval_core<false>(L.ytab + g.yt_off, L.ytab_ni, S == 1 ? L.ytab_over : &over_local, g.yt_inv_h, 0.25 * H4s, unused);
+      return (Y * Gq) * (H4 * H4s) * gS2;
+    }
     return (AF ? sA[slot][threadIdx.x] : AGq) * (H4 * H4s) * gS2;  // sA: A Gam / (1024 (2dx)^2) of the thread's own nodes
   };
   // Flux form of cell_div_vals<true>: the flux through the face between two cells is the same number seen
@@ -565,16 +576,16 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
   }
 }
 
-template <bool AF, int NR, bool UPL, bool SQ>
+template <bool AF, int NR, bool UPL, bool SQ, bool YT = false>
 __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                               const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                               double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
                                               double (&E)[NR], const double (&bb)[NR], volatile int* sFlag) {
-  strip_stage<1, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
-  strip_stage<2, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
-  strip_stage<3, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
-  strip_stage<4, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
-  strip_stage<5, AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+  strip_stage<1, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+  strip_stage<2, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+  strip_stage<3, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+  strip_stage<4, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+  strip_stage<5, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
 }
 
 // ---- self-controlled step (SC): no controller / post-step launches ---------------------------------------
@@ -656,7 +667,8 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
 // spills (a separate predicate-free kernel for the tiles strictly inside the grid was measured and lost: its
 // second launch costs more than the selects it saves).
 // NR: rows per thread (7: 54x46 output tiles; 8: 54x54 tiles, less halo work, for batches that fill the GPU twice over)
-template <bool SKIP, bool AF, int NR, bool SC = false, bool SQ = false>
+// YT: the Y law through its table (every glacier yt_fast; replaces the scalar A -- see strip_stage's node)
+template <bool SKIP, bool AF, int NR, bool SC = false, bool SQ = false, bool YT = false>
 __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, LawDev L, const int4* __restrict__ tilesF,
                                                                     double* __restrict__ U0, double* __restrict__ U1,
                                                                     double* __restrict__ partF, double abstol, double reltol,
@@ -846,7 +858,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
 #pragma unroll
     for (int m = 0; m <= NR; ++m) sA[AF ? m : 0][threadIdx.x] = aa[AF ? m : 0] * Gq;
   }
-  strip_stages<AF, NR, UPL, SQ>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb, sFlag);
+  static_assert(!YT || !AF, "the table replaces the scalar A");
+  strip_stages<AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb, sFlag);
   // ---- output rows [FH, (NR * TNW)-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
   double upf[NR];
@@ -862,6 +875,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     if (r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny) {
       const double upv = upf[m];
       stg32(dst, (unsigned)(id0 + g.nx * m), u[m]);
+      if constexpr (YT) { if (!(u[m] * g.yt_inv_h < (double)L.ytab_ni)) *L.ytab_over = 1; }  // (Hbar <= the largest of its four cells)
       const double err = (u[m] - upv) - E[m];
       const double sk = abstol + fmax(fabs(upv), fabs(u[m])) * reltol;
       const double q = err / sk;
