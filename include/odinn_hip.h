@@ -174,7 +174,11 @@ typedef struct odinn_schedule {
                               for the batch in 128 x 64 bi-quintic patches -- rebuilt from the network whenever theta changes, used
                               only while its measured deviation from the network is < 1e-12 relative (else the network); a solve
                               that leaves the table's range is repeated with a wider one.  The seam calls always evaluate the
-                              network                                                                                              */
+                              network.  What the 1e-12 bounds are the VALUES of the law: the finite-difference terms of the adjoints
+                              ((Y(Hbar + 1e-4) - Y(Hbar)) / 1e-4, the U law's central differences) are then differences of the
+                              interpolant, whose error is amplified by 1 / step -- 1e-8 relative at the bound, the accuracy those
+                              differences have in fp64 anyway; gradients with and without the table agree to 1e-8 ... 5e-8
+                              (tests/test_gpu_law_table*.py)                                                                       */
   int32_t interp_async;    /* ODINN_INTERP_ASYNC: 0 = the Y law's `:Linear` contraction of a stop (sort, knots, interval sums, knot
                               backprop) on the batch's own stream; n = 1 ... 4: overlapped with the following reverse steps of both
                               adjoints on n lane streams (default: 3 in the DiscreteAdjoint, 1 or 4 in the ContinuousAdjoint; results

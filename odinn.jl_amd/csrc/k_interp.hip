@@ -402,8 +402,10 @@ size_t interp_batch_temp_bytes(long long n_max) {
 // 2^(12 - gbits) binades, i.e. its pattern leaves the top gbits bits free.  ONE radix sort then leaves every glacier's nodes
 // in exact Hbar order at the glacier's pooled offset.  With gbits <= 6 (64 glaciers per call) the exact range reaches down to
 // 2^-48 m = 3.6e-15 m; thinner ice (the subnormal thicknesses an advancing margin leaves) keeps its order up to the rounding
-// of the scaled value and stays behind the exact zeros.  More than 128 glaciers per call sort twice (by Hbar, then by glacier).
-constexpr int INTERP_KEY_GBITS_MAX = 7;
+// of the scaled value and stays behind the exact zeros.  More than 64 glaciers per call sort twice (by Hbar, then by glacier).
+// (6, not 7: with 7 glacier bits the scaled thicknesses below 2^-16 m turn subnormal and lose mantissa bits -- distinct values tie
+//  and come out in index order; batches of more than 64 glaciers take the sort-free contraction or the two-pass sort)
+constexpr int INTERP_KEY_GBITS_MAX = 6;
 __global__ void k_interp_keys(const unsigned* __restrict__ gid, const double* __restrict__ H, long long n, unsigned g0, int gbits,
                               double scale, unsigned long long* __restrict__ keys) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {

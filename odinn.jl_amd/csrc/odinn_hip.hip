@@ -2244,9 +2244,9 @@ static int interp_async_setup(odinn_batch* b, int lanes) {
   static const bool dense = std::getenv("ODINN_INTERP_ACTIVE") && std::getenv("ODINN_INTERP_ACTIVE")[0] == '0';
   int gbits = 0;
   while ((1ll << gbits) < (long long)b->G) ++gbits;
-  // (the composite (glacier, Hbar) sort key has room for 128 glaciers; the sort-free contraction has no such limit)
+  // (the composite (glacier, Hbar) sort key has room for 64 glaciers; the sort-free contraction has no such limit)
   b->ia_select = sched_val(-1, "ODINN_INTERP_SELECT") != 0;
-  if (!dense && (gbits <= 7 || b->ia_select) && b->solved) {
+  if (!dense && (gbits <= 6 || b->ia_select) && b->solved) {
     if (!b->ia_flags) {
       CHK(dalloc(&b->ia_flags, N)); CHK(dalloc(&b->ia_act, N)); CHK(dalloc(&b->ia_gid_act, N)); CHK(dalloc(&b->ia_nact_dev, (size_t)1));
       CHK(dalloc(&b->ia_aoff, (size_t)b->G + 1));
