@@ -31,31 +31,21 @@ typedef double (*AdjEdgesL)[TNW][2][FRX];
 
 // ODINN_ADJ_ELDS: the embedded-error accumulator of the thread's rows lives in a thread-private LDS column instead of 2 NR
 // VGPRs (it is touched once per row and stage)
-#ifndef ODINN_ADJ_ELDS
-#define ODINN_ADJ_ELDS 1
-#endif
+#define ODINN_ADJ_ELDS 1  // (fixed: its A/B is recorded above; no longer a build-time knob)
 // ODINN_ADJ_PF2: constant-A variants fetch {Hc,S} two rows ahead instead of one (fits 128 VGPRs without scratch once E is in
 // LDS).  Same-box A/B: +2.1 % on the bench's continuous-adjoint gradient (half ice-free domains, shortcut on), but -10 % on
 // the dense all-ice launch (0.260 -> 0.287 ms per 8 x 1024^2): off.
-#ifndef ODINN_ADJ_PF2
-#define ODINN_ADJ_PF2 0
-#endif
+#define ODINN_ADJ_PF2 0  // (fixed: its A/B is recorded above; no longer a build-time knob)
 // ODINN_ADJ_APF: gridded A one node row ahead of its use (like {Hc,S}) instead of inside node_face (8 x 1024^2, gridded
 // law: 282 -> 262 us per reverse step; 0 restores the load at the point of use)
-#ifndef ODINN_ADJ_APF
-#define ODINN_ADJ_APF 1
-#endif
+#define ODINN_ADJ_APF 1  // (fixed: its A/B is recorded above; no longer a build-time knob)
 // ODINN_ADJ_RC: the gridded-A variants keep everything a stage re-reads -- {H_j, H_j+1 - H_j}, B, the A nodes and lambda at the
 // start of the step -- in registers for the five stages (4 doubles per row + the A row below the strip: 72 VGPRs at 7 rows) and
 // run at 2 wavefronts per SIMD (one workgroup per CU, 256 VGPRs).  At 4 per SIMD the variant spilled 11-17 registers and was
 // HBM-bound on its own re-reads: PMC at 64 x 1024^2, 15.4 GB fetched per launch = 5 x the algorithmic traffic at 5.4 TB/s
 // (3.05 ms; the constant-A variant: 6.3 GB, 2.13 ms) -- the A field is one more 512 MB stream through a 4 MB L2 in every stage.
-#ifndef ODINN_ADJ_RC
-#define ODINN_ADJ_RC 1
-#endif
-#ifndef ODINN_ADJ_RC_EREG  // ... and the embedded-error accumulator too (the LDS column exists for the 128-register variants)
-#define ODINN_ADJ_RC_EREG 1
-#endif
+#define ODINN_ADJ_RC 1  // (fixed: its A/B is recorded above; no longer a build-time knob)
+#define ODINN_ADJ_RC_EREG 1  // (fixed: its A/B is recorded above; no longer a build-time knob)
 typedef double (*AdjErr)[FRX];
 // register cache of a thread's stage-invariant inputs (ODINN_ADJ_RC)
 template <int NR>
@@ -308,9 +298,7 @@ constexpr bool adj_rc(bool AF, bool SG, int NR) { return ODINN_ADJ_RC && (AF || 
 // dependent L2 gathers) -- 174 -> 165 us per launch beside the contraction lanes at 8 x 512^2, 120.9 vs 121.2 ms per continuous
 // gradient, 10.66 vs 10.68 gradient evaluations per second at 64 x 1024^2: the gathers are not what this kernel waits for;
 // -DODINN_ADJ_YT_WPE=2 alone (256 registers, no spills): the same kernel time.
-#ifndef ODINN_ADJ_YT_LDS
-#define ODINN_ADJ_YT_LDS 0
-#endif
+#define ODINN_ADJ_YT_LDS 0  // (fixed: its A/B is recorded above; no longer a build-time knob)
 // (round 5, at 64 x 1024^2, ms per continuous gradient of 13 snapshots: 4 waves per SIMD with ~30 spilled registers 1036, the LDS
 //  copy 938, 2 waves per SIMD and 256 registers without spills 903: the default now)
 #ifndef ODINN_ADJ_YT_WPE
@@ -658,9 +646,7 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
 // reference thickness, mask -- issued before the sweep, like MODE 0's H and lambda.  At 128 registers those were fetched one
 // row ahead inside the sweep, i.e. each row waited for its own loads: 0.74 ms per 64 x 1024^2 against 0.36 ms for MODE 0,
 // which moves 32 of MODE 1's 41 B/cell.
-#ifndef ODINN_VJPH_RC
-#define ODINN_VJPH_RC 1
-#endif
+#define ODINN_VJPH_RC 1  // (fixed: its A/B is recorded above; no longer a build-time knob)
 // YT: the Y law through its table with Y(Hbar) in A's place plus the reference's forward-difference term of dD/dHbar (as in
 // adj_strip_stage<..., YT>; 256 registers: the table evaluation does not fit 128 without spills)
 template <bool AF, int MODE, bool YT = false>

@@ -442,9 +442,7 @@ __device__ __forceinline__ double dpostscale_f(const LawDev& L, double y) {
 
 // Per-lane MLP evaluation (_pred_NN, src/laws/Laws.jl:34-36) for run-time architectures; weights are read with wave-uniform
 // addresses (scalar loads through the constant cache), activations live in registers.
-#ifndef ODINN_RT_PREFETCH
-#define ODINN_RT_PREFETCH 1
-#endif
+#define ODINN_RT_PREFETCH 1  // (fixed: its A/B is recorded above; no longer a build-time knob)
 // Rolled: ONE copy of the unit code (a padded row of weights through one scalar load, MW multiply-adds at compile-time register
 // indices -- the padding multiplies zeros -- one activation, chosen by a uniform branch) looped over the units of a layer and
 // over the layers; the unit's result goes to z[o] with a wave-uniform dynamic register index (s_set_gpr_idx).  Summation order
@@ -766,15 +764,9 @@ constexpr double PERT_DZ_MAX = 2e-3;
 // units between two scheduling fences: 1 = strictly one unit at a time (fewest registers, longest dependent chains),
 // 2-3 = that many exponentials in flight (the kernels run 2 waves per SIMD: some instruction-level parallelism is needed)
 // (per number of perturbations: the Y law's single perturbation leaves registers for more units in flight than the U law's four)
-#ifndef ODINN_PERT_Y
-#define ODINN_PERT_Y 0
-#endif
-#ifndef ODINN_PERT_GROUP1
-#define ODINN_PERT_GROUP1 5
-#endif
-#ifndef ODINN_PERT_GROUP4
-#define ODINN_PERT_GROUP4 2
-#endif
+#define ODINN_PERT_Y 0  // (fixed: its A/B is recorded above; no longer a build-time knob)
+#define ODINN_PERT_GROUP1 5  // (fixed: its A/B is recorded above; no longer a build-time knob)
+#define ODINN_PERT_GROUP4 2  // (fixed: its A/B is recorded above; no longer a build-time knob)
 #ifndef ODINN_PERT_INLINE
 #define ODINN_PERT_INLINE __forceinline__
 #endif

@@ -98,9 +98,7 @@ __device__ __forceinline__ void fused_stage(const GDev& g, const LawDev& L, cons
   }
 }
 
-#ifndef ODINN_FFAST
-#define ODINN_FFAST 1
-#endif
+#define ODINN_FFAST 1  // (fixed: its A/B is recorded above; no longer a build-time knob)
 // Variant of fused_stage for the integer-power A law (LM_FAST), trimmed for the LDS pipe and the
 // scalar unit, which co-limit the kernel with the fp64 VALU (LDS array busy 53 %, VALU 57 %, waves
 // parked 40 % of their life in s_waitcnt / s_barrier):
@@ -289,9 +287,7 @@ __device__ __forceinline__ void fused_stages(const GDev& g, const LawDev& L, con
   }
 }
 
-#ifndef ODINN_FINNER
-#define ODINN_FINNER 1
-#endif
+#define ODINN_FINNER 1  // (fixed: its A/B is recorded above; no longer a build-time knob)
 #ifndef ODINN_FWPE
 #define ODINN_FWPE 4
 #endif
@@ -444,9 +440,7 @@ typedef double2 (*StripEdges)[TNW][2][FRX];
 // its edge rows and waits for its two neighbours' counters.  (The edge rows are double-buffered: wavefront w overwrites the
 // buffer of stage s at the end of stage s + 2, which it can only reach after its neighbours published stage s + 1, i.e.
 // after they read the stage-s rows.)
-#ifndef ODINN_STRIP_FLAGSYNC
-#define ODINN_STRIP_FLAGSYNC 0
-#endif
+#define ODINN_STRIP_FLAGSYNC 0  // (fixed: its A/B is recorded above; no longer a build-time knob)
 __device__ __forceinline__ void strip_flag_sync(volatile int* f, int w, int stage) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if ((threadIdx.x & 63) == 0) f[w] = stage;
