@@ -12,6 +12,17 @@ static void adjf_dispatch(int nblk, int afield, int skip, int rows, hipStream_t 
   // measurement aid: ODINN_ADJ_LDS_PAD=<bytes> of unused dynamic LDS per workgroup (> 2 KB: one workgroup per CU instead of two,
   // i.e. half the per-XCD working set against the 4 MB L2 at half the occupancy)
   static const unsigned pad = std::getenv("ODINN_ADJ_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ODINN_ADJ_LDS_PAD")) : 0u;
+  if (A.utab) {  // the U law (target :D) through its table: own law block, no SC (the caller guarantees A.segs, !afield, rows 2 / 4 / 7)
+    if constexpr (!SC) {
+#define ODINN_ADJF_UT(SK, NR) \
+  hipLaunchKernelGGL((k_adj_fused_strip<false, SK, true, NR, false, false, false, true>), dim3(nblk), dim3(TNT), pad, st, P, A)
+      if (rows == 2) { if (skip) ODINN_ADJF_UT(true, 2); else ODINN_ADJF_UT(false, 2); }
+      else if (rows == 4) { if (skip) ODINN_ADJF_UT(true, 4); else ODINN_ADJF_UT(false, 4); }
+      else { if (skip) ODINN_ADJF_UT(true, TRPT); else ODINN_ADJF_UT(false, TRPT); }
+#undef ODINN_ADJF_UT
+    }
+    return;
+  }
   if (rows == 2) {  // the smallest batches: 2 rows per thread (54 x 6 output tiles); the caller guarantees A.segs
     if (A.ytab) {
       if (skip) ODINN_ADJF(false, true, true, 2, false, true); else ODINN_ADJF(false, false, true, 2, false, true);

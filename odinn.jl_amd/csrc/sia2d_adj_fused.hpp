@@ -56,7 +56,7 @@ struct AdjRowCache {
   double u0[NR];      // lambda at the start of the step
 };
 
-template <int S, bool AF, bool SG, int NR, bool GA = false, bool RC = false, bool YT = false>
+template <int S, bool AF, bool SG, int NR, bool GA = false, bool RC = false, bool YT = false, bool UT = false>
 __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __restrict__ Afield, const double* __restrict__ Ha,
                                                  const double* __restrict__ Hb, const double* __restrict__ src, const AdjState& a,
                                                  int gic, int gi, int gj0, int w, int lane, double dt, AdjEdgesHS sE,
@@ -67,7 +67,8 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
                                                  [[maybe_unused]] const YtabRef yt = YtabRef{nullptr, nullptr, 0},
                                                  [[maybe_unused]] double* __restrict__ Eh = nullptr,
                                                  [[maybe_unused]] double* __restrict__ Ev = nullptr,
-                                                 [[maybe_unused]] double* __restrict__ emax = nullptr) {
+                                                 [[maybe_unused]] double* __restrict__ emax = nullptr,
+                                                 [[maybe_unused]] const LawDev* Lu = nullptr) {
   constexpr int rd = (S - 1) & 1, wr = S & 1;
   constexpr bool ELDS = ODINN_ADJ_ELDS && !(RC && ODINN_ADJ_RC_EREG);
   const int r0 = NR * w;
@@ -145,10 +146,36 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     // yt_fast), plus the reference's finite-difference term of dD/dHbar (target_D_hybrid.jl:58-71) in alpha below
     [[maybe_unused]] double Yp = 0.0;
     if constexpr (YT) An = ytab_eval_core<true>(yt.tab, yt.ni, yt.over, g.yt_inv_h, 0.25 * Hs, Yp);
+    const double Da = -fma(g.hinv_dx2, Pe_lo + Pe_hi, g.hinv_dy2 * (Pn + Pn_e));
+    if constexpr (UT) {
+      // target :D (target_D_pure.jl:78-137): D = Hbar U, alpha = dD/dHbar and beta = dD/d|grad S| by central differences of
+      // D with steps 1e-4 / 1e-6, the perturbed values of U from the node's own bi-quintic patch (node_D<LM_UTAB>'s arithmetic);
+      // beta is NOT divided by |grad S| (as written upstream: "for now we ignore the derivative in surface slope")
+      const double Hb = 0.25 * Hs;
+      double al = 0.0, be = 0.0;
+      D = 0.0;
+      if (Hb > 0.0) {
+        double up[4];
+        const double U = utab_eval<true>(*Lu, Hb, sqrt(gS2), up);
+        const double dH = 1e-4, dS = 1e-6;
+        al = (up[0] * (Hb + dH) - up[1] * (Hb - dH)) / (2.0 * dH);
+        be = (up[2] * Hb - up[3] * Hb) / (2.0 * dS);
+        D = Hb * U;
+      }
+      tw = 0.0;
+      const double ad = (0.25 * al) * Da, bd = be * Da;
+      const double bx = g.hinv_dx * (bd * gx), by = g.hinv_dy * (bd * gy);
+      const double am = ad - bx, ap = ad + bx;
+      k00 = am - by; k10 = ap - by; k01 = am + by; k11 = ap + by;
+      const double Dw = dpp_from_west(D);
+      const double tn = ((Dw + D) * g.hinv_dy2) * qn;
+      Mn = (dyw < hs_hi.x && dyw != -hs_lo.x) ? tn : 0.0;
+      PLn = (dyw > -hs_lo.x && dyw != hs_hi.x) ? -tn : 0.0;
+      return;
+    }
     const double Kq = An * Gq;
     const double H2 = Hs * Hs, H4 = H2 * H2, H5 = H4 * Hs;
     D = (Kq * H5) * gS2;
-    const double Da = -fma(g.hinv_dx2, Pe_lo + Pe_hi, g.hinv_dy2 * (Pn + Pn_e));
     // (stage 1 only) the node's weight in the theta-VJP of the A-type laws, dD/dA x D_adjoint = Gam Hbar^5 |grad S|^2 Da
     // (adjoint.jl:235-250; k_vjp_theta_strip's expression): stage 1 sits exactly on the state the reverse solve has just
     // reached, so a quadrature node reached by the previous step gets its theta-VJP here instead of in a launch of its own
@@ -319,9 +346,12 @@ constexpr int YT_LDS_NI = 1024;  // the table size the LDS copy is laid out for 
 __device__ __forceinline__ double wave_uniform(double x) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
-template <bool AF, bool SKIP, bool SG = false, int NR = TRPT, bool GA = false, bool YT = false, bool SC = false>
-__global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_WPE : ODINN_FWPE))) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
+// UT: the U law (target :D) through its table -- D, alpha, beta of a node from the bi-quintic patch instead of the power law
+// (256 registers: the patch's 36 coefficients do not fit 128)
+template <bool AF, bool SKIP, bool SG = false, int NR = TRPT, bool GA = false, bool YT = false, bool SC = false, bool UT = false>
+__global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : ((YT || UT) ? ODINN_ADJ_YT_WPE : ODINN_FWPE))) void k_adj_fused_strip(Pools P, AdjFusedArgs A) {
   static_assert(!YT || (!AF && !GA), "the table's instantiation replaces the scalar A");
+  static_assert(!UT || (!AF && !GA && !YT && !SC), "the U law's instantiation: its own law block, theta-VJP in launches of its own");
   constexpr bool RC = adj_rc(AF, SG, NR);
   __shared__ double2 sE[2][TNW][2][FRX];
   __shared__ double sLm[2][TNW][2][FRX];
@@ -576,9 +606,14 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
   const YtabRef yt{YTL ? reinterpret_cast<const double*>(sYt) : (YT ? A.ytab + g.yt_off : nullptr), A.ytab_over, A.ytab_ni};
   [[maybe_unused]] double emx[2] = {0.0, 0.0};
   [[maybe_unused]] const bool emit = YT && A.emitH != nullptr && a.qw != 0.0;
-  adj_strip_stage<1, AF, SG, NR, GA, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr,
-                                             GA ? A.Gacc + g.offd : nullptr, &rc, yt, emit ? A.emitH + g.offd : nullptr,
-                                             emit ? A.emitV + g.offd : nullptr, emx);
+  [[maybe_unused]] LawDev Lu{};
+  if constexpr (UT) {
+    Lu.utab = A.utab; Lu.utab_nh = A.utab_nh; Lu.utab_ns = A.utab_ns; Lu.ut_inv_h = A.ut_inv_h; Lu.ut_inv_s = A.ut_inv_s;
+    Lu.ytab_over = A.ytab_over;
+  }
+  adj_strip_stage<1, AF, SG, NR, GA, RC, YT, UT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, thr,
+                                                 GA ? A.Gacc + g.offd : nullptr, &rc, yt, emit ? A.emitH + g.offd : nullptr,
+                                                 emit ? A.emitV + g.offd : nullptr, emx, &Lu);
   if constexpr (YT) {
     if (emit) {
       const double mh = wave_max(emx[0]), mv = wave_max(emx[1]);
@@ -594,10 +629,14 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : (YT ? ODINN_ADJ_YT_W
     for (int k = 0; k < TNW; ++k) sum += th_red[k];
     A.th_part[t4.w] = fma(a.qw, sum, A.th_part[t4.w]);
   }
-  adj_strip_stage<2, AF, SG, NR, false, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt);
-  adj_strip_stage<3, AF, SG, NR, false, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt);
-  adj_strip_stage<4, AF, SG, NR, false, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt);
-  adj_strip_stage<5, AF, SG, NR, false, RC, YT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt);
+  adj_strip_stage<2, AF, SG, NR, false, RC, YT, UT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt,
+                                                     nullptr, nullptr, nullptr, &Lu);
+  adj_strip_stage<3, AF, SG, NR, false, RC, YT, UT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt,
+                                                     nullptr, nullptr, nullptr, &Lu);
+  adj_strip_stage<4, AF, SG, NR, false, RC, YT, UT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt,
+                                                     nullptr, nullptr, nullptr, &Lu);
+  adj_strip_stage<5, AF, SG, NR, false, RC, YT, UT>(g, Afg, Ha, Hb, src, a, gic, gi, gj0, w, lane, dt, sE, sLm, u, tmp, E, Bg, sEr, nullptr, nullptr, &rc, yt,
+                                                     nullptr, nullptr, nullptr, &Lu);
   // ---- output rows [FH, (NR * TNW)-1-FH]: lam' from the registers, embedded error partial -----------------------
   const bool ocol = lane >= FH && lane < FH + FOX && inx;
   double errsq = 0.0;

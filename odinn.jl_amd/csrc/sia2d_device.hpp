@@ -2457,6 +2457,11 @@ struct AdjFusedArgs {
   double* emitV;
   unsigned long long* emit_amax;
   unsigned long long* emit_vmax;
+  // UT: the U law of target :D through its batch-wide table (LM_UTAB): D = Hbar U(Hbar, |grad S|), alpha and beta by the reference's
+  // central differences on the same bi-quintic patch (node_D<LM_UTAB>); overflow raises *ytab_over like the Y table
+  const double* utab;
+  int utab_nh, utab_ns;
+  double ut_inv_h, ut_inv_s;
   // self-controlled reverse step (the kernel's SC instantiations; see k_adj_fused_strip): launch n decides attempt n - 1 itself.
   // State, AdjState and error partials alternate between two arrays from launch to launch (nobody reads what another
   // workgroup of the same launch writes); C.errpart must point at the partials the PREVIOUS launch wrote.

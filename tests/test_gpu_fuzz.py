@@ -33,7 +33,8 @@ T0 = 2010.0
 SCHEDULES = [dict(step_sc=0), dict(step_sc=1), dict(fused_tiles=1), dict(fused_tiles=2), dict(fused_tiles=3), dict(fused_tiles=4),
              dict(dhdt_strip=0), dict(vjph_strip=0), dict(vjph_strip=1), dict(vjpth_strip=0), dict(vjpth_strip=1),
              dict(snap_on_load=0), dict(adj_fused=0), dict(adj_skip=0), dict(adj_segs=0), dict(adj_rows=4), dict(adj_rows=7),
-             dict(adj_theta_fused=0)]
+             dict(adj_theta_fused=0), dict(adj_rows=2), dict(adj_sc=0), dict(adj_sc=1), dict(adj_sc=1, adj_rows=2), dict(adj_sc=1, adj_rows=7),
+             dict(interp_async=0), dict(interp_async=2)]
 
 
 def _seeds():

@@ -97,3 +97,30 @@ def test_overflow_widens_the_table(gpu, monkeypatch):
     assert b.law_table()["hmax"][0] == 240.0 and b.law_table()["usable"]
     assert rel_l2(b.snapshot(1, 2), Hn) < 1e-11
     b.close()
+
+
+@pytest.mark.parametrize("rows", ["7", "4", "2"])
+def test_fused_reverse_step_of_the_U_table_matches_the_staged_one(gpu, monkeypatch, rows):
+    """The ContinuousAdjoint's reverse step of target :D through the table as ONE kernel (k_adj_fused_strip<..., UT>: D = Hbar U,
+    alpha and beta by the reference's central differences on the node's bi-quintic patch, face form of the H-VJP) against the five
+    k_adj_stage<LM_UTAB> launches (ODINN_ADJ_UT_FUSED=0): same loss, reverse step counts within the accept-threshold flips, gradient
+    and lambda(t0) to the tolerance of the adaptive reverse solve; ragged batch, three tile heights."""
+    monkeypatch.setenv("ODINN_ADJ_ROWS", rows)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ODINN_ADJ_UT_FUSED", mode)
+        b, om, th, fields = _batch(gpu, "default", ((56, 40), (70, 57), (131, 64)))
+        ts = [2010.0 + j / 24.0 for j in range(4)]
+        for g in range(3):
+            b.set_reference(g, ts, [fields[g][0] * (1.0 - 0.01 * j) for j in range(4)], 3)
+        assert b.law_table()["usable"]
+        L, g_ = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+        out[mode] = (L, np.array(g_, dtype=float).ravel(), [b.lambda0(k) for k in range(3)], [(s.naccept, s.nreject) for s in b.last_stats_rev])
+        b.close()
+    a, f = out["0"], out["1"]
+    assert a[0] == f[0]
+    for (na, ra), (nf, rf) in zip(a[3], f[3]):
+        assert abs(na - nf) <= max(2, na // 10) and abs(ra - rf) <= max(2, ra // 2), (a[3], f[3])
+    assert np.linalg.norm(a[1] - f[1]) <= 2e-6 * np.linalg.norm(a[1]), np.linalg.norm(a[1] - f[1]) / np.linalg.norm(a[1])
+    for la, lf in zip(a[2], f[2]):
+        assert rel_l2(lf, la) < 2e-6
