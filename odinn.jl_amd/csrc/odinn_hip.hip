@@ -485,7 +485,10 @@ struct odinn_batch {
   // U law: ONE bivariate table U(Hbar, |grad S|) for the batch (LM_UTAB), the same life cycle -- built from the network at every
   // theta update, used while it agrees with it to YTAB_TOL, a solve that leaves [0, utab_hmax] x [0, utab_smax] is repeated with
   // twice the range (d_ytab / d_ytab_over / d_ytab_stat are shared with the Y law's table)
-  int utab_nh = 128, utab_ns = 64;
+  // The table's resolution is chosen by measurement (ytab_refresh): the coarsest of 16 x 8, 32 x 16, 64 x 32, 128 x 64 patches whose
+  // deviation from the network passes -- a smooth law needs 37 ... 147 KB instead of 2.4 MB, so that the 64 nodes of a wavefront row
+  // gather from a handful of patches that stay in the L1 (utab_level: where the search starts; reset with the range).
+  int utab_nh = 16, utab_ns = 8, utab_level = 0;
   double utab_hmax = 0.0, utab_smax = 0.0;
   // law mode of the stencil kernels that evaluate the law per node and stage (forward stages, H-VJP, reverse stages)
   int lm_kern() const { return (ytab_scope > 0 && ytab_ok) ? (law_kind == ODINN_LAW_NN_U ? LM_UTAB : LM_YTAB) : lm(); }
@@ -568,7 +571,23 @@ void dfree(T*& p) {
 // network measured by k_ytab_build between the interpolation nodes must stay below YTAB_TOL relative to the law's value
 // (values below 1e-3 of the largest value in the table: relative to that largest value).
 constexpr double YTAB_TOL = 1e-12;
+constexpr int UTAB_LEVELS = 4;
+int ytab_refresh_level(odinn_batch* b, double gate);
 int ytab_refresh(odinn_batch* b) {
+  if (b->law_kind != ODINN_LAW_NN_U) return ytab_refresh_level(b, 1.0);
+  // U law: the coarsest level that passes (coarser levels must pass with a margin of 10: their 16 check points per patch are sparser
+  // in absolute terms); a level that failed is never tried again for this law / range
+  static const int forced = std::getenv("ODINN_UTAB_LEVEL") ? std::atoi(std::getenv("ODINN_UTAB_LEVEL")) : -1;  // (A/B aid)
+  if (forced >= 0 && forced < UTAB_LEVELS) b->utab_level = forced;
+  for (int lev = b->utab_level;; ++lev) {
+    b->utab_level = lev;
+    b->utab_nh = 16 << lev; b->utab_ns = 8 << lev;
+    const bool last = lev == UTAB_LEVELS - 1 || forced >= 0;
+    CHK(ytab_refresh_level(b, last ? 1.0 : 0.1));
+    if (b->ytab_ok || last) return ODINN_OK;
+  }
+}
+int ytab_refresh_level(odinn_batch* b, double gate) {
   const bool isU = b->law_kind == ODINN_LAW_NN_U;
   const size_t need = isU ? (size_t)36 * b->utab_nh * b->utab_ns : (size_t)b->G * 6 * b->ytab_ni;
   if (need > b->ytab_cap || !b->d_ytab) {
@@ -598,7 +617,7 @@ int ytab_refresh(odinn_batch* b) {
     floor_abs = 1e-3 * st[2];
   }
   b->ytab_err_rel = st[0]; b->ytab_err_abs = st[1]; b->ytab_ymax = st[2];
-  b->ytab_ok = st[0] <= YTAB_TOL && st[1] <= YTAB_TOL * st[2] && std::isfinite(st[2]) && st[2] > 0.0;
+  b->ytab_ok = st[0] <= gate * YTAB_TOL && st[1] <= gate * YTAB_TOL * st[2] && std::isfinite(st[2]) && st[2] > 0.0;
   static const bool verbose = std::getenv("ODINN_LAW_TABLE_VERBOSE") != nullptr;
   if (verbose)
     std::fprintf(stderr, "[odinn %s] %d x %d %s, rel %.3g abs %.3g max %.3g -> %s\n", isU ? "utab" : "ytab", isU ? b->utab_nh : b->G,
@@ -1020,7 +1039,7 @@ int odinn_set_fields(odinn_batch* b, int g, const double* H0, const double* B) {
     for (size_t i = 0; i < n; ++i) if (H0[i] > m) m = H0[i];
     b->h0max[g] = m;
     b->ytab_hmax[g] = 0.0;
-    b->utab_hmax = 0.0;
+    b->utab_hmax = 0.0; b->utab_level = 0;
     b->ytab_blocked = false;
     if (b->law_kind == ODINN_LAW_NN_Y || b->law_kind == ODINN_LAW_NN_U) b->gd_dirty = true;
   }
@@ -1129,7 +1148,7 @@ int odinn_set_law(odinn_batch* b, int kind, const odinn_mlp_desc* mlp, const dou
   b->mlp = *mlp;
   b->P = P;
   b->ytab_blocked = false;  // (a new law: its table gets its chance)
-  b->utab_hmax = 0.0;
+  b->utab_hmax = 0.0; b->utab_level = 0;
   b->nH = n_H; b->nS = n_gradS;
   // the reference's defaults: SIA2D_D_hybrid_target(interpolation = :Linear, n_interp_half = 75) (target_D_hybrid.jl:12-15),
   // SIA2D_D_target(interpolation = :None) (target_D_pure.jl:34-39); A-type laws have no spatial law gradient

@@ -54,6 +54,15 @@ constexpr int FOYS = 8;               // "latency" tile height: used when the ba
                                       // the GPU -- a workgroup then walks 18 region rows instead of 50
 constexpr int FNT = ODINN_FNT;        // threads per block
 constexpr int FNW = FNT / 64;
+#ifndef ODINN_UT_LAWFIRST
+#define ODINN_UT_LAWFIRST 1
+#endif
+#ifndef ODINN_UT_STREAMS_EARLY
+#define ODINN_UT_STREAMS_EARLY 0
+#endif
+#ifndef ODINN_UT_OCC
+#define ODINN_UT_OCC 2                // workgroups per CU the reverse stage kernels of the tabulated U law are compiled for
+#endif
 #ifndef ODINN_TNW
 #define ODINN_TNW 8
 #endif
@@ -1041,27 +1050,68 @@ __device__ __forceinline__ void quintic_shift(const double (&q)[6], double x, do
   plus = val + (ev + od);
   minus = val + (ev - od);
 }
-template <bool ADJ>
-__device__ __forceinline__ double utab_eval(const LawDev& L, double Hb, double gS, double (&up)[4]) {
+// The patches one tile's nodes fall into, staged in LDS by the workgroup (utab_stage): lds == nullptr -> every lane reads the table
+// in global memory.  Why: the vector L1 returns data in order, so a table load that hits still queues behind the streaming misses
+// of the other workgroups of the CU (measured on k_adj_stage / k_vjp_H / k_rk_stage at 8 x 1024^2: 27 / 26 / 42 us of 220 / 130 /
+// 127 us per launch are the table loads, with the table L1-resident); LDS reads do not.
+struct UtabTile {
+  const double2* lds;
+  int ih0, is0, nsr;
+  // per node, filled by the caller from utab_stage's pass (pre): the node's patch -- offset of its 18 double2 in `lds`, or the patch
+  // number in the global table -- and its patch coordinates, so that the evaluation repeats neither the square root nor the indexing
+  bool pre;
+  int slot;
+  double u, v;
+};
+#define ODINN_UT_NONE UtabTile{nullptr, 0, 0, 0, false, 0, 0.0, 0.0}
+// patch (ih, is) and the patch coordinates (u, v) of a node; a node beyond the table takes the table's edge and raises the flag
+__device__ __forceinline__ void utab_index(const LawDev& L, double Hb, double gS, int& ih, int& is, double& u, double& v) {
   double xh = Hb * L.ut_inv_h, xs = gS * L.ut_inv_s;
   if (!(xh < (double)L.utab_nh)) { xh = (double)L.utab_nh; *L.ytab_over = 1; }  // beyond the table (or NaN): its edge value
   if (!(xs < (double)L.utab_ns)) { xs = (double)L.utab_ns; *L.ytab_over = 1; }
-  const int ih = min((int)xh, L.utab_nh - 1), is = min((int)xs, L.utab_ns - 1);
-  const double u = fma(2.0, xh - (double)ih, -1.0), v = fma(2.0, xs - (double)is, -1.0);
-  const double2* __restrict__ c = reinterpret_cast<const double2*>(L.utab) + 18 * ((long long)ih * L.utab_ns + is);
-  double cc[6][6];  // cc[a][b]
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    const double2 c0 = c[3 * a], c1 = c[3 * a + 1], c2 = c[3 * a + 2];
-    cc[a][0] = c0.x; cc[a][1] = c0.y; cc[a][2] = c1.x; cc[a][3] = c1.y; cc[a][4] = c2.x; cc[a][5] = c2.y;
+  ih = min((int)xh, L.utab_nh - 1); is = min((int)xs, L.utab_ns - 1);
+  u = fma(2.0, xh - (double)ih, -1.0); v = fma(2.0, xs - (double)is, -1.0);
+}
+template <bool ADJ>
+__device__ __forceinline__ double utab_eval(const LawDev& L, double Hb, double gS, double (&up)[4], const UtabTile ut = ODINN_UT_NONE) {
+  int ih = 0, is = 0, slot;
+  double u, v;
+  if (ut.pre) { slot = ut.slot; u = ut.u; v = ut.v; }
+  else {
+    utab_index(L, Hb, gS, ih, is, u, v);
+    slot = ut.lds ? 18 * ((ih - ut.ih0) * ut.nsr + (is - ut.is0)) : ih * L.utab_ns + is;
   }
-  double qu[6];  // the quintic in u at the node's v
+  // (explicit address spaces: with generic pointers the compiler folds the two branches into ONE set of flat loads on a selected
+  //  pointer, and a flat load of LDS data queues in the vector memory pipeline like the global one it was meant to avoid)
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  typedef const d2v __attribute__((address_space(3))) * lds_p;
+  typedef const d2v __attribute__((address_space(1))) * glb_p;
+  d2v cr[18];  // c[a][b] of u^a v^b: cr[3 a + b / 2]
+  if (ut.lds) {    // (workgroup-uniform)
+    lds_p c = (lds_p)(ut.lds) + slot;
 #pragma unroll
-  for (int a = 0; a < 6; ++a) qu[a] = fma(fma(fma(fma(fma(cc[a][5], v, cc[a][4]), v, cc[a][3]), v, cc[a][2]), v, cc[a][1]), v, cc[a][0]);
+    for (int k = 0; k < 18; ++k) cr[k] = c[k];
+  } else {
+    glb_p c = (glb_p)(L.utab) + 18 * (long long)slot;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) cr[k] = c[k];
+  }
+  // row a = c[a][0..5], highest power of u first: qu[a] = the row's quintic in v at the node's v; qv[b] = Horner in u down the rows (ADJ)
+  double qu[6], qv[6];
+#pragma unroll
+  for (int a = 5; a >= 0; --a) {
+    const d2v c0 = cr[3 * a], c1 = cr[3 * a + 1], c2 = cr[3 * a + 2];
+    qu[a] = fma(fma(fma(fma(fma(c2.y, v, c2.x), v, c1.y), v, c1.x), v, c0.y), v, c0.x);
+    if (ADJ) {
+      if (a == 5) {
+        qv[0] = c0.x; qv[1] = c0.y; qv[2] = c1.x; qv[3] = c1.y; qv[4] = c2.x; qv[5] = c2.y;
+      } else {
+        qv[0] = fma(qv[0], u, c0.x); qv[1] = fma(qv[1], u, c0.y); qv[2] = fma(qv[2], u, c1.x);
+        qv[3] = fma(qv[3], u, c1.y); qv[4] = fma(qv[4], u, c2.x); qv[5] = fma(qv[5], u, c2.y);
+      }
+    }
+  }
   if (!ADJ) return fma(fma(fma(fma(fma(qu[5], u, qu[4]), u, qu[3]), u, qu[2]), u, qu[1]), u, qu[0]);
-  double qv[6];  // the quintic in v at the node's u
-#pragma unroll
-  for (int b = 0; b < 6; ++b) qv[b] = fma(fma(fma(fma(fma(cc[5][b], u, cc[4][b]), u, cc[3][b]), u, cc[2][b]), u, cc[1][b]), u, cc[0][b]);
   double U, U2;
   quintic_shift(qu, u, 2.0 * (1e-4 * L.ut_inv_h), U, up[0], up[1]);
   quintic_shift(qv, v, 2.0 * (1e-6 * L.ut_inv_s), U2, up[2], up[3]);
@@ -1070,21 +1120,21 @@ __device__ __forceinline__ double utab_eval(const LawDev& L, double Hb, double g
 
 template <bool ADJ, int LM, int NK = 0>
 __device__ __forceinline__ double node_D(const GDev& g, const LawDev& L, double Hb, double gS2, double Anode,
-                                         double& alpha, double& beta, double& spat) {
+                                         double& alpha, double& beta, double& spat, const UtabTile ut = ODINN_UT_NONE) {
   if constexpr (LM == LM_UTAB) {  // the U law's branch below with U and its four finite-difference points from the table
     if (!(Hb > 0.0)) {
       if (ADJ) { alpha = 0.0; beta = 0.0; spat = 0.0; }
       return 0.0;
     }
-    const double gS = sqrt(gS2);
+    const double gS = ut.pre ? 0.0 : sqrt(gS2);
     double up[4];
-    const double U = utab_eval<ADJ>(L, Hb, gS, up);
+    const double U = utab_eval<ADJ>(L, Hb, gS, up, ut);
     if (ADJ) {
       const double dH = 1e-4, dS = 1e-6;  // target_D_pure.jl:109,125
       const double Dp = up[0] * (Hb + dH), Dm = up[1] * (Hb - dH);
-      alpha = (Dp - Dm) / (2.0 * dH);
-      const double Ep = up[2] * Hb, Em = up[3] * Hb;
-      beta = (Ep - Em) / (2.0 * dS);
+      alpha = (Dp - Dm) * (1.0 / (2.0 * dH));  // (the quotients as products with the constant reciprocals: <= 1 ulp from the division,
+      const double Ep = up[2] * Hb, Em = up[3] * Hb;   //  ~60 fp64 instructions per node less)
+      beta = (Ep - Em) * (1.0 / (2.0 * dS));
       spat = Hb;
     }
     return Hb * U;
@@ -2033,14 +2083,15 @@ struct AdjArgs {
 // slopes and their bounds are already at hand from D_adjoint (adjoint.jl:99-104).
 template <int LM, int NK = 0>
 __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const Pools& P, const double2 (*sHS)[LDW],
-                                          const double (*sL)[LDW], int i0, int j0, int a, int b, double (&k)[4]) {
+                                          const double (*sL)[LDW], int i0, int j0, int a, int b, double (&k)[4],
+                                          const UtabTile ut = ODINN_UT_NONE) {
   const int gi = i0 - 1 + a, gj = j0 - 1 + b;
   k[0] = k[1] = k[2] = k[3] = 0.0;
   if (gi < 0 || gi > g.nx - 2 || gj < 0 || gj > g.ny - 2) return;
   const double2* p = &sHS[b][a];
   const double* pl = &sL[b][a];
   double al, be, sp, Dnn = 0.0;
-  constexpr bool LAW_FIRST = lm_is_nn(LM) && NK == 4;  // (measured: pays for the U law's five-point evaluation, costs the Y law 18 %)
+  constexpr bool LAW_FIRST = (lm_is_nn(LM) && NK == 4) || (LM == LM_UTAB && ODINN_UT_LAWFIRST);  // (measured: pays for the U law's five-point evaluation, costs the Y law 18 %)
   if constexpr (LAW_FIRST) {
     // per-node network: evaluate the law FIRST, from the node's thickness and slope alone, so that none of the node's other
     // quantities (corner values, bounds, lambda differences) is live across the ~2000 instructions of the network; the
@@ -2048,7 +2099,7 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
     const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
     const double gx = ((c10.y - c00.y) + (c11.y - c01.y)) * g.hinv_dx, gy = ((c01.y - c00.y) + (c11.y - c10.y)) * g.hinv_dy;
     const double Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
-    Dnn = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, g.A, al, be, sp);
+    Dnn = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, g.A, al, be, sp, ut);
     asm volatile("" ::: "memory");
   }
   const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
@@ -2069,7 +2120,7 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
   } else {
     double An = g.A;
     if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
-    D = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
+    D = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp, ut);
   }
   // first term: avg^T(alpha Da) + dx^T(ay^T(beta gx Da))/dx + dy^T(ax^T(beta gy Da))/dy
   const double ad = 0.25 * al * Da, bd = be * Da;
@@ -2105,6 +2156,9 @@ struct VjpHLds {
   static constexpr int A_D2 = (TY + 2) * LDW + ((TY + 2) * LDW + 1) / 2;  // in double2 units
   static constexpr int B_D2 = (VJ ? 3 : 2) * (TY + 1) * LDN;
   static constexpr int SIZE = ALIAS ? (A_D2 > B_D2 ? A_D2 : B_D2) : A_D2 + B_D2;
+  // tabulated U law: the tile's table patches (utab_stage) live behind the tiles, in the part of the node-result region the tiles
+  // do not cover -- 4 double2 of reduction scratch, then UT_CAP patches of 18 double2 (23 for the DiscreteVJP stencil, no extra LDS)
+  static constexpr int UT_CAP = (LM == LM_UTAB && ALIAS && B_D2 > A_D2 + 4) ? (B_D2 - A_D2 - 4) / 18 : 0;
   static __device__ __forceinline__ double2 (*hs(double2* m))[LDW] { return reinterpret_cast<double2(*)[LDW]>(m); }
   static __device__ __forceinline__ double (*lam(double2* m))[LDW] {
     return reinterpret_cast<double(*)[LDW]>(m + (TY + 2) * LDW);
@@ -2119,7 +2173,7 @@ struct VjpHLds {
 template <int LM, int NK = 0>
 __device__ __forceinline__ void vjpHc_node(const GDev& g, const LawDev& L, const Pools& P, const double2 (*sHS)[LDW],
                                            const double (*sL)[LDW], int i0, int j0, int a, int b, double (&k)[4],
-                                           double& a4, double& q4) {
+                                           double& a4, double& q4, const UtabTile ut = ODINN_UT_NONE) {
   const int gi = i0 - 1 + a, gj = j0 - 1 + b;
   k[0] = k[1] = k[2] = k[3] = 0.0;
   a4 = 0.0; q4 = 0.0;
@@ -2134,7 +2188,7 @@ __device__ __forceinline__ void vjpHc_node(const GDev& g, const LawDev& L, const
   double An = g.A;
   if (g.use_Afield) An = P.Afield[g.offd + gi + (long long)(g.nx - 1) * gj];
   double al, be, sp;
-  const double D = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp);
+  const double D = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, An, al, be, sp, ut);
   const double mxl = l10 - l00, mxu = l11 - l01, myl = l01 - l00, myr = l11 - l10;
   const double q = fma(g.hinv_dx2, fma(dxu, mxu, dxl * mxl), g.hinv_dy2 * fma(dyr, myr, dyl * myl));
   const double wx = D * g.hinv_dx2, wy = D * g.hinv_dy2;
@@ -2145,6 +2199,61 @@ __device__ __forceinline__ void vjpHc_node(const GDev& g, const LawDev& L, const
   k[3] = fma(-wx, mxu, -wy * myr) - px - py;  // cell NE
   a4 = 0.25 * al;
   q4 = 0.25 * q;
+}
+
+// Stage the table patches of this tile's nodes in LDS (tabulated U law; see UtabTile).  Every thread passes the (up to RPT + 1)
+// nodes it will evaluate; the workgroup reduces the patch rectangle [ih0, ih1] x [is0, is1] of the nodes that carry ice, and, when it
+// has at most `cap` patches, copies it to `buf` (18 double2 per patch, row-major in (ih, is)).  scratch: 4 * NW ints of LDS.  Contains
+// two barriers, the second one after the copy; the tiles must be complete (synchronised) on entry.
+__device__ __forceinline__ UtabTile utab_stage(const GDev& g, const LawDev& L, const double2 (*sHS)[LDW], int i0, int j0, int tx, int ty,
+                                               int ea, int eb, bool extra, double2* buf, int cap, int* scratch, int (&slot)[RPT + 1],
+                                               double (&pu)[RPT + 1], double (&pv)[RPT + 1]) {
+  int lo_h = 1 << 30, hi_h = -1, lo_s = 1 << 30, hi_s = -1;
+  int nih[RPT + 1], nis[RPT + 1];
+#pragma unroll
+  for (int m = 0; m <= RPT; ++m) {
+    const int a = m < RPT ? tx : ea, b = m < RPT ? ty + NW * m : eb;
+    const int gi = i0 - 1 + a, gj = j0 - 1 + b;
+    nih[m] = 0; nis[m] = 0; pu[m] = 0.0; pv[m] = 0.0;
+    if ((m < RPT || extra) && gi >= 0 && gi <= g.nx - 2 && gj >= 0 && gj <= g.ny - 2) {
+      double gx, gy, Hb;
+      node_geom<LDW>(g, &sHS[b][a], gx, gy, Hb);
+      if (Hb > 0.0) {
+        utab_index(L, Hb, sqrt(gx * gx + gy * gy), nih[m], nis[m], pu[m], pv[m]);
+        lo_h = min(lo_h, nih[m]); hi_h = max(hi_h, nih[m]); lo_s = min(lo_s, nis[m]); hi_s = max(hi_s, nis[m]);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo_h = min(lo_h, __shfl_xor(lo_h, o, 64)); hi_h = max(hi_h, __shfl_xor(hi_h, o, 64));
+    lo_s = min(lo_s, __shfl_xor(lo_s, o, 64)); hi_s = max(hi_s, __shfl_xor(hi_s, o, 64));
+  }
+  if (tx == 0) { scratch[4 * ty] = lo_h; scratch[4 * ty + 1] = hi_h; scratch[4 * ty + 2] = lo_s; scratch[4 * ty + 3] = hi_s; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    lo_h = min(lo_h, scratch[4 * w]); hi_h = max(hi_h, scratch[4 * w + 1]);
+    lo_s = min(lo_s, scratch[4 * w + 2]); hi_s = max(hi_s, scratch[4 * w + 3]);
+  }
+  UtabTile T = ODINN_UT_NONE;
+  T.pre = true;
+  const int nhr = hi_h - lo_h + 1, nsr = hi_s - lo_s + 1;
+  const bool fits = hi_h >= 0 && nhr * nsr <= cap;
+#pragma unroll
+  for (int m = 0; m <= RPT; ++m)  // (nodes without ice never evaluate the table: whatever their slot says)
+    slot[m] = fits ? 18 * ((nih[m] - lo_h) * nsr + (nis[m] - lo_s)) : nih[m] * L.utab_ns + nis[m];
+  if (fits) {  // (workgroup-uniform)
+    const double2* __restrict__ tab = reinterpret_cast<const double2*>(L.utab);
+    for (int idx = threadIdx.x; idx < 18 * nhr * nsr; idx += NT) {
+      const int p = idx / 18, k = idx - 18 * p;
+      const int ph = p / nsr, ps = p - ph * nsr;
+      buf[idx] = tab[18 * ((long long)(lo_h + ph) * L.utab_ns + (lo_s + ps)) + k];
+    }
+    T.lds = buf; T.ih0 = lo_h; T.is0 = lo_s; T.nsr = nsr;
+  }
+  __syncthreads();
+  return T;
 }
 
 // v[m] = (J_H(H)^T lam)[cell m of this thread] from tiles already in LDS (and synchronised).
@@ -2163,13 +2272,24 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
   // the 65th column and 17th row of nodes: wavefront 0 takes the row, wavefront 1 the column
   const int ea = ty == 0 ? tx : TX, eb = ty == 0 ? TY : tx;
   const bool extra = ty == 0 || (ty == 1 && tx <= TY);
+  UtabTile ut = ODINN_UT_NONE;
+  int ut_slot[RPT + 1];
+  double ut_u[RPT + 1], ut_v[RPT + 1];
+  if constexpr (S::UT_CAP > 0)
+    ut = utab_stage(g, L, sHS, i0, j0, tx, ty, ea, eb, extra, smem + S::A_D2 + 4, S::UT_CAP, reinterpret_cast<int*>(smem + S::A_D2),
+                    ut_slot, ut_u, ut_v);
+  auto utn = [&](int m) {  // the tile descriptor with node m's patch and coordinates
+    UtabTile t = ut;
+    if constexpr (S::UT_CAP > 0) { t.slot = ut_slot[m]; t.u = ut_u[m]; t.v = ut_v[m]; }
+    return t;
+  };
   if constexpr (VJ == 1) {
     double2(*sCc)[LDN] = reinterpret_cast<double2(*)[LDN]>(cbase + 2 * (TY + 1) * LDN);  // {alpha/4, q/4}
     if constexpr (S::ALIAS) {  // closed-form A laws: the node results are staged in registers, their LDS aliases the tiles
       double kk[RPT + 1][4], aa[RPT + 1], qq[RPT + 1];
 #pragma unroll
-      for (int m = 0; m < RPT; ++m) vjpHc_node<LM, NK>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m], aa[m], qq[m]);
-      if (extra) vjpHc_node<LM, NK>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT], aa[RPT], qq[RPT]);
+      for (int m = 0; m < RPT; ++m) vjpHc_node<LM, NK>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m], aa[m], qq[m], utn(m));
+      if (extra) vjpHc_node<LM, NK>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT], aa[RPT], qq[RPT], utn(RPT));
       __syncthreads();
 #pragma unroll
       for (int m = 0; m < RPT; ++m) {
@@ -2213,8 +2333,11 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
   if constexpr (S::ALIAS) {
     double kk[RPT + 1][4];
 #pragma unroll
-    for (int m = 0; m < RPT; ++m) vjpH_node<LM, NK>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m]);
-    if (extra) vjpH_node<LM, NK>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT]);
+    for (int m = 0; m < RPT; ++m) {
+      vjpH_node<LM, NK>(g, L, P, sHS, sL, i0, j0, tx, ty + NW * m, kk[m], utn(m));
+      if constexpr (LM == LM_UTAB) asm volatile("" ::: "memory");  // one node's 36 table loads at a time (register budget)
+    }
+    if (extra) vjpH_node<LM, NK>(g, L, P, sHS, sL, i0, j0, ea, eb, kk[RPT], utn(RPT));
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < RPT; ++m) {
@@ -2271,7 +2394,7 @@ __device__ __forceinline__ bool vjpH_tile_or_zero(const GDev& g, const LawDev& L
 }
 
 template <int MODE, int LM, int VJ = 0, int NK = 0>
-__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
+__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : LM == LM_UTAB ? ODINN_UT_OCC : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
   __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
@@ -2475,7 +2598,7 @@ struct AdjFusedArgs {
 
 
 template <int STAGE, int LM, int VJ = 0, int NK = 0>
-__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_stage(Pools P, LawDev L, AdjStageArgs A) {
+__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : LM == LM_UTAB ? ODINN_UT_OCC : 2)) void k_adj_stage(Pools P, LawDev L, AdjStageArgs A) {
   __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x];
@@ -2515,9 +2638,10 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_
       }
     }
   };
-  if constexpr (NK != 4) fetch_streams();
+  constexpr bool STREAMS_LATE = NK == 4 || (LM == LM_UTAB && ODINN_UT_LAWFIRST && !ODINN_UT_STREAMS_EARLY);
+  if constexpr (!STREAMS_LATE) fetch_streams();
   vjpH_tile_or_zero<LM, VJ, NK>(g, L, P, smem, i0, j0, ownH, v);
-  if constexpr (NK == 4) fetch_streams();
+  if constexpr (STREAMS_LATE) fetch_streams();
   constexpr int s = STAGE - 1;
   constexpr double g1 = c_g1[s], g2 = c_g2[s], g3 = c_g3[s], dl = c_dl[s], bt = c_bt[s], bh = c_bh[s];
   double errsq = 0.0;

@@ -46,7 +46,7 @@ def test_table_reproduces_the_network(gpu, arch):
     Lc, gc = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
     b.set_schedule()
     info = b.law_table()
-    assert info["usable"] and info["max_rel_dev"] < 1e-12 and info["n_intervals"] == 128 * 64, info
+    assert info["usable"] and info["max_rel_dev"] < 1e-12 and info["n_intervals"] in (16 * 8, 32 * 16, 64 * 32, 128 * 64), info
     b.solve(ts, reltol=1e-8)
     for g in range(2):
         assert rel_l2(b.snapshot(g, 3), Hn[g]) < 1e-11
@@ -118,7 +118,7 @@ def test_fused_reverse_step_of_the_U_table_matches_the_staged_one(gpu, monkeypat
         out[mode] = (L, np.array(g_, dtype=float).ravel(), [b.lambda0(k) for k in range(3)], [(s.naccept, s.nreject) for s in b.last_stats_rev])
         b.close()
     a, f = out["0"], out["1"]
-    assert a[0] == f[0]
+    assert abs(a[0] - f[0]) <= 1e-13 * abs(a[0])  # (the loss partials are summed per tile of the kernel that meets the stop: strips vs 64 x 16 tiles)
     for (na, ra), (nf, rf) in zip(a[3], f[3]):
         assert abs(na - nf) <= max(2, na // 10) and abs(ra - rf) <= max(2, ra // 2), (a[3], f[3])
     assert np.linalg.norm(a[1] - f[1]) <= 2e-6 * np.linalg.norm(a[1]), np.linalg.norm(a[1] - f[1]) / np.linalg.norm(a[1])
