@@ -171,7 +171,8 @@ typedef struct odinn_schedule {
                               glacier's scalar temperature and Hbar) or the U law (ODINN_LAW_NN_U: inputs = Hbar and |grad S|)
                               evaluate the network at every dual node and stage.  Default (-1 / 1): inside the forward solve and
                               both adjoints they read the law from a table -- Y(Hbar) per glacier in 1024 quintics, U(Hbar, |grad S|)
-                              for the batch in 128 x 64 bi-quintic patches -- rebuilt from the network whenever theta changes, used
+                              for the batch in bi-quintic patches, the coarsest of 16 x 8 ... 128 x 64 that passes the check (a
+                              smooth law: 37 KB that stay in the L1 instead of 2.4 MB) -- rebuilt from the network whenever theta changes, used
                               only while its measured deviation from the network is < 1e-12 relative (else the network); a solve
                               that leaves the table's range is repeated with a wider one.  The seam calls always evaluate the
                               network.  What the 1e-12 bounds are the VALUES of the law: the finite-difference terms of the adjoints

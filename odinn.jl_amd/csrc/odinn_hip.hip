@@ -531,6 +531,10 @@ struct odinn_batch {
     L.ytab_ni = ytab_ni;
     L.utab = d_ytab;
     L.utab_nh = utab_nh; L.utab_ns = utab_ns;
+    {
+      const char* e = std::getenv("ODINN_UT_LDS");  // (read per call: tests toggle it)
+      L.ut_nolds = e && e[0] == '0' ? 1 : 0;
+    }
     L.ut_inv_h = utab_hmax > 0.0 ? (double)utab_nh / utab_hmax : 1.0;
     L.ut_inv_s = utab_smax > 0.0 ? (double)utab_ns / utab_smax : 1.0;
     return L;
@@ -577,7 +581,7 @@ int ytab_refresh(odinn_batch* b) {
   if (b->law_kind != ODINN_LAW_NN_U) return ytab_refresh_level(b, 1.0);
   // U law: the coarsest level that passes (coarser levels must pass with a margin of 10: their 16 check points per patch are sparser
   // in absolute terms); a level that failed is never tried again for this law / range
-  static const int forced = std::getenv("ODINN_UTAB_LEVEL") ? std::atoi(std::getenv("ODINN_UTAB_LEVEL")) : -1;  // (A/B aid)
+  const int forced = std::getenv("ODINN_UTAB_LEVEL") ? std::atoi(std::getenv("ODINN_UTAB_LEVEL")) : -1;  // (A/B and test aid; read per call)
   if (forced >= 0 && forced < UTAB_LEVELS) b->utab_level = forced;
   for (int lev = b->utab_level;; ++lev) {
     b->utab_level = lev;

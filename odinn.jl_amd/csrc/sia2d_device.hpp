@@ -190,6 +190,7 @@ struct LawDev {  // passed by value to kernels
   // [j, j + 1) / ut_inv_s of |grad S|; overflow raises *ytab_over as well
   const double* utab;
   int utab_nh, utab_ns;
+  int ut_nolds;  // ODINN_UT_LDS=0 (test aid): the tile kernels read the patches from global memory even where utab_stage could stage them
   double ut_inv_h, ut_inv_s;
 };
 
@@ -2276,7 +2277,7 @@ __device__ __forceinline__ void vjpH_tile(const GDev& g, const LawDev& L, const 
   int ut_slot[RPT + 1];
   double ut_u[RPT + 1], ut_v[RPT + 1];
   if constexpr (S::UT_CAP > 0)
-    ut = utab_stage(g, L, sHS, i0, j0, tx, ty, ea, eb, extra, smem + S::A_D2 + 4, S::UT_CAP, reinterpret_cast<int*>(smem + S::A_D2),
+    ut = utab_stage(g, L, sHS, i0, j0, tx, ty, ea, eb, extra, smem + S::A_D2 + 4, L.ut_nolds ? 0 : S::UT_CAP, reinterpret_cast<int*>(smem + S::A_D2),
                     ut_slot, ut_u, ut_v);
   auto utn = [&](int m) {  // the tile descriptor with node m's patch and coordinates
     UtabTile t = ut;

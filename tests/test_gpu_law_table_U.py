@@ -1,5 +1,5 @@
 """GPU: the tabulated U law (law mode LM_UTAB): LawU's inputs are Hbar and |grad S| (Laws.jl:97-183) -- one bivariate function for
-the whole batch, read by the stencil kernels of the solve and of both adjoints from 128 x 64 bi-quintic patches built from the
+the whole batch, read by the stencil kernels of the solve and of both adjoints from bi-quintic patches (16 x 8 ... 128 x 64, the coarsest resolution that passes) built from the
 network (and checked against it to 1e-12) unless odinn_schedule.law_table = 0.  Same contract as the Y law's table
 (test_gpu_law_table.py): table == network to 1e-11 (states) / 1e-7 (gradients: central differences with 1e-4 and 1e-6 amplify any
 difference in U), oracle tolerances of the network path, overflow repeats the solve, the seams keep the network."""
@@ -124,3 +124,58 @@ def test_fused_reverse_step_of_the_U_table_matches_the_staged_one(gpu, monkeypat
     assert np.linalg.norm(a[1] - f[1]) <= 2e-6 * np.linalg.norm(a[1]), np.linalg.norm(a[1] - f[1]) / np.linalg.norm(a[1])
     for la, lf in zip(a[2], f[2]):
         assert rel_l2(lf, la) < 2e-6
+
+
+def test_table_resolution_is_chosen_by_measurement(gpu, monkeypatch):
+    """The table's resolution: the coarsest of 16 x 8 ... 128 x 64 patches that passes the check (the default) against the finest
+    (ODINN_UTAB_LEVEL=3, the fixed size of round 4): both within 1e-12 of the network, same solve to 1e-11, same gradients to the
+    tolerance the table has against the network."""
+    out = {}
+    for lev in (None, "3"):
+        if lev is None:
+            monkeypatch.delenv("ODINN_UTAB_LEVEL", raising=False)
+        else:
+            monkeypatch.setenv("ODINN_UTAB_LEVEL", lev)
+        b, om, th, fields = _batch(gpu, "default")
+        ts = [2010.0 + j / 24.0 for j in range(4)]
+        for g in range(2):
+            b.set_reference(g, ts, [fields[g][0] * (1.0 - 0.01 * j) for j in range(4)], 3)
+        b.solve(ts, reltol=1e-8)
+        info = b.law_table()
+        assert info["usable"] and info["max_rel_dev"] < 1e-12, info
+        L, gd = b.loss_grad(ts, theta=th, reltol=1e-8)
+        Lc, gc = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+        out[lev] = (info["n_intervals"], [b.snapshot(g, 3) for g in range(2)], L, np.array(gd, float).ravel(), Lc, np.array(gc, float).ravel())
+        b.close()
+    a, f = out[None], out["3"]
+    assert f[0] == 128 * 64 and a[0] <= f[0]
+    for g in range(2):
+        assert rel_l2(a[1][g], f[1][g]) < 1e-11
+    assert abs(a[2] - f[2]) <= 1e-10 * abs(f[2]) and rel_l2(a[3], f[3]) < 1e-7
+    assert abs(a[4] - f[4]) <= 1e-10 * abs(f[4]) and rel_l2(a[5], f[5]) < 1e-6
+
+
+@pytest.mark.parametrize("vjp", ["discrete", "continuous"])
+def test_staged_patches_are_bit_identical_to_global_loads(gpu, monkeypatch, vjp):
+    """The reverse tile kernels stage the patches of their tile's nodes in LDS (utab_stage: patch rectangle of the workgroup, every
+    node's patch and patch coordinates from one pass); ODINN_UT_LDS=0 keeps the same evaluation on loads from the global table.  Same
+    arithmetic on the same coefficients: bit-identical losses, gradients and lambda(t0), ragged batch, both VJP stencils."""
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ODINN_UT_LDS", mode)
+        b, om, th, fields = _batch(gpu, "default", ((56, 40), (70, 57), (131, 64)))
+        if vjp == "continuous":
+            b.set_vjp_method(gpu._lib.VJP_CONTINUOUS)
+        ts = [2010.0 + j / 24.0 for j in range(4)]
+        for g in range(3):
+            b.set_reference(g, ts, [fields[g][0] * (1.0 - 0.01 * j) for j in range(4)], 3)
+        assert b.law_table()["usable"]
+        L, gd = b.loss_grad(ts, theta=th, reltol=1e-8)
+        Lc, gc = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+        out[mode] = (L, np.array(gd, float).ravel(), Lc, np.array(gc, float).ravel(), [b.lambda0(k) for k in range(3)])
+        b.close()
+    a, f = out["1"], out["0"]
+    assert a[0] == f[0] and np.array_equal(a[1], f[1])
+    assert a[2] == f[2] and np.array_equal(a[3], f[3])
+    for la, lf in zip(a[4], f[4]):
+        assert np.array_equal(la, lf)
