@@ -777,7 +777,20 @@ def test_random_batch_forward_solve_matches_the_oracle(gpu, monkeypatch, seed):
         else:
             cfg = O.SimConfig(tstops=c["own"][g], reltol=1e-8, mb=mb, mb_times=mt, fixed_dt=c["dts"] if how == "fixed" else None)
             snaps, so, _ = O.forward(gl, law, cfg)
-            assert abs(st[g].naccept - so.naccept) <= 2 and abs(st[g].nreject - so.nreject) <= 2, (tag, g, st[g], so)
+            close = lambda s_: abs(st[g].naccept - s_.naccept) <= 2 and abs(st[g].nreject - s_.nreject) <= 2
+            unstable = False
+            if how == "adaptive" and not close(so):
+                # A step that ends within ~1e-5 of its length before a stop is followed by a sliver step onto the stop and by a dozen
+                # steps in which the controller grows the step size back (dt = h * factor, factor <= 1 + pi / 2); one that reaches the
+                # stop is not.  Where the error estimate sits at the round-off floor (smooth draws: err ~ 1e-14 m) the two sides'
+                # step sizes differ by 1e-5 relative and can fall on either side of that edge (seed 19220: 20 steps here, 7 in the
+                # oracle -- whose own count is 7, 16, 15, 11 under 1e-4 ... 1e-2 relative changes of reltol -- snapshots equal to
+                # 3e-13).  The step count is then not a property of the algorithm: not compared where the ORACLE's own count moves by
+                # more than the window under such a change; the snapshots still are.
+                counts = [O.forward(gl, law, O.SimConfig(tstops=c["own"][g], reltol=1e-8 * rs, mb=mb, mb_times=mt))[1].naccept
+                          for rs in (1.0 - 1e-4, 1.0 + 1e-4, 1.0 - 1e-3, 1.0 + 1e-3)] + [so.naccept]
+                unstable = max(counts) - min(counts) > 2
+            assert unstable or close(so), (tag, g, st[g], so)
             tol = 1e-11 if how == "fixed" else 1e-6
         assert abs(st[g].t_final - c["own"][g][-1]) < 1e-12, (tag, g)
         for j in range(len(snaps)):
