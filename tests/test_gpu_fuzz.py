@@ -207,6 +207,19 @@ def _draw(gpu, seed, velocity=False):
                 laws=laws, sched=sched, step=step, dts=dts, vel=vel, fV=fV, phs=phs)
 
 
+def _oracle_gradient_or_skip(test, seed, tag, c, nq, parts=None):
+    """_oracle_gradient; a draw on which the CHECKER's own adaptive solve runs into maxiters is skipped (audited).  Seen once in
+    21 200 seeds (aggregated terms, seed 19681: constant A with sliding, LogSum loss, two mass-balance times, ContinuousAdjoint -- the
+    reverse ODE's step size collapses); the device was run on that draw by hand and reports the same thing, ODINN_ERR_MAXITERS "in the
+    reverse solve with 1 glaciers active" after its 10^6 attempts."""
+    try:
+        return _oracle_gradient(c, nq, parts=parts)
+    except RuntimeError as e:
+        if "maxiters" not in str(e):
+            raise
+        _skip(test, seed, "the checker's own solve reaches maxiters", tag)
+
+
 def _oracle_gradient(c, nq, rel_perturbation=0.0, parts=None):
     """(loss, d loss / d theta) of the draw by the oracle, summed over the glaciers; the parameters (theta, or the glaciers' A)
     scaled by 1 + rel_perturbation."""
@@ -310,7 +323,7 @@ def test_random_batch_gradient_matches_the_oracle(gpu, monkeypatch, seed):
     dt_fixed = c["dts"]
     # ---- oracle, glacier by glacier
     per = []
-    Lo, go = _oracle_gradient(c, nq, parts=per)
+    Lo, go = _oracle_gradient_or_skip("gradient", seed, tag, c, nq, parts=per)
     ill = mode != "discrete_fixed" and _ill_conditioned(c, nq, go, 2e-5)
     ILL = "the checker's own gradient moves by more than the tolerance under a 1e-12 perturbation of the parameters"
     if ill and not _audit():
@@ -387,7 +400,7 @@ def test_random_batch_velocity_loss_gradient_matches_the_oracle(gpu, monkeypatch
     tag = {k: c[k] for k in ("G", "kind", "mode", "log_eps", "mbt", "interp", "shapes", "dxs", "dys", "sched", "fV")}
     tag.update({k: v[k] for k in ("kind", "component", "log_eps", "scale")}, sliding=ph.C != 0.0, law=kind)
     nq = 8
-    Lo, go = _oracle_gradient(c, nq)
+    Lo, go = _oracle_gradient_or_skip("velocity", seed, tag, c, nq)
     ill = mode != "discrete_fixed" and _ill_conditioned(c, nq, go, 2e-5)
     ILL = "the checker's own gradient moves by more than the tolerance under a 1e-12 perturbation of the parameters"
     if ill and not _audit():
@@ -654,7 +667,7 @@ def test_random_batch_time_aggregated_terms_match_the_oracle(gpu, monkeypatch, s
     tag = {q: c[q] for q in ("G", "kind", "mode", "log_eps", "mbt", "interp", "shapes", "dxs", "dys", "sched")}
     tag.update(terms=terms, comp=comp, dist=dist, sliding=ph.C != 0.0)
     nq = 8
-    Lo, go = _oracle_gradient(c, nq)
+    Lo, go = _oracle_gradient_or_skip("aggregated", seed, tag, c, nq)
     ill = mode != "discrete_fixed" and _ill_conditioned(c, nq, go, 2e-5)
     ILL = "the checker's own gradient moves by more than the tolerance under a 1e-12 perturbation of the parameters"
     if ill and not _audit():
