@@ -476,7 +476,9 @@ def test_fused_reverse_step_with_rejected_steps(gpu, monkeypatch):
     a, f = out["0"], out["1"]
     assert a[2] == f[2] and sum(r for _, r in a[2]) > 0, (a[2], f[2])
     assert np.abs(a[1] - f[1]).max() <= 1e-10 * np.abs(a[1]).max()
-    assert rel_l2(f[3], a[3]) < 1e-10
+    # (lambda(t0) of a reverse solve run at reltol 1e-4 across three jumps: 1e-11 under the default schedule, 9e-10 with the LDS-tile
+    #  forward kernel -- ODINN_FUSED_TILES=l in tools/suite_matrix.sh -- whose snapshots differ from the strip kernel's in the last bits)
+    assert rel_l2(f[3], a[3]) < 1e-8
 
 
 @pytest.mark.parametrize("case", ["scalar_nn_mb", "gridded_nn", "ragged_batch", "rejections", "mb_only_stops", "y_table"])
@@ -510,6 +512,7 @@ def test_self_controlled_reverse_step_matches_the_three_launch_loop(gpu, monkeyp
             # the Y law through its table, `:Linear` gradient: stage 1 of the fused step emits the node pairs of a quadrature node
             # (both loops), the sort-free contraction runs on the lanes
             from test_gpu_parity import _mlp_pair
+            monkeypatch.delenv("ODINN_LAW_TABLE", raising=False)  # (the case IS the table: tools/suite_matrix.sh runs the suite with it off)
             ph = O.Phys()
             om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
             shapes = [(70, 57), (131, 64), (54, 46)]
