@@ -54,15 +54,6 @@ constexpr int FOYS = 8;               // "latency" tile height: used when the ba
                                       // the GPU -- a workgroup then walks 18 region rows instead of 50
 constexpr int FNT = ODINN_FNT;        // threads per block
 constexpr int FNW = FNT / 64;
-#ifndef ODINN_UT_LAWFIRST
-#define ODINN_UT_LAWFIRST 1
-#endif
-#ifndef ODINN_UT_STREAMS_EARLY
-#define ODINN_UT_STREAMS_EARLY 0
-#endif
-#ifndef ODINN_UT_OCC
-#define ODINN_UT_OCC 2                // workgroups per CU the reverse stage kernels of the tabulated U law are compiled for
-#endif
 #ifndef ODINN_TNW
 #define ODINN_TNW 8
 #endif
@@ -2092,7 +2083,8 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
   const double2* p = &sHS[b][a];
   const double* pl = &sL[b][a];
   double al, be, sp, Dnn = 0.0;
-  constexpr bool LAW_FIRST = (lm_is_nn(LM) && NK == 4) || (LM == LM_UTAB && ODINN_UT_LAWFIRST);  // (measured: pays for the U law's five-point evaluation, costs the Y law 18 %)
+  // (measured: pays for the U law's five-point evaluation, costs the Y law 18 %; the U TABLE: 200 -> 142 VGPRs, 275 -> 221 us at 8 x 1024^2)
+  constexpr bool LAW_FIRST = (lm_is_nn(LM) && NK == 4) || LM == LM_UTAB;
   if constexpr (LAW_FIRST) {
     // per-node network: evaluate the law FIRST, from the node's thickness and slope alone, so that none of the node's other
     // quantities (corner values, bounds, lambda differences) is live across the ~2000 instructions of the network; the
@@ -2395,7 +2387,7 @@ __device__ __forceinline__ bool vjpH_tile_or_zero(const GDev& g, const LawDev& L
 }
 
 template <int MODE, int LM, int VJ = 0, int NK = 0>
-__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : LM == LM_UTAB ? ODINN_UT_OCC : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
+__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_vjp_H(Pools P, LawDev L, AdjArgs A, int tile_base) {
   __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x + tile_base];
@@ -2599,7 +2591,7 @@ struct AdjFusedArgs {
 
 
 template <int STAGE, int LM, int VJ = 0, int NK = 0>
-__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : LM == LM_UTAB ? ODINN_UT_OCC : 2)) void k_adj_stage(Pools P, LawDev L, AdjStageArgs A) {
+__global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : 2)) void k_adj_stage(Pools P, LawDev L, AdjStageArgs A) {
   __shared__ double2 smem[VjpHLds<LM, VJ>::SIZE];
   __shared__ double red[NW];
   const int4 t4 = P.tiles[blockIdx.x];
@@ -2639,7 +2631,8 @@ __global__ __launch_bounds__(NT, (LM == LM_FAST && VJ == 0 ? 4 : LM == LM_UTAB ?
       }
     }
   };
-  constexpr bool STREAMS_LATE = NK == 4 || (LM == LM_UTAB && ODINN_UT_LAWFIRST && !ODINN_UT_STREAMS_EARLY);
+  // (the U table: fetched after the stencil as well -- 24 registers less across it; fetching them early measured 206 vs 202 us, noise)
+  constexpr bool STREAMS_LATE = NK == 4 || LM == LM_UTAB;
   if constexpr (!STREAMS_LATE) fetch_streams();
   vjpH_tile_or_zero<LM, VJ, NK>(g, L, P, smem, i0, j0, ownH, v);
   if constexpr (STREAMS_LATE) fetch_streams();
