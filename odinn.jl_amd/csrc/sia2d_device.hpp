@@ -2158,6 +2158,9 @@ struct VjpHLds {
   }
 };
 
+static_assert(VjpHLds<LM_UTAB, 0>::UT_CAP == 23 && VjpHLds<LM_UTAB, 0>::SIZE == VjpHLds<LM_FAST, 0>::SIZE && VjpHLds<LM_FAST, 0>::UT_CAP == 0,
+              "the staged patches of the U table fit the node-result region the tiles leave free: no extra LDS");
+
 // One dual node of the CONTINUOUS-form H-VJP (VJP_lambda_dSIA/dH_continuous, adjoint.jl:442-553):
 //   dlam = div(D grad lam) - avg(dD/dH) avg(q) + avg_y(dx(q beta gSx))/dx + avg_x(dy(q beta gSy))/dy
 // on the interior, q = <grad S, grad lam> on the dual grid (:534-538), slopes unclamped, lambda raw.

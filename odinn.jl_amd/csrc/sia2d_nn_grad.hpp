@@ -91,6 +91,12 @@ struct NNG {
   static constexpr int XBUF = NW * 64 * ROW;  // doubles
 };
 
+// the groupings the three compile-time architectures get (a change of ROWCAP or of make_groups shows up here, not in a profile)
+static_assert(NNG<ArchDef>::GR.n == 2 && NNG<ArchDef>::GR.lo[0] == 2 && NNG<ArchDef>::NACC == 2 && NNG<ArchDef>::ROW == 19 && NNG<ArchDef>::P == 86,
+              "2-3-10-3-1: {L3, L2} and {L1, L0}, one 64-parameter slot each, rows of 19 doubles");
+static_assert(NNG<Arch16>::GR.n == 3 && NNG<Arch16>::ROW == 33 && NNG<Arch16>::NACC == 1 + 5 + 1, "2-16-16-1: one group per layer, rows of 33 doubles");
+static_assert(NNG<ArchLight>::GR.n == 1 && NNG<ArchLight>::NACC == 1 && NNG<ArchLight>::P == 13, "2-3-1: one group, one slot");
+
 template <int CODE>
 __device__ __forceinline__ void act_and_deriv(double z, double& h, double& d) {
   if (CODE == 1) {  // softplus, derivative sigmoid: share t = exp(-|z|)
