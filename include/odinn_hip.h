@@ -52,6 +52,9 @@ extern "C" {
 #define ODINN_ERR_MAXITERS 5
 #define ODINN_ERR_NONFINITE 6
 #define ODINN_ERR_UNSUPPORTED 7
+#define ODINN_ERR_DTMIN 8 /* an adaptive solve (forward or reverse) whose step size fell to the resolution of its time variable,
+                             dt <= eps(t): it cannot proceed.  OrdinaryDiffEq ends such a solve with ReturnCode.DtLessThanMin
+                             ("dt <= dtmin ... Aborting"); without this exit it would spin until maxiters */
 
 #define ODINN_MAX_LAYERS 8
 #define ODINN_MAX_WIDTH 32

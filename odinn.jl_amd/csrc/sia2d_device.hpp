@@ -1816,6 +1816,14 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
     return 1;
   }
   double dtn = C.adaptive ? h * fac : C.fixed_dt;
+  // the step size has fallen to the resolution of t: the solve cannot proceed (OrdinaryDiffEq aborts with ReturnCode.DtLessThanMin at
+  // dt <= dtmin = eps(t)) -- the glacier leaves the loop, the host reports ODINN_ERR_DTMIN (GState::nonfinite == 2)
+  if (C.adaptive && !(dtn > 2.220446049250313e-16 * fabs(t))) {
+    if (!st.nonfinite) st.nonfinite = 2;  // (a non-finite error estimate on the way down stays the reported cause)
+    st.done = 1;
+    est = 0;
+    return 1;
+  }
   if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
   const double rem = tstop_at(st.istop) - t;
   // snap to the stop when the step would end within 100 ulp of it

@@ -643,6 +643,12 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
     return;
   }
   double dtn = C.adaptive ? h * fac : C.fixed_dt;
+  if (C.adaptive && !(dtn > 2.220446049250313e-16 * fabs(t))) {  // dt <= eps(t): see controller_decide
+    if (!s.nonfinite) s.nonfinite = 2;
+    s.done = 1;
+    est = 0;
+    return;
+  }
   if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
   const double rem = C.tstop(s.istop, gidx) - t;
   if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {

@@ -1024,6 +1024,10 @@ def solve(
             else:
                 st.nreject += 1
             dt = h * fac
+            # OrdinaryDiffEq's check_error: dt <= dtmin = eps(t) ends the solve with ReturnCode.DtLessThanMin ("Aborting")
+            if t < tstops[-1] and not dt > np.finfo(F).eps * abs(t):
+                raise RuntimeError("dt <= dtmin: the step size fell to the resolution of t at t = %r after %d accepted / %d rejected steps"
+                                   % (t, st.naccept, st.nreject))
         if callback is not None and ts in cbt:
             unew = callback(u, ts)
             cb_inc[ts] = unew - u

@@ -139,6 +139,22 @@ def test_abi_error_behaviour(gpu):
     b.set_glacier_stops(0, None)
     with pytest.raises(gpu.OdinnError, match="maxiters"):
         b.solve([0.0, 50.0], maxiters=3, dt0=1e-9)
+    # a tolerance no step size can meet: dt falls to the resolution of t and the solve ends with ODINN_ERR_DTMIN (error 8; OrdinaryDiffEq:
+    # ReturnCode.DtLessThanMin) after a few dozen rejections -- under every forward schedule, and in the reverse solve
+    for sched, scheme in ((dict(), 0), (dict(), 1), (dict(step_sc=0), 0), (dict(step_sc=1), 0), (dict(fused_tiles=1), 0)):
+        b.set_schedule(**sched)
+        with pytest.raises(gpu.OdinnError, match=r"error 8: step size below the resolution of t"):
+            b.solve([2010.0, 2010.5], reltol=1e-30, abstol=1e-300, scheme=scheme)
+    b.set_schedule()
+    ts = [2010.0, 2010.25, 2010.5]
+    b.set_reference(0, ts, [H0 * (1.0 - 0.01 * j) for j in range(3)], 3)
+    for sched in (dict(), dict(adj_sc=1), dict(adj_sc=0), dict(adj_fused=0)):
+        b.set_schedule(**sched)
+        with pytest.raises(gpu.OdinnError, match=r"error 8: step size below the resolution of tau"):
+            b.loss_grad_continuous(ts, reltol=1e-8, adj_reltol=1e-30, adj_abstol=1e-300, n_quadrature=6)
+    b.set_schedule()
+    L0, g0 = b.loss_grad_continuous(ts, reltol=1e-8, n_quadrature=6)  # (the batch is usable afterwards)
+    assert np.isfinite(L0)
     with pytest.raises(ValueError):
         b.set_fields(0, H0[:-1], B)
     with pytest.raises(gpu.OdinnError):

@@ -3,6 +3,7 @@ convergence order, the PID controller, the Halfar known answer and volume conser
 import math
 
 import numpy as np
+import pytest
 
 from conftest import rel_l2
 from oracle import sia2d_oracle as O
@@ -75,6 +76,18 @@ def test_adaptive_solve_tolerance_and_tstops():
     # callback applied exactly at its stop and included in the stored state
     sn3, _, inc = O.solve(f, np.array([1.0]), [0.0, 1.0, 2.0], reltol=1e-8, callback=lambda u, t: u + 1.0, callback_times=[1.0])
     assert abs(sn3[1][0] - (0.5 + 1.0)) < 1e-5 and abs(inc[1.0][0] - 1.0) < 1e-12
+
+
+def test_step_size_collapse_ends_the_solve_with_dtmin():
+    """An error tolerance that no step size can meet: the controller's factor bottoms out at 1 - pi / 4 per rejection and dt reaches
+    the resolution of t after a few dozen attempts -- the solve ends there (OrdinaryDiffEq's check_error: dt <= dtmin = eps(t),
+    ReturnCode.DtLessThanMin) instead of spinning until maxiters; the device exits the same way (ODINN_ERR_DTMIN,
+    tests/test_gpu_classical_errors.py)."""
+    f = lambda u: -u * u
+    with pytest.raises(RuntimeError, match="dtmin"):
+        O.solve(f, np.array([1.0, 2.0]), [2010.0, 2010.5], reltol=1e-30, abstol=1e-300)
+    sn, st, _ = O.solve(f, np.array([1.0, 2.0]), [2010.0, 2010.5], reltol=1e-8, abstol=1e-10)  # (the same problem at a tolerance it can meet)
+    assert st.naccept > 0 and np.allclose(sn[-1], np.array([1.0, 2.0]) / (1.0 + np.array([1.0, 2.0]) * 0.5), rtol=2e-7)
 
 
 def test_halfar_and_volume():
