@@ -207,8 +207,9 @@ int odinn_batch_sync(odinn_batch* b);
 /* sc == NULL: everything automatic.  odinn_get_schedule returns what is in effect (environment overrides applied). */
 int odinn_set_schedule(odinn_batch* b, const odinn_schedule* sc);
 int odinn_get_schedule(odinn_batch* b, odinn_schedule* out);
-/* State of the Y law's table (odinn_schedule.law_table; builds it for the current theta if needed): *usable = 1 when the stencil
- * kernels of the next solve / gradient will read it, its interval count, its largest measured deviation from the network
+/* State of the Y law's / U law's table (odinn_schedule.law_table; builds it for the current theta if needed): *usable = 1 when the stencil
+ * kernels of the next solve / gradient will read it, its interval count (Y law: per glacier; U law: patches of the batch's bivariate table at the
+ * resolution the build settled on, 16 x 8 ... 128 x 64), its largest measured deviation from the network
  * (relative; values below 1e-3 of the table's largest value: relative to that value) and the Hbar range per glacier
  * (metres; doubled by a solve that left it).  Any pointer may be NULL.  No counterpart in the reference. */
 int odinn_get_law_table(odinn_batch* b, int* usable, int* n_intervals, double* max_rel_dev, double* hmax_per_glacier);
