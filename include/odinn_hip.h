@@ -52,9 +52,10 @@ extern "C" {
 #define ODINN_ERR_MAXITERS 5
 #define ODINN_ERR_NONFINITE 6
 #define ODINN_ERR_UNSUPPORTED 7
-#define ODINN_ERR_DTMIN 8 /* an adaptive solve (forward or reverse) whose step size fell to the resolution of its time variable,
-                             dt <= eps(t): it cannot proceed.  OrdinaryDiffEq ends such a solve with ReturnCode.DtLessThanMin
-                             ("dt <= dtmin ... Aborting"); without this exit it would spin until maxiters */
+#define ODINN_ERR_DTMIN 8 /* an adaptive solve (forward or reverse) that is stuck: 256 attempts in a row without advancing its time
+                             variable -- rejections, or accepted steps so small that t + dt == t (step size at the resolution of t).
+                             It would spin until maxiters.  OrdinaryDiffEq gives up earlier, at the first dt <= dtmin = eps(t)
+                             (ReturnCode.DtLessThanMin), also where the step size recovers after a few such attempts */
 
 #define ODINN_MAX_LAYERS 8
 #define ODINN_MAX_WIDTH 32

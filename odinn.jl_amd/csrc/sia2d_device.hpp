@@ -146,7 +146,7 @@ struct GState {  // per-glacier integrator state (written by the controller kern
   int nonfinite;
   int pad;
   int snap_slot;  // snapshot slot of the stop just reached (forward solve: CtrlArgs::snap_slot of that stop)
-  int pad2;
+  int pad2;       // adaptive solves: consecutive attempts that did not advance t (rejections, accepted steps below the resolution of t)
 };
 
 struct AdjState {  // per-glacier state of the reverse (continuous-adjoint) solve, written by the controller
@@ -1647,6 +1647,7 @@ struct CtrlArgs {
   double* qw_out;         // per glacier: weight of the node reached by this step (0 otherwise)
   double* trace;          // (nullable, diagnostics: ODINN_TRACE_STEPS) [trace_cap][4] of glacier 0: t, dt, EEst, +-factor per attempt
   int trace_cap;
+  int stuck_off;          // ODINN_DTMIN=0 (diagnostics): no exit on a collapsed step size
   int nrows;              // rows of the stop tables; t_last: the time of every glacier's last stop (self-controlled reverse step:
   double t_last;          //   CtrlPre)
 };
@@ -1736,6 +1737,7 @@ __device__ __forceinline__ void controller_errsum(const CtrlArgs& C, const GDev&
 // on values in registers: one thread.  Returns 1 when the glacier has just finished; est: steps still needed (-1: n/a).
 // pre (self-controlled reverse step): table entries requested before the decision starts -- stop `is` (the one the attempt
 // aimed at), the time of stop is + 1, the last stop's time, the snapshot times of segment `seg`; the same values the tables hold
+constexpr int STALL_MAX = 256;  // consecutive attempts without progress in t after which an adaptive solve is given up (controller_decide)
 struct CtrlPre {
   int is, seg, n_stops, mbf, mbs, snap, hid;
   double t_is, t_is1, t_last, qw, ta, tb;
@@ -1767,6 +1769,7 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
     if (accept) { st.e3 = st.e2; st.e2 = e1; }
   }
   double t = st.t;
+  const double t0_ = st.t;
   if (C.trace && gidx == 0) {
     const long long q = st.naccept + st.nreject;
     if (q < C.trace_cap) { C.trace[4 * q] = t; C.trace[4 * q + 1] = h; C.trace[4 * q + 2] = st.EEst; C.trace[4 * q + 3] = accept ? fac : -fac; }
@@ -1803,6 +1806,21 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
     st.nreject++;
     st.accepted = 0;
   }
+  // A solve that is stuck: STALL_MAX consecutive attempts without advancing t -- rejections, or accepted steps so small that
+  // t + dt == t.  Seen where the reverse solve meets a jump of its right-hand side at a mass-balance stop a few 1e-5 yr from the next
+  // stop: rejections down to dt < eps(t), an accepted step that does not move tau, growth, rejection, ... for ever (three fuzz draws in
+  // 23 200 seeds spun like that to maxiters).  The glacier leaves the loop, the host reports ODINN_ERR_DTMIN (nonfinite == 2).
+  // OrdinaryDiffEq aborts EARLIER, at the first dt <= dtmin = eps(t) (ReturnCode.DtLessThanMin) -- also on the ~1 % of the fuzz draws
+  // whose reverse solve dips below eps(t) for a few attempts and recovers; those keep running here, as they always did.
+  if (C.adaptive) {
+    if (accept && st.t != t0_) st.pad2 = 0;
+    else if (++st.pad2 >= STALL_MAX && !C.stuck_off) {
+      if (!st.nonfinite) st.nonfinite = 2;
+      st.done = 1;
+      est = 0;
+      return 1;
+    }
+  }
   if (!C.adj) {
     // forward solve, mass balance applied ON LOAD by the strip step kernel (ScArgs::snap_on_load with a mass balance): bit 2
     // of `pad` says the buffer `cur` still lacks the mass balance of the stop it sits on -- set when an accepted step lands
@@ -1816,14 +1834,6 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
     return 1;
   }
   double dtn = C.adaptive ? h * fac : C.fixed_dt;
-  // the step size has fallen to the resolution of t: the solve cannot proceed (OrdinaryDiffEq aborts with ReturnCode.DtLessThanMin at
-  // dt <= dtmin = eps(t)) -- the glacier leaves the loop, the host reports ODINN_ERR_DTMIN (GState::nonfinite == 2)
-  if (C.adaptive && !(dtn > 2.220446049250313e-16 * fabs(t))) {
-    if (!st.nonfinite) st.nonfinite = 2;  // (a non-finite error estimate on the way down stays the reported cause)
-    st.done = 1;
-    est = 0;
-    return 1;
-  }
   if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
   const double rem = tstop_at(st.istop) - t;
   // snap to the stop when the step would end within 100 ulp of it

@@ -616,6 +616,7 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
     if (accept) { s.e3 = s.e2; s.e2 = e1; }
   }
   double t = s.t;
+  const double t0_ = s.t;
   s.at_stop = 0;
   s.mb_now = 0;
   if (accept) {
@@ -637,18 +638,21 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
     s.nreject++;
     s.accepted = 0;
   }
+  if (C.adaptive) {  // a stuck solve: see controller_decide
+    if (accept && s.t != t0_) s.pad2 = 0;
+    else if (++s.pad2 >= STALL_MAX && !C.stuck_off) {
+      if (!s.nonfinite) s.nonfinite = 2;
+      s.done = 1;
+      est = 0;
+      return;
+    }
+  }
   if (s.istop >= n_stops) {
     s.done = 1;
     est = 0;
     return;
   }
   double dtn = C.adaptive ? h * fac : C.fixed_dt;
-  if (C.adaptive && !(dtn > 2.220446049250313e-16 * fabs(t))) {  // dt <= eps(t): see controller_decide
-    if (!s.nonfinite) s.nonfinite = 2;
-    s.done = 1;
-    est = 0;
-    return;
-  }
   if (C.dtmax > 0.0 && dtn > C.dtmax) dtn = C.dtmax;
   const double rem = C.tstop(s.istop, gidx) - t;
   if (dtn >= rem || fabs(rem - dtn) <= 100.0 * 2.220446049250313e-16 * fabs(t)) {

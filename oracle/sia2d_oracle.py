@@ -994,11 +994,13 @@ def solve(
     else:
         dt = fixed_dt
     e1 = e2 = e3 = 1.0
+    stall = 0
     for ts in tstops[1:]:
         while t < ts:
             if st.naccept + st.nreject >= maxiters:
                 raise RuntimeError("maxiters reached")
             h = min(dt, dtmax)
+            t_before = t
             rem = ts - t
             # land exactly on the stop when the step would end within 100 ulp of it
             clipped = h >= rem or abs(rem - h) <= 100.0 * np.finfo(F).eps * abs(t)
@@ -1024,10 +1026,16 @@ def solve(
             else:
                 st.nreject += 1
             dt = h * fac
-            # OrdinaryDiffEq's check_error: dt <= dtmin = eps(t) ends the solve with ReturnCode.DtLessThanMin ("Aborting")
-            if t < tstops[-1] and not dt > np.finfo(F).eps * abs(t):
-                raise RuntimeError("dt <= dtmin: the step size fell to the resolution of t at t = %r after %d accepted / %d rejected steps"
-                                   % (t, st.naccept, st.nreject))
+            # a stuck solve (the device's rule, sia2d_device.hpp controller_decide): STALL_MAX attempts in a row without advancing t
+            # -- rejections, or accepted steps with t + h == t.  OrdinaryDiffEq aborts earlier, at the first dt <= dtmin = eps(t)
+            # (ReturnCode.DtLessThanMin), also where the step size recovers after a few such attempts.
+            if t != t_before:
+                stall = 0
+            else:
+                stall += 1
+                if stall >= 256:
+                    raise RuntimeError("dtmin: the solve is stuck at t = %r: 256 attempts in a row without advancing t, after %d accepted / %d rejected steps"
+                                       % (t, st.naccept, st.nreject))
         if callback is not None and ts in cbt:
             unew = callback(u, ts)
             cb_inc[ts] = unew - u

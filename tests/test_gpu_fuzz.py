@@ -209,15 +209,15 @@ def _draw(gpu, seed, velocity=False):
 
 # cap of the CHECKER's reverse solve: the draws' reverse solves take 10 ... a few hundred steps (the three draws in 23 200 seeds on which
 # the reverse ODE's step size collapses -- aggregated terms, seeds 19681, 22159, 22782 -- cost the numpy checker its full 10^6 attempts
-# before both sides got the dt <= eps(t) exit: they end in 0.3 s now)
+# before both sides got the stuck-solve exit, ODINN_ERR_DTMIN: they end in a fraction of a second now)
 _ORACLE_REV_MAXITERS = 30000
 
 
 def _oracle_gradient_or_skip(test, seed, tag, c, nq, parts=None):
     """_oracle_gradient; a draw on which the CHECKER's own adaptive solve cannot finish (maxiters, dt <= eps(t)) is skipped (audited).
     Seen three times in 23 200 seeds (aggregated terms, seeds 19681, 22159, 22782: ContinuousAdjoint over stops a few 1e-4 yr apart -- after
-    a mass-balance stop the reverse solve rejects 14 steps in a row and dt reaches the resolution of tau); the device was run on all three by
-    hand and ends the same way: ODINN_ERR_DTMIN "in the reverse solve of glacier g after 6 accepted / 14 rejected steps"."""
+    a mass-balance stop the reverse solve rejects 14 steps in a row, dt reaches the resolution of tau and never recovers); the device was run on
+    all three by hand and ends the same way: ODINN_ERR_DTMIN "the reverse solve is stuck at tau = ... 256 attempts in a row without advancing tau"."""
     try:
         return _oracle_gradient(c, nq, parts=parts)
     except RuntimeError as e:

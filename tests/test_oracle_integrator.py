@@ -79,10 +79,10 @@ def test_adaptive_solve_tolerance_and_tstops():
 
 
 def test_step_size_collapse_ends_the_solve_with_dtmin():
-    """An error tolerance that no step size can meet: the controller's factor bottoms out at 1 - pi / 4 per rejection and dt reaches
-    the resolution of t after a few dozen attempts -- the solve ends there (OrdinaryDiffEq's check_error: dt <= dtmin = eps(t),
-    ReturnCode.DtLessThanMin) instead of spinning until maxiters; the device exits the same way (ODINN_ERR_DTMIN,
-    tests/test_gpu_classical_errors.py)."""
+    """An error tolerance that no step size can meet: every attempt is rejected (the controller's factor bottoms out at 1 - pi / 4) and
+    the solve is given up after 256 attempts in a row that did not advance t, instead of spinning until maxiters -- the device's rule
+    (ODINN_ERR_DTMIN, tests/test_gpu_classical_errors.py); OrdinaryDiffEq's check_error ends such a solve earlier, at the first
+    dt <= dtmin = eps(t) (ReturnCode.DtLessThanMin)."""
     f = lambda u: -u * u
     with pytest.raises(RuntimeError, match="dtmin"):
         O.solve(f, np.array([1.0, 2.0]), [2010.0, 2010.5], reltol=1e-30, abstol=1e-300)
