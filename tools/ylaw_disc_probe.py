@@ -26,5 +26,6 @@ def tm(f, nrep=2):
     for _ in range(nrep): f()
     b.sync()
     return (time.perf_counter() - t0) / nrep * 1e3
-print("solve ms %.2f" % tm(lambda: b.solve(ts, reltol=1e-8)), [(s.naccept, s.nreject) for s in b.last_stats][:4])
-print("discrete ms %.2f" % tm(lambda: b.batch_loss_grad(None, ts, theta=thY, continuous=False, reltol=1e-8)), [(s.naccept, s.nreject) for s in b.last_stats][:4], b.law_table()["usable"])
+st = b.solve(ts, reltol=1e-8)
+print("solve ms %.2f" % tm(lambda: b.solve(ts, reltol=1e-8)), "forward steps (accepted, rejected) of the first glaciers:", [(s.naccept, s.nreject) for s in st][:4])
+print("discrete ms %.2f" % tm(lambda: b.batch_loss_grad(None, ts, theta=thY, continuous=False, reltol=1e-8)), "table usable:", b.law_table()["usable"])
