@@ -617,6 +617,10 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
   }
   double t = s.t;
   const double t0_ = s.t;
+  if (C.trace && gidx == 0 && lane == 0) {  // (diagnostics, ODINN_TRACE_STEPS: every workgroup of glacier 0 writes the same four numbers)
+    const long long q = s.naccept + s.nreject;
+    if (q < C.trace_cap) { C.trace[4 * q] = t; C.trace[4 * q + 1] = h; C.trace[4 * q + 2] = s.EEst; C.trace[4 * q + 3] = accept ? fac : -fac; }
+  }
   s.at_stop = 0;
   s.mb_now = 0;
   if (accept) {

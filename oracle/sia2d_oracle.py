@@ -950,6 +950,14 @@ class SolveStats:
     naccept: int = 0
     nreject: int = 0
     nrhs: int = 0
+    # diagnostics of the adaptive solve (used by the fuzz tests to recognise draws whose outcome round-off decides):
+    max_stall: int = 0             # longest run of attempts that did not advance t (rejections, accepted steps with t + h == t)
+    min_stop_gap: float = np.inf   # smallest |distance to the next stop - proposed step| / proposed step over all attempts: a
+                                   # step that all but reaches its stop (followed by a sliver step and a dozen recovery steps) or
+                                   # all but misses being clipped
+
+
+SOLVE_DIAG = {"max_stall": 0}  # largest SolveStats.max_stall of the adaptive solves since the caller last reset it (fuzz tests)
 
 
 def solve(
@@ -1002,6 +1010,8 @@ def solve(
             h = min(dt, dtmax)
             t_before = t
             rem = ts - t
+            if fixed_dt is None and h > 0.0:
+                st.min_stop_gap = min(st.min_stop_gap, abs(rem - h) / h)
             # land exactly on the stop when the step would end within 100 ulp of it
             clipped = h >= rem or abs(rem - h) <= 100.0 * np.finfo(F).eps * abs(t)
             if clipped:
@@ -1033,7 +1043,9 @@ def solve(
                 stall = 0
             else:
                 stall += 1
+                st.max_stall = max(st.max_stall, stall)
                 if stall >= 256:
+                    SOLVE_DIAG["max_stall"] = max(SOLVE_DIAG["max_stall"], stall)
                     raise RuntimeError("dtmin: the solve is stuck at t = %r: 256 attempts in a row without advancing t, after %d accepted / %d rejected steps"
                                        % (t, st.naccept, st.nreject))
         if callback is not None and ts in cbt:
@@ -1042,6 +1054,7 @@ def solve(
             u = unew
         if ts in saved:
             snaps.append(u.copy())
+    SOLVE_DIAG["max_stall"] = max(SOLVE_DIAG["max_stall"], st.max_stall)
     return snaps, st, cb_inc
 
 
