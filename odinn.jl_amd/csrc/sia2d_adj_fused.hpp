@@ -64,7 +64,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
                                                  const double* __restrict__ Bp, AdjErr sEr, double* __restrict__ th_red,
                                                  [[maybe_unused]] double* __restrict__ Gp = nullptr,
                                                  [[maybe_unused]] const AdjRowCache<RC ? NR : 1>* rc = nullptr,
-                                                 [[maybe_unused]] const YtabRef yt = YtabRef{nullptr, nullptr, 0},
+                                                 [[maybe_unused]] const YtabRef yt = YtabRef{nullptr, nullptr, 0, nullptr},
                                                  [[maybe_unused]] double* __restrict__ Eh = nullptr,
                                                  [[maybe_unused]] double* __restrict__ Ev = nullptr,
                                                  [[maybe_unused]] double* __restrict__ emax = nullptr,
@@ -145,7 +145,7 @@ __device__ __forceinline__ void adj_strip_stage(const GDev& g, const double* __r
     // YT: the Y law of target :D_hybrid with n_H = n_gradS = 3 and no sliding is this law with Y(Hbar) in A's place (node_D<LM_YTAB>,
     // yt_fast), plus the reference's finite-difference term of dD/dHbar (target_D_hybrid.jl:58-71) in alpha below
     [[maybe_unused]] double Yp = 0.0;
-    if constexpr (YT) An = ytab_eval_core<true>(yt.tab, yt.ni, yt.over, g.yt_inv_h, 0.25 * Hs, Yp);
+    if constexpr (YT) An = ytab_eval_acc<true>(yt.tab, yt.ni, *yt.beyond, g.yt_inv_h, 0.25 * Hs, Yp);  // (no branch inside the stage code)
     const double Da = -fma(g.hinv_dx2, Pe_lo + Pe_hi, g.hinv_dy2 * (Pn + Pn_e));
     if constexpr (UT) {
       // target :D (target_D_pure.jl:78-137): D = Hbar U, alpha = dD/dHbar and beta = dD/d|grad S| by central differences of
@@ -603,7 +603,8 @@ __global__ __launch_bounds__(TNT, (adj_rc(AF, SG, NR) ? 2 : ((YT || UT) ? ODINN_
   // theta-VJP of the quadrature node the previous step reached (a.qw: its Gauss-Legendre weight, 0 otherwise; the controller
   // resets it at every call, so a repeated attempt after a rejection does not count the node twice)
   double* const thr = (A.th_part && a.qw != 0.0) ? th_red : nullptr;
-  const YtabRef yt{YTL ? reinterpret_cast<const double*>(sYt) : (YT ? A.ytab + g.yt_off : nullptr), A.ytab_over, A.ytab_ni};
+  unsigned long long yt_beyond = 0ull;  // lanes whose node left the law table, any stage (raised at the kernel's end)
+  const YtabRef yt{YTL ? reinterpret_cast<const double*>(sYt) : (YT ? A.ytab + g.yt_off : nullptr), A.ytab_over, A.ytab_ni, &yt_beyond};
   [[maybe_unused]] double emx[2] = {0.0, 0.0};
   [[maybe_unused]] const bool emit = YT && A.emitH != nullptr && a.qw != 0.0;
   [[maybe_unused]] LawDev Lu{};
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(TNT, (((ODINN_VJPH_RC && MODE == 1) || YT) ? 2 : OD
   const int gi = gi0 + lane, r0 = DNR * w;
   const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
   const bool ocol = lane >= 1 && lane <= DOX && inx;
+  [[maybe_unused]] unsigned long long yt_beyond = 0ull;  // (YT) lanes whose node left the law table: raised at the kernel's end (ytab_eval_acc)
   const int id0 = gi + g.nx * (gj0 + r0);
   const double* __restrict__ Hg = A.H + g.off;
   const double* __restrict__ Bg = P.B + g.off;
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(TNT, (((ODINN_VJPH_RC && MODE == 1) || YT) ? 2 : OD
       const double gS2 = gx * gx + gy * gy;
       double An = AF ? an : g.A;
       [[maybe_unused]] double Yp = 0.0;
-      if constexpr (YT) An = ytab_eval_core<true>(A.ytab + g.yt_off, A.ytab_ni, A.ytab_over, g.yt_inv_h, 0.25 * Hs, Yp);
+      if constexpr (YT) An = ytab_eval_acc<true>(A.ytab + g.yt_off, A.ytab_ni, yt_beyond, g.yt_inv_h, 0.25 * Hs, Yp);
       const double Kq = An * Gq;
       const double H2 = Hs * Hs, H4 = H2 * H2, H5 = H4 * Hs;
       D = (Kq * H5) * gS2;
@@ -950,6 +952,7 @@ __global__ __launch_bounds__(TNT, (((ODINN_VJPH_RC && MODE == 1) || YT) ? 2 : OD
       P.part[slot] = sum * wl * Ninv;
     }
   }
+  if constexpr (YT) ytab_raise(A.ytab_over, yt_beyond);
 }
 
 // ================= theta-VJP in the strip layout (integer-power A-type laws) ========================================

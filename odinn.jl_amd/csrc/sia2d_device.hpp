@@ -993,14 +993,18 @@ struct YtabRef {  // one glacier's table as the strip kernels take it (AdjFusedA
   const double* tab;
   int* over;
   int ni;
+  unsigned long long* beyond;  // the kernel's own ballot accumulator (ytab_eval_acc): the flag is raised once, at the kernel's end
 };
 template <bool ADJ>
-__device__ __forceinline__ double ytab_eval_core(const double* __restrict__ tab, int ni, int* over, double inv_h, double Hb, double& Yp) {
+__device__ __forceinline__ double ytab_eval_acc(const double* __restrict__ tab, int ni, unsigned long long& beyond, double inv_h, double Hb, double& Yp) {
+  // `beyond` collects the lanes whose node lies beyond the table (or is NaN): a ballot, i.e. scalar arithmetic -- NO divergent
+  // branch.  The branch `if (beyond) *over = 1` that used to sit here, inside the register-pressured stage code of the strip kernels,
+  // is what ROCm 7.2's backend miscompiled (a live-range-split VGPR copy / spill store placed in the join block AHEAD of the
+  // `s_or_b64 exec` that restores EXEC: fuzz seed 24379; tools/exec_lint.py checks every built kernel for it).
   double x = Hb * inv_h;
-  if (!(x < (double)ni)) {  // beyond the table (or NaN): the table's last value, so that the doomed solve stays tame
-    x = (double)ni;
-    *over = 1;
-  }
+  const bool out = !(x < (double)ni);
+  beyond |= __builtin_amdgcn_ballot_w64(out);
+  x = out ? (double)ni : x;  // the table's last value, so that the doomed solve stays tame
   const int i = min((int)x, ni - 1);  // Hbar >= 0
   const double s = fma(2.0, x - (double)i, -1.0);
   const double2* __restrict__ c = reinterpret_cast<const double2*>(tab) + 3 * i;
@@ -1014,6 +1018,17 @@ __device__ __forceinline__ double ytab_eval_core(const double* __restrict__ tab,
     const double p4 = fma(5.0 * c45.y, s, c45.x);
     Yp = fma(ds, fma(ds, fma(ds, fma(ds, fma(ds, c45.y, p4), p3), p2), p1), Y);
   }
+  return Y;
+}
+// the flag itself: raised by a UNIFORM branch (the ballot is a scalar: s_cbranch_scc, EXEC untouched)
+__device__ __forceinline__ void ytab_raise(int* over, unsigned long long beyond) {
+  if (beyond != 0ull) *over = 1;
+}
+template <bool ADJ>
+__device__ __forceinline__ double ytab_eval_core(const double* __restrict__ tab, int ni, int* over, double inv_h, double Hb, double& Yp) {
+  unsigned long long beyond = 0ull;
+  const double Y = ytab_eval_acc<ADJ>(tab, ni, beyond, inv_h, Hb, Yp);
+  ytab_raise(over, beyond);
   return Y;
 }
 template <bool ADJ>
@@ -1059,8 +1074,9 @@ struct UtabTile {
 // patch (ih, is) and the patch coordinates (u, v) of a node; a node beyond the table takes the table's edge and raises the flag
 __device__ __forceinline__ void utab_index(const LawDev& L, double Hb, double gS, int& ih, int& is, double& u, double& v) {
   double xh = Hb * L.ut_inv_h, xs = gS * L.ut_inv_s;
-  if (!(xh < (double)L.utab_nh)) { xh = (double)L.utab_nh; *L.ytab_over = 1; }  // beyond the table (or NaN): its edge value
-  if (!(xs < (double)L.utab_ns)) { xs = (double)L.utab_ns; *L.ytab_over = 1; }
+  const bool oh = !(xh < (double)L.utab_nh), os = !(xs < (double)L.utab_ns);  // beyond the table (or NaN): its edge value
+  xh = oh ? (double)L.utab_nh : xh; xs = os ? (double)L.utab_ns : xs;
+  ytab_raise(L.ytab_over, __builtin_amdgcn_ballot_w64(oh || os));  // (uniform branch: see ytab_eval_acc)
   ih = min((int)xh, L.utab_nh - 1); is = min((int)xs, L.utab_ns - 1);
   u = fma(2.0, xh - (double)ih, -1.0); v = fma(2.0, xs - (double)is, -1.0);
 }
@@ -1646,7 +1662,7 @@ struct CtrlArgs {
   const int* stop_hid;    // [imax][G] (nullable) per stop: hidden snapshot slot + 1 of a mass-balance-only stop, else 0
   double* qw_out;         // per glacier: weight of the node reached by this step (0 otherwise)
   double* trace;          // (nullable, diagnostics: ODINN_TRACE_STEPS) [trace_cap][4] of glacier 0: t, dt, EEst, +-factor per attempt
-  int trace_cap;
+  int trace_cap, trace_g;  // trace_g: the traced glacier (ODINN_TRACE_GLACIER, default 0)
   int stuck_off;          // ODINN_DTMIN=0 (diagnostics): no exit on a collapsed step size
   int nrows;              // rows of the stop tables; t_last: the time of every glacier's last stop (self-controlled reverse step:
   double t_last;          //   CtrlPre)
@@ -1770,7 +1786,7 @@ __device__ __forceinline__ int controller_decide(GState& st, AdjState& ad, const
   }
   double t = st.t;
   const double t0_ = st.t;
-  if (C.trace && gidx == 0) {
+  if (C.trace && gidx == C.trace_g) {
     const long long q = st.naccept + st.nreject;
     if (q < C.trace_cap) { C.trace[4 * q] = t; C.trace[4 * q + 1] = h; C.trace[4 * q + 2] = st.EEst; C.trace[4 * q + 3] = accept ? fac : -fac; }
   }

@@ -455,7 +455,10 @@ template <int S, bool AF, int NR, bool UPL, bool SQ, bool YT = false>
 __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                              const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                              double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
-                                             double (&E)[NR], const double (&bb)[NR], volatile int* sFlag) {
+                                             double (&E)[NR], const double (&bb)[NR], volatile int* sFlag,
+                                             [[maybe_unused]] unsigned long long& ovm) {
+  // ovm (YT): ballot of the lanes that met a node beyond the law table in stage 1 -- collected WITHOUT a branch, raised by the kernel
+  // at its end (ytab_eval_acc)
   // src, Afield: based at the glacier's first cell / dual node (block-uniform), cells addressed by 32-bit indices;
   // gic: gi clamped into the grid; dtl: dt on the lanes with 1 <= gi <= nx-2, else 0
   constexpr int rd = (S - 1) & 1, wr = S & 1;  // stage S reads the edge rows from buffer rd, publishes into wr
@@ -489,8 +492,8 @@ __device__ __forceinline__ void strip_stage(const GDev& g, const LawDev& L, cons
       // output cells; in stages 2-5 the rows outside region_S hold whatever the stale neighbours produced -- never read, but
       // possibly far outside the table, where the evaluation clamps silently.
       double unused;
-      int over_local = 0;
-      const double Y = ytab_eval_core<false>(L.ytab + g.yt_off, L.ytab_ni, S == 1 ? L.ytab_over : &over_local, g.yt_inv_h, 0.25 * H4s, unused);
+      unsigned long long stale = 0ull;
+      const double Y = ytab_eval_acc<false>(L.ytab + g.yt_off, L.ytab_ni, S == 1 ? ovm : stale, g.yt_inv_h, 0.25 * H4s, unused);
       return (Y * Gq) * (H4 * H4s) * gS2;
     }
     return (AF ? sA[slot][threadIdx.x] : AGq) * (H4 * H4s) * gS2;  // sA: A Gam / (1024 (2dx)^2) of the thread's own nodes
@@ -574,12 +577,12 @@ template <bool AF, int NR, bool UPL, bool SQ, bool YT = false>
 __device__ __forceinline__ void strip_stages(const GDev& g, const LawDev& L, const double (*sA)[TNT], const double (*sUp)[TNT],
                                               const double* __restrict__ src, int gic, int gi, int gj0, int w, int lane,
                                               double dtl, StripEdges sE, double (&u)[NR], double (&tmp)[NR],
-                                              double (&E)[NR], const double (&bb)[NR], volatile int* sFlag) {
-  strip_stage<1, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
-  strip_stage<2, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
-  strip_stage<3, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
-  strip_stage<4, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
-  strip_stage<5, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag);
+                                              double (&E)[NR], const double (&bb)[NR], volatile int* sFlag, unsigned long long& ovm) {
+  strip_stage<1, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag, ovm);
+  strip_stage<2, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag, ovm);
+  strip_stage<3, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag, ovm);
+  strip_stage<4, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag, ovm);
+  strip_stage<5, AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, dtl, sE, u, tmp, E, bb, sFlag, ovm);
 }
 
 // ---- self-controlled step (SC): no controller / post-step launches ---------------------------------------
@@ -617,7 +620,7 @@ __device__ __forceinline__ void sc_decide(GState& s, const GDev& g, const CtrlAr
   }
   double t = s.t;
   const double t0_ = s.t;
-  if (C.trace && gidx == 0 && lane == 0) {  // (diagnostics, ODINN_TRACE_STEPS: every workgroup of glacier 0 writes the same four numbers)
+  if (C.trace && gidx == C.trace_g && lane == 0) {  // (diagnostics, ODINN_TRACE_STEPS: every workgroup of the traced glacier writes the same four numbers)
     const long long q = s.naccept + s.nreject;
     if (q < C.trace_cap) { C.trace[4 * q] = t; C.trace[4 * q + 1] = h; C.trace[4 * q + 2] = s.EEst; C.trace[4 * q + 3] = accept ? fac : -fac; }
   }
@@ -867,7 +870,8 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     for (int m = 0; m <= NR; ++m) sA[AF ? m : 0][threadIdx.x] = aa[AF ? m : 0] * Gq;
   }
   static_assert(!YT || !AF, "the table replaces the scalar A");
-  strip_stages<AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb, sFlag);
+  unsigned long long ovm = 0ull;  // (YT) lanes that left the law table: see strip_stage
+  strip_stages<AF, NR, UPL, SQ, YT>(g, L, sA, sUp, src, gic, gi, gj0, w, lane, gi >= 1 && gi <= g.nx - 2 ? dt : 0.0, sE, u, tmp, E, bb, sFlag, ovm);
   // ---- output rows [FH, (NR * TNW)-1-FH]: u' from the registers, embedded error partial -----------------------
   double errsq = 0.0;
   double upf[NR];
@@ -883,7 +887,7 @@ __global__ __launch_bounds__(TNT, ODINN_FWPE) void k_rk_fused_strip(Pools P, Law
     if (r >= FH && r <= (NR * TNW) - 1 - FH && ocol && gj < g.ny) {
       const double upv = upf[m];
       stg32(dst, (unsigned)(id0 + g.nx * m), u[m]);
-      if constexpr (YT) { if (!(u[m] * g.yt_inv_h < (double)L.ytab_ni)) *L.ytab_over = 1; }  // (Hbar <= the largest of its four cells)
+      if constexpr (YT) ovm |= __builtin_amdgcn_ballot_w64(!(u[m] * g.yt_inv_h < (double)L.ytab_ni));  // (Hbar <= the largest of its four cells)
       const double err = (u[m] - upv) - E[m];
       const double sk = abstol + fmax(fabs(upv), fabs(u[m])) * reltol;
       const double q = err / sk;

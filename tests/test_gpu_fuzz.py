@@ -37,12 +37,19 @@ SCHEDULES = [dict(step_sc=0), dict(step_sc=1), dict(fused_tiles=1), dict(fused_t
              dict(interp_async=0), dict(interp_async=2)]
 
 
+NAMED_SEEDS = [1746, 2450, 3206, 3351, 19220, 19681, 22159, 22782, 23649, 23721, 24379]
+
+
 def _seeds():
     e = os.environ.get("ODINN_FUZZ_SEEDS")
     if e:
         a, b = e.split(":")
         return list(range(int(a), int(b)))
-    return list(range(20)) + [1746, 2450, 3206, 3351]  # (the last four: subnormal thickness at the margin, `:Linear` knots)
+    # the fixed slice the driver's `pytest -m gpu` sees: 140 consecutive draws per test plus every seed that ever found a defect on
+    # either side (tests/README.md lists what each one found): subnormal thickness at the margin / `:Linear` knots (1746, 2450, 3206,
+    # 3351), a step count that is not a property of the algorithm (19220), the three stuck reverse solves (19681, 22159, 22782), the
+    # stuck ill-conditioning probe (23649), a solve at the resolution of tau (23721), the miscompiled self-controlled Y-table step (24379)
+    return list(range(140)) + NAMED_SEEDS
 
 
 
@@ -213,14 +220,20 @@ def _draw(gpu, seed, velocity=False):
 _ORACLE_REV_MAXITERS = 30000
 
 
+_CHECKER = {"stall": 0}  # longest run of attempts without progress in the checker's UNPERTURBED solve of the current draw
+
+
 def _oracle_gradient_or_skip(test, seed, tag, c, nq, parts=None):
     """_oracle_gradient; a draw on which the CHECKER's own adaptive solve cannot finish (maxiters, dt <= eps(t)) is skipped (audited).
     Seen three times in 23 200 seeds (aggregated terms, seeds 19681, 22159, 22782: ContinuousAdjoint over stops a few 1e-4 yr apart -- after
     a mass-balance stop the reverse solve rejects 14 steps in a row, dt reaches the resolution of tau and never recovers); the device was run on
     all three by hand and ends the same way: ODINN_ERR_DTMIN "the reverse solve is stuck at tau = ... 256 attempts in a row without advancing tau"."""
     O.SOLVE_DIAG["max_stall"] = 0
+    _CHECKER["stall"] = 0
     try:
-        return _oracle_gradient(c, nq, parts=parts)
+        out = _oracle_gradient(c, nq, parts=parts)
+        _CHECKER["stall"] = O.SOLVE_DIAG["max_stall"]  # of THIS solve: the perturbed solves of _ill_conditioned keep adding to SOLVE_DIAG
+        return out
     except RuntimeError as e:
         if "maxiters" not in str(e) and "dtmin" not in str(e):
             raise
@@ -235,7 +248,7 @@ def _device_or_skip(test, seed, tag, fn):
     try:
         return fn()
     except Exception as e:
-        if "is stuck" in str(e) and O.SOLVE_DIAG["max_stall"] >= 6:
+        if "is stuck" in str(e) and _CHECKER["stall"] >= 6:
             _skip(test, seed, "solve at the resolution of its time variable: round-off decides", tag)
         raise
 
@@ -828,7 +841,7 @@ def test_random_batch_forward_solve_matches_the_oracle(gpu, monkeypatch, seed):
                 counts = [O.forward(gl, law, O.SimConfig(tstops=c["own"][g], reltol=1e-8 * rs, mb=mb, mb_times=mt))[1].naccept
                           for rs in (1.0 - 1e-4, 1.0 + 1e-4, 1.0 - 1e-3, 1.0 + 1e-3)] + [so.naccept]
                 # ... or where one of its steps all but reached / all but missed a stop (SolveStats.min_stop_gap; seed 24379: 15 vs 11)
-                unstable = max(counts) - min(counts) > 2 or so.min_stop_gap < 1e-3
+                unstable = max(counts) - min(counts) > 2 or so.min_stop_gap < 1e-9
             assert unstable or close(so), (tag, g, st[g], so)
             tol = 1e-11 if how == "fixed" else 1e-6
         assert abs(st[g].t_final - c["own"][g][-1]) < 1e-12, (tag, g)
