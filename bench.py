@@ -70,7 +70,7 @@ B_PER_CELL_FUSED_NN = 32.0  # + the dual-grid A field
 # fp64 flops per EXECUTED cell-stage of the strip kernel, fallback when profiles/r0x/pmc_roofline.json is absent:
 # profiles/r01/pmc_fused_strip_sq.md: (9.60 + 14.03 + 2 x 11.12) M wave-instr x 64 lanes / (2888 tiles x 4096 cells x 5)
 FLOP_PER_CELL_STAGE_FALLBACK = 49.7
-PMC_FILES = [os.path.join(ROOT, "profiles", r, "pmc_roofline.json") for r in ("r04", "r03", "r02")]  # newest committed pass first
+PMC_FILES = [os.path.join(ROOT, "profiles", r, "pmc_roofline.json") for r in ("r06", "r04", "r03", "r02")]  # newest committed pass first
 
 
 def make_glacier(n, gidx, dx=100.0):
@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--no-full-config", action="store_true", help="(accepted for old command lines; the 64-glacier job IS the timed workload now)")
     ap.add_argument("--no-weak", action="store_true", help="skip aux.weak_8_per_gpu (the fixed 8-glaciers-per-GPU figure)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--headline-only", action="store_true", help="only the timed headline loop (for `rocprofv3 --kernel-trace --stats`: the "
+                    "kernel averages are then those of THIS workload, not mixed with the auxiliary batches)")
     ap.add_argument("--repeats", type=int, default=7, help="repeats of the timed region inside this invocation (value = the median)")
     args = ap.parse_args()
 
@@ -237,9 +239,13 @@ def main():
     # this invocation and `value` is the MEDIAN repeat: a 20-step driver run times ~17 ms, where a single bracket moves by
     # several per cent with whatever else the host does at that moment.  `steps` stays the per-repeat count; every repeat is
     # in aux.timed_region_repeats.
+    # The dominant kernel of every timed step sits between two HIP events on the library's stream (odinn_bench_kernel_events), read
+    # after the bracket closes: roofline.ms_per_launch is the kernel's time in the SAME launches that `ms_per_step` times.
     b.bench_prepare()
+    b.bench_kernel_events(True)
     b.bench_enqueue(T.TIMED_SOLVE_STEP, 0, args.warmup)
-    repeats = []
+    b.bench_kernel_ms()  # (drops the warm-up's pairs)
+    repeats, kernel_ms = [], []
     done = args.warmup
     for _ in range(max(1, args.repeats)):
         barrier()
@@ -248,6 +254,8 @@ def main():
         b.sync()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        kms, kn_l = b.bench_kernel_ms()
+        kernel_ms.append(kms / max(kn_l, 1))
         done += args.steps
         el = t1 - t0
         if dist is not None:
@@ -257,8 +265,20 @@ def main():
             dist.barrier()
         repeats.append(el)
     elapsed = float(np.median(repeats))
+    i_med = int(np.argsort(repeats)[len(repeats) // 2])   # the median repeat: its own kernel time goes with its step time
+    ms_kernel_in_loop = kernel_ms[i_med]
+    b.bench_kernel_events(False)
     cellsteps = 5.0 * cells_job * args.steps  # the whole job: every rank's glaciers
     value = cellsteps / elapsed
+
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps({"metric": "cell-steps/s (forward SIA2D+NN)", "value": value, "unit": "cell-steps/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "dtype": "f64",
+                              "fused_kernel_ms_per_launch_in_loop": ms_kernel_in_loop, "repeats_ms_per_step": [e / args.steps * 1e3 for e in repeats],
+                              "config": {"workload": f"{G} x {n}^2 glaciers per GPU, headline loop only (--headline-only)"}}), flush=True)
+        b.close()
+        return
 
     # ---- the fixed per-GPU share (8 glaciers per GPU, weak scaling): same launches, same bracket -------------------
     weak = None
@@ -292,6 +312,7 @@ def main():
     aux = {}
     aux["timed_region_repeats"] = {
         "n": len(repeats), "steps_each": args.steps, "ms_per_step": [e / args.steps * 1e3 for e in repeats],
+        "fused_kernel_ms_per_launch": kernel_ms,
         "value_min": cellsteps / max(repeats), "value_median": value, "value_max": cellsteps / min(repeats),
         "note": "`value` / `ms_per_step` of the line are the median repeat; every repeat is a barrier + synchronize bracket around "
                 "exactly `steps` steps, max over ranks"}
@@ -799,7 +820,7 @@ def main():
     if traffic:
         traffic *= pmc_scale  # (per-cell figure of the committed pass x the cells of this launch when the batch differs)
     flops_useful = fpcs_nn * 5.0 * cells
-    ach_tf = flops_useful / (ms_fused_nn * 1e-3) / 1e12
+    ach_tf = flops_useful / (ms_kernel_in_loop * 1e-3) / 1e12
     big = hbm.get("kernels", {}) if isinstance(hbm, dict) else {}
     r_nn = big.get("dhdt_nn_gridded")
     r_st = big.get("rk_stage2")
@@ -850,7 +871,11 @@ def main():
                                   "per SIMD issues one wave-instruction per 5.3-6.0 cycles on this part (profiles/r02/valu_issue_cost_ubench.txt), "
                                   "i.e. reaches 0.67-0.75 by this measure: the kernel sits at the fp64 pipe's sustained issue rate, and only "
                                   "fewer instructions per cell-stage (now 43.8 flop in 51.6 VALU instructions, halo redundancy 1.41) move it",
-                "ms_per_launch": ms_fused_nn,
+                "ms_per_launch": ms_kernel_in_loop,
+                "ms_per_launch_source": "HIP events on the library's stream around the fused step kernel of every one of the `steps` timed steps "
+                                        "of the median repeat (odinn_bench_kernel_events): the same launches `ms_per_step` brackets, "
+                                        "so kernel time <= step time; the step adds the controller launch",
+                "ms_per_launch_back_to_back": ms_fused_nn,
                 "flop_per_cell_stage": fpcs_nn,
                 "flop_source": (pmc_src + ": 64 x (SQ_INSTS_VALU_ADD_F64 + MUL_F64 + 2 FMA_F64) per launch / executed cell-stages "
                                 "(tiles x 64 x 64 x 5, halo included)") if pmc_src else
@@ -861,9 +886,9 @@ def main():
                                    "gfx950 note of MI355X_MICROARCH.md; committed measurement of this kernel on this workload, "
                                    "not collected in this run)") if traffic else None,
                 "algorithmic_bytes_per_launch": B_PER_CELL_FUSED_NN * cells,
-                "hbm_traffic_GBs": (traffic / (ms_fused_nn * 1e-3) / 1e9) if traffic else None,
-                "hbm_traffic_frac_of_peak": (traffic / (ms_fused_nn * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "hbm_algorithmic_frac_of_peak": B_PER_CELL_FUSED_NN * cells / (ms_fused_nn * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hbm_traffic_GBs": (traffic / (ms_kernel_in_loop * 1e-3) / 1e9) if traffic else None,
+                "hbm_traffic_frac_of_peak": (traffic / (ms_kernel_in_loop * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "hbm_algorithmic_frac_of_peak": B_PER_CELL_FUSED_NN * cells / (ms_kernel_in_loop * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "constA_kernel": {"ms_per_launch": ms_fused_c, "flop_per_cell_stage": fpcs_c,
                                   "achieved": fpcs_c * 5.0 * cells / (ms_fused_c * 1e-3) / 1e12,
                                   "frac": fpcs_c * 5.0 * cells / (ms_fused_c * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,

@@ -429,6 +429,11 @@ int odinn_time_kernel(odinn_batch* b, int which, int warmup, int iters, double* 
  * first_iter .. first_iter+n-1 asynchronously on the batch's stream (sync with odinn_batch_sync). */
 int odinn_bench_prepare(odinn_batch* b);
 int odinn_bench_enqueue(odinn_batch* b, int which, int first_iter, int n);
+/* on != 0: odinn_bench_enqueue(ODINN_TIMED_SOLVE_STEP) records a pair of HIP events around the fused step kernel of every step it
+ * launches (on the batch's stream); odinn_bench_kernel_ms synchronises, returns the summed kernel time of the pairs recorded since
+ * the last call and the number of launches, and starts over.  bench.py: the kernel's time and the step's time from ONE loop. */
+int odinn_bench_kernel_events(odinn_batch* b, int on);
+int odinn_bench_kernel_ms(odinn_batch* b, double* ms_total, int* launches);
 /* total primal cells in the batch */
 int64_t odinn_batch_cells(odinn_batch* b);
 

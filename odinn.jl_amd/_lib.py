@@ -152,6 +152,8 @@ SIGNATURES = {
     "odinn_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "odinn_bench_prepare": (C.c_int, [_vp]),
     "odinn_bench_enqueue": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "odinn_bench_kernel_events": (C.c_int, [_vp, C.c_int]),
+    "odinn_bench_kernel_ms": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "odinn_batch_cells": (C.c_int64, [_vp]),
 }
 

@@ -516,5 +516,15 @@ class GlacierBatch:
     def bench_enqueue(self, which, first_iter, n):
         L.check(L.lib().odinn_bench_enqueue(self._h, int(which), int(first_iter), int(n)))
 
+    def bench_kernel_events(self, on=True):
+        """HIP events around the fused step kernel of every TIMED_SOLVE_STEP that bench_enqueue launches from now on."""
+        L.check(L.lib().odinn_bench_kernel_events(self._h, 1 if on else 0))
+
+    def bench_kernel_ms(self):
+        """(summed kernel milliseconds, launches) of the event pairs recorded since the last call; synchronises."""
+        ms, n = C.c_double(0.0), C.c_int(0)
+        L.check(L.lib().odinn_bench_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def sync(self):
         L.check(L.lib().odinn_batch_sync(self._h))

@@ -150,6 +150,10 @@ struct odinn_batch {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // odinn_bench_kernel_events: HIP events around the dominant kernel of every step that odinn_bench_enqueue launches
+  bool bench_ev_on = false;
+  std::vector<hipEvent_t> bench_ev;  // pool, pairs
+  size_t bench_ev_used = 0;
   int G = 0;
   std::vector<odinn_glacier_desc> descs;
   std::vector<GDev> gd;
@@ -1009,6 +1013,7 @@ int odinn_batch_destroy(odinn_batch* b) {
   dfree(b->d_dthq);
   dfree(b->d_mb_flag); dfree(b->d_mb_slot); dfree(b->d_dts); dfree(b->d_ws); dfree(b->d_refslot);
   dfree(b->d_Vabs); dfree(b->d_Vxr); dfree(b->d_Vyr); dfree(b->d_wv); dfree(b->d_vsc); dfree(b->d_vslot);
+  for (hipEvent_t e : b->bench_ev) (void)hipEventDestroy(e);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream) (void)hipStreamDestroy(b->stream);

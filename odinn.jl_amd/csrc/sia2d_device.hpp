@@ -2107,10 +2107,11 @@ struct AdjArgs {
 // cells {SW, SE, NW, NE} -- the diffusivity term (adjoint.jl:123-127) AND its share D_node of the
 // clamp/flux term of its four edges (adjoint.jl:130-144, inversion_utils.jl:22-43); the clamped
 // slopes and their bounds are already at hand from D_adjoint (adjoint.jl:99-104).
-template <int LM, int NK = 0>
-__device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const Pools& P, const double2 (*sHS)[LDW],
-                                          const double (*sL)[LDW], int i0, int j0, int a, int b, double (&k)[4],
+template <int LM, int NK = 0, int LD = LDW>
+__device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const Pools& P, const double2 (*sHS)[LD],
+                                          const double (*sL)[LD], int i0, int j0, int a, int b, double (&k)[4],
                                           const UtabTile ut = ODINN_UT_NONE) {
+  // LD: row stride of the two tiles (LDW: the 64 x 16 tiles with their one-cell halo; FLD: the regions of the fused LDS-tile steps)
   const int gi = i0 - 1 + a, gj = j0 - 1 + b;
   k[0] = k[1] = k[2] = k[3] = 0.0;
   if (gi < 0 || gi > g.nx - 2 || gj < 0 || gj > g.ny - 2) return;
@@ -2123,14 +2124,14 @@ __device__ __forceinline__ void vjpH_node(const GDev& g, const LawDev& L, const 
     // per-node network: evaluate the law FIRST, from the node's thickness and slope alone, so that none of the node's other
     // quantities (corner values, bounds, lambda differences) is live across the ~2000 instructions of the network; the
     // corner values are read again from LDS afterwards (the memory clobber keeps the two sets of loads apart)
-    const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
+    const double2 c00 = p[0], c10 = p[1], c01 = p[LD], c11 = p[LD + 1];
     const double gx = ((c10.y - c00.y) + (c11.y - c01.y)) * g.hinv_dx, gy = ((c01.y - c00.y) + (c11.y - c10.y)) * g.hinv_dy;
     const double Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));
     Dnn = node_D<true, LM, NK>(g, L, Hb, gx * gx + gy * gy, g.A, al, be, sp, ut);
     asm volatile("" ::: "memory");
   }
-  const double2 c00 = p[0], c10 = p[1], c01 = p[LDW], c11 = p[LDW + 1];
-  const double l00 = pl[0], l10 = pl[1], l01 = pl[LDW], l11 = pl[LDW + 1];
+  const double2 c00 = p[0], c10 = p[1], c01 = p[LD], c11 = p[LD + 1];
+  const double l00 = pl[0], l10 = pl[1], l01 = pl[LD], l11 = pl[LD + 1];
   const double dxl = c10.y - c00.y, dxu = c11.y - c01.y, dyl = c01.y - c00.y, dyr = c11.y - c10.y;
   const double gx = (dxl + dxu) * g.hinv_dx, gy = (dyl + dyr) * g.hinv_dy;
   const double Hb = 0.25 * ((c00.x + c10.x) + (c01.x + c11.x));

@@ -167,6 +167,7 @@ MUST_BIND = (
 # exported for bench.py / probes / device-pointer callers only: a Julia host has no use for them
 SHIM_WHITELIST = (
     "odinn_time_kernel", "odinn_bench_prepare", "odinn_bench_enqueue", "odinn_batch_cells",   # measurement (HIP events in the library)
+    "odinn_bench_kernel_events", "odinn_bench_kernel_ms",
     "odinn_batch_sync", "odinn_device_name",                                                     # probes
     "odinn_comm_allreduce_sum_dev",                                                              # takes a DEVICE pointer + hipStream_t
 )
