@@ -191,7 +191,10 @@ typedef struct odinn_schedule {
   int32_t adj_sc;          /* ODINN_ADJ_SC: 1 = self-controlled reverse step of the ContinuousAdjoint (the fused reverse step decides
                               the previous attempt and does the post-step of a stop itself: one launch per reverse step), 0 = the
                               three-launch loop (fused step, controller, post-step); same decisions, same arithmetic             */
-  int32_t reserved[2];     /* zero                                                                                                 */
+  int32_t adj_ut_fused;    /* ODINN_ADJ_UT_FUSED: reverse step of the ContinuousAdjoint for the U law (target :D) through its table: 0 = five
+                              k_adj_stage launches, 1 = the strip kernel's UT form (measured 3 x slower, kept as a cross-check), 2 = the
+                              fused step on LDS tiles (k_adj_fused_lds, sia2d_adj_lds.hpp); -1 = the library's measured rule             */
+  int32_t reserved[1];     /* zero                                                                                                 */
 } odinn_schedule;
 
 typedef struct odinn_batch odinn_batch;

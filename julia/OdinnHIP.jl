@@ -22,7 +22,7 @@ struct AdjointOpts; reltol::Float64; abstol::Float64; dtmax::Float64; n_quadratu
 struct Schedule; step_sc::Int32; fused_tiles::Int32; dhdt_strip::Int32; vjph_strip::Int32; vjpth_strip::Int32
                  snap_on_load::Int32; interp_streams::Int32; interp_batch::Int32; lawgrad_wave::Int32; vq_onepass::Int32
                  adj_fused::Int32; adj_skip::Int32; adj_segs::Int32; adj_rows::Int32; adj_theta_fused::Int32
-                 law_table::Int32; interp_async::Int32; adj_sc::Int32; reserved::NTuple{2, Int32}; end
+                 law_table::Int32; interp_async::Int32; adj_sc::Int32; adj_ut_fused::Int32; reserved::NTuple{1, Int32}; end
 # odinn_mlp_desc: a Lux.Chain of Dense layers with ODINN's pre / post-scaling (ML_utils.jl:23-39, target_utils.jl:58-141)
 struct MlpDesc; n_layers::Int32; widths::NTuple{9, Int32}; acts::NTuple{8, Int32}; has_prescale::Int32
                 pre_lo::NTuple{2, Float64}; pre_hi::NTuple{2, Float64}; post_kind::Int32; post_lo::Float64; post_hi::Float64; end
@@ -114,10 +114,10 @@ function set_glacier_stops!(b::Batch, simulation)
 end
 
 function set_schedule!(b; kw...)
-    f = fieldnames(Schedule)[1:18]
+    f = fieldnames(Schedule)[1:19]
     unknown = setdiff(keys(kw), f)
     isempty(unknown) || error("unknown schedule field(s): $(unknown)")
-    sc = Ref(Schedule((Int32(get(kw, k, -1)) for k in f)..., ntuple(_ -> Int32(0), 2)))
+    sc = Ref(Schedule((Int32(get(kw, k, -1)) for k in f)..., ntuple(_ -> Int32(0), 1)))
     check(ccall((:odinn_set_schedule, lib), Cint, (Ptr{Cvoid}, Ptr{Schedule}), b.h, sc))
 end
 
@@ -427,7 +427,7 @@ function grad_field(b::Batch, i::Integer, nx::Integer, ny::Integer)
     g = zeros(nx - 1, ny - 1); check(ccall((:odinn_get_grad_field, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}), b.h, i - 1, g)); g
 end
 function get_schedule(b::Batch)
-    sc = Ref(Schedule(ntuple(_ -> Int32(-1), 18)..., ntuple(_ -> Int32(0), 2)))
+    sc = Ref(Schedule(ntuple(_ -> Int32(-1), 19)..., ntuple(_ -> Int32(0), 1)))
     check(ccall((:odinn_get_schedule, lib), Cint, (Ptr{Cvoid}, Ptr{Schedule}), b.h, sc)); sc[]
 end
 # state of the Y law's table (set_schedule!(b; law_table = 1)): (usable, intervals, largest relative deviation from the network, Hbar range per glacier)

@@ -69,12 +69,12 @@ class AdjointOpts(C.Structure):
 
 SCHEDULE_FIELDS = ("step_sc", "fused_tiles", "dhdt_strip", "vjph_strip", "vjpth_strip", "snap_on_load", "interp_streams",
                    "interp_batch", "lawgrad_wave", "vq_onepass", "adj_fused", "adj_skip", "adj_segs", "adj_rows", "adj_theta_fused",
-                   "law_table", "interp_async", "adj_sc")
+                   "law_table", "interp_async", "adj_sc", "adj_ut_fused")
 
 
 class Schedule(C.Structure):
     """odinn_schedule: which of the library's equivalent kernel forms run; every field -1 = automatic."""
-    _fields_ = [(k, C.c_int32) for k in SCHEDULE_FIELDS] + [("reserved", C.c_int32 * 2)]
+    _fields_ = [(k, C.c_int32) for k in SCHEDULE_FIELDS] + [("reserved", C.c_int32 * 1)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -18,7 +18,7 @@ _Static_assert(sizeof(odinn_mlp_desc) == 136 && offsetof(odinn_mlp_desc, pre_lo)
 _Static_assert(sizeof(odinn_solver_opts) == 64 && offsetof(odinn_solver_opts, cfl) == 56, "odinn_solver_opts");
 _Static_assert(sizeof(odinn_solve_stats) == 40, "odinn_solve_stats");
 _Static_assert(sizeof(odinn_adjoint_opts) == 40 && offsetof(odinn_adjoint_opts, maxiters) == 32, "odinn_adjoint_opts");
-_Static_assert(sizeof(odinn_schedule) == 80 && offsetof(odinn_schedule, reserved) == 72, "odinn_schedule");
+_Static_assert(sizeof(odinn_schedule) == 80 && offsetof(odinn_schedule, adj_ut_fused) == 72 && offsetof(odinn_schedule, reserved) == 76, "odinn_schedule");
 
 int main(void) {
   S(odinn_phys);
@@ -46,6 +46,6 @@ int main(void) {
   F(odinn_schedule, vjpth_strip); F(odinn_schedule, snap_on_load); F(odinn_schedule, interp_streams);
   F(odinn_schedule, interp_batch); F(odinn_schedule, lawgrad_wave); F(odinn_schedule, vq_onepass); F(odinn_schedule, adj_fused);
   F(odinn_schedule, adj_skip); F(odinn_schedule, adj_segs); F(odinn_schedule, adj_rows); F(odinn_schedule, adj_theta_fused);
-  F(odinn_schedule, law_table); F(odinn_schedule, interp_async); F(odinn_schedule, adj_sc); F(odinn_schedule, reserved);
+  F(odinn_schedule, law_table); F(odinn_schedule, interp_async); F(odinn_schedule, adj_sc); F(odinn_schedule, adj_ut_fused); F(odinn_schedule, reserved);
   return 0;
 }

@@ -146,7 +146,7 @@ static int sched_val(int field, const char* env) {
 }
 
 struct odinn_batch {
-  odinn_schedule sched = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
+  odinn_schedule sched = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, {0}};
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

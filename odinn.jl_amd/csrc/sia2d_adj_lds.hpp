@@ -24,7 +24,8 @@ __device__ __forceinline__ void adj_lds_stage(const GDev& g, const LawDev& L, co
                                                double2 (*sCb)[FLD], double (&u)[(FOYV + 2 * FH + FNW - 1) / FNW],
                                                double (&tmp)[(FOYV + 2 * FH + FNW - 1) / FNW], const double (&up)[(FOYV + 2 * FH + FNW - 1) / FNW],
                                                double (&E)[(FOYV + 2 * FH + FNW - 1) / FNW], const double (&ha)[(FOYV + 2 * FH + FNW - 1) / FNW],
-                                               const double (&dh)[(FOYV + 2 * FH + FNW - 1) / FNW], const double (&bb)[(FOYV + 2 * FH + FNW - 1) / FNW]) {
+                                               const double (&dh)[(FOYV + 2 * FH + FNW - 1) / FNW], const double (&bb)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                               const UtabTile ut) {
   constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + FNW - 1) / FNW;
   const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
   // ---- 1. the stage's tiles: H_itp(tau_S) = H_j + s_S (H_j+1 - H_j) (gradient.jl:287: linear in the forward snapshots), lambda masked
@@ -51,7 +52,7 @@ __device__ __forceinline__ void adj_lds_stage(const GDev& g, const LawDev& L, co
     const int r = w + FNW * m;
     if (r >= S - 1 && r <= FRY - 1 - S) {  // wave-uniform
       double k[4] = {0.0, 0.0, 0.0, 0.0};
-      if (ncol) vjpH_node<LM, 0, FLD>(g, L, P, sHS, sL, gi0 + 1, gj0 + 1, lane, r, k);
+      if (ncol) vjpH_node<LM, 0, FLD>(g, L, P, sHS, sL, gi0 + 1, gj0 + 1, lane, r, k, ut);
       sCa[r][lane] = make_double2(k[0], k[1]);   // {SW, SE}
       sCb[r][lane] = make_double2(k[2], k[3]);   // {NW, NE}
     }
@@ -102,11 +103,25 @@ __global__ __launch_bounds__(FNT, 2) void k_adj_fused_lds(Pools P, LawDev L, Adj
   __shared__ double2 sCa[FRY][FLD];
   __shared__ double2 sCb[FRY][FLD];
   __shared__ double red[FNW];
+  // the U law's WHOLE table where it is the coarsest level (16 x 8 bi-quintic patches, 36 KB: what ytab_refresh picks for a law as smooth as
+  // the reference's scaled LawU) -- the LDS the tiles leave free on a CU that holds one workgroup anyway; every patch gather of the
+  // five stages is then an LDS read (the vector L1 returns data in order: a table load that hits still queues behind the misses)
+  constexpr int UT_LDS_PATCHES = LM == LM_UTAB ? 128 : 0;
+  __shared__ double2 sTab[UT_LDS_PATCHES > 0 ? 18 * UT_LDS_PATCHES : 1];
   const int4 t4 = A.tilesF[blockIdx.x];
   const GState* gs = P.gs + t4.x;
   if (gs->done) return;
   const GDev g = P.gd[t4.x];
   const AdjState a = A.adj[t4.x];
+  UtabTile ut = ODINN_UT_NONE;
+  if constexpr (LM == LM_UTAB) {
+    const int np = L.utab_nh * L.utab_ns;
+    if (np <= UT_LDS_PATCHES && !L.ut_nolds) {  // (block-uniform; published by the first barrier of stage 1)
+      const double2* __restrict__ tg = reinterpret_cast<const double2*>(L.utab);
+      for (int k = threadIdx.x; k < 18 * np; k += FNT) sTab[k] = tg[k];
+      ut.lds = sTab; ut.ih0 = 0; ut.is0 = 0; ut.nsr = L.utab_ns;
+    }
+  }
   const double dt = gs->dt;
   const int cur = gs->cur;
   const double* __restrict__ src = (cur ? A.lam1 : A.lam0) + g.off;   // the step reads lam[cur] and writes lam[1 - cur]: the controller
@@ -161,11 +176,11 @@ __global__ __launch_bounds__(FNT, 2) void k_adj_fused_lds(Pools P, LawDev L, Adj
     }
   }
   if (run) {
-    adj_lds_stage<1, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[0], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb);
-    adj_lds_stage<2, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[1], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb);
-    adj_lds_stage<3, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[2], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb);
-    adj_lds_stage<4, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[3], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb);
-    adj_lds_stage<5, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[4], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb);
+    adj_lds_stage<1, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[0], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
+    adj_lds_stage<2, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[1], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
+    adj_lds_stage<3, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[2], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
+    adj_lds_stage<4, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[3], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
+    adj_lds_stage<5, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[4], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
   }
   // ---- output tile = region_5: lambda' from the registers, embedded error partial (k_adj_stage<5>'s expression)
   double errsq = 0.0;

@@ -126,6 +126,35 @@ def test_fused_reverse_step_of_the_U_table_matches_the_staged_one(gpu, monkeypat
         assert rel_l2(lf, la) < 2e-6
 
 
+@pytest.mark.parametrize("skip", [1, 0])
+def test_lds_tile_reverse_step_of_the_U_table_matches_the_staged_one(gpu, monkeypatch, skip):
+    """The reverse step fused over LDS TILES (k_adj_fused_lds<LM_UTAB>, odinn_schedule.adj_ut_fused = 2: one dual node per thread at a
+    time with vjpH_node<LM_UTAB> -- the staged kernels' own node function -- on 54 x 22 tiles whose regions shrink by a ring per
+    stage) against the five k_adj_stage<LM_UTAB> launches (adj_ut_fused = 0): the nodes and cells see the same expressions, only the
+    error partials are summed over different tiles, so the loss agrees to 1e-13, the reverse step counts to the accept-threshold flips
+    and gradient / lambda(t0) to the tolerance of the adaptive reverse solve; ragged batch (a glacier narrower than a tile, one wider than
+    two), with and without the ice-free shortcut.  Reference: target_D_pure.jl:78-137, gradient.jl:316-324."""
+    monkeypatch.delenv("ODINN_ADJ_UT_FUSED", raising=False)
+    out = {}
+    for mode in (0, 2):
+        b, om, th, fields = _batch(gpu, "default", ((56, 40), (70, 57), (131, 64)))
+        b.set_schedule(adj_ut_fused=mode, adj_skip=skip)
+        ts = [2010.0 + j / 24.0 for j in range(4)]
+        for g in range(3):
+            b.set_reference(g, ts, [fields[g][0] * (1.0 - 0.01 * j) for j in range(4)], 3)
+        assert b.law_table()["usable"]
+        L, g_ = b.loss_grad_continuous(ts, theta=th, reltol=1e-8, n_quadrature=8)
+        out[mode] = (L, np.array(g_, dtype=float).ravel(), [b.lambda0(k) for k in range(3)], [(s.naccept, s.nreject) for s in b.last_stats_rev])
+        b.close()
+    a, f = out[0], out[2]
+    assert abs(a[0] - f[0]) <= 1e-13 * abs(a[0])
+    for (na, ra), (nf, rf) in zip(a[3], f[3]):
+        assert abs(na - nf) <= max(2, na // 10) and abs(ra - rf) <= max(2, ra // 2), (a[3], f[3])
+    assert np.linalg.norm(a[1] - f[1]) <= 2e-6 * np.linalg.norm(a[1]), np.linalg.norm(a[1] - f[1]) / np.linalg.norm(a[1])
+    for la, lf in zip(a[2], f[2]):
+        assert rel_l2(lf, la) < 2e-6
+
+
 def test_table_resolution_is_chosen_by_measurement(gpu, monkeypatch):
     """The table's resolution: the coarsest of 16 x 8 ... 128 x 64 patches that passes the check (the default) against the finest
     (ODINN_UTAB_LEVEL=3, the fixed size of round 4): both within 1e-12 of the network, same solve to 1e-11, same gradients to the
