@@ -995,6 +995,12 @@ struct YtabRef {  // one glacier's table as the strip kernels take it (AdjFusedA
   int ni;
   unsigned long long* beyond;  // the kernel's own ballot accumulator (ytab_eval_acc): the flag is raised once, at the kernel's end
 };
+// Y(Hbar + 1e-4) of the reverse kernels (the reference's forward difference of dD/dHbar, target_D_hybrid.jl:58-71): the interval's quintic
+// evaluated again at s + ds (6 instructions) instead of its exact Taylor shift from s (23: four derivative Horner chains).  The quotient
+// (Y(H + 1e-4) - Y(H)) / 1e-4 then carries the rounding of two evaluations, 2e-10 relative -- what the reference's own two network
+// evaluations carry -- where the shift kept 1e-16.  Measured (round 6, k_adj_fused_strip<..., YT>, 64 x 1024^2): 3625 -> 3309 us dense,
+// 2476 -> 2328 us with the ice-free shortcut; at 4 waves per SIMD (36-40 spilled VGPRs) 3500 / 2355: the kernel stays at 2.
+#define ODINN_YTAB_SHIFT_EXACT 0  // (fixed: its A/B is recorded above)
 template <bool ADJ>
 __device__ __forceinline__ double ytab_eval_acc(const double* __restrict__ tab, int ni, unsigned long long& beyond, double inv_h, double Hb, double& Yp) {
   // `beyond` collects the lanes whose node lies beyond the table (or is NaN): a ballot, i.e. scalar arithmetic -- NO divergent
@@ -1012,11 +1018,16 @@ __device__ __forceinline__ double ytab_eval_acc(const double* __restrict__ tab, 
   const double Y = fma(fma(fma(fma(fma(c45.y, s, c45.x), s, c23.y), s, c23.x), s, c01.y), s, c01.x);
   if (ADJ) {
     const double ds = 2.0 * (((Hb + 1e-4) - Hb) * inv_h);
+#if ODINN_YTAB_SHIFT_EXACT
     const double p1 = fma(fma(fma(fma(5.0 * c45.y, s, 4.0 * c45.x), s, 3.0 * c23.y), s, 2.0 * c23.x), s, c01.y);
     const double p2 = fma(fma(fma(10.0 * c45.y, s, 6.0 * c45.x), s, 3.0 * c23.y), s, c23.x);
     const double p3 = fma(fma(10.0 * c45.y, s, 4.0 * c45.x), s, c23.y);
     const double p4 = fma(5.0 * c45.y, s, c45.x);
     Yp = fma(ds, fma(ds, fma(ds, fma(ds, fma(ds, c45.y, p4), p3), p2), p1), Y);
+#else
+    const double s2 = s + ds;
+    Yp = fma(fma(fma(fma(fma(c45.y, s2, c45.x), s2, c23.y), s2, c23.x), s2, c01.y), s2, c01.x);
+#endif
   }
   return Y;
 }
