@@ -351,6 +351,64 @@ __global__ __launch_bounds__(64) void k_slot_sum(int P, const double* __restrict
   dth[q] = accumulate ? dth[q] + s : s;
 }
 
+// ---- the same corner sums WITHOUT a sort (round 6) --------------------------------------------------------------------------------
+// The sort only grouped the dual nodes by grid cell so that a workgroup could add a cell's weights in a fixed order.  Order-free
+// addition does not need the grouping: every node adds its four corner weights into the cell's accumulators with 64-bit INTEGER
+// atomics -- fixed point, two limbs at 2^(e - 35) and 2^(e - 71) of the launch's largest |v| (2^e > max |v|: one reduction pass first),
+// exact for 2^27 terms per cell and 2^19 x finer than a double's ulp of the largest weight: bitwise repeatable although atomic
+// (the scheme of k_sel_sums, with head-room for 64 x 1024^2 nodes in one cell).  Nodes with v == 0 (no ice) add nothing.
+__global__ __launch_bounds__(256) void k_ucell_vmax(const double* __restrict__ V, long long nd, unsigned long long* __restrict__ vmax) {
+  double m = 0.0;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nd; q += (long long)gridDim.x * 256) m = fmax(m, fabs(V[q]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(vmax, (unsigned long long)__double_as_longlong(m));  // (positive doubles order like their patterns)
+}
+__device__ __forceinline__ bool ucell_scales(double vmax, double& s1, double& s2) {
+  if (!(vmax > 0x1p-800)) return false;
+  int e;
+  (void)frexp(vmax, &e);
+  s1 = ldexp(1.0, e - 35);
+  s2 = ldexp(1.0, e - 71);
+  return true;
+}
+__global__ __launch_bounds__(256) void k_ucell_accum(const double* __restrict__ H, const double* __restrict__ S, const double* __restrict__ V,
+                                                     long long nd, int K, const unsigned long long* __restrict__ vmax,
+                                                     unsigned long long* __restrict__ bins, int* __restrict__ err) {
+  double s1, s2;
+  const bool on = ucell_scales(__longlong_as_double((long long)*vmax), s1, s2);
+  const double i1 = on ? 1.0 / s1 : 0.0, i2 = on ? 1.0 / s2 : 0.0;  // (powers of two: exact)
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nd; q += (long long)gridDim.x * 256) {
+    const double x = H[q], y = S[q];
+    if (!(x >= 0.0 && x <= UNODE_MAX && y >= 0.0 && y <= UNODE_MAX)) { atomicOr(err, 1); continue; }  // Gridded(Linear()) throws
+    const double v = V[q];
+    if (!on || v == 0.0) continue;
+    const int iH = ucell(x, K), iS = ucell(y, K);
+    const double h0 = unode(iH, K), s0 = unode(iS, K);
+    const double ih = 1.0 / (unode(iH + 1, K) - h0), is = 1.0 / (unode(iS + 1, K) - s0);
+    const double wh = (x - h0) * ih, ws = (y - s0) * is;   // k_ucell_sums' expressions
+    unsigned long long* b = bins + 8 * ((size_t)iH * (K - 1) + iS);
+    auto add = [&](int slot, double t) {
+      const double hi = rint(t * i1);
+      const double lo = rint(fma(-hi, s1, t) * i2);
+      if (hi != 0.0) atomicAdd(b + 2 * slot, (unsigned long long)(long long)hi);
+      if (lo != 0.0) atomicAdd(b + 2 * slot + 1, (unsigned long long)(long long)lo);
+    };
+    add(0, v * ((1.0 - wh) * (1.0 - ws)));
+    add(1, v * (wh * (1.0 - ws)));
+    add(2, v * ((1.0 - wh) * ws));
+    add(3, v * (wh * ws));
+  }
+}
+__global__ __launch_bounds__(256) void k_ucell_finish(int ncell4, const unsigned long long* __restrict__ vmax, const unsigned long long* __restrict__ bins,
+                                                      double* __restrict__ cell4) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= ncell4) return;
+  double s1, s2, a = 0.0;
+  if (ucell_scales(__longlong_as_double((long long)*vmax), s1, s2))
+    a = fma((double)(long long)bins[2 * (size_t)k], s1, (double)(long long)bins[2 * (size_t)k + 1] * s2);
+  cell4[k] = a;
+}
+
 size_t interp_sort_temp_bytes(long long nd_max) {
   size_t bytes = 0, bytes_u = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, (const double*)nullptr, (double*)nullptr, (const double*)nullptr,
@@ -367,6 +425,24 @@ int launch_interp_theta_U(hipStream_t st, const LawDev& L, int n_half, const dou
                           double* dth, int accumulate) {
   const int K = 2 * n_half;
   if (K > KMAX || n_half < 2 || nd >= (1ll << 32)) return 1;
+  const char* esel = std::getenv("ODINN_INTERP_SELECT");  // (the Y law's switch; read per call: tests toggle it)
+  const bool sorted = esel && esel[0] == '0';
+  if (!sorted) {
+    // behind cell4 (4 (KMAX - 1)^2 doubles): the fixed-point limbs, 8 words per cell, then the launch's max |v|
+    unsigned long long* bins = reinterpret_cast<unsigned long long*>(cell4 + (size_t)4 * (KMAX - 1) * (KMAX - 1));
+    unsigned long long* vmax = bins + (size_t)8 * (KMAX - 1) * (KMAX - 1);
+    const size_t nb = (size_t)8 * (K - 1) * (K - 1);
+    if (hipMemsetAsync(bins, 0, nb * sizeof(unsigned long long), st) != hipSuccess) return 2;
+    if (hipMemsetAsync(vmax, 0, sizeof(unsigned long long), st) != hipSuccess) return 2;
+    const unsigned nblk = (unsigned)std::min<long long>((nd + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_ucell_vmax, dim3(nblk), dim3(256), 0, st, nodeV, nd, vmax);
+    hipLaunchKernelGGL(k_ucell_accum, dim3(nblk), dim3(256), 0, st, nodeH, nodeS, nodeV, nd, K, vmax, bins, err);
+    const int n4 = 4 * (K - 1) * (K - 1);
+    hipLaunchKernelGGL(k_ucell_finish, dim3((n4 + 255) / 256), dim3(256), 0, st, n4, vmax, bins, cell4);
+    hipLaunchKernelGGL(k_unode_grads, dim3(KMAX / 64), dim3(64), 0, st, L, K, cell4, G);
+    hipLaunchKernelGGL(k_slot_sum, dim3((L.P + 63) / 64), dim3(64), 0, st, L.P, G, dth, accumulate);
+    return 0;
+  }
   unsigned* keys = reinterpret_cast<unsigned*>(sA);
   unsigned* idx = keys + nd;
   unsigned* skeys = reinterpret_cast<unsigned*>(sB);

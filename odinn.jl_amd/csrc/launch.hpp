@@ -43,6 +43,8 @@ void launch_vjp_theta_strip(int gacc, int itp, int nblk, hipStream_t st, Pools P
 
 // k_interp.hip: `:Linear` spatial interpolation of d law / d theta for the Y law (target_D_hybrid.jl:136-160)
 constexpr int INTERP_KMAX = 512;
+// odinn_batch::d_ucell per lane (8-byte words): 4 (KMAX - 1)^2 corner sums, 8 (KMAX - 1)^2 fixed-point limbs, max |v| (launch_interp_theta_U)
+constexpr size_t INTERP_UCELL_WORDS = (size_t)12 * (INTERP_KMAX - 1) * (INTERP_KMAX - 1) + 8;
 size_t interp_batch_temp_bytes(long long n_max);
 size_t interp_batch_lds_bytes(int P);
 size_t node_backprop_part_count(int ng, int Pn);

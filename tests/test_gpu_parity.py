@@ -876,6 +876,33 @@ def test_Y_law_interpolation_by_selection_matches_the_sorted_contraction(gpu, mo
     assert rel_l2(out[0][1], out[1][1]) < 1e-12
 
 
+def test_U_law_bilinear_contraction_without_a_sort_matches_the_sorted_one(gpu, monkeypatch):
+    """Laws.jl:128-169 on the device: the corner sums of the node-grid cells by order-free fixed-point accumulation (64-bit integer
+    atomics, two limbs; k_ucell_accum, the default since round 6) against the stable radix sort by grid cell + fixed-order sums it
+    replaced (ODINN_INTERP_SELECT=0): 1e-13, and the sort-free form repeats to the bit."""
+    om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+    shapes = [(131, 97), (80, 48)]
+    b = gpu.GlacierBatch(shapes, [100.0] * 2)
+    fields = []
+    for k, (nx, ny) in enumerate(shapes):
+        H0, B = (O.synthetic_valley(nx, ny, 100.0) if k == 0 else O.synthetic_icecap(nx, ny, 100.0))
+        fields.append((H0 * (90.0 / H0.max()), B))
+        b.set_fields(k, *fields[-1])
+    b.set_law(gpu.LAW_NN_U, gm, th)
+    rng = np.random.default_rng(11)
+    lams = [rng.standard_normal(s) for s in shapes]
+    for n in (10, 100, 256):
+        b.set_grad_interpolation(gpu._lib.GRAD_INTERP_LINEAR, n)
+        for k in range(2):
+            monkeypatch.delenv("ODINN_INTERP_SELECT", raising=False)
+            free = b.vjp_theta(k, lams[k], fields[k][0])
+            assert np.array_equal(free, b.vjp_theta(k, lams[k], fields[k][0]))
+            monkeypatch.setenv("ODINN_INTERP_SELECT", "0")
+            srt = b.vjp_theta(k, lams[k], fields[k][0])
+            assert np.linalg.norm(free) > 0 and rel_l2(free, srt) < 1e-13, (n, k, rel_l2(free, srt))
+    b.close()
+
+
 def test_U_law_theta_gradient_bilinear_interpolation(gpu):
     """SIA2D_D_target(interpolation = :Linear) (target_D_pure.jl:179-193): gradients of the U law on the fixed
     (2 n_interp_half)^2 node grid of LawU's p_VJP! (Laws.jl:128-169), bilinear in (Hbar, |grad S|).  On the device: dual
