@@ -112,7 +112,7 @@ typedef struct odinn_solver_opts {
   int32_t scheme;   /* 0 auto, 1/2: kernel schedule of one RDPK3Sp35 step (same arithmetic either way):
                        1 five per-stage kernels (HBM-bound, 264 B/cell/step),
                        2 one temporally fused kernel (~24 B/cell/step, fp64-VALU-bound);
-                       the environment variable ODINN_SCHEME=1|2 overrides 0.
+                       ODINN_SCHEDULE="scheme=1|2" overrides 0.
                        3 ODINN_SCHEME_EULER_CFL: explicit Euler with the CFL-limited step
                          dt = cfl * min(dx,dy)^2 / (4 max D) (the classical SIA stepping; max D by an
                          in-kernel wavefront reduction; 24 B per cell-step).  Not a reference scheme:
@@ -151,27 +151,44 @@ typedef struct odinn_adjoint_opts {
 
 /* Kernel schedule of a batch: which of the library's equivalent kernel forms run (same arithmetic, results agree to rounding --
  * see DESIGN.md "Different compilations of the same per-cell expression sequence").  Every field: -1 = automatic (the library's
- * measured rule, the default), otherwise the forced choice.  The environment variable named with each field, if set,
- * overrides the field (measurement / A-B aid).  `scheme` and `dense` of odinn_solver_opts stay per solve. */
+ * measured rule, the default), otherwise the forced choice.  The environment variable ODINN_SCHEDULE="field=value,field=value,..."
+ * (field names as below, plus scheme=1|2), if set, overrides the named fields of every batch of the process (measurement / A-B aid;
+ * read at every call).  `scheme` and `dense` of odinn_solver_opts stay per solve.
+ *
+ * ALL environment variables the library reads (14):
+ *   ODINN_SCHEDULE            the schedule override above
+ *   ODINN_INTERP_SELECT=0     `:Linear` law gradients by the radix-sorted contractions instead of the sort-free ones (Y and U law)
+ *   ODINN_INTERP_ACTIVE=0     ... over all dual nodes instead of the list of nodes that ever carry ice
+ *   ODINN_UTAB_LEVEL=0..3     U law: force the table resolution (16 x 8 ... 128 x 64 patches) instead of the coarsest that passes
+ *   ODINN_UT_LDS=0            U law: table patches from global memory even where a kernel stages them in LDS (test aid)
+ *   ODINN_LAW_TABLE_HMAX=x    first range of the law tables (test aid: small enough to overflow and be widened)
+ *   ODINN_LAW_TABLE_VERBOSE   one line per table build on stderr (size, measured deviation, table / network)
+ *   ODINN_DTMIN=0             no ODINN_ERR_DTMIN exit of a stuck adaptive solve (diagnostics)
+ *   ODINN_TRACE_STEPS=n       the first n attempts (t, dt, error estimate, step factor) of one glacier's solves on stderr
+ *   ODINN_TRACE_GLACIER=g     ... of glacier g instead of glacier 0
+ *   ODINN_PROFILE_HOST        host-side phase timings of odinn_solve / the gradients on stderr
+ *   ODINN_TIMED_ADJ_SKIP      odinn_time_kernel(ODINN_TIMED_ADJ_FUSED_STEP) times the kernel with its ice-free shortcut
+ *   ODINN_RCCL_LIB=path       librccl.so to dlopen for odinn_comm_* (default: the loader's search path, then torch's copy)
+ *   ODINN_REQUEST_DEV_KERNARG=1  sets HIP_FORCE_DEV_KERNARG=1 at load time (kernel arguments in device memory) */
 typedef struct odinn_schedule {
-  int32_t step_sc;         /* ODINN_STEP_SC: 1 = self-controlled step loop (no controller / post-step launches), 0 = off          */
-  int32_t fused_tiles;     /* ODINN_FUSED_TILES (s|l|t|u): fused step kernel -- 1 54x8 latency tiles, 2 54x40 tiles, 3 strip kernel
+  int32_t step_sc;         /* step_sc: 1 = self-controlled step loop (no controller / post-step launches), 0 = off          */
+  int32_t fused_tiles;     /* fused_tiles (s|l|t|u): fused step kernel -- 1 54x8 latency tiles, 2 54x40 tiles, 3 strip kernel
                               with 7 rows per thread, 4 strip kernel with 8 rows per thread                                        */
-  int32_t dhdt_strip;      /* ODINN_DHDT_STRIP: 0 = keep the 64x16-tile RHS / CFL-Euler kernels instead of the strip layout        */
-  int32_t vjph_strip;      /* ODINN_VJPH_STRIP: H-VJP in the strip layout (1) or on 64x16 LDS tiles (0)                            */
-  int32_t vjpth_strip;     /* ODINN_VJPTH_STRIP: the same for the theta-VJP reduction                                              */
-  int32_t snap_on_load;    /* ODINN_SNAP_ON_LOAD: 0 = post-step launch per step instead of the snapshot-on-load two-launch loop    */
-  int32_t interp_streams;  /* ODINN_INTERP_STREAMS: side streams of the per-glacier `:Linear` interpolation sequences (1 ... 8)     */
-  int32_t interp_batch;    /* ODINN_INTERP_BATCH: 0 = one interpolation sequence per glacier instead of one per call (Y law)      */
-  int32_t lawgrad_wave;    /* ODINN_LAWGRAD_WAVE: 0 = per-thread accumulators for the gridded law's theta-gradient                */
-  int32_t vq_onepass;      /* ODINN_VQ_ONEPASS: 0 = interpolate / scale / pull-back / reduce sequence at the quadrature nodes of a
+  int32_t dhdt_strip;      /* dhdt_strip: 0 = keep the 64x16-tile RHS / CFL-Euler kernels instead of the strip layout        */
+  int32_t vjph_strip;      /* vjph_strip: H-VJP in the strip layout (1) or on 64x16 LDS tiles (0)                            */
+  int32_t vjpth_strip;     /* vjpth_strip: the same for the theta-VJP reduction                                              */
+  int32_t snap_on_load;    /* snap_on_load: 0 = post-step launch per step instead of the snapshot-on-load two-launch loop    */
+  int32_t interp_streams;  /* interp_streams: side streams of the per-glacier `:Linear` interpolation sequences (1 ... 8)     */
+  int32_t interp_batch;    /* interp_batch: 0 = one interpolation sequence per glacier instead of one per call (Y law)      */
+  int32_t lawgrad_wave;    /* lawgrad_wave: 0 = per-thread accumulators for the gridded law's theta-gradient                */
+  int32_t vq_onepass;      /* vq_onepass: 0 = interpolate / scale / pull-back / reduce sequence at the quadrature nodes of a
                               velocity loss instead of the one-pass node kernel                                                    */
-  int32_t adj_fused;       /* ODINN_ADJ_FUSED: 0 = five k_adj_stage launches per reverse step instead of the fused reverse step   */
-  int32_t adj_skip;        /* ODINN_ADJ_SKIP: 0 = no ice-free shortcut in the fused reverse step                                   */
-  int32_t adj_segs;        /* ODINN_ADJ_SEGS: 0 = read the two snapshots instead of the interleaved {H_j, H_j+1 - H_j} pairs       */
-  int32_t adj_rows;        /* ODINN_ADJ_ROWS: 4 | 7 | 8 rows per thread of the fused reverse step (8: gridded A only, else ignored) */
-  int32_t adj_theta_fused; /* ODINN_ADJ_THETA_FUSED: 0 = theta-VJP of a quadrature node in launches of its own                     */
-  int32_t law_table;       /* ODINN_LAW_TABLE: 0 = the stencil kernels of a batch with the Y law (ODINN_LAW_NN_Y: inputs = the
+  int32_t adj_fused;       /* adj_fused: 0 = five k_adj_stage launches per reverse step instead of the fused reverse step   */
+  int32_t adj_skip;        /* adj_skip: 0 = no ice-free shortcut in the fused reverse step                                   */
+  int32_t adj_segs;        /* adj_segs: 0 = read the two snapshots instead of the interleaved {H_j, H_j+1 - H_j} pairs       */
+  int32_t adj_rows;        /* adj_rows: 4 | 7 | 8 rows per thread of the fused reverse step (8: gridded A only, else ignored) */
+  int32_t adj_theta_fused; /* adj_theta_fused: 0 = theta-VJP of a quadrature node in launches of its own                     */
+  int32_t law_table;       /* law_table: 0 = the stencil kernels of a batch with the Y law (ODINN_LAW_NN_Y: inputs = the
                               glacier's scalar temperature and Hbar) or the U law (ODINN_LAW_NN_U: inputs = Hbar and |grad S|)
                               evaluate the network at every dual node and stage.  Default (-1 / 1): inside the forward solve and
                               both adjoints they read the law from a table -- Y(Hbar) per glacier in 1024 quintics, U(Hbar, |grad S|)
@@ -184,14 +201,14 @@ typedef struct odinn_schedule {
                               interpolant, whose error is amplified by 1 / step -- 1e-8 relative at the bound, the accuracy those
                               differences have in fp64 anyway; gradients with and without the table agree to 1e-8 ... 5e-8
                               (tests/test_gpu_law_table*.py)                                                                       */
-  int32_t interp_async;    /* ODINN_INTERP_ASYNC: 0 = the Y law's `:Linear` contraction of a stop (sort, knots, interval sums, knot
+  int32_t interp_async;    /* interp_async: 0 = the Y law's `:Linear` contraction of a stop (sort, knots, interval sums, knot
                               backprop) on the batch's own stream; n = 1 ... 4: overlapped with the following reverse steps of both
                               adjoints on n lane streams (default: 3 in the DiscreteAdjoint, 1 or 4 in the ContinuousAdjoint; results
                               bit-identical: every contribution has its own slot, the slots are added in the order of the stops)  */
-  int32_t adj_sc;          /* ODINN_ADJ_SC: 1 = self-controlled reverse step of the ContinuousAdjoint (the fused reverse step decides
+  int32_t adj_sc;          /* adj_sc: 1 = self-controlled reverse step of the ContinuousAdjoint (the fused reverse step decides
                               the previous attempt and does the post-step of a stop itself: one launch per reverse step), 0 = the
                               three-launch loop (fused step, controller, post-step); same decisions, same arithmetic             */
-  int32_t adj_ut_fused;    /* ODINN_ADJ_UT_FUSED: reverse step of the ContinuousAdjoint for the U law (target :D) through its table: 0 = five
+  int32_t adj_ut_fused;    /* adj_ut_fused: reverse step of the ContinuousAdjoint for the U law (target :D) through its table: 0 = five
                               k_adj_stage launches, 1 = the strip kernel's UT form (measured 3 x slower, kept as a cross-check), 2 = the
                               fused step on LDS tiles (k_adj_fused_lds, sia2d_adj_lds.hpp); -1 = the library's measured rule             */
   int32_t reserved[1];     /* zero                                                                                                 */

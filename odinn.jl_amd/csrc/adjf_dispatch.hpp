@@ -9,9 +9,7 @@ namespace odinn {
   hipLaunchKernelGGL((k_adj_fused_strip<AF, SK, SG, NR, GA, YT, SC>), dim3(nblk), dim3(TNT), pad, st, P, A)
 template <bool SC>
 static void adjf_dispatch(int nblk, int afield, int skip, int rows, hipStream_t st, const Pools& P, const AdjFusedArgs& A) {
-  // measurement aid: ODINN_ADJ_LDS_PAD=<bytes> of unused dynamic LDS per workgroup (> 2 KB: one workgroup per CU instead of two,
-  // i.e. half the per-XCD working set against the 4 MB L2 at half the occupancy)
-  static const unsigned pad = std::getenv("ODINN_ADJ_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ODINN_ADJ_LDS_PAD")) : 0u;
+  constexpr unsigned pad = 0u;  // (dynamic LDS; the one-workgroup-per-CU experiment it once served is recorded in DESIGN section 5)
   if (A.utab) {  // the U law (target :D) through its table: own law block, no SC (the caller guarantees A.segs, !afield, rows 2 / 4 / 7)
     if constexpr (!SC) {
 #define ODINN_ADJF_UT(SK, NR) \

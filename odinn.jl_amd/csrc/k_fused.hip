@@ -32,8 +32,7 @@ void CAT(launch_rk_fused_lm, ODINN_LM)(int nblk, hipStream_t st, Pools P, LawDev
 void launch_rk_fused_strip(int nblk, int afield, int rows, hipStream_t st, Pools P, LawDev L, const int4* tilesF, double* U0,
                            double* U1, double* partF, double abstol, double reltol, int skip, const ScArgs* sc, int sq, int ytab) {
   const ScArgs A = sc ? *sc : ScArgs{};
-  // measurement aid: ODINN_LDS_PAD=<bytes> of unused dynamic LDS per workgroup lowers the occupancy (A/B of waves per SIMD)
-  static const unsigned pad = std::getenv("ODINN_LDS_PAD") ? (unsigned)std::atoi(std::getenv("ODINN_LDS_PAD")) : 0u;
+  constexpr unsigned pad = 0u;  // (dynamic LDS; the occupancy A/B it once served is recorded in DESIGN section 5)
   // sq: dx == dy on every glacier of the batch (one multiplication less per node, bit-identical)
 #define ODINN_STRIP_Q(SK, AF, NR, SCV, SQV) \
   hipLaunchKernelGGL((k_rk_fused_strip<SK, AF, NR, SCV, SQV>), dim3(nblk), dim3(TNT), pad, st, P, L, tilesF, U0, U1, partF, abstol, reltol, A)

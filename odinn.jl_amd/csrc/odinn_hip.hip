@@ -137,10 +137,36 @@ int mlp_nparams(const odinn_mlp_desc& m) {
 
 }  // namespace
 
-// Kernel-schedule switch: the environment variable (a measurement / A-B override) if it is set, else the batch's
-// odinn_schedule field, else -1 = the library's own measured rule.  Flags are '0' / '1' (any other digit string: atoi).
+// Kernel-schedule switch: ONE environment variable, ODINN_SCHEDULE="field=value,field=value,..." (a measurement / A-B override of the
+// odinn_schedule fields of every batch of the process: step_sc, fused_tiles, ..., adj_ut_fused, plus scheme = 1 | 2), if it names the
+// field; else the batch's odinn_schedule field; else -1 = the library's own measured rule.  Values are digit strings (fused_tiles also
+// s | l | t | u).  `env` is the historical per-field variable name: its suffix in lower case is the key.  Read per call: tests toggle it.
+static const char* sched_env_str(const char* env, char* buf, size_t nbuf) {
+  const char* all = std::getenv("ODINN_SCHEDULE");
+  if (!all || !*all) return nullptr;
+  char key[48];
+  size_t n = 0;
+  for (const char* c = env + 6; *c && n + 1 < sizeof(key); ++c) key[n++] = (char)(*c >= 'A' && *c <= 'Z' ? *c - 'A' + 'a' : *c);
+  key[n] = 0;
+  for (const char* p = all; *p;) {
+    const char* e = p;
+    while (*e && *e != ',') ++e;
+    const char* q = p;
+    while (q < e && *q != '=') ++q;
+    while (p < q && *p == ' ') ++p;
+    if ((size_t)(q - p) == n && std::strncmp(p, key, n) == 0 && q < e) {
+      size_t m = std::min((size_t)(e - q - 1), nbuf - 1);
+      std::memcpy(buf, q + 1, m);
+      buf[m] = 0;
+      return buf;
+    }
+    p = *e ? e + 1 : e;
+  }
+  return nullptr;
+}
 static int sched_val(int field, const char* env) {
-  if (const char* e = std::getenv(env))
+  char buf[32];
+  if (const char* e = sched_env_str(env, buf, sizeof(buf)))
     if (e[0] >= '0' && e[0] <= '9') return std::atoi(e);
   return field;
 }
@@ -183,7 +209,8 @@ struct odinn_batch {
   // odinn_schedule::fused_tiles / ODINN_FUSED_TILES (s | l | t | u, or the digit): 0 automatic, 1 small, 2 large,
   // 3 strip with 7 rows per thread, 4 strip with 8 rows per thread
   int fused_override() const {
-    if (const char* e = std::getenv("ODINN_FUSED_TILES")) {
+    char ebuf[32];
+    if (const char* e = sched_env_str("ODINN_FUSED_TILES", ebuf, sizeof(ebuf))) {
       const int v = e[0] == 's' ? 1 : e[0] == 'l' ? 2 : e[0] == 't' ? 3 : e[0] == 'u' ? 4 : (e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 0;
       if (v) return v;
     }
@@ -198,8 +225,7 @@ struct odinn_batch {
   bool ytab_strip() const {
     if (lm_kern() != LM_YTAB || gd.empty()) return false;
     for (const GDev& r : gd) if (!r.yt_fast) return false;
-    static const bool off = std::getenv("ODINN_YT_STRIP") && std::getenv("ODINN_YT_STRIP")[0] == '0';
-    return !off;
+    return true;
   }
   bool strip_law() const { return lm() == 0 || ytab_strip(); }
   int fused_kind() const {
@@ -701,7 +727,7 @@ int refresh_gd(odinn_batch* b) {
       }
       b->gd[g].yt_inv_h = (double)b->ytab_ni / b->ytab_hmax[g];
       b->gd[g].yt_off = (long long)g * 6 * b->ytab_ni;
-      b->gd[g].yt_fast = (b->gd[g].fast && b->gd[g].nH == 3.0 && b->gd[g].nS == 3.0 && !std::getenv("ODINN_LAW_TABLE_NOFAST")) ? 1 : 0;
+      b->gd[g].yt_fast = (b->gd[g].fast && b->gd[g].nH == 3.0 && b->gd[g].nS == 3.0) ? 1 : 0;
     }
   }
   HIPCHK(hipMemcpyAsync(b->d_gd, b->gd.data(), sizeof(GDev) * b->G, hipMemcpyHostToDevice, b->stream));

@@ -40,3 +40,22 @@ def rel_l2(a, b):
     b = np.asarray(b, float)
     d = np.linalg.norm(b)
     return np.linalg.norm(a - b) / (d if d > 0 else 1.0)
+
+
+def sched_env(monkeypatch, **fields):
+    """Set / clear fields of ODINN_SCHEDULE (the library's one schedule override variable: "field=value,...") for this test.
+    sched_env(monkeypatch, ADJ_FUSED="0", ADJ_ROWS=4) merges into what is set; a value of None removes the field."""
+    cur = {}
+    for item in os.environ.get("ODINN_SCHEDULE", "").split(","):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            cur[k.strip()] = v.strip()
+    for k, v in fields.items():
+        if v is None:
+            cur.pop(k.lower(), None)
+        else:
+            cur[k.lower()] = str(v)
+    if cur:
+        monkeypatch.setenv("ODINN_SCHEDULE", ",".join(f"{k}={v}" for k, v in cur.items()))
+    else:
+        monkeypatch.delenv("ODINN_SCHEDULE", raising=False)

@@ -263,3 +263,18 @@ def test_julia_struct_mirrors_match_the_compiled_header():
         csize, cfields = lay[cname]
         assert size == csize, f"{jl}: {size} bytes in the shim, {csize} in C"
         assert [(f, o, s) for f, o, s in fields] == [(f, o, s) for f, (o, s) in cfields.items()], (jl, fields, cfields)
+
+
+def test_every_environment_variable_the_library_reads_is_documented_in_the_header():
+    """The knob surface: at most 15 variables, each listed with its purpose in include/odinn_hip.h; the kernel-schedule overrides go
+    through ONE of them (ODINN_SCHEDULE="field=value,...")."""
+    import glob, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    for f in glob.glob(os.path.join(root, "odinn.jl_amd", "csrc", "*")):
+        if f.endswith((".hip", ".hpp", ".inc")):
+            read |= set(re.findall(r'getenv\("(ODINN_[A-Z0-9_]+)"', open(f).read()))
+    hdr = open(os.path.join(root, "include", "odinn_hip.h")).read()
+    listed = set(re.findall(r"^ \*   (ODINN_[A-Z0-9_]+)", hdr, flags=re.M))
+    assert read == listed, (sorted(read - listed), sorted(listed - read))
+    assert len(read) <= 15

@@ -5,7 +5,7 @@ lives in test_gpu_golden_api.py::test_config4_four_glaciers_gradient."""
 import numpy as np
 import pytest
 
-from conftest import rel_l2
+from conftest import rel_l2, sched_env
 from oracle import c_oracle as CO
 from oracle import sia2d_oracle as O
 
@@ -161,7 +161,7 @@ def test_config4_batch_of_1024_glaciers(gpu, monkeypatch):
     7-row one for a single glacier --, which changes results at rounding level only)."""
     import bench
 
-    monkeypatch.delenv("ODINN_FUSED_TILES", raising=False)  # this test is about the library's own choice
+    sched_env(monkeypatch, FUSED_TILES=None)  # this test is about the library's own choice
     n, G = 1024, 8
     gl = [bench.make_glacier(n, k) for k in range(G)]
     b = gpu.GlacierBatch([(n, n)] * G, [100.0] * G, A=[g[2] for g in gl])
@@ -180,8 +180,8 @@ def test_config4_batch_of_1024_glaciers(gpu, monkeypatch):
     one.solve([0.0, 0.02], fixed_dt=0.005)
     assert rel_l2(one.snapshot(0, 1), b.snapshot(5, 1)) < 1e-13
     one.close()
-    monkeypatch.setenv("ODINN_FUSED_TILES", "u")  # the kernel the batch of 8 ran on ...
-    monkeypatch.setenv("ODINN_STEP_SC", "0")      # ... in the same instantiation (three-launch loop)
+    sched_env(monkeypatch, FUSED_TILES="u")  # the kernel the batch of 8 ran on ...
+    sched_env(monkeypatch, STEP_SC="0")      # ... in the same instantiation (three-launch loop)
     one = gpu.GlacierBatch([(n, n)], [100.0], A=[gl[5][2]])
     one.set_fields(0, gl[5][0], gl[5][1])
     one.solve([0.0, 0.02], fixed_dt=0.005)

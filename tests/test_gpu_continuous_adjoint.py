@@ -5,7 +5,7 @@ the GPU forward loss with the reference's own thresholds [1e-3, 1e-8, 1e-3] (run
 import numpy as np
 import pytest
 
-from conftest import rel_l2, stats_err_arrays
+from conftest import rel_l2, stats_err_arrays, sched_env
 from oracle import sia2d_oracle as O
 from test_gpu_parity import _inversion_case, _mb
 
@@ -105,7 +105,7 @@ def test_continuous_adjoint_with_velocity_losses(gpu, monkeypatch, kind, compone
     quadrature with the reference velocities interpolated linearly in time.  Against the oracle, through the one-pass
     node kernel (k_surfV_theta_node, the default for closed-form laws without a dual-grid accumulator) and through the
     interpolate / scale / pull-back / reduce sequence it replaces (ODINN_VQ_ONEPASS=0)."""
-    monkeypatch.setenv("ODINN_VQ_ONEPASS", onepass)
+    sched_env(monkeypatch, VQ_ONEPASS=onepass)
     from test_gpu_velocity import _velocity_case
 
     ph = O.Phys()
@@ -146,7 +146,7 @@ def test_continuous_adjoint_velocity_loss_with_the_gridded_law(gpu, monkeypatch,
     glacier's normalisation) or the interpolate / scale / pull-back sequence (ODINN_VQ_ONEPASS=0).  Against the oracle."""
     from test_gpu_velocity import _velocity_case
 
-    monkeypatch.setenv("ODINN_VQ_ONEPASS", onepass)
+    sched_env(monkeypatch, VQ_ONEPASS=onepass)
     ph = O.Phys()
     nx, ny = 64, 48
     H0, B, ts, mlp, th_true, th0, gl, cfg, ref, tV, Vref = _velocity_case(nx, ny, ph)
@@ -396,7 +396,7 @@ def test_fused_reverse_step_matches_the_staged_reverse_solve(gpu, monkeypatch, c
     an ulp into a 1e-10 relative change of the step sizes; observed differences 1e-16 ... 2e-8)."""
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("ODINN_ADJ_FUSED", mode)
+        sched_env(monkeypatch, ADJ_FUSED=mode)
         out[mode] = _reverse_case(gpu, case)
     a, f = out["0"], out["1"]
     assert a[0] == f[0]  # the forward solve is the same code
@@ -418,11 +418,11 @@ def test_fused_reverse_step_rows_per_thread(gpu, monkeypatch, case):
     (54 x 22 tiles; what batches too small to fill the GPU run, ODINN_ADJ_ROWS forces either) -- evaluate the same face
     form cell by cell; only the tiling of the error norm's partial sums differs, so the step sequences agree up to
     threshold flips and the results to the tolerance of the reverse solve."""
-    monkeypatch.setenv("ODINN_ADJ_FUSED", "1")
+    sched_env(monkeypatch, ADJ_FUSED="1")
     out = {}
     # (8 rows: the register-cached instantiation of the gridded law on the forward kernel's 54 x 54 tiles; ignored otherwise)
     for rows in ("7", "4", "2") + (("8",) if case == "gridded_nn" else ()):
-        monkeypatch.setenv("ODINN_ADJ_ROWS", rows)
+        sched_env(monkeypatch, ADJ_ROWS=rows)
         out[rows] = _reverse_case(gpu, case)
     for other in [r for r in out if r != "7"]:
         a, f = out["7"], out[other]
@@ -441,10 +441,10 @@ def test_fused_reverse_step_ice_free_shortcut_is_bitwise_exact(gpu, monkeypatch)
     H0, B = O.synthetic_icecap(n, n, 100.0)
     H0 = np.asfortranarray(np.where(H0 > 500.0, H0 - 500.0, 0.0))  # small cap: most strip tiles ice-free
     ts = [0.0, 0.25, 0.5]
-    monkeypatch.setenv("ODINN_ADJ_FUSED", "1")
+    sched_env(monkeypatch, ADJ_FUSED="1")
     out = []
     for skip in ("0", "1"):
-        monkeypatch.setenv("ODINN_ADJ_SKIP", skip)
+        sched_env(monkeypatch, ADJ_SKIP=skip)
         b = gpu.GlacierBatch([(n, n)], [100.0], A=[4e-17])
         b.set_fields(0, H0, B)
         b.set_reference(0, ts, [H0 * (1.0 - 0.05 * j) for j in range(3)], 3)
@@ -462,7 +462,7 @@ def test_fused_reverse_step_with_rejected_steps(gpu, monkeypatch):
     path restarts from its uprev register.  Same accept / reject counts, gradients equal to rounding."""
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("ODINN_ADJ_FUSED", mode)
+        sched_env(monkeypatch, ADJ_FUSED=mode)
         shapes = [(130, 97), (96, 80)]
         b = gpu.GlacierBatch(shapes, [50.0] * 2, A=[6e-17, 4e-17])
         ts = [2010.0, 2010.5, 2011.0, 2011.5]
@@ -491,11 +491,11 @@ def test_self_controlled_reverse_step_matches_the_three_launch_loop(gpu, monkeyp
     and lambda(t0) -- on a single glacier with a mass balance, the gridded law (dual-grid accumulator fed by stage 1), a ragged
     batch whose glaciers run out of step, a reverse solve with rejected steps, and mass-balance times that are not result
     stops."""
-    monkeypatch.setenv("ODINN_ADJ_FUSED", "1")
-    monkeypatch.setenv("ODINN_ADJ_ROWS", rows)
+    sched_env(monkeypatch, ADJ_FUSED="1")
+    sched_env(monkeypatch, ADJ_ROWS=rows)
     out = {}
     for sc in ("0", "1"):
-        monkeypatch.setenv("ODINN_ADJ_SC", sc)
+        sched_env(monkeypatch, ADJ_SC=sc)
         if case == "rejections":
             shapes = [(130, 97), (96, 80)]
             b = gpu.GlacierBatch(shapes, [50.0] * 2, A=[6e-17, 4e-17])
@@ -512,7 +512,7 @@ def test_self_controlled_reverse_step_matches_the_three_launch_loop(gpu, monkeyp
             # the Y law through its table, `:Linear` gradient: stage 1 of the fused step emits the node pairs of a quadrature node
             # (both loops), the sort-free contraction runs on the lanes
             from test_gpu_parity import _mlp_pair
-            monkeypatch.delenv("ODINN_LAW_TABLE", raising=False)  # (the case IS the table: tools/suite_matrix.sh runs the suite with it off)
+            sched_env(monkeypatch, LAW_TABLE=None)  # (the case IS the table: tools/suite_matrix.sh runs the suite with it off)
             ph = O.Phys()
             om, gm, th = _mlp_pair(gpu, [2, 3, 10, 3, 1], [1, 1, 1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
             shapes = [(70, 57), (131, 64), (54, 46)]

@@ -7,7 +7,7 @@ network path, follow theta, and survive a solve that leaves its range."""
 import numpy as np
 import pytest
 
-from conftest import rel_l2, stats_err_arrays
+from conftest import rel_l2, stats_err_arrays, sched_env
 from oracle import sia2d_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _no_overrides(monkeypatch):  # (the suite is also run under ODINN_LAW_TABLE=1 / ODINN_INTERP_ASYNC=0: these tests set the fields)
-    monkeypatch.delenv("ODINN_LAW_TABLE", raising=False)
-    monkeypatch.delenv("ODINN_INTERP_ASYNC", raising=False)
+    sched_env(monkeypatch, LAW_TABLE=None)
+    sched_env(monkeypatch, INTERP_ASYNC=None)
 
 ARCHS = {"light": ([2, 3, 1], [1, 2]), "default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "x16": ([2, 16, 16, 1], [1, 1, 2]),
          "runtime": ([2, 5, 10, 5, 1], [3, 3, 3, 1])}

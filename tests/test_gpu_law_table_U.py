@@ -6,7 +6,7 @@ difference in U), oracle tolerances of the network path, overflow repeats the so
 import numpy as np
 import pytest
 
-from conftest import rel_l2, stats_err_arrays
+from conftest import rel_l2, stats_err_arrays, sched_env
 from oracle import sia2d_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _no_overrides(monkeypatch):
-    monkeypatch.delenv("ODINN_LAW_TABLE", raising=False)
+    sched_env(monkeypatch, LAW_TABLE=None)
 
 
 def _batch(gpu, arch="default", shapes=((56, 40), (70, 57))):
@@ -105,10 +105,10 @@ def test_fused_reverse_step_of_the_U_table_matches_the_staged_one(gpu, monkeypat
     alpha and beta by the reference's central differences on the node's bi-quintic patch, face form of the H-VJP) against the five
     k_adj_stage<LM_UTAB> launches (ODINN_ADJ_UT_FUSED=0): same loss, reverse step counts within the accept-threshold flips, gradient
     and lambda(t0) to the tolerance of the adaptive reverse solve; ragged batch, three tile heights."""
-    monkeypatch.setenv("ODINN_ADJ_ROWS", rows)
+    sched_env(monkeypatch, ADJ_ROWS=rows)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("ODINN_ADJ_UT_FUSED", mode)
+        sched_env(monkeypatch, ADJ_UT_FUSED=mode)
         b, om, th, fields = _batch(gpu, "default", ((56, 40), (70, 57), (131, 64)))
         ts = [2010.0 + j / 24.0 for j in range(4)]
         for g in range(3):
@@ -134,7 +134,7 @@ def test_lds_tile_reverse_step_of_the_U_table_matches_the_staged_one(gpu, monkey
     error partials are summed over different tiles, so the loss agrees to 1e-13, the reverse step counts to the accept-threshold flips
     and gradient / lambda(t0) to the tolerance of the adaptive reverse solve; ragged batch (a glacier narrower than a tile, one wider than
     two), with and without the ice-free shortcut.  Reference: target_D_pure.jl:78-137, gradient.jl:316-324."""
-    monkeypatch.delenv("ODINN_ADJ_UT_FUSED", raising=False)
+    sched_env(monkeypatch, ADJ_UT_FUSED=None)
     out = {}
     for mode in (0, 2):
         b, om, th, fields = _batch(gpu, "default", ((56, 40), (70, 57), (131, 64)))

@@ -4,7 +4,7 @@ rel-L2 <= 1e-6 on the final H and the reference's FD thresholds on the gradients
 import numpy as np
 import pytest
 
-from conftest import rel_l2, stats_err_arrays
+from conftest import rel_l2, stats_err_arrays, sched_env
 from oracle import sia2d_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -159,7 +159,7 @@ def test_nn_A_gridded(gpu, monkeypatch, arch, wave):
     """LawA(nn; scalar = false): A = NN(T) hoisted onto the dual grid; dtheta = sum_nodes Gacc dA/dtheta(T) by the wave-reduced
     backprop kernel (k_law_field_grad_wave: compile-time 1-3-10-3-1 and 1-16-16-1 nets, run-time architectures) and by the
     per-thread-accumulator kernel it replaces (ODINN_LAWGRAD_WAVE=0)."""
-    monkeypatch.setenv("ODINN_LAWGRAD_WAVE", wave)
+    sched_env(monkeypatch, LAWGRAD_WAVE=wave)
     ph = O.Phys()
     widths, acts = {
         "default": ([1, 3, 10, 3, 1], [1, 1, 1, 2]),
@@ -461,7 +461,7 @@ def test_ice_free_tile_shortcut_is_bitwise_exact(gpu, monkeypatch, tiles):
     """The fused step kernels skip workgroups whose whole halo region has u == 0; the result must be
     bit-identical to running all five stages everywhere (opts.dense = 1).  tiles: the 54x8 latency tile,
     the 54x40 row-interleaved kernel, the 54x46 strip kernel ("t")."""
-    monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
+    sched_env(monkeypatch, FUSED_TILES=tiles)
     n = 320
     H0, B = O.synthetic_icecap(n, n, 100.0)
     H0 = np.where(H0 > 500.0, H0 - 500.0, 0.0)  # small cap: most tiles ice-free
@@ -488,7 +488,7 @@ def test_fused_tile_sizes_are_equivalent(gpu, monkeypatch):
     ts = [2010.0, 2010.25, 2010.5]
     out = {}
     for tiles in ("small", "large", "t", "u"):
-        monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
+        sched_env(monkeypatch, FUSED_TILES=tiles)
         b = gpu.GlacierBatch([(130, 97)], [50.0], A=[4e-17])
         b.set_fields(0, H0, B)
         st = b.solve(ts, reltol=1e-8)
@@ -513,7 +513,7 @@ def test_strip_kernel_matches_the_per_stage_schedule(gpu, monkeypatch, shape, ti
     ragged grids around its 54x46 tile, with a constant A and with a gridded A field: equal to rounding under a
     fixed dt, within the solver tolerance under step-size control (see test_fused_tile_sizes_are_equivalent);
     and against the oracle's integrator.  tiles: "t" = 7 rows per thread (54x46 tiles), "u" = 8 rows (54x54)."""
-    monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
+    sched_env(monkeypatch, FUSED_TILES=tiles)
     nx, ny = shape
     H0, B = O.synthetic_valley(nx, ny, 50.0)
     rng = np.random.default_rng(7)
@@ -621,7 +621,7 @@ def test_strip_kernel_randomised_shapes_fixed_dt(gpu, monkeypatch):
         fields.append((np.asfortranarray(np.maximum(H, 0.0)), np.asfortranarray(B)))
     res = {}
     for key, scheme, tiles in (("staged", 1, "t"), ("t", 2, "t"), ("u", 2, "u")):
-        monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
+        sched_env(monkeypatch, FUSED_TILES=tiles)
         b = gpu.GlacierBatch(shapes, [40.0] * len(shapes), [55.0] * len(shapes), A=[3e-17] * len(shapes))
         for k, (H, B) in enumerate(fields):
             b.set_fields(k, H, B)
@@ -640,7 +640,7 @@ def test_self_controlled_step_loop_matches_the_three_launch_loop(gpu, monkeypatc
     kernel arithmetic and the same decisions as the three-launch loop: same step counts, same snapshots, on a ragged
     batch with rejections, many stops and a mass balance on half of the glaciers (applied on load by the
     self-controlled kernel, in place by k_poststep)."""
-    monkeypatch.setenv("ODINN_FUSED_TILES", "t")
+    sched_env(monkeypatch, FUSED_TILES="t")
     shapes = [(130, 97), (96, 80), (201, 103), (54, 46)]
     ts = [2010.0 + 0.05 * j for j in range(9)]
     out = {}
@@ -648,8 +648,8 @@ def test_self_controlled_step_loop_matches_the_three_launch_loop(gpu, monkeypatc
     # (step kernel + controller; snapshot and mass balance on load, GState::pad bit 2 kept by the controller); "1": the
     # self-controlled loop
     for sc in ("0", "2", "1"):
-        monkeypatch.setenv("ODINN_STEP_SC", "1" if sc == "1" else "0")
-        monkeypatch.setenv("ODINN_SNAP_ON_LOAD", "0" if sc == "0" else "1")
+        sched_env(monkeypatch, STEP_SC="1" if sc == "1" else "0")
+        sched_env(monkeypatch, SNAP_ON_LOAD="0" if sc == "0" else "1")
         b = gpu.GlacierBatch(shapes, [50.0] * 4, A=[8e-17, 4e-17, 6e-17, 2e-17])
         for k, (nx, ny) in enumerate(shapes):
             H0, B = O.synthetic_valley(nx, ny, 50.0)
@@ -683,8 +683,8 @@ def test_largest_single_gpu_configuration_64x1024(gpu, monkeypatch):
     bit for bit, the same glacier stepped alone with the same kernel form)."""
     from bench import make_glacier
 
-    monkeypatch.setenv("ODINN_FUSED_TILES", "u")  # the 8-row strip kernel for both batch sizes
-    monkeypatch.setenv("ODINN_STEP_SC", "0")      # and the same three-launch loop
+    sched_env(monkeypatch, FUSED_TILES="u")  # the 8-row strip kernel for both batch sizes
+    sched_env(monkeypatch, STEP_SC="0")      # and the same three-launch loop
     n, G = 1024, 64
     rng = np.random.default_rng(5)
     base = [make_glacier(n, k) for k in range(4)]
@@ -722,7 +722,7 @@ def test_inlined_mlp_fused_step_matches_per_stage_and_oracle(gpu, monkeypatch, c
     RDPK3Sp35 step, the MLP evaluated once per dual node and stage inside the stencil) against the five per-stage
     kernels and against the oracle's integrator: equal to rounding under a fixed dt, within the solver tolerance under
     step-size control.  Compile-time architectures (LM 3, 4, 5) and the run-time ones (LM 2 "gelu5", LM 6 "wide"); both tile heights."""
-    monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
+    sched_env(monkeypatch, FUSED_TILES=tiles)
     ph = O.Phys()
     widths, acts = {"default": ([2, 3, 10, 3, 1], [1, 1, 1, 2]), "w16": ([2, 16, 16, 1], [1, 1, 2]),
                     "light": ([2, 3, 1], [1, 2]), "gelu5": ([2, 5, 10, 5, 1], [3, 3, 3, 1]),
@@ -821,8 +821,8 @@ def test_Y_law_interpolation_batched_and_per_glacier_sequences_agree(gpu, monkey
     ts = [0.0, 0.5, 1.0]
     out = []
     for batch, streams in (("1", "8"), ("0", "8"), ("0", "1")):
-        monkeypatch.setenv("ODINN_INTERP_BATCH", batch)
-        monkeypatch.setenv("ODINN_INTERP_STREAMS", streams)
+        sched_env(monkeypatch, INTERP_BATCH=batch)
+        sched_env(monkeypatch, INTERP_STREAMS=streams)
         b = gpu.GlacierBatch(shapes, [100.0] * 4, T=[-5.0, -2.0, -7.0, -4.0])
         for k, (nx, ny) in enumerate(shapes):
             H0, B = O.synthetic_icecap(nx, ny, 100.0) if k != 1 else O.synthetic_valley(nx, ny, 100.0)
@@ -974,15 +974,15 @@ def test_snapshot_on_load_matches_the_post_step_launch(gpu, monkeypatch):
     the snapshot of a stop from the state it loads, finished glaciers flush theirs in the next launch.  Bit-identical
     snapshots, step counts and final states to the three-launch loop (ODINN_SNAP_ON_LOAD=0), ragged glaciers that finish
     at different launches, 7- and 8-row tiles."""
-    monkeypatch.setenv("ODINN_STEP_SC", "0")
+    sched_env(monkeypatch, STEP_SC="0")
     shapes = [(130, 97), (54, 46), (201, 103), (70, 57)]
     As = [4e-17, 1e-17, 6e-17, 2e-17]
     ts = [2010.0 + j / 24.0 for j in range(7)]
     for tiles in ("t", "u"):
-        monkeypatch.setenv("ODINN_FUSED_TILES", tiles)
+        sched_env(monkeypatch, FUSED_TILES=tiles)
         out = {}
         for mode in ("1", "0"):
-            monkeypatch.setenv("ODINN_SNAP_ON_LOAD", mode)
+            sched_env(monkeypatch, SNAP_ON_LOAD=mode)
             b = gpu.GlacierBatch(shapes, [50.0] * 4, A=As)
             for k, (nx, ny) in enumerate(shapes):
                 b.set_fields(k, *O.synthetic_valley(nx, ny, 50.0))
@@ -1017,8 +1017,8 @@ def test_strip_H_vjp_matches_the_tile_kernel(gpu, monkeypatch):
     for afield in (False, True):
         res = {}
         for strip in ("1", "0"):
-            monkeypatch.setenv("ODINN_VJPH_STRIP", strip)
-            monkeypatch.setenv("ODINN_VJPTH_STRIP", strip)  # k_vjp_theta_strip against k_vjp_theta in the same go
+            sched_env(monkeypatch, VJPH_STRIP=strip)
+            sched_env(monkeypatch, VJPTH_STRIP=strip)  # k_vjp_theta_strip against k_vjp_theta in the same go
             b = gpu.GlacierBatch(shapes, [60.0] * len(shapes), A=[4e-17] * len(shapes))
             for k, (H0, B) in enumerate(fields):
                 b.set_fields(k, H0, B)
@@ -1050,7 +1050,7 @@ def test_strip_H_vjp_matches_the_tile_kernel(gpu, monkeypatch):
         # from the default's in the last bits)
         assert np.linalg.norm(res["1"][5] - res["0"][5]) <= 5e-6 * np.linalg.norm(res["0"][5])
     # the strip kernel against the oracle directly (one glacier per batch: the per-glacier entry point runs it too)
-    monkeypatch.setenv("ODINN_VJPH_STRIP", "1")
+    sched_env(monkeypatch, VJPH_STRIP="1")
     H0, B = fields[0]
     b = gpu.GlacierBatch([shapes[0]], [60.0], A=[4e-17])
     b.set_fields(0, H0, B)
@@ -1060,7 +1060,7 @@ def test_strip_H_vjp_matches_the_tile_kernel(gpu, monkeypatch):
     want = O.vjp_H(lam, H, B, 60.0, 60.0, ph, O.Law(kind=O.LAW_CONST_A, A=Afs[0]))
     assert rel_l2(b.vjp_H(0, lam, H), want) < 1e-11
     b.close()
-    monkeypatch.setenv("ODINN_VJPTH_STRIP", "1")
+    sched_env(monkeypatch, VJPTH_STRIP="1")
     b = gpu.GlacierBatch([shapes[0]], [60.0], A=[4e-17])
     b.set_fields(0, H0, B)
     wth = O.vjp_theta(lam, H, B, 60.0, 60.0, ph, O.Law(kind=O.LAW_CONST_A, A=4e-17))

@@ -9,7 +9,7 @@ restatement, for the forward solve and both adjoints; a Prediction with step_MB 
 import numpy as np
 import pytest
 
-from conftest import rel_l2, stats_err_arrays
+from conftest import rel_l2, stats_err_arrays, sched_env
 from oracle import sia2d_oracle as O
 from test_gpu_parity import _mb
 
@@ -129,7 +129,7 @@ def test_ragged_data_times_adaptive_solve_lands_on_own_stops_only(gpu):
 def test_ragged_data_times_continuous_adjoint(gpu, monkeypatch, fused):
     """ContinuousAdjoint: H_itp interpolates the glacier's own snapshots, the loss callbacks fire at its own data times
     (gradient.jl:287, :331-365); the batch == each glacier alone == the oracle."""
-    monkeypatch.setenv("ODINN_ADJ_FUSED", fused)
+    sched_env(monkeypatch, ADJ_FUSED=fused)
     ph, shapes, own, om, gm, th_true, th0, gls, mbs = _two_glaciers(gpu)
     union = sorted(set(own[0]) | set(own[1]))
     refs, Lo, go, lam0, sto = [], [], [], [], []
@@ -275,7 +275,7 @@ def test_continuous_adjoint_with_mass_balance_steps_that_are_not_result_stops(gp
     """ContinuousAdjoint with step_MB = 1/48 yr and result stops every 1/24 yr: the reverse PeriodicCallback (gradient.jl:413-432)
     stops the reverse integrator at the in-between mass-balance times too and adds VJP_MB(lambda, H_itp(t) - MB_t), H_itp being
     the interpolant of the RESULT snapshots -- against the oracle's restatement."""
-    monkeypatch.setenv("ODINN_ADJ_FUSED", fused)
+    sched_env(monkeypatch, ADJ_FUSED=fused)
     ph = O.Phys()
     nx, ny = 64, 48
     H0, B = O.synthetic_valley(nx, ny, 50.0)

@@ -56,10 +56,7 @@ GENERIC = [dict(step_sc=0), dict(step_sc=1), dict(fused_tiles=1), dict(fused_til
 
 @pytest.mark.parametrize("sched", GENERIC, ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
 def test_every_schedule_field_selects_an_equivalent_kernel_form(gpu, monkeypatch, sched):
-    for k in ("ODINN_STEP_SC", "ODINN_FUSED_TILES", "ODINN_DHDT_STRIP", "ODINN_VJPH_STRIP", "ODINN_VJPTH_STRIP", "ODINN_SNAP_ON_LOAD",
-              "ODINN_ADJ_FUSED", "ODINN_ADJ_SKIP", "ODINN_ADJ_SEGS", "ODINN_ADJ_ROWS", "ODINN_ADJ_THETA_FUSED", "ODINN_SCHEME",
-              "ODINN_LAW_TABLE", "ODINN_INTERP_ASYNC"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("ODINN_SCHEDULE", raising=False)
     b, ts = _case(gpu)
     assert all(v == -1 for v in b.get_schedule().values())
     Ld, gd = _grads(b, ts, False)
@@ -74,11 +71,11 @@ def test_every_schedule_field_selects_an_equivalent_kernel_form(gpu, monkeypatch
     b.set_schedule()  # back to automatic: bitwise the first results again (same kernels, deterministic reductions)
     Ld3, gd3 = _grads(b, ts, False)
     assert Ld3 == Ld and np.array_equal(gd3, gd)
-    # the environment variable overrides the field
+    # the environment (ODINN_SCHEDULE="field=value,...") overrides the field
     key, val = next(iter(sched.items()))
     if key != "fused_tiles":
         b.set_schedule(**{key: val})
-        monkeypatch.setenv("ODINN_" + key.upper(), "7" if key == "adj_rows" and val == 4 else ("4" if key == "adj_rows" else str(1 - val)))
+        monkeypatch.setenv("ODINN_SCHEDULE", "dhdt_strip=1, %s=%s" % (key, "7" if key == "adj_rows" and val == 4 else ("4" if key == "adj_rows" else str(1 - val))))
         assert b.get_schedule()[key] != val
     b.close()
 
@@ -87,8 +84,7 @@ def test_every_schedule_field_selects_an_equivalent_kernel_form(gpu, monkeypatch
                                        ("Y", dict(interp_batch=0, interp_streams=1))],
                          ids=["lawgrad_wave=0", "interp_batch=0", "interp_streams=1"])
 def test_law_specific_schedule_fields(gpu, monkeypatch, law, sched):
-    for k in ("ODINN_LAWGRAD_WAVE", "ODINN_INTERP_BATCH", "ODINN_INTERP_STREAMS"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("ODINN_SCHEDULE", raising=False)
     b, ts = _case(gpu, law)
     L0, g0 = _grads(b, ts, False)
     b.close()

@@ -29,5 +29,5 @@ print("loss_grad ms", tm(lambda: b.loss_grad(ts, theta=nn.theta, reltol=1e-6)))
 print("loss_grad (theta unchanged) ms", tm(lambda: b.loss_grad(ts, reltol=1e-6)))
 os.environ["ODINN_PROFILE_HOST"] = "1"
 for mode in ("0", "1"):
-    os.environ["ODINN_ADJ_FUSED"] = mode
+    os.environ["ODINN_SCHEDULE"] = "adj_fused=" + mode
     print("continuous loss_grad ms (ODINN_ADJ_FUSED=%s)" % mode, tm(lambda: b.loss_grad_continuous(ts, theta=nn.theta, reltol=1e-6), n=2), b.last_stats_rev[0].naccept, b.loss_grad_continuous(ts, theta=nn.theta, reltol=1e-6)[0])

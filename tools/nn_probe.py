@@ -4,7 +4,7 @@ import sys, os, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) > 2:  # child: scheme, law
-    os.environ["ODINN_SCHEME"] = sys.argv[1]
+    os.environ["ODINN_SCHEDULE"] = "scheme=" + sys.argv[1]
     import numpy as np
     import _odinn_import
     odinn = _odinn_import.load()

@@ -55,7 +55,7 @@ for spec in args:
     row = {"case": spec + (":gridded" if gridded else "")}
     ref = None
     for sc in ("0", "1"):
-        os.environ["ODINN_ADJ_SC"] = sc
+        os.environ["ODINN_SCHEDULE"] = "adj_sc=" + sc
         b, ts, th0 = build(spec)
         b.loss_grad_continuous(ts, theta=th0, reltol=1e-8)
         b.sync()

@@ -3,7 +3,7 @@
 n=${1:-1024}; G=${2:-16}; m=${3:-2}
 R=${GRAFT_REPO_ROOT:-$PWD}; mkdir -p $R/gpurun_out/ut
 cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/utp
-ODINN_ADJ_UT_FUSED=$m rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/utp -- python $R/tools/workflow_probe.py U $n $G scaled > $R/gpurun_out/ut/probe_${n}_${G}_m$m.txt 2>&1
+ODINN_SCHEDULE=adj_ut_fused=$m rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/utp -- python $R/tools/workflow_probe.py U $n $G scaled > $R/gpurun_out/ut/probe_${n}_${G}_m$m.txt 2>&1
 f=$(find /tmp/utp -name "*kernel_stats.csv" | head -1); cp $f $R/gpurun_out/ut/kstats_${n}_${G}_m$m.csv
 python3 - <<PY
 import csv

@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 N=${1:-512}; G=${2:-8}
 timeout 900 python -m pytest tests/test_gpu_law_table.py -x -q 2>&1 | tail -30 > gpurun_out/ytab_test.txt
-(echo "== network"; ODINN_LAW_TABLE=0 ODINN_INTERP_ASYNC=0 timeout 900 python tools/workflow_probe.py Y $N $G; echo "== table"; timeout 900 python tools/workflow_probe.py Y $N $G) > gpurun_out/ytab_probe.txt 2>&1
+(echo "== network"; ODINN_SCHEDULE=law_table=0,interp_async=0 timeout 900 python tools/workflow_probe.py Y $N $G; echo "== table"; timeout 900 python tools/workflow_probe.py Y $N $G) > gpurun_out/ytab_probe.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_ytab
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ytab -- python $R/tools/workflow_probe.py Y $N $G > /tmp/p_ytab.log 2>/dev/null
