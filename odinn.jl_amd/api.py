@@ -1347,15 +1347,16 @@ def V_from_H(simulation: _Simulation, H, t, theta=None, glacier_idx: int = 0):
     return Vx, Vy, np.sqrt(Vx ** 2 + Vy ** 2)
 
 
-def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion, _loss_only: bool = False):
+def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion, _loss_only: bool = False, _grad=None):
     """SIA2D_grad!(dθ, θ, simulation): loss and gradient over ALL glaciers of ALL ranks
     (gradient.jl:6-31).  Returns the loss; dθ is written in place.  θ = [law parameters, IC matrices].
-    (_loss_only: loss_iceflow_transient's forward-only evaluation of the same loss.)"""
+    (_loss_only / _grad: loss_iceflow_transient's forward-only evaluation of the same loss under an adjoint of its own -- passed in,
+    the simulation's parameters are not touched.)"""
     b = simulation.batch()
     model = simulation.model
     law = model.iceflow.law
     p = simulation.parameters
-    grad = p.UDE.grad
+    grad = p.UDE.grad if _grad is None else _grad
     _, w_data, regs = _split_loss(p.UDE.empirical_loss_function)
     if isinstance(grad, ContinuousAdjoint):  # gradient.jl:276
         def loss_grad(*a, **kw):
@@ -1480,15 +1481,19 @@ def SIA2D_grad_b(dtheta: np.ndarray, theta: np.ndarray, simulation: Inversion, _
 
 def loss_iceflow_transient(theta: np.ndarray, simulation: Inversion) -> float:
     """loss_iceflow_transient(θ, simulation, pmap) (inversion_utils.jl:287-296): the loss of SIA2D_grad_b(θ) alone -- forward
-    solves, the empirical loss with its weights, the time-aggregated and regularisation terms -- whatever adjoint is configured
-    (the function the reference's test_grad_finite_diff differences, test/test_grad_loss.jl:262-265)."""
-    p = simulation.parameters
-    saved = p.UDE.grad
-    p.UDE.grad = DummyAdjoint(grad_function=lambda th: np.zeros_like(th), VJP_method=DiscreteVJP())
+    solves, the empirical loss with its weights and the regularisation terms (the function the reference's test_grad_finite_diff
+    differences, test/test_grad_loss.jl:262-265).  Losses without a time-aggregated term are evaluated forward-only; with one
+    (LossDhdt / velocity-regularisation terms, which only the gradient drivers evaluate) the DiscreteAdjoint driver runs for its loss,
+    whatever adjoint the simulation is configured with -- the loss VALUE does not depend on the adjoint.  Re-entrant: the simulation's
+    parameters are not modified and the batch's VJP method is restored."""
+    b = simulation.batch()
+    vjp_saved = getattr(b, "vjp_method", None)
     try:
-        return SIA2D_grad_b(np.zeros_like(np.asarray(theta, dtype=np.float64)), theta, simulation, _loss_only=True)
+        return SIA2D_grad_b(np.zeros_like(np.asarray(theta, dtype=np.float64)), theta, simulation, _loss_only=True,
+                            _grad=DummyAdjoint(grad_function=lambda th: np.zeros_like(th), VJP_method=DiscreteVJP()))
     finally:
-        p.UDE.grad = saved
+        if vjp_saved is not None:
+            b.set_vjp_method(vjp_saved)
 
 
 def _run_prediction(sim: Prediction):

@@ -155,6 +155,7 @@ class GlacierBatch:
         self.law_kind = L.LAW_CONST_A
         self.tstops = None
         self._A_field = set()  # glaciers that carry a dual-grid A field (odinn_set_A_field)
+        self.vjp_method = L.VJP_DISCRETE  # the library's default (odinn_set_vjp_method)
 
     # -- lifetime -------------------------------------------------------------------
     def close(self):
@@ -475,6 +476,7 @@ class GlacierBatch:
     def set_vjp_method(self, method=L.VJP_DISCRETE):
         """DiscreteVJP (default) or ContinuousVJP stencil for vjp_H and both adjoints (VJPTypes.jl:29-50)."""
         L.check(L.lib().odinn_set_vjp_method(self._h, int(method)))
+        self.vjp_method = int(method)  # (what is in effect: api.loss_iceflow_transient restores it)
 
     def tikhonov(self, a, dx, dy, mask=None):
         """(loss, grad) of TikhonovRegularization(:laplacian) on one field (Regularization.jl:92-126)."""
