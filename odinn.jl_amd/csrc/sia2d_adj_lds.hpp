@@ -2,7 +2,7 @@
 // does not fit the register strips of k_adj_fused_strip: the U law of target :D through its bi-quintic table (LM_UTAB).
 //
 // The per-stage path (k_adj_stage<S, LM>) moves 72 B/cell per stage -- 360 B/cell per reverse step -- and its time is HBM time plus
-// VALU issue time.  The strip form of the fused step (k_adj_fused_strip<..., UT>) lost by 3 x: the node's
+// VALU issue time (docs/HISTORY.md, round 5 item 9).  The strip form of the fused step (k_adj_fused_strip<..., UT>) lost by 3 x: the node's
 // 36 coefficients, two quintic collapses and two Taylor shifts do not fit beside seven rows of state.  Here a workgroup owns a
 // 54 x FOYV output tile like the forward k_rk_fused<LM>: its 64 x (FOYV + 10) halo region of {H_j, dH}, B and lambda is loaded ONCE
 // (40 B/cell), every thread keeps the 3S*+ registers of its cells, and each stage

@@ -1006,7 +1006,7 @@ __device__ __forceinline__ double ytab_eval_acc(const double* __restrict__ tab, 
   // `beyond` collects the lanes whose node lies beyond the table (or is NaN): a ballot, i.e. scalar arithmetic -- NO divergent
   // branch.  The branch `if (beyond) *over = 1` that used to sit here, inside the register-pressured stage code of the strip kernels,
   // is what ROCm 7.2's backend miscompiled (a live-range-split VGPR copy / spill store placed in the join block AHEAD of the
-  // `s_or_b64 exec` that restores EXEC: fuzz seed 24379, DESIGN section 0.3; tools/exec_lint.py checks every built kernel for it).
+  // `s_or_b64 exec` that restores EXEC: fuzz seed 24379, DESIGN section 0.1 item 1; tools/exec_lint.py checks every built kernel for it).
   double x = Hb * inv_h;
   const bool out = !(x < (double)ni);
   beyond |= __builtin_amdgcn_ballot_w64(out);

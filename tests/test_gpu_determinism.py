@@ -1,7 +1,7 @@
 """GPU: every self-controlled kernel instantiation gives the SAME BITS in separate processes.
 
 Round 5 left one product kernel (k_rk_fused_strip<SC, YT>, the Y law's table in the self-controlled forward loop) that took 15 / 16 /
-17 steps on fuzz seed 24379 where everything else takes 11, varying from process to process.  Root cause (DESIGN section 0.3): ROCm 7.2's
+17 steps on fuzz seed 24379 where everything else takes 11, varying from process to process.  Root cause (DESIGN section 0.1 item 1): ROCm 7.2's
 backend placed the register allocator's copy of a strip row's bed elevation AHEAD of the `s_or_b64 exec` that ends the divergent branch
 of the table-overflow flag; the lanes that had not left the table went on with a stale register whose upper half was never initialised
 -- hence "from process to process".  The flag is collected without a branch now and `tools/exec_lint.py` checks every built kernel.

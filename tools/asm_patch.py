@@ -1,6 +1,6 @@
 """Edit ONE kernel of a gfx950 assembly listing: python tools/asm_patch.py in.s out.s KERNEL_PREFIX MODE
 MODE: dpp (s_nop 7 before every DPP move), lane (s_nop 7 around v_readlane / v_writelane), scratch (s_waitcnt vmcnt(0) + s_nop around
-every scratch access), all.  Used to test hazard hypotheses on a miscompiled kernel without recompiling it (DESIGN 0.3)."""
+every scratch access), all.  Used to test hazard hypotheses on a miscompiled kernel without recompiling it (DESIGN section 0.1 item 1)."""
 import sys
 src, dst, prefix, mode = sys.argv[1:5]
 out = []; inside = False; n = 0

@@ -1,4 +1,4 @@
-"""ISA lint for a miscompile of ROCm 7.2's AMDGPU backend (DESIGN section 0.3, `profiles/r06/sc_yt_rootcause.md`).
+"""ISA lint for a miscompile of ROCm 7.2's AMDGPU backend (DESIGN section 0.1 item 1, `profiles/r06/sc_yt_rootcause.md`).
 
 After a divergent `if` the join block restores EXEC with `s_or_b64 exec, exec, s[a:b]`.  Vector instructions the backend placed in
 that block BEFORE the restore -- a VGPR copy of the register allocator's live-range splitting, a spill store -- run under the branch's

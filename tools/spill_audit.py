@@ -1,5 +1,5 @@
 """Per kernel of gfx950 assembly listings (hipcc -S --cuda-device-only): VGPR spills (scratch bytes) and SGPR spills into VGPR lanes
-(v_writelane / v_readlane counts).  Kernels with BOTH are listed first: the combination miscompiled k_rk_fused_strip<SC, YT> (DESIGN 0.3).
+(v_writelane / v_readlane counts).  Kernels with BOTH are listed first: the combination miscompiled k_rk_fused_strip<SC, YT> (DESIGN section 0.1 item 1).
     python tools/spill_audit.py file.s [...]"""
 import re, sys, subprocess
 rows = []
