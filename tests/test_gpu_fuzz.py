@@ -661,7 +661,9 @@ def test_random_seams_match_the_oracle(gpu, monkeypatch, seed):
         close(lawv.ravel(), np.atleast_1d(O.law_value(law, ph, O.avg(np.maximum(H, 0.0)), _gradS(H, B, dx, dy))).ravel(), 1e-12, "eval_law")
 
 
-@pytest.mark.parametrize("seed", _seeds())
+# (seeds 49 and 78 of the fixed slice cost the numpy CHECKER 57 s and 84 s -- reverse solves of several thousand steps on the CPU; the
+#  device needs a fraction of a second.  They stay in the exploration runs, ODINN_FUZZ_SEEDS=a:b, and in the other three tests.)
+@pytest.mark.parametrize("seed", [s_ for s_ in _seeds() if s_ not in (49, 78) or os.environ.get("ODINN_FUZZ_SEEDS")])
 def test_random_batch_time_aggregated_terms_match_the_oracle(gpu, monkeypatch, seed):
     """The draw of the first test with LossH and a random subset of the time-aggregated terms of a MultiLoss: LossDhdt
     (TimeAggregatedLosses.jl:38-113), LossAvgV (:115-258, :xy / :abs), VelocityRegularization (Regularization.jl:64-79,
