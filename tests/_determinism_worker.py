@@ -71,6 +71,9 @@ def reverse(law, sched):
         if law == "A":
             om = O.default_nn(1, light=False, post_kind=O.POST_AFFINE, post_lo=ph.minA, post_hi=ph.maxA)
             th = om.init_theta(np.random.default_rng(42)); kind = O.LAW_NN_A_SCALAR
+        elif law == "U":  # LawU as the reference's tests scale it: the table follows it (k_adj_fused_lds in the reverse solve)
+            om = O.MLP([2, 3, 10, 3, 1], [1, 1, 1, 2], [(0.0, 300.0), (0.0, 0.5)], O.POST_EXPMAX, 0.0, 50.0)
+            th = om.init_theta(np.random.default_rng(9)); kind = O.LAW_NN_U
         else:
             om = O.MLP([2, 3, 10, 3, 1], [1, 1, 1, 2], [(-25.0, 0.0), (0.0, 500.0)], O.POST_EXPMAX, 0.0, ph.maxA)
             th = om.init_theta(np.random.default_rng(9)); kind = O.LAW_NN_Y
@@ -88,7 +91,7 @@ def reverse(law, sched):
 CASES = {
     "fwdA": lambda s: forward("A", s), "fwdAg": lambda s: forward("Ag", s), "fwdY": lambda s: forward("Y", s),
     "fwdYsq": lambda s: forward("Y", s, dxdy=False), "fwdYskip": lambda s: forward("Y", s, dense=0),
-    "revA": lambda s: reverse("A", s), "revY": lambda s: reverse("Y", s),
+    "revA": lambda s: reverse("A", s), "revY": lambda s: reverse("Y", s), "revU": lambda s: reverse("U", s),
 }
 
 if __name__ == "__main__":

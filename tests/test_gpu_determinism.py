@@ -50,8 +50,15 @@ def test_self_controlled_reverse_step_is_bit_deterministic_across_processes(gpu,
     assert three["loss"] == runs[0]["loss"] and three["grad"] == runs[0]["grad"] and three["lambda0"] == runs[0]["lambda0"], (case, rows)
 
 
+def test_lds_tile_reverse_step_of_the_U_law_is_bit_deterministic_across_processes(gpu):
+    """k_adj_fused_lds<LM_UTAB> (the U law's reverse step on LDS tiles, its whole table staged in LDS; three launches per step)"""
+    runs = [_run("revU", adj_ut_fused=2) for _ in range(N_PROC)]
+    assert all(r == runs[0] for r in runs[1:]), runs
+    assert runs[0]["rev_steps"] and all(n > 0 for n, _ in runs[0]["rev_steps"])
+
+
 def test_default_schedules_are_bit_deterministic_across_processes(gpu):
     """what a user gets without touching the schedule: the automatic choice (self-controlled for these small batches)"""
-    for case in ("fwdA", "fwdY", "revA", "revY"):
+    for case in ("fwdA", "fwdY", "revA", "revY", "revU"):
         runs = [_run(case) for _ in range(3)]
         assert all(r == runs[0] for r in runs[1:]), (case, runs)
