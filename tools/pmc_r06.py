@@ -66,7 +66,12 @@ for tag, key, pat, tiles, bpc in (("fused_step_nnA", "fused_step_nn_gridded", "k
         e["hbm_bytes_per_launch"] = (2.0 * fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024.0
         e["hbm_bytes_per_cell"] = e["hbm_bytes_per_launch"] / cells
         e["traffic_over_algorithmic"] = e["hbm_bytes_per_cell"] / bpc
+        e["ratio"] = e["traffic_over_algorithmic"]
+    e["valu_insts_per_useful_cell_stage"] = 64.0 * f.get("SQ_INSTS_VALU", 0.0) / (5.0 * cells)
+    e["fma_share_of_f64_insts"] = fma / max(add + mul + fma + tr, 1.0)
     out[key] = e
+    if key == "adj_fused_step_constA":
+        out["adj_fused_step_64"] = e   # (the name bench.py's roofline_adjoint block reads)
 for tag, key, pat, bpc in (("dhdt_nnA", "dhdt_nn_gridded_64", "k_dhdt", 32.0), ("rk_stage2_const", "rk_stage2_64", "k_rk_stage", 56.0)):
     fe, names = med(tag + "_fetch", pat)
     wr, _ = med(tag + "_write", pat)
