@@ -5,5 +5,5 @@ for env in "ODINN_SCHEDULE=scheme=1" "ODINN_SCHEDULE=step_sc=0" "ODINN_SCHEDULE=
            "ODINN_SCHEDULE=law_table=0" "ODINN_SCHEDULE=interp_async=0" "ODINN_SCHEDULE=adj_sc=0" "ODINN_SCHEDULE=adj_sc=1" "ODINN_SCHEDULE=adj_rows=2" \
            "ODINN_SCHEDULE=adj_ut_fused=0" "ODINN_INTERP_SELECT=0" "ODINN_UTAB_LEVEL=3" "ODINN_UT_LDS=0"; do
   echo "== $env"
-  env $env python -m pytest tests -m gpu -q -x -n 6 --deselect tests/test_gpu_schedule.py --deselect tests/test_gpu_determinism.py 2>&1 | grep -E "passed|failed|error" | tail -2
+  env $env python -m pytest tests -m gpu -q -x -n 6 --deselect tests/test_gpu_schedule.py --deselect tests/test_gpu_determinism.py 2>&1 | grep -E "^FAILED|^ERROR|passed|failed" | cut -c1-300 | tail -6
 done
