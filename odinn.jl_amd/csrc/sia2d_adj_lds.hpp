@@ -46,6 +46,9 @@ __device__ __forceinline__ void adj_lds_stage(const GDev& g, const LawDev& L, co
   }
   __syncthreads();
   // ---- 2. nodes needed by region_S: columns [S-1, 63-S], rows [S-1, FRY-1-S]; node (c, r) = north-east corner of cell (c, r)
+  //         (measured and rejected: TWO nodes of the thread's column inside one divergent region, so that the scheduler can interleave the two
+  //          bi-quintic evaluations -- 256 VGPRs with 13-37 spilled, both nodes evaluated wherever one of them has ice: 1.46 against 1.32 ms
+  //          at 16 x 1024^2, 5.18 against 4.65 ms at 64 x 1024^2 with the shortcut)
   const bool ncol = lane >= S - 1 && lane <= FRX - 1 - S;
 #pragma unroll 1
   for (int m = 0; m < FSLOT; ++m) {
