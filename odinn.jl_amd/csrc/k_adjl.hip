@@ -2,14 +2,9 @@
 #include "launch.hpp"
 #include "sia2d_adj_lds.hpp"
 namespace odinn {
-// rows: 22 = the 54 x 22 tile table (Fv), 8 = the 54 x 8 latency tiles (Fs); tilesF / partF of A belong to that table
-void launch_adj_fused_lds(int nblk, int skip, int foy, hipStream_t st, Pools P, LawDev L, AdjFusedArgs A) {
-  if (foy == FOYS) {
-    if (skip) hipLaunchKernelGGL((k_adj_fused_lds<LM_UTAB, true, FOYS>), dim3(nblk), dim3(FNT), 0, st, P, L, A);
-    else hipLaunchKernelGGL((k_adj_fused_lds<LM_UTAB, false, FOYS>), dim3(nblk), dim3(FNT), 0, st, P, L, A);
-  } else {
-    if (skip) hipLaunchKernelGGL((k_adj_fused_lds<LM_UTAB, true, FOYT4>), dim3(nblk), dim3(FNT), 0, st, P, L, A);
-    else hipLaunchKernelGGL((k_adj_fused_lds<LM_UTAB, false, FOYT4>), dim3(nblk), dim3(FNT), 0, st, P, L, A);
-  }
+// 54 x 22 output tiles (the table Fv of the strip kernels' 4-row form: tilesF / partF of A belong to it), LNW = 12 waves per workgroup
+void launch_adj_fused_lds(int nblk, int skip, hipStream_t st, Pools P, LawDev L, AdjFusedArgs A) {
+  if (skip) hipLaunchKernelGGL((k_adj_fused_lds<LM_UTAB, true, FOYT4, LNW>), dim3(nblk), dim3(64 * LNW), 0, st, P, L, A);
+  else hipLaunchKernelGGL((k_adj_fused_lds<LM_UTAB, false, FOYT4, LNW>), dim3(nblk), dim3(64 * LNW), 0, st, P, L, A);
 }
 }  // namespace odinn

@@ -37,7 +37,7 @@ constexpr int DHDT_OX = 62, DHDT_OY = 62;  // output tile of k_dhdt_strip (sia2d
 
 // k_adjf.hip, law mode 0 only
 void launch_adj_fused_strip(int nblk, int afield, int skip, int rows, hipStream_t st, Pools P, AdjFusedArgs A, int sc = 0);
-void launch_adj_fused_lds(int nblk, int skip, int foy, hipStream_t st, Pools P, LawDev L, AdjFusedArgs A);  // k_adjl.hip
+void launch_adj_fused_lds(int nblk, int skip, hipStream_t st, Pools P, LawDev L, AdjFusedArgs A);  // k_adjl.hip
 void launch_vjp_H_strip(int mode, int afield, int nblk, hipStream_t st, Pools P, const int4* tilesD, AdjArgs A);
 void launch_vjp_theta_strip(int gacc, int itp, int nblk, hipStream_t st, Pools P, const int4* tilesD, ThArgs A);
 

@@ -18,22 +18,22 @@
 
 namespace odinn {
 
-template <int S, int LM, int FOYV>
+template <int S, int LM, int FOYV, int NWV>
 __device__ __forceinline__ void adj_lds_stage(const GDev& g, const LawDev& L, const Pools& P, int gi, int gi0, int gj0, int w, int lane,
                                                double dt, double sw, double2 (*sHS)[FLD], double (*sL)[FLD], double2 (*sCa)[FLD],
-                                               double2 (*sCb)[FLD], double (&u)[(FOYV + 2 * FH + FNW - 1) / FNW],
-                                               double (&tmp)[(FOYV + 2 * FH + FNW - 1) / FNW], const double (&up)[(FOYV + 2 * FH + FNW - 1) / FNW],
-                                               double (&E)[(FOYV + 2 * FH + FNW - 1) / FNW], const double (&ha)[(FOYV + 2 * FH + FNW - 1) / FNW],
-                                               const double (&dh)[(FOYV + 2 * FH + FNW - 1) / FNW], const double (&bb)[(FOYV + 2 * FH + FNW - 1) / FNW],
+                                               double2 (*sCb)[FLD], double (&u)[(FOYV + 2 * FH + NWV - 1) / NWV],
+                                               double (&tmp)[(FOYV + 2 * FH + NWV - 1) / NWV], const double (&up)[(FOYV + 2 * FH + NWV - 1) / NWV],
+                                               double (&E)[(FOYV + 2 * FH + NWV - 1) / NWV], const double (&ha)[(FOYV + 2 * FH + NWV - 1) / NWV],
+                                               const double (&dh)[(FOYV + 2 * FH + NWV - 1) / NWV], const double (&bb)[(FOYV + 2 * FH + NWV - 1) / NWV],
                                                const UtabTile ut) {
-  constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + FNW - 1) / FNW;
+  constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + NWV - 1) / NWV;
   const bool inx = gi >= 0 && gi < g.nx, intx = gi >= 1 && gi <= g.nx - 2;
   // ---- 1. the stage's tiles: H_itp(tau_S) = H_j + s_S (H_j+1 - H_j) (gradient.jl:287: linear in the forward snapshots), lambda masked
   //         to the interior (adjoint.jl:52-97 acts on inn(lambda)); cells outside the grid hold zeros
   double hcS[FSLOT];
 #pragma unroll
   for (int m = 0; m < FSLOT; ++m) {
-    const int r = w + FNW * m;
+    const int r = w + NWV * m;
     hcS[m] = 0.0;
     if (r < FRY) {
       const int gj = gj0 + r;
@@ -52,7 +52,7 @@ __device__ __forceinline__ void adj_lds_stage(const GDev& g, const LawDev& L, co
   const bool ncol = lane >= S - 1 && lane <= FRX - 1 - S;
 #pragma unroll 1
   for (int m = 0; m < FSLOT; ++m) {
-    const int r = w + FNW * m;
+    const int r = w + NWV * m;
     if (r >= S - 1 && r <= FRY - 1 - S) {  // wave-uniform
       double k[4] = {0.0, 0.0, 0.0, 0.0};
       if (ncol) vjpH_node<LM, 0, FLD>(g, L, P, sHS, sL, gi0 + 1, gj0 + 1, lane, r, k, ut);
@@ -67,7 +67,7 @@ __device__ __forceinline__ void adj_lds_stage(const GDev& g, const LawDev& L, co
   const bool ccol = lane >= S && lane <= FRX - 1 - S;
 #pragma unroll
   for (int m = 0; m < FSLOT; ++m) {
-    const int r = w + FNW * m;
+    const int r = w + NWV * m;
     if (r >= S && r <= FRY - 1 - S) {
       const int gj = gj0 + r;
       if (ccol && inx && gj >= 0 && gj < g.ny) {
@@ -96,21 +96,27 @@ __device__ __forceinline__ void adj_lds_stage(const GDev& g, const LawDev& L, co
   //  pass overwrites sCa / sCb behind its own first barrier, which every cell-pass read of this stage precedes)
 }
 
-// FOYV: 22 (the 54 x 22 tile table Fv of the strip kernels' 4-row form: 116 KB of LDS, one workgroup per CU) or FOYS = 8 (the
-// latency tiles of the forward k_rk_fused: 66 KB)
-template <int LM, bool SKIP, int FOYV>
-__global__ __launch_bounds__(FNT, 2) void k_adj_fused_lds(Pools P, LawDev L, AdjFusedArgs A) {
-  constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + FNW - 1) / FNW;
+// FOYV = 22: the 54 x 22 tile table Fv of the strip kernels' 4-row form, 117 KB of tiles + 36 KB of table = one workgroup per CU.
+// NWV waves per workgroup, rows dealt round-robin.  Measured at 8 / 12 / 16 waves (184 / 167 / 128 VGPRs, the last with 49 spilled):
+// 1.31 / 1.19 / 1.48 ms per reverse step at 16 x 1024^2, 4.62 / 4.19 / 5.33 ms at 64 x 1024^2 with the shortcut -- three waves per
+// SIMD hide more of the node's dependent fp64 chains than two, and 32 rows over 12 waves leave three slots of state per thread, not four.
+constexpr int LNW = 12;
+template <int LM, bool SKIP, int FOYV, int NWV>
+__global__ __launch_bounds__(64 * NWV, 1) void k_adj_fused_lds(Pools P, LawDev L, AdjFusedArgs A) {
+  constexpr int FRY = FOYV + 2 * FH, FSLOT = (FRY + NWV - 1) / NWV;
   __shared__ double2 sHS[FRY][FLD];
   __shared__ double sL[FRY][FLD];
   __shared__ double2 sCa[FRY][FLD];
   __shared__ double2 sCb[FRY][FLD];
-  __shared__ double red[FNW];
+  __shared__ double red[NWV];
   // the U law's WHOLE table where it is the coarsest level (16 x 8 bi-quintic patches, 36 KB: what ytab_refresh picks for a law as smooth as
   // the reference's scaled LawU) -- the LDS the tiles leave free on a CU that holds one workgroup anyway; every patch gather of the
   // five stages is then an LDS read (the vector L1 returns data in order: a table load that hits still queues behind the misses)
   constexpr int UT_LDS_PATCHES = LM == LM_UTAB ? 128 : 0;
-  __shared__ double2 sTab[UT_LDS_PATCHES > 0 ? 18 * UT_LDS_PATCHES : 1];
+  // (19 double2 per patch, not 18: neighbouring patches along Hbar are 8 patches = 8 x 72 words = a multiple of the 64 banks apart at 18,
+  //  so that a wave whose nodes straddle two of them -- the common case -- reads every coefficient twice)
+  constexpr int UT_PST = 19;
+  __shared__ double2 sTab[UT_LDS_PATCHES > 0 ? UT_PST * UT_LDS_PATCHES : 1];
   const int4 t4 = A.tilesF[blockIdx.x];
   const GState* gs = P.gs + t4.x;
   if (gs->done) return;
@@ -121,8 +127,8 @@ __global__ __launch_bounds__(FNT, 2) void k_adj_fused_lds(Pools P, LawDev L, Adj
     const int np = L.utab_nh * L.utab_ns;
     if (np <= UT_LDS_PATCHES && !L.ut_nolds) {  // (block-uniform; published by the first barrier of stage 1)
       const double2* __restrict__ tg = reinterpret_cast<const double2*>(L.utab);
-      for (int k = threadIdx.x; k < 18 * np; k += FNT) sTab[k] = tg[k];
-      ut.lds = sTab; ut.ih0 = 0; ut.is0 = 0; ut.nsr = L.utab_ns;
+      for (int k = threadIdx.x; k < 18 * np; k += 64 * NWV) sTab[k + k / 18] = tg[k];
+      ut.lds = sTab; ut.ih0 = 0; ut.is0 = 0; ut.nsr = L.utab_ns; ut.pst = UT_PST;
     }
   }
   const double dt = gs->dt;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(FNT, 2) void k_adj_fused_lds(Pools P, LawDev L, Adj
   bool ice = false;
 #pragma unroll
   for (int m = 0; m < FSLOT; ++m) {
-    const int r = w + FNW * m, gj = gj0 + r;
+    const int r = w + NWV * m, gj = gj0 + r;
     double l = 0.0, h0 = 0.0, d0 = 0.0, b = 0.0;
     if (r < FRY && inx && gj >= 0 && gj < g.ny) {
       const unsigned id = (unsigned)(gi + g.nx * gj);
@@ -179,17 +185,17 @@ __global__ __launch_bounds__(FNT, 2) void k_adj_fused_lds(Pools P, LawDev L, Adj
     }
   }
   if (run) {
-    adj_lds_stage<1, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[0], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
-    adj_lds_stage<2, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[1], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
-    adj_lds_stage<3, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[2], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
-    adj_lds_stage<4, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[3], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
-    adj_lds_stage<5, LM, FOYV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[4], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
+    adj_lds_stage<1, LM, FOYV, NWV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[0], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
+    adj_lds_stage<2, LM, FOYV, NWV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[1], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
+    adj_lds_stage<3, LM, FOYV, NWV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[2], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
+    adj_lds_stage<4, LM, FOYV, NWV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[3], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
+    adj_lds_stage<5, LM, FOYV, NWV>(g, L, P, gi, gi0, gj0, w, lane, dt, a.sitp[4], sHS, sL, sCa, sCb, u, tmp, up, E, ha, dh, bb, ut);
   }
   // ---- output tile = region_5: lambda' from the registers, embedded error partial (k_adj_stage<5>'s expression)
   double errsq = 0.0;
 #pragma unroll
   for (int m = 0; m < FSLOT; ++m) {
-    const int r = w + FNW * m, gj = gj0 + r;
+    const int r = w + NWV * m, gj = gj0 + r;
     if (r >= FH && r <= FRY - 1 - FH && ocol && gj < g.ny) {
       dst[(unsigned)(gi + g.nx * gj)] = u[m];
       const double err = (u[m] - up[m]) - E[m];
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(FNT, 2) void k_adj_fused_lds(Pools P, LawDev L, Adj
   if (threadIdx.x == 0) {
     double sum = 0.0;
 #pragma unroll
-    for (int k = 0; k < FNW; ++k) sum += red[k];
+    for (int k = 0; k < NWV; ++k) sum += red[k];
     A.partF[t4.w] = sum;
   }
 }

@@ -1080,8 +1080,9 @@ struct UtabTile {
   bool pre;
   int slot;
   double u, v;
+  int pst;  // double2 per patch in `lds`: 18, or 19 where the whole table is resident (k_adj_fused_lds)
 };
-#define ODINN_UT_NONE UtabTile{nullptr, 0, 0, 0, false, 0, 0.0, 0.0}
+#define ODINN_UT_NONE UtabTile{nullptr, 0, 0, 0, false, 0, 0.0, 0.0, 18}
 // patch (ih, is) and the patch coordinates (u, v) of a node; a node beyond the table takes the table's edge and raises the flag
 __device__ __forceinline__ void utab_index(const LawDev& L, double Hb, double gS, int& ih, int& is, double& u, double& v) {
   double xh = Hb * L.ut_inv_h, xs = gS * L.ut_inv_s;
@@ -1098,7 +1099,7 @@ __device__ __forceinline__ double utab_eval(const LawDev& L, double Hb, double g
   if (ut.pre) { slot = ut.slot; u = ut.u; v = ut.v; }
   else {
     utab_index(L, Hb, gS, ih, is, u, v);
-    slot = ut.lds ? 18 * ((ih - ut.ih0) * ut.nsr + (is - ut.is0)) : ih * L.utab_ns + is;
+    slot = ut.lds ? ut.pst * ((ih - ut.ih0) * ut.nsr + (is - ut.is0)) : ih * L.utab_ns + is;
   }
   // (explicit address spaces: with generic pointers the compiler folds the two branches into ONE set of flat loads on a selected
   //  pointer, and a flat load of LDS data queues in the vector memory pipeline like the global one it was meant to avoid)
