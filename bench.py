@@ -579,7 +579,7 @@ def main():
                     "discrete_adjoint": G_job / tud, "continuous_adjoint": G_job / tuc,
                     "table_usable": info["usable"], "table_patches": info["n_intervals"], "table_max_rel_dev_from_network": info["max_rel_dev"],
                     "sample": "as bench_workload, but the U law (86 parameters, prescale (0, 300) x (0, 0.5), U <= 50 m/yr) through its table; "
-                              "ContinuousAdjoint: five staged reverse launches per step" +
+                              "ContinuousAdjoint: one fused LDS-tile reverse launch per step" +
                               (f", {revu.naccept}+{revu.nreject} reverse RK steps" if revu else "") + ", theta-VJP by backprop at every node",
                 }
             except Exception as e:

@@ -45,11 +45,11 @@ def _seeds():
     if e:
         a, b = e.split(":")
         return list(range(int(a), int(b)))
-    # the fixed slice the driver's `pytest -m gpu` sees: 230 consecutive draws per test plus every seed that ever found a defect on
+    # the fixed slice the driver's `pytest -m gpu` sees: 236 consecutive draws per test plus every seed that ever found a defect on
     # either side (tests/README.md lists what each one found): subnormal thickness at the margin / `:Linear` knots (1746, 2450, 3206,
     # 3351), a step count that is not a property of the algorithm (19220), the three stuck reverse solves (19681, 22159, 22782), the
     # stuck ill-conditioning probe (23649), a solve at the resolution of tau (23721), the miscompiled self-controlled Y-table step (24379)
-    return list(range(230)) + NAMED_SEEDS
+    return list(range(236)) + NAMED_SEEDS
 
 
 

@@ -1,5 +1,6 @@
 """The reference's DEFAULT gradient (ContinuousAdjoint, A(T) law) on the bench workload, G x n^2 (default 64 x 1024^2): wall clock, the host
-phases (ODINN_PROFILE_HOST), and -- under rocprofv3 --kernel-trace --stats -- the kernel shares.  python tools/cont_default_probe.py [n G]"""
+phases (ODINN_PROFILE_HOST), and -- under rocprofv3 --kernel-trace --stats -- the kernel shares.  python tools/cont_default_probe.py [n G law]
+law: A (default), Y (bench.json's bench_workload_Y_law) or U (bench_workload_U_law)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,11 +17,22 @@ for k, (H0, B, A) in enumerate(gl):
 ph = odinn.PhysicalParameters()
 nn = odinn.NeuralNetwork(odinn.Parameters(), seed=666)
 mlp = odinn.MLPSpec(nn.widths, nn.acts, None, odinn.POST_AFFINE, ph.minA, ph.maxA)
-b.set_law(odinn.LAW_NN_A_SCALAR, mlp, nn.theta)
+law = sys.argv[3] if len(sys.argv) > 3 else "A"
+theta = nn.theta
+if law == "A":
+    b.set_law(odinn.LAW_NN_A_SCALAR, mlp, nn.theta)
+elif law == "Y":
+    m = odinn.MLPSpec([2, 3, 10, 3, 1], [odinn.ACT_SOFTPLUS] * 3 + [odinn.ACT_SIGMOID], [(-25.0, 0.0), (0.0, 500.0)], odinn.POST_EXPMAX, 0.0, ph.maxA)
+    theta = np.random.default_rng(1234).uniform(-0.5, 0.5, m.n_params)
+    b.set_law(odinn.LAW_NN_Y, m, theta)
+else:
+    m = odinn.MLPSpec([2, 3, 10, 3, 1], [odinn.ACT_SOFTPLUS] * 3 + [odinn.ACT_SIGMOID], [(0.0, 300.0), (0.0, 0.5)], odinn.POST_EXPMAX, 0.0, 50.0)
+    theta = np.random.default_rng(1234).uniform(-0.5, 0.5, m.n_params)
+    b.set_law(odinn.LAW_NN_U, m, theta)
 ts = [2010.0 + k / 12.0 for k in range(25)]
 for k in range(G):
     b.set_reference(k, ts, [gl[k][0] * (1.0 - 0.002 * j) for j in range(len(ts))], 3)
-f = lambda: b.batch_loss_grad(None, ts, theta=nn.theta, continuous=True, reltol=1e-8)
+f = lambda: b.batch_loss_grad(None, ts, theta=theta, continuous=True, reltol=1e-8)
 f(); b.sync()
 os.environ["ODINN_PROFILE_HOST"] = "1"
 t0 = time.perf_counter(); f(); b.sync(); t = time.perf_counter() - t0

@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/cdp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cdp -- python $R/tools/cont_default_probe.py ${1:-1024} ${2:-64} > /tmp/cdp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/cdp -- python $R/tools/cont_default_probe.py ${1:-1024} ${2:-64} ${3:-A} > /tmp/cdp.log 2>&1
 grep -v "^[EWI]2026" /tmp/cdp.log | tail -12
 python3 - <<PY
 import csv,glob
