@@ -49,6 +49,8 @@ __device__ __forceinline__ void adj_lds_stage(const GDev& g, const LawDev& L, co
   //         (measured and rejected: TWO nodes of the thread's column inside one divergent region, so that the scheduler can interleave the two
   //          bi-quintic evaluations -- 256 VGPRs with 13-37 spilled, both nodes evaluated wherever one of them has ice: 1.46 against 1.32 ms
   //          at 16 x 1024^2, 5.18 against 4.65 ms at 64 x 1024^2 with the shortcut)
+  //         (measured and rejected: the stage's (65 - 2 S) x (FRY + 1 - 2 S) nodes dealt FLAT over the 768 threads -- 3, 3, 3, 2, 2 rounds where
+  //          whole rows need 3 each; 168 VGPRs with 5-8 spilled, waves that straddle two rows: 1.23 against 1.18 ms, 4.27 against 4.16 ms)
   const bool ncol = lane >= S - 1 && lane <= FRX - 1 - S;
 #pragma unroll 1
   for (int m = 0; m < FSLOT; ++m) {
