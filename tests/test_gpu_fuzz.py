@@ -351,7 +351,7 @@ def _subnormal_margin(c, mode):
 @pytest.mark.parametrize("seed", _seeds())
 def test_random_batch_gradient_matches_the_oracle(gpu, monkeypatch, seed):
     for key in list(os.environ):
-        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT"):
+        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT", "ODINN_FUZZ_BIG"):
             monkeypatch.delenv(key, raising=False)
     c = _draw(gpu, seed)
     G, ph, kind, mode = c["G"], c["ph"], c["kind"], c["mode"]
@@ -431,7 +431,7 @@ def test_random_batch_velocity_loss_gradient_matches_the_oracle(gpu, monkeypatch
     """The same draw with LossV / LossHV (Losses.jl:293-440): velocity maps at some of the stops, :xy / :abs / LogSum, scaled or
     not, every law (the U law with a surface-velocity factor), both adjoints."""
     for key in list(os.environ):
-        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT"):
+        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT", "ODINN_FUZZ_BIG"):
             monkeypatch.delenv(key, raising=False)
     c = _draw(gpu, seed, velocity=True)
     G, ph, kind, mode, v = c["G"], c["ph"], c["kind"], c["mode"], c["vel"]
@@ -584,7 +584,7 @@ def test_random_seams_match_the_oracle(gpu, monkeypatch, seed):
     ice-free areas, negative entries (clamped, :52), integer values (ties in the slope clamp, inversion_utils.jl:22-43) and
     cells on the boundary ring."""
     for key in list(os.environ):
-        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT"):
+        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT", "ODINN_FUZZ_BIG"):
             monkeypatch.delenv(key, raising=False)
     q = _draw_seam(gpu, seed)
     nx, ny, dx, dy, ph, kind, style, H, B, T, A = (q[k] for k in ("nx", "ny", "dx", "dy", "ph", "kind", "style", "H", "B", "T", "A"))
@@ -669,7 +669,7 @@ def test_random_batch_time_aggregated_terms_match_the_oracle(gpu, monkeypatch, s
     (TimeAggregatedLosses.jl:38-113), LossAvgV (:115-258, :xy / :abs), VelocityRegularization (Regularization.jl:64-79,
     192-245), with random weights and windows, every law, both adjoints."""
     for key in list(os.environ):
-        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT"):
+        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT", "ODINN_FUZZ_BIG"):
             monkeypatch.delenv(key, raising=False)
     c = _draw(gpu, 700000 + seed)
     rng = np.random.default_rng(31000 + seed)
@@ -777,7 +777,7 @@ def test_random_batch_forward_solve_matches_the_oracle(gpu, monkeypatch, seed):
     counts within 2), the fixed-step sequence (1e-11), and the CFL-limited Euler scheme against its restatement (same step
     count, 1e-10); mass-balance times on stops and between them, per-glacier stop tables."""
     for key in list(os.environ):
-        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT"):
+        if key.startswith("ODINN_") and key not in ("ODINN_FUZZ_SEEDS", "ODINN_LIB", "ODINN_FUZZ_AUDIT", "ODINN_FUZZ_BIG"):
             monkeypatch.delenv(key, raising=False)
     c = _draw(gpu, 400000 + seed)
     rng = np.random.default_rng(52000 + seed)
