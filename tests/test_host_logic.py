@@ -284,3 +284,17 @@ def test_trainable_components_and_inversion_binder_names(odinn):
     reg = odinn.GlacierWideInv(p, gl, "A")
     m2 = odinn.Model(odinn.SIA2Dmodel(p, A=odinn.LawA(p, scalar=True)), regressors={"A": reg})
     assert m2.trainable_components.split_theta(m2.theta, 1)["A"].size == 1
+
+
+def test_fuzz_env_scrub_keeps_every_variable_the_fuzz_file_reads():
+    """tests/test_gpu_fuzz.py deletes ODINN_* from the environment of every draw (a developer's ODINN_SCHEDULE must not steer the
+    checked schedules) -- except the variables the file itself reads.  ODINN_FUZZ_BIG was missing from that list for a round: the
+    large-grid mode was dead without anybody noticing."""
+    import os, re
+    src = open(os.path.join(os.path.dirname(__file__), "test_gpu_fuzz.py")).read()
+    read = set(re.findall(r'os\.environ\.get\("(ODINN_[A-Z_]+)"\)', src))
+    keeps = re.findall(r'key not in \(([^)]*)\)', src)
+    assert len(keeps) >= 5 and "ODINN_FUZZ_BIG" in read
+    for k in keeps:
+        kept = set(re.findall(r'"(ODINN_[A-Z_]+)"', k))
+        assert read <= kept, (sorted(read - kept), k)
