@@ -1,6 +1,6 @@
 #!/bin/bash
 # the fuzz tests against a build of the library whose host code carries libstdc++ assertions (-D_GLIBCXX_ASSERTIONS on odinn_hip.hip;
-# odinn.jl_amd/csrc/libodinn_hip_chk.so), glibc's fatal messages on stderr (CHK_MALLOC=1: MALLOC_CHECK_=3, MALLOC_PERTURB_): tools/chk_fuzz.sh a:b [pytest args]
+# odinn.jl_amd/csrc/libodinn_hip_chk.so from `make -C odinn.jl_amd/csrc chk`), glibc's fatal messages on stderr (CHK_MALLOC=1: MALLOC_CHECK_=3, MALLOC_PERTURB_): tools/chk_fuzz.sh a:b [pytest args]
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; O=gpurun_out/chk; mkdir -p $O
 export ODINN_LIB=$R/odinn.jl_amd/csrc/libodinn_hip_chk.so
 export LIBC_FATAL_STDERR_=1; [ -n "$CHK_MALLOC" ] && export MALLOC_CHECK_=3 MALLOC_PERTURB_=165
